@@ -1,0 +1,951 @@
+/*
+ * azref.c -- CPU ORACLE for the AlphaZero.jl self-play hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may load it.  The product (libazhip.so and the
+ * azhip Python package) never links, imports or calls anything in this directory.
+ *
+ * PARITY UNPINNED: the reference cannot run in the build container (no Julia) and
+ * its own tests hold no numeric result for this path.  The
+ * restatement is pinned only against (i) SURVEY.md Appendix D's RNG-free vectors,
+ * (ii) the PLSchedule known-answer in src/schedule.jl:82-87, (iii) the 6000 legal
+ * Connect-Four positions in games/connect-four/benchmark/Test_L*_R* (rules), and
+ * (iv) an independent NumPy/PyTorch restatement (oracle/pyref.py).
+ *
+ * Every function cites the reference lines it restates (paths relative to
+ * /root/reference).  Arithmetic follows the reference's types: priors Float32,
+ * W Float64, N Int64, UCT in Float64 evaluated left to right without contraction.
+ * Randomness and transcendental functions follow include/az_numerics.h (the RNG
+ * contract of SURVEY.md §8c) because Julia's streams cannot be reproduced.
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -mavx2 -mfma).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/az_numerics.h"
+
+#define AZR_C4 0
+#define AZR_TTT 1
+#define AZR_MANCALA 2
+
+#define AZR_AMAX 9      /* max #actions over the three games */
+#define AZR_CELLS 42    /* max #cells in a state */
+
+#define WHITE 1
+#define BLACK 2
+
+/* ------------------------------------------------------------------ states */
+/* A state is the reference's `(board=..., curplayer=...)` named tuple, stored as
+ * raw cells + player.  Connect-Four: cells[col + 7*row] in {0 EMPTY,1 WHITE,2 BLACK}
+ * (games/connect-four/game.jl:11-22).  Tic-tac-toe: cells[pos] in {0 nothing,
+ * 1 WHITE(true), 2 BLACK(false)} (games/tictactoe/game.jl:7-14).  Mancala:
+ * cells[0..1] = stores, cells[2 + (player-1) + 2*(num-1)] = houses[player,num]
+ * (games/mancala/game.jl:20-31). */
+typedef struct {
+  uint8_t cells[AZR_CELLS];
+  uint8_t curplayer;
+  uint8_t pad;
+} azr_state;
+
+typedef struct {
+  int game;
+  azr_state s;
+  uint8_t finished;
+  uint8_t winner;
+  uint8_t amask[AZR_AMAX];
+} azr_env;
+
+static int azr_num_actions_(int game) { return game == AZR_C4 ? 7 : game == AZR_TTT ? 9 : 6; }
+int azr_num_actions(int game) { return azr_num_actions_(game); }
+
+static uint8_t other(uint8_t p) { return (uint8_t)(3 - p); }
+
+/* ============================ Connect Four ============================== */
+#define C4_COLS 7
+#define C4_ROWS 6
+#define C4(b, col, row) ((b)[(col) + C4_COLS * (row)]) /* 0-based col,row */
+
+/* games/connect-four/game.jl:87-93 */
+static int c4_first_free(const uint8_t* b, int col) {
+  int row = 0;
+  while (row < C4_ROWS && C4(b, col, row) != 0) row++;
+  return row; /* == C4_ROWS when the column is full */
+}
+/* games/connect-four/game.jl:95-99 */
+static void c4_update_actions_mask(azr_env* g) {
+  for (int col = 0; col < C4_COLS; ++col) g->amask[col] = c4_first_free(g->s.cells, col) < C4_ROWS;
+}
+static int c4_valid(int col, int row) { return col >= 0 && col < C4_COLS && row >= 0 && row < C4_ROWS; }
+/* games/connect-four/game.jl:105-114 */
+static int c4_num_connected_dir(const uint8_t* b, uint8_t player, int col, int row, int dc, int dr) {
+  int n = 0;
+  col += dc; row += dr;
+  while (c4_valid(col, row) && C4(b, col, row) == player) { n++; col += dc; row += dr; }
+  return n;
+}
+/* games/connect-four/game.jl:116-127 */
+static int c4_winning_pattern_at(const uint8_t* b, uint8_t player, int col, int row) {
+  static const int axes[4][2] = {{1, 1}, {1, -1}, {1, 0}, {0, 1}};
+  for (int a = 0; a < 4; ++a) {
+    int n = 1 + c4_num_connected_dir(b, player, col, row, axes[a][0], axes[a][1]) +
+            c4_num_connected_dir(b, player, col, row, -axes[a][0], -axes[a][1]);
+    if (n >= 4) return 1;
+  }
+  return 0;
+}
+static int any_mask(const azr_env* g) {
+  int n = azr_num_actions_(g->game);
+  for (int i = 0; i < n; ++i) if (g->amask[i]) return 1;
+  return 0;
+}
+/* games/connect-four/game.jl:39-48 */
+static void c4_init(azr_env* g) {
+  memset(g, 0, sizeof *g);
+  g->game = AZR_C4;
+  g->s.curplayer = WHITE;
+  for (int c = 0; c < C4_COLS; ++c) g->amask[c] = 1;
+}
+/* games/connect-four/game.jl:50-68 (only the TOP stone of each column is tested) */
+static void c4_set_state(azr_env* g, const azr_state* st) {
+  g->s = *st;
+  c4_update_actions_mask(g);
+  if (!any_mask(g)) g->finished = 1;
+  for (int col = 0; col < C4_COLS; ++col) {
+    int top = c4_first_free(g->s.cells, col);
+    if (top == 0) continue;
+    int row = top - 1;
+    uint8_t c = C4(st->cells, col, row);
+    if (c != 0 && c4_winning_pattern_at(st->cells, c, col, row)) {
+      g->winner = c; g->finished = 1; break;
+    }
+  }
+}
+/* games/connect-four/game.jl:130-146 */
+static void c4_play(azr_env* g, int col) {
+  int row = c4_first_free(g->s.cells, col);
+  C4(g->s.cells, col, row) = g->s.curplayer;
+  c4_update_actions_mask(g);
+  if (c4_winning_pattern_at(g->s.cells, g->s.curplayer, col, row)) {
+    g->winner = g->s.curplayer; g->finished = 1;
+  } else {
+    g->finished = !any_mask(g);
+  }
+  g->s.curplayer = other(g->s.curplayer);
+}
+/* games/connect-four/game.jl:160-168 */
+static double c4_white_reward(const azr_env* g) {
+  if (g->finished) {
+    if (g->winner == WHITE) return 1.;
+    if (g->winner == BLACK) return -1.;
+    return 0.;
+  }
+  return 0.;
+}
+/* games/connect-four/game.jl:226-241: Float32[board[col,row]==c for col,row,c in (EMPTY,WHITE,BLACK)]
+ * after swapping colours when black is to move; column-major 7x6x3. */
+static void c4_vectorize(const azr_state* st, float* out) {
+  for (int ch = 0; ch < 3; ++ch)
+    for (int row = 0; row < C4_ROWS; ++row)
+      for (int col = 0; col < C4_COLS; ++col) {
+        uint8_t c = C4(st->cells, col, row);
+        if (st->curplayer != WHITE && c != 0) c = other(c);
+        out[col + C4_COLS * (row + C4_ROWS * ch)] = (c == ch) ? 1.0f : 0.0f;
+      }
+}
+
+/* ============================= Tic-tac-toe ============================== */
+/* games/tictactoe/game.jl:42-58; pos = (y-1)*3 + x */
+static const int TTT_AL[8][3] = {
+    {0, 3, 6}, {1, 4, 7}, {2, 5, 8},   /* [(i,j) for j] for i : x fixed           */
+    {0, 1, 2}, {3, 4, 5}, {6, 7, 8},   /* [(i,j) for i] for j : y fixed           */
+    {0, 4, 8}, {2, 4, 6}};
+static int ttt_has_won(const azr_env* g, uint8_t player) {
+  for (int a = 0; a < 8; ++a)
+    if (g->s.cells[TTT_AL[a][0]] == player && g->s.cells[TTT_AL[a][1]] == player &&
+        g->s.cells[TTT_AL[a][2]] == player) return 1;
+  return 0;
+}
+static void ttt_refresh(azr_env* g) { /* actions_mask = map(isnothing, board), :69 */
+  for (int i = 0; i < 9; ++i) g->amask[i] = g->s.cells[i] == 0;
+  /* terminal_white_reward, :75-82 */
+  g->finished = 1;
+  if (ttt_has_won(g, WHITE)) g->winner = WHITE;
+  else if (ttt_has_won(g, BLACK)) g->winner = BLACK;
+  else if (!any_mask(g)) g->winner = 0;
+  else g->finished = 0;
+}
+static void ttt_init(azr_env* g) {
+  memset(g, 0, sizeof *g);
+  g->game = AZR_TTT;
+  g->s.curplayer = WHITE;
+  ttt_refresh(g);
+}
+static void ttt_set_state(azr_env* g, const azr_state* st) { g->s = *st; g->winner = 0; ttt_refresh(g); }
+/* games/tictactoe/game.jl:89-92 (no terminal guard) */
+static void ttt_play(azr_env* g, int pos) {
+  g->s.cells[pos] = g->s.curplayer;
+  g->s.curplayer = other(g->s.curplayer);
+  g->winner = 0;
+  ttt_refresh(g);
+}
+static double ttt_white_reward(const azr_env* g) {
+  if (!g->finished) return 0.;
+  return g->winner == WHITE ? 1. : g->winner == BLACK ? -1. : 0.;
+}
+/* games/tictactoe/game.jl:126-143: 3x3x3, x fastest, channels (nothing, WHITE, BLACK) */
+static void ttt_vectorize(const azr_state* st, float* out) {
+  for (int ch = 0; ch < 3; ++ch)
+    for (int pos = 0; pos < 9; ++pos) {
+      uint8_t c = st->cells[pos];
+      if (st->curplayer != WHITE && c != 0) c = other(c);
+      out[pos + 9 * ch] = (c == ch) ? 1.0f : 0.0f;
+    }
+}
+
+/* =============================== Mancala ================================ */
+#define MH 6
+#define M_STORE(b, p) ((b)[(p) - 1])
+#define M_HOUSE(b, p, n) ((b)[2 + ((p) - 1) + 2 * ((n) - 1)]) /* 1-based player, num */
+typedef struct { int is_store; int player; int num; } mpos;
+/* games/mancala/game.jl:80-97 */
+static mpos m_next_pos(mpos pos, int player) {
+  mpos r = {0, 0, 0};
+  if (pos.is_store) { r.is_store = 0; r.player = 3 - player; r.num = MH; return r; }
+  if (pos.num > 1) { r.player = pos.player; r.num = pos.num - 1; return r; }
+  if (pos.player == player) { r.is_store = 1; r.player = player; return r; }
+  r.player = player; r.num = MH; return r;
+}
+static uint8_t m_read(const uint8_t* b, mpos p) { return p.is_store ? M_STORE(b, p.player) : M_HOUSE(b, p.player, p.num); }
+static void m_write(uint8_t* b, mpos p, uint8_t v) { if (p.is_store) M_STORE(b, p.player) = v; else M_HOUSE(b, p.player, p.num) = v; }
+static int m_sum_houses(const uint8_t* b, int player) {
+  int s = 0;
+  for (int n = 1; n <= MH; ++n) s += M_HOUSE(b, player, n);
+  return s;
+}
+/* games/mancala/game.jl:137-142 */
+static void m_capture_leftovers(uint8_t* b, int player) {
+  M_STORE(b, player) = (uint8_t)(M_STORE(b, player) + m_sum_houses(b, player));
+  for (int p = 1; p <= 2; ++p) for (int n = 1; n <= MH; ++n) M_HOUSE(b, p, n) = 0;
+}
+static void m_refresh_mask(azr_env* g) { /* :121-123 */
+  for (int n = 1; n <= MH; ++n) g->amask[n - 1] = M_HOUSE(g->s.cells, g->s.curplayer, n) > 0;
+}
+static void m_init(azr_env* g) {
+  memset(g, 0, sizeof *g);
+  g->game = AZR_MANCALA;
+  g->s.curplayer = WHITE;
+  for (int p = 1; p <= 2; ++p) for (int n = 1; n <= MH; ++n) M_HOUSE(g->s.cells, p, n) = 3;
+  m_refresh_mask(g);
+}
+/* games/mancala/game.jl:54-60 */
+static void m_set_state(azr_env* g, const azr_state* st) {
+  g->s = *st;
+  if (m_sum_houses(g->s.cells, g->s.curplayer) == 0 || m_sum_houses(g->s.cells, 3 - g->s.curplayer) == 0)
+    g->finished = 1;
+  m_refresh_mask(g);
+}
+/* games/mancala/game.jl:144-177 */
+static void m_play(azr_env* g, int a /*0-based*/) {
+  uint8_t* b = g->s.cells;
+  int cur = g->s.curplayer;
+  mpos pos = {0, cur, a + 1};
+  int nseeds = m_read(b, pos);
+  m_write(b, pos, 0);
+  for (int i = 0; i < nseeds; ++i) {
+    pos = m_next_pos(pos, cur);
+    m_write(b, pos, (uint8_t)(m_read(b, pos) + 1));
+  }
+  if (m_sum_houses(b, cur) == 0) {
+    m_capture_leftovers(b, 3 - cur);
+    g->finished = 1;
+  } else if (!pos.is_store) {
+    if (m_read(b, pos) == 1 && cur == pos.player) {
+      /* capture_last_and_opposite, :125-133 */
+      mpos opp = {0, 3 - pos.player, MH - pos.num + 1};
+      M_STORE(b, pos.player) = (uint8_t)(M_STORE(b, pos.player) + m_read(b, opp) + 1);
+      m_write(b, pos, 0);
+      m_write(b, opp, 0);
+      if (m_sum_houses(b, 3 - cur) == 0) { m_capture_leftovers(b, cur); g->finished = 1; m_refresh_mask(g); return; }
+      if (m_sum_houses(b, cur) == 0) { m_capture_leftovers(b, 3 - cur); g->finished = 1; m_refresh_mask(g); return; }
+    }
+    g->s.curplayer = (uint8_t)(3 - cur);
+  }
+  m_refresh_mask(g);
+}
+/* games/mancala/game.jl:187-206 */
+static double m_white_reward(const azr_env* g) {
+  if (!g->finished) return 0.;
+  int nw = M_STORE(g->s.cells, 1), nb = M_STORE(g->s.cells, 2);
+  return nw > nb ? 1. : nw < nb ? -1. : 0.;
+}
+/* games/mancala/game.jl:224-257.  BUG-COMPATIBLE: flip_colors ignores its argument and
+ * returns the INITIAL board (stores 0, houses 3), so when black is to move the network
+ * sees the initial position.  14x1x5, positions: white houses 6..1, white store, black
+ * houses 6..1, black store; channels nstones, whouse, wstore, bhouse, bstore. */
+static void m_vectorize(const azr_state* st, float* out) {
+  uint8_t init[AZR_CELLS];
+  memset(init, 0, sizeof init);
+  for (int p = 1; p <= 2; ++p) for (int n = 1; n <= MH; ++n) M_HOUSE(init, p, n) = 3;
+  const uint8_t* b = st->curplayer == WHITE ? st->cells : init;
+  for (int i = 0; i < 14; ++i) {
+    int player = i < 7 ? 1 : 2, j = i % 7;
+    int is_store = (j == 6);
+    float nst = is_store ? (float)M_STORE(b, player) : (float)M_HOUSE(b, player, MH - j);
+    out[i + 14 * 0] = nst;
+    out[i + 14 * 1] = (!is_store && player == 1) ? 1.f : 0.f;
+    out[i + 14 * 2] = (is_store && player == 1) ? 1.f : 0.f;
+    out[i + 14 * 3] = (!is_store && player == 2) ? 1.f : 0.f;
+    out[i + 14 * 4] = (is_store && player == 2) ? 1.f : 0.f;
+  }
+}
+
+/* ========================= GameInterface dispatch ======================= */
+/* src/game.jl:34-336 -- the subset the path uses (SURVEY.md §8b seam 4). */
+void azr_init(azr_env* g, int game) {
+  if (game == AZR_C4) c4_init(g); else if (game == AZR_TTT) ttt_init(g); else m_init(g);
+}
+void azr_init_state(azr_env* g, int game, const azr_state* st) { /* GI.init(gspec, state) */
+  azr_init(g, game);
+  if (game == AZR_C4) c4_set_state(g, st); else if (game == AZR_TTT) ttt_set_state(g, st); else m_set_state(g, st);
+}
+void azr_play(azr_env* g, int a) {
+  if (g->game == AZR_C4) c4_play(g, a); else if (g->game == AZR_TTT) ttt_play(g, a); else m_play(g, a);
+}
+double azr_white_reward(const azr_env* g) {
+  return g->game == AZR_C4 ? c4_white_reward(g) : g->game == AZR_TTT ? ttt_white_reward(g) : m_white_reward(g);
+}
+int azr_terminated(const azr_env* g) { return g->finished; }
+int azr_white_playing(const azr_env* g) { return g->s.curplayer == WHITE; }
+void azr_actions_mask(const azr_env* g, uint8_t* mask) { memcpy(mask, g->amask, (size_t)azr_num_actions_(g->game)); }
+void azr_current_state(const azr_env* g, azr_state* st) { *st = g->s; }
+void azr_state_dims(int game, int* w, int* h, int* c) {
+  if (game == AZR_C4) { *w = 7; *h = 6; *c = 3; } else if (game == AZR_TTT) { *w = 3; *h = 3; *c = 3; } else { *w = 14; *h = 1; *c = 5; }
+}
+void azr_vectorize_state(int game, const azr_state* st, float* out) {
+  if (game == AZR_C4) c4_vectorize(st, out); else if (game == AZR_TTT) ttt_vectorize(st, out); else m_vectorize(st, out);
+}
+/* available_actions (src/game.jl:318-321): indices of set mask bits, in action order */
+static int available(const azr_env* g, int* acts) {
+  int n = 0, A = azr_num_actions_(g->game);
+  for (int a = 0; a < A; ++a) if (g->amask[a]) acts[n++] = a;
+  return n;
+}
+
+/* Packed 16-byte state key shared with the C ABI (include/azhip.h "state keys"). */
+void azr_pack_key(int game, const azr_state* st, uint64_t key[2]) {
+  uint64_t a = 0, b = 0;
+  if (game == AZR_C4) {
+    for (int col = 0; col < 7; ++col) for (int row = 0; row < 6; ++row) {
+      uint8_t c = C4(st->cells, col, row);
+      if (c == WHITE) a |= 1ULL << (col * 7 + row);
+      if (c == BLACK) b |= 1ULL << (col * 7 + row);
+    }
+  } else if (game == AZR_TTT) {
+    for (int p = 0; p < 9; ++p) {
+      if (st->cells[p] == WHITE) a |= 1ULL << p;
+      if (st->cells[p] == BLACK) b |= 1ULL << p;
+    }
+  } else {
+    for (int n = 1; n <= MH; ++n) {
+      a |= (uint64_t)M_HOUSE(st->cells, 1, n) << (8 * (n - 1));
+      b |= (uint64_t)M_HOUSE(st->cells, 2, n) << (8 * (n - 1));
+    }
+    a |= (uint64_t)M_STORE(st->cells, 1) << 48;
+    b |= (uint64_t)M_STORE(st->cells, 2) << 48;
+  }
+  if (st->curplayer == BLACK) a |= 1ULL << 63;
+  key[0] = a; key[1] = b;
+}
+void azr_unpack_key(int game, const uint64_t key[2], azr_state* st) {
+  memset(st, 0, sizeof *st);
+  uint64_t a = key[0], b = key[1];
+  st->curplayer = (a >> 63) ? BLACK : WHITE;
+  if (game == AZR_C4) {
+    for (int col = 0; col < 7; ++col) for (int row = 0; row < 6; ++row) {
+      int bit = col * 7 + row;
+      C4(st->cells, col, row) = ((a >> bit) & 1) ? WHITE : ((b >> bit) & 1) ? BLACK : 0;
+    }
+  } else if (game == AZR_TTT) {
+    for (int p = 0; p < 9; ++p) st->cells[p] = ((a >> p) & 1) ? WHITE : ((b >> p) & 1) ? BLACK : 0;
+  } else {
+    for (int n = 1; n <= MH; ++n) {
+      M_HOUSE(st->cells, 1, n) = (uint8_t)(a >> (8 * (n - 1)));
+      M_HOUSE(st->cells, 2, n) = (uint8_t)(b >> (8 * (n - 1)));
+    }
+    M_STORE(st->cells, 1) = (uint8_t)(a >> 48);
+    M_STORE(st->cells, 2) = (uint8_t)(b >> 48);
+  }
+}
+
+/* ================================ Network ================================ */
+/* src/networks/architectures/resnet.jl:53-92 in test mode, fp32.
+ * Parameter blob = fp32 arrays in Flux layout, in this order (include/azhip.h):
+ *   stem   conv W(kw,kh,Cin,F) b(F)  bn g,b,mu,var (F each)
+ *   block  x num_blocks: conv1 W(3,3,F,F) b bn(4F)  conv2 W b bn(4F)
+ *   phead  conv W(1,1,F,npf) b bn(4npf)  dense W(A, P*npf) b(A)
+ *   vhead  conv W(1,1,F,nvf) b bn(4nvf)  dense1 W(F, P*nvf) b(F)  dense2 W(1,F) b(1)
+ * Conv = true convolution (flipped kernel), pad 1 (NNlib default -- from memory, not in
+ * tree); BN eps = 1f-5 (Flux default -- from memory).
+ * SUMMATION ORDER (the fp32 contract, include/azhip.h "fp32 contract"): every output is
+ * one fp32 fma chain starting from +0:
+ *   3x3 conv, Cin even : taps t=0..8 ((dy,dx) = (t/3-1, t%3-1)), inside a tap channels in
+ *                        the order c = j, Cin/2 + j  for j = 0..Cin/2-1
+ *   stem (Cin = planes): k = t*Cin + c ascending
+ *   1x1 conv           : c = j, Cin/2 + j
+ *   dense              : k = p*nf + f ascending (p = x + W*y board position, f = filter)
+ * then y = fma(acc, scale, shift) with scale = g / sqrtf(var + eps),
+ * shift = fma(b - mu, scale, beta); dense: y = acc + bias. */
+typedef struct {
+  int W, H, C, A;            /* board dims, planes, actions */
+  int nblocks, F, npf, nvf;
+  const float* blob;
+} azr_net;
+
+static size_t net_nparams(const azr_net* n) {
+  size_t P = (size_t)n->W * n->H, F = n->F;
+  size_t s = 9 * (size_t)n->C * F + F + 4 * F;
+  s += (size_t)n->nblocks * 2 * (9 * F * F + F + 4 * F);
+  s += F * n->npf + n->npf + 4 * (size_t)n->npf + (size_t)n->A * P * n->npf + n->A;
+  s += F * n->nvf + n->nvf + 4 * (size_t)n->nvf + F * P * n->nvf + F + F + 1;
+  return s;
+}
+size_t azr_net_num_params(int W, int H, int C, int A, int nblocks, int F, int npf, int nvf) {
+  azr_net n = {W, H, C, A, nblocks, F, npf, nvf, 0};
+  return net_nparams(&n);
+}
+
+static void bn_fold(const float* bias, const float* bn, int n, float* scale, float* shift) {
+  const float *g = bn, *be = bn + n, *mu = bn + 2 * n, *var = bn + 3 * n;
+  for (int i = 0; i < n; ++i) {
+    scale[i] = g[i] / sqrtf(var[i] + 1e-5f);
+    shift[i] = az_fmaf(bias[i] - mu[i], scale[i], be[i]);
+  }
+}
+
+/* in: [P][Cin] (position-major, channel fastest); out: [P][Cout].  Flux weight
+ * W[i + kw*(j + kh*(ci + Cin*co))]; tap (dx,dy) uses i = 1-dx, j = 1-dy (flip). */
+static void conv_bn(const azr_net* n, const float* in, int Cin, int Cout, int ksz, const float* Wt,
+                    const float* bias, const float* bn, const float* res, int relu, int paired, float* out) {
+  int W = n->W, H = n->H;
+  float* scale = malloc(sizeof(float) * 2 * (size_t)Cout);
+  float* shift = scale + Cout;
+  bn_fold(bias, bn, Cout, scale, shift);
+  int half = Cin / 2;
+  for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+    float* o = out + (size_t)(x + W * y) * Cout;
+    for (int co = 0; co < Cout; ++co) o[co] = 0.0f;
+    int ntap = ksz * ksz;
+    for (int t = 0; t < ntap; ++t) {
+      int dy = ksz == 3 ? t / 3 - 1 : 0, dx = ksz == 3 ? t % 3 - 1 : 0;
+      int yy = y + dy, xx = x + dx;
+      int inside = (yy >= 0 && yy < H && xx >= 0 && xx < W);
+      int wi = ksz == 3 ? 1 - dx : 0, wj = ksz == 3 ? 1 - dy : 0;
+      for (int kk = 0; kk < Cin; ++kk) {
+        int ci = paired ? ((kk & 1) ? half + (kk >> 1) : (kk >> 1)) : kk;
+        float v = inside ? in[(size_t)(xx + W * yy) * Cin + ci] : 0.0f;
+        const float* wrow = Wt + (size_t)wi + (size_t)ksz * (wj + (size_t)ksz * ci);
+        size_t costride = (size_t)ksz * ksz * Cin;
+        for (int co = 0; co < Cout; ++co) o[co] = az_fmaf(v, wrow[costride * co], o[co]);
+      }
+    }
+    for (int co = 0; co < Cout; ++co) {
+      float v = az_fmaf(o[co], scale[co], shift[co]);
+      if (res) v = v + res[(size_t)(x + W * y) * Cout + co];
+      if (relu) v = v > 0.0f ? v : 0.0f;
+      o[co] = v;
+    }
+  }
+  free(scale);
+}
+
+/* Network.forward (src/networks/flux.jl:127-132) on ONE sample given as Flux-layout planes
+ * x[W][H][C] (column-major, W fastest).  Outputs the raw softmax p[A] and tanh value. */
+static void net_forward_one(const azr_net* n, const float* xin, float* p, float* v) {
+  int P = n->W * n->H, F = n->F, C = n->C, A = n->A;
+  const float* w = n->blob;
+  float* x0 = malloc(sizeof(float) * (size_t)P * (C + 3 * F + n->npf + n->nvf + F));
+  float* a = x0 + (size_t)P * C;
+  float* t = a + (size_t)P * F;
+  float* b2 = t + (size_t)P * F;
+  float* hp = b2 + (size_t)P * F;
+  float* hv = hp + (size_t)P * n->npf;
+  float* vh = hv + (size_t)P * n->nvf;
+  for (int pz = 0; pz < P; ++pz) for (int c = 0; c < C; ++c) x0[(size_t)pz * C + c] = xin[pz + (size_t)P * c];
+  /* stem, resnet.jl:75-77 */
+  conv_bn(n, x0, C, F, 3, w, w + 9 * C * F, w + 9 * C * F + F, 0, 1, 0, a);
+  w += 9 * (size_t)C * F + 5 * (size_t)F;
+  /* tower, resnet.jl:53-63,78 */
+  for (int blk = 0; blk < n->nblocks; ++blk) {
+    size_t cw = 9 * (size_t)F * F;
+    conv_bn(n, a, F, F, 3, w, w + cw, w + cw + F, 0, 1, 1, t);
+    w += cw + 5 * (size_t)F;
+    conv_bn(n, t, F, F, 3, w, w + cw, w + cw + F, a, 1, 1, b2);
+    w += cw + 5 * (size_t)F;
+    memcpy(a, b2, sizeof(float) * (size_t)P * F);
+  }
+  /* policy head, resnet.jl:79-84 */
+  conv_bn(n, a, F, n->npf, 1, w, w + (size_t)F * n->npf, w + (size_t)F * n->npf + n->npf, 0, 1, 1, hp);
+  w += (size_t)F * n->npf + 5 * (size_t)n->npf;
+  {
+    float logits[AZR_AMAX];
+    int K = P * n->npf;
+    for (int o = 0; o < A; ++o) {
+      float acc = 0.0f;
+      for (int pz = 0; pz < P; ++pz) for (int f = 0; f < n->npf; ++f)
+        acc = az_fmaf(hp[(size_t)pz * n->npf + f], w[o + (size_t)A * (pz + (size_t)P * f)], acc);
+      logits[o] = acc + w[(size_t)A * K + o];
+    }
+    w += (size_t)A * K + A;
+    /* softmax (NNlib, from memory): exp(x - max) / sum, accumulated in action order */
+    float m = logits[0];
+    for (int o = 1; o < A; ++o) m = logits[o] > m ? logits[o] : m;
+    float s = 0.0f;
+    for (int o = 0; o < A; ++o) { p[o] = az_expf(logits[o] - m); s += p[o]; }
+    for (int o = 0; o < A; ++o) p[o] = p[o] / s;
+  }
+  /* value head, resnet.jl:85-90 */
+  conv_bn(n, a, F, n->nvf, 1, w, w + (size_t)F * n->nvf, w + (size_t)F * n->nvf + n->nvf, 0, 1, 1, hv);
+  w += (size_t)F * n->nvf + 5 * (size_t)n->nvf;
+  {
+    int K = P * n->nvf;
+    for (int o = 0; o < F; ++o) {
+      float acc = 0.0f;
+      for (int pz = 0; pz < P; ++pz) for (int f = 0; f < n->nvf; ++f)
+        acc = az_fmaf(hv[(size_t)pz * n->nvf + f], w[o + (size_t)F * (pz + (size_t)P * f)], acc);
+      acc = acc + w[(size_t)F * K + o];
+      vh[o] = acc > 0.0f ? acc : 0.0f;
+    }
+    w += (size_t)F * K + F;
+    float acc = 0.0f;
+    for (int k = 0; k < F; ++k) acc = az_fmaf(vh[k], w[k], acc);
+    acc = acc + w[F];
+    *v = az_tanhf(acc);
+  }
+  free(x0);
+}
+
+/* Network.forward_normalized (src/networks/network.jl:264-271), one column */
+static void forward_normalized_one(const azr_net* n, const float* x, const float* amask, float* p, float* v, float* pinv) {
+  net_forward_one(n, x, p, v);
+  float sp = 0.0f;
+  for (int a = 0; a < n->A; ++a) { p[a] = p[a] * amask[a]; sp += p[a]; }
+  for (int a = 0; a < n->A; ++a) p[a] = p[a] / (sp + 1.1920929e-7f); /* eps(Float32) */
+  *pinv = 1.0f - sp;
+}
+/* batch form: X is W*H*C*N (WHCN), Amask is A*N; outputs P (A*N), V (N), Pinv (N) */
+void azr_net_forward_normalized(int W, int H, int C, int A, int nblocks, int F, int npf, int nvf,
+                                const float* blob, const float* X, const float* Amask, int N,
+                                float* P, float* V, float* Pinv) {
+  azr_net n = {W, H, C, A, nblocks, F, npf, nvf, blob};
+  size_t xs = (size_t)W * H * C;
+  for (int i = 0; i < N; ++i)
+    forward_normalized_one(&n, X + xs * i, Amask + (size_t)A * i, P + (size_t)A * i, V + i, Pinv + i);
+}
+
+/* ================================= MCTS ================================= */
+/* src/mcts.jl:78-89 */
+typedef struct {
+  azr_state key;
+  int used;
+  int n;                        /* #available actions */
+  float P[AZR_AMAX];            /* ActionStats.P :: Float32 */
+  double Wt[AZR_AMAX];          /* ActionStats.W :: Float64 */
+  int64_t N[AZR_AMAX];          /* ActionStats.N :: Int     */
+  float Vest;                   /* StateInfo.Vest :: Float32 */
+} azr_node;
+
+#define AZR_ORACLE_UNIFORM 0   /* MCTS.RandomOracle, src/mcts.jl:62-72 */
+#define AZR_ORACLE_HASH 1      /* synthetic: priors/value derived from the packed key */
+#define AZR_ORACLE_NET 2       /* Network.evaluate, src/networks/network.jl:287-298 */
+
+typedef struct {
+  int game;
+  /* Dict{State,StateInfo} (src/mcts.jl:126): open addressing, exact key compare */
+  azr_node* tab;
+  size_t cap, count;
+  int oracle_kind;
+  azr_net net;
+  /* src/mcts.jl:129-137 */
+  double gamma, cpuct, noise_eps, noise_alpha, prior_temperature;
+  int64_t total_simulations, total_nodes_traversed;
+  int64_t oracle_calls;
+} azr_mcts;
+
+static uint64_t state_hash(const azr_state* s) {
+  uint64_t h = 0xcbf29ce484222325ULL;
+  const uint8_t* p = (const uint8_t*)s;
+  for (size_t i = 0; i < sizeof(azr_state); ++i) { h ^= p[i]; h *= 0x100000001b3ULL; }
+  return az_mix64(h);
+}
+static azr_node* tree_find(azr_mcts* e, const azr_state* s, int insert) {
+  if (insert && (e->count + 1) * 2 > e->cap) {
+    size_t ncap = e->cap ? e->cap * 2 : 1024;
+    azr_node* nt = calloc(ncap, sizeof(azr_node));
+    for (size_t i = 0; i < e->cap; ++i) if (e->tab[i].used) {
+      size_t j = state_hash(&e->tab[i].key) & (ncap - 1);
+      while (nt[j].used) j = (j + 1) & (ncap - 1);
+      nt[j] = e->tab[i];
+    }
+    free(e->tab); e->tab = nt; e->cap = ncap;
+  }
+  if (!e->cap) return 0;
+  size_t j = state_hash(s) & (e->cap - 1);
+  while (e->tab[j].used) {
+    if (memcmp(&e->tab[j].key, s, sizeof(azr_state)) == 0) return &e->tab[j];
+    j = (j + 1) & (e->cap - 1);
+  }
+  if (!insert) return 0;
+  e->tab[j].used = 1; e->tab[j].key = *s; e->count++;
+  return &e->tab[j];
+}
+
+azr_mcts* azr_mcts_new(int game, int oracle_kind, double gamma, double cpuct, double noise_eps,
+                       double noise_alpha, double prior_temperature) {
+  azr_mcts* e = calloc(1, sizeof *e);
+  e->game = game; e->oracle_kind = oracle_kind;
+  e->gamma = gamma; e->cpuct = cpuct; e->noise_eps = noise_eps; e->noise_alpha = noise_alpha;
+  e->prior_temperature = prior_temperature;
+  return e;
+}
+void azr_mcts_set_net(azr_mcts* e, int nblocks, int F, int npf, int nvf, const float* blob) {
+  int W, H, C; azr_state_dims(e->game, &W, &H, &C);
+  azr_net n = {W, H, C, azr_num_actions_(e->game), nblocks, F, npf, nvf, blob};
+  e->net = n;
+}
+/* MCTS.reset! (src/mcts.jl:278-281): empties the tree, keeps the counters */
+void azr_mcts_reset(azr_mcts* e) { if (e->tab) memset(e->tab, 0, e->cap * sizeof(azr_node)); e->count = 0; }
+void azr_mcts_free(azr_mcts* e) { free(e->tab); free(e); }
+int64_t azr_mcts_num_nodes(const azr_mcts* e) { return (int64_t)e->count; }
+int64_t azr_mcts_total_simulations(const azr_mcts* e) { return e->total_simulations; }
+int64_t azr_mcts_total_nodes_traversed(const azr_mcts* e) { return e->total_nodes_traversed; }
+int64_t azr_mcts_oracle_calls(const azr_mcts* e) { return e->oracle_calls; }
+
+/* Synthetic oracle: exact small-integer arithmetic so CPU and GPU agree bit for bit.
+ * raw_a = 1 + 16 low bits of mix(key, a) for each AVAILABLE action; P = raw / sum(raw)
+ * (fp32, sum in action order); V = (h16 - 32768) / 65536. */
+void azr_hash_oracle(int game, const azr_state* st, const uint8_t* mask, float* Pfull, float* V) {
+  uint64_t key[2]; azr_pack_key(game, st, key);
+  uint64_t h = az_hash_key(key[0], key[1]);
+  int A = azr_num_actions_(game);
+  float s = 0.0f;
+  for (int a = 0; a < A; ++a) {
+    float raw = mask[a] ? (float)(1 + (int)(az_mix64(h + (uint64_t)(a + 1)) & 0xffff)) : 0.0f;
+    Pfull[a] = raw; s += raw;
+  }
+  for (int a = 0; a < A; ++a) Pfull[a] = Pfull[a] / s;
+  *V = (float)((int)(az_mix64(h + 99) & 0xffff) - 32768) / 65536.0f;
+}
+
+/* oracle(state) -> (P over available actions, V); src/mcts.jl:6-17 */
+static void call_oracle(azr_mcts* e, const azr_state* st, float* P, float* V) {
+  azr_env g; azr_init_state(&g, e->game, st);       /* GI.init(gspec, state) */
+  int acts[AZR_AMAX]; int n = available(&g, acts);
+  e->oracle_calls++;
+  if (e->oracle_kind == AZR_ORACLE_UNIFORM) {
+    for (int i = 0; i < n; ++i) P[i] = (float)(1.0 / (double)n);   /* ones(n) ./ n -> Float32(p) */
+    *V = 0.0f;
+  } else if (e->oracle_kind == AZR_ORACLE_HASH) {
+    float pf[AZR_AMAX];
+    azr_hash_oracle(e->game, st, g.amask, pf, V);
+    for (int i = 0; i < n; ++i) P[i] = pf[acts[i]];
+  } else {
+    /* Network.evaluate (src/networks/network.jl:287-298) */
+    int A = e->net.A;
+    float x[AZR_CELLS * 5], am[AZR_AMAX], pf[AZR_AMAX], pinv;
+    azr_vectorize_state(e->game, st, x);
+    for (int a = 0; a < A; ++a) am[a] = g.amask[a] ? 1.0f : 0.0f;
+    forward_normalized_one(&e->net, x, am, pf, V, &pinv);
+    for (int i = 0; i < n; ++i) P[i] = pf[acts[i]];
+  }
+}
+
+/* Util.apply_temperature on a Float64 vector (src/util.jl:98-110) */
+static void apply_temperature(const double* pi, int n, double tau, double* res) {
+  if (tau == 1.0) { for (int i = 0; i < n; ++i) res[i] = pi[i]; return; }
+  if (tau == 0.0) {
+    int am = 0;
+    for (int i = 1; i < n; ++i) if (pi[i] > pi[am]) am = i;       /* first maximum */
+    for (int i = 0; i < n; ++i) res[i] = 0.0;
+    res[am] = 1.0;
+    return;
+  }
+  double inv = 1.0 / tau, s = 0.0;
+  for (int i = 0; i < n; ++i) { res[i] = az_pow(pi[i], inv); s += res[i]; }
+  for (int i = 0; i < n; ++i) res[i] = res[i] / s;
+}
+
+/* init_state_info + state_info (src/mcts.jl:157-174) */
+static azr_node* state_info(azr_mcts* e, const azr_state* st, int* new_node) {
+  azr_node* nd = tree_find(e, st, 0);
+  if (nd) { *new_node = 0; return nd; }
+  float P[AZR_AMAX], V;
+  call_oracle(e, st, P, &V);
+  nd = tree_find(e, st, 1);
+  azr_env g; azr_init_state(&g, e->game, st);
+  int acts[AZR_AMAX]; int n = available(&g, acts);
+  nd->n = n;
+  double pd[AZR_AMAX], pt[AZR_AMAX];
+  for (int i = 0; i < n; ++i) pd[i] = (double)P[i];
+  if (e->prior_temperature == 1.0) for (int i = 0; i < n; ++i) pt[i] = pd[i];
+  else apply_temperature(pd, n, e->prior_temperature, pt);
+  for (int i = 0; i < n; ++i) { nd->P[i] = (float)pt[i]; nd->Wt[i] = 0.0; nd->N[i] = 0; }
+  nd->Vest = V;
+  *new_node = 1;
+  return nd;
+}
+
+/* uct_scores + argmax (src/mcts.jl:180-188,211): Float64, left to right, first maximum */
+static int select_action(const azr_node* nd, double cpuct, double eps, const double* eta) {
+  int64_t ntot = 0;
+  for (int i = 0; i < nd->n; ++i) ntot += nd->N[i];
+  double sqrtNtot = sqrt((double)ntot);
+  int best = 0; double bests = 0.0;
+  for (int i = 0; i < nd->n; ++i) {
+    int64_t N = nd->N[i];
+    double Q = nd->Wt[i] / (double)(N > 1 ? N : 1);
+    double P = (eps == 0.0) ? (double)nd->P[i] : (1.0 - eps) * (double)nd->P[i] + eps * eta[i];
+    double sc = Q + cpuct * P * sqrtNtot / (double)(N + 1);
+    if (i == 0 || sc > bests) { best = i; bests = sc; }
+  }
+  return best;
+}
+
+/* run_simulation! (src/mcts.jl:199-226), recursive as in the reference */
+static double run_simulation(azr_mcts* e, azr_env* game, const double* eta, int root) {
+  if (azr_terminated(game)) return 0.;
+  azr_state st; azr_current_state(game, &st);
+  int acts[AZR_AMAX]; available(game, acts);
+  int new_node;
+  azr_node* info = state_info(e, &st, &new_node);
+  if (new_node) return (double)info->Vest;
+  double eps = root ? e->noise_eps : 0.;
+  int aid = select_action(info, e->cpuct, eps, eta);
+  int action = acts[aid];
+  int wp = azr_white_playing(game);
+  azr_play(game, action);
+  double wr = azr_white_reward(game);
+  double r = wp ? wr : -wr;
+  int pswitch = wp != azr_white_playing(game);
+  double qnext = run_simulation(e, game, eta, 0);
+  qnext = pswitch ? -qnext : qnext;
+  double q = r + e->gamma * qnext;
+  /* update_state_info! (:190-194) -- re-find: the table may have been rehashed */
+  info = tree_find(e, &st, 0);
+  info->Wt[aid] += q; info->N[aid] += 1;
+  e->total_nodes_traversed += 1;
+  return q;
+}
+
+/* explore! (src/mcts.jl:239-245).  eta: caller-provided noise (length = #available
+ * actions) or NULL to draw it from the RNG contract keyed by (seed, game id, move). */
+void azr_mcts_explore(azr_mcts* e, const azr_env* game, int nsims, const double* eta_in, uint64_t seed,
+                      uint32_t game_id, uint32_t move) {
+  double eta[AZR_AMAX];
+  int acts[AZR_AMAX]; int n = available(game, acts);
+  if (eta_in) memcpy(eta, eta_in, sizeof(double) * (size_t)n);
+  else { az_rng r = az_rng_make(seed, game_id, move, AZ_RNG_NOISE); az_dirichlet(&r, n, e->noise_alpha, eta); }
+  for (int i = 0; i < nsims; ++i) {
+    e->total_simulations += 1;
+    azr_env clone = *game;                       /* GI.clone */
+    run_simulation(e, &clone, eta, 1);
+  }
+}
+/* Convenience for tests: explore from a state, returning root statistics by rank. */
+int azr_mcts_root_stats(azr_mcts* e, const azr_state* st, int64_t* N, double* W, float* P, float* Vest) {
+  azr_node* nd = tree_find(e, st, 0);
+  if (!nd) return -1;
+  for (int i = 0; i < nd->n; ++i) { N[i] = nd->N[i]; W[i] = nd->Wt[i]; P[i] = nd->P[i]; }
+  *Vest = nd->Vest;
+  return nd->n;
+}
+/* policy (src/mcts.jl:255-271) */
+int azr_mcts_policy(azr_mcts* e, const azr_env* game, int* actions, double* pi) {
+  azr_state st; azr_current_state(game, &st);
+  azr_node* nd = tree_find(e, &st, 0);
+  if (!nd) return -1;
+  int n = available(game, actions);
+  int64_t ntot = 0;
+  for (int i = 0; i < n; ++i) ntot += nd->N[i];
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) { pi[i] = (double)nd->N[i] / (double)ntot; s += pi[i]; }
+  for (int i = 0; i < n; ++i) pi[i] = pi[i] / s;
+  return n;
+}
+
+/* ============================ schedules / sampling ======================= */
+/* PLSchedule getindex (src/schedule.jl:64-80), Float64 schedule */
+double azr_plschedule(const int* xs, const double* ys, int len, int i) {
+  int ptidx = -1;
+  for (int k = 0; k < len; ++k) if (xs[k] <= i) ptidx = k;
+  if (ptidx < 0) return ys[0];
+  if (ptidx == len - 1) return ys[len - 1];
+  double x0 = xs[ptidx], y0 = ys[ptidx], x1 = xs[ptidx + 1], y1 = ys[ptidx + 1];
+  return y0 + (y1 - y0) / (x1 - x0) * ((double)i - x0);
+}
+/* Integer PLSchedule (ceil), the known-answer of src/schedule.jl:82-87 */
+int azr_plschedule_int(const int* xs, const int* ys, int len, int i) {
+  int ptidx = -1;
+  for (int k = 0; k < len; ++k) if (xs[k] <= i) ptidx = k;
+  if (ptidx < 0) return ys[0];
+  if (ptidx == len - 1) return ys[len - 1];
+  double x0 = xs[ptidx], y0 = ys[ptidx], x1 = xs[ptidx + 1], y1 = ys[ptidx + 1];
+  return (int)ceil(y0 + (y1 - y0) / (x1 - x0) * ((double)i - x0));
+}
+/* fix_probvec + rand_categorical (src/util.jl:68-90) with the uniform given */
+int azr_rand_categorical(const double* pi, int n, float u) {
+  float p[AZR_AMAX];
+  float s = 0.0f;
+  for (int i = 0; i < n; ++i) { p[i] = (float)pi[i]; s += p[i]; }
+  /* !(s ≈ 1): isapprox with rtol = sqrt(eps(Float32)) */
+  float tol = 0.00034526698f * (fabsf(s) > 1.0f ? fabsf(s) : 1.0f);
+  if (!(fabsf(s - 1.0f) <= tol)) {
+    if (s == 0.0f) for (int i = 0; i < n; ++i) p[i] = 1.0f / (float)n;
+    else for (int i = 0; i < n; ++i) p[i] = p[i] / s;
+  }
+  return az_categorical_f32(p, n, u);
+}
+void azr_apply_temperature(const double* pi, int n, double tau, double* res) { apply_temperature(pi, n, tau, res); }
+
+/* ============================ play_game / simulate ======================= */
+typedef struct {
+  /* MctsParams (src/params.jl:49-57) */
+  double gamma, cpuct, noise_eps, noise_alpha, prior_temperature;
+  int num_iters_per_turn;
+  int temp_len; int temp_xs[8]; double temp_ys[8];   /* PLSchedule; len 1 == ConstSchedule */
+  /* SimParams (src/params.jl:92-101) */
+  int num_games, num_workers, reset_every;
+  uint64_t seed;
+  int game, oracle_kind;
+  int nblocks, F, npf, nvf; const float* blob;
+} azr_sim_params;
+
+/* One trace record per move: state BEFORE the move (packed key), visit counts by action
+ * (full width, 0 for unavailable), the action played, white reward after the move. */
+typedef struct {
+  uint64_t key[2];
+  int32_t N[AZR_AMAX + 1];
+  int32_t action;
+  float reward;
+} azr_move_rec;
+typedef struct {
+  int32_t game_id, slot, num_moves, first_move;   /* index into the move record array */
+  int64_t nodes;                                   /* length(env.tree) at game end */
+  int64_t total_simulations, total_nodes_traversed; /* cumulative per worker (mcts.jl:136-137) */
+  uint64_t final_key[2];
+} azr_game_rec;
+
+typedef struct {
+  azr_mcts* mcts;
+  azr_env game;
+  int game_id, nmoves, first_move, worker_sim_id, active;
+} azr_slot;
+
+/* simulate (src/simulations.jl:207-244) with num_workers lock-step workers: every round
+ * each active worker plays ONE move of its game (think -> sample -> play!, play.jl:298-315);
+ * game ids are handed out in increasing order, ties between workers finishing in the same
+ * round resolved by worker index (the reference's assignment is a race, util.jl:181-188).
+ * Returns the number of move records written. */
+int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap) {
+  int G = p->num_workers < p->num_games ? p->num_workers : p->num_games;
+  azr_slot* slots = calloc((size_t)G, sizeof(azr_slot));
+  int64_t nm = 0;
+  int next_game = 0, finished = 0;
+  int A = azr_num_actions_(p->game);
+  for (int s = 0; s < G; ++s) {
+    slots[s].mcts = azr_mcts_new(p->game, p->oracle_kind, p->gamma, p->cpuct, p->noise_eps, p->noise_alpha, p->prior_temperature);
+    if (p->oracle_kind == AZR_ORACLE_NET) azr_mcts_set_net(slots[s].mcts, p->nblocks, p->F, p->npf, p->nvf, p->blob);
+    slots[s].game_id = next_game++; slots[s].active = 1;
+    azr_init(&slots[s].game, p->game);
+    slots[s].first_move = -1;
+  }
+  /* move records of one game must be contiguous: reserve max game length per game lazily
+   * by writing into a per-slot staging area first */
+  int maxlen = 512;
+  azr_move_rec* stage = calloc((size_t)G * maxlen, sizeof(azr_move_rec));
+  while (finished < p->num_games) {
+    for (int s = 0; s < G; ++s) {
+      azr_slot* sl = &slots[s];
+      if (!sl->active) continue;
+      /* think (play.jl:196-206) */
+      azr_mcts_explore(sl->mcts, &sl->game, p->num_iters_per_turn, 0, p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves);
+      int acts[AZR_AMAX]; double pi[AZR_AMAX], pis[AZR_AMAX];
+      int n = azr_mcts_policy(sl->mcts, &sl->game, acts, pi);
+      azr_move_rec* mr = &stage[(size_t)s * maxlen + sl->nmoves];
+      memset(mr, 0, sizeof *mr);
+      azr_pack_key(p->game, &sl->game.s, mr->key);
+      { azr_node* nd = tree_find(sl->mcts, &sl->game.s, 0);
+        for (int i = 0; i < n; ++i) mr->N[acts[i]] = (int32_t)nd->N[i]; }
+      (void)A;
+      /* temperature index = #moves already played (play.jl:309) */
+      double tau = azr_plschedule(p->temp_xs, p->temp_ys, p->temp_len, sl->nmoves);
+      apply_temperature(pi, n, tau, pis);
+      az_rng r = az_rng_make(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, AZ_RNG_MOVE);
+      int a = acts[azr_rand_categorical(pis, n, az_rng_f32(&r))];
+      azr_play(&sl->game, a);
+      mr->action = a; mr->reward = (float)azr_white_reward(&sl->game);
+      sl->nmoves++;
+      if (sl->nmoves >= maxlen) { fprintf(stderr, "azref: game too long\n"); abort(); }
+    }
+    /* end-of-round bookkeeping in worker order */
+    for (int s = 0; s < G; ++s) {
+      azr_slot* sl = &slots[s];
+      if (!sl->active || !azr_terminated(&sl->game)) continue;
+      azr_game_rec* gr = &games[sl->game_id];
+      gr->game_id = sl->game_id; gr->slot = s; gr->num_moves = sl->nmoves; gr->first_move = (int32_t)nm;
+      if (nm + sl->nmoves > moves_cap) { fprintf(stderr, "azref: move buffer too small\n"); abort(); }
+      memcpy(moves + nm, stage + (size_t)s * maxlen, sizeof(azr_move_rec) * (size_t)sl->nmoves);
+      nm += sl->nmoves;
+      /* measure (training.jl:269-273) happens BEFORE the periodic reset */
+      gr->nodes = azr_mcts_num_nodes(sl->mcts);
+      gr->total_simulations = sl->mcts->total_simulations;
+      gr->total_nodes_traversed = sl->mcts->total_nodes_traversed;
+      azr_pack_key(p->game, &sl->game.s, gr->final_key);
+      sl->worker_sim_id++;
+      if (p->reset_every > 0 && sl->worker_sim_id % p->reset_every == 0) azr_mcts_reset(sl->mcts);
+      finished++;
+      if (next_game < p->num_games) {
+        sl->game_id = next_game++; sl->nmoves = 0;
+        azr_init(&sl->game, p->game);
+      } else sl->active = 0;
+    }
+  }
+  for (int s = 0; s < G; ++s) azr_mcts_free(slots[s].mcts);
+  free(slots); free(stage);
+  return nm;
+}
+
+/* push_trace! (src/memory.jl:74-87): discounted side-relative z and t for each position */
+void azr_push_trace(int game, const azr_move_rec* moves, int n, double gamma, double* z, double* t) {
+  double wr = 0.;
+  for (int i = n - 1; i >= 0; --i) {
+    wr = gamma * wr + (double)moves[i].reward;
+    int wp = !(moves[i].key[0] >> 63);
+    (void)game;
+    z[i] = wp ? wr : -wr;
+    t[i] = (double)(n - i);
+  }
+}
+
+/* ================================ misc =================================== */
+int azr_numerics_selftest(void) { return az_numerics_selftest(); }
+float azr_expf(float x) { return az_expf(x); }
+float azr_tanhf(float x) { return az_tanhf(x); }
+double azr_log(double x) { return az_log(x); }
+double azr_exp(double x) { return az_exp(x); }
+double azr_pow(double x, double y) { return az_pow(x, y); }
+void azr_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { az_philox4x32_10(ctr, key, out); }
+void azr_dirichlet(uint64_t seed, uint32_t game, uint32_t move, int n, double alpha, double* eta) {
+  az_rng r = az_rng_make(seed, game, move, AZ_RNG_NOISE); az_dirichlet(&r, n, alpha, eta);
+}
+float azr_move_uniform(uint64_t seed, uint32_t game, uint32_t move) {
+  az_rng r = az_rng_make(seed, game, move, AZ_RNG_MOVE); return az_rng_f32(&r);
+}
+size_t azr_sizeof_state(void) { return sizeof(azr_state); }
+size_t azr_sizeof_env(void) { return sizeof(azr_env); }
+size_t azr_sizeof_move_rec(void) { return sizeof(azr_move_rec); }
+size_t azr_sizeof_game_rec(void) { return sizeof(azr_game_rec); }
+size_t azr_sizeof_sim_params(void) { return sizeof(azr_sim_params); }

@@ -1,0 +1,271 @@
+"""ctypes binding of the CPU oracle (oracle/libazref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by the
+cpu_baseline leg of bench.py.  The product package (alphazero.jl_amd/azhip) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libazref.so")
+
+C4, TTT, MANCALA = 0, 1, 2
+ORACLE_UNIFORM, ORACLE_HASH, ORACLE_NET = 0, 1, 2
+AMAX = 9
+CELLS = 42
+
+
+def build(force=False):
+    src = os.path.join(HERE, "azref.c")
+    hdr = os.path.join(HERE, "..", "include", "az_numerics.h")
+    if (force or not os.path.exists(LIB)
+            or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.check_call(["make", "-s", "-C", HERE, "libazref.so"])
+    return LIB
+
+
+class State(C.Structure):
+    _fields_ = [("cells", C.c_uint8 * CELLS), ("curplayer", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class Env(C.Structure):
+    _fields_ = [("game", C.c_int), ("s", State), ("finished", C.c_uint8), ("winner", C.c_uint8),
+                ("amask", C.c_uint8 * AMAX)]
+
+
+class SimParams(C.Structure):
+    _fields_ = [("gamma", C.c_double), ("cpuct", C.c_double), ("noise_eps", C.c_double),
+                ("noise_alpha", C.c_double), ("prior_temperature", C.c_double),
+                ("num_iters_per_turn", C.c_int), ("temp_len", C.c_int), ("temp_xs", C.c_int * 8),
+                ("temp_ys", C.c_double * 8), ("num_games", C.c_int), ("num_workers", C.c_int),
+                ("reset_every", C.c_int), ("seed", C.c_uint64), ("game", C.c_int),
+                ("oracle_kind", C.c_int), ("nblocks", C.c_int), ("F", C.c_int), ("npf", C.c_int),
+                ("nvf", C.c_int), ("blob", C.POINTER(C.c_float))]
+
+
+class MoveRec(C.Structure):
+    _fields_ = [("key", C.c_uint64 * 2), ("N", C.c_int32 * (AMAX + 1)), ("action", C.c_int32),
+                ("reward", C.c_float)]
+
+
+class GameRec(C.Structure):
+    _fields_ = [("game_id", C.c_int32), ("slot", C.c_int32), ("num_moves", C.c_int32),
+                ("first_move", C.c_int32), ("nodes", C.c_int64), ("total_simulations", C.c_int64),
+                ("total_nodes_traversed", C.c_int64), ("final_key", C.c_uint64 * 2)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        L.azr_white_reward.restype = C.c_double
+        L.azr_net_num_params.restype = C.c_size_t
+        L.azr_mcts_new.restype = C.c_void_p
+        L.azr_mcts_new.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.azr_mcts_set_net.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.azr_mcts_reset.argtypes = [C.c_void_p]
+        L.azr_mcts_free.argtypes = [C.c_void_p]
+        for f in ("azr_mcts_num_nodes", "azr_mcts_total_simulations", "azr_mcts_total_nodes_traversed",
+                  "azr_mcts_oracle_calls"):
+            getattr(L, f).restype = C.c_int64
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.azr_mcts_explore.argtypes = [C.c_void_p, C.POINTER(Env), C.c_int, C.c_void_p, C.c_uint64,
+                                       C.c_uint32, C.c_uint32]
+        L.azr_mcts_root_stats.argtypes = [C.c_void_p, C.POINTER(State), C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+        L.azr_mcts_policy.argtypes = [C.c_void_p, C.POINTER(Env), C.c_void_p, C.c_void_p]
+        L.azr_plschedule.restype = C.c_double
+        L.azr_simulate.restype = C.c_int64
+        L.azr_simulate.argtypes = [C.POINTER(SimParams), C.c_void_p, C.c_void_p, C.c_int64]
+        L.azr_expf.restype = C.c_float
+        L.azr_expf.argtypes = [C.c_float]
+        L.azr_tanhf.restype = C.c_float
+        L.azr_tanhf.argtypes = [C.c_float]
+        for f in ("azr_log", "azr_exp"):
+            getattr(L, f).restype = C.c_double
+            getattr(L, f).argtypes = [C.c_double]
+        L.azr_pow.restype = C.c_double
+        L.azr_pow.argtypes = [C.c_double, C.c_double]
+        L.azr_dirichlet.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_double, C.c_void_p]
+        L.azr_move_uniform.restype = C.c_float
+        L.azr_move_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.azr_rand_categorical.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        for f in ("azr_sizeof_state", "azr_sizeof_env", "azr_sizeof_move_rec", "azr_sizeof_game_rec",
+                  "azr_sizeof_sim_params"):
+            getattr(L, f).restype = C.c_size_t
+        assert L.azr_sizeof_state() == C.sizeof(State)
+        assert L.azr_sizeof_env() == C.sizeof(Env)
+        assert L.azr_sizeof_move_rec() == C.sizeof(MoveRec)
+        assert L.azr_sizeof_game_rec() == C.sizeof(GameRec)
+        assert L.azr_sizeof_sim_params() == C.sizeof(SimParams)
+        assert L.azr_numerics_selftest() == 0, "oracle built with fp contraction / without fma"
+        _lib = L
+    return _lib
+
+
+NUM_ACTIONS = {C4: 7, TTT: 9, MANCALA: 6}
+DIMS = {C4: (7, 6, 3), TTT: (3, 3, 3), MANCALA: (14, 1, 5)}
+
+
+class Game:
+    """GameInterface view of one oracle game environment (src/game.jl)."""
+
+    def __init__(self, game, state=None):
+        self.game = game
+        self.env = Env()
+        if state is None:
+            lib().azr_init(C.byref(self.env), game)
+        else:
+            lib().azr_init_state(C.byref(self.env), game, C.byref(state))
+
+    def clone(self):
+        g = Game.__new__(Game)
+        g.game = self.game
+        g.env = Env.from_buffer_copy(self.env)
+        return g
+
+    def play(self, a):
+        lib().azr_play(C.byref(self.env), int(a))
+
+    def terminated(self):
+        return bool(lib().azr_terminated(C.byref(self.env)))
+
+    def white_playing(self):
+        return bool(lib().azr_white_playing(C.byref(self.env)))
+
+    def white_reward(self):
+        return lib().azr_white_reward(C.byref(self.env))
+
+    def actions_mask(self):
+        return np.array(self.env.amask[:NUM_ACTIONS[self.game]], dtype=bool)
+
+    def available_actions(self):
+        return np.nonzero(self.actions_mask())[0]
+
+    def state(self):
+        return State.from_buffer_copy(self.env.s)
+
+    def key(self):
+        k = (C.c_uint64 * 2)()
+        lib().azr_pack_key(self.game, C.byref(self.env.s), k)
+        return int(k[0]), int(k[1])
+
+    def vectorize(self):
+        w, h, c = DIMS[self.game]
+        out = np.zeros(w * h * c, dtype=np.float32)
+        lib().azr_vectorize_state(self.game, C.byref(self.env.s), out.ctypes.data_as(C.c_void_p))
+        return out  # Flux memory order: W fastest, then H, then C
+
+
+def unpack_key(game, key):
+    st = State()
+    k = (C.c_uint64 * 2)(key[0], key[1])
+    lib().azr_unpack_key(game, k, C.byref(st))
+    return st
+
+
+class Mcts:
+    """MCTS.Env (src/mcts.jl:124-151)."""
+
+    def __init__(self, game, oracle=ORACLE_UNIFORM, gamma=1.0, cpuct=1.0, noise_eps=0.0, noise_alpha=1.0,
+                 prior_temperature=1.0, net=None):
+        self.game = game
+        self.h = lib().azr_mcts_new(game, oracle, gamma, cpuct, noise_eps, noise_alpha, prior_temperature)
+        self._blob = None
+        if net is not None:
+            nblocks, F, npf, nvf, blob = net
+            self._blob = np.ascontiguousarray(blob, dtype=np.float32)
+            lib().azr_mcts_set_net(self.h, nblocks, F, npf, nvf, self._blob.ctypes.data_as(C.c_void_p))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().azr_mcts_free(self.h)
+            self.h = None
+
+    def explore(self, g, nsims, eta=None, seed=0, game_id=0, move=0):
+        e = None
+        if eta is not None:
+            e = np.ascontiguousarray(eta, dtype=np.float64)
+        lib().azr_mcts_explore(self.h, C.byref(g.env), nsims, None if e is None else e.ctypes.data_as(C.c_void_p),
+                               seed, game_id, move)
+
+    def root_stats(self, g):
+        N = np.zeros(AMAX, dtype=np.int64)
+        W = np.zeros(AMAX, dtype=np.float64)
+        P = np.zeros(AMAX, dtype=np.float32)
+        V = C.c_float()
+        st = g.state()
+        n = lib().azr_mcts_root_stats(self.h, C.byref(st), N.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p),
+                                      P.ctypes.data_as(C.c_void_p), C.byref(V))
+        if n < 0:
+            raise KeyError("state not in tree")
+        return N[:n], W[:n], P[:n], V.value
+
+    def policy(self, g):
+        acts = (C.c_int * AMAX)()
+        pi = np.zeros(AMAX, dtype=np.float64)
+        n = lib().azr_mcts_policy(self.h, C.byref(g.env), acts, pi.ctypes.data_as(C.c_void_p))
+        if n < 0:
+            raise KeyError("MCTS.explore! must be called before MCTS.policy")
+        return list(acts[:n]), pi[:n]
+
+    def reset(self):
+        lib().azr_mcts_reset(self.h)
+
+    num_nodes = property(lambda s: lib().azr_mcts_num_nodes(s.h))
+    total_simulations = property(lambda s: lib().azr_mcts_total_simulations(s.h))
+    total_nodes_traversed = property(lambda s: lib().azr_mcts_total_nodes_traversed(s.h))
+    oracle_calls = property(lambda s: lib().azr_mcts_oracle_calls(s.h))
+
+
+def net_num_params(game, nblocks, F, npf, nvf):
+    w, h, c = DIMS[game]
+    return lib().azr_net_num_params(w, h, c, NUM_ACTIONS[game], nblocks, F, npf, nvf)
+
+
+def net_forward_normalized(game, hp, blob, X, A):
+    """Network.forward_normalized on a batch: X (N, C, H, W) == Julia WHCN memory, A (N, nA)."""
+    nblocks, F, npf, nvf = hp
+    w, h, c = DIMS[game]
+    nA = NUM_ACTIONS[game]
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    N = X.shape[0]
+    blob = np.ascontiguousarray(blob, dtype=np.float32)
+    assert blob.size == net_num_params(game, nblocks, F, npf, nvf)
+    P = np.zeros((N, nA), dtype=np.float32)
+    V = np.zeros(N, dtype=np.float32)
+    Pinv = np.zeros(N, dtype=np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().azr_net_forward_normalized(w, h, c, nA, nblocks, F, npf, nvf, vp(blob), vp(X), vp(A), N, vp(P), vp(V), vp(Pinv))
+    return P, V, Pinv
+
+
+def simulate(game, oracle, num_games, num_workers, nsims, gamma=1.0, cpuct=1.0, noise_eps=0.0, noise_alpha=1.0,
+             prior_temperature=1.0, temp_xs=(0,), temp_ys=(1.0,), reset_every=1, seed=1, net=None):
+    """simulate (src/simulations.jl:207-244) in lock-step; returns (games, moves) record arrays."""
+    p = SimParams()
+    p.gamma, p.cpuct, p.noise_eps, p.noise_alpha, p.prior_temperature = gamma, cpuct, noise_eps, noise_alpha, prior_temperature
+    p.num_iters_per_turn = nsims
+    p.temp_len = len(temp_xs)
+    for i, (x, y) in enumerate(zip(temp_xs, temp_ys)):
+        p.temp_xs[i] = x
+        p.temp_ys[i] = y
+    p.num_games, p.num_workers, p.reset_every, p.seed = num_games, num_workers, reset_every or 0, seed
+    p.game, p.oracle_kind = game, oracle
+    blob = None
+    if net is not None:
+        p.nblocks, p.F, p.npf, p.nvf, blob = net[0], net[1], net[2], net[3], np.ascontiguousarray(net[4], dtype=np.float32)
+        p.blob = blob.ctypes.data_as(C.POINTER(C.c_float))
+    games = (GameRec * num_games)()
+    cap = num_games * 512
+    moves = (MoveRec * cap)()
+    nm = lib().azr_simulate(C.byref(p), games, moves, cap)
+    return games, moves, nm
