@@ -1,0 +1,10 @@
+"""azhip -- host-side mirror of AlphaZero.jl's self-play interface over the MI355X engine.
+
+The names follow the reference (MctsParams, SimParams, ResNetHP, ResNet, MctsPlayer, Simulator,
+simulate, simulate_distributed, Trace, push_trace ...); every call ends in the C ABI of
+include/azhip.h (libazhip.so, hand-written HIP for gfx950).  There is no CPU fallback.
+"""
+from . import _lib
+from ._lib import (AzError, GAME_CONNECT_FOUR, GAME_MANCALA, GAME_TICTACTOE, ORACLE_HASH, ORACLE_RESNET,
+                   ORACLE_UNIFORM)
+from .engine import Engine, default_cfg

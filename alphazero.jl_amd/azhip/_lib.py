@@ -1,0 +1,134 @@
+"""ctypes binding of libazhip.so (the C ABI of include/azhip.h).
+
+The HIP extension is the product: if the shared library is missing this module raises at import
+time -- there is NO CPU fallback (the oracle under oracle/ is test infrastructure only).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
+LIB_PATH = os.path.join(CSRC, "libazhip.so")
+
+AZ_OK, AZ_ERR_BAD_ARG, AZ_ERR_CAPACITY, AZ_ERR_HIP, AZ_ERR_STATE = 0, -1, -2, -3, -4
+GAME_CONNECT_FOUR, GAME_TICTACTOE, GAME_MANCALA = 0, 1, 2
+ORACLE_UNIFORM, ORACLE_HASH, ORACLE_RESNET = 0, 1, 2
+MAX_ACTIONS = 9
+SCHED_MAX = 8
+PROF_NUM = 8
+KERNEL_CLASSES = ("select", "compact", "tower", "heads", "expand", "move", "synth", "start")
+
+
+class AzError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("azhip status %d: %s" % (status, msg))
+        self.status = status
+
+
+class EngineCfg(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("game", C.c_int32), ("oracle", C.c_int32),
+        ("gamma", C.c_double), ("cpuct", C.c_double), ("dirichlet_noise_eps", C.c_double),
+        ("dirichlet_noise_alpha", C.c_double), ("prior_temperature", C.c_double),
+        ("num_iters_per_turn", C.c_int32), ("temperature_len", C.c_int32),
+        ("temperature_xs", C.c_int32 * SCHED_MAX), ("temperature_ys", C.c_double * SCHED_MAX),
+        ("num_workers", C.c_int32), ("batch_size", C.c_int32), ("reset_every", C.c_int32),
+        ("fill_batches", C.c_int32), ("flip_probability", C.c_double), ("seed", C.c_uint64),
+        ("max_nodes_per_slot", C.c_int32), ("max_moves_per_game", C.c_int32),
+        ("num_blocks", C.c_int32), ("num_filters", C.c_int32),
+        ("num_policy_head_filters", C.c_int32), ("num_value_head_filters", C.c_int32),
+    ]
+
+
+class MoveRec(C.Structure):
+    _fields_ = [("key", C.c_uint64 * 2), ("N", C.c_int32 * (MAX_ACTIONS + 1)), ("action", C.c_int32),
+                ("reward", C.c_float)]
+
+
+class GameRec(C.Structure):
+    _fields_ = [("game_id", C.c_int32), ("slot", C.c_int32), ("num_moves", C.c_int32),
+                ("first_move", C.c_int32), ("nodes", C.c_int64), ("total_simulations", C.c_int64),
+                ("total_nodes_traversed", C.c_int64), ("final_key", C.c_uint64 * 2)]
+
+
+class TraceBuf(C.Structure):
+    _fields_ = [("games", C.POINTER(GameRec)), ("games_cap", C.c_int64), ("num_games", C.c_int64),
+                ("moves", C.POINTER(MoveRec)), ("moves_cap", C.c_int64), ("num_moves", C.c_int64)]
+
+
+class SelfplayStats(C.Structure):
+    _fields_ = [("simulations", C.c_int64), ("nodes_traversed", C.c_int64), ("leaf_evals", C.c_int64),
+                ("moves", C.c_int64), ("games", C.c_int64), ("waves", C.c_int64), ("seconds", C.c_double)]
+
+
+class Prof(C.Structure):
+    _fields_ = [("launches", C.c_int64 * PROF_NUM), ("ms", C.c_double * PROF_NUM), ("units", C.c_int64 * PROF_NUM)]
+
+
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p)
+
+# every symbol include/azhip.h declares: name -> argtypes (restype is int unless noted)
+_VP, _I32, _I64, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+SYMBOLS = {
+    "az_last_error": None,
+    "az_abi_version": [],
+    "az_engine_cfg_init": [C.POINTER(EngineCfg)],
+    "az_engine_create": [C.POINTER(EngineCfg), C.POINTER(_VP)],
+    "az_engine_destroy": [_VP],
+    "az_game_num_actions": [C.c_int, C.POINTER(_I32)],
+    "az_game_state_dim": [C.c_int, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)],
+    "az_game_init_key": [C.c_int, C.POINTER(C.c_uint64)],
+    "az_game_encode": [_VP, _VP, _I32, _VP, _VP],
+    "az_game_play": [_VP, _VP, _VP, _I32, _VP, _VP, _VP],
+    "az_net_num_params": [_VP, C.POINTER(_I64)],
+    "az_net_set_params": [_VP, _VP, _I64],
+    "az_net_get_params": [_VP, _VP, _I64],
+    "az_net_forward": [_VP, _VP, _VP, _I32, _VP, _VP, _VP],
+    "az_net_evaluate_keys": [_VP, _VP, _I32, _VP, _VP],
+    "az_mcts_reset": [_VP],
+    "az_mcts_explore": [_VP, _VP, _I32, _I32, _VP, _VP, _VP],
+    "az_mcts_node_stats": [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP],
+    "az_mcts_counters": [_VP, _I32, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)],
+    "az_selfplay_run": [_VP, _I32, _I32, C.POINTER(TraceBuf), PROGRESS_CB, _VP, C.POINTER(SelfplayStats)],
+    "az_selfplay_begin": [_VP, _I32, _I32],
+    "az_selfplay_step": [_VP, _I32],
+    "az_selfplay_collect": [_VP, C.POINTER(TraceBuf)],
+    "az_selfplay_get_stats": [_VP, C.POINTER(SelfplayStats)],
+    "az_selfplay_active": [_VP, C.POINTER(_I32)],
+    "az_selfplay_end": [_VP],
+    "az_push_trace": [_VP, _I32, C.c_double, _VP, _VP],
+    "az_prof_enable": [_VP, _I32],
+    "az_prof_get": [_VP, C.POINTER(Prof)],
+    "az_prof_reset": [_VP],
+    "az_device_info": [_VP, C.c_char_p, _I32, C.POINTER(_I32), C.POINTER(_I64)],
+}
+
+_lib = None
+
+
+def lib():
+    """Load libazhip.so; raises ImportError loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libazhip.so is missing at %s -- build it with `python __graft_entry__.py` or "
+                "`make -C alphazero.jl_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, args in SYMBOLS.items():
+            f = getattr(L, name)     # AttributeError if a declared symbol is not exported
+            if name == "az_last_error":
+                f.restype = C.c_char_p
+                f.argtypes = []
+            else:
+                f.restype = C.c_int
+                f.argtypes = args
+        if L.az_abi_version() != 1:
+            raise ImportError("libazhip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != AZ_OK:
+        raise AzError(status, lib().az_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,876 @@
+// azhip.hip -- host side of libazhip.so: engine lifetime, the lock-step self-play driver and the
+// C ABI of include/azhip.h.  Device code lives in tree.h (search) and resnet.h (network).
+//
+// Reference seams: simulate (src/simulations.jl:207-244) -> az_selfplay_*;
+// MCTS.explore!/policy/reset! (src/mcts.jl:239-281) -> az_mcts_*; Network.forward_normalized /
+// evaluate_batch (src/networks/network.jl:264-315) -> az_net_*; GameInterface -> az_game_*.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/az_numerics.h"
+#include "../../include/azhip.h"
+#include "games.h"
+#include "resnet.h"
+#include "tree.h"
+
+// ------------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t _e = (x);                                                                            \
+    if (_e != hipSuccess) return fail(AZ_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define AZCHK(x)            \
+  do {                      \
+    int _s = (x);           \
+    if (_s != AZ_OK) return _s; \
+  } while (0)
+
+extern "C" const char* az_last_error(void) { return g_err.c_str(); }
+extern "C" int az_abi_version(void) { return AZ_ABI_VERSION; }
+
+#define DISPATCH_GAME(gid, ...)                                   \
+  switch (gid) {                                                  \
+    case AZ_GAME_CONNECT_FOUR: { using Gm = ConnectFour; __VA_ARGS__; break; } \
+    case AZ_GAME_TICTACTOE: { using Gm = TicTacToe; __VA_ARGS__; break; }      \
+    case AZ_GAME_MANCALA: { using Gm = Mancala; __VA_ARGS__; break; }          \
+    default: return fail(AZ_ERR_BAD_ARG, "unknown game id %d", (int)(gid));    \
+  }
+
+struct GameInfo { int A, APAD, W, H, C, P, max_plies, node_bytes; };
+static bool game_info(int gid, GameInfo* gi) {
+  switch (gid) {
+    case AZ_GAME_CONNECT_FOUR: *gi = {ConnectFour::A, ConnectFour::APAD, ConnectFour::W, ConnectFour::H, ConnectFour::C, ConnectFour::P, ConnectFour::MAX_PLIES, NodeL<ConnectFour>::BYTES}; return true;
+    case AZ_GAME_TICTACTOE: *gi = {TicTacToe::A, TicTacToe::APAD, TicTacToe::W, TicTacToe::H, TicTacToe::C, TicTacToe::P, TicTacToe::MAX_PLIES, NodeL<TicTacToe>::BYTES}; return true;
+    case AZ_GAME_MANCALA: *gi = {Mancala::A, Mancala::APAD, Mancala::W, Mancala::H, Mancala::C, Mancala::P, Mancala::MAX_PLIES, NodeL<Mancala>::BYTES}; return true;
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------- engine
+struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; };
+struct az_engine {
+  az_engine_cfg cfg;
+  GameInfo gi;
+  int device;
+  hipStream_t stream;
+  DView v;
+  DParams p;
+  std::vector<void*> allocs;
+  // network
+  bool net_loaded;
+  std::vector<float> blob;
+  NetDev net;
+  int nn_cap;
+  float* d_hfeat; float* d_X; float* d_A; float* d_P; float* d_V; float* d_Pinv;
+  GEnv* d_tmp_env; int* d_iota; int* d_ntmp;
+  // staging
+  int* d_slots; uint32_t* d_gids; GEnv* d_roots; uint32_t* d_moves; double* d_eta; int* d_offsets;
+  az_move_rec* d_stage; unsigned long long* d_keys; int* d_actions; unsigned long long* d_next; signed char* d_term; float* d_reward;
+  char* d_nodebuf;
+  int io_cap;
+  // self-play state
+  bool running;
+  int total_games, next_game, first_game_id, games_done, wave_in_move, active_slots;
+  std::vector<az_game_rec> q_games;
+  std::vector<az_move_rec> q_moves;
+  az_selfplay_stats stats;
+  std::chrono::steady_clock::time_point t_begin;
+  // profiling
+  bool prof_on;
+  std::vector<ProfRec> prof_pool;
+  size_t prof_used;
+  az_prof prof;
+  std::vector<int> h_finished;
+  std::vector<az_game_rec> h_grec;
+};
+
+template <class T> static int dalloc(az_engine* e, T** p, size_t n, bool zero = true) {
+  void* q = nullptr;
+  size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+  hipError_t r = hipMalloc(&q, bytes);
+  if (r != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r));
+  e->allocs.push_back(q);
+  if (zero) HIPCHK(hipMemsetAsync(q, 0, bytes, e->stream));
+  *p = (T*)q;
+  return AZ_OK;
+}
+
+static int prof_flush(az_engine* e) {
+  if (!e->prof_used) return AZ_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (size_t i = 0; i < e->prof_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->prof_pool[i].a, e->prof_pool[i].b));
+    e->prof.ms[e->prof_pool[i].cls] += ms;
+  }
+  e->prof_used = 0;
+  return AZ_OK;
+}
+static int prof_begin(az_engine* e, int cls, int64_t units) {
+  if (!e->prof_on) return AZ_OK;
+  if (e->prof_used == e->prof_pool.size()) AZCHK(prof_flush(e));
+  ProfRec& r = e->prof_pool[e->prof_used];
+  r.cls = cls;
+  e->prof.launches[cls] += 1;
+  e->prof.units[cls] += units;
+  HIPCHK(hipEventRecord(r.a, e->stream));
+  return AZ_OK;
+}
+static int prof_end(az_engine* e) {
+  if (!e->prof_on) return AZ_OK;
+  HIPCHK(hipEventRecord(e->prof_pool[e->prof_used].b, e->stream));
+  e->prof_used++;
+  return AZ_OK;
+}
+#define LAUNCH(e, cls, units, kern, grid, block, shmem, ...)                \
+  do {                                                                      \
+    AZCHK(prof_begin(e, cls, units));                                       \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, (e)->stream, __VA_ARGS__); \
+    AZCHK(prof_end(e));                                                     \
+  } while (0)
+
+static int check_device_error(az_engine* e) {
+  int code = 0;
+  HIPCHK(hipMemcpyAsync(&code, e->v.err, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipGetLastError());
+  if (code == 0) return AZ_OK;
+  int zero = 0;
+  HIPCHK(hipMemcpy(e->v.err, &zero, sizeof(int), hipMemcpyHostToDevice));
+  switch (code) {
+    case DERR_NODE_POOL: return fail(AZ_ERR_CAPACITY, "node pool exhausted (max_nodes_per_slot = %d)", e->v.cap_nodes);
+    case DERR_HASH_FULL: return fail(AZ_ERR_CAPACITY, "hash table full (%d entries per slot)", e->v.ht_size);
+    case DERR_DEPTH: return fail(AZ_ERR_CAPACITY, "simulation path deeper than %d plies", e->v.max_depth);
+    case DERR_MOVES: return fail(AZ_ERR_CAPACITY, "game longer than max_moves_per_game = %d", e->v.max_moves);
+    case DERR_NO_ROOT: return fail(AZ_ERR_STATE, "MCTS.explore! must be called before MCTS.policy");
+  }
+  return fail(AZ_ERR_HIP, "unknown device error %d", code);
+}
+
+extern "C" int az_engine_cfg_init(az_engine_cfg* c) {
+  if (!c) return fail(AZ_ERR_BAD_ARG, "cfg is NULL");
+  memset(c, 0, sizeof *c);
+  c->struct_size = (int32_t)sizeof *c;
+  c->game = AZ_GAME_CONNECT_FOUR;
+  c->oracle = AZ_ORACLE_RESNET;
+  // games/connect-four/params.jl:5-30 (self-play), 64-filter trunk (scripts/profile/self_play.jl:28-30)
+  c->gamma = 1.0; c->cpuct = 2.0; c->dirichlet_noise_eps = 0.25; c->dirichlet_noise_alpha = 1.0;
+  c->prior_temperature = 1.0;
+  c->num_iters_per_turn = 600;
+  c->temperature_len = 3;
+  c->temperature_xs[0] = 0; c->temperature_xs[1] = 20; c->temperature_xs[2] = 30;
+  c->temperature_ys[0] = 1.0; c->temperature_ys[1] = 1.0; c->temperature_ys[2] = 0.3;
+  c->num_workers = 128; c->batch_size = 64; c->reset_every = 2; c->fill_batches = 1;
+  c->flip_probability = 0.0; c->seed = 1;
+  c->num_blocks = 5; c->num_filters = 64; c->num_policy_head_filters = 32; c->num_value_head_filters = 32;
+  return AZ_OK;
+}
+
+static size_t net_nparams(const GameInfo& gi, const az_engine_cfg& c) {
+  size_t P = gi.P, F = c.num_filters, npf = c.num_policy_head_filters, nvf = c.num_value_head_filters;
+  size_t s = 9 * (size_t)gi.C * F + 5 * F;
+  s += (size_t)c.num_blocks * 2 * (9 * F * F + 5 * F);
+  s += F * npf + 5 * npf + (size_t)gi.A * P * npf + gi.A;
+  s += F * nvf + 5 * nvf + F * P * nvf + F + F + 1;
+  return s;
+}
+
+extern "C" int az_engine_destroy(az_engine* e) {
+  if (!e) return AZ_OK;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (auto& r : e->prof_pool) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
+  for (void* q : e->allocs) (void)hipFree(q);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return AZ_OK;
+}
+
+template <class Gm> static int set_kernel_attrs() {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<64>::BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<64>::BYTES));
+  return AZ_OK;
+}
+
+__global__ void k_fill_u32(uint32_t* p, uint32_t val, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = val;
+}
+__global__ void k_iota(int* p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
+  if (!c || !out) return fail(AZ_ERR_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  if (c->struct_size != (int32_t)sizeof(az_engine_cfg)) return fail(AZ_ERR_BAD_ARG, "az_engine_cfg size mismatch (%d vs %zu): call az_engine_cfg_init", c->struct_size, sizeof(az_engine_cfg));
+  GameInfo gi;
+  if (!game_info(c->game, &gi)) return fail(AZ_ERR_BAD_ARG, "unknown game id %d", c->game);
+  if (c->oracle < AZ_ORACLE_UNIFORM || c->oracle > AZ_ORACLE_RESNET) return fail(AZ_ERR_BAD_ARG, "unknown oracle kind %d", c->oracle);
+  if (c->num_workers < 1) return fail(AZ_ERR_BAD_ARG, "num_workers must be >= 1");
+  if (c->batch_size > c->num_workers) return fail(AZ_ERR_BAD_ARG, "batch_size (%d) must be <= num_workers (%d) (src/params.jl:361-384)", c->batch_size, c->num_workers);
+  if (c->num_iters_per_turn < 2) return fail(AZ_ERR_BAD_ARG, "num_iters_per_turn must be >= 2 (with 1 the policy is 0/0, src/mcts.jl:267)");
+  if (c->flip_probability != 0.0) return fail(AZ_ERR_BAD_ARG, "flip_probability != 0 is not supported on the device path");
+  if (c->temperature_len < 1 || c->temperature_len > AZ_SCHED_MAX) return fail(AZ_ERR_BAD_ARG, "temperature schedule needs 1..%d breakpoints", AZ_SCHED_MAX);
+  if (c->reset_every < 0) return fail(AZ_ERR_BAD_ARG, "reset_every must be >= 0");
+  if (!(c->prior_temperature >= 0.0)) return fail(AZ_ERR_BAD_ARG, "prior_temperature must be >= 0");
+  if (c->oracle == AZ_ORACLE_RESNET) {
+    if (c->num_filters != 64) return fail(AZ_ERR_BAD_ARG, "num_filters = %d: this build instantiates the 64-filter tower only", c->num_filters);
+    int hf = c->num_policy_head_filters + c->num_value_head_filters;
+    if (c->num_policy_head_filters < 1 || c->num_value_head_filters < 1 || hf > 64) return fail(AZ_ERR_BAD_ARG, "head filters %d/%d unsupported (policy + value must be <= 64)", c->num_policy_head_filters, c->num_value_head_filters);
+    if (c->num_blocks < 0 || c->num_blocks > 64) return fail(AZ_ERR_BAD_ARG, "num_blocks out of range");
+  }
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (c->device < 0 || c->device >= ndev) return fail(AZ_ERR_BAD_ARG, "device %d not available (%d visible)", c->device, ndev);
+  HIPCHK(hipSetDevice(c->device));
+  az_engine* e = new (std::nothrow) az_engine();
+  if (!e) return fail(AZ_ERR_HIP, "out of host memory");
+  e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr;
+  e->net_loaded = false; e->running = false; e->prof_on = false; e->prof_used = 0;
+  memset(&e->prof, 0, sizeof e->prof);
+  memset(&e->stats, 0, sizeof e->stats);
+  int st = [&]() -> int {
+    HIPCHK(hipStreamCreate(&e->stream));
+    const int G = c->num_workers;
+    DView& v = e->v;
+    memset(&v, 0, sizeof v);
+    v.G = G;
+    v.max_moves = c->max_moves_per_game > 0 ? c->max_moves_per_game : gi.max_plies;
+    v.max_depth = gi.max_plies + 1;
+    long long cap = c->max_nodes_per_slot;
+    if (cap <= 0) {
+      long long plies = c->game == AZ_GAME_MANCALA ? 64 : gi.max_plies;
+      cap = (long long)c->num_iters_per_turn * plies * std::max(1, c->reset_every);
+      if (c->reset_every == 0) cap *= 4;
+      cap = std::max<long long>(cap, 1024);
+    }
+    if (cap > (1LL << 30)) return fail(AZ_ERR_BAD_ARG, "max_nodes_per_slot too large");
+    v.cap_nodes = (int)cap;
+    int hs = 1024;
+    while ((long long)hs * 2 < cap * 3) hs <<= 1;
+    v.ht_size = hs;
+    AZCHK(dalloc(e, &v.root, G)); AZCHK(dalloc(e, &v.active, G)); AZCHK(dalloc(e, &v.game_id, G));
+    AZCHK(dalloc(e, &v.move_idx, G)); AZCHK(dalloc(e, &v.epoch, G)); AZCHK(dalloc(e, &v.node_count, G));
+    AZCHK(dalloc(e, &v.worker_sim_id, G)); AZCHK(dalloc(e, &v.tot_sims, G)); AZCHK(dalloc(e, &v.tot_trav, G));
+    AZCHK(dalloc(e, &v.eta, (size_t)G * gi.APAD));
+    AZCHK(dalloc(e, &v.ht, (size_t)G * hs));
+    AZCHK(dalloc(e, &v.nodes, (size_t)G * cap * gi.node_bytes, false));
+    AZCHK(dalloc(e, &v.path, (size_t)G * v.max_depth));
+    AZCHK(dalloc(e, &v.leaf_kind, G)); AZCHK(dalloc(e, &v.leaf_depth, G)); AZCHK(dalloc(e, &v.leaf_env, G));
+    AZCHK(dalloc(e, &v.leaf_ins, G)); AZCHK(dalloc(e, &v.eidx, G)); AZCHK(dalloc(e, &v.eval_slots, G));
+    AZCHK(dalloc(e, &v.n_eval, 1));
+    AZCHK(dalloc(e, &v.Pout, (size_t)std::max(G, 1) * gi.APAD)); AZCHK(dalloc(e, &v.Vout, G));
+    AZCHK(dalloc(e, &v.trace, (size_t)G * v.max_moves)); AZCHK(dalloc(e, &v.grec, G));
+    AZCHK(dalloc(e, &v.finished, G)); AZCHK(dalloc(e, &v.err, 1)); AZCHK(dalloc(e, &v.stat, 8));
+    hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, v.epoch, 1u, G);
+    // staging
+    e->io_cap = std::max(G, 4096);
+    AZCHK(dalloc(e, &e->d_slots, e->io_cap)); AZCHK(dalloc(e, &e->d_gids, e->io_cap)); AZCHK(dalloc(e, &e->d_roots, e->io_cap));
+    AZCHK(dalloc(e, &e->d_moves, e->io_cap)); AZCHK(dalloc(e, &e->d_eta, (size_t)e->io_cap * AZ_MAX_ACTIONS));
+    AZCHK(dalloc(e, &e->d_offsets, e->io_cap)); AZCHK(dalloc(e, &e->d_stage, (size_t)G * v.max_moves));
+    AZCHK(dalloc(e, &e->d_keys, (size_t)2 * e->io_cap)); AZCHK(dalloc(e, &e->d_actions, e->io_cap));
+    AZCHK(dalloc(e, &e->d_next, (size_t)2 * e->io_cap)); AZCHK(dalloc(e, &e->d_term, e->io_cap)); AZCHK(dalloc(e, &e->d_reward, e->io_cap));
+    AZCHK(dalloc(e, &e->d_nodebuf, 512));
+    // network buffers
+    e->nn_cap = e->io_cap;
+    AZCHK(dalloc(e, &e->d_hfeat, (size_t)e->nn_cap * gi.P * 64, false));
+    AZCHK(dalloc(e, &e->d_X, (size_t)e->nn_cap * gi.C * gi.P)); AZCHK(dalloc(e, &e->d_A, (size_t)e->nn_cap * gi.A));
+    AZCHK(dalloc(e, &e->d_P, (size_t)e->nn_cap * 16)); AZCHK(dalloc(e, &e->d_V, e->nn_cap)); AZCHK(dalloc(e, &e->d_Pinv, e->nn_cap));
+    AZCHK(dalloc(e, &e->d_tmp_env, e->nn_cap)); AZCHK(dalloc(e, &e->d_iota, e->nn_cap)); AZCHK(dalloc(e, &e->d_ntmp, 1));
+    hipLaunchKernelGGL(k_iota, dim3((e->nn_cap + 255) / 256), dim3(256), 0, e->stream, e->d_iota, e->nn_cap);
+    memset(&e->net, 0, sizeof e->net);
+    DISPATCH_GAME(c->game, AZCHK(set_kernel_attrs<Gm>()));
+    // search parameters
+    DParams& p = e->p;
+    memset(&p, 0, sizeof p);
+    p.gamma = c->gamma; p.cpuct = c->cpuct; p.eps = c->dirichlet_noise_eps; p.alpha = c->dirichlet_noise_alpha;
+    p.prior_temp = c->prior_temperature; p.nsims = c->num_iters_per_turn; p.temp_len = c->temperature_len;
+    for (int i = 0; i < AZ_SCHED_MAX; ++i) { p.temp_xs[i] = c->temperature_xs[i]; p.temp_ys[i] = c->temperature_ys[i]; }
+    p.seed = c->seed; p.oracle = c->oracle; p.reset_every = c->reset_every;
+    e->h_finished.resize(G); e->h_grec.resize(G);
+    e->prof_pool.resize(2048);
+    for (auto& r : e->prof_pool) { HIPCHK(hipEventCreate(&r.a)); HIPCHK(hipEventCreate(&r.b)); }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    return AZ_OK;
+  }();
+  if (st != AZ_OK) { std::string keep = g_err; az_engine_destroy(e); g_err = keep; return st; }
+  *out = e;
+  return AZ_OK;
+}
+
+#define ENGINE(e)                                              \
+  if (!(e)) return fail(AZ_ERR_BAD_ARG, "engine is NULL");      \
+  HIPCHK(hipSetDevice((e)->device))
+
+extern "C" int az_device_info(az_engine* e, char* name, int32_t name_cap, int32_t* num_cu, int64_t* hbm_bytes) {
+  ENGINE(e);
+  hipDeviceProp_t pr;
+  HIPCHK(hipGetDeviceProperties(&pr, e->device));
+  if (name && name_cap > 0) { snprintf(name, (size_t)name_cap, "%s (%s)", pr.name, pr.gcnArchName); }
+  if (num_cu) *num_cu = pr.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)pr.totalGlobalMem;
+  return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------- game plugin
+extern "C" int az_game_num_actions(int game, int32_t* n) {
+  GameInfo gi;
+  if (!n || !game_info(game, &gi)) return fail(AZ_ERR_BAD_ARG, "bad game id or NULL");
+  *n = gi.A;
+  return AZ_OK;
+}
+extern "C" int az_game_state_dim(int game, int32_t* w, int32_t* h, int32_t* c) {
+  GameInfo gi;
+  if (!w || !h || !c || !game_info(game, &gi)) return fail(AZ_ERR_BAD_ARG, "bad game id or NULL");
+  *w = gi.W; *h = gi.H; *c = gi.C;
+  return AZ_OK;
+}
+extern "C" int az_game_init_key(int game, uint64_t key[2]) {
+  if (!key) return fail(AZ_ERR_BAD_ARG, "NULL");
+  DISPATCH_GAME(game, { GEnv g = Gm::init(); key[0] = g.a; key[1] = g.b; });
+  return AZ_OK;
+}
+extern "C" int az_game_encode(az_engine* e, const uint64_t* keys, int32_t n, float* X, float* A) {
+  ENGINE(e);
+  if (n < 0 || (n > 0 && (!keys || !X || !A))) return fail(AZ_ERR_BAD_ARG, "NULL buffer");
+  const GameInfo& gi = e->gi;
+  for (int off = 0; off < n; off += e->io_cap) {
+    int m = std::min(e->io_cap, n - off);
+    HIPCHK(hipMemcpyAsync(e->d_keys, keys + 2 * (size_t)off, sizeof(uint64_t) * 2 * m, hipMemcpyHostToDevice, e->stream));
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_game_encode<Gm>), dim3((m + 255) / 256), dim3(256), 0, e->stream, e->d_keys, m, e->d_X, e->d_A));
+    HIPCHK(hipMemcpyAsync(X + (size_t)off * gi.C * gi.P, e->d_X, sizeof(float) * (size_t)m * gi.C * gi.P, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(A + (size_t)off * gi.A, e->d_A, sizeof(float) * (size_t)m * gi.A, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  HIPCHK(hipGetLastError());
+  return AZ_OK;
+}
+extern "C" int az_game_play(az_engine* e, const uint64_t* keys, const int32_t* actions, int32_t n,
+                            uint64_t* next_keys, int8_t* terminated, float* white_reward) {
+  ENGINE(e);
+  if (n < 0 || (n > 0 && (!keys || !actions || !next_keys || !terminated || !white_reward))) return fail(AZ_ERR_BAD_ARG, "NULL buffer");
+  for (int i = 0; i < n; ++i) if (actions[i] < -1 || actions[i] >= e->gi.A) return fail(AZ_ERR_BAD_ARG, "action %d out of range at %d", actions[i], i);
+  for (int off = 0; off < n; off += e->io_cap) {
+    int m = std::min(e->io_cap, n - off);
+    HIPCHK(hipMemcpyAsync(e->d_keys, keys + 2 * (size_t)off, sizeof(uint64_t) * 2 * m, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_actions, actions + off, sizeof(int) * m, hipMemcpyHostToDevice, e->stream));
+    DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_game_play<Gm>), dim3((m + 255) / 256), dim3(256), 0, e->stream, e->d_keys, e->d_actions, m, e->d_next, e->d_term, e->d_reward));
+    HIPCHK(hipMemcpyAsync(next_keys + 2 * (size_t)off, e->d_next, sizeof(uint64_t) * 2 * m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(terminated + off, e->d_term, (size_t)m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(white_reward + off, e->d_reward, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  HIPCHK(hipGetLastError());
+  return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------- network
+extern "C" int az_net_num_params(const az_engine* e, int64_t* n) {
+  if (!e || !n) return fail(AZ_ERR_BAD_ARG, "NULL");
+  *n = (int64_t)net_nparams(e->gi, e->cfg);
+  return AZ_OK;
+}
+
+// scale = gamma / sqrtf(var + eps), shift = fma(bias - mean, scale, beta)  (fp32 contract)
+static void bn_fold(const float* bias, const float* bn, int n, float* scale, float* shift) {
+  const float *g = bn, *be = bn + n, *mu = bn + 2 * n, *var = bn + 3 * n;
+  for (int i = 0; i < n; ++i) {
+    scale[i] = g[i] / sqrtf(var[i] + 1e-5f);
+    shift[i] = az_fmaf(bias[i] - mu[i], scale[i], be[i]);
+  }
+}
+// Flux conv weight W[i + k*(j + k*(ci + Cin*co))] -> MFMA B-fragment order.  Tap t = (dy+1)*3 +
+// (dx+1) reads W[i = 1-dx, j = 1-dy] (true convolution, flipped kernel).
+static void pack_conv(const float* Wt, int ksz, int Cin, int Cout, int CoutPad, float* dst /* [ntap][CoutPad/32][Cin/8][64][4] */) {
+  const int ntap = ksz * ksz, NT = CoutPad / 32, JQ = Cin / 8, half = Cin / 2;
+  for (int t = 0; t < ntap; ++t) {
+    int dy = ksz == 3 ? t / 3 - 1 : 0, dx = ksz == 3 ? t % 3 - 1 : 0;
+    int wi = ksz == 3 ? 1 - dx : 0, wj = ksz == 3 ? 1 - dy : 0;
+    for (int n = 0; n < NT; ++n) for (int jq = 0; jq < JQ; ++jq) for (int l = 0; l < 64; ++l) for (int q = 0; q < 4; ++q) {
+      int ci = (l >> 5) * half + jq * 4 + q, co = n * 32 + (l & 31);
+      float val = co < Cout ? Wt[(size_t)wi + (size_t)ksz * (wj + (size_t)ksz * (ci + (size_t)Cin * co))] : 0.0f;
+      dst[((((size_t)t * NT + n) * JQ + jq) * 64 + l) * 4 + q] = val;
+    }
+  }
+}
+
+extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
+  ENGINE(e);
+  if (e->cfg.oracle != AZ_ORACLE_RESNET) return fail(AZ_ERR_STATE, "engine was created without the ResNet oracle");
+  if (e->running) return fail(AZ_ERR_STATE, "self-play in progress");
+  const GameInfo& gi = e->gi;
+  const az_engine_cfg& c = e->cfg;
+  if (!blob || n != (int64_t)net_nparams(gi, c)) return fail(AZ_ERR_BAD_ARG, "parameter blob has %lld values, expected %zu", (long long)n, net_nparams(gi, c));
+  const int F = c.num_filters, npf = c.num_policy_head_filters, nvf = c.num_value_head_filters, P = gi.P, C = gi.C, A = gi.A;
+  const int HF = ((npf + nvf + 31) / 32) * 32, L = gi.APAD, nb = c.num_blocks;
+  e->blob.assign(blob, blob + n);
+  const float* w = blob;
+  std::vector<float> stem_w((size_t)9 * C * F), stem_ss(2 * F);
+  for (int t = 0; t < 9; ++t) {
+    int dy = t / 3 - 1, dx = t % 3 - 1, wi = 1 - dx, wj = 1 - dy;
+    for (int ci = 0; ci < C; ++ci) for (int co = 0; co < F; ++co)
+      stem_w[(size_t)(t * C + ci) * F + co] = w[wi + 3 * (wj + 3 * (ci + (size_t)C * co))];
+  }
+  bn_fold(w + 9 * C * F, w + 9 * C * F + F, F, stem_ss.data(), stem_ss.data() + F);
+  w += (size_t)9 * C * F + 5 * F;
+  const size_t layer_f = (size_t)9 * (F / 32) * (F / 8) * 64 * 4;
+  std::vector<float> conv_w(layer_f * 2 * nb + 4), conv_ss((size_t)2 * nb * 2 * F + 4);
+  for (int l = 0; l < 2 * nb; ++l) {
+    pack_conv(w, 3, F, F, F, conv_w.data() + layer_f * l);
+    bn_fold(w + (size_t)9 * F * F, w + (size_t)9 * F * F + F, F, conv_ss.data() + (size_t)l * 2 * F, conv_ss.data() + (size_t)l * 2 * F + F);
+    w += (size_t)9 * F * F + 5 * F;
+  }
+  // heads: concatenate the two 1x1 convolutions along the output channel
+  std::vector<float> hw((size_t)F * HF, 0.0f), hb(HF, 0.0f), hbn((size_t)4 * HF, 0.0f), head_w((size_t)(HF / 32) * (F / 8) * 64 * 4), head_ss(2 * HF);
+  for (int i = 0; i < HF; ++i) { hbn[i] = 0.0f; hbn[3 * HF + i] = 1.0f; }   // padded channels: gamma 0, var 1
+  const float* pw = w; const float* pb = pw + (size_t)F * npf; const float* pbn = pb + npf;
+  const float* pdw = pbn + 4 * npf; const float* pdb = pdw + (size_t)A * P * npf;
+  const float* vw = pdb + A; const float* vb = vw + (size_t)F * nvf; const float* vbn = vb + nvf;
+  const float* vdw = vbn + 4 * nvf; const float* vdb = vdw + (size_t)F * P * nvf;
+  const float* v2w = vdb + F; const float* v2b = v2w + F;
+  for (int co = 0; co < npf; ++co) {
+    for (int ci = 0; ci < F; ++ci) hw[ci + (size_t)F * co] = pw[ci + (size_t)F * co];
+    hb[co] = pb[co];
+    for (int k = 0; k < 4; ++k) hbn[(size_t)k * HF + co] = pbn[(size_t)k * npf + co];
+  }
+  for (int co = 0; co < nvf; ++co) {
+    for (int ci = 0; ci < F; ++ci) hw[ci + (size_t)F * (npf + co)] = vw[ci + (size_t)F * co];
+    hb[npf + co] = vb[co];
+    for (int k = 0; k < 4; ++k) hbn[(size_t)k * HF + npf + co] = vbn[(size_t)k * nvf + co];
+  }
+  pack_conv(hw.data(), 1, F, HF, HF, head_w.data());
+  bn_fold(hb.data(), hbn.data(), HF, head_ss.data(), head_ss.data() + HF);
+  // dense layers, k-major with k = p*nf + f; Flux Dense W[out + nout*(p + P*f)]
+  std::vector<float> pol_w((size_t)P * npf * L, 0.0f), pol_b(L, 0.0f), val_w((size_t)P * nvf * F), val_b(F), val2_w(F);
+  for (int q = 0; q < P; ++q) for (int f = 0; f < npf; ++f) for (int a = 0; a < A; ++a)
+    pol_w[(size_t)(q * npf + f) * L + a] = pdw[a + (size_t)A * (q + (size_t)P * f)];
+  for (int a = 0; a < A; ++a) pol_b[a] = pdb[a];
+  for (int q = 0; q < P; ++q) for (int f = 0; f < nvf; ++f) for (int o = 0; o < F; ++o)
+    val_w[(size_t)(q * nvf + f) * F + o] = vdw[o + (size_t)F * (q + (size_t)P * f)];
+  for (int o = 0; o < F; ++o) { val_b[o] = vdb[o]; val2_w[o] = v2w[o]; }
+  auto up = [&](const std::vector<float>& h, const float** d) -> int {
+    float* q = nullptr;
+    AZCHK(dalloc(e, &q, h.size(), false));
+    HIPCHK(hipMemcpyAsync(q, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    *d = q;
+    return AZ_OK;
+  };
+  NetDev nd;
+  memset(&nd, 0, sizeof nd);
+  nd.nblocks = nb; nd.F = F; nd.npf = npf; nd.nvf = nvf; nd.HF = HF;
+  const float* tmp = nullptr;
+  AZCHK(up(stem_w, &nd.stem_w)); AZCHK(up(stem_ss, &nd.stem_ss));
+  AZCHK(up(conv_w, &tmp)); nd.conv_w = (const float4*)tmp;
+  AZCHK(up(conv_ss, &nd.conv_ss));
+  AZCHK(up(head_w, &tmp)); nd.head_w = (const float4*)tmp;
+  AZCHK(up(head_ss, &nd.head_ss));
+  AZCHK(up(pol_w, &nd.pol_w)); AZCHK(up(pol_b, &nd.pol_b)); AZCHK(up(val_w, &nd.val_w)); AZCHK(up(val_b, &nd.val_b)); AZCHK(up(val2_w, &nd.val2_w));
+  nd.val2_b = *v2b;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->net = nd;
+  e->net_loaded = true;
+  return AZ_OK;
+}
+extern "C" int az_net_get_params(const az_engine* e, float* blob, int64_t n) {
+  if (!e || !blob) return fail(AZ_ERR_BAD_ARG, "NULL");
+  if (!e->net_loaded) return fail(AZ_ERR_STATE, "no parameters loaded");
+  if (n != (int64_t)e->blob.size()) return fail(AZ_ERR_BAD_ARG, "blob size mismatch");
+  memcpy(blob, e->blob.data(), sizeof(float) * (size_t)n);
+  return AZ_OK;
+}
+
+// launches tower + heads on `n` boards (device count in n_ptr when n < 0)
+template <class Gm, bool FROM_PLANES>
+static int launch_net(az_engine* e, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
+                      const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
+  constexpr int TB = TOWER_ROWS / Gm::P;
+  const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
+  if (gt == 0) return AZ_OK;
+  LAUNCH(e, AZ_K_TOWER, n_max, (k_tower<Gm, 64, FROM_PLANES>), gt, 256, TowerLds<64>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, e->d_hfeat);
+  LAUNCH(e, AZ_K_HEADS, n_max, (k_heads<Gm, 64>), gh, 320, 0, e->net, envs, eslots, n_ptr, n_max, Amask, e->d_hfeat, Pout, Vout, Pinv, pstride);
+  return AZ_OK;
+}
+
+extern "C" int az_net_forward(az_engine* e, const float* X, const float* A, int32_t N, float* P, float* V, float* Pinv) {
+  ENGINE(e);
+  if (!e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
+  if (N < 0 || (N > 0 && (!X || !A || !P || !V))) return fail(AZ_ERR_BAD_ARG, "NULL buffer");
+  const GameInfo& gi = e->gi;
+  const size_t xs = (size_t)gi.C * gi.P;
+  for (int off = 0; off < N; off += e->nn_cap) {
+    int m = std::min(e->nn_cap, N - off);
+    HIPCHK(hipMemcpyAsync(e->d_X, X + xs * off, sizeof(float) * xs * m, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_A, A + (size_t)gi.A * off, sizeof(float) * gi.A * m, hipMemcpyHostToDevice, e->stream));
+    DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, true>(e, nullptr, nullptr, nullptr, m, e->d_X, e->d_A, e->d_P, e->d_V, e->d_Pinv, gi.A))));
+    HIPCHK(hipMemcpyAsync(P + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(V + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
+    if (Pinv) HIPCHK(hipMemcpyAsync(Pinv + off, e->d_Pinv, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  HIPCHK(hipGetLastError());
+  return AZ_OK;
+}
+
+extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t N, float* P, float* V) {
+  ENGINE(e);
+  if (!e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
+  if (N < 0 || (N > 0 && (!keys || !P || !V))) return fail(AZ_ERR_BAD_ARG, "NULL buffer");
+  const GameInfo& gi = e->gi;
+  std::vector<GEnv> envs;
+  for (int off = 0; off < N; off += e->nn_cap) {
+    int m = std::min(e->nn_cap, N - off);
+    envs.resize(m);
+    DISPATCH_GAME(e->cfg.game, { for (int i = 0; i < m; ++i) envs[i] = Gm::from_key(keys[2 * (size_t)(off + i)], keys[2 * (size_t)(off + i) + 1]); });
+    HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * m, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_ntmp, &m, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, false>(e, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A))));
+    HIPCHK(hipMemcpyAsync(P + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(V + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  HIPCHK(hipGetLastError());
+  return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------- search waves
+// One wave = one run_simulation! for every active slot: select -> gather misses -> oracle ->
+// expand + backup.  Nothing is read back by the host.
+template <class Gm> static int wave(az_engine* e) {
+  constexpr int L = Gm::APAD;
+  const int G = e->v.G;
+  const int gb = (G * L + 255) / 256;
+  LAUNCH(e, AZ_K_SELECT, G, (k_select<Gm>), gb, 256, 0, e->v, e->p);
+  LAUNCH(e, AZ_K_COMPACT, G, k_compact, 1, 1024, 0, e->v);
+  if (e->cfg.oracle == AZ_ORACLE_RESNET) {
+    AZCHK((launch_net<Gm, false>(e, e->v.leaf_env, e->v.eval_slots, e->v.n_eval, G, nullptr, nullptr, e->v.Pout, e->v.Vout, nullptr, L)));
+  } else {
+    LAUNCH(e, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, e->v, e->p);
+  }
+  LAUNCH(e, AZ_K_EXPAND, G, (k_expand_backup<Gm>), gb, 256, 0, e->v, e->p);
+  e->stats.waves++;
+  return AZ_OK;
+}
+
+template <class Gm>
+static int start_games(az_engine* e, const std::vector<int>& slots, const std::vector<uint32_t>& gids,
+                       const std::vector<GEnv>* roots, int reset_tree, int arm) {
+  const int n = (int)slots.size();
+  if (!n) return AZ_OK;
+  HIPCHK(hipMemcpyAsync(e->d_slots, slots.data(), sizeof(int) * n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_gids, gids.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
+  if (roots) HIPCHK(hipMemcpyAsync(e->d_roots, roots->data(), sizeof(GEnv) * n, hipMemcpyHostToDevice, e->stream));
+  LAUNCH(e, AZ_K_START, n, (k_start_games<Gm>), (n + 255) / 256, 256, 0, e->v, e->p, e->d_slots, e->d_gids, roots ? e->d_roots : nullptr, n, reset_tree);
+  if (arm) LAUNCH(e, AZ_K_START, n, (k_arm_noise<Gm>), (n + 255) / 256, 256, 0, e->v, e->p, e->d_slots, (const uint32_t*)nullptr, (const double*)nullptr, n);
+  HIPCHK(hipStreamSynchronize(e->stream));   // host vectors go out of scope after return
+  return AZ_OK;
+}
+
+extern "C" int az_mcts_reset(az_engine* e) {
+  ENGINE(e);
+  if (e->running) return fail(AZ_ERR_STATE, "self-play in progress");
+  const int G = e->v.G;
+  HIPCHK(hipMemsetAsync(e->v.ht, 0, sizeof(unsigned long long) * (size_t)G * e->v.ht_size, e->stream));
+  HIPCHK(hipMemsetAsync(e->v.node_count, 0, sizeof(int) * G, e->stream));
+  hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, e->v.epoch, 1u, G);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return AZ_OK;
+}
+
+extern "C" int az_mcts_explore(az_engine* e, const uint64_t* root_keys, int32_t nslots, int32_t nsims,
+                               const double* eta, const uint32_t* game_ids, const uint32_t* moves) {
+  ENGINE(e);
+  if (e->running) return fail(AZ_ERR_STATE, "self-play in progress");
+  if (!root_keys || nslots < 1 || nslots > e->v.G) return fail(AZ_ERR_BAD_ARG, "nslots must be in 1..num_workers");
+  if (nsims < 1) return fail(AZ_ERR_BAD_ARG, "nsims must be >= 1");
+  if (e->cfg.oracle == AZ_ORACLE_RESNET && !e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
+  std::vector<int> slots(nslots);
+  std::vector<uint32_t> gids(nslots), mv(nslots);
+  std::vector<GEnv> roots(nslots);
+  for (int i = 0; i < nslots; ++i) { slots[i] = i; gids[i] = game_ids ? game_ids[i] : 0; mv[i] = moves ? moves[i] : 0; }
+  DISPATCH_GAME(e->cfg.game, {
+    for (int i = 0; i < nslots; ++i) {
+      roots[i] = Gm::from_key(root_keys[2 * i], root_keys[2 * i + 1]);
+      if (roots[i].fin & 1) return fail(AZ_ERR_BAD_ARG, "root state %d is terminal", i);
+    }
+  });
+  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
+  DISPATCH_GAME(e->cfg.game, AZCHK(start_games<Gm>(e, slots, gids, &roots, 0, 0)));
+  HIPCHK(hipMemcpyAsync(e->d_moves, mv.data(), sizeof(uint32_t) * nslots, hipMemcpyHostToDevice, e->stream));
+  if (eta) HIPCHK(hipMemcpyAsync(e->d_eta, eta, sizeof(double) * (size_t)nslots * AZ_MAX_ACTIONS, hipMemcpyHostToDevice, e->stream));
+  DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_arm_noise<Gm>), dim3((nslots + 255) / 256), dim3(256), 0, e->stream, e->v, e->p, e->d_slots, e->d_moves, eta ? e->d_eta : nullptr, nslots));
+  for (int i = 0; i < nsims; ++i) DISPATCH_GAME(e->cfg.game, AZCHK(wave<Gm>(e)));
+  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
+  return check_device_error(e);
+}
+
+template <class Gm>
+__global__ void k_node_stats(DView v, int slot, unsigned long long ka, unsigned long long kb, char* out) {
+  using NL = NodeL<Gm>;
+  const uint32_t epoch = v.epoch[slot];
+  const unsigned long long hk = az_hash_key(ka, kb);
+  const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
+  const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
+  const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
+  int* found = (int*)out;
+  *found = 0;
+  for (uint32_t i = 0; i <= H1; ++i) {
+    unsigned long long e = tab[((uint32_t)hk + i) & H1];
+    uint32_t idx1 = (uint32_t)e;
+    if (!((uint32_t)(e >> 48) == epoch && idx1 != 0)) return;
+    if (((uint32_t)(e >> 32) & 0xffff) == tag) {
+      const char* nd = pool + (size_t)(idx1 - 1) * NL::BYTES;
+      const unsigned long long* k = (const unsigned long long*)nd;
+      if (k[0] == ka && k[1] == kb) {
+        *found = 1;
+        for (int b = 0; b < NL::BYTES; ++b) out[16 + b] = nd[b];
+        return;
+      }
+    }
+  }
+}
+
+extern "C" int az_mcts_node_stats(az_engine* e, int32_t slot, const uint64_t key[2], int32_t* N, double* W, float* P,
+                                  float* Vest, uint32_t* mask) {
+  ENGINE(e);
+  if (slot < 0 || slot >= e->v.G || !key) return fail(AZ_ERR_BAD_ARG, "bad slot or NULL key");
+  DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_node_stats<Gm>), dim3(1), dim3(1), 0, e->stream, e->v, (int)slot, (unsigned long long)key[0], (unsigned long long)key[1], e->d_nodebuf));
+  char buf[512];
+  HIPCHK(hipMemcpyAsync(buf, e->d_nodebuf, 512, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  int found; memcpy(&found, buf, 4);
+  if (!found) return fail(AZ_ERR_BAD_ARG, "state not in the tree of slot %d", slot);
+  const char* nd = buf + 16;
+  const int L = e->gi.APAD, A = e->gi.A;
+  for (int a = 0; a < A; ++a) {
+    if (N) memcpy(&N[a], nd + 32 + 4 * a, 4);
+    if (P) memcpy(&P[a], nd + 32 + 4 * L + 4 * a, 4);
+    if (W) memcpy(&W[a], nd + 32 + 8 * L + 8 * a, 8);
+  }
+  if (Vest) memcpy(Vest, nd + 16, 4);
+  if (mask) memcpy(mask, nd + 20, 4);
+  return AZ_OK;
+}
+
+extern "C" int az_mcts_counters(az_engine* e, int32_t slot, int64_t* ts, int64_t* tt, int64_t* nn) {
+  ENGINE(e);
+  if (slot < 0 || slot >= e->v.G) return fail(AZ_ERR_BAD_ARG, "bad slot");
+  long long a = 0, b = 0; int c = 0;
+  HIPCHK(hipMemcpyAsync(&a, e->v.tot_sims + slot, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(&b, e->v.tot_trav + slot, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(&c, e->v.node_count + slot, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (ts) *ts = a;
+  if (tt) *tt = b;
+  if (nn) *nn = c;
+  return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------- self-play
+extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_game_id) {
+  ENGINE(e);
+  if (e->running) return fail(AZ_ERR_STATE, "self-play already in progress");
+  if (num_games == 0) return fail(AZ_ERR_BAD_ARG, "num_games must be != 0");
+  if (e->cfg.oracle == AZ_ORACLE_RESNET && !e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
+  const int G = e->v.G;
+  // a fresh player per worker (simulations.jl:217-218): empty trees, zero counters
+  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * G, e->stream));
+  HIPCHK(hipMemsetAsync(e->v.finished, 0, sizeof(int) * G, e->stream));
+  HIPCHK(hipMemsetAsync(e->v.worker_sim_id, 0, sizeof(int) * G, e->stream));
+  HIPCHK(hipMemsetAsync(e->v.tot_sims, 0, sizeof(long long) * G, e->stream));
+  HIPCHK(hipMemsetAsync(e->v.tot_trav, 0, sizeof(long long) * G, e->stream));
+  HIPCHK(hipMemsetAsync(e->v.stat, 0, sizeof(long long) * 8, e->stream));
+  e->total_games = num_games; e->first_game_id = first_game_id; e->next_game = 0; e->games_done = 0; e->wave_in_move = 0;
+  e->q_games.clear(); e->q_moves.clear();
+  memset(&e->stats, 0, sizeof e->stats);
+  const int n0 = num_games < 0 ? G : std::min(G, (int)num_games);
+  std::vector<int> slots(n0);
+  std::vector<uint32_t> gids(n0);
+  for (int i = 0; i < n0; ++i) { slots[i] = i; gids[i] = (uint32_t)(first_game_id + e->next_game++); }
+  DISPATCH_GAME(e->cfg.game, AZCHK(start_games<Gm>(e, slots, gids, nullptr, 1, 1)));
+  e->active_slots = n0;
+  e->running = true;
+  e->t_begin = std::chrono::steady_clock::now();
+  return AZ_OK;
+}
+
+// the move step (play.jl:308-313) for every slot, then collection of finished games and refill
+template <class Gm> static int move_round(az_engine* e) {
+  const int G = e->v.G;
+  LAUNCH(e, AZ_K_MOVE, G, (k_move<Gm>), (G + 255) / 256, 256, 0, e->v, e->p);
+  HIPCHK(hipMemcpyAsync(e->h_finished.data(), e->v.finished, sizeof(int) * G, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_grec.data(), e->v.grec, sizeof(az_game_rec) * G, hipMemcpyDeviceToHost, e->stream));
+  AZCHK(check_device_error(e));   // synchronises
+  e->stats.moves += e->active_slots;
+  std::vector<int> fslots, offs;
+  int total = 0;
+  for (int s = 0; s < G; ++s) if (e->h_finished[s]) { fslots.push_back(s); offs.push_back(total); total += e->h_grec[s].num_moves; }
+  if (fslots.empty()) return AZ_OK;
+  const int nf = (int)fslots.size();
+  HIPCHK(hipMemcpyAsync(e->d_slots, fslots.data(), sizeof(int) * nf, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_offsets, offs.data(), sizeof(int) * nf, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_gather_traces, dim3(nf), dim3(64), 0, e->stream, e->v, e->d_slots, e->d_offsets, nf, e->d_stage);
+  const size_t m0 = e->q_moves.size();
+  e->q_moves.resize(m0 + total);
+  HIPCHK(hipMemcpyAsync(e->q_moves.data() + m0, e->d_stage, sizeof(az_move_rec) * total, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemsetAsync(e->v.finished, 0, sizeof(int) * G, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  std::vector<int> rslots;
+  std::vector<uint32_t> rgids;
+  for (int i = 0; i < nf; ++i) {
+    az_game_rec g = e->h_grec[fslots[i]];
+    g.first_move = (int32_t)(m0 + offs[i]);
+    e->q_games.push_back(g);
+    e->games_done++;
+    e->stats.games++;
+    e->active_slots--;
+    if (e->total_games < 0 || e->next_game < e->total_games) {      // next id, in slot order (util.jl:181-188)
+      rslots.push_back(fslots[i]);
+      rgids.push_back((uint32_t)(e->first_game_id + e->next_game++));
+      e->active_slots++;
+    }
+  }
+  AZCHK(start_games<Gm>(e, rslots, rgids, nullptr, 0, 1));
+  return AZ_OK;
+}
+
+extern "C" int az_selfplay_step(az_engine* e, int32_t nwaves) {
+  ENGINE(e);
+  if (!e->running) return fail(AZ_ERR_STATE, "az_selfplay_begin has not been called");
+  for (int w = 0; w < nwaves; ++w) {
+    if (e->active_slots == 0) break;
+    DISPATCH_GAME(e->cfg.game, AZCHK(wave<Gm>(e)));
+    if (++e->wave_in_move == e->p.nsims) {
+      e->wave_in_move = 0;
+      DISPATCH_GAME(e->cfg.game, AZCHK(move_round<Gm>(e)));
+    }
+  }
+  return AZ_OK;
+}
+
+extern "C" int az_selfplay_active(az_engine* e, int32_t* n) {
+  ENGINE(e);
+  if (!n) return fail(AZ_ERR_BAD_ARG, "NULL");
+  *n = e->running ? e->active_slots : 0;
+  return AZ_OK;
+}
+
+extern "C" int az_selfplay_get_stats(az_engine* e, az_selfplay_stats* s) {
+  ENGINE(e);
+  if (!s) return fail(AZ_ERR_BAD_ARG, "NULL");
+  long long st[8];
+  HIPCHK(hipMemcpyAsync(st, e->v.stat, sizeof st, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->stats.simulations = st[0]; e->stats.nodes_traversed = st[1]; e->stats.leaf_evals = st[2];
+  e->stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - e->t_begin).count();
+  *s = e->stats;
+  return AZ_OK;
+}
+
+extern "C" int az_selfplay_collect(az_engine* e, az_trace_buf* out) {
+  ENGINE(e);
+  if (!out) return fail(AZ_ERR_BAD_ARG, "NULL");
+  const int64_t ng = (int64_t)e->q_games.size(), nm = (int64_t)e->q_moves.size();
+  if (ng > out->games_cap || nm > out->moves_cap || (ng && !out->games) || (nm && !out->moves))
+    return fail(AZ_ERR_CAPACITY, "trace buffer too small: need %lld games / %lld moves", (long long)ng, (long long)nm);
+  // sorted by game id, move records re-packed in that order
+  std::vector<int> ord(ng);
+  for (int i = 0; i < ng; ++i) ord[i] = i;
+  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return e->q_games[a].game_id < e->q_games[b].game_id; });
+  int64_t m = 0;
+  for (int64_t i = 0; i < ng; ++i) {
+    az_game_rec g = e->q_games[ord[i]];
+    memcpy(out->moves + m, e->q_moves.data() + g.first_move, sizeof(az_move_rec) * (size_t)g.num_moves);
+    g.first_move = (int32_t)m;
+    m += g.num_moves;
+    out->games[i] = g;
+  }
+  out->num_games = ng; out->num_moves = nm;
+  e->q_games.clear(); e->q_moves.clear();
+  return AZ_OK;
+}
+
+extern "C" int az_selfplay_end(az_engine* e) {
+  ENGINE(e);
+  if (!e->running) return AZ_OK;
+  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->running = false;
+  e->active_slots = 0;
+  return AZ_OK;
+}
+
+extern "C" int az_selfplay_run(az_engine* e, int32_t num_games, int32_t first_game_id, az_trace_buf* out,
+                               az_progress_cb cb, void* user, az_selfplay_stats* stats) {
+  ENGINE(e);
+  if (num_games < 1 || !out) return fail(AZ_ERR_BAD_ARG, "num_games must be >= 1 and out non-NULL");
+  if (out->games_cap < num_games) return fail(AZ_ERR_CAPACITY, "games_cap %lld < num_games %d", (long long)out->games_cap, num_games);
+  AZCHK(az_selfplay_begin(e, num_games, first_game_id));
+  int reported = 0;
+  int st = AZ_OK;
+  while (e->games_done < num_games) {
+    st = az_selfplay_step(e, e->p.nsims);
+    if (st != AZ_OK) break;
+    if (cb) for (; reported < e->games_done; ++reported) cb(user);   // game_simulated()
+  }
+  if (st == AZ_OK && stats) st = az_selfplay_get_stats(e, stats);
+  if (st == AZ_OK) st = az_selfplay_collect(e, out);
+  std::string keep = g_err;
+  az_selfplay_end(e);
+  if (st != AZ_OK) g_err = keep;
+  return st;
+}
+
+extern "C" int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, double* z, double* t) {
+  if (n < 0 || (n > 0 && (!moves || !z || !t))) return fail(AZ_ERR_BAD_ARG, "NULL buffer");
+  double wr = 0.;                                                // memory.jl:74-87
+  for (int i = n - 1; i >= 0; --i) {
+    wr = gamma * wr + (double)moves[i].reward;
+    const bool wp = !(moves[i].key[0] >> 63);
+    z[i] = wp ? wr : -wr;
+    t[i] = (double)(n - i);
+  }
+  return AZ_OK;
+}
+
+// ------------------------------------------------------------------------------- profiling
+extern "C" int az_prof_enable(az_engine* e, int32_t on) {
+  ENGINE(e);
+  AZCHK(prof_flush(e));
+  e->prof_on = on != 0;
+  return AZ_OK;
+}
+extern "C" int az_prof_reset(az_engine* e) {
+  ENGINE(e);
+  AZCHK(prof_flush(e));
+  memset(&e->prof, 0, sizeof e->prof);
+  return AZ_OK;
+}
+extern "C" int az_prof_get(az_engine* e, az_prof* out) {
+  ENGINE(e);
+  if (!out) return fail(AZ_ERR_BAD_ARG, "NULL");
+  AZCHK(prof_flush(e));
+  *out = e->prof;
+  return AZ_OK;
+}

@@ -1,0 +1,271 @@
+// resnet.h -- the two-headed ResNet oracle (src/networks/architectures/resnet.jl:53-92, test
+// mode) as two CDNA4 kernels.
+//
+//  k_tower   one workgroup (4 wavefronts) owns TB = 128/P whole boards (3 Connect-Four boards =
+//            126 of 128 GEMM rows) and runs stem + every residual block + the two 1x1 head
+//            convolutions WITHOUT leaving the CU: activations live in two LDS buffers
+//            ([129 rows][F + 4 pad] fp32, row 128 = zeros for the padding taps), so the tower's
+//            only HBM traffic is 16 B of state in and P*64 fp32 of head features out per board.
+//            Every 3x3 convolution is an implicit GEMM on v_mfma_f32_32x32x2_f32: wavefront w owns
+//            rows 32w..32w+31 and all F output channels (F/32 accumulators of 16 VGPRs); the A
+//            operand (activations) is a ds_read_b128 of 4 consecutive channels of the tap-shifted
+//            row, the B operand (weights) a coalesced 1 KiB global_load_dwordx4 from a buffer
+//            pre-packed in fragment order (L2-resident: 147 KB per layer).  BatchNorm (folded to
+//            scale/shift), residual add and ReLU are the accumulator epilogue.
+//            The MFMA K order is the fp32 contract of include/azhip.h: lanes 0-31 carry channel j,
+//            lanes 32-63 channel F/2 + j, so each output is the fma chain the oracle restates.
+//  k_heads   flatten + Dense layers + softmax / tanh + Network.forward_normalized
+//            (src/networks/network.jl:264-271), one thread per output, sequential fp32 chain.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/az_numerics.h"
+#include "games.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct NetDev {
+  int nblocks, F, npf, nvf, HF;       // HF = padded npf + nvf (multiple of 32)
+  const float* stem_w;                // [9*C][F]  k-major
+  const float* stem_ss;               // [2][F] scale, shift
+  const float4* conv_w;               // [2*nblocks][9][F/32][F/8][64] float4 (fragment order)
+  const float* conv_ss;               // [2*nblocks][2][F]
+  const float4* head_w;               // [1][HF/32][F/8][64] float4
+  const float* head_ss;               // [2][HF]
+  const float* pol_w;                 // [P*npf][APAD]  k-major
+  const float* pol_b;                 // [APAD]
+  const float* val_w;                 // [P*nvf][F]     k-major
+  const float* val_b;                 // [F]
+  const float* val2_w;                // [F]
+  float val2_b;
+};
+
+static constexpr int TOWER_ROWS = 128;
+
+template <int F> struct TowerLds {
+  static constexpr int STRIDE = F + 4;                       // +16 B: conflict-free ds_read_b128 columns
+  static constexpr int BUF = (TOWER_ROWS + 1) * STRIDE;      // floats per buffer (row 128 = zeros)
+  static constexpr int BYTES = 2 * BUF * 4;
+};
+
+// one 3x3 (NTAP = 9) or 1x1 (NTAP = 1) convolution over the workgroup's 128 rows
+template <int F, int NT, int NTAP>
+__device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* __restrict__ out,
+                                          const float4* __restrict__ wpk, const float* __restrict__ ss,
+                                          int out_ch, bool residual, const int* nbr, int wave, int lane) {
+  constexpr int STRIDE = TowerLds<F>::STRIDE;
+  constexpr int JQ = F / 8;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  const int khalf = (lane >> 5) * (F / 2);
+#pragma unroll 1
+  for (int t = 0; t < NTAP; ++t) {
+    const float* arow = in + nbr[NTAP == 1 ? 4 : t] + khalf;
+    const float4* wt = wpk + (size_t)t * NT * JQ * 64 + lane;
+#pragma unroll
+    for (int jq = 0; jq < JQ; ++jq) {
+      const float4 a4 = *(const float4*)(arow + jq * 4);
+      float4 b4[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b4[n] = wt[(size_t)(n * JQ + jq) * 64];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[n].x, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[n].y, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[n].z, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[n].w, acc[n], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: folded BN, residual, ReLU.  C/D layout of the 32x32 MFMA: col = lane & 31,
+  // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = n * 32 + (lane & 31);
+    const float sc = ss[col], sh = ss[out_ch + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      float v = az_fmaf(acc[n][r], sc, sh);
+      if (residual) v = v + out[row * STRIDE + col];
+      v = v > 0.0f ? v : 0.0f;
+      out[row * STRIDE + col] = v;
+    }
+  }
+}
+
+// FROM_PLANES = false: inputs are the leaf states of the evaluation batch (encode fused);
+// FROM_PLANES = true : inputs are Flux-layout planes X[n][C][H][W] (Network.forward seam).
+template <class Gm, int F, bool FROM_PLANES>
+__global__ void __launch_bounds__(256, 2)
+k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+        const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
+  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, C = Gm::C;
+  constexpr int TB = TOWER_ROWS / P;
+  constexpr int STRIDE = TowerLds<F>::STRIDE;
+  constexpr int BUF = TowerLds<F>::BUF;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* bufX = lds;
+  float* bufT = lds + BUF;
+  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
+  const int board0 = blockIdx.x * TB;
+  if (board0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- stage planes + stem weights in the (still unused) T buffer --------------------------
+  float* planes = bufT;                       // [128][C]
+  float* sw = bufT + TOWER_ROWS * C;          // [9*C][F]
+  for (int i = tid; i < TOWER_ROWS * C; i += 256) {
+    const int row = i / C, c = i % C;
+    const int b = row / P, q = row % P;
+    float val = 0.0f;
+    if (b < TB && board0 + b < n) {
+      if (FROM_PLANES) val = X[((size_t)(board0 + b) * C + c) * P + q];
+      else val = Gm::plane(leaf_env[eval_slots[board0 + b]], q, c);
+    }
+    planes[i] = val;
+  }
+  for (int i = tid; i < 9 * C * F; i += 256) sw[i] = net.stem_w[i];
+  for (int i = tid; i < STRIDE; i += 256) { bufX[TOWER_ROWS * STRIDE + i] = 0.0f; }
+  __syncthreads();
+
+  // ---- stem: Conv(3x3, C=>F) + BN + ReLU (resnet.jl:75-77), fp32 VALU chain k = t*C + c -----
+  {
+    const int row = tid >> 1, half = tid & 1;
+    const int b = row / P, q = row % P, x = q % W, y = q / W;
+    float acc[F / 2];
+#pragma unroll
+    for (int i = 0; i < F / 2; ++i) acc[i] = 0.0f;
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = (b < TB) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
+      const int nrow = ok ? row + dy * W + dx : 0;
+      for (int c = 0; c < C; ++c) {
+        const float val = ok ? planes[nrow * C + c] : 0.0f;
+        const float* wk = sw + (t * C + c) * F + half * (F / 2);
+#pragma unroll
+        for (int i = 0; i < F / 2; ++i) acc[i] = az_fmaf(val, wk[i], acc[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < F / 2; ++i) {
+      const int co = half * (F / 2) + i;
+      float v = az_fmaf(acc[i], net.stem_ss[co], net.stem_ss[F + co]);
+      bufX[row * STRIDE + co] = v > 0.0f ? v : 0.0f;
+    }
+  }
+  // tap-shifted LDS row offsets of this lane's A row; the zero row for out-of-board taps
+  int nbr[9];
+  {
+    const int row = 32 * wave + (lane & 31);
+    const int b = row / P, q = row % P, x = q % W, y = q / W;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = (b < TB) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
+      nbr[t] = (ok ? row + dy * W + dx : TOWER_ROWS) * STRIDE;
+    }
+  }
+  __syncthreads();
+  // the T buffer's zero row (planes/stem weights lived there until now)
+  for (int i = tid; i < STRIDE; i += 256) bufT[TOWER_ROWS * STRIDE + i] = 0.0f;
+  __syncthreads();
+
+  // ---- residual tower (resnet.jl:53-63,78) ---------------------------------------------------
+  constexpr int NT = F / 32;
+  constexpr size_t LAYER_W = (size_t)9 * NT * (F / 8) * 64;   // float4 per conv layer
+  for (int blk = 0; blk < net.nblocks; ++blk) {
+    conv_mfma<F, NT, 9>(bufX, bufT, net.conv_w + (size_t)(2 * blk) * LAYER_W, net.conv_ss + (size_t)(2 * blk) * 2 * F,
+                        F, false, nbr, wave, lane);
+    __syncthreads();
+    conv_mfma<F, NT, 9>(bufT, bufX, net.conv_w + (size_t)(2 * blk + 1) * LAYER_W,
+                        net.conv_ss + (size_t)(2 * blk + 1) * 2 * F, F, true, nbr, wave, lane);
+    __syncthreads();
+  }
+  // ---- both 1x1 head convolutions + BN + ReLU as one F => HF GEMM (resnet.jl:80-81,86-87) ----
+  // (HF == F == 64 for the 32/32 heads; general HF <= F handled by NT of the head)
+  conv_mfma<F, NT, 1>(bufX, bufT, net.head_w, net.head_ss, net.HF, false, nbr, wave, lane);
+  __syncthreads();
+  // head features -> HBM, [board][P][HF] (the flatten order of the dense contract)
+  {
+    const int HF = net.HF;
+    const int nb = (n - board0) < TB ? (n - board0) : TB;
+    const int total = nb * P * (HF / 4);
+    for (int i = tid; i < total; i += 256) {
+      const int row = i / (HF / 4), c4 = i % (HF / 4);
+      const float4 v4 = *(const float4*)(bufT + row * STRIDE + c4 * 4);
+      *(float4*)(hfeat + ((size_t)board0 * P + row) * HF + c4 * 4) = v4;
+    }
+  }
+}
+
+// Dense heads, softmax, tanh, forward_normalized.  HB boards per 320-thread workgroup; thread
+// (b, o): o < F -> value hidden unit, F <= o < F + A -> policy logit.
+template <class Gm, int F>
+__global__ void __launch_bounds__(320)
+k_heads(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+        const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ Amask,
+        const float* __restrict__ hfeat, float* __restrict__ Pout, float* __restrict__ Vout,
+        float* __restrict__ Pinv, int pstride) {
+  constexpr int P = Gm::P, A = Gm::A, HB = 4, PER = 80;       // 64 + up to 16 outputs per board
+  static_assert(F + Gm::APAD <= PER || F + A <= PER, "thread map");
+  __shared__ float s_logit[HB][16];
+  __shared__ float s_vh[HB][F];
+  const int n = n_eval_ptr ? *n_eval_ptr : n_fixed;
+  const int board0 = blockIdx.x * HB;
+  if (board0 >= n) return;
+  const int b = threadIdx.x / PER, o = threadIdx.x % PER;
+  const int e = board0 + b;
+  const int HF = net.HF;
+  if (e < n && o < F + A) {
+    const float* hf = hfeat + (size_t)e * P * HF;
+    float acc = 0.0f;
+    if (o < F) {                                   // Dense(P*nvf => F, relu), resnet.jl:89
+      const int nvf = net.nvf;
+      const float* w = net.val_w + o;
+      for (int q = 0; q < P; ++q) {
+        const float* h = hf + q * HF + net.npf;
+        for (int f = 0; f < nvf; ++f) acc = az_fmaf(h[f], w[(size_t)(q * nvf + f) * F], acc);
+      }
+      acc = acc + net.val_b[o];
+      s_vh[b][o] = acc > 0.0f ? acc : 0.0f;
+    } else {                                       // Dense(P*npf => A), resnet.jl:83
+      const int a = o - F, npf = net.npf;
+      const float* w = net.pol_w + a;
+      for (int q = 0; q < P; ++q) {
+        const float* h = hf + q * HF;
+        for (int f = 0; f < npf; ++f) acc = az_fmaf(h[f], w[(size_t)(q * npf + f) * Gm::APAD], acc);
+      }
+      s_logit[b][a] = acc + net.pol_b[a];
+    }
+  }
+  __syncthreads();
+  if (o == 0 && e < n) {
+    float pr[A];
+    float mx = s_logit[b][0];
+    for (int a = 1; a < A; ++a) mx = s_logit[b][a] > mx ? s_logit[b][a] : mx;
+    float s = 0.0f;
+    for (int a = 0; a < A; ++a) { pr[a] = az_expf(s_logit[b][a] - mx); s += pr[a]; }
+    for (int a = 0; a < A; ++a) pr[a] = pr[a] / s;                 // softmax, resnet.jl:84
+    float acc = 0.0f;
+    for (int k = 0; k < F; ++k) acc = az_fmaf(s_vh[b][k], net.val2_w[k], acc);
+    acc = acc + net.val2_b;
+    const float val = az_tanhf(acc);                               // Dense(F => 1, tanh), resnet.jl:90
+    // forward_normalized, network.jl:264-271
+    float sp = 0.0f;
+    for (int a = 0; a < A; ++a) {
+      float mk;
+      if (Amask) mk = Amask[(size_t)e * A + a];
+      else mk = (float)((Gm::mask(leaf_env[eval_slots[e]]) >> a) & 1);
+      pr[a] = pr[a] * mk;
+      sp += pr[a];
+    }
+    for (int a = 0; a < A; ++a) Pout[(size_t)e * pstride + a] = pr[a] / (sp + 1.1920929e-7f);
+    for (int a = A; a < pstride; ++a) Pout[(size_t)e * pstride + a] = 0.0f;
+    Vout[e] = val;
+    if (Pinv) Pinv[e] = 1.0f - sp;
+  }
+}

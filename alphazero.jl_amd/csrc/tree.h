@@ -1,0 +1,521 @@
+// tree.h -- search-tree kernels: the device form of MCTS.Env (src/mcts.jl) and of the move
+// step of play_game (src/play.jl:298-315).
+//
+// Layout in HBM (one engine = G game slots, every array is slot-major):
+//   nodes  [G][cap][NODE_BYTES]   one record per stored state (the reference's StateInfo +
+//                                 Vector{ActionStats}, src/mcts.jl:78-87), full action width:
+//                                   +0  key a,b (16 B)   +16 Vest f32   +20 availability mask u32
+//                                   +32 N i32[APAD]   then P f32[APAD]   then W f64[APAD]
+//   ht     [G][H] u64             the Dict{State,StateInfo} of src/mcts.jl:126 as an open-addressed
+//                                 table: epoch(16) | tag(16) | node index+1 (32); an entry is live
+//                                 only if its epoch equals the slot's epoch, so MCTS.reset! is O(1)
+//   path   [G][max_depth] u64     explicit stack replacing the recursion of run_simulation!
+//
+// Thread mapping: APAD lanes per slot (8 for 7/6 actions, 16 for 9), lane a owns action a.  A
+// 64-wide wavefront therefore advances 8 (or 4) slots; N/P/W rows are read as one coalesced
+// 32/32/64-byte segment per slot, sums and argmax are wavefront shuffles inside the lane group.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/az_numerics.h"
+#include "../../include/azhip.h"
+#include "games.h"
+
+enum { LEAF_NONE = 0, LEAF_NEW = 1, LEAF_TERMINAL = 2 };
+enum { DERR_NODE_POOL = 1, DERR_HASH_FULL = 2, DERR_DEPTH = 3, DERR_MOVES = 4, DERR_NO_ROOT = 5 };
+
+struct DParams {
+  double gamma, cpuct, eps, alpha, prior_temp;
+  int nsims, temp_len;
+  int temp_xs[AZ_SCHED_MAX];
+  double temp_ys[AZ_SCHED_MAX];
+  uint64_t seed;
+  int oracle, reset_every;
+};
+
+struct DView {
+  int G, cap_nodes, ht_size, max_depth, max_moves;
+  GEnv* root;
+  int* active;
+  uint32_t* game_id;
+  uint32_t* move_idx;
+  uint32_t* epoch;
+  int* node_count;
+  int* worker_sim_id;
+  long long* tot_sims;
+  long long* tot_trav;
+  double* eta;            // [G][APAD] by full action index
+  unsigned long long* ht;
+  char* nodes;
+  unsigned long long* path;
+  int* leaf_kind;
+  int* leaf_depth;
+  GEnv* leaf_env;
+  uint32_t* leaf_ins;
+  int* eidx;              // slot -> index in the evaluation batch
+  int* eval_slots;        // evaluation batch -> slot
+  int* n_eval;            // device scalar
+  float* Pout;            // [n_eval][APAD] masked-normalised priors, full width
+  float* Vout;            // [n_eval]
+  az_move_rec* trace;     // [G][max_moves]
+  az_game_rec* grec;      // [G]
+  int* finished;          // [G] set by k_move when the slot's game ended this round
+  int* err;               // device error word (first error wins)
+  long long* stat;        // [0] simulations [1] nodes traversed [2] leaf evals [3] moves
+};
+
+template <class Gm> struct NodeL {
+  static constexpr int L = Gm::APAD;
+  static constexpr int OFF_VEST = 16, OFF_MASK = 20, OFF_N = 32, OFF_P = 32 + 4 * L, OFF_W = 32 + 8 * L;
+  static constexpr int BYTES = 32 + 16 * L;
+};
+
+__device__ inline void dev_fail(const DView& v, int code) { atomicCAS(v.err, 0, code); }
+
+// ---- lane-group helpers (L = 8 or 16 lanes, group-uniform control flow) -----------------
+template <int L> __device__ inline unsigned group_ballot(bool pred) {
+  unsigned long long b = __ballot(pred);
+  int base = (threadIdx.x & 63) & ~(L - 1);
+  return (unsigned)((b >> base) & ((1u << L) - 1));
+}
+template <int L> __device__ inline int group_sum(int x) {
+#pragma unroll
+  for (int o = 1; o < L; o <<= 1) x += __shfl_xor(x, o, L);
+  return x;
+}
+// first maximum: highest score, ties to the lowest lane (argmax, src/mcts.jl:211)
+template <int L> __device__ inline int group_argmax(double s, int lane) {
+  int idx = lane;
+#pragma unroll
+  for (int o = 1; o < L; o <<= 1) {
+    double so = __shfl_xor(s, o, L);
+    int io = __shfl_xor(idx, o, L);
+    if (so > s || (so == s && io < idx)) { s = so; idx = io; }
+  }
+  return idx;
+}
+
+// ---- Dict lookup: haskey(env.tree, state) (src/mcts.jl:165-174) ---------------------------
+// Returns the node index or -1; *ins receives the table position a new entry would take.
+template <class Gm>
+__device__ inline int ht_lookup(const DView& v, int slot, int lane, unsigned long long ka,
+                                unsigned long long kb, uint32_t epoch, uint32_t* ins) {
+  constexpr int L = Gm::APAD;
+  constexpr int NB = NodeL<Gm>::BYTES;
+  const unsigned long long hk = az_hash_key(ka, kb);
+  const uint32_t H1 = (uint32_t)v.ht_size - 1;
+  const uint32_t h0 = (uint32_t)hk & H1;
+  const uint32_t tag = (uint32_t)(hk >> 40) & 0xffff;
+  const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
+  const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NB;
+  const int iters = v.ht_size / L;
+  for (int i = 0; i < iters; ++i) {
+    uint32_t pos = (h0 + (uint32_t)(i * L + lane)) & H1;
+    unsigned long long e = tab[pos];
+    uint32_t idx1 = (uint32_t)e;
+    bool live = ((uint32_t)(e >> 48) == epoch) && idx1 != 0;
+    bool match = false;
+    if (live && ((uint32_t)(e >> 32) & 0xffff) == tag) {
+      const unsigned long long* k = (const unsigned long long*)(pool + (size_t)(idx1 - 1) * NB);
+      match = (k[0] == ka) && (k[1] == kb);
+    }
+    unsigned mb = group_ballot<L>(match), db = group_ballot<L>(!live);
+    int fm = mb ? __ffs(mb) - 1 : 99, fd = db ? __ffs(db) - 1 : 99;
+    if (fm < fd) {
+      int base = (threadIdx.x & 63) & ~(L - 1);
+      return (int)__shfl((int)idx1, base + fm) - 1;
+    }
+    if (fd != 99) { *ins = (h0 + (uint32_t)(i * L + fd)) & H1; return -1; }
+  }
+  dev_fail(v, DERR_HASH_FULL);
+  *ins = 0;
+  return -1;
+}
+
+// ---- dirichlet_noise (src/mcts.jl:228-232): one draw per explore!, by rank among available --
+template <class Gm>
+__device__ inline void arm_noise(const DView& v, const DParams& p, int slot, const GEnv& env) {
+  constexpr int L = Gm::APAD;
+  uint32_t m = Gm::mask(env);
+  int n = __popc(m);
+  double eta[AZ_MAX_ACTIONS];
+  az_rng r = az_rng_make(p.seed, v.game_id[slot], v.move_idx[slot], AZ_RNG_NOISE);
+  az_dirichlet(&r, n, p.alpha, eta);
+  int k = 0;
+  for (int a = 0; a < L; ++a) {
+    double e = 0.0;
+    if (a < Gm::A && ((m >> a) & 1)) e = eta[k++];
+    v.eta[(size_t)slot * L + a] = e;
+  }
+}
+
+// =========================================================================================
+// select: the descent of run_simulation! (src/mcts.jl:199-226) until a miss or a terminal state
+// =========================================================================================
+template <class Gm>
+__global__ void __launch_bounds__(256) k_select(DView v, DParams p) {
+  constexpr int L = Gm::APAD;
+  using NL = NodeL<Gm>;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = tid / L, lane = tid % L;
+  if (slot >= v.G) return;
+  if (!v.active[slot]) { if (lane == 0) v.leaf_kind[slot] = LEAF_NONE; return; }
+  GEnv env = v.root[slot];
+  const uint32_t epoch = v.epoch[slot];
+  const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
+  unsigned long long* path = v.path + (size_t)slot * v.max_depth;
+  int depth = 0, kind = LEAF_NONE;
+  uint32_t ins = 0;
+  for (;;) {
+    if (env.fin & 1) { kind = LEAF_TERMINAL; break; }             // mcts.jl:200-201
+    int idx = ht_lookup<Gm>(v, slot, lane, env.a, env.b, epoch, &ins);
+    if (idx < 0) { kind = LEAF_NEW; break; }                      // mcts.jl:205-207
+    if (depth >= v.max_depth) { dev_fail(v, DERR_DEPTH); kind = LEAF_NONE; break; }
+    const char* nd = pool + (size_t)idx * NL::BYTES;
+    const uint32_t amask = *(const uint32_t*)(nd + NL::OFF_MASK);
+    const int N = ((const int*)(nd + NL::OFF_N))[lane];
+    const float Pf = ((const float*)(nd + NL::OFF_P))[lane];
+    const double W = ((const double*)(nd + NL::OFF_W))[lane];
+    // uct_scores (mcts.jl:180-188): Float64, evaluated left to right
+    const int Ntot = group_sum<L>(N);
+    const double sqrtNtot = __builtin_sqrt((double)Ntot);
+    const double Q = W / (double)(N > 1 ? N : 1);
+    double Pd = (double)Pf;
+    if (depth == 0 && p.eps != 0.0) Pd = (1.0 - p.eps) * Pd + p.eps * v.eta[(size_t)slot * L + lane];
+    double sc = Q + p.cpuct * Pd * sqrtNtot / (double)(N + 1);
+    if (!((amask >> lane) & 1)) sc = -__builtin_inf();
+    const int act = group_argmax<L>(sc, lane);
+    const bool wp = Gm::white_playing(env);
+    Gm::play(env, act);                                           // mcts.jl:213-217
+    const float wr = Gm::white_reward(env);
+    const int r = (int)(wp ? wr : -wr);
+    const bool psw = wp != Gm::white_playing(env);
+    if (lane == 0)
+      path[depth] = (unsigned long long)(uint32_t)idx | ((unsigned long long)act << 32) |
+                    ((unsigned long long)(psw ? 1 : 0) << 40) | ((unsigned long long)(r + 1) << 41);
+    depth++;
+  }
+  if (lane == 0) {
+    v.leaf_kind[slot] = kind;
+    v.leaf_depth[slot] = depth;
+    v.leaf_env[slot] = env;
+    v.leaf_ins[slot] = ins;
+  }
+}
+
+// compaction of the slots whose simulation ended on an unseen state -> evaluation batch,
+// ascending slot order (what Batchifier.launch_server collects, src/batchifier.jl:47-81)
+__global__ void __launch_bounds__(1024) k_compact(DView v) {
+  __shared__ int wsum[16];
+  __shared__ int total;
+  const int per = (v.G + 1023) / 1024;
+  const int s0 = threadIdx.x * per;
+  int cnt = 0, sims = 0, trav = 0;
+  for (int i = 0; i < per; ++i) {
+    int s = s0 + i;
+    if (s < v.G) {
+      const int k = v.leaf_kind[s];
+      if (k == LEAF_NEW) cnt++;
+      if (k != LEAF_NONE) { sims++; trav += v.leaf_depth[s]; }
+    }
+  }
+  if (sims) {
+    atomicAdd((unsigned long long*)&v.stat[0], (unsigned long long)sims);
+    atomicAdd((unsigned long long*)&v.stat[1], (unsigned long long)trav);
+  }
+  int x = cnt;                                       // inclusive scan inside the wavefront
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
+  if (lane == 63) wsum[w] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) { int a = 0; for (int i = 0; i < 16; ++i) { int t = wsum[i]; wsum[i] = a; a += t; } total = a; }
+  __syncthreads();
+  int off = wsum[w] + x - cnt;
+  for (int i = 0; i < per; ++i) {
+    int s = s0 + i;
+    if (s < v.G) {
+      if (v.leaf_kind[s] == LEAF_NEW) { v.eidx[s] = off; v.eval_slots[off] = s; off++; }
+      else v.eidx[s] = -1;
+    }
+  }
+  if (threadIdx.x == 0) { *v.n_eval = total; v.stat[2] += total; }
+}
+
+// NN-free oracles: MCTS.RandomOracle (src/mcts.jl:62-72) and the synthetic hash oracle
+template <class Gm>
+__global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p) {
+  constexpr int L = Gm::APAD;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= *v.n_eval) return;
+  const GEnv env = v.leaf_env[v.eval_slots[e]];
+  const uint32_t m = Gm::mask(env);
+  float P[L];
+  float V = 0.f;
+  if (p.oracle == AZ_ORACLE_UNIFORM) {
+    const float u = (float)(1.0 / (double)__popc(m));             // Float32(ones(n) ./ n)
+    for (int a = 0; a < L; ++a) P[a] = ((m >> a) & 1) ? u : 0.f;
+  } else {
+    const unsigned long long h = az_hash_key(env.a, env.b);
+    float s = 0.f;
+    for (int a = 0; a < L; ++a) {
+      float raw = (a < Gm::A && ((m >> a) & 1)) ? (float)(1 + (int)(az_mix64(h + (unsigned long long)(a + 1)) & 0xffff)) : 0.f;
+      P[a] = raw;
+      if (a < Gm::A) s += raw;
+    }
+    for (int a = 0; a < L; ++a) P[a] = P[a] / s;
+    V = (float)((int)(az_mix64(h + 99) & 0xffff) - 32768) / 65536.0f;
+  }
+  for (int a = 0; a < L; ++a) v.Pout[(size_t)e * L + a] = P[a];
+  v.Vout[e] = V;
+}
+
+// =========================================================================================
+// expand + backup: init_state_info (mcts.jl:157-161), update_state_info! (mcts.jl:190-194) and
+// the unwinding half of run_simulation! (mcts.jl:218-223)
+// =========================================================================================
+template <class Gm>
+__global__ void __launch_bounds__(256) k_expand_backup(DView v, DParams p) {
+  constexpr int L = Gm::APAD;
+  using NL = NodeL<Gm>;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = tid / L, lane = tid % L;
+  if (slot >= v.G) return;
+  const int kind = v.leaf_kind[slot];
+  if (kind == LEAF_NONE) return;
+  char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
+  const int depth = v.leaf_depth[slot];
+  double q = 0.0;                                                 // terminal: return 0.
+  if (kind == LEAF_NEW) {
+    const int e = v.eidx[slot];
+    const int idx = v.node_count[slot];
+    if (idx >= v.cap_nodes) { dev_fail(v, DERR_NODE_POOL); return; }
+    const GEnv env = v.leaf_env[slot];
+    const uint32_t m = Gm::mask(env);
+    float Pf = v.Pout[(size_t)e * L + lane];
+    const float V = v.Vout[e];
+    if (p.prior_temp != 1.0) {                                    // Util.apply_temperature, util.jl:98-110
+      const bool av = (m >> lane) & 1;
+      const int base = (threadIdx.x & 63) & ~(L - 1);
+      double res;
+      if (p.prior_temp == 0.0) {
+        int am = group_argmax<L>(av ? (double)Pf : -__builtin_inf(), lane);
+        res = (lane == am) ? 1.0 : 0.0;
+      } else {
+        double pw = av ? az_pow((double)Pf, 1.0 / p.prior_temp) : 0.0;
+        double s = 0.0;
+        for (int a = 0; a < Gm::A; ++a) { double t = __shfl(pw, base + a); if ((m >> a) & 1) s += t; }
+        res = pw / s;
+      }
+      Pf = av ? (float)res : 0.f;
+    }
+    char* nd = pool + (size_t)idx * NL::BYTES;
+    ((int*)(nd + NL::OFF_N))[lane] = 0;
+    ((float*)(nd + NL::OFF_P))[lane] = Pf;
+    ((double*)(nd + NL::OFF_W))[lane] = 0.0;
+    if (lane == 0) {
+      ((unsigned long long*)nd)[0] = env.a;
+      ((unsigned long long*)nd)[1] = env.b;
+      *(float*)(nd + NL::OFF_VEST) = V;
+      *(uint32_t*)(nd + NL::OFF_MASK) = m;
+      const unsigned long long hk = az_hash_key(env.a, env.b);
+      const unsigned long long tag = (hk >> 40) & 0xffff;
+      v.ht[(size_t)slot * v.ht_size + v.leaf_ins[slot]] =
+          ((unsigned long long)v.epoch[slot] << 48) | (tag << 32) | (unsigned long long)(idx + 1);
+      v.node_count[slot] = idx + 1;
+    }
+    q = (double)V;                                                // return info.Vest
+  }
+  if (lane == 0) {
+    const unsigned long long* path = v.path + (size_t)slot * v.max_depth;
+    for (int k = depth - 1; k >= 0; --k) {
+      const unsigned long long st = path[k];
+      const uint32_t idx = (uint32_t)st;
+      const int act = (int)((st >> 32) & 0xff);
+      const bool psw = (st >> 40) & 1;
+      const double r = (double)((int)((st >> 41) & 3) - 1);
+      q = psw ? -q : q;
+      q = r + p.gamma * q;                                        // mcts.jl:219-220
+      char* nd = pool + (size_t)idx * NL::BYTES;
+      ((double*)(nd + NL::OFF_W))[act] += q;
+      ((int*)(nd + NL::OFF_N))[act] += 1;
+    }
+    v.tot_trav[slot] += depth;                                    // mcts.jl:222
+    v.tot_sims[slot] += 1;                                        // mcts.jl:242
+  }
+}
+
+// =========================================================================================
+// move: MCTS.policy (mcts.jl:255-271) + the body of play_game's loop (play.jl:308-313) +
+// end-of-game bookkeeping of simulate (simulations.jl:231-240)
+// =========================================================================================
+__device__ inline double pl_schedule(const DParams& p, int i) {   // schedule.jl:64-80
+  int pt = -1;
+  for (int k = 0; k < p.temp_len; ++k) if (p.temp_xs[k] <= i) pt = k;
+  if (pt < 0) return p.temp_ys[0];
+  if (pt == p.temp_len - 1) return p.temp_ys[pt];
+  double x0 = p.temp_xs[pt], y0 = p.temp_ys[pt], x1 = p.temp_xs[pt + 1], y1 = p.temp_ys[pt + 1];
+  return y0 + (y1 - y0) / (x1 - x0) * ((double)i - x0);
+}
+
+template <class Gm>
+__global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
+  using NL = NodeL<Gm>;
+  constexpr int L = Gm::APAD;
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;       // one lane per slot: n <= 9, serial
+  if (slot >= v.G || !v.active[slot]) return;
+  GEnv env = v.root[slot];
+  // tree[state] must exist after explore!
+  const uint32_t epoch = v.epoch[slot];
+  const unsigned long long hk = az_hash_key(env.a, env.b);
+  const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
+  const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
+  const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
+  const char* nd = nullptr;
+  for (uint32_t i = 0; i <= H1; ++i) {
+    unsigned long long e = tab[((uint32_t)hk + i) & H1];
+    uint32_t idx1 = (uint32_t)e;
+    if (!((uint32_t)(e >> 48) == epoch && idx1 != 0)) break;
+    if (((uint32_t)(e >> 32) & 0xffff) == tag) {
+      const unsigned long long* k = (const unsigned long long*)(pool + (size_t)(idx1 - 1) * NL::BYTES);
+      if (k[0] == env.a && k[1] == env.b) { nd = (const char*)k; break; }
+    }
+  }
+  if (!nd) { dev_fail(v, DERR_NO_ROOT); return; }
+  const uint32_t m = *(const uint32_t*)(nd + NL::OFF_MASK);
+  const int* Nn = (const int*)(nd + NL::OFF_N);
+  int acts[AZ_MAX_ACTIONS];
+  double pi[AZ_MAX_ACTIONS], pis[AZ_MAX_ACTIONS];
+  int n = 0;
+  long long ntot = 0;
+  for (int a = 0; a < Gm::A; ++a) if ((m >> a) & 1) { acts[n++] = a; ntot += Nn[a]; }
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) { pi[i] = (double)Nn[acts[i]] / (double)ntot; s += pi[i]; }
+  for (int i = 0; i < n; ++i) pi[i] = pi[i] / s;
+  const uint32_t mv = v.move_idx[slot];
+  if ((int)mv >= v.max_moves) { dev_fail(v, DERR_MOVES); return; }
+  az_move_rec* rec = v.trace + (size_t)slot * v.max_moves + mv;
+  rec->key[0] = env.a; rec->key[1] = env.b;
+  for (int a = 0; a < AZ_MAX_ACTIONS + 1; ++a) rec->N[a] = (a < Gm::A && ((m >> a) & 1)) ? Nn[a] : 0;
+  // temperature index = number of moves already played (play.jl:309)
+  const double tau = pl_schedule(p, (int)mv);
+  if (tau == 1.0) for (int i = 0; i < n; ++i) pis[i] = pi[i];
+  else if (tau == 0.0) {
+    int am = 0;
+    for (int i = 1; i < n; ++i) if (pi[i] > pi[am]) am = i;
+    for (int i = 0; i < n; ++i) pis[i] = 0.0;
+    pis[am] = 1.0;
+  } else {
+    const double inv = 1.0 / tau;
+    double t = 0.0;
+    for (int i = 0; i < n; ++i) { pis[i] = az_pow(pi[i], inv); t += pis[i]; }
+    for (int i = 0; i < n; ++i) pis[i] = pis[i] / t;
+  }
+  // fix_probvec + rand_categorical (util.jl:68-90)
+  float pf[AZ_MAX_ACTIONS];
+  float fs = 0.f;
+  for (int i = 0; i < n; ++i) { pf[i] = (float)pis[i]; fs += pf[i]; }
+  const float tol = 0.00034526698f * (__builtin_fabsf(fs) > 1.0f ? __builtin_fabsf(fs) : 1.0f);
+  if (!(__builtin_fabsf(fs - 1.0f) <= tol)) {
+    if (fs == 0.0f) for (int i = 0; i < n; ++i) pf[i] = 1.0f / (float)n;
+    else for (int i = 0; i < n; ++i) pf[i] = pf[i] / fs;
+  }
+  az_rng r = az_rng_make(p.seed, v.game_id[slot], mv, AZ_RNG_MOVE);
+  const int act = acts[az_categorical_f32(pf, n, az_rng_f32(&r))];
+  Gm::play(env, act);
+  rec->action = act;
+  rec->reward = Gm::white_reward(env);
+  v.root[slot] = env;
+  v.move_idx[slot] = mv + 1;
+  if (env.fin & 1) {
+    az_game_rec* g = v.grec + slot;
+    g->game_id = (int32_t)v.game_id[slot];
+    g->slot = slot;
+    g->num_moves = (int32_t)(mv + 1);
+    g->first_move = 0;
+    g->nodes = v.node_count[slot];                               // measured BEFORE the periodic reset
+    g->total_simulations = v.tot_sims[slot];
+    g->total_nodes_traversed = v.tot_trav[slot];
+    g->final_key[0] = env.a; g->final_key[1] = env.b;
+    v.finished[slot] = 1;
+    v.active[slot] = 0;
+    const int ws = v.worker_sim_id[slot] + 1;
+    v.worker_sim_id[slot] = ws;
+    if (p.reset_every > 0 && ws % p.reset_every == 0) {          // reset_player!, simulations.jl:235-237
+      v.epoch[slot] = epoch + 1;                                  // wrap handled by k_start_games
+      v.node_count[slot] = 0;
+    }
+  } else {
+    arm_noise<Gm>(v, p, slot, env);                               // next explore! draws its eta
+  }
+  (void)L;
+}
+
+// start games on a list of slots (GI.init(gspec), play.jl:299); MCTS.reset! when asked
+template <class Gm>
+__global__ void __launch_bounds__(256) k_start_games(DView v, DParams p, const int* slots, const uint32_t* game_ids,
+                                                     const GEnv* roots, int n, int reset_tree) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int slot = slots[i];
+  GEnv env = roots ? roots[i] : Gm::init();
+  v.root[slot] = env;
+  v.game_id[slot] = game_ids ? game_ids[i] : 0;
+  v.move_idx[slot] = 0;
+  v.active[slot] = 1;
+  v.finished[slot] = 0;
+  uint32_t ep = v.epoch[slot];
+  if (reset_tree) { ep += 1; v.node_count[slot] = 0; }
+  if (ep == 0 || ep >= 0xffff) {                                  // epoch space exhausted: really clear
+    unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
+    for (int k = 0; k < v.ht_size; ++k) tab[k] = 0;
+    ep = 1; v.node_count[slot] = 0;
+  }
+  v.epoch[slot] = ep;
+}
+// eta for explore!: given by the caller (full action index) or drawn from the RNG contract
+template <class Gm>
+__global__ void __launch_bounds__(256) k_arm_noise(DView v, DParams p, const int* slots, const uint32_t* moves,
+                                                   const double* eta_in, int n) {
+  constexpr int L = Gm::APAD;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int slot = slots[i];
+  if (moves) v.move_idx[slot] = moves[i];
+  if (eta_in) { for (int a = 0; a < L; ++a) v.eta[(size_t)slot * L + a] = a < AZ_MAX_ACTIONS ? eta_in[(size_t)i * AZ_MAX_ACTIONS + a] : 0.0; }
+  else arm_noise<Gm>(v, p, slot, v.root[slot]);
+}
+
+// gather the move records of finished games into one contiguous staging area
+__global__ void k_gather_traces(DView v, const int* slots, const int* offsets, int n, az_move_rec* out) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const int slot = slots[i];
+  const int nm = v.grec[slot].num_moves;
+  const uint4* src = (const uint4*)(v.trace + (size_t)slot * v.max_moves);
+  uint4* dst = (uint4*)(out + offsets[i]);
+  for (int k = threadIdx.x; k < nm * 4; k += blockDim.x) dst[k] = src[k];
+}
+
+// ---- game plugin kernels (GI.vectorize_state / actions_mask / play!) ------------------------
+template <class Gm>
+__global__ void k_game_encode(const unsigned long long* keys, int n, float* X, float* A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const GEnv env = Gm::from_key(keys[2 * i], keys[2 * i + 1]);
+  for (int c = 0; c < Gm::C; ++c)
+    for (int q = 0; q < Gm::P; ++q) X[(size_t)i * Gm::C * Gm::P + c * Gm::P + q] = Gm::plane(env, q, c);
+  const uint32_t m = Gm::mask(env);
+  for (int a = 0; a < Gm::A; ++a) A[(size_t)i * Gm::A + a] = (float)((m >> a) & 1);
+}
+template <class Gm>
+__global__ void k_game_play(const unsigned long long* keys, const int* actions, int n,
+                            unsigned long long* next, signed char* term, float* reward) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  GEnv env = Gm::from_key(keys[2 * i], keys[2 * i + 1]);
+  if (!(env.fin & 1) && actions[i] >= 0) Gm::play(env, actions[i]);
+  next[2 * i] = env.a; next[2 * i + 1] = env.b;
+  term[i] = (signed char)(env.fin & 1);
+  reward[i] = Gm::white_reward(env);
+}

@@ -1,0 +1,235 @@
+/*
+ * azhip.h -- C ABI of the MI355X-native self-play engine (libazhip.so).
+ *
+ * This is the drop-in boundary for ONE path of jonathan-laurent/AlphaZero.jl: the batched
+ * MCTS self-play loop plus the ResNet oracle forward.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference repository) -- see
+ * INTEGRATION.md for the Julia `ccall` glue a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns an int status: AZ_OK (0) or a negative az_status; no C++
+ *     exception crosses the boundary; az_last_error() gives a thread-local message that
+ *     stays valid until the next call on that thread;
+ *   - the caller allocates and frees every host buffer and passes capacities; the engine
+ *     owns all device memory and frees it in az_engine_destroy();
+ *   - one engine per GPU, not thread-safe, calls block until their results are ready;
+ *   - callbacks are invoked synchronously on the calling thread only.
+ *
+ * State keys.  A game state (the reference's `(board=…, curplayer=…)` named tuple) crosses
+ * the ABI as two 64-bit words `key[0], key[1]`; bit 63 of key[0] is set when BLACK is to move.
+ *   Connect-Four  key[0] bits col*7+row = WHITE stones, key[1] same for BLACK
+ *                 (col 0..6, row 0..5, row 0 = bottom; games/connect-four/game.jl:19,87-93)
+ *   Tic-tac-toe   key[0] bits pos = WHITE marks, key[1] bits pos = BLACK marks
+ *                 (pos = (y-1)*3 + x - 1; games/tictactoe/game.jl:39)
+ *   Mancala       key[0] bytes 0..5 = WHITE houses 1..6, byte 6 = WHITE store;
+ *                 key[1] the same for BLACK (games/mancala/game.jl:20-31)
+ *
+ * fp32 contract of the network (what "the same result" means, bit for bit).  Every output
+ * of a convolution or dense layer is ONE fp32 fused-multiply-add chain starting from +0:
+ *   3x3 conv (Cin even): taps t = 0..8 with (dy,dx) = (t/3-1, t%3-1); inside a tap the
+ *                        channels in the order c = j, Cin/2 + j for j = 0..Cin/2-1 (the K
+ *                        order of v_mfma_f32_32x32x2_f32: lanes 0-31 then lanes 32-63)
+ *   stem conv          : k = t*Cin + c ascending
+ *   1x1 conv           : c = j, Cin/2 + j
+ *   dense              : k = p*nf + f ascending (p = x + W*y, f = head filter)
+ * followed by y = fma(acc, scale, shift), scale = gamma / sqrtf(var + 1e-5f),
+ * shift = fma(bias - mean, scale, beta) (test-mode BatchNorm folded), `+ residual`, ReLU;
+ * dense layers add their bias after the chain.  softmax/tanh use az_expf/az_tanhf of
+ * az_numerics.h.  The reference (Flux/NNlib/cuDNN) defines no summation order; any order
+ * is within the 1e-5 tolerance BASELINE.json states, this one is also reproducible.
+ *
+ * RNG contract: include/az_numerics.h (philox4x32-10 keyed by seed, counter = game id,
+ * move index, purpose, draw index).
+ */
+#ifndef AZHIP_H
+#define AZHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_ABI_VERSION 1
+
+typedef enum {
+  AZ_OK = 0,
+  AZ_ERR_BAD_ARG = -1,   /* invalid argument / unsupported configuration */
+  AZ_ERR_CAPACITY = -2,  /* node pool, hash table, path, trace or caller buffer too small */
+  AZ_ERR_HIP = -3,       /* a HIP runtime call failed */
+  AZ_ERR_STATE = -4      /* call made in the wrong engine state */
+} az_status;
+
+typedef enum { AZ_GAME_CONNECT_FOUR = 0, AZ_GAME_TICTACTOE = 1, AZ_GAME_MANCALA = 2 } az_game_id;
+
+/* Which oracle the search consults (src/mcts.jl:6-17). */
+typedef enum {
+  AZ_ORACLE_UNIFORM = 0, /* MCTS.RandomOracle (src/mcts.jl:62-72): uniform prior, V = 0 */
+  AZ_ORACLE_HASH = 1,    /* synthetic, exact: priors/value derived from the state key (tests) */
+  AZ_ORACLE_RESNET = 2   /* the two-headed ResNet (src/networks/architectures/resnet.jl) */
+} az_oracle_kind;
+
+#define AZ_MAX_ACTIONS 9
+#define AZ_SCHED_MAX 8
+
+/* MctsParams (src/params.jl:49-57) + SimParams (src/params.jl:92-101) + ResNetHP
+ * (src/networks/architectures/resnet.jl:30-37).  Fill with az_engine_cfg_init() first. */
+typedef struct {
+  int32_t struct_size;        /* sizeof(az_engine_cfg), set by az_engine_cfg_init */
+  int32_t device;             /* HIP device ordinal */
+  int32_t game;               /* az_game_id */
+  int32_t oracle;             /* az_oracle_kind */
+  /* MctsParams */
+  double gamma;               /* reward discount */
+  double cpuct;
+  double dirichlet_noise_eps;
+  double dirichlet_noise_alpha;
+  double prior_temperature;
+  int32_t num_iters_per_turn;
+  int32_t temperature_len;    /* PLSchedule breakpoints; 1 == ConstSchedule */
+  int32_t temperature_xs[AZ_SCHED_MAX];
+  double temperature_ys[AZ_SCHED_MAX];
+  /* SimParams */
+  int32_t num_workers;        /* number of device game slots searched in lock-step */
+  int32_t batch_size;         /* must be <= num_workers (src/params.jl:361-384); the device path
+                                 evaluates every pending leaf of a wave in one pass */
+  int32_t reset_every;        /* reset a slot's tree every n games; 0 = never (`nothing`) */
+  int32_t fill_batches;       /* accepted, no effect: test-mode BN is per sample (Appendix A.13) */
+  double flip_probability;    /* must be 0 on the device path (self-play configs use 0) */
+  uint64_t seed;
+  /* capacities; 0 = derive from the game and num_iters_per_turn */
+  int32_t max_nodes_per_slot;
+  int32_t max_moves_per_game;
+  /* ResNetHP (kernel 3x3) */
+  int32_t num_blocks;
+  int32_t num_filters;
+  int32_t num_policy_head_filters;
+  int32_t num_value_head_filters;
+} az_engine_cfg;
+
+typedef struct az_engine az_engine;
+
+const char* az_last_error(void);
+int az_abi_version(void);
+
+/* Defaults = games/connect-four/params.jl:5-30 with the 64-filter trunk. */
+int az_engine_cfg_init(az_engine_cfg* cfg);
+int az_engine_create(const az_engine_cfg* cfg, az_engine** out);
+int az_engine_destroy(az_engine* e);
+
+/* ---- game plugin, device twins (GameInterface, src/game.jl:34-336) -------------------- */
+int az_game_num_actions(int game, int32_t* num_actions);
+int az_game_state_dim(int game, int32_t* w, int32_t* h, int32_t* c); /* GI.state_dim */
+int az_game_init_key(int game, uint64_t key[2]);                   /* current_state(init(gspec)) */
+/* GI.vectorize_state + GI.actions_mask(GI.init(gspec, s)) for n states, computed on the GPU.
+ * X: n*C*H*W floats (per state the Julia W x H x C array in memory order), A: n*num_actions. */
+int az_game_encode(az_engine* e, const uint64_t* keys, int32_t n, float* X, float* A);
+/* GI.init(gspec, s); GI.play!(g, a): next state, game_terminated, white_reward, on the GPU.
+ * actions are 0-based; action -1 = no move (status of GI.init(gspec, s) only).  States that are
+ * already terminal are returned unchanged. */
+int az_game_play(az_engine* e, const uint64_t* keys, const int32_t* actions, int32_t n,
+                 uint64_t* next_keys, int8_t* terminated, float* white_reward);
+
+/* ---- network plugin (Network interface, src/networks/network.jl:30-206) ---------------- */
+/* Number of fp32 values in the parameter blob.  Layout, Flux array memory order:
+ *   stem   conv W(3,3,C,F) b(F)  bn gamma,beta,mean,var (F each)
+ *   block  x num_blocks: conv1 W(3,3,F,F) b bn(4F)  conv2 W(3,3,F,F) b bn(4F)
+ *   phead  conv W(1,1,F,npf) b bn(4npf)  dense W(A, P*npf) b(A)
+ *   vhead  conv W(1,1,F,nvf) b bn(4nvf)  dense W(F, P*nvf) b(F)  dense W(1,F) b(1)   */
+int az_net_num_params(const az_engine* e, int64_t* n);
+int az_net_set_params(az_engine* e, const float* blob, int64_t n); /* Network.copy(nn; on_gpu=true, test_mode=true) */
+int az_net_get_params(const az_engine* e, float* blob, int64_t n);
+/* Network.forward_normalized (network.jl:264-271) on host arrays: X W*H*C*N, A nA*N ->
+ * P nA*N, V N, Pinv N. */
+int az_net_forward(az_engine* e, const float* X, const float* A, int32_t N, float* P, float* V, float* Pinv);
+/* Network.evaluate_batch (network.jl:308-315) from state keys: encode + forward on the GPU.
+ * P is full width (0 on unavailable actions). */
+int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t N, float* P, float* V);
+
+/* ---- MCTS hooks (src/mcts.jl:239-281; parity + explorer UI, src/ui/explorer.jl:70-86) -- */
+int az_mcts_reset(az_engine* e);  /* MCTS.reset! on every slot (counters kept) */
+/* MCTS.explore!(env, GI.init(gspec, root), nsims) on slots 0..nslots-1, one root per slot.
+ * eta: nslots*AZ_MAX_ACTIONS Dirichlet noise by FULL action index, or NULL to draw it from the
+ * RNG contract with (seed, game_ids[i], moves[i]). */
+int az_mcts_explore(az_engine* e, const uint64_t* root_keys, int32_t nslots, int32_t nsims,
+                    const double* eta, const uint32_t* game_ids, const uint32_t* moves);
+/* tree[state] of one slot: per FULL action index (unavailable: N = 0, P = 0); returns
+ * AZ_ERR_BAD_ARG if the state is not in the tree. mask = availability bitmask. */
+int az_mcts_node_stats(az_engine* e, int32_t slot, const uint64_t key[2], int32_t* N, double* W,
+                       float* P, float* Vest, uint32_t* mask);
+int az_mcts_counters(az_engine* e, int32_t slot, int64_t* total_simulations,
+                     int64_t* total_nodes_traversed, int64_t* num_nodes);
+
+/* ---- self-play (simulate, src/simulations.jl:207-244; play_game, src/play.jl:298-315) --- */
+/* One record per move: state BEFORE the move, visit counts by full action index (policy =
+ * N / sum N, src/mcts.jl:255-271), the action played (0-based), white reward after it. */
+typedef struct {
+  uint64_t key[2];
+  int32_t N[AZ_MAX_ACTIONS + 1];
+  int32_t action;
+  float reward;
+} az_move_rec;
+/* One record per game (Trace + self_play_measurements, src/training.jl:269-273). */
+typedef struct {
+  int32_t game_id;
+  int32_t slot;
+  int32_t num_moves;
+  int32_t first_move;               /* index of the game's first az_move_rec */
+  int64_t nodes;                    /* length(env.tree) at the end of the game */
+  int64_t total_simulations;        /* cumulative per slot (src/mcts.jl:136-137) */
+  int64_t total_nodes_traversed;
+  uint64_t final_key[2];
+} az_game_rec;
+typedef struct {
+  az_game_rec* games; int64_t games_cap; int64_t num_games;
+  az_move_rec* moves; int64_t moves_cap; int64_t num_moves;
+} az_trace_buf;
+typedef struct {
+  int64_t simulations;              /* MCTS simulations run (src/mcts.jl:242) */
+  int64_t nodes_traversed;          /* src/mcts.jl:222 */
+  int64_t leaf_evals;               /* oracle calls */
+  int64_t moves;                    /* samples */
+  int64_t games;
+  int64_t waves;
+  double seconds;
+} az_selfplay_stats;
+typedef void (*az_progress_cb)(void* user);   /* game_simulated(), once per finished game */
+
+/* simulate(simulator, gspec, SimParams(num_games=…)): plays num_games games with global ids
+ * first_game_id .. first_game_id+num_games-1 (so a sharded run is independent of the shard
+ * count) and writes the traces sorted by game id. */
+int az_selfplay_run(az_engine* e, int32_t num_games, int32_t first_game_id, az_trace_buf* out,
+                    az_progress_cb cb, void* user, az_selfplay_stats* stats);
+/* Stepping form of the same loop (bench, polling): begin, step `nwaves` search waves (one
+ * simulation per active slot per wave; the move step runs after every num_iters_per_turn
+ * waves), collect finished games, end.  num_games < 0 = refill slots forever. */
+int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_game_id);
+int az_selfplay_step(az_engine* e, int32_t nwaves);
+int az_selfplay_collect(az_engine* e, az_trace_buf* out);   /* finished, not yet collected */
+int az_selfplay_get_stats(az_engine* e, az_selfplay_stats* stats);
+int az_selfplay_active(az_engine* e, int32_t* active_slots);
+int az_selfplay_end(az_engine* e);
+
+/* push_trace! (src/memory.jl:74-87): z (discounted, side relative) and t per move record. */
+int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, double* z, double* t);
+
+/* ---- profiling (bench.py roofline): HIP-event time per kernel class ---------------------- */
+#define AZ_PROF_NUM 8
+typedef enum {
+  AZ_K_SELECT = 0, AZ_K_COMPACT = 1, AZ_K_TOWER = 2, AZ_K_HEADS = 3,
+  AZ_K_EXPAND = 4, AZ_K_MOVE = 5, AZ_K_SYNTH = 6, AZ_K_START = 7
+} az_kernel_class;
+typedef struct {
+  int64_t launches[AZ_PROF_NUM];
+  double ms[AZ_PROF_NUM];
+  int64_t units[AZ_PROF_NUM];       /* boards (tower/heads) or slots processed */
+} az_prof;
+int az_prof_enable(az_engine* e, int32_t on);   /* wraps every launch in a HIP event pair */
+int az_prof_get(az_engine* e, az_prof* out);    /* synchronises, accumulates, returns totals */
+int az_prof_reset(az_engine* e);
+int az_device_info(az_engine* e, char* name, int32_t name_cap, int32_t* num_cu, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZHIP_H */

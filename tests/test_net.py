@@ -1,0 +1,122 @@
+"""Network parity.  Three legs:
+  * the oracle's fp32 forward vs an independent PyTorch fp64 restatement of the Flux model
+    (src/networks/architectures/resnet.jl:53-92, network.jl:264-271), tolerance 1e-5  [CPU]
+  * the HIP tower/heads kernels vs the oracle: bit-exact fp32 (the fp32 contract of include/azhip.h),
+    and within 1e-5 of the fp64 restatement  [GPU]
+"""
+import numpy as np
+import pytest
+import torch
+
+import azref as R
+from azhip.network import ResNetHP, num_parameters, random_params, split_params
+
+TOL = 1e-5   # BASELINE.json: "within 1e-5 on fp32 policy/value outputs"
+
+
+def torch_forward_normalized(game, hp, blob, X, A):
+    """Independent fp64 restatement with torch ops (conv2d = cross-correlation, so kernels are flipped)."""
+    p = {k: torch.tensor(np.ascontiguousarray(v), dtype=torch.float64) for k, v in split_params(game, hp, blob).items()}
+    x = torch.tensor(X, dtype=torch.float64)
+
+    def conv(x, W, b, pad):
+        w = W.flip(0, 1).permute(3, 2, 1, 0).contiguous()      # (co, ci, ky, kx), true convolution
+        return torch.nn.functional.conv2d(x, w, b, padding=pad)
+
+    def bn(x, pre):
+        g, be, mu, var = p[pre + ".gamma"], p[pre + ".beta"], p[pre + ".mean"], p[pre + ".var"]
+        s = (1, -1, 1, 1)
+        return g.view(s) * (x - mu.view(s)) / torch.sqrt(var.view(s) + 1e-5) + be.view(s)
+
+    x = torch.relu(bn(conv(x, p["stem.conv.W"], p["stem.conv.b"], 1), "stem.bn"))
+    for b in range(hp.num_blocks):
+        y = torch.relu(bn(conv(x, p["block%d.conv1.W" % b], p["block%d.conv1.b" % b], 1), "block%d.bn1" % b))
+        y = bn(conv(y, p["block%d.conv2.W" % b], p["block%d.conv2.b" % b], 1), "block%d.bn2" % b)
+        x = torch.relu(y + x)
+    N = x.shape[0]
+    hp_ = torch.relu(bn(conv(x, p["phead.conv.W"], p["phead.conv.b"], 0), "phead.bn")).reshape(N, -1)
+    logits = hp_ @ p["phead.dense.W"].T + p["phead.dense.b"]
+    pol = torch.softmax(logits, dim=1)
+    hv = torch.relu(bn(conv(x, p["vhead.conv.W"], p["vhead.conv.b"], 0), "vhead.bn")).reshape(N, -1)
+    v1 = torch.relu(hv @ p["vhead.dense1.W"].T + p["vhead.dense1.b"])
+    val = torch.tanh(v1 @ p["vhead.dense2.W"].T + p["vhead.dense2.b"]).reshape(N)
+    A = torch.tensor(A, dtype=torch.float64)
+    pm = pol * A
+    sp = pm.sum(dim=1, keepdim=True)
+    eps32 = float(np.finfo(np.float32).eps)
+    return (pm / (sp + eps32)).numpy(), val.numpy(), (1 - sp).reshape(N).numpy()
+
+
+def random_positions(game, n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        g = R.Game(game)
+        for _ in range(int(rng.integers(0, 30))):
+            if g.terminated():
+                break
+            g.play(int(rng.choice(g.available_actions())))
+        if not g.terminated():
+            out.append(g)
+    return out
+
+
+def batch_of(game, envs):
+    w, h, c = R.DIMS[game]
+    X = np.stack([g.vectorize().reshape(c, h, w) for g in envs])
+    A = np.stack([g.actions_mask().astype(np.float32) for g in envs])
+    return X, A
+
+
+@pytest.mark.parametrize("game,hp", [
+    (R.C4, ResNetHP(num_blocks=2, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)),
+    (R.TTT, ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)),
+    (R.MANCALA, ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)),
+    (R.C4, ResNetHP(num_blocks=1, num_filters=16, num_policy_head_filters=2, num_value_head_filters=1)),
+])
+def test_oracle_forward_vs_torch_fp64(game, hp):
+    blob = random_params(game, hp, seed=5)
+    assert blob.size == num_parameters(game, hp) == R.net_num_params(game, hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters)
+    X, A = batch_of(game, random_positions(game, 6, 1))
+    P, V, Pinv = R.net_forward_normalized(game, (hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters), blob, X, A)
+    Pt, Vt, Pit = torch_forward_normalized(game, hp, blob, X, A)
+    assert np.abs(P - Pt).max() < TOL and np.abs(V - Vt).max() < TOL and np.abs(Pinv - Pit).max() < TOL
+    assert np.all(P[A == 0] == 0) and np.allclose(P.sum(1), 1, atol=1e-5)
+
+
+def test_param_count_matches_reference_doc():
+    """5x64 with 32/32 heads = 472 328 trainable parameters, 5x128 = 1 672 328 ("about 1.6M",
+    docs/src/tutorial/connect_four.md:60-61)."""
+    from azhip.game import ConnectFourSpec
+    from azhip.network import ResNet
+    for F, n in ((64, 472328), (128, 1672328)):
+        nn = ResNet(ConnectFourSpec(), ResNetHP(num_blocks=5, num_filters=F, num_policy_head_filters=32, num_value_head_filters=32))
+        assert nn.num_parameters() == n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,nblocks,n", [(R.C4, 5, 64), (R.C4, 1, 7), (R.TTT, 2, 33), (R.MANCALA, 2, 20)])
+def test_hip_forward_bit_exact_vs_oracle(game, nblocks, n):
+    import azhip
+    hp = ResNetHP(num_blocks=nblocks, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    blob = random_params(game, hp, seed=2026)
+    envs = random_positions(game, n, 3)
+    X, A = batch_of(game, envs)
+    with azhip.Engine(game=game, oracle=azhip.ORACLE_RESNET, num_workers=8, batch_size=8, num_iters_per_turn=8,
+                      num_blocks=nblocks, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32) as e:
+        e.net_set_params(blob)
+        assert np.array_equal(e.net_get_params(), blob)
+        P, V, Pinv = e.net_forward(X, A)
+        keys = np.array([g.key() for g in envs], dtype=np.uint64)
+        Pk, Vk = e.net_evaluate_keys(keys)
+        Xd, Ad = e.encode(keys)
+    assert np.array_equal(Xd, X) and np.array_equal(Ad, A)          # vectorize_state / actions_mask twins
+    Pr, Vr, Pir = R.net_forward_normalized(game, (nblocks, 64, 32, 32), blob, X, A)
+    Pt, Vt, Pit = torch_forward_normalized(game, hp, blob, X, A)
+    # tolerance leg (BASELINE.json): 1e-5 vs the fp64 restatement
+    assert np.abs(P - Pt).max() < TOL and np.abs(V - Vt).max() < TOL and np.abs(Pinv - Pit).max() < TOL
+    # contract leg: bit-exact vs the oracle's fp32 chain
+    assert np.array_equal(P, Pr), np.abs(P - Pr).max()
+    assert np.array_equal(V, Vr), np.abs(V - Vr).max()
+    assert np.array_equal(Pinv, Pir)
+    assert np.array_equal(Pk, P) and np.array_equal(Vk, V)           # fused encode path == planes path
