@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py -- self-play MCTS simulations/sec on MI355X (BASELINE.json metric).
+
+A *step* is one search wave of the hot path over one batch of game slots: select -> gather misses
+-> ResNet tower + heads -> expand + backup for every one of the G = 4096 Connect-Four slots (one
+run_simulation! each, src/mcts.jl:199-226), plus the move step of play_game (src/play.jl:308-313) after
+every 400th wave and slot refill when games end.  Workload = BASELINE.json configs[1]:
+Connect-Four, 400 sims/move, 4096 parallel games, ResNet 5x64 fp32, synthetic weights.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): games shard embarrassingly -- every rank
+runs its own 4096 slots with global game ids offset by rank, no collective in the timed region
+(weak scaling); value = simulations of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "alphazero.jl_amd"))
+
+import numpy as np  # noqa: E402
+
+# algorithmic work per evaluated leaf, ResNet 5x64 heads 32/32 on 7x6x3 planes
+TOWER_FLOP = 2 * 42 * 64 * (27 + 10 * 576 + 64)     # stem + 10 tower convs + both 1x1 head convs
+HEADS_FLOP = 2 * (1344 * 7 + 1344 * 64 + 64)
+assert TOWER_FLOP + HEADS_FLOP == 31645952
+PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(blob, hp, nsims, roots=16, threads=None):
+    """The oracle (a port, not the reference: Julia is absent) on the host cores: `roots` independent
+    Connect-Four searches of `nsims` simulations each (one move of `roots` games) with the fp32 ResNet."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import azref as R
+    threads = threads or min(os.cpu_count() or 1, roots)
+    done = [0] * threads
+
+    def work(t):
+        for r in range(t, roots, threads):
+            m = R.Mcts(R.C4, oracle=R.ORACLE_NET, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0,
+                       net=(hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters, blob))
+            m.explore(R.Game(R.C4), nsims, seed=1, game_id=r, move=0)
+            done[t] += m.total_simulations
+    R.lib()
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    return {"value": sum(done) / dt, "unit": "sims/s", "cores": threads, "kind": "port",
+            "sample": "%d Connect-Four roots x %d sims (one move of %d games), ResNet 5x64 fp32, %d threads, %.1f s"
+                      % (roots, nsims, roots, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--slots", type=int, default=4096)
+    ap.add_argument("--sims", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not wrap launches in HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import azhip
+    from azhip.network import ResNetHP, random_params
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libazhip.so has no CPU fallback)")
+
+    hp = ResNetHP(num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    blob = random_params(azhip.GAME_CONNECT_FOUR, hp, seed=2026)
+    # games/connect-four/params.jl:24-30 with 400 sims (BASELINE.json configs[1])
+    eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=local_rank,
+                       num_workers=args.slots, batch_size=args.slots, num_iters_per_turn=args.sims,
+                       gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
+                       prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
+                       num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    eng.net_set_params(blob)
+    dev_name, ncu, hbm = eng.device_info()
+    eng.selfplay_begin(-1, first_game_id=rank * (1 << 24))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    eng.selfplay_step(args.warmup)
+    s0 = eng.selfplay_stats()
+    if not args.no_prof:
+        eng.prof_reset()
+        eng.prof_enable(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.selfplay_step(args.steps)
+    s1 = eng.selfplay_stats()          # synchronises the engine's stream
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    prof = eng.prof_get() if not args.no_prof else None
+    eng.prof_enable(False)
+
+    elapsed = t1 - t0
+    sims = s1.simulations - s0.simulations
+    evals = s1.leaf_evals - s0.leaf_evals
+    trav = s1.nodes_traversed - s0.nodes_traversed
+    moves = s1.moves - s0.moves
+    local_evals = evals
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([sims, evals, trav, moves], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        sims, evals, trav, moves = [float(x) for x in c.tolist()]
+    eng.selfplay_end()
+
+    if rank == 0:
+        out = {
+            "metric": "self-play MCTS sims/sec (Connect-Four, 4096 parallel games per GPU)",
+            "value": sims / elapsed, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Connect-Four self-play, %d sims/move, %d parallel games per GPU, ResNet 5x64 fp32 "
+                                   "(heads 32/32), cpuct 2, eps 0.25, alpha 1, PLSchedule([0,20,30],[1,1,.3]), reset_every 1; "
+                                   "step = one search wave (1 simulation per slot)" % (args.sims, args.slots),
+                       "slots_per_gpu": args.slots, "sims_per_move": args.sims, "parallelism": "dp%d (games sharded, no collective in the timed region)" % world,
+                       "device": dev_name, "compute_units": ncu},
+            "sims_per_sec_per_gpu": sims / elapsed / world,
+            "samples_per_sec": moves / elapsed,
+            "avg_exploration_depth": trav / max(sims, 1),
+            "leaf_evals_per_sim": evals / max(sims, 1),
+        }
+        if prof is not None:
+            tw = prof["tower"]
+            flops = local_evals * TOWER_FLOP
+            achieved = flops / (tw["ms"] * 1e-3) / 1e12 if tw["ms"] > 0 else 0.0
+            out["roofline"] = {
+                "kernel": "k_tower<ConnectFour,64,false>", "bound": "mfma", "achieved": achieved,
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": None,
+                "flop_per_board": TOWER_FLOP, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
+                "avg_boards_per_launch": local_evals / max(tw["launches"], 1),
+                "launches": tw["launches"],
+            }
+            out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(blob, hp, args.sims)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@
  * Randomness and transcendental functions follow include/az_numerics.h (the RNG
  * contract of SURVEY.md §8c) because Julia's streams cannot be reproduced.
  *
- * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -mavx2 -mfma).
+ * Build: see oracle/Makefile  (gcc -O3 -ffp-contract=off -mavx2 -mfma).
  */
 #include <math.h>
 #include <stdint.h>
@@ -403,6 +403,7 @@ typedef struct {
   int W, H, C, A;            /* board dims, planes, actions */
   int nblocks, F, npf, nvf;
   const float* blob;
+  float* pk;                 /* net_pack(blob), built lazily */
 } azr_net;
 
 static size_t net_nparams(const azr_net* n) {
@@ -414,7 +415,7 @@ static size_t net_nparams(const azr_net* n) {
   return s;
 }
 size_t azr_net_num_params(int W, int H, int C, int A, int nblocks, int F, int npf, int nvf) {
-  azr_net n = {W, H, C, A, nblocks, F, npf, nvf, 0};
+  azr_net n = {W, H, C, A, nblocks, F, npf, nvf, 0, 0};
   return net_nparams(&n);
 }
 
@@ -426,9 +427,20 @@ static void bn_fold(const float* bias, const float* bn, int n, float* scale, flo
   }
 }
 
-/* in: [P][Cin] (position-major, channel fastest); out: [P][Cout].  Flux weight
- * W[i + kw*(j + kh*(ci + Cin*co))]; tap (dx,dy) uses i = 1-dx, j = 1-dy (flip). */
-static void conv_bn(const azr_net* n, const float* in, int Cin, int Cout, int ksz, const float* Wt,
+/* Flux conv weight W[i + k*(j + k*(ci + Cin*co))] -> [tap][ci][co] (co fastest) so the inner loop runs
+ * over output channels; tap t = (dy+1)*3 + (dx+1) reads W[i = 1-dx, j = 1-dy] (true convolution). */
+static void pack_conv_w(const float* Wt, int ksz, int Cin, int Cout, float* dst) {
+  int ntap = ksz * ksz;
+  for (int t = 0; t < ntap; ++t) {
+    int dy = ksz == 3 ? t / 3 - 1 : 0, dx = ksz == 3 ? t % 3 - 1 : 0;
+    int wi = ksz == 3 ? 1 - dx : 0, wj = ksz == 3 ? 1 - dy : 0;
+    for (int ci = 0; ci < Cin; ++ci) for (int co = 0; co < Cout; ++co)
+      dst[((size_t)t * Cin + ci) * Cout + co] = Wt[(size_t)wi + (size_t)ksz * (wj + (size_t)ksz * (ci + (size_t)Cin * co))];
+  }
+}
+
+/* in: [P][Cin] (position-major, channel fastest); out: [P][Cout]; Wp packed by pack_conv_w. */
+static void conv_bn(const azr_net* n, const float* in, int Cin, int Cout, int ksz, const float* Wp,
                     const float* bias, const float* bn, const float* res, int relu, int paired, float* out) {
   int W = n->W, H = n->H;
   float* scale = malloc(sizeof(float) * 2 * (size_t)Cout);
@@ -443,13 +455,11 @@ static void conv_bn(const azr_net* n, const float* in, int Cin, int Cout, int ks
       int dy = ksz == 3 ? t / 3 - 1 : 0, dx = ksz == 3 ? t % 3 - 1 : 0;
       int yy = y + dy, xx = x + dx;
       int inside = (yy >= 0 && yy < H && xx >= 0 && xx < W);
-      int wi = ksz == 3 ? 1 - dx : 0, wj = ksz == 3 ? 1 - dy : 0;
       for (int kk = 0; kk < Cin; ++kk) {
         int ci = paired ? ((kk & 1) ? half + (kk >> 1) : (kk >> 1)) : kk;
         float v = inside ? in[(size_t)(xx + W * yy) * Cin + ci] : 0.0f;
-        const float* wrow = Wt + (size_t)wi + (size_t)ksz * (wj + (size_t)ksz * ci);
-        size_t costride = (size_t)ksz * ksz * Cin;
-        for (int co = 0; co < Cout; ++co) o[co] = az_fmaf(v, wrow[costride * co], o[co]);
+        const float* wrow = Wp + ((size_t)t * Cin + ci) * Cout;
+        for (int co = 0; co < Cout; ++co) o[co] = az_fmaf(v, wrow[co], o[co]);
       }
     }
     for (int co = 0; co < Cout; ++co) {
@@ -462,11 +472,27 @@ static void conv_bn(const azr_net* n, const float* in, int Cin, int Cout, int ks
   free(scale);
 }
 
+/* copy of the blob with every conv kernel re-ordered by pack_conv_w and the value head's first dense
+ * matrix transposed to [k][o]; everything else unchanged (same offsets). */
+static float* net_pack(const azr_net* n) {
+  size_t np = net_nparams(n);
+  float* pk = malloc(sizeof(float) * np);
+  memcpy(pk, n->blob, sizeof(float) * np);
+  int P = n->W * n->H, F = n->F, C = n->C;
+  size_t off = 0;
+  pack_conv_w(n->blob + off, 3, C, F, pk + off); off += 9 * (size_t)C * F + 5 * (size_t)F;
+  for (int l = 0; l < 2 * n->nblocks; ++l) { pack_conv_w(n->blob + off, 3, F, F, pk + off); off += 9 * (size_t)F * F + 5 * (size_t)F; }
+  pack_conv_w(n->blob + off, 1, F, n->npf, pk + off); off += (size_t)F * n->npf + 5 * (size_t)n->npf;
+  off += (size_t)n->A * P * n->npf + n->A;
+  pack_conv_w(n->blob + off, 1, F, n->nvf, pk + off); off += (size_t)F * n->nvf + 5 * (size_t)n->nvf;
+  return pk;
+}
+
 /* Network.forward (src/networks/flux.jl:127-132) on ONE sample given as Flux-layout planes
  * x[W][H][C] (column-major, W fastest).  Outputs the raw softmax p[A] and tanh value. */
 static void net_forward_one(const azr_net* n, const float* xin, float* p, float* v) {
   int P = n->W * n->H, F = n->F, C = n->C, A = n->A;
-  const float* w = n->blob;
+  const float* w = n->pk;
   float* x0 = malloc(sizeof(float) * (size_t)P * (C + 3 * F + n->npf + n->nvf + F));
   float* a = x0 + (size_t)P * C;
   float* t = a + (size_t)P * F;
@@ -512,11 +538,14 @@ static void net_forward_one(const azr_net* n, const float* xin, float* p, float*
   w += (size_t)F * n->nvf + 5 * (size_t)n->nvf;
   {
     int K = P * n->nvf;
+    for (int o = 0; o < F; ++o) vh[o] = 0.0f;
+    for (int pz = 0; pz < P; ++pz) for (int f = 0; f < n->nvf; ++f) {
+      float hvv = hv[(size_t)pz * n->nvf + f];
+      const float* wr = w + (size_t)F * (pz + (size_t)P * f);
+      for (int o = 0; o < F; ++o) vh[o] = az_fmaf(hvv, wr[o], vh[o]);
+    }
     for (int o = 0; o < F; ++o) {
-      float acc = 0.0f;
-      for (int pz = 0; pz < P; ++pz) for (int f = 0; f < n->nvf; ++f)
-        acc = az_fmaf(hv[(size_t)pz * n->nvf + f], w[o + (size_t)F * (pz + (size_t)P * f)], acc);
-      acc = acc + w[(size_t)F * K + o];
+      float acc = vh[o] + w[(size_t)F * K + o];
       vh[o] = acc > 0.0f ? acc : 0.0f;
     }
     w += (size_t)F * K + F;
@@ -540,10 +569,12 @@ static void forward_normalized_one(const azr_net* n, const float* x, const float
 void azr_net_forward_normalized(int W, int H, int C, int A, int nblocks, int F, int npf, int nvf,
                                 const float* blob, const float* X, const float* Amask, int N,
                                 float* P, float* V, float* Pinv) {
-  azr_net n = {W, H, C, A, nblocks, F, npf, nvf, blob};
+  azr_net n = {W, H, C, A, nblocks, F, npf, nvf, blob, 0};
+  n.pk = net_pack(&n);
   size_t xs = (size_t)W * H * C;
   for (int i = 0; i < N; ++i)
     forward_normalized_one(&n, X + xs * i, Amask + (size_t)A * i, P + (size_t)A * i, V + i, Pinv + i);
+  free(n.pk);
 }
 
 /* ================================= MCTS ================================= */
@@ -613,12 +644,14 @@ azr_mcts* azr_mcts_new(int game, int oracle_kind, double gamma, double cpuct, do
 }
 void azr_mcts_set_net(azr_mcts* e, int nblocks, int F, int npf, int nvf, const float* blob) {
   int W, H, C; azr_state_dims(e->game, &W, &H, &C);
-  azr_net n = {W, H, C, azr_num_actions_(e->game), nblocks, F, npf, nvf, blob};
+  azr_net n = {W, H, C, azr_num_actions_(e->game), nblocks, F, npf, nvf, blob, 0};
+  free(e->net.pk);
+  n.pk = net_pack(&n);
   e->net = n;
 }
 /* MCTS.reset! (src/mcts.jl:278-281): empties the tree, keeps the counters */
 void azr_mcts_reset(azr_mcts* e) { if (e->tab) memset(e->tab, 0, e->cap * sizeof(azr_node)); e->count = 0; }
-void azr_mcts_free(azr_mcts* e) { free(e->tab); free(e); }
+void azr_mcts_free(azr_mcts* e) { free(e->tab); free(e->net.pk); free(e); }
 int64_t azr_mcts_num_nodes(const azr_mcts* e) { return (int64_t)e->count; }
 int64_t azr_mcts_total_simulations(const azr_mcts* e) { return e->total_simulations; }
 int64_t azr_mcts_total_nodes_traversed(const azr_mcts* e) { return e->total_nodes_traversed; }
