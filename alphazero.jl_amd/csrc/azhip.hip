@@ -470,6 +470,26 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   for (int q = 0; q < P; ++q) for (int f = 0; f < nvf; ++f) for (int o = 0; o < F; ++o)
     val_w[(size_t)(q * nvf + f) * F + o] = vdw[o + (size_t)F * (q + (size_t)P * f)];
   for (int o = 0; o < F; ++o) { val_b[o] = vdb[o]; val2_w[o] = v2w[o]; }
+  // MFMA dense-head fragments: per MFMA pair i (k = 4i..4i+3) and lane: (W[4i+h][o], W[4i+2+h][o])
+  const bool hd_ok = (npf % 4 == 0) && (nvf % 4 == 0);
+  const int NVT = F / 32;
+  std::vector<float> hd_w(4);
+  if (hd_ok) {
+    const size_t vsteps = (size_t)P * nvf / 4, psteps = (size_t)P * npf / 4;
+    hd_w.assign((NVT * vsteps + psteps) * 64 * 2, 0.0f);
+    for (int t = 0; t < NVT; ++t) for (size_t i = 0; i < vsteps; ++i) for (int l = 0; l < 64; ++l) {
+      int hh = l >> 5, o = t * 32 + (l & 31);
+      float* d = &hd_w[((t * vsteps + i) * 64 + l) * 2];
+      d[0] = val_w[(4 * i + hh) * F + o];
+      d[1] = val_w[(4 * i + 2 + hh) * F + o];
+    }
+    for (size_t i = 0; i < psteps; ++i) for (int l = 0; l < 64; ++l) {
+      int hh = l >> 5, o = l & 31;
+      float* d = &hd_w[((NVT * vsteps + i) * 64 + l) * 2];
+      d[0] = o < A ? pol_w[(4 * i + hh) * L + o] : 0.0f;
+      d[1] = o < A ? pol_w[(4 * i + 2 + hh) * L + o] : 0.0f;
+    }
+  }
   auto up = [&](const std::vector<float>& h, const float** d) -> int {
     float* q = nullptr;
     AZCHK(dalloc(e, &q, h.size(), false));
@@ -488,6 +508,8 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   AZCHK(up(head_ss, &nd.head_ss));
   AZCHK(up(pol_w, &nd.pol_w)); AZCHK(up(pol_b, &nd.pol_b)); AZCHK(up(val_w, &nd.val_w)); AZCHK(up(val_b, &nd.val_b)); AZCHK(up(val2_w, &nd.val2_w));
   nd.val2_b = *v2b;
+  AZCHK(up(hd_w, &tmp)); nd.hd_w = (const float2*)tmp;
+  nd.hd_ok = hd_ok ? 1 : 0;
   HIPCHK(hipStreamSynchronize(e->stream));
   e->net = nd;
   e->net_loaded = true;
@@ -509,7 +531,10 @@ static int launch_net(az_engine* e, const GEnv* envs, const int* eslots, const i
   const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
   if (gt == 0) return AZ_OK;
   LAUNCH(e, AZ_K_TOWER, n_max, (k_tower<Gm, 64, FROM_PLANES>), gt, 256, TowerLds<64>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, e->d_hfeat);
-  LAUNCH(e, AZ_K_HEADS, n_max, (k_heads<Gm, 64>), gh, 320, 0, e->net, envs, eslots, n_ptr, n_max, Amask, e->d_hfeat, Pout, Vout, Pinv, pstride);
+  if (e->net.hd_ok)
+    LAUNCH(e, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, 64>), (n_max + 31) / 32, 64 * 3, 0, e->net, envs, eslots, n_ptr, n_max, Amask, e->d_hfeat, Pout, Vout, Pinv, pstride);
+  else
+    LAUNCH(e, AZ_K_HEADS, n_max, (k_heads<Gm, 64>), gh, 320, 0, e->net, envs, eslots, n_ptr, n_max, Amask, e->d_hfeat, Pout, Vout, Pinv, pstride);
   return AZ_OK;
 }
 

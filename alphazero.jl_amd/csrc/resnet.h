@@ -38,6 +38,8 @@ struct NetDev {
   const float* val_b;                 // [F]
   const float* val2_w;                // [F]
   float val2_b;
+  const float2* hd_w;                 // MFMA dense heads: [F/32 value tiles + 1 policy tile][K/4][64] float2
+  int hd_ok;                          // 1 when npf % 4 == 0 && nvf % 4 == 0 (k_heads_mfma usable)
 };
 
 static constexpr int TOWER_ROWS = 128;
@@ -48,35 +50,64 @@ template <int F> struct TowerLds {
   static constexpr int BYTES = 2 * BUF * 4;
 };
 
-// one 3x3 (NTAP = 9) or 1x1 (NTAP = 1) convolution over the workgroup's 128 rows
+// one 3x3 (NTAP = 9) or 1x1 (NTAP = 1) convolution over the workgroup's 128 rows.
+// Software pipeline: the B fragments (weights) of tap t+1 are requested from L2 before the 64 MFMAs
+// of tap t are issued, so a global load has ~4000 cycles to land; the tap loop is fully unrolled so
+// both register sets are statically indexed.
+template <int F, int NT>
+__device__ __forceinline__ void load_b_tap(const float4* __restrict__ wt, float4 (&b)[NT][F / 8]) {
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int jq = 0; jq < F / 8; ++jq) b[n][jq] = wt[(size_t)(n * (F / 8) + jq) * 64];
+}
+template <int F, int NT>
+__device__ __forceinline__ void mfma_tap(const float* __restrict__ arow, const float4 (&b)[NT][F / 8], f32x16 (&acc)[NT]) {
+  float4 a[F / 8];
+#pragma unroll
+  for (int jq = 0; jq < F / 8; ++jq) a[jq] = *(const float4*)(arow + jq * 4);
+#pragma unroll
+  for (int jq = 0; jq < F / 8; ++jq) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].x, b[n][jq].x, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].y, b[n][jq].y, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].z, b[n][jq].z, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].w, b[n][jq].w, acc[n], 0, 0, 0);
+    }
+  }
+}
 template <int F, int NT, int NTAP>
 __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* __restrict__ out,
                                           const float4* __restrict__ wpk, const float* __restrict__ ss,
-                                          int out_ch, bool residual, const int* nbr, int wave, int lane) {
+                                          int out_ch, bool residual, const int (&nbr)[9], int wave, int lane) {
   constexpr int STRIDE = TowerLds<F>::STRIDE;
   constexpr int JQ = F / 8;
+  constexpr size_t TAPW = (size_t)NT * JQ * 64;
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
   const int khalf = (lane >> 5) * (F / 2);
-#pragma unroll 1
-  for (int t = 0; t < NTAP; ++t) {
-    const float* arow = in + nbr[NTAP == 1 ? 4 : t] + khalf;
-    const float4* wt = wpk + (size_t)t * NT * JQ * 64 + lane;
+  const float4* wl = wpk + lane;
+  float4 b0[NT][JQ], b1[NT][JQ];
+  load_b_tap<F, NT>(wl, b0);
+  if (NTAP == 1) {
+    mfma_tap<F, NT>(in + nbr[4] + khalf, b0, acc);
+  } else {
 #pragma unroll
-    for (int jq = 0; jq < JQ; ++jq) {
-      const float4 a4 = *(const float4*)(arow + jq * 4);
-      float4 b4[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) b4[n] = wt[(size_t)(n * JQ + jq) * 64];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[n].x, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[n].y, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[n].z, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[n].w, acc[n], 0, 0, 0);
+    for (int t = 0; t < NTAP; t += 2) {
+      // sched_barrier(0): hipcc otherwise sinks the prefetch next to its first use
+      if (t + 1 < NTAP) load_b_tap<F, NT>(wl + (size_t)(t + 1) * TAPW, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_tap<F, NT>(in + nbr[t] + khalf, b0, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < NTAP) {
+        if (t + 2 < NTAP) load_b_tap<F, NT>(wl + (size_t)(t + 2) * TAPW, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tap<F, NT>(in + nbr[t + 1] + khalf, b1, acc);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -139,10 +170,12 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
     float acc[F / 2];
 #pragma unroll
     for (int i = 0; i < F / 2; ++i) acc[i] = 0.0f;
+#pragma unroll 1
     for (int t = 0; t < 9; ++t) {
       const int dy = t / 3 - 1, dx = t % 3 - 1;
       const bool ok = (b < TB) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
       const int nrow = ok ? row + dy * W + dx : 0;
+#pragma unroll 1
       for (int c = 0; c < C; ++c) {
         const float val = ok ? planes[nrow * C + c] : 0.0f;
         const float* wk = sw + (t * C + c) * F + half * (F / 2);
@@ -255,6 +288,101 @@ k_heads(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
     acc = acc + net.val2_b;
     const float val = az_tanhf(acc);                               // Dense(F => 1, tanh), resnet.jl:90
     // forward_normalized, network.jl:264-271
+    float sp = 0.0f;
+    for (int a = 0; a < A; ++a) {
+      float mk;
+      if (Amask) mk = Amask[(size_t)e * A + a];
+      else mk = (float)((Gm::mask(leaf_env[eval_slots[e]]) >> a) & 1);
+      pr[a] = pr[a] * mk;
+      sp += pr[a];
+    }
+    for (int a = 0; a < A; ++a) Pout[(size_t)e * pstride + a] = pr[a] / (sp + 1.1920929e-7f);
+    for (int a = A; a < pstride; ++a) Pout[(size_t)e * pstride + a] = 0.0f;
+    Vout[e] = val;
+    if (Pinv) Pinv[e] = 1.0f - sp;
+  }
+}
+
+// Dense heads on MFMA.  One 32-board tile per workgroup; wavefront w < F/32 computes value-hidden
+// outputs 32w..32w+31, the last wavefront the (padded) policy logits.  The A operand is the board's
+// head-feature row (K = P*nf values, read as float4 = k 4i..4i+3), the B operand the dense matrix
+// pre-packed per MFMA as (W[4i+h][o], W[4i+2+h][o]) with h = lane >> 5: v_mfma_f32_32x32x2_f32
+// consumes k = 2j (lanes 0-31) then 2j+1 (lanes 32-63), i.e. the ascending-k chain of the contract.
+template <class Gm, int F>
+__global__ void __launch_bounds__(64 * (F / 32 + 1))
+k_heads_mfma(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+             const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ Amask,
+             const float* __restrict__ hfeat, float* __restrict__ Pout, float* __restrict__ Vout,
+             float* __restrict__ Pinv, int pstride) {
+  constexpr int P = Gm::P, A = Gm::A, NVT = F / 32;
+  __shared__ float s_vh[32][F + 1];
+  __shared__ float s_logit[32][16];
+  const int n = n_eval_ptr ? *n_eval_ptr : n_fixed;
+  const int board0 = blockIdx.x * 32;
+  if (board0 >= n) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int HF = net.HF;
+  const bool is_pol = wave == NVT;
+  const int nf = is_pol ? net.npf : net.nvf, foff = is_pol ? 0 : net.npf;
+  int e = board0 + (lane & 31);
+  if (e >= n) e = n - 1;                         // clamp: rows past the batch are computed and dropped
+  const float* hf = hfeat + (size_t)e * P * HF + foff;
+  // fragment pointer: value tiles first (each P*nvf/4 steps), then the policy tile
+  const float2* wp = net.hd_w + ((size_t)(is_pol ? NVT * (P * net.nvf / 4) : wave * (P * net.nvf / 4))) * 64 + lane;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const int q4 = nf / 4;
+  if (q4 == 8) {                                 // 32 head filters: fully unrolled position step
+#pragma unroll 2
+    for (int q = 0; q < P; ++q) {
+      const float* hq = hf + q * HF;
+      float4 a4[8];
+      float2 b2[8];
+#pragma unroll
+      for (int f4 = 0; f4 < 8; ++f4) { a4[f4] = *(const float4*)(hq + f4 * 4); b2[f4] = wp[(size_t)(q * 8 + f4) * 64]; }
+#pragma unroll
+      for (int f4 = 0; f4 < 8; ++f4) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4[f4].y : a4[f4].x, b2[f4].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4[f4].w : a4[f4].z, b2[f4].y, acc, 0, 0, 0);
+      }
+    }
+  } else {
+    for (int q = 0; q < P; ++q) {
+      const float* hq = hf + q * HF;
+      for (int f4 = 0; f4 < q4; ++f4) {
+        const float4 a4 = *(const float4*)(hq + f4 * 4);
+        const float2 b2 = wp[(size_t)(q * q4 + f4) * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4.y : a4.x, b2.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4.w : a4.z, b2.y, acc, 0, 0, 0);
+      }
+    }
+  }
+  const int col = lane & 31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (is_pol) { if (col < A) s_logit[row][col] = acc[r] + net.pol_b[col]; }
+    else {
+      const int o = wave * 32 + col;
+      const float v = acc[r] + net.val_b[o];
+      s_vh[row][o] = v > 0.0f ? v : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int b = threadIdx.x;
+  if (b < 32 && board0 + b < n) {
+    e = board0 + b;
+    float pr[A];
+    float mx = s_logit[b][0];
+    for (int a = 1; a < A; ++a) mx = s_logit[b][a] > mx ? s_logit[b][a] : mx;
+    float s = 0.0f;
+    for (int a = 0; a < A; ++a) { pr[a] = az_expf(s_logit[b][a] - mx); s += pr[a]; }
+    for (int a = 0; a < A; ++a) pr[a] = pr[a] / s;
+    float av = 0.0f;
+    for (int k = 0; k < F; ++k) av = az_fmaf(s_vh[b][k], net.val2_w[k], av);
+    av = av + net.val2_b;
+    const float val = az_tanhf(av);
     float sp = 0.0f;
     for (int a = 0; a < A; ++a) {
       float mk;
