@@ -1,0 +1,90 @@
+"""Player abstraction of the path (src/play.jl:156-214,298-315): MctsPlayer, think, play_game."""
+import numpy as np
+
+from . import mcts as MCTS
+from .params import MctsParams
+from .trace import Trace
+
+
+def apply_temperature(pi, tau):
+    """Util.apply_temperature, src/util.jl:98-110"""
+    pi = np.asarray(pi, dtype=np.float64)
+    if tau == 1:
+        return pi
+    if tau == 0:
+        res = np.zeros_like(pi)
+        res[int(np.argmax(pi))] = 1
+        return res
+    res = pi ** (1.0 / tau)
+    return res / res.sum()
+
+
+def fix_probvec(pi):
+    """Util.fix_probvec, src/util.jl:68-81"""
+    p = np.asarray(pi, dtype=np.float32)
+    s = np.float32(0)
+    for x in p:
+        s = np.float32(s + x)
+    if not (abs(float(s) - 1.0) <= 0.00034526698 * max(abs(float(s)), 1.0)):
+        p = np.full(len(p), np.float32(1) / np.float32(len(p)), dtype=np.float32) if s == 0 else (p / s).astype(np.float32)
+    return p
+
+
+def rand_categorical(pi, u):
+    """Util.rand_categorical (util.jl:87-90) with the Float32 uniform supplied"""
+    p = fix_probvec(pi)
+    cp, i = p[0], 0
+    while cp <= u and i < len(p) - 1:
+        i += 1
+        cp = np.float32(cp + p[i])
+    return i
+
+
+class MctsPlayer:
+    """MctsPlayer(gspec, oracle, params::MctsParams; timeout=nothing), play.jl:156-214"""
+
+    def __init__(self, gspec, oracle, params: MctsParams, timeout=None, seed=1):
+        if timeout is not None:
+            raise ValueError("timeout-driven search is not supported on the device path")
+        assert params.num_iters_per_turn > 0
+        self.gspec, self.oracle, self.params = gspec, oracle, params
+        self.niters, self.τ, self.seed = params.num_iters_per_turn, params.temperature, seed
+        self._mcts = None
+
+    @property
+    def mcts(self):
+        if self._mcts is None:
+            p = self.params
+            self._mcts = MCTS.Env(self.gspec, self.oracle, gamma=p.gamma, cpuct=p.cpuct, noise_ϵ=p.dirichlet_noise_ϵ,
+                                  noise_α=p.dirichlet_noise_α, prior_temperature=p.prior_temperature, seed=self.seed)
+        return self._mcts
+
+    def think(self, game):
+        self.mcts.explore(game, self.niters)
+        return self.mcts.policy(game)
+
+    def player_temperature(self, game, turn):
+        return self.τ[turn]
+
+    def reset_player(self):
+        if self._mcts is not None:
+            self._mcts.reset()
+
+
+def play_game(gspec, player, flip_probability=0.0, rng=None):
+    """play_game, play.jl:298-315 -- host-stepped (one device search per move).  Self-play at scale goes
+    through simulations.simulate instead, which runs this loop for thousands of games on the GPU."""
+    if flip_probability != 0.0:
+        raise ValueError("flip_probability > 0 is not supported")
+    rng = rng or np.random.Generator(np.random.Philox(1))
+    game = gspec.init()
+    trace = Trace(game.current_state())
+    while True:
+        if game.game_terminated():
+            return trace
+        actions, pi_target = player.think(game)
+        tau = player.player_temperature(game, len(trace))
+        pi_sample = apply_temperature(pi_target, tau)
+        a = actions[rand_categorical(pi_sample, np.float32(rng.random(dtype=np.float32)))]
+        game.play(a)
+        trace.push(pi_target, game.white_reward(), game.current_state())

@@ -1,0 +1,52 @@
+"""The N > 1 path on CPU: world_size-2 gloo group, shard -> (synthetic) local records -> gather_records.
+The records are produced by the oracle so the test also checks that the union of the shards equals the
+unsharded run (results keyed by GLOBAL game id do not depend on the number of ranks)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path[:0] = [os.path.join(ROOT, "alphazero.jl_amd"), os.path.join(ROOT, "oracle")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import azref as R
+    from azhip.simulations import GAME_DTYPE, MOVE_DTYPE, gather_records, shard_games
+    first, count = shard_games(7, world, rank)
+    # the oracle keys its RNG by game id, so a shard is simulated by running ids first..first+count-1:
+    # simulate all 7 and keep ours (the oracle has no first_game_id argument)
+    games, moves, nm = R.simulate(R.TTT, R.ORACLE_HASH, 7, 7, 20, cpuct=1.5, noise_eps=0.25, seed=3)
+    g = np.frombuffer(bytes(games), dtype=GAME_DTYPE)[first:first + count].copy()
+    m = np.concatenate([np.frombuffer(bytes(moves), dtype=MOVE_DTYPE)[r["first_move"]:r["first_move"] + r["num_moves"]] for r in g])
+    g["first_move"] = np.cumsum([0] + list(g["num_moves"][:-1]))
+    G, M = gather_records(g, m)
+    np.save(os.path.join(out_dir, "G%d.npy" % rank), G)
+    np.save(os.path.join(out_dir, "M%d.npy" % rank), M)
+    dist.destroy_process_group()
+
+
+def test_gather_records_gloo_world2(tmp_path):
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sys.path[:0] = [os.path.join(ROOT, "oracle")]
+    import azref as R
+    from azhip.simulations import GAME_DTYPE, MOVE_DTYPE
+    games, moves, nm = R.simulate(R.TTT, R.ORACLE_HASH, 7, 7, 20, cpuct=1.5, noise_eps=0.25, seed=3)
+    ref_g = np.frombuffer(bytes(games), dtype=GAME_DTYPE)[:7]
+    ref_m = np.frombuffer(bytes(moves), dtype=MOVE_DTYPE)[:nm]
+    G0, M0 = np.load(tmp_path / "G0.npy"), np.load(tmp_path / "M0.npy")
+    G1, M1 = np.load(tmp_path / "G1.npy"), np.load(tmp_path / "M1.npy")
+    assert np.array_equal(G0, G1) and np.array_equal(M0, M1)          # every rank holds the same gather
+    assert list(G0["game_id"]) == list(range(7)) and len(M0) == nm
+    for r, q in zip(G0, ref_g):
+        a = M0[r["first_move"]:r["first_move"] + r["num_moves"]]
+        b = ref_m[q["first_move"]:q["first_move"] + q["num_moves"]]
+        assert np.array_equal(a, b) and tuple(r["final_key"]) == tuple(q["final_key"])
