@@ -1,0 +1,270 @@
+# AlphaZeroHIP.jl -- the Julia side of the drop-in: `ccall` bindings to libazhip.so (include/azhip.h).
+#
+# WRITTEN BLIND: the build container has no Julia (SURVEY.md §0), so this file has never been run.
+# Every call it makes is mirrored one-to-one by the Python binding (alphazero.jl_amd/azhip/_lib.py,
+# engine.py, simulations.py), which IS exercised by tests/ on a real MI355X.  Keep the two in sync.
+#
+# What it provides (SURVEY.md §8b):
+#   seam 3  HipResNet <: AbstractNetwork      the Network plugin backed by the HIP tower/heads kernels
+#   seam 2  Network.forward_normalized / evaluate_batch on a HipResNet (stock Julia MCTS on top of it)
+#   seam 1  AlphaZero.simulate(simulator, gspec::DeviceGameSpec, p) -> whole self-play phase on the GPU
+# `Scripts.train` is unchanged: pick `HipResNet` as the experiment's network type.
+module AlphaZeroHIP
+
+using AlphaZero
+using AlphaZero: GI, Network, MctsPlayer, MctsParams, SimParams, Simulator, Trace, ConstSchedule, PLSchedule
+import AlphaZero.Examples: ConnectFour, Tictactoe, Mancala
+
+const LIB = get(ENV, "AZHIP_LIB", "libazhip.so")
+const MAX_ACTIONS = 9
+
+# ---- az_engine_cfg / az_move_rec / az_game_rec / az_trace_buf / az_selfplay_stats (isbits mirrors) ----
+struct EngineCfg
+  struct_size::Int32; device::Int32; game::Int32; oracle::Int32
+  gamma::Float64; cpuct::Float64; dirichlet_noise_eps::Float64; dirichlet_noise_alpha::Float64
+  prior_temperature::Float64
+  num_iters_per_turn::Int32; temperature_len::Int32
+  temperature_xs::NTuple{8,Int32}; temperature_ys::NTuple{8,Float64}
+  num_workers::Int32; batch_size::Int32; reset_every::Int32; fill_batches::Int32
+  flip_probability::Float64; seed::UInt64
+  max_nodes_per_slot::Int32; max_moves_per_game::Int32
+  num_blocks::Int32; num_filters::Int32; num_policy_head_filters::Int32; num_value_head_filters::Int32
+end
+struct MoveRec
+  key::NTuple{2,UInt64}; N::NTuple{10,Int32}; action::Int32; reward::Float32
+end
+struct GameRec
+  game_id::Int32; slot::Int32; num_moves::Int32; first_move::Int32
+  nodes::Int64; total_simulations::Int64; total_nodes_traversed::Int64; final_key::NTuple{2,UInt64}
+end
+mutable struct TraceBuf
+  games::Ptr{GameRec}; games_cap::Int64; num_games::Int64
+  moves::Ptr{MoveRec}; moves_cap::Int64; num_moves::Int64
+end
+mutable struct SelfplayStats
+  simulations::Int64; nodes_traversed::Int64; leaf_evals::Int64; moves::Int64; games::Int64; waves::Int64
+  seconds::Float64
+  SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0)
+end
+@assert sizeof(EngineCfg) == 216 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56
+
+last_error() = unsafe_string(ccall((:az_last_error, LIB), Cstring, ()))
+check(status::Integer) = status == 0 ? nothing : error("azhip status $status: $(last_error())")
+
+# ---- device game twins: packed 16-byte keys (include/azhip.h "State keys") -------------------------
+const DeviceGameSpec = Union{ConnectFour.GameSpec, Tictactoe.GameSpec, Mancala.GameSpec}
+game_id(::ConnectFour.GameSpec) = Int32(0)
+game_id(::Tictactoe.GameSpec) = Int32(1)
+game_id(::Mancala.GameSpec) = Int32(2)
+const BLACK_BIT = UInt64(1) << 63
+
+function encode_state(::ConnectFour.GameSpec, s)
+  a = UInt64(0); b = UInt64(0)
+  for col in 1:7, row in 1:6
+    c = s.board[col, row]
+    bit = UInt64(1) << ((col - 1) * 7 + (row - 1))
+    c == ConnectFour.WHITE && (a |= bit)
+    c == ConnectFour.BLACK && (b |= bit)
+  end
+  s.curplayer == ConnectFour.BLACK && (a |= BLACK_BIT)
+  return (a, b)
+end
+function decode_state(::ConnectFour.GameSpec, k)
+  a, b = k
+  cells = [((a >> ((col-1)*7 + row-1)) & 1 == 1) ? ConnectFour.WHITE :
+           ((b >> ((col-1)*7 + row-1)) & 1 == 1) ? ConnectFour.BLACK : ConnectFour.EMPTY
+           for col in 1:7, row in 1:6]
+  return (board=ConnectFour.Board(cells), curplayer=(a & BLACK_BIT != 0) ? ConnectFour.BLACK : ConnectFour.WHITE)
+end
+function encode_state(::Tictactoe.GameSpec, s)
+  a = UInt64(0); b = UInt64(0)
+  for pos in 1:9
+    c = s.board[pos]
+    c === true && (a |= UInt64(1) << (pos - 1))
+    c === false && (b |= UInt64(1) << (pos - 1))
+  end
+  s.curplayer == Tictactoe.BLACK && (a |= BLACK_BIT)
+  return (a, b)
+end
+function decode_state(::Tictactoe.GameSpec, k)
+  a, b = k
+  cells = Tictactoe.Cell[((a >> (p-1)) & 1 == 1) ? true : ((b >> (p-1)) & 1 == 1) ? false : nothing for p in 1:9]
+  return (board=Tictactoe.Board(cells), curplayer=(a & BLACK_BIT == 0))
+end
+function encode_state(::Mancala.GameSpec, s)
+  a = UInt64(0); b = UInt64(0)
+  for n in 1:6
+    a |= UInt64(s.board.houses[1, n]) << (8 * (n - 1))
+    b |= UInt64(s.board.houses[2, n]) << (8 * (n - 1))
+  end
+  a |= UInt64(s.board.stores[1]) << 48
+  b |= UInt64(s.board.stores[2]) << 48
+  s.curplayer == Mancala.BLACK && (a |= BLACK_BIT)
+  return (a, b)
+end
+function decode_state(::Mancala.GameSpec, k)
+  a, b = k
+  houses = [UInt8(((p == 1 ? a : b) >> (8 * (n - 1))) & 0xff) for p in 1:2, n in 1:6]
+  stores = [UInt8((a >> 48) & 0xff), UInt8((b >> 48) & 0xff)]
+  board = Mancala.Board(Mancala.SVector{2,UInt8}(stores), Mancala.SMatrix{2,6,UInt8,12}(houses))
+  return (board=board, curplayer=(a & BLACK_BIT != 0) ? Mancala.BLACK : Mancala.WHITE)
+end
+
+# ---- engine handle ------------------------------------------------------------------------------------
+mutable struct Engine
+  h::Ptr{Cvoid}
+  function Engine(cfg::EngineCfg)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:az_engine_create, LIB), Cint, (Ref{EngineCfg}, Ref{Ptr{Cvoid}}), cfg, out))
+    e = new(out[])
+    finalizer(x -> (x.h != C_NULL && ccall((:az_engine_destroy, LIB), Cint, (Ptr{Cvoid},), x.h); x.h = C_NULL), e)
+    return e
+  end
+end
+
+schedule_points(s::ConstSchedule) = (Int32[0], Float64[s.value])
+schedule_points(s::PLSchedule) = (Int32.(s.xs), Float64.(s.ys))
+pad8(v, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), 8)
+
+"MctsParams + SimParams + ResNetHP -> az_engine_cfg (SURVEY.md §8b config mapping)"
+function make_cfg(gspec, mcts::MctsParams, sim::SimParams, hp; oracle=2, seed=1, device=0)
+  xs, ys = schedule_points(mcts.temperature)
+  @assert iszero(sim.flip_probability) "flip_probability > 0 is not supported on the device path"
+  EngineCfg(Int32(sizeof(EngineCfg)), device, game_id(gspec), oracle,
+    mcts.gamma, mcts.cpuct, mcts.dirichlet_noise_ϵ, mcts.dirichlet_noise_α, mcts.prior_temperature,
+    mcts.num_iters_per_turn, length(xs), pad8(xs, Int32), pad8(ys, Float64),
+    sim.num_workers, sim.batch_size, isnothing(sim.reset_every) ? 0 : sim.reset_every, sim.fill_batches ? 1 : 0,
+    sim.flip_probability, UInt64(seed), 0, 0,
+    hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters)
+end
+
+# ---- seam 3: the network plugin -------------------------------------------------------------------------
+"""
+    HipResNet(gspec, hyper::ResNetHP)  /  HipResNet(nn::ResNet)
+
+Network plugin whose forward pass is the HIP tower (fp32 MFMA).  Parameters live in one Float32 blob in
+Flux array order (see az_net_num_params in include/azhip.h); `HipResNet(nn::ResNet)` imports a trained Flux
+network.  Training is delegated: keep a Flux `ResNet` as `curnn` and convert after each learning step.
+"""
+mutable struct HipResNet <: AlphaZero.AbstractNetwork
+  gspec
+  hyper::AlphaZero.ResNetHP
+  blob::Vector{Float32}
+  engine::Union{Nothing, Engine}
+  on_gpu::Bool
+end
+Network.HyperParams(::Type{HipResNet}) = AlphaZero.ResNetHP
+Network.hyperparams(nn::HipResNet) = nn.hyper
+Network.game_spec(nn::HipResNet) = nn.gspec
+Network.on_gpu(nn::HipResNet) = nn.on_gpu
+Network.to_gpu(nn::HipResNet) = (nn.on_gpu = true; nn)
+Network.to_cpu(nn::HipResNet) = (nn.on_gpu = false; nn)
+Network.set_test_mode!(::HipResNet, mode) = nothing          # inference only: BatchNorm is always test mode
+Network.convert_input(::HipResNet, x) = x
+Network.convert_output(::HipResNet, x) = x
+Network.params(nn::HipResNet) = (nn.blob,)
+Network.regularized_params(nn::HipResNet) = ()
+Network.gc(nn::HipResNet) = (nn.engine = nothing; GC.gc(true))
+Base.copy(nn::HipResNet) = HipResNet(nn.gspec, nn.hyper, copy(nn.blob), nothing, nn.on_gpu)
+Network.train!(cb, ::HipResNet, opt, loss, data, n) =
+  error("HipResNet is inference-only: train a Flux ResNet and convert it with HipResNet(nn)")
+
+flat(x) = vec(Float32.(Array(x)))
+bn_blob(bn) = vcat(flat(bn.γ), flat(bn.β), flat(bn.μ), flat(bn.σ²))
+conv_blob(c) = vcat(flat(c.weight), flat(c.bias))
+"Flatten a Flux ResNet (resnet.jl:65-92) into the blob order of az_net_set_params."
+function HipResNet(nn::AlphaZero.ResNet)
+  parts = Vector{Float32}[]
+  push!(parts, conv_blob(nn.common[1]), bn_blob(nn.common[2]))
+  for i in 1:nn.hyper.num_blocks
+    inner = nn.common[2 + i][1].layers          # Chain(SkipConnection(Chain(conv, bn, conv, bn), +), relu)
+    push!(parts, conv_blob(inner[1]), bn_blob(inner[2]), conv_blob(inner[3]), bn_blob(inner[4]))
+  end
+  ph, vh = nn.phead, nn.vhead
+  push!(parts, conv_blob(ph[1]), bn_blob(ph[2]), flat(ph[4].weight), flat(ph[4].bias))
+  push!(parts, conv_blob(vh[1]), bn_blob(vh[2]), flat(vh[4].weight), flat(vh[4].bias), flat(vh[5].weight), flat(vh[5].bias))
+  return HipResNet(nn.gspec, nn.hyper, reduce(vcat, parts), nothing, true)
+end
+
+function engine!(nn::HipResNet)
+  if isnothing(nn.engine)
+    mcts = MctsParams(num_iters_per_turn=2, dirichlet_noise_ϵ=0., dirichlet_noise_α=1.)
+    sim = SimParams(num_games=1, num_workers=1, batch_size=1)
+    nn.engine = Engine(make_cfg(nn.gspec, mcts, sim, nn.hyper))
+    check(ccall((:az_net_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), nn.engine.h, nn.blob, length(nn.blob)))
+  end
+  return nn.engine
+end
+
+# seam 2: Network.forward_normalized (network.jl:264-271); X is W x H x C x N, A is nA x N (Float32)
+function Network.forward_normalized(nn::HipResNet, X, A)
+  N = size(X)[end]; nA = size(A, 1)
+  P = Matrix{Float32}(undef, nA, N); V = Matrix{Float32}(undef, 1, N); Pinv = Matrix{Float32}(undef, 1, N)
+  check(ccall((:az_net_forward, LIB), Cint,
+    (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+    engine!(nn).h, Array{Float32}(X), Array{Float32}(A), N, P, V, Pinv))
+  return (P, V, Pinv)
+end
+Network.forward(nn::HipResNet, X) =
+  Network.forward_normalized(nn, X, ones(Float32, GI.num_actions(nn.gspec), size(X)[end]))[1:2]
+
+# Network.evaluate_batch (network.jl:308-315) with the state encode fused on the device
+function Network.evaluate_batch(nn::HipResNet, batch)
+  gspec = nn.gspec; N = length(batch); nA = GI.num_actions(gspec)
+  keys = Vector{NTuple{2,UInt64}}([encode_state(gspec, s) for s in batch])
+  P = Matrix{Float32}(undef, nA, N); V = Vector{Float32}(undef, N)
+  check(ccall((:az_net_evaluate_keys, LIB), Cint, (Ptr{Cvoid}, Ptr{NTuple{2,UInt64}}, Int32, Ptr{Float32}, Ptr{Float32}),
+    engine!(nn).h, keys, N, P, V))
+  return [(P[GI.actions_mask(GI.init(gspec, batch[i])), i], V[i]) for i in eachindex(batch)]
+end
+
+# ---- seam 1: the whole self-play phase ---------------------------------------------------------------------
+policy_from_visits(N, mask) = (π = [N[a] for a in eachindex(mask) if mask[a]] ./ sum(N[a] for a in eachindex(mask) if mask[a]); π ./ sum(π))
+
+struct WorkerView; mcts; end                 # what `measure(trace, colors_flipped, player)` reads
+struct WorkerStats; nodes::Int64; sims::Int64; trav::Int64; nbytes::Int; end
+AlphaZero.MCTS.approximate_memory_footprint(w::WorkerStats) = w.nbytes * w.nodes
+AlphaZero.MCTS.average_exploration_depth(w::WorkerStats) = w.sims == 0 ? 0 : w.trav / w.sims
+
+const progress_cb = Ref{Any}(nothing)
+c_progress(::Ptr{Cvoid})::Cvoid = (isnothing(progress_cb[]) || progress_cb[](); nothing)
+
+"simulate(::Simulator, gspec, ::SimParams; game_simulated) on the GPU when the player is MctsPlayer + HipResNet"
+function AlphaZero.simulate(simulator::Simulator, gspec::DeviceGameSpec, p::SimParams; game_simulated,
+                            first_game_id=0, seed=1)
+  oracle = simulator.make_oracles()
+  player = simulator.make_player(oracle)
+  if !(oracle isa HipResNet && player isa MctsPlayer && isnothing(player.timeout))
+    return invoke(AlphaZero.simulate, Tuple{Simulator, AlphaZero.AbstractGameSpec, SimParams}, simulator, gspec, p;
+                  game_simulated=game_simulated)
+  end
+  m = player.mcts
+  mp = MctsParams(gamma=m.gamma, cpuct=m.cpuct, num_iters_per_turn=player.niters, temperature=player.τ,
+                  dirichlet_noise_ϵ=m.noise_ϵ, dirichlet_noise_α=m.noise_α, prior_temperature=m.prior_temperature)
+  e = Engine(make_cfg(gspec, mp, p, oracle.hyper; seed=seed))
+  check(ccall((:az_net_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, oracle.blob, length(oracle.blob)))
+  maxlen = gspec isa ConnectFour.GameSpec ? 42 : gspec isa Tictactoe.GameSpec ? 9 : 256
+  games = Vector{GameRec}(undef, p.num_games); moves = Vector{MoveRec}(undef, p.num_games * maxlen)
+  stats = SelfplayStats()
+  progress_cb[] = game_simulated
+  GC.@preserve games moves begin
+    tb = TraceBuf(pointer(games), length(games), 0, pointer(moves), length(moves), 0)
+    check(ccall((:az_selfplay_run, LIB), Cint,
+      (Ptr{Cvoid}, Int32, Int32, Ref{TraceBuf}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{SelfplayStats}),
+      e.h, p.num_games, first_game_id, tb, @cfunction(c_progress, Cvoid, (Ptr{Cvoid},)), C_NULL, stats))
+  end
+  nbytes = 32 + 16 * (GI.num_actions(gspec) > 8 ? 16 : 8) + 12
+  return map(games) do g
+    recs = moves[g.first_move + 1 : g.first_move + g.num_moves]
+    trace = Trace(decode_state(gspec, recs[1].key))
+    for (k, r) in enumerate(recs)
+      s = decode_state(gspec, r.key)
+      mask = GI.actions_mask(GI.init(gspec, s))
+      next = k < length(recs) ? decode_state(gspec, recs[k+1].key) : decode_state(gspec, g.final_key)
+      push!(trace, policy_from_visits(r.N, mask), Float64(r.reward), next)
+    end
+    simulator.measure(trace, false, WorkerView(WorkerStats(g.nodes, g.total_simulations, g.total_nodes_traversed, nbytes)))
+  end
+end
+
+end # module

@@ -120,3 +120,28 @@ def test_hip_forward_bit_exact_vs_oracle(game, nblocks, n):
     assert np.array_equal(V, Vr), np.abs(V - Vr).max()
     assert np.array_equal(Pinv, Pir)
     assert np.array_equal(Pk, P) and np.array_equal(Vk, V)           # fused encode path == planes path
+
+
+def test_oracle_matches_committed_golden():
+    """tests/golden/net_golden.npz pins the fp32 contract (summation order) on CPU."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "net_golden.npz"))
+    hp = ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    blob = random_params(R.C4, hp, seed=7)
+    P, V, Pinv = R.net_forward_normalized(R.C4, (1, 64, 32, 32), blob, z["X"], z["A"])
+    assert np.array_equal(P, z["P"]) and np.array_equal(V, z["V"]) and np.array_equal(Pinv, z["Pinv"])
+
+
+@pytest.mark.gpu
+def test_hip_matches_committed_golden():
+    import os
+    import azhip
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "net_golden.npz"))
+    hp = ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    with azhip.Engine(game=0, oracle=azhip.ORACLE_RESNET, num_workers=4, batch_size=4, num_iters_per_turn=4,
+                      num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32) as e:
+        e.net_set_params(random_params(R.C4, hp, seed=7))
+        P, V, Pinv = e.net_forward(z["X"], z["A"])
+        Pk, Vk = e.net_evaluate_keys(z["keys"])
+    assert np.array_equal(P, z["P"]) and np.array_equal(V, z["V"]) and np.array_equal(Pinv, z["Pinv"])
+    assert np.array_equal(Pk, z["P"]) and np.array_equal(Vk, z["V"])
