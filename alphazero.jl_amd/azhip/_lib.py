@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC, "libazhip.so")
+LIB_PATH = os.environ.get("AZHIP_LIB", os.path.join(CSRC, "libazhip.so"))   # override: A/B builds
 
 AZ_OK, AZ_ERR_BAD_ARG, AZ_ERR_CAPACITY, AZ_ERR_HIP, AZ_ERR_STATE = 0, -1, -2, -3, -4
 GAME_CONNECT_FOUR, GAME_TICTACTOE, GAME_MANCALA = 0, 1, 2

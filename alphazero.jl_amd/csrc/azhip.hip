@@ -66,14 +66,24 @@ static bool game_info(int gid, GameInfo* gi) {
 }
 
 // ------------------------------------------------------------------------------- engine
+static constexpr int AZ_MAX_GROUPS = 4;
 struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; };
 struct az_engine {
   az_engine_cfg cfg;
   GameInfo gi;
   int device;
   hipStream_t stream;
-  DView v;
+  DView v;                       // global view over all G slots (start / move / hooks)
   DParams p;
+  // slot groups: num_workers / batch_size interleaved half-batches, each with its own stream, so the
+  // tree kernels of one group run under the network of another (the device form of the reference's
+  // num_workers = 2 x batch_size, games/connect-four/params.jl:18-19)
+  int ngroups;
+  DView gv[AZ_MAX_GROUPS];
+  hipStream_t gs[AZ_MAX_GROUPS];      // tree-kernel stream of the group (high priority when ngroups > 1)
+  hipStream_t gt[AZ_MAX_GROUPS];      // network stream of the group
+  hipEvent_t ev_tree[AZ_MAX_GROUPS], ev_net[AZ_MAX_GROUPS];
+  float* g_hfeat[AZ_MAX_GROUPS];
   std::vector<void*> allocs;
   // network
   bool net_loaded;
@@ -114,9 +124,21 @@ template <class T> static int dalloc(az_engine* e, T** p, size_t n, bool zero = 
   return AZ_OK;
 }
 
+static int sync_groups(az_engine* e) {
+  for (int g = 0; g < e->ngroups; ++g) if (e->gs[g] != e->stream) {
+    HIPCHK(hipStreamSynchronize(e->gt[g]));
+    HIPCHK(hipStreamSynchronize(e->gs[g]));
+  }
+  return AZ_OK;
+}
+static int sync_all(az_engine* e) {
+  AZCHK(sync_groups(e));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return AZ_OK;
+}
 static int prof_flush(az_engine* e) {
   if (!e->prof_used) return AZ_OK;
-  HIPCHK(hipStreamSynchronize(e->stream));
+  AZCHK(sync_all(e));
   for (size_t i = 0; i < e->prof_used; ++i) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e->prof_pool[i].a, e->prof_pool[i].b));
@@ -125,31 +147,33 @@ static int prof_flush(az_engine* e) {
   e->prof_used = 0;
   return AZ_OK;
 }
-static int prof_begin(az_engine* e, int cls, int64_t units) {
+static int prof_begin(az_engine* e, hipStream_t st, int cls, int64_t units) {
   if (!e->prof_on) return AZ_OK;
   if (e->prof_used == e->prof_pool.size()) AZCHK(prof_flush(e));
   ProfRec& r = e->prof_pool[e->prof_used];
   r.cls = cls;
   e->prof.launches[cls] += 1;
   e->prof.units[cls] += units;
-  HIPCHK(hipEventRecord(r.a, e->stream));
+  HIPCHK(hipEventRecord(r.a, st));
   return AZ_OK;
 }
-static int prof_end(az_engine* e) {
+static int prof_end(az_engine* e, hipStream_t st) {
   if (!e->prof_on) return AZ_OK;
-  HIPCHK(hipEventRecord(e->prof_pool[e->prof_used].b, e->stream));
+  HIPCHK(hipEventRecord(e->prof_pool[e->prof_used].b, st));
   e->prof_used++;
   return AZ_OK;
 }
-#define LAUNCH(e, cls, units, kern, grid, block, shmem, ...)                \
+#define LAUNCH_ON(e, st, cls, units, kern, grid, block, shmem, ...)         \
   do {                                                                      \
-    AZCHK(prof_begin(e, cls, units));                                       \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, (e)->stream, __VA_ARGS__); \
-    AZCHK(prof_end(e));                                                     \
+    AZCHK(prof_begin(e, st, cls, units));                                   \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, st, __VA_ARGS__); \
+    AZCHK(prof_end(e, st));                                                 \
   } while (0)
+#define LAUNCH(e, cls, units, kern, grid, block, shmem, ...) LAUNCH_ON(e, (e)->stream, cls, units, kern, grid, block, shmem, __VA_ARGS__)
 
 static int check_device_error(az_engine* e) {
   int code = 0;
+  AZCHK(sync_groups(e));
   HIPCHK(hipMemcpyAsync(&code, e->v.err, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipGetLastError());
@@ -197,6 +221,11 @@ static size_t net_nparams(const GameInfo& gi, const az_engine_cfg& c) {
 extern "C" int az_engine_destroy(az_engine* e) {
   if (!e) return AZ_OK;
   (void)hipSetDevice(e->device);
+  for (int g = 0; g < e->ngroups; ++g) if (e->gs[g] && e->gs[g] != e->stream) {
+    (void)hipStreamSynchronize(e->gt[g]); (void)hipStreamSynchronize(e->gs[g]);
+    (void)hipStreamDestroy(e->gt[g]); (void)hipStreamDestroy(e->gs[g]);
+    (void)hipEventDestroy(e->ev_tree[g]); (void)hipEventDestroy(e->ev_net[g]);
+  }
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto& r : e->prof_pool) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
   for (void* q : e->allocs) (void)hipFree(q);
@@ -246,7 +275,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   HIPCHK(hipSetDevice(c->device));
   az_engine* e = new (std::nothrow) az_engine();
   if (!e) return fail(AZ_ERR_HIP, "out of host memory");
-  e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr;
+  e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0;
   e->net_loaded = false; e->running = false; e->prof_on = false; e->prof_used = 0;
   memset(&e->prof, 0, sizeof e->prof);
   memset(&e->stats, 0, sizeof e->stats);
@@ -279,7 +308,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &v.path, (size_t)G * v.max_depth));
     AZCHK(dalloc(e, &v.leaf_kind, G)); AZCHK(dalloc(e, &v.leaf_depth, G)); AZCHK(dalloc(e, &v.leaf_env, G));
     AZCHK(dalloc(e, &v.leaf_ins, G)); AZCHK(dalloc(e, &v.eidx, G)); AZCHK(dalloc(e, &v.eval_slots, G));
-    AZCHK(dalloc(e, &v.n_eval, 1));
+    AZCHK(dalloc(e, &v.n_eval, AZ_MAX_GROUPS));
     AZCHK(dalloc(e, &v.Pout, (size_t)std::max(G, 1) * gi.APAD)); AZCHK(dalloc(e, &v.Vout, G));
     AZCHK(dalloc(e, &v.trace, (size_t)G * v.max_moves)); AZCHK(dalloc(e, &v.grec, G));
     AZCHK(dalloc(e, &v.finished, G)); AZCHK(dalloc(e, &v.err, 1)); AZCHK(dalloc(e, &v.stat, 8));
@@ -301,6 +330,36 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     hipLaunchKernelGGL(k_iota, dim3((e->nn_cap + 255) / 256), dim3(256), 0, e->stream, e->d_iota, e->nn_cap);
     memset(&e->net, 0, sizeof e->net);
     DISPATCH_GAME(c->game, AZCHK(set_kernel_attrs<Gm>()));
+    // slot groups
+    int ng = c->batch_size > 0 ? G / c->batch_size : 1;
+    if (ng < 1) ng = 1;
+    if (ng > AZ_MAX_GROUPS) ng = AZ_MAX_GROUPS;
+    while (ng > 1 && G % ng != 0) --ng;
+    const int Gh = G / ng;
+    for (int g = 0; g < ng; ++g) {
+      DView gv = v;
+      const size_t o = (size_t)g * Gh;
+      gv.G = Gh;
+      gv.root += o; gv.active += o; gv.game_id += o; gv.move_idx += o; gv.epoch += o; gv.node_count += o;
+      gv.worker_sim_id += o; gv.tot_sims += o; gv.tot_trav += o; gv.eta += o * gi.APAD;
+      gv.ht += o * hs; gv.nodes += o * (size_t)cap * gi.node_bytes; gv.path += o * v.max_depth;
+      gv.leaf_kind += o; gv.leaf_depth += o; gv.leaf_env += o; gv.leaf_ins += o; gv.eidx += o; gv.eval_slots += o;
+      gv.n_eval += g; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
+      e->gv[g] = gv;
+      if (ng == 1) { e->gs[g] = e->gt[g] = e->stream; }
+      else {
+        // the short latency-bound tree kernels must not queue behind the other group's tower workgroups:
+        // they get the high-priority queue, the tower the normal one
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&e->gs[g], hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&e->gt[g], hipStreamNonBlocking, lo));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_tree[g], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_net[g], hipEventDisableTiming));
+      }
+      AZCHK(dalloc(e, &e->g_hfeat[g], (size_t)Gh * gi.P * 64, false));
+      e->ngroups = g + 1;
+    }
     // search parameters
     DParams& p = e->p;
     memset(&p, 0, sizeof p);
@@ -424,7 +483,7 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   const az_engine_cfg& c = e->cfg;
   if (!blob || n != (int64_t)net_nparams(gi, c)) return fail(AZ_ERR_BAD_ARG, "parameter blob has %lld values, expected %zu", (long long)n, net_nparams(gi, c));
   const int F = c.num_filters, npf = c.num_policy_head_filters, nvf = c.num_value_head_filters, P = gi.P, C = gi.C, A = gi.A;
-  const int HF = ((npf + nvf + 31) / 32) * 32, L = gi.APAD, nb = c.num_blocks;
+  const int HF = F, L = gi.APAD, nb = c.num_blocks;   // head features padded to the trunk width
   e->blob.assign(blob, blob + n);
   const float* w = blob;
   std::vector<float> stem_w((size_t)9 * C * F), stem_ss(2 * F);
@@ -525,16 +584,16 @@ extern "C" int az_net_get_params(const az_engine* e, float* blob, int64_t n) {
 
 // launches tower + heads on `n` boards (device count in n_ptr when n < 0)
 template <class Gm, bool FROM_PLANES>
-static int launch_net(az_engine* e, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
+static int launch_net(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
                       const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
   constexpr int TB = TOWER_ROWS / Gm::P;
   const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
   if (gt == 0) return AZ_OK;
-  LAUNCH(e, AZ_K_TOWER, n_max, (k_tower<Gm, 64, FROM_PLANES>), gt, 256, TowerLds<64>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, e->d_hfeat);
+  LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, 64, FROM_PLANES>), gt, 256, TowerLds<64>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
   if (e->net.hd_ok)
-    LAUNCH(e, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, 64>), (n_max + 31) / 32, 64 * 3, 0, e->net, envs, eslots, n_ptr, n_max, Amask, e->d_hfeat, Pout, Vout, Pinv, pstride);
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, 64>), (n_max + 31) / 32, 64 * 3, 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
   else
-    LAUNCH(e, AZ_K_HEADS, n_max, (k_heads<Gm, 64>), gh, 320, 0, e->net, envs, eslots, n_ptr, n_max, Amask, e->d_hfeat, Pout, Vout, Pinv, pstride);
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads<Gm, 64>), gh, 320, 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
   return AZ_OK;
 }
 
@@ -548,7 +607,7 @@ extern "C" int az_net_forward(az_engine* e, const float* X, const float* A, int3
     int m = std::min(e->nn_cap, N - off);
     HIPCHK(hipMemcpyAsync(e->d_X, X + xs * off, sizeof(float) * xs * m, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_A, A + (size_t)gi.A * off, sizeof(float) * gi.A * m, hipMemcpyHostToDevice, e->stream));
-    DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, true>(e, nullptr, nullptr, nullptr, m, e->d_X, e->d_A, e->d_P, e->d_V, e->d_Pinv, gi.A))));
+    DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, true>(e, e->stream, e->d_hfeat, nullptr, nullptr, nullptr, m, e->d_X, e->d_A, e->d_P, e->d_V, e->d_Pinv, gi.A))));
     HIPCHK(hipMemcpyAsync(P + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(V + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
     if (Pinv) HIPCHK(hipMemcpyAsync(Pinv + off, e->d_Pinv, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
@@ -570,7 +629,7 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
     DISPATCH_GAME(e->cfg.game, { for (int i = 0; i < m; ++i) envs[i] = Gm::from_key(keys[2 * (size_t)(off + i)], keys[2 * (size_t)(off + i) + 1]); });
     HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * m, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_ntmp, &m, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, false>(e, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A))));
+    DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, false>(e, e->stream, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A))));
     HIPCHK(hipMemcpyAsync(P + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(V + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -582,18 +641,30 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
 // ------------------------------------------------------------------------------- search waves
 // One wave = one run_simulation! for every active slot: select -> gather misses -> oracle ->
 // expand + backup.  Nothing is read back by the host.
-template <class Gm> static int wave(az_engine* e) {
+template <class Gm> static int wave(az_engine* e, int ngroups_active) {
   constexpr int L = Gm::APAD;
-  const int G = e->v.G;
-  const int gb = (G * L + 255) / 256;
-  LAUNCH(e, AZ_K_SELECT, G, (k_select<Gm>), gb, 256, 0, e->v, e->p);
-  LAUNCH(e, AZ_K_COMPACT, G, k_compact, 1, 1024, 0, e->v);
-  if (e->cfg.oracle == AZ_ORACLE_RESNET) {
-    AZCHK((launch_net<Gm, false>(e, e->v.leaf_env, e->v.eval_slots, e->v.n_eval, G, nullptr, nullptr, e->v.Pout, e->v.Vout, nullptr, L)));
-  } else {
-    LAUNCH(e, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, e->v, e->p);
+  for (int g = 0; g < ngroups_active; ++g) {
+    const DView& v = e->gv[g];
+    hipStream_t st = e->gs[g], sn = e->gt[g];
+    const bool split = st != sn;
+    const int G = v.G;
+    const int gb = (G * L + 255) / 256;
+    LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_select<Gm>), gb, 256, 0, v, e->p);
+    LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact, 1, 1024, 0, v);
+    if (e->cfg.oracle == AZ_ORACLE_RESNET) {
+      constexpr int TB = TOWER_ROWS / Gm::P;
+      if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
+      LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower<Gm, 64, false>), (G + TB - 1) / TB, 256, TowerLds<64>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
+      if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
+      if (e->net.hd_ok)
+        LAUNCH_ON(e, st, AZ_K_HEADS, G, (k_heads_mfma<Gm, 64>), (G + 31) / 32, 64 * 3, 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
+      else
+        LAUNCH_ON(e, st, AZ_K_HEADS, G, (k_heads<Gm, 64>), (G + 3) / 4, 320, 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
+    } else {
+      LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p);
+    }
+    LAUNCH_ON(e, st, AZ_K_EXPAND, G, (k_expand_backup<Gm>), gb, 256, 0, v, e->p);
   }
-  LAUNCH(e, AZ_K_EXPAND, G, (k_expand_backup<Gm>), gb, 256, 0, e->v, e->p);
   e->stats.waves++;
   return AZ_OK;
 }
@@ -645,7 +716,10 @@ extern "C" int az_mcts_explore(az_engine* e, const uint64_t* root_keys, int32_t 
   HIPCHK(hipMemcpyAsync(e->d_moves, mv.data(), sizeof(uint32_t) * nslots, hipMemcpyHostToDevice, e->stream));
   if (eta) HIPCHK(hipMemcpyAsync(e->d_eta, eta, sizeof(double) * (size_t)nslots * AZ_MAX_ACTIONS, hipMemcpyHostToDevice, e->stream));
   DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_arm_noise<Gm>), dim3((nslots + 255) / 256), dim3(256), 0, e->stream, e->v, e->p, e->d_slots, e->d_moves, eta ? e->d_eta : nullptr, nslots));
-  for (int i = 0; i < nsims; ++i) DISPATCH_GAME(e->cfg.game, AZCHK(wave<Gm>(e)));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const int nga = std::min(e->ngroups, (nslots + e->gv[0].G - 1) / e->gv[0].G);
+  for (int i = 0; i < nsims; ++i) DISPATCH_GAME(e->cfg.game, AZCHK(wave<Gm>(e, nga)));
+  AZCHK(sync_groups(e));
   HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
   return check_device_error(e);
 }
@@ -680,6 +754,7 @@ extern "C" int az_mcts_node_stats(az_engine* e, int32_t slot, const uint64_t key
                                   float* Vest, uint32_t* mask) {
   ENGINE(e);
   if (slot < 0 || slot >= e->v.G || !key) return fail(AZ_ERR_BAD_ARG, "bad slot or NULL key");
+  AZCHK(sync_groups(e));
   DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_node_stats<Gm>), dim3(1), dim3(1), 0, e->stream, e->v, (int)slot, (unsigned long long)key[0], (unsigned long long)key[1], e->d_nodebuf));
   char buf[512];
   HIPCHK(hipMemcpyAsync(buf, e->d_nodebuf, 512, hipMemcpyDeviceToHost, e->stream));
@@ -701,6 +776,7 @@ extern "C" int az_mcts_node_stats(az_engine* e, int32_t slot, const uint64_t key
 extern "C" int az_mcts_counters(az_engine* e, int32_t slot, int64_t* ts, int64_t* tt, int64_t* nn) {
   ENGINE(e);
   if (slot < 0 || slot >= e->v.G) return fail(AZ_ERR_BAD_ARG, "bad slot");
+  AZCHK(sync_groups(e));
   long long a = 0, b = 0; int c = 0;
   HIPCHK(hipMemcpyAsync(&a, e->v.tot_sims + slot, 8, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(&b, e->v.tot_trav + slot, 8, hipMemcpyDeviceToHost, e->stream));
@@ -743,6 +819,7 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
 // the move step (play.jl:308-313) for every slot, then collection of finished games and refill
 template <class Gm> static int move_round(az_engine* e) {
   const int G = e->v.G;
+  AZCHK(sync_groups(e));
   LAUNCH(e, AZ_K_MOVE, G, (k_move<Gm>), (G + 255) / 256, 256, 0, e->v, e->p);
   HIPCHK(hipMemcpyAsync(e->h_finished.data(), e->v.finished, sizeof(int) * G, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->h_grec.data(), e->v.grec, sizeof(az_game_rec) * G, hipMemcpyDeviceToHost, e->stream));
@@ -785,7 +862,7 @@ extern "C" int az_selfplay_step(az_engine* e, int32_t nwaves) {
   if (!e->running) return fail(AZ_ERR_STATE, "az_selfplay_begin has not been called");
   for (int w = 0; w < nwaves; ++w) {
     if (e->active_slots == 0) break;
-    DISPATCH_GAME(e->cfg.game, AZCHK(wave<Gm>(e)));
+    DISPATCH_GAME(e->cfg.game, AZCHK(wave<Gm>(e, e->ngroups)));
     if (++e->wave_in_move == e->p.nsims) {
       e->wave_in_move = 0;
       DISPATCH_GAME(e->cfg.game, AZCHK(move_round<Gm>(e)));
@@ -805,6 +882,7 @@ extern "C" int az_selfplay_get_stats(az_engine* e, az_selfplay_stats* s) {
   ENGINE(e);
   if (!s) return fail(AZ_ERR_BAD_ARG, "NULL");
   long long st[8];
+  AZCHK(sync_groups(e));
   HIPCHK(hipMemcpyAsync(st, e->v.stat, sizeof st, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->stats.simulations = st[0]; e->stats.nodes_traversed = st[1]; e->stats.leaf_evals = st[2];
@@ -839,6 +917,7 @@ extern "C" int az_selfplay_collect(az_engine* e, az_trace_buf* out) {
 extern "C" int az_selfplay_end(az_engine* e) {
   ENGINE(e);
   if (!e->running) return AZ_OK;
+  AZCHK(sync_groups(e));
   HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->running = false;
@@ -876,6 +955,28 @@ extern "C" int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, 
     z[i] = wp ? wr : -wr;
     t[i] = (double)(n - i);
   }
+  return AZ_OK;
+}
+
+// debug aid (not part of the ABI in azhip.h): s_memtime stamps of one tower launch on n boards
+extern "C" int az_debug_tower_timeline(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
+  ENGINE(e);
+  if (!e->net_loaded || n < 1 || n > e->nn_cap) return fail(AZ_ERR_BAD_ARG, "bad n / no net");
+  if (e->cfg.game != AZ_GAME_CONNECT_FOUR) return fail(AZ_ERR_BAD_ARG, "connect-four only");
+  const int nb = (n + 2) / 3;
+  if (cap < (int64_t)nb * 16) return fail(AZ_ERR_CAPACITY, "need %d words", nb * 16);
+  unsigned long long* d = nullptr;
+  AZCHK(dalloc(e, &d, (size_t)nb * 16));
+  std::vector<GEnv> envs(n, ConnectFour::init());
+  HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_ntmp, &n, sizeof(int), hipMemcpyHostToDevice, e->stream));
+  NetDev nd = e->net;
+  for (int rep = 0; rep < 2; ++rep) {
+    nd.dbg = rep ? d : nullptr;
+    hipLaunchKernelGGL((k_tower<ConnectFour, 64, false>), dim3(nb), dim3(256), TowerLds<64>::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat);
+  }
+  HIPCHK(hipMemcpyAsync(out, d, sizeof(unsigned long long) * nb * 16, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
   return AZ_OK;
 }
 

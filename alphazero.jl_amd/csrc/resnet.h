@@ -38,6 +38,7 @@ struct NetDev {
   const float* val_b;                 // [F]
   const float* val2_w;                // [F]
   float val2_b;
+  unsigned long long* dbg;            // optional [blocks][16] s_memtime stamps (az_debug_tower_timeline)
   const float2* hd_w;                 // MFMA dense heads: [F/32 value tiles + 1 policy tile][K/4][64] float2
   int hd_ok;                          // 1 when npf % 4 == 0 && nvf % 4 == 0 (k_heads_mfma usable)
 };
@@ -77,13 +78,18 @@ __device__ __forceinline__ void mfma_tap(const float* __restrict__ arow, const f
     }
   }
 }
+// bA holds this layer's tap-0 fragments on entry; on exit bB holds the NEXT layer's tap-0 fragments
+// (wnext), requested before the epilogue so the L2 latency hides under epilogue + barrier.
 template <int F, int NT, int NTAP>
 __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* __restrict__ out,
-                                          const float4* __restrict__ wpk, const float* __restrict__ ss,
-                                          int out_ch, bool residual, const int (&nbr)[9], int wave, int lane) {
+                                          const float4* __restrict__ wpk, const float4* __restrict__ wnext,
+                                          float4 (&bA)[NT][F / 8], float4 (&bB)[NT][F / 8],
+                                          const float* __restrict__ ss, int out_ch, bool residual,
+                                          const int (&nbr)[9], int wave, int lane) {
   constexpr int STRIDE = TowerLds<F>::STRIDE;
   constexpr int JQ = F / 8;
   constexpr size_t TAPW = (size_t)NT * JQ * 64;
+  static_assert(NTAP == 1 || NTAP == 9, "tap count");
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -91,36 +97,57 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* _
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
   const int khalf = (lane >> 5) * (F / 2);
   const float4* wl = wpk + lane;
-  float4 b0[NT][JQ], b1[NT][JQ];
-  load_b_tap<F, NT>(wl, b0);
-  if (NTAP == 1) {
-    mfma_tap<F, NT>(in + nbr[4] + khalf, b0, acc);
-  } else {
+#ifndef AZ_XLAYER
+#define AZ_XLAYER 0
+#endif
+#ifndef AZ_SSPRE
+#define AZ_SSPRE 0
+#endif
+  float sc[NT], sh[NT];
+#if AZ_SSPRE
 #pragma unroll
-    for (int t = 0; t < NTAP; t += 2) {
-      // sched_barrier(0): hipcc otherwise sinks the prefetch next to its first use
-      if (t + 1 < NTAP) load_b_tap<F, NT>(wl + (size_t)(t + 1) * TAPW, b1);
+  for (int n = 0; n < NT; ++n) { sc[n] = ss[n * 32 + (lane & 31)]; sh[n] = ss[out_ch + n * 32 + (lane & 31)]; }
+#endif
+#if !AZ_XLAYER
+  load_b_tap<F, NT>(wl, bA);
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  if (NTAP == 1) {
+    mfma_tap<F, NT>(in + nbr[4] + khalf, bA, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    // sched_barrier(0): hipcc otherwise sinks the prefetch next to its first use
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) {
+      load_b_tap<F, NT>(wl + (size_t)(t + 1) * TAPW, bB);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_tap<F, NT>(in + nbr[t] + khalf, b0, acc);
+      mfma_tap<F, NT>(in + nbr[t] + khalf, bA, acc);
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < NTAP) {
-        if (t + 2 < NTAP) load_b_tap<F, NT>(wl + (size_t)(t + 2) * TAPW, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_tap<F, NT>(in + nbr[t + 1] + khalf, b1, acc);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      load_b_tap<F, NT>(wl + (size_t)(t + 2) * TAPW, bA);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_tap<F, NT>(in + nbr[t + 1] + khalf, bB, acc);
+      __builtin_amdgcn_sched_barrier(0);
     }
+#if AZ_XLAYER
+    load_b_tap<F, NT>(wnext + lane, bB);      // unconditional: a branch here would force vmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    mfma_tap<F, NT>(in + nbr[8] + khalf, bA, acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // epilogue: folded BN, residual, ReLU.  C/D layout of the 32x32 MFMA: col = lane & 31,
   // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+#if !AZ_SSPRE
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { sc[n] = ss[n * 32 + (lane & 31)]; sh[n] = ss[out_ch + n * 32 + (lane & 31)]; }
+#endif
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int col = n * 32 + (lane & 31);
-    const float sc = ss[col], sh = ss[out_ch + col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      float v = az_fmaf(acc[n][r], sc, sh);
+      float v = az_fmaf(acc[n][r], sc[n], sh[n]);
       if (residual) v = v + out[row * STRIDE + col];
       v = v > 0.0f ? v : 0.0f;
       out[row * STRIDE + col] = v;
@@ -145,6 +172,15 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
   const int board0 = blockIdx.x * TB;
   if (board0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long* dbg = net.dbg ? net.dbg + (size_t)blockIdx.x * 16 : nullptr;
+  int dbgi = 0;
+#define AZ_STAMP() do { if (dbg && tid == 0) dbg[dbgi++] = __builtin_readcyclecounter(); } while (0)
+  AZ_STAMP();
+#ifdef AZ_STAGGER
+  // co-resident workgroups start in phase (same code, same duration): offset every second resident set by
+  // about half a layer so one workgroup's epilogue/barrier overlaps the other's MFMA stream
+  if ((blockIdx.x >> 8) & 1) { for (int i = 0; i < AZ_STAGGER; ++i) __builtin_amdgcn_s_sleep(127); }
+#endif
 
   // ---- stage planes + stem weights in the (still unused) T buffer --------------------------
   float* planes = bufT;                       // [128][C]
@@ -190,6 +226,7 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
       bufX[row * STRIDE + co] = v > 0.0f ? v : 0.0f;
     }
   }
+  AZ_STAMP();
   // tap-shifted LDS row offsets of this lane's A row; the zero row for out-of-board taps
   int nbr[9];
   {
@@ -210,18 +247,25 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
   // ---- residual tower (resnet.jl:53-63,78) ---------------------------------------------------
   constexpr int NT = F / 32;
   constexpr size_t LAYER_W = (size_t)9 * NT * (F / 8) * 64;   // float4 per conv layer
+  float4 b0[NT][F / 8], b1[NT][F / 8];
+#if AZ_XLAYER
+  load_b_tap<F, NT>((net.nblocks ? net.conv_w : net.head_w) + lane, b0);
+#endif
   for (int blk = 0; blk < net.nblocks; ++blk) {
-    conv_mfma<F, NT, 9>(bufX, bufT, net.conv_w + (size_t)(2 * blk) * LAYER_W, net.conv_ss + (size_t)(2 * blk) * 2 * F,
-                        F, false, nbr, wave, lane);
+    const float4* w1 = net.conv_w + (size_t)(2 * blk) * LAYER_W;
+    const float4* w2 = w1 + LAYER_W;
+    const float4* w3 = (blk + 1 < net.nblocks) ? w2 + LAYER_W : net.head_w;
+    conv_mfma<F, NT, 9>(bufX, bufT, w1, w2, b0, b1, net.conv_ss + (size_t)(2 * blk) * 2 * F, F, false, nbr, wave, lane);
     __syncthreads();
-    conv_mfma<F, NT, 9>(bufT, bufX, net.conv_w + (size_t)(2 * blk + 1) * LAYER_W,
-                        net.conv_ss + (size_t)(2 * blk + 1) * 2 * F, F, true, nbr, wave, lane);
+    conv_mfma<F, NT, 9>(bufT, bufX, w2, w3, b1, b0, net.conv_ss + (size_t)(2 * blk + 1) * 2 * F, F, true, nbr, wave, lane);
     __syncthreads();
+    AZ_STAMP();
   }
   // ---- both 1x1 head convolutions + BN + ReLU as one F => HF GEMM (resnet.jl:80-81,86-87) ----
-  // (HF == F == 64 for the 32/32 heads; general HF <= F handled by NT of the head)
-  conv_mfma<F, NT, 1>(bufX, bufT, net.head_w, net.head_ss, net.HF, false, nbr, wave, lane);
+  // (padded head channels have zero weights, scale 0, shift 0)
+  conv_mfma<F, NT, 1>(bufX, bufT, net.head_w, nullptr, b0, b1, net.head_ss, net.HF, false, nbr, wave, lane);
   __syncthreads();
+  AZ_STAMP();
   // head features -> HBM, [board][P][HF] (the flatten order of the dense contract)
   {
     const int HF = net.HF;
@@ -233,6 +277,9 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
       *(float4*)(hfeat + ((size_t)board0 * P + row) * HF + c4 * 4) = v4;
     }
   }
+  AZ_STAMP();
+  if (dbg && tid == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); dbg[14] = xcc; dbg[15] = hw; }
+#undef AZ_STAMP
 }
 
 // Dense heads, softmax, tanh, forward_normalized.  HB boards per 320-thread workgroup; thread
@@ -315,6 +362,7 @@ k_heads_mfma(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restric
              const float* __restrict__ hfeat, float* __restrict__ Pout, float* __restrict__ Vout,
              float* __restrict__ Pinv, int pstride) {
   constexpr int P = Gm::P, A = Gm::A, NVT = F / 32;
+  __builtin_amdgcn_s_setprio(3);   // few workgroups on the critical path of the group's next wave
   __shared__ float s_vh[32][F + 1];
   __shared__ float s_logit[32][16];
   const int n = n_eval_ptr ? *n_eval_ptr : n_fixed;

@@ -154,6 +154,7 @@ __device__ inline void arm_noise(const DView& v, const DParams& p, int slot, con
 // =========================================================================================
 template <class Gm>
 __global__ void __launch_bounds__(256) k_select(DView v, DParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   constexpr int L = Gm::APAD;
   using NL = NodeL<Gm>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,6 +207,7 @@ __global__ void __launch_bounds__(256) k_select(DView v, DParams p) {
 // compaction of the slots whose simulation ended on an unseen state -> evaluation batch,
 // ascending slot order (what Batchifier.launch_server collects, src/batchifier.jl:47-81)
 __global__ void __launch_bounds__(1024) k_compact(DView v) {
+  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   __shared__ int wsum[16];
   __shared__ int total;
   const int per = (v.G + 1023) / 1024;
@@ -239,12 +241,13 @@ __global__ void __launch_bounds__(1024) k_compact(DView v) {
       else v.eidx[s] = -1;
     }
   }
-  if (threadIdx.x == 0) { *v.n_eval = total; v.stat[2] += total; }
+  if (threadIdx.x == 0) { *v.n_eval = total; atomicAdd((unsigned long long*)&v.stat[2], (unsigned long long)total); }
 }
 
 // NN-free oracles: MCTS.RandomOracle (src/mcts.jl:62-72) and the synthetic hash oracle
 template <class Gm>
 __global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   constexpr int L = Gm::APAD;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= *v.n_eval) return;
@@ -276,6 +279,7 @@ __global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p) {
 // =========================================================================================
 template <class Gm>
 __global__ void __launch_bounds__(256) k_expand_backup(DView v, DParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   constexpr int L = Gm::APAD;
   using NL = NodeL<Gm>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -360,6 +364,7 @@ __device__ inline double pl_schedule(const DParams& p, int i) {   // schedule.jl
 
 template <class Gm>
 __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   using NL = NodeL<Gm>;
   constexpr int L = Gm::APAD;
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;       // one lane per slot: n <= 9, serial

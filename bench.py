@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--slots", type=int, default=4096)
     ap.add_argument("--sims", type=int, default=400)
+    ap.add_argument("--groups", type=int, default=1, help="interleaved slot groups = num_workers / batch_size (2 overlaps the tree kernels of one half-batch with the network of the other; default 1 keeps per-kernel timings clean)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not wrap launches in HIP events")
     args = ap.parse_args()
@@ -85,7 +86,7 @@ def main():
     blob = random_params(azhip.GAME_CONNECT_FOUR, hp, seed=2026)
     # games/connect-four/params.jl:24-30 with 400 sims (BASELINE.json configs[1])
     eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=local_rank,
-                       num_workers=args.slots, batch_size=args.slots, num_iters_per_turn=args.sims,
+                       num_workers=args.slots, batch_size=args.slots // args.groups, num_iters_per_turn=args.sims,
                        gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
                        prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
                        num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)

@@ -15,9 +15,9 @@ def _hp(nblocks):
     return ResNetHP(num_blocks=nblocks, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
 
 
-@pytest.mark.parametrize("game,spec,ngames,workers,nsims", [(R.C4, "ConnectFourSpec", 12, 6, 40), (R.TTT, "TicTacToeSpec", 10, 4, 24),
-                                                            (R.MANCALA, "MancalaSpec", 6, 3, 24)])
-def test_simulate_with_resnet_matches_oracle(game, spec, ngames, workers, nsims):
+@pytest.mark.parametrize("game,spec,ngames,workers,batch,nsims", [(R.C4, "ConnectFourSpec", 12, 6, 6, 40), (R.TTT, "TicTacToeSpec", 10, 4, 4, 24),
+                                                                  (R.MANCALA, "MancalaSpec", 6, 3, 3, 24), (R.C4, "ConnectFourSpec", 12, 6, 3, 40)])
+def test_simulate_with_resnet_matches_oracle(game, spec, ngames, workers, batch, nsims):
     """Simulator / simulate (simulations.jl:179-244) with MctsPlayer + ResNet, vs the oracle's simulate."""
     import azhip
     gspec = getattr(azhip, spec)()
@@ -25,7 +25,7 @@ def test_simulate_with_resnet_matches_oracle(game, spec, ngames, workers, nsims)
     nn = azhip.ResNet(gspec, hp, seed=11)
     mp = azhip.MctsParams(num_iters_per_turn=nsims, dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0, cpuct=2.0,
                           temperature=azhip.PLSchedule([0, 6, 10], [1.0, 1.0, 0.3]), gamma=1.0)
-    sp = azhip.SimParams(num_games=ngames, num_workers=workers, batch_size=workers, use_gpu=True, reset_every=2)
+    sp = azhip.SimParams(num_games=ngames, num_workers=workers, batch_size=batch, use_gpu=True, reset_every=2)
     from azhip.network import copy as netcopy
     sim = azhip.Simulator(lambda oracle: azhip.MctsPlayer(gspec, oracle, mp), lambda: netcopy(nn, on_gpu=True, test_mode=True),
                           azhip.self_play_measurements)

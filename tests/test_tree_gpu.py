@@ -72,13 +72,15 @@ def test_explore_matches_oracle(game, oracle):
             assert (ts, tt, nn) == (m.total_simulations, m.total_nodes_traversed, m.num_nodes)
 
 
-@pytest.mark.parametrize("game,nsims,ngames,workers", [(1, 64, 32, 32), (0, 100, 24, 8), (2, 60, 12, 8)])
+@pytest.mark.parametrize("game,nsims,ngames,workers,batch", [(1, 64, 32, 32, 32), (0, 100, 24, 8, 8), (2, 60, 12, 8, 8),
+                                                              (1, 64, 40, 32, 8), (0, 100, 24, 8, 4)])
 @pytest.mark.parametrize("oracle", [0, 1])
-def test_selfplay_traces_match_oracle(game, nsims, ngames, workers, oracle):
-    """Whole self-play phase (simulate): every move record, visit count, action, reward, node count."""
+def test_selfplay_traces_match_oracle(game, nsims, ngames, workers, batch, oracle):
+    """Whole self-play phase (simulate): every move record, visit count, action, reward, node count.
+    batch < workers runs workers/batch interleaved slot groups on separate streams: same results."""
     kw = dict(gamma=1.0, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0, temp_xs=(0, 4, 8), temp_ys=(1.0, 1.0, 0.3))
     games, moves, nm = R.simulate(game, oracle, ngames, workers, nsims, reset_every=2, seed=11, **kw)
-    with _engine(game, oracle, num_workers=workers, batch_size=workers, num_iters_per_turn=nsims, cpuct=2.0,
+    with _engine(game, oracle, num_workers=workers, batch_size=batch, num_iters_per_turn=nsims, cpuct=2.0,
                  dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=((0, 4, 8), (1.0, 1.0, 0.3)),
                  reset_every=2, seed=11, max_moves_per_game=200 if game == 2 else 0) as e:
         dg, dm, ng, ndm, stats = e.selfplay_run(ngames)
