@@ -486,11 +486,15 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   const int HF = F, L = gi.APAD, nb = c.num_blocks;   // head features padded to the trunk width
   e->blob.assign(blob, blob + n);
   const float* w = blob;
-  std::vector<float> stem_w((size_t)9 * C * F), stem_ss(2 * F);
-  for (int t = 0; t < 9; ++t) {
-    int dy = t / 3 - 1, dx = t % 3 - 1, wi = 1 - dx, wj = 1 - dy;
-    for (int ci = 0; ci < C; ++ci) for (int co = 0; co < F; ++co)
-      stem_w[(size_t)(t * C + ci) * F + co] = w[wi + 3 * (wj + 3 * (ci + (size_t)C * co))];
+  // stem fragments: k = t*C + ci (tap t = (dy+1)*3 + (dx+1) reads W[1-dx, 1-dy]), K padded to 2*K2,
+  // lane l supplies k = (l>>5)*K2 + j for MFMA j
+  const int K2 = (9 * C + 1) / 2;
+  std::vector<float> stem_w((size_t)(F / 32) * K2 * 64, 0.0f), stem_ss(2 * F);
+  for (int nt = 0; nt < F / 32; ++nt) for (int j = 0; j < K2; ++j) for (int l = 0; l < 64; ++l) {
+    int k = (l >> 5) * K2 + j, co = nt * 32 + (l & 31);
+    if (k >= 9 * C) continue;
+    int t = k / C, ci = k % C, dy = t / 3 - 1, dx = t % 3 - 1, wi = 1 - dx, wj = 1 - dy;
+    stem_w[((size_t)nt * K2 + j) * 64 + l] = w[wi + 3 * (wj + 3 * (ci + (size_t)C * co))];
   }
   bn_fold(w + 9 * C * F, w + 9 * C * F + F, F, stem_ss.data(), stem_ss.data() + F);
   w += (size_t)9 * C * F + 5 * F;

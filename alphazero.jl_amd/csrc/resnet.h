@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct NetDev {
   int nblocks, F, npf, nvf, HF;       // HF = padded npf + nvf (multiple of 32)
-  const float* stem_w;                // [9*C][F]  k-major
+  const float* stem_w;                // [F/32][K2][64] MFMA B fragments, K2 = ceil(9C/2): W[k = (lane>>5)*K2 + j][co]
   const float* stem_ss;               // [2][F] scale, shift
   const float4* conv_w;               // [2*nblocks][9][F/32][F/8][64] float4 (fragment order)
   const float* conv_ss;               // [2*nblocks][2][F]
@@ -57,25 +57,40 @@ template <int F> struct TowerLds {
 // both register sets are statically indexed.
 template <int F, int NT>
 __device__ __forceinline__ void load_b_tap(const float4* __restrict__ wt, float4 (&b)[NT][F / 8]) {
+#ifdef AZ_ABLATE_B
+  asm volatile("" : "+v"(b[0][0].x));   // timing experiment: keep stale fragments, no load
+  return;
+#endif
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
     for (int jq = 0; jq < F / 8; ++jq) b[n][jq] = wt[(size_t)(n * (F / 8) + jq) * 64];
 }
+// `afirst` = channels 0..3 of the tap's A row, requested one tap earlier so that the first MFMA of a tap
+// never waits for LDS; the other 7 float4 of the row are read here and land under the first 8 MFMAs.
 template <int F, int NT>
-__device__ __forceinline__ void mfma_tap(const float* __restrict__ arow, const float4 (&b)[NT][F / 8], f32x16 (&acc)[NT]) {
+__device__ __forceinline__ void mfma_tap(const float4& afirst, const float* __restrict__ arow,
+                                         const float4 (&b)[NT][F / 8], f32x16 (&acc)[NT]) {
   float4 a[F / 8];
+  a[0] = afirst;
+#ifdef AZ_ABLATE_A
 #pragma unroll
-  for (int jq = 0; jq < F / 8; ++jq) a[jq] = *(const float4*)(arow + jq * 4);
+  for (int jq = 1; jq < F / 8; ++jq) a[jq] = afirst;
+#else
+#pragma unroll
+  for (int jq = 1; jq < F / 8; ++jq) a[jq] = *(const float4*)(arow + jq * 4);
+#endif
+  // consecutive MFMAs alternate between the NT accumulators (each accumulator still sees x,y,z,w in order)
 #pragma unroll
   for (int jq = 0; jq < F / 8; ++jq) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].x, b[n][jq].x, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].y, b[n][jq].y, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].z, b[n][jq].z, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].w, b[n][jq].w, acc[n], 0, 0, 0);
-    }
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].x, b[n][jq].x, acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].y, b[n][jq].y, acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].z, b[n][jq].z, acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].w, b[n][jq].w, acc[n], 0, 0, 0);
   }
 }
 // bA holds this layer's tap-0 fragments on entry; on exit bB holds the NEXT layer's tap-0 fragments
@@ -85,7 +100,7 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* _
                                           const float4* __restrict__ wpk, const float4* __restrict__ wnext,
                                           float4 (&bA)[NT][F / 8], float4 (&bB)[NT][F / 8],
                                           const float* __restrict__ ss, int out_ch, bool residual,
-                                          const int (&nbr)[9], int wave, int lane) {
+                                          const int (&nbr)[9], int wave, int lane, unsigned long long* stamp = nullptr) {
   constexpr int STRIDE = TowerLds<F>::STRIDE;
   constexpr int JQ = F / 8;
   constexpr size_t TAPW = (size_t)NT * JQ * 64;
@@ -112,29 +127,53 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* _
   load_b_tap<F, NT>(wl, bA);
   __builtin_amdgcn_sched_barrier(0);
 #endif
+  float4 af0, af1;
   if (NTAP == 1) {
-    mfma_tap<F, NT>(in + nbr[4] + khalf, bA, acc);
+    af0 = *(const float4*)(in + nbr[4] + khalf);
+    mfma_tap<F, NT>(af0, in + nbr[4] + khalf, bA, acc);
     __builtin_amdgcn_sched_barrier(0);
   } else {
-    // sched_barrier(0): hipcc otherwise sinks the prefetch next to its first use
+    // Per tap: 64 MFMAs of tap t, the 16 weight loads of tap t+1 and the LDS reads.  A burst of 16
+    // global_load_dwordx4 stalls the wave's own MFMA issue for ~400 cycles (measured: 10 % of a layer), so
+    // the loads are threaded through the MFMA stream, one VMEM per 4 MFMAs (sched_group_barrier), and the
+    // whole tap is fenced with sched_barrier(0) so hipcc cannot sink the prefetch next to its first use.
+#define AZ_TAP_PIPELINE()                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < NT * JQ; ++i_) {            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
+    }
+    af0 = *(const float4*)(in + nbr[0] + khalf);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 8; t += 2) {
       load_b_tap<F, NT>(wl + (size_t)(t + 1) * TAPW, bB);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_tap<F, NT>(in + nbr[t] + khalf, bA, acc);
+      af1 = *(const float4*)(in + nbr[t + 1] + khalf);
+      mfma_tap<F, NT>(af0, in + nbr[t] + khalf, bA, acc);
+      AZ_TAP_PIPELINE();
       __builtin_amdgcn_sched_barrier(0);
       load_b_tap<F, NT>(wl + (size_t)(t + 2) * TAPW, bA);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_tap<F, NT>(in + nbr[t + 1] + khalf, bB, acc);
+      af0 = *(const float4*)(in + nbr[t + 2] + khalf);
+      mfma_tap<F, NT>(af1, in + nbr[t + 1] + khalf, bB, acc);
+      AZ_TAP_PIPELINE();
       __builtin_amdgcn_sched_barrier(0);
     }
 #if AZ_XLAYER
-    load_b_tap<F, NT>(wnext + lane, bB);      // unconditional: a branch here would force vmcnt(0)
-    __builtin_amdgcn_sched_barrier(0);
+    load_b_tap<F, NT>(wnext + lane, bB);      // next layer's tap 0 (unconditional: a branch would force vmcnt(0))
+    mfma_tap<F, NT>(af0, in + nbr[8] + khalf, bA, acc);
+    AZ_TAP_PIPELINE();
+#else
+    mfma_tap<F, NT>(af0, in + nbr[8] + khalf, bA, acc);
 #endif
-    mfma_tap<F, NT>(in + nbr[8] + khalf, bA, acc);
+#undef AZ_TAP_PIPELINE
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (stamp) { asm volatile("s_nop 0" ::: "memory"); stamp[0] = __builtin_readcyclecounter(); }
+#ifndef AZ_EPI_PRIO
+#define AZ_EPI_PRIO 2
+#endif
+  // the epilogue + barrier is the only non-MFMA stretch of a layer: run it at raised priority so it is
+  // not starved by the co-resident workgroup's MFMA stream (7.2k -> ~1k cycles measured)
+  __builtin_amdgcn_s_setprio(AZ_EPI_PRIO);
   // epilogue: folded BN, residual, ReLU.  C/D layout of the 32x32 MFMA: col = lane & 31,
   // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
 #if !AZ_SSPRE
@@ -153,6 +192,7 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* _
       out[row * STRIDE + col] = v;
     }
   }
+  if (stamp) stamp[1] = __builtin_readcyclecounter();
 }
 
 // FROM_PLANES = false: inputs are the leaf states of the evaluation batch (encode fused);
@@ -182,53 +222,21 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
   if ((blockIdx.x >> 8) & 1) { for (int i = 0; i < AZ_STAGGER; ++i) __builtin_amdgcn_s_sleep(127); }
 #endif
 
-  // ---- stage planes + stem weights in the (still unused) T buffer --------------------------
-  float* planes = bufT;                       // [128][C]
-  float* sw = bufT + TOWER_ROWS * C;          // [9*C][F]
-  for (int i = tid; i < TOWER_ROWS * C; i += 256) {
+  // ---- stage the input planes in the (still unused) T buffer: [128 rows + zero row][C] -------
+  float* planes = bufT;
+  for (int i = tid; i < (TOWER_ROWS + 1) * C; i += 256) {
     const int row = i / C, c = i % C;
     const int b = row / P, q = row % P;
     float val = 0.0f;
-    if (b < TB && board0 + b < n) {
+    if (row < TOWER_ROWS && b < TB && board0 + b < n) {
       if (FROM_PLANES) val = X[((size_t)(board0 + b) * C + c) * P + q];
       else val = Gm::plane(leaf_env[eval_slots[board0 + b]], q, c);
     }
     planes[i] = val;
   }
-  for (int i = tid; i < 9 * C * F; i += 256) sw[i] = net.stem_w[i];
   for (int i = tid; i < STRIDE; i += 256) { bufX[TOWER_ROWS * STRIDE + i] = 0.0f; }
-  __syncthreads();
-
-  // ---- stem: Conv(3x3, C=>F) + BN + ReLU (resnet.jl:75-77), fp32 VALU chain k = t*C + c -----
-  {
-    const int row = tid >> 1, half = tid & 1;
-    const int b = row / P, q = row % P, x = q % W, y = q / W;
-    float acc[F / 2];
-#pragma unroll
-    for (int i = 0; i < F / 2; ++i) acc[i] = 0.0f;
-#pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-      const int dy = t / 3 - 1, dx = t % 3 - 1;
-      const bool ok = (b < TB) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
-      const int nrow = ok ? row + dy * W + dx : 0;
-#pragma unroll 1
-      for (int c = 0; c < C; ++c) {
-        const float val = ok ? planes[nrow * C + c] : 0.0f;
-        const float* wk = sw + (t * C + c) * F + half * (F / 2);
-#pragma unroll
-        for (int i = 0; i < F / 2; ++i) acc[i] = az_fmaf(val, wk[i], acc[i]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < F / 2; ++i) {
-      const int co = half * (F / 2) + i;
-      float v = az_fmaf(acc[i], net.stem_ss[co], net.stem_ss[F + co]);
-      bufX[row * STRIDE + co] = v > 0.0f ? v : 0.0f;
-    }
-  }
-  AZ_STAMP();
-  // tap-shifted LDS row offsets of this lane's A row; the zero row for out-of-board taps
-  int nbr[9];
+  // tap-shifted row of this lane's A row (row 128 = zeros for out-of-board taps)
+  int nrow[9];
   {
     const int row = 32 * wave + (lane & 31);
     const int b = row / P, q = row % P, x = q % W, y = q / W;
@@ -236,9 +244,52 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
     for (int t = 0; t < 9; ++t) {
       const int dy = t / 3 - 1, dx = t % 3 - 1;
       const bool ok = (b < TB) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
-      nbr[t] = (ok ? row + dy * W + dx : TOWER_ROWS) * STRIDE;
+      nrow[t] = ok ? row + dy * W + dx : TOWER_ROWS;
     }
   }
+  __syncthreads();
+
+  // ---- stem: Conv(3x3, C=>F) + BN + ReLU (resnet.jl:75-77) on the same MFMA: K = 9C padded to even,
+  //      k = t*C + c, lanes 0-31 carry k = j, lanes 32-63 k = K2 + j (the paired order of the contract)
+  {
+    constexpr int NTS = F / 32, KK = 9 * C, K2 = (KK + 1) / 2;
+    const int h = lane >> 5;
+    f32x16 acc[NTS];
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bw[NTS][K2];
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
+#pragma unroll
+      for (int j = 0; j < K2; ++j) bw[t][j] = net.stem_w[(size_t)(t * K2 + j) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < K2; ++j) {
+      constexpr int dummy = 0; (void)dummy;
+      const int k0 = j, k1 = K2 + j;
+      const int a0 = nrow[k0 / C] * C + k0 % C;
+      const int a1 = (k1 < KK) ? nrow[(k1 < KK ? k1 : 0) / C] * C + k1 % C : TOWER_ROWS * C;
+      const float a = planes[h ? a1 : a0];
+#pragma unroll
+      for (int t = 0; t < NTS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[t][j], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NTS; ++t) {
+      const int col = t * 32 + (lane & 31);
+      const float sc = net.stem_ss[col], sh = net.stem_ss[F + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = az_fmaf(acc[t][r], sc, sh);
+        bufX[row * STRIDE + col] = v > 0.0f ? v : 0.0f;
+      }
+    }
+  }
+  AZ_STAMP();
+  int nbr[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) nbr[t] = nrow[t] * STRIDE;
   __syncthreads();
   // the T buffer's zero row (planes/stem weights lived there until now)
   for (int i = tid; i < STRIDE; i += 256) bufT[TOWER_ROWS * STRIDE + i] = 0.0f;
@@ -255,16 +306,21 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
     const float4* w1 = net.conv_w + (size_t)(2 * blk) * LAYER_W;
     const float4* w2 = w1 + LAYER_W;
     const float4* w3 = (blk + 1 < net.nblocks) ? w2 + LAYER_W : net.head_w;
-    conv_mfma<F, NT, 9>(bufX, bufT, w1, w2, b0, b1, net.conv_ss + (size_t)(2 * blk) * 2 * F, F, false, nbr, wave, lane);
+    if (dbg && tid == 0 && blk == 1) dbg[9] = __builtin_readcyclecounter();
+    conv_mfma<F, NT, 9>(bufX, bufT, w1, w2, b0, b1, net.conv_ss + (size_t)(2 * blk) * 2 * F, F, false, nbr, wave, lane, (dbg && tid == 0 && blk == 1) ? dbg + 10 : nullptr);
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    if (dbg && tid == 0 && blk == 1) dbg[12] = __builtin_readcyclecounter();
     conv_mfma<F, NT, 9>(bufT, bufX, w2, w3, b1, b0, net.conv_ss + (size_t)(2 * blk + 1) * 2 * F, F, true, nbr, wave, lane);
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
     AZ_STAMP();
   }
   // ---- both 1x1 head convolutions + BN + ReLU as one F => HF GEMM (resnet.jl:80-81,86-87) ----
   // (padded head channels have zero weights, scale 0, shift 0)
   conv_mfma<F, NT, 1>(bufX, bufT, net.head_w, nullptr, b0, b1, net.head_ss, net.HF, false, nbr, wave, lane);
   __syncthreads();
+  __builtin_amdgcn_s_setprio(0);
   AZ_STAMP();
   // head features -> HBM, [board][P][HF] (the flatten order of the dense contract)
   {

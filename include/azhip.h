@@ -29,7 +29,8 @@
  *   3x3 conv (Cin even): taps t = 0..8 with (dy,dx) = (t/3-1, t%3-1); inside a tap the
  *                        channels in the order c = j, Cin/2 + j for j = 0..Cin/2-1 (the K
  *                        order of v_mfma_f32_32x32x2_f32: lanes 0-31 then lanes 32-63)
- *   stem conv          : k = t*Cin + c ascending
+ *   stem conv          : k = t*Cin + c, K = 9*Cin; order k = j, K2 + j for j = 0..K2-1 with
+ *                        K2 = ceil(K/2) (same MFMA, K padded to even with a zero)
  *   1x1 conv           : c = j, Cin/2 + j
  *   dense              : k = p*nf + f ascending (p = x + W*y, f = head filter)
  * followed by y = fma(acc, scale, shift), scale = gamma / sqrtf(var + 1e-5f),

@@ -394,7 +394,8 @@ void azr_unpack_key(int game, const uint64_t key[2], azr_state* st) {
  * one fp32 fma chain starting from +0:
  *   3x3 conv, Cin even : taps t=0..8 ((dy,dx) = (t/3-1, t%3-1)), inside a tap channels in
  *                        the order c = j, Cin/2 + j  for j = 0..Cin/2-1
- *   stem (Cin = planes): k = t*Cin + c ascending
+ *   stem (Cin = planes): k = t*Cin + c, K = 9 Cin, in the order k = j, K2 + j for j = 0..K2-1,
+ *                        K2 = ceil(K/2) (k = K is a zero pad when K is odd)
  *   1x1 conv           : c = j, Cin/2 + j
  *   dense              : k = p*nf + f ascending (p = x + W*y board position, f = filter)
  * then y = fma(acc, scale, shift) with scale = g / sqrtf(var + eps),
@@ -451,6 +452,20 @@ static void conv_bn(const azr_net* n, const float* in, int Cin, int Cout, int ks
     float* o = out + (size_t)(x + W * y) * Cout;
     for (int co = 0; co < Cout; ++co) o[co] = 0.0f;
     int ntap = ksz * ksz;
+    if (paired == 2) {                      /* stem: pairing over the whole K = 9 Cin */
+      int K = ntap * Cin, K2 = (K + 1) / 2;
+      for (int s = 0; s < 2 * K2; ++s) {
+        int k = (s & 1) ? K2 + (s >> 1) : (s >> 1);
+        if (k >= K) continue;
+        int t = k / Cin, ci = k % Cin;
+        int dy = t / 3 - 1, dx = t % 3 - 1, yy = y + dy, xx = x + dx;
+        int inside = (yy >= 0 && yy < H && xx >= 0 && xx < W);
+        float v = inside ? in[(size_t)(xx + W * yy) * Cin + ci] : 0.0f;
+        const float* wrow = Wp + ((size_t)t * Cin + ci) * Cout;
+        for (int co = 0; co < Cout; ++co) o[co] = az_fmaf(v, wrow[co], o[co]);
+      }
+      ntap = 0;
+    }
     for (int t = 0; t < ntap; ++t) {
       int dy = ksz == 3 ? t / 3 - 1 : 0, dx = ksz == 3 ? t % 3 - 1 : 0;
       int yy = y + dy, xx = x + dx;
@@ -502,7 +517,7 @@ static void net_forward_one(const azr_net* n, const float* xin, float* p, float*
   float* vh = hv + (size_t)P * n->nvf;
   for (int pz = 0; pz < P; ++pz) for (int c = 0; c < C; ++c) x0[(size_t)pz * C + c] = xin[pz + (size_t)P * c];
   /* stem, resnet.jl:75-77 */
-  conv_bn(n, x0, C, F, 3, w, w + 9 * C * F, w + 9 * C * F + F, 0, 1, 0, a);
+  conv_bn(n, x0, C, F, 3, w, w + 9 * C * F, w + 9 * C * F + F, 0, 1, 2, a);
   w += 9 * (size_t)C * F + 5 * (size_t)F;
   /* tower, resnet.jl:53-63,78 */
   for (int blk = 0; blk < n->nblocks; ++blk) {

@@ -30,4 +30,5 @@ for n in (4096, 1536, 768):
     print(" segments mean (stem, blk0..4, head, store):", np.diff(t, axis=1).mean(axis=0).round())
     print(" start quantiles", np.percentile(start, [0, 25, 50, 75, 90, 100]).round())
     print(" end quantiles", np.percentile(end, [0, 25, 50, 75, 90, 100]).round())
-    print(" xcc counts", np.bincount(out[:, 14].astype(int)))
+    s = out[:, 9:13].astype(np.int64)
+    print(" blk1.conv1 (mfma, epilogue, barrier):", np.diff(s, axis=1).mean(axis=0).round())
