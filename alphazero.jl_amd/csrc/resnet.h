@@ -51,142 +51,113 @@ template <int F> struct TowerLds {
   static constexpr int BYTES = 2 * BUF * 4;
 };
 
-// one 3x3 (NTAP = 9) or 1x1 (NTAP = 1) convolution over the workgroup's 128 rows.
-// Software pipeline: the B fragments (weights) of tap t+1 are requested from L2 before the 64 MFMAs
-// of tap t are issued, so a global load has ~4000 cycles to land; the tap loop is fully unrolled so
-// both register sets are statically indexed.
-template <int F, int NT>
-__device__ __forceinline__ void load_b_tap(const float4* __restrict__ wt, float4 (&b)[NT][F / 8]) {
+// One 3x3 (NTAP = 9) or 1x1 (NTAP = 1) convolution over the workgroup's 128 rows.
+// Wave tiling: wave = (rh, nh) owns rows rh*64..rh*64+63 (two 32-row MFMA tiles) x output channels
+// nh*32..nh*32+31, i.e. two accumulators that share ONE B fragment stream (8 KiB of weights per tap per
+// wave instead of 16: the VMEM issue slots of the weight loads were the largest non-MFMA cost).
+// Software pipeline: the B fragments of tap t+1 are requested from L2 while the 64 MFMAs of tap t issue,
+// one global_load per 8 MFMAs (sched_group_barrier); each tap is fenced by sched_barrier(0) so hipcc cannot
+// sink the prefetch next to its first use; the tap loop is fully unrolled so both register sets are
+// statically indexed.
+template <int F>
+__device__ __forceinline__ void load_b_tap(const float4* __restrict__ wt, float4 (&b)[F / 8]) {
 #ifdef AZ_ABLATE_B
-  asm volatile("" : "+v"(b[0][0].x));   // timing experiment: keep stale fragments, no load
+  asm volatile("" : "+v"(b[0].x));   // timing experiment: keep stale fragments, no load
   return;
 #endif
 #pragma unroll
-  for (int n = 0; n < NT; ++n)
-#pragma unroll
-    for (int jq = 0; jq < F / 8; ++jq) b[n][jq] = wt[(size_t)(n * (F / 8) + jq) * 64];
+  for (int jq = 0; jq < F / 8; ++jq) b[jq] = wt[(size_t)jq * 64];
 }
-// `afirst` = channels 0..3 of the tap's A row, requested one tap earlier so that the first MFMA of a tap
-// never waits for LDS; the other 7 float4 of the row are read here and land under the first 8 MFMAs.
-template <int F, int NT>
-__device__ __forceinline__ void mfma_tap(const float4& afirst, const float* __restrict__ arow,
-                                         const float4 (&b)[NT][F / 8], f32x16 (&acc)[NT]) {
-  float4 a[F / 8];
-  a[0] = afirst;
-#ifdef AZ_ABLATE_A
+// `af` = channels 0..3 of the two A rows of this tap, requested one tap earlier so the first MFMAs never
+// wait for LDS; the other 7 float4 per row are read here and land under the first MFMAs.
+template <int F>
+__device__ __forceinline__ void mfma_tap(const float4 (&af)[2], const float* __restrict__ arow0,
+                                         const float* __restrict__ arow1, const float4 (&b)[F / 8], f32x16 (&acc)[2]) {
+  float4 a0[F / 8], a1[F / 8];
+  a0[0] = af[0];
+  a1[0] = af[1];
 #pragma unroll
-  for (int jq = 1; jq < F / 8; ++jq) a[jq] = afirst;
-#else
-#pragma unroll
-  for (int jq = 1; jq < F / 8; ++jq) a[jq] = *(const float4*)(arow + jq * 4);
-#endif
-  // consecutive MFMAs alternate between the NT accumulators (each accumulator still sees x,y,z,w in order)
+  for (int jq = 1; jq < F / 8; ++jq) { a0[jq] = *(const float4*)(arow0 + jq * 4); a1[jq] = *(const float4*)(arow1 + jq * 4); }
+  // consecutive MFMAs alternate between the two accumulators (each still sees x,y,z,w of jq = 0.. in order)
 #pragma unroll
   for (int jq = 0; jq < F / 8; ++jq) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].x, b[n][jq].x, acc[n], 0, 0, 0);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].y, b[n][jq].y, acc[n], 0, 0, 0);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].z, b[n][jq].z, acc[n], 0, 0, 0);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jq].w, b[n][jq].w, acc[n], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].x, b[jq].x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].x, b[jq].x, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].y, b[jq].y, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].y, b[jq].y, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].z, b[jq].z, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].z, b[jq].z, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].w, b[jq].w, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].w, b[jq].w, acc[1], 0, 0, 0);
   }
 }
-// bA holds this layer's tap-0 fragments on entry; on exit bB holds the NEXT layer's tap-0 fragments
-// (wnext), requested before the epilogue so the L2 latency hides under epilogue + barrier.
-template <int F, int NT, int NTAP>
+template <int F, int NTAP>
 __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* __restrict__ out,
-                                          const float4* __restrict__ wpk, const float4* __restrict__ wnext,
-                                          float4 (&bA)[NT][F / 8], float4 (&bB)[NT][F / 8],
-                                          const float* __restrict__ ss, int out_ch, bool residual,
-                                          const int (&nbr)[9], int wave, int lane, unsigned long long* stamp = nullptr) {
-  constexpr int STRIDE = TowerLds<F>::STRIDE;
-  constexpr int JQ = F / 8;
-  constexpr size_t TAPW = (size_t)NT * JQ * 64;
+                                          const float4* __restrict__ wpk, const float* __restrict__ ss, int out_ch,
+                                          bool residual, const int (&nbr)[2][9], int rh, int nh, int lane,
+                                          unsigned long long* stamp = nullptr) {
+  static_assert(F == 64, "wave tiling (2 row halves x 2 channel halves) is written for 64 filters");
   static_assert(NTAP == 1 || NTAP == 9, "tap count");
-  f32x16 acc[NT];
+  constexpr int STRIDE = TowerLds<F>::STRIDE;
+  constexpr int JQ = F / 8, NT = F / 32;
+  constexpr size_t TAPW = (size_t)NT * JQ * 64;
+  f32x16 acc[2];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
   const int khalf = (lane >> 5) * (F / 2);
-  const float4* wl = wpk + lane;
-#ifndef AZ_XLAYER
-#define AZ_XLAYER 0
-#endif
-#ifndef AZ_SSPRE
-#define AZ_SSPRE 0
-#endif
-  float sc[NT], sh[NT];
-#if AZ_SSPRE
-#pragma unroll
-  for (int n = 0; n < NT; ++n) { sc[n] = ss[n * 32 + (lane & 31)]; sh[n] = ss[out_ch + n * 32 + (lane & 31)]; }
-#endif
-#if !AZ_XLAYER
-  load_b_tap<F, NT>(wl, bA);
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-  float4 af0, af1;
+  const float4* wl = wpk + (size_t)nh * JQ * 64 + lane;
+  float4 bA[JQ], bB[JQ];
+  float4 af0[2], af1[2];
+  load_b_tap<F>(wl, bA);
   if (NTAP == 1) {
-    af0 = *(const float4*)(in + nbr[4] + khalf);
-    mfma_tap<F, NT>(af0, in + nbr[4] + khalf, bA, acc);
+    af0[0] = *(const float4*)(in + nbr[0][4] + khalf);
+    af0[1] = *(const float4*)(in + nbr[1][4] + khalf);
+    mfma_tap<F>(af0, in + nbr[0][4] + khalf, in + nbr[1][4] + khalf, bA, acc);
     __builtin_amdgcn_sched_barrier(0);
   } else {
-    // Per tap: 64 MFMAs of tap t, the 16 weight loads of tap t+1 and the LDS reads.  A burst of 16
-    // global_load_dwordx4 stalls the wave's own MFMA issue for ~400 cycles (measured: 10 % of a layer), so
-    // the loads are threaded through the MFMA stream, one VMEM per 4 MFMAs (sched_group_barrier), and the
-    // whole tap is fenced with sched_barrier(0) so hipcc cannot sink the prefetch next to its first use.
 #define AZ_TAP_PIPELINE()                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < NT * JQ; ++i_) {            \
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                \
+    _Pragma("unroll") for (int i_ = 0; i_ < JQ; ++i_) {                 \
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                \
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
     }
-    af0 = *(const float4*)(in + nbr[0] + khalf);
+    af0[0] = *(const float4*)(in + nbr[0][0] + khalf);
+    af0[1] = *(const float4*)(in + nbr[1][0] + khalf);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 8; t += 2) {
-      load_b_tap<F, NT>(wl + (size_t)(t + 1) * TAPW, bB);
-      af1 = *(const float4*)(in + nbr[t + 1] + khalf);
-      mfma_tap<F, NT>(af0, in + nbr[t] + khalf, bA, acc);
+      load_b_tap<F>(wl + (size_t)(t + 1) * TAPW, bB);
+      af1[0] = *(const float4*)(in + nbr[0][t + 1] + khalf);
+      af1[1] = *(const float4*)(in + nbr[1][t + 1] + khalf);
+      mfma_tap<F>(af0, in + nbr[0][t] + khalf, in + nbr[1][t] + khalf, bA, acc);
       AZ_TAP_PIPELINE();
       __builtin_amdgcn_sched_barrier(0);
-      load_b_tap<F, NT>(wl + (size_t)(t + 2) * TAPW, bA);
-      af0 = *(const float4*)(in + nbr[t + 2] + khalf);
-      mfma_tap<F, NT>(af1, in + nbr[t + 1] + khalf, bB, acc);
+      load_b_tap<F>(wl + (size_t)(t + 2) * TAPW, bA);
+      af0[0] = *(const float4*)(in + nbr[0][t + 2] + khalf);
+      af0[1] = *(const float4*)(in + nbr[1][t + 2] + khalf);
+      mfma_tap<F>(af1, in + nbr[0][t + 1] + khalf, in + nbr[1][t + 1] + khalf, bB, acc);
       AZ_TAP_PIPELINE();
       __builtin_amdgcn_sched_barrier(0);
     }
-#if AZ_XLAYER
-    load_b_tap<F, NT>(wnext + lane, bB);      // next layer's tap 0 (unconditional: a branch would force vmcnt(0))
-    mfma_tap<F, NT>(af0, in + nbr[8] + khalf, bA, acc);
-    AZ_TAP_PIPELINE();
-#else
-    mfma_tap<F, NT>(af0, in + nbr[8] + khalf, bA, acc);
-#endif
 #undef AZ_TAP_PIPELINE
+    mfma_tap<F>(af0, in + nbr[0][8] + khalf, in + nbr[1][8] + khalf, bA, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (stamp) { asm volatile("s_nop 0" ::: "memory"); stamp[0] = __builtin_readcyclecounter(); }
-#ifndef AZ_EPI_PRIO
-#define AZ_EPI_PRIO 2
-#endif
-  // the epilogue + barrier is the only non-MFMA stretch of a layer: run it at raised priority so it is
-  // not starved by the co-resident workgroup's MFMA stream (7.2k -> ~1k cycles measured)
-  __builtin_amdgcn_s_setprio(AZ_EPI_PRIO);
+  // the epilogue + barrier is the only non-MFMA stretch of a layer: run it at raised priority so it is not
+  // starved by the co-resident workgroup's MFMA stream
+  __builtin_amdgcn_s_setprio(2);
   // epilogue: folded BN, residual, ReLU.  C/D layout of the 32x32 MFMA: col = lane & 31,
   // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-#if !AZ_SSPRE
+  const int col = nh * 32 + (lane & 31);
+  const float sc = ss[col], sh = ss[out_ch + col];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) { sc[n] = ss[n * 32 + (lane & 31)]; sh[n] = ss[out_ch + n * 32 + (lane & 31)]; }
-#endif
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int col = n * 32 + (lane & 31);
+  for (int t = 0; t < 2; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      float v = az_fmaf(acc[n][r], sc[n], sh[n]);
+      const int row = rh * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      float v = az_fmaf(acc[t][r], sc, sh);
       if (residual) v = v + out[row * STRIDE + col];
       v = v > 0.0f ? v : 0.0f;
       out[row * STRIDE + col] = v;
@@ -287,38 +258,43 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
     }
   }
   AZ_STAMP();
-  int nbr[9];
+  // conv wave tiling: (rh, nh) = (wave >> 1, wave & 1); tap-shifted LDS offsets of this lane's two A rows
+  const int rh = wave >> 1, nh = wave & 1;
+  int nbr[2][9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) nbr[t] = nrow[t] * STRIDE;
+  for (int tt = 0; tt < 2; ++tt) {
+    const int row = rh * 64 + tt * 32 + (lane & 31);
+    const int b = row / P, q = row % P, x = q % W, y = q / W;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = (b < TB) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
+      nbr[tt][t] = (ok ? row + dy * W + dx : TOWER_ROWS) * STRIDE;
+    }
+  }
   __syncthreads();
-  // the T buffer's zero row (planes/stem weights lived there until now)
+  // the T buffer's zero row (the planes lived there until now)
   for (int i = tid; i < STRIDE; i += 256) bufT[TOWER_ROWS * STRIDE + i] = 0.0f;
   __syncthreads();
 
   // ---- residual tower (resnet.jl:53-63,78) ---------------------------------------------------
-  constexpr int NT = F / 32;
-  constexpr size_t LAYER_W = (size_t)9 * NT * (F / 8) * 64;   // float4 per conv layer
-  float4 b0[NT][F / 8], b1[NT][F / 8];
-#if AZ_XLAYER
-  load_b_tap<F, NT>((net.nblocks ? net.conv_w : net.head_w) + lane, b0);
-#endif
+  constexpr size_t LAYER_W = (size_t)9 * (F / 32) * (F / 8) * 64;   // float4 per conv layer
   for (int blk = 0; blk < net.nblocks; ++blk) {
     const float4* w1 = net.conv_w + (size_t)(2 * blk) * LAYER_W;
     const float4* w2 = w1 + LAYER_W;
-    const float4* w3 = (blk + 1 < net.nblocks) ? w2 + LAYER_W : net.head_w;
     if (dbg && tid == 0 && blk == 1) dbg[9] = __builtin_readcyclecounter();
-    conv_mfma<F, NT, 9>(bufX, bufT, w1, w2, b0, b1, net.conv_ss + (size_t)(2 * blk) * 2 * F, F, false, nbr, wave, lane, (dbg && tid == 0 && blk == 1) ? dbg + 10 : nullptr);
+    conv_mfma<F, 9>(bufX, bufT, w1, net.conv_ss + (size_t)(2 * blk) * 2 * F, F, false, nbr, rh, nh, lane, (dbg && tid == 0 && blk == 1) ? dbg + 10 : nullptr);
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
     if (dbg && tid == 0 && blk == 1) dbg[12] = __builtin_readcyclecounter();
-    conv_mfma<F, NT, 9>(bufT, bufX, w2, w3, b1, b0, net.conv_ss + (size_t)(2 * blk + 1) * 2 * F, F, true, nbr, wave, lane);
+    conv_mfma<F, 9>(bufT, bufX, w2, net.conv_ss + (size_t)(2 * blk + 1) * 2 * F, F, true, nbr, rh, nh, lane);
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
     AZ_STAMP();
   }
   // ---- both 1x1 head convolutions + BN + ReLU as one F => HF GEMM (resnet.jl:80-81,86-87) ----
   // (padded head channels have zero weights, scale 0, shift 0)
-  conv_mfma<F, NT, 1>(bufX, bufT, net.head_w, nullptr, b0, b1, net.head_ss, net.HF, false, nbr, wave, lane);
+  conv_mfma<F, 1>(bufX, bufT, net.head_w, net.head_ss, net.HF, false, nbr, rh, nh, lane);
   __syncthreads();
   __builtin_amdgcn_s_setprio(0);
   AZ_STAMP();
