@@ -67,8 +67,15 @@ class Engine:
         check(lib().az_device_info(self._h, name, 256, C.byref(ncu), C.byref(mem)))
         return name.value.decode(), ncu.value, mem.value
 
-    def prof_enable(self, on=True):
-        check(lib().az_prof_enable(self._h, 1 if on else 0))
+    def prof_enable(self, on=True, classes=None):
+        """classes: iterable of kernel class names (KERNEL_CLASSES) to time; None = all"""
+        flag = 1 if on else 0
+        if on and classes:
+            mask = 0
+            for c in classes:
+                mask |= 1 << L.KERNEL_CLASSES.index(c)
+            flag |= mask << 1
+        check(lib().az_prof_enable(self._h, flag))
 
     def prof_reset(self):
         check(lib().az_prof_reset(self._h))

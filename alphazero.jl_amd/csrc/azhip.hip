@@ -106,6 +106,7 @@ struct az_engine {
   std::chrono::steady_clock::time_point t_begin;
   // profiling
   bool prof_on;
+  int prof_mask;                 // 0 = every kernel class, else bit per az_kernel_class
   std::vector<ProfRec> prof_pool;
   size_t prof_used;
   az_prof prof;
@@ -148,7 +149,7 @@ static int prof_flush(az_engine* e) {
   return AZ_OK;
 }
 static int prof_begin(az_engine* e, hipStream_t st, int cls, int64_t units) {
-  if (!e->prof_on) return AZ_OK;
+  if (!e->prof_on || (e->prof_mask && !((e->prof_mask >> cls) & 1))) return AZ_OK;
   if (e->prof_used == e->prof_pool.size()) AZCHK(prof_flush(e));
   ProfRec& r = e->prof_pool[e->prof_used];
   r.cls = cls;
@@ -157,8 +158,8 @@ static int prof_begin(az_engine* e, hipStream_t st, int cls, int64_t units) {
   HIPCHK(hipEventRecord(r.a, st));
   return AZ_OK;
 }
-static int prof_end(az_engine* e, hipStream_t st) {
-  if (!e->prof_on) return AZ_OK;
+static int prof_end(az_engine* e, hipStream_t st, int cls) {
+  if (!e->prof_on || (e->prof_mask && !((e->prof_mask >> cls) & 1))) return AZ_OK;
   HIPCHK(hipEventRecord(e->prof_pool[e->prof_used].b, st));
   e->prof_used++;
   return AZ_OK;
@@ -167,7 +168,7 @@ static int prof_end(az_engine* e, hipStream_t st) {
   do {                                                                      \
     AZCHK(prof_begin(e, st, cls, units));                                   \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, st, __VA_ARGS__); \
-    AZCHK(prof_end(e, st));                                                 \
+    AZCHK(prof_end(e, st, cls));                                            \
   } while (0)
 #define LAUNCH(e, cls, units, kern, grid, block, shmem, ...) LAUNCH_ON(e, (e)->stream, cls, units, kern, grid, block, shmem, __VA_ARGS__)
 
@@ -276,7 +277,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   az_engine* e = new (std::nothrow) az_engine();
   if (!e) return fail(AZ_ERR_HIP, "out of host memory");
   e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0;
-  e->net_loaded = false; e->running = false; e->prof_on = false; e->prof_used = 0;
+  e->net_loaded = false; e->running = false; e->prof_on = false; e->prof_mask = 0; e->prof_used = 0;
   memset(&e->prof, 0, sizeof e->prof);
   memset(&e->stats, 0, sizeof e->stats);
   int st = [&]() -> int {
@@ -989,6 +990,7 @@ extern "C" int az_prof_enable(az_engine* e, int32_t on) {
   ENGINE(e);
   AZCHK(prof_flush(e));
   e->prof_on = on != 0;
+  e->prof_mask = on > 1 ? (on >> 1) : 0;      // on = 1 | (class mask << 1): time only the selected classes
   return AZ_OK;
 }
 extern "C" int az_prof_reset(az_engine* e) {

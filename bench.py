@@ -62,9 +62,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--slots", type=int, default=4096)
     ap.add_argument("--sims", type=int, default=400)
-    ap.add_argument("--groups", type=int, default=1, help="interleaved slot groups = num_workers / batch_size (2 overlaps the tree kernels of one half-batch with the network of the other; default 1 keeps per-kernel timings clean)")
+    ap.add_argument("--groups", type=int, default=2, help="interleaved slot groups = num_workers / batch_size: 2 (default) overlaps the tree kernels of one half-batch with the network of the other, the reference's num_workers = 2 x batch_size; 1 = one 4096-leaf batch per wave")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not wrap launches in HIP events")
+    ap.add_argument("--prof-all", action="store_true", help="time every kernel class (default: only the dominant kernel, k_tower)")
     args = ap.parse_args()
 
     import torch
@@ -102,7 +103,7 @@ def main():
     s0 = eng.selfplay_stats()
     if not args.no_prof:
         eng.prof_reset()
-        eng.prof_enable(True)
+        eng.prof_enable(True, classes=None if args.prof_all else ("tower",))
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -136,9 +137,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Connect-Four self-play, %d sims/move, %d parallel games per GPU, ResNet 5x64 fp32 "
-                                   "(heads 32/32), cpuct 2, eps 0.25, alpha 1, PLSchedule([0,20,30],[1,1,.3]), reset_every 1; "
-                                   "step = one search wave (1 simulation per slot)" % (args.sims, args.slots),
-                       "slots_per_gpu": args.slots, "sims_per_move": args.sims, "parallelism": "dp%d (games sharded, no collective in the timed region)" % world,
+                                   "(heads 32/32), cpuct 2, eps 0.25, alpha 1, PLSchedule([0,20,30],[1,1,.3]), reset_every 1, num_workers/batch_size = %d; "
+                                   "step = one search wave (1 simulation per slot)" % (args.sims, args.slots, args.groups),
+                       "slots_per_gpu": args.slots, "sims_per_move": args.sims, "slot_groups": args.groups, "leaves_per_network_launch": args.slots // args.groups, "parallelism": "dp%d (games sharded, no collective in the timed region)" % world,
                        "device": dev_name, "compute_units": ncu},
             "sims_per_sec_per_gpu": sims / elapsed / world,
             "samples_per_sec": moves / elapsed,

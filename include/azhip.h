@@ -225,7 +225,8 @@ typedef struct {
   double ms[AZ_PROF_NUM];
   int64_t units[AZ_PROF_NUM];       /* boards (tower/heads) or slots processed */
 } az_prof;
-int az_prof_enable(az_engine* e, int32_t on);   /* wraps every launch in a HIP event pair */
+int az_prof_enable(az_engine* e, int32_t on);   /* 1: wrap every launch in a HIP event pair; 1 | (mask << 1):
+                                                   only the kernel classes whose bit is set in mask; 0: off */
 int az_prof_get(az_engine* e, az_prof* out);    /* synchronises, accumulates, returns totals */
 int az_prof_reset(az_engine* e);
 int az_device_info(az_engine* e, char* name, int32_t name_cap, int32_t* num_cu, int64_t* hbm_bytes);
