@@ -30,12 +30,27 @@ assert TOWER_FLOP + HEADS_FLOP == 31645952
 PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def cpu_baseline(blob, hp, nsims, roots=16, threads=None):
+def pmc_traffic(boards_per_launch):
+    """HBM bytes per k_tower launch from the committed PMC passes (profiles/r1/r1c_pmc_summary_groups1.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this workload at 4096 boards per launch; KB units,
+    FETCH doubled on gfx950 as MI355X_MICROARCH.md prescribes).  The write side (head features) scales with
+    the boards of a launch, the read side (weights, once per XCD L2) does not.  None if the file is absent."""
+    p = os.path.join(ROOT, "profiles", "r1", "r1c_pmc_summary_groups1.json")
+    try:
+        d = json.load(open(p))
+        k = [v for name, v in d.items() if "k_tower" in name][0]
+        return 2.0 * k["FETCH_SIZE"] * 1024.0 + k["WRITE_SIZE"] * 1024.0 * boards_per_launch / 4096.0
+    except Exception:
+        return None
+
+
+def cpu_baseline(blob, hp, nsims, roots=None, threads=None):
     """The oracle (a port, not the reference: Julia is absent) on the host cores: `roots` independent
     Connect-Four searches of `nsims` simulations each (one move of `roots` games) with the fp32 ResNet."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import azref as R
-    threads = threads or min(os.cpu_count() or 1, roots)
+    threads = threads or (os.cpu_count() or 1)
+    roots = roots or 24 * threads          # ~15 s of work at ~500 sims/s per core
     done = [0] * threads
 
     def work(t):
@@ -153,7 +168,7 @@ def main():
             out["roofline"] = {
                 "kernel": "k_tower<ConnectFour,64,false>", "bound": "mfma", "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(local_evals / max(tw["launches"], 1)),
                 "flop_per_board": TOWER_FLOP, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
                 "avg_boards_per_launch": local_evals / max(tw["launches"], 1),
                 "launches": tw["launches"],
