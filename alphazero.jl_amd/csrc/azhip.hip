@@ -235,9 +235,14 @@ extern "C" int az_engine_destroy(az_engine* e) {
   return AZ_OK;
 }
 
+template <class Gm, int F> static int set_kernel_attrs_f() {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
+  return AZ_OK;
+}
 template <class Gm> static int set_kernel_attrs() {
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<64>::BYTES));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<64>::BYTES));
+  AZCHK((set_kernel_attrs_f<Gm, 64>()));
+  AZCHK((set_kernel_attrs_f<Gm, 128>()));
   return AZ_OK;
 }
 
@@ -265,9 +270,9 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   if (c->reset_every < 0) return fail(AZ_ERR_BAD_ARG, "reset_every must be >= 0");
   if (!(c->prior_temperature >= 0.0)) return fail(AZ_ERR_BAD_ARG, "prior_temperature must be >= 0");
   if (c->oracle == AZ_ORACLE_RESNET) {
-    if (c->num_filters != 64) return fail(AZ_ERR_BAD_ARG, "num_filters = %d: this build instantiates the 64-filter tower only", c->num_filters);
+    if (c->num_filters != 64 && c->num_filters != 128) return fail(AZ_ERR_BAD_ARG, "num_filters = %d: this build instantiates the 64- and 128-filter towers", c->num_filters);
     int hf = c->num_policy_head_filters + c->num_value_head_filters;
-    if (c->num_policy_head_filters < 1 || c->num_value_head_filters < 1 || hf > 64) return fail(AZ_ERR_BAD_ARG, "head filters %d/%d unsupported (policy + value must be <= 64)", c->num_policy_head_filters, c->num_value_head_filters);
+    if (c->num_policy_head_filters < 1 || c->num_value_head_filters < 1 || hf > c->num_filters) return fail(AZ_ERR_BAD_ARG, "head filters %d/%d unsupported (policy + value must be <= num_filters)", c->num_policy_head_filters, c->num_value_head_filters);
     if (c->num_blocks < 0 || c->num_blocks > 64) return fail(AZ_ERR_BAD_ARG, "num_blocks out of range");
   }
   int ndev = 0;
@@ -324,7 +329,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &e->d_nodebuf, 512));
     // network buffers
     e->nn_cap = e->io_cap;
-    AZCHK(dalloc(e, &e->d_hfeat, (size_t)e->nn_cap * gi.P * 64, false));
+    AZCHK(dalloc(e, &e->d_hfeat, (size_t)e->nn_cap * gi.P * std::max(64, c->num_filters), false));
     AZCHK(dalloc(e, &e->d_X, (size_t)e->nn_cap * gi.C * gi.P)); AZCHK(dalloc(e, &e->d_A, (size_t)e->nn_cap * gi.A));
     AZCHK(dalloc(e, &e->d_P, (size_t)e->nn_cap * 16)); AZCHK(dalloc(e, &e->d_V, e->nn_cap)); AZCHK(dalloc(e, &e->d_Pinv, e->nn_cap));
     AZCHK(dalloc(e, &e->d_tmp_env, e->nn_cap)); AZCHK(dalloc(e, &e->d_iota, e->nn_cap)); AZCHK(dalloc(e, &e->d_ntmp, 1));
@@ -358,7 +363,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
         HIPCHK(hipEventCreateWithFlags(&e->ev_tree[g], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&e->ev_net[g], hipEventDisableTiming));
       }
-      AZCHK(dalloc(e, &e->g_hfeat[g], (size_t)Gh * gi.P * 64, false));
+      AZCHK(dalloc(e, &e->g_hfeat[g], (size_t)Gh * gi.P * std::max(64, c->num_filters), false));
       e->ngroups = g + 1;
     }
     // search parameters
@@ -588,18 +593,25 @@ extern "C" int az_net_get_params(const az_engine* e, float* blob, int64_t n) {
 }
 
 // launches tower + heads on `n` boards (device count in n_ptr when n < 0)
-template <class Gm, bool FROM_PLANES>
-static int launch_net(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
-                      const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
+template <class Gm, int F, bool FROM_PLANES>
+static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
+                        const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
   constexpr int TB = TOWER_ROWS / Gm::P;
   const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
   if (gt == 0) return AZ_OK;
-  LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, 64, FROM_PLANES>), gt, 256, TowerLds<64>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
+  LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, F, FROM_PLANES>), gt, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
   if (e->net.hd_ok)
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, 64>), (n_max + 31) / 32, 64 * 3, 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, F>), (n_max + 31) / 32, 64 * (F / 32 + 1), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
   else
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads<Gm, 64>), gh, 320, 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads<Gm, F>), gh, 4 * (F + 16), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
   return AZ_OK;
+}
+// launches tower + heads on `n` boards (device count in n_ptr when given)
+template <class Gm, bool FROM_PLANES>
+static int launch_net(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
+                      const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
+  if (e->cfg.num_filters == 128) return launch_net_f<Gm, 128, FROM_PLANES>(e, st, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
+  return launch_net_f<Gm, 64, FROM_PLANES>(e, st, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
 }
 
 extern "C" int az_net_forward(az_engine* e, const float* X, const float* A, int32_t N, float* P, float* V, float* Pinv) {
@@ -646,6 +658,23 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
 // ------------------------------------------------------------------------------- search waves
 // One wave = one run_simulation! for every active slot: select -> gather misses -> oracle ->
 // expand + backup.  Nothing is read back by the host.
+template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split) {
+  constexpr int L = Gm::APAD, TB = TOWER_ROWS / Gm::P;
+  const DView& v = e->gv[g];
+  hipStream_t st = e->gs[g], sn = e->gt[g];
+  const int G = v.G;
+  if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
+  LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower<Gm, F, false>), (G + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
+  if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
+  if (e->net.hd_ok)
+    LAUNCH_ON(e, st, AZ_K_HEADS, G, (k_heads_mfma<Gm, F>), (G + 31) / 32, 64 * (F / 32 + 1), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
+  else
+    LAUNCH_ON(e, st, AZ_K_HEADS, G, (k_heads<Gm, F>), (G + 3) / 4, 4 * (F + 16), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
+  return AZ_OK;
+}
+template <class Gm> static int wave_net(az_engine* e, int g, bool split) {
+  return e->cfg.num_filters == 128 ? wave_net_f<Gm, 128>(e, g, split) : wave_net_f<Gm, 64>(e, g, split);
+}
 template <class Gm> static int wave(az_engine* e, int ngroups_active) {
   constexpr int L = Gm::APAD;
   for (int g = 0; g < ngroups_active; ++g) {
@@ -657,14 +686,7 @@ template <class Gm> static int wave(az_engine* e, int ngroups_active) {
     LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_select<Gm>), gb, 256, 0, v, e->p);
     LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact, 1, 1024, 0, v);
     if (e->cfg.oracle == AZ_ORACLE_RESNET) {
-      constexpr int TB = TOWER_ROWS / Gm::P;
-      if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
-      LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower<Gm, 64, false>), (G + TB - 1) / TB, 256, TowerLds<64>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
-      if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
-      if (e->net.hd_ok)
-        LAUNCH_ON(e, st, AZ_K_HEADS, G, (k_heads_mfma<Gm, 64>), (G + 31) / 32, 64 * 3, 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
-      else
-        LAUNCH_ON(e, st, AZ_K_HEADS, G, (k_heads<Gm, 64>), (G + 3) / 4, 320, 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
+      AZCHK((wave_net<Gm>(e, g, split)));
     } else {
       LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p);
     }
@@ -967,7 +989,7 @@ extern "C" int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, 
 extern "C" int az_debug_tower_timeline(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
   ENGINE(e);
   if (!e->net_loaded || n < 1 || n > e->nn_cap) return fail(AZ_ERR_BAD_ARG, "bad n / no net");
-  if (e->cfg.game != AZ_GAME_CONNECT_FOUR) return fail(AZ_ERR_BAD_ARG, "connect-four only");
+  if (e->cfg.game != AZ_GAME_CONNECT_FOUR || e->cfg.num_filters != 64) return fail(AZ_ERR_BAD_ARG, "connect-four with 64 filters only");
   const int nb = (n + 2) / 3;
   if (cap < (int64_t)nb * 16) return fail(AZ_ERR_CAPACITY, "need %d words", nb * 16);
   unsigned long long* d = nullptr;
@@ -978,7 +1000,7 @@ extern "C" int az_debug_tower_timeline(az_engine* e, int32_t n, unsigned long lo
   NetDev nd = e->net;
   for (int rep = 0; rep < 2; ++rep) {
     nd.dbg = rep ? d : nullptr;
-    hipLaunchKernelGGL((k_tower<ConnectFour, 64, false>), dim3(nb), dim3(256), TowerLds<64>::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat);
+    hipLaunchKernelGGL((k_tower<ConnectFour, 64, false>), dim3(nb), dim3(TowerCfg<64>::THREADS), TowerLds<64>::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat);
   }
   HIPCHK(hipMemcpyAsync(out, d, sizeof(unsigned long long) * nb * 16, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));

@@ -73,22 +73,27 @@ __device__ __forceinline__ void load_b_tap(const float4* __restrict__ wt, float4
 template <int F>
 __device__ __forceinline__ void mfma_tap(const float4 (&af)[2], const float* __restrict__ arow0,
                                          const float* __restrict__ arow1, const float4 (&b)[F / 8], f32x16 (&acc)[2]) {
-  float4 a0[F / 8], a1[F / 8];
-  a0[0] = af[0];
-  a1[0] = af[1];
+  // A is consumed in chunks of 8 float4 per row (32 channels) so that at most 64 VGPRs hold activations
 #pragma unroll
-  for (int jq = 1; jq < F / 8; ++jq) { a0[jq] = *(const float4*)(arow0 + jq * 4); a1[jq] = *(const float4*)(arow1 + jq * 4); }
-  // consecutive MFMAs alternate between the two accumulators (each still sees x,y,z,w of jq = 0.. in order)
+  for (int c0 = 0; c0 < F / 8; c0 += 8) {
+    float4 a0[8], a1[8];
 #pragma unroll
-  for (int jq = 0; jq < F / 8; ++jq) {
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].x, b[jq].x, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].x, b[jq].x, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].y, b[jq].y, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].y, b[jq].y, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].z, b[jq].z, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].z, b[jq].z, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].w, b[jq].w, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].w, b[jq].w, acc[1], 0, 0, 0);
+    for (int jq = 0; jq < 8; ++jq) {
+      if (c0 == 0 && jq == 0) { a0[0] = af[0]; a1[0] = af[1]; }
+      else { a0[jq] = *(const float4*)(arow0 + (c0 + jq) * 4); a1[jq] = *(const float4*)(arow1 + (c0 + jq) * 4); }
+    }
+    // consecutive MFMAs alternate between the two accumulators (each still sees its k order unchanged)
+#pragma unroll
+    for (int jq = 0; jq < 8; ++jq) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].x, b[c0 + jq].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].x, b[c0 + jq].x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].y, b[c0 + jq].y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].y, b[c0 + jq].y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].z, b[c0 + jq].z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].z, b[c0 + jq].z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jq].w, b[c0 + jq].w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jq].w, b[c0 + jq].w, acc[1], 0, 0, 0);
+    }
   }
 }
 template <int F, int NTAP>
@@ -96,7 +101,7 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* _
                                           const float4* __restrict__ wpk, const float* __restrict__ ss, int out_ch,
                                           bool residual, const int (&nbr)[2][9], int rh, int nh, int lane,
                                           unsigned long long* stamp = nullptr) {
-  static_assert(F == 64, "wave tiling (2 row halves x 2 channel halves) is written for 64 filters");
+  static_assert(F % 32 == 0 && F >= 64, "wave tiling: 2 row halves x F/32 channel groups");
   static_assert(NTAP == 1 || NTAP == 9, "tap count");
   constexpr int STRIDE = TowerLds<F>::STRIDE;
   constexpr int JQ = F / 8, NT = F / 32;
@@ -168,8 +173,12 @@ __device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* _
 
 // FROM_PLANES = false: inputs are the leaf states of the evaluation batch (encode fused);
 // FROM_PLANES = true : inputs are Flux-layout planes X[n][C][H][W] (Network.forward seam).
+template <int F> struct TowerCfg {
+  static constexpr int WAVES = 2 * (F / 32);        // (row half, 32-channel group)
+  static constexpr int THREADS = 64 * WAVES;        // 256 for F = 64 (2 workgroups per CU), 512 for F = 128 (1 per CU)
+};
 template <class Gm, int F, bool FROM_PLANES>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(TowerCfg<F>::THREADS, 2)
 k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
         const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
   constexpr int P = Gm::P, W = Gm::W, H = Gm::H, C = Gm::C;
@@ -182,6 +191,7 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
   const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
   const int board0 = blockIdx.x * TB;
   if (board0 >= n) return;
+  constexpr int NTHR = TowerCfg<F>::THREADS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long* dbg = net.dbg ? net.dbg + (size_t)blockIdx.x * 16 : nullptr;
   int dbgi = 0;
@@ -195,7 +205,7 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
 
   // ---- stage the input planes in the (still unused) T buffer: [128 rows + zero row][C] -------
   float* planes = bufT;
-  for (int i = tid; i < (TOWER_ROWS + 1) * C; i += 256) {
+  for (int i = tid; i < (TOWER_ROWS + 1) * C; i += NTHR) {
     const int row = i / C, c = i % C;
     const int b = row / P, q = row % P;
     float val = 0.0f;
@@ -205,11 +215,12 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
     }
     planes[i] = val;
   }
-  for (int i = tid; i < STRIDE; i += 256) { bufX[TOWER_ROWS * STRIDE + i] = 0.0f; }
+  for (int i = tid; i < STRIDE; i += NTHR) { bufX[TOWER_ROWS * STRIDE + i] = 0.0f; }
   // tap-shifted row of this lane's A row (row 128 = zeros for out-of-board taps)
+  const int srt = wave & 3, sng = wave >> 2;     // stem tiling: 32-row tile, pair of 32-channel tiles
   int nrow[9];
   {
-    const int row = 32 * wave + (lane & 31);
+    const int row = 32 * srt + (lane & 31);
     const int b = row / P, q = row % P, x = q % W, y = q / W;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -223,7 +234,7 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
   // ---- stem: Conv(3x3, C=>F) + BN + ReLU (resnet.jl:75-77) on the same MFMA: K = 9C padded to even,
   //      k = t*C + c, lanes 0-31 carry k = j, lanes 32-63 k = K2 + j (the paired order of the contract)
   {
-    constexpr int NTS = F / 32, KK = 9 * C, K2 = (KK + 1) / 2;
+    constexpr int NTS = 2, KK = 9 * C, K2 = (KK + 1) / 2;
     const int h = lane >> 5;
     f32x16 acc[NTS];
 #pragma unroll
@@ -234,10 +245,9 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
 #pragma unroll
     for (int t = 0; t < NTS; ++t)
 #pragma unroll
-      for (int j = 0; j < K2; ++j) bw[t][j] = net.stem_w[(size_t)(t * K2 + j) * 64 + lane];
+      for (int j = 0; j < K2; ++j) bw[t][j] = net.stem_w[(size_t)((sng * 2 + t) * K2 + j) * 64 + lane];
 #pragma unroll
     for (int j = 0; j < K2; ++j) {
-      constexpr int dummy = 0; (void)dummy;
       const int k0 = j, k1 = K2 + j;
       const int a0 = nrow[k0 / C] * C + k0 % C;
       const int a1 = (k1 < KK) ? nrow[(k1 < KK ? k1 : 0) / C] * C + k1 % C : TOWER_ROWS * C;
@@ -247,11 +257,11 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
     }
 #pragma unroll
     for (int t = 0; t < NTS; ++t) {
-      const int col = t * 32 + (lane & 31);
+      const int col = (sng * 2 + t) * 32 + (lane & 31);
       const float sc = net.stem_ss[col], sh = net.stem_ss[F + col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int row = 32 * srt + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = az_fmaf(acc[t][r], sc, sh);
         bufX[row * STRIDE + col] = v > 0.0f ? v : 0.0f;
       }
@@ -259,7 +269,7 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
   }
   AZ_STAMP();
   // conv wave tiling: (rh, nh) = (wave >> 1, wave & 1); tap-shifted LDS offsets of this lane's two A rows
-  const int rh = wave >> 1, nh = wave & 1;
+  const int rh = wave / (F / 32), nh = wave % (F / 32);
   int nbr[2][9];
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
@@ -274,7 +284,7 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
   }
   __syncthreads();
   // the T buffer's zero row (the planes lived there until now)
-  for (int i = tid; i < STRIDE; i += 256) bufT[TOWER_ROWS * STRIDE + i] = 0.0f;
+  for (int i = tid; i < STRIDE; i += NTHR) bufT[TOWER_ROWS * STRIDE + i] = 0.0f;
   __syncthreads();
 
   // ---- residual tower (resnet.jl:53-63,78) ---------------------------------------------------
@@ -303,7 +313,7 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
     const int HF = net.HF;
     const int nb = (n - board0) < TB ? (n - board0) : TB;
     const int total = nb * P * (HF / 4);
-    for (int i = tid; i < total; i += 256) {
+    for (int i = tid; i < total; i += NTHR) {
       const int row = i / (HF / 4), c4 = i % (HF / 4);
       const float4 v4 = *(const float4*)(bufT + row * STRIDE + c4 * 4);
       *(float4*)(hfeat + ((size_t)board0 * P + row) * HF + c4 * 4) = v4;
@@ -314,15 +324,15 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
 #undef AZ_STAMP
 }
 
-// Dense heads, softmax, tanh, forward_normalized.  HB boards per 320-thread workgroup; thread
+// Dense heads, softmax, tanh, forward_normalized.  HB boards per 4(F+16)-thread workgroup; thread
 // (b, o): o < F -> value hidden unit, F <= o < F + A -> policy logit.
 template <class Gm, int F>
-__global__ void __launch_bounds__(320)
+__global__ void __launch_bounds__(4 * (F + 16))
 k_heads(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
         const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ Amask,
         const float* __restrict__ hfeat, float* __restrict__ Pout, float* __restrict__ Vout,
         float* __restrict__ Pinv, int pstride) {
-  constexpr int P = Gm::P, A = Gm::A, HB = 4, PER = 80;       // 64 + up to 16 outputs per board
+  constexpr int P = Gm::P, A = Gm::A, HB = 4, PER = F + 16;   // F value-hidden units + up to 16 logits per board
   static_assert(F + Gm::APAD <= PER || F + A <= PER, "thread map");
   __shared__ float s_logit[HB][16];
   __shared__ float s_vh[HB][F];

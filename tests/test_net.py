@@ -95,15 +95,20 @@ def test_param_count_matches_reference_doc():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("game,nblocks,n", [(R.C4, 5, 64), (R.C4, 1, 7), (R.TTT, 2, 33), (R.MANCALA, 2, 20)])
-def test_hip_forward_bit_exact_vs_oracle(game, nblocks, n):
+@pytest.mark.parametrize("game,nblocks,n,F,heads", [(R.C4, 5, 64, 64, (32, 32)), (R.C4, 1, 7, 64, (32, 32)), (R.TTT, 2, 33, 64, (32, 32)),
+                                                      (R.MANCALA, 2, 20, 64, (32, 32)), (R.C4, 2, 40, 128, (32, 32)),
+                                                      (R.C4, 1, 9, 64, (2, 1)), (R.TTT, 1, 5, 128, (16, 8))])
+def test_hip_forward_bit_exact_vs_oracle(game, nblocks, n, F, heads):
+    """F = 128 is the shipped connect-four network (games/connect-four/params.jl:7-13); heads (2, 1) are the
+    ResNetHP defaults (resnet.jl:30-37) and take the VALU dense-head kernel."""
     import azhip
-    hp = ResNetHP(num_blocks=nblocks, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    npf, nvf = heads
+    hp = ResNetHP(num_blocks=nblocks, num_filters=F, num_policy_head_filters=npf, num_value_head_filters=nvf)
     blob = random_params(game, hp, seed=2026)
     envs = random_positions(game, n, 3)
     X, A = batch_of(game, envs)
     with azhip.Engine(game=game, oracle=azhip.ORACLE_RESNET, num_workers=8, batch_size=8, num_iters_per_turn=8,
-                      num_blocks=nblocks, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32) as e:
+                      num_blocks=nblocks, num_filters=F, num_policy_head_filters=npf, num_value_head_filters=nvf) as e:
         e.net_set_params(blob)
         assert np.array_equal(e.net_get_params(), blob)
         P, V, Pinv = e.net_forward(X, A)
@@ -111,7 +116,7 @@ def test_hip_forward_bit_exact_vs_oracle(game, nblocks, n):
         Pk, Vk = e.net_evaluate_keys(keys)
         Xd, Ad = e.encode(keys)
     assert np.array_equal(Xd, X) and np.array_equal(Ad, A)          # vectorize_state / actions_mask twins
-    Pr, Vr, Pir = R.net_forward_normalized(game, (nblocks, 64, 32, 32), blob, X, A)
+    Pr, Vr, Pir = R.net_forward_normalized(game, (nblocks, F, npf, nvf), blob, X, A)
     Pt, Vt, Pit = torch_forward_normalized(game, hp, blob, X, A)
     # tolerance leg (BASELINE.json): 1e-5 vs the fp64 restatement
     assert np.abs(P - Pt).max() < TOL and np.abs(V - Vt).max() < TOL and np.abs(Pinv - Pit).max() < TOL

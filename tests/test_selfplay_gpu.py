@@ -10,18 +10,19 @@ import azref as R
 pytestmark = pytest.mark.gpu
 
 
-def _hp(nblocks):
+def _hp(nblocks, F=64):
     from azhip import ResNetHP
-    return ResNetHP(num_blocks=nblocks, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    return ResNetHP(num_blocks=nblocks, num_filters=F, num_policy_head_filters=32, num_value_head_filters=32)
 
 
-@pytest.mark.parametrize("game,spec,ngames,workers,batch,nsims", [(R.C4, "ConnectFourSpec", 12, 6, 6, 40), (R.TTT, "TicTacToeSpec", 10, 4, 4, 24),
-                                                                  (R.MANCALA, "MancalaSpec", 6, 3, 3, 24), (R.C4, "ConnectFourSpec", 12, 6, 3, 40)])
-def test_simulate_with_resnet_matches_oracle(game, spec, ngames, workers, batch, nsims):
+@pytest.mark.parametrize("game,spec,ngames,workers,batch,nsims,F", [(R.C4, "ConnectFourSpec", 12, 6, 6, 40, 64), (R.TTT, "TicTacToeSpec", 10, 4, 4, 24, 64),
+                                                                    (R.MANCALA, "MancalaSpec", 6, 3, 3, 24, 64), (R.C4, "ConnectFourSpec", 12, 6, 3, 40, 64),
+                                                                    (R.C4, "ConnectFourSpec", 6, 4, 2, 24, 128)])
+def test_simulate_with_resnet_matches_oracle(game, spec, ngames, workers, batch, nsims, F):
     """Simulator / simulate (simulations.jl:179-244) with MctsPlayer + ResNet, vs the oracle's simulate."""
     import azhip
     gspec = getattr(azhip, spec)()
-    hp = _hp(2)
+    hp = _hp(2, F)
     nn = azhip.ResNet(gspec, hp, seed=11)
     mp = azhip.MctsParams(num_iters_per_turn=nsims, dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0, cpuct=2.0,
                           temperature=azhip.PLSchedule([0, 6, 10], [1.0, 1.0, 0.3]), gamma=1.0)
@@ -34,7 +35,7 @@ def test_simulate_with_resnet_matches_oracle(game, spec, ngames, workers, batch,
     assert count[0] == ngames == len(res)
     games, moves, nm = R.simulate(game, R.ORACLE_NET, ngames, workers, nsims, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0,
                                   temp_xs=(0, 6, 10), temp_ys=(1.0, 1.0, 0.3), reset_every=2, seed=5,
-                                  net=(2, 64, 32, 32, nn.params()))
+                                  net=(2, F, 32, 32, nn.params()))
     from azhip.trace import trace_from_records
     for i in range(ngames):
         t = res[i]["trace"]

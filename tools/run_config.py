@@ -17,12 +17,13 @@ ap.add_argument("--waves", type=int, default=1600)
 ap.add_argument("--blocks", type=int, default=5)
 ap.add_argument("--games", type=int, default=-1)
 ap.add_argument("--groups", type=int, default=1)
+ap.add_argument("--filters", type=int, default=64)
 a = ap.parse_args()
 gid = {"connect-four": 0, "tictactoe": 1, "mancala": 2}[a.game]
-hp = ResNetHP(a.blocks, 64, (3, 3), 32, 32)
+hp = ResNetHP(a.blocks, a.filters, (3, 3), 32, 32)
 e = azhip.Engine(game=gid, oracle=azhip.ORACLE_RESNET, num_workers=a.slots, batch_size=a.slots // a.groups, num_iters_per_turn=a.sims, cpuct=2.0,
                  dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1,
-                 num_blocks=a.blocks, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32,
+                 num_blocks=a.blocks, num_filters=a.filters, num_policy_head_filters=32, num_value_head_filters=32,
                  max_moves_per_game=256 if gid == 2 else 0)
 e.net_set_params(random_params(gid, hp))
 e.selfplay_begin(a.games, 0)
