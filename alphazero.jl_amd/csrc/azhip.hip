@@ -85,6 +85,7 @@ struct az_engine {
   hipEvent_t ev_tree[AZ_MAX_GROUPS], ev_net[AZ_MAX_GROUPS];
   float* g_hfeat[AZ_MAX_GROUPS];
   std::vector<void*> allocs;
+  std::vector<void*> net_allocs;   // device copies of the packed network (replaced by az_net_set_params)
   // network
   bool net_loaded;
   std::vector<float> blob;
@@ -229,6 +230,7 @@ extern "C" int az_engine_destroy(az_engine* e) {
   }
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto& r : e->prof_pool) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
+  for (void* q : e->net_allocs) (void)hipFree(q);
   for (void* q : e->allocs) (void)hipFree(q);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -559,9 +561,15 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
       d[1] = o < A ? pol_w[(4 * i + 2 + hh) * L + o] : 0.0f;
     }
   }
+  AZCHK(sync_all(e));
+  for (void* q : e->net_allocs) (void)hipFree(q);
+  e->net_allocs.clear();
+  e->net_loaded = false;
   auto up = [&](const std::vector<float>& h, const float** d) -> int {
     float* q = nullptr;
     AZCHK(dalloc(e, &q, h.size(), false));
+    e->allocs.pop_back();
+    e->net_allocs.push_back(q);
     HIPCHK(hipMemcpyAsync(q, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
     *d = q;
     return AZ_OK;
@@ -1004,6 +1012,8 @@ extern "C" int az_debug_tower_timeline(az_engine* e, int32_t n, unsigned long lo
   }
   HIPCHK(hipMemcpyAsync(out, d, sizeof(unsigned long long) * nb * 16, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->allocs.pop_back();
+  (void)hipFree(d);
   return AZ_OK;
 }
 

@@ -44,30 +44,34 @@ def pmc_traffic(boards_per_launch):
         return None
 
 
-def cpu_baseline(blob, hp, nsims, roots=None, threads=None):
-    """The oracle (a port, not the reference: Julia is absent) on the host cores: `roots` independent
-    Connect-Four searches of `nsims` simulations each (one move of `roots` games) with the fp32 ResNet."""
+def cpu_baseline(blob, hp, nsims, seconds=12.0, threads=None):
+    """The oracle (a port, not the reference: Julia is absent) on the host cores: independent Connect-Four
+    searches of `nsims` simulations each (= one move of a game) with the fp32 ResNet, one search at a time per
+    thread, started until `seconds` have elapsed (bounded sample: the default bench stays within minutes)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import azref as R
-    threads = threads or (os.cpu_count() or 1)
-    roots = roots or 24 * threads          # ~15 s of work at ~500 sims/s per core
+    threads = threads or min(os.cpu_count() or 1, 32)
     done = [0] * threads
+    roots = [0] * threads
+    R.lib()
+    t0 = time.perf_counter()
 
     def work(t):
-        for r in range(t, roots, threads):
+        r = t
+        while time.perf_counter() - t0 < seconds:
             m = R.Mcts(R.C4, oracle=R.ORACLE_NET, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0,
                        net=(hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters, blob))
             m.explore(R.Game(R.C4), nsims, seed=1, game_id=r, move=0)
             done[t] += m.total_simulations
-    R.lib()
-    t0 = time.perf_counter()
+            roots[t] += 1
+            r += threads
     ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
     [t.start() for t in ths]
     [t.join() for t in ths]
     dt = time.perf_counter() - t0
     return {"value": sum(done) / dt, "unit": "sims/s", "cores": threads, "kind": "port",
-            "sample": "%d Connect-Four roots x %d sims (one move of %d games), ResNet 5x64 fp32, %d threads, %.1f s"
-                      % (roots, nsims, roots, threads, dt)}
+            "sample": "%d Connect-Four searches x %d sims (one move each), ResNet 5x64 fp32, %d threads, %.1f s"
+                      % (sum(roots), nsims, threads, dt)}
 
 
 def main():

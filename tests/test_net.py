@@ -150,3 +150,24 @@ def test_hip_matches_committed_golden():
         Pk, Vk = e.net_evaluate_keys(z["keys"])
     assert np.array_equal(P, z["P"]) and np.array_equal(V, z["V"]) and np.array_equal(Pinv, z["Pinv"])
     assert np.array_equal(Pk, z["P"]) and np.array_equal(Vk, z["V"])
+
+
+@pytest.mark.gpu
+def test_set_params_twice_replaces_the_network():
+    """Network.copy per self-play phase (training.jl:278-279) re-uploads weights: the second upload wins."""
+    import azhip
+    hp = ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    b1, b2 = random_params(R.C4, hp, seed=1), random_params(R.C4, hp, seed=2)
+    X, A = batch_of(R.C4, random_positions(R.C4, 5, 9))
+    with azhip.Engine(game=0, oracle=azhip.ORACLE_RESNET, num_workers=4, batch_size=4, num_iters_per_turn=4,
+                      num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32) as e:
+        with pytest.raises(azhip.AzError):
+            e.net_forward(X, A)                      # no parameters yet
+        e.net_set_params(b1)
+        P1, V1, _ = e.net_forward(X, A)
+        e.net_set_params(b2)
+        P2, V2, _ = e.net_forward(X, A)
+        with pytest.raises(azhip.AzError):
+            e.net_set_params(b1[:-1])                # wrong blob size
+    assert np.array_equal(P1, R.net_forward_normalized(R.C4, (1, 64, 32, 32), b1, X, A)[0])
+    assert np.array_equal(P2, R.net_forward_normalized(R.C4, (1, 64, 32, 32), b2, X, A)[0]) and not np.array_equal(P1, P2)

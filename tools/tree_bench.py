@@ -1,0 +1,33 @@
+"""Tree kernels alone (NN-free hash oracle) at increasing slot counts: HIP-event time per kernel class and the
+algorithmic HBM bytes of SURVEY.md §8(d) (148 B per traversed node + per-leaf terms without the network part)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "alphazero.jl_amd"))
+import azhip  # noqa: E402
+
+for G in (4096, 65536, 262144, 1048576):
+    nsims, waves = 200, 400
+    e = azhip.Engine(game=0, oracle=azhip.ORACLE_HASH, num_workers=G, batch_size=G, num_iters_per_turn=nsims, cpuct=2.0,
+                     dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, reset_every=1, max_nodes_per_slot=nsims * 3)
+    e.selfplay_begin(-1, 0)
+    e.selfplay_step(100)
+    s0 = e.selfplay_stats()
+    e.prof_reset(); e.prof_enable(True)
+    e.selfplay_step(waves)
+    s1 = e.selfplay_stats()
+    p = e.prof_get()
+    e.selfplay_end()
+    sims = s1.simulations - s0.simulations
+    trav = s1.nodes_traversed - s0.nodes_traversed
+    evals = s1.leaf_evals - s0.leaf_evals
+    d = trav / sims
+    sel_bytes = 148 * trav + 16 * sims          # probes + node reads + path (per traversed node), final probe miss
+    exp_bytes = 160 * evals + 12 * trav + 32 * evals   # node write + W,N read-modify-write per path step + oracle answer read
+    print("G=%7d depth %.2f | select %.1f us/wave %.0f GB/s | expand+backup %.1f us/wave %.0f GB/s | compact %.1f us | synth %.1f us | %.1f M sims/s tree-only"
+          % (G, d, 1e3 * p["select"]["ms"] / waves, sel_bytes / (p["select"]["ms"] * 1e-3) / 1e9,
+             1e3 * p["expand"]["ms"] / waves, exp_bytes / (p["expand"]["ms"] * 1e-3) / 1e9,
+             1e3 * p["compact"]["ms"] / waves, 1e3 * p["synth"]["ms"] / waves,
+             sims / (sum(v["ms"] for v in p.values()) * 1e-3) / 1e6))
+    e.close()
