@@ -317,6 +317,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &v.leaf_kind, G)); AZCHK(dalloc(e, &v.leaf_depth, G)); AZCHK(dalloc(e, &v.leaf_env, G));
     AZCHK(dalloc(e, &v.leaf_ins, G)); AZCHK(dalloc(e, &v.eidx, G)); AZCHK(dalloc(e, &v.eval_slots, G));
     AZCHK(dalloc(e, &v.n_eval, AZ_MAX_GROUPS));
+    AZCHK(dalloc(e, &v.chunk_cnt, (size_t)(G + 1023) / 1024 + AZ_MAX_GROUPS));
     AZCHK(dalloc(e, &v.Pout, (size_t)std::max(G, 1) * gi.APAD)); AZCHK(dalloc(e, &v.Vout, G));
     AZCHK(dalloc(e, &v.trace, (size_t)G * v.max_moves)); AZCHK(dalloc(e, &v.grec, G));
     AZCHK(dalloc(e, &v.finished, G)); AZCHK(dalloc(e, &v.err, 1)); AZCHK(dalloc(e, &v.stat, 8));
@@ -352,7 +353,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       gv.worker_sim_id += o; gv.tot_sims += o; gv.tot_trav += o; gv.eta += o * gi.APAD;
       gv.ht += o * hs; gv.nodes += o * (size_t)cap * gi.node_bytes; gv.path += o * v.max_depth;
       gv.leaf_kind += o; gv.leaf_depth += o; gv.leaf_env += o; gv.leaf_ins += o; gv.eidx += o; gv.eval_slots += o;
-      gv.n_eval += g; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
+      gv.n_eval += g; gv.chunk_cnt += (o + 1023) / 1024 + g; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;
       if (ng == 1) { e->gs[g] = e->gt[g] = e->stream; }
       else {
@@ -692,7 +693,8 @@ template <class Gm> static int wave(az_engine* e, int ngroups_active) {
     const int G = v.G;
     const int gb = (G * L + 255) / 256;
     LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_select<Gm>), gb, 256, 0, v, e->p);
-    LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact, 1, 1024, 0, v);
+    LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact_count, (G + 1023) / 1024, 1024, 0, v);
+    LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact_assign, (G + 1023) / 1024, 1024, 0, v);
     if (e->cfg.oracle == AZ_ORACLE_RESNET) {
       AZCHK((wave_net<Gm>(e, g, split)));
     } else {

@@ -55,6 +55,7 @@ struct DView {
   int* eidx;              // slot -> index in the evaluation batch
   int* eval_slots;        // evaluation batch -> slot
   int* n_eval;            // device scalar
+  int* chunk_cnt;         // [ceil(G/1024)] new leaves per 1024-slot chunk (compaction)
   float* Pout;            // [n_eval][APAD] masked-normalised priors, full width
   float* Vout;            // [n_eval]
   az_move_rec* trace;     // [G][max_moves]
@@ -204,44 +205,66 @@ __global__ void __launch_bounds__(256) k_select(DView v, DParams p) {
   }
 }
 
-// compaction of the slots whose simulation ended on an unseen state -> evaluation batch,
-// ascending slot order (what Batchifier.launch_server collects, src/batchifier.jl:47-81)
-__global__ void __launch_bounds__(1024) k_compact(DView v) {
+// Compaction of the slots whose simulation ended on an unseen state -> evaluation batch in ascending slot
+// order (what Batchifier.launch_server collects, src/batchifier.jl:47-81).  Two passes over 1024-slot chunks so
+// that it scales to any slot count: k_compact_count leaves each slot's rank inside its chunk in eidx[] and the
+// chunk total in chunk_cnt[]; k_compact_assign adds the totals of the chunks before it.
+__global__ void __launch_bounds__(1024) k_compact_count(DView v) {
   __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
-  __shared__ int wsum[16];
-  __shared__ int total;
-  const int per = (v.G + 1023) / 1024;
-  const int s0 = threadIdx.x * per;
-  int cnt = 0, sims = 0, trav = 0;
-  for (int i = 0; i < per; ++i) {
-    int s = s0 + i;
-    if (s < v.G) {
-      const int k = v.leaf_kind[s];
-      if (k == LEAF_NEW) cnt++;
-      if (k != LEAF_NONE) { sims++; trav += v.leaf_depth[s]; }
+  __shared__ int wsum[16], wsims[16], wtrav[16];
+  const int s = blockIdx.x * 1024 + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int kind = s < v.G ? v.leaf_kind[s] : LEAF_NONE;
+  const bool isnew = kind == LEAF_NEW;
+  const unsigned long long bal = __ballot(isnew);
+  const int rank = __popcll(bal & ((1ULL << lane) - 1ULL));
+  // statistics of the wave: simulations (src/mcts.jl:242) and traversed nodes (src/mcts.jl:222)
+  int sims = kind != LEAF_NONE ? 1 : 0, trav = kind != LEAF_NONE ? v.leaf_depth[s] : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sims += __shfl_down(sims, o); trav += __shfl_down(trav, o); }
+  if (lane == 0) { wsum[w] = __popcll(bal); wsims[w] = sims; wtrav[w] = trav; }
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += wsum[i];
+  if (s < v.G) v.eidx[s] = isnew ? base + rank : -1;
+  if (threadIdx.x == 0) {
+    int tot = 0, ts = 0, tt = 0;
+    for (int i = 0; i < 16; ++i) { tot += wsum[i]; ts += wsims[i]; tt += wtrav[i]; }
+    v.chunk_cnt[blockIdx.x] = tot;
+    if (ts) {                                   // one atomic pair per 1024 slots
+      atomicAdd((unsigned long long*)&v.stat[0], (unsigned long long)ts);
+      atomicAdd((unsigned long long*)&v.stat[1], (unsigned long long)tt);
     }
   }
-  if (sims) {
-    atomicAdd((unsigned long long*)&v.stat[0], (unsigned long long)sims);
-    atomicAdd((unsigned long long*)&v.stat[1], (unsigned long long)trav);
-  }
-  int x = cnt;                                       // inclusive scan inside the wavefront
+}
+__global__ void __launch_bounds__(1024) k_compact_assign(DView v) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ int red[16];
+  __shared__ int s_base, s_total;
+  const int nchunks = (v.G + 1023) / 1024;
+  // exclusive sum of the chunk totals before this chunk (and the grand total in chunk 0)
+  int before = 0, all = 0;
+  for (int c = threadIdx.x; c < nchunks; c += 1024) { const int x = v.chunk_cnt[c]; all += x; if (c < (int)blockIdx.x) before += x; }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
-  if (lane == 63) wsum[w] = x;
+  for (int o = 32; o > 0; o >>= 1) { before += __shfl_down(before, o); all += __shfl_down(all, o); }
+  if (lane == 0) red[w] = before;
   __syncthreads();
-  if (threadIdx.x == 0) { int a = 0; for (int i = 0; i < 16; ++i) { int t = wsum[i]; wsum[i] = a; a += t; } total = a; }
+  if (threadIdx.x == 0) { int b = 0; for (int i = 0; i < 16; ++i) b += red[i]; s_base = b; }
   __syncthreads();
-  int off = wsum[w] + x - cnt;
-  for (int i = 0; i < per; ++i) {
-    int s = s0 + i;
-    if (s < v.G) {
-      if (v.leaf_kind[s] == LEAF_NEW) { v.eidx[s] = off; v.eval_slots[off] = s; off++; }
-      else v.eidx[s] = -1;
-    }
+  if (lane == 0) red[w] = all;
+  __syncthreads();
+  if (threadIdx.x == 0) { int a = 0; for (int i = 0; i < 16; ++i) a += red[i]; s_total = a; }
+  __syncthreads();
+  const int s = blockIdx.x * 1024 + threadIdx.x;
+  if (s < v.G) {
+    const int r = v.eidx[s];
+    if (r >= 0) { const int e = s_base + r; v.eidx[s] = e; v.eval_slots[e] = s; }
   }
-  if (threadIdx.x == 0) { *v.n_eval = total; atomicAdd((unsigned long long*)&v.stat[2], (unsigned long long)total); }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *v.n_eval = s_total;
+    atomicAdd((unsigned long long*)&v.stat[2], (unsigned long long)s_total);
+  }
 }
 
 // NN-free oracles: MCTS.RandomOracle (src/mcts.jl:62-72) and the synthetic hash oracle
