@@ -102,5 +102,6 @@ class Env:
 
 
 def memory_footprint_per_node(gspec):
-    apad = 16 if gspec.num_actions() > 8 else 8
-    return 32 + 16 * apad + 12      # node record + its share of the 1.5x hash table (8 B entries)
+    nA = gspec.num_actions()
+    rec = ((16 + 8 * nA + 7) // 8 * 8 + 8 * nA + 31) // 32 * 32
+    return rec + 4 + 12             # node record + Vest + its share of the 1.5x hash table (8 B entries)

@@ -313,6 +313,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &v.eta, (size_t)G * gi.APAD));
     AZCHK(dalloc(e, &v.ht, (size_t)G * hs));
     AZCHK(dalloc(e, &v.nodes, (size_t)G * cap * gi.node_bytes, false));
+    AZCHK(dalloc(e, &v.vest, (size_t)G * cap, false));
     AZCHK(dalloc(e, &v.path, (size_t)G * v.max_depth));
     AZCHK(dalloc(e, &v.leaf_kind, G)); AZCHK(dalloc(e, &v.leaf_depth, G)); AZCHK(dalloc(e, &v.leaf_env, G));
     AZCHK(dalloc(e, &v.leaf_ins, G)); AZCHK(dalloc(e, &v.eidx, G)); AZCHK(dalloc(e, &v.eval_slots, G));
@@ -351,7 +352,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       gv.G = Gh;
       gv.root += o; gv.active += o; gv.game_id += o; gv.move_idx += o; gv.epoch += o; gv.node_count += o;
       gv.worker_sim_id += o; gv.tot_sims += o; gv.tot_trav += o; gv.eta += o * gi.APAD;
-      gv.ht += o * hs; gv.nodes += o * (size_t)cap * gi.node_bytes; gv.path += o * v.max_depth;
+      gv.ht += o * hs; gv.nodes += o * (size_t)cap * gi.node_bytes; gv.vest += o * (size_t)cap; gv.path += o * v.max_depth;
       gv.leaf_kind += o; gv.leaf_depth += o; gv.leaf_env += o; gv.leaf_ins += o; gv.eidx += o; gv.eval_slots += o;
       gv.n_eval += g; gv.chunk_cnt += (o + 1023) / 1024 + g; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;
@@ -780,6 +781,7 @@ __global__ void k_node_stats(DView v, int slot, unsigned long long ka, unsigned 
       const unsigned long long* k = (const unsigned long long*)nd;
       if (k[0] == ka && k[1] == kb) {
         *found = 1;
+        *(float*)(out + 4) = v.vest[(size_t)slot * v.cap_nodes + (idx1 - 1)];
         for (int b = 0; b < NL::BYTES; ++b) out[16 + b] = nd[b];
         return;
       }
@@ -799,14 +801,14 @@ extern "C" int az_mcts_node_stats(az_engine* e, int32_t slot, const uint64_t key
   int found; memcpy(&found, buf, 4);
   if (!found) return fail(AZ_ERR_BAD_ARG, "state not in the tree of slot %d", slot);
   const char* nd = buf + 16;
-  const int L = e->gi.APAD, A = e->gi.A;
+  const int A = e->gi.A, offP = 16 + 4 * A, offW = (16 + 8 * A + 7) / 8 * 8;
   for (int a = 0; a < A; ++a) {
-    if (N) memcpy(&N[a], nd + 32 + 4 * a, 4);
-    if (P) memcpy(&P[a], nd + 32 + 4 * L + 4 * a, 4);
-    if (W) memcpy(&W[a], nd + 32 + 8 * L + 8 * a, 8);
+    if (N) memcpy(&N[a], nd + 16 + 4 * a, 4);
+    if (P) memcpy(&P[a], nd + offP + 4 * a, 4);
+    if (W) memcpy(&W[a], nd + offW + 8 * a, 8);
   }
-  if (Vest) memcpy(Vest, nd + 16, 4);
-  if (mask) memcpy(mask, nd + 20, 4);
+  if (Vest) memcpy(Vest, buf + 4, 4);
+  if (mask) DISPATCH_GAME(e->cfg.game, *mask = Gm::mask(Gm::from_key(key[0], key[1])));
   return AZ_OK;
 }
 

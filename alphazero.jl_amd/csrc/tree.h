@@ -4,8 +4,8 @@
 // Layout in HBM (one engine = G game slots, every array is slot-major):
 //   nodes  [G][cap][NODE_BYTES]   one record per stored state (the reference's StateInfo +
 //                                 Vector{ActionStats}, src/mcts.jl:78-87), full action width:
-//                                   +0  key a,b (16 B)   +16 Vest f32   +20 availability mask u32
-//                                   +32 N i32[APAD]   then P f32[APAD]   then W f64[APAD]
+//                                   +0 key a,b (16 B)   +16 N i32[A]   then P f32[A]   then W f64[A]
+//                                 (128 B for 7 actions: one cache line per visit);  vest [G][cap] f32
 //   ht     [G][H] u64             the Dict{State,StateInfo} of src/mcts.jl:126 as an open-addressed
 //                                 table: epoch(16) | tag(16) | node index+1 (32); an entry is live
 //                                 only if its epoch equals the slot's epoch, so MCTS.reset! is O(1)
@@ -47,6 +47,7 @@ struct DView {
   double* eta;            // [G][APAD] by full action index
   unsigned long long* ht;
   char* nodes;
+  float* vest;            // [G][cap] StateInfo.Vest (src/mcts.jl:86), off the hot path
   unsigned long long* path;
   int* leaf_kind;
   int* leaf_depth;
@@ -65,10 +66,14 @@ struct DView {
   long long* stat;        // [0] simulations [1] nodes traversed [2] leaf evals [3] moves
 };
 
+// Node record: key (16 B) | N i32[A] | P f32[A] | W f64[A], padded to a multiple of 32 B.  With A = 7 that is
+// exactly 128 B = ONE cache line per visited node (Connect-Four; 128 B for Mancala's A = 6, 160 B for A = 9).
+// Vest (only read by the explorer hook) lives in a side array; the availability mask is recomputed from the
+// state in registers.
 template <class Gm> struct NodeL {
-  static constexpr int L = Gm::APAD;
-  static constexpr int OFF_VEST = 16, OFF_MASK = 20, OFF_N = 32, OFF_P = 32 + 4 * L, OFF_W = 32 + 8 * L;
-  static constexpr int BYTES = 32 + 16 * L;
+  static constexpr int A = Gm::A;
+  static constexpr int OFF_N = 16, OFF_P = 16 + 4 * A, OFF_W = (16 + 8 * A + 7) / 8 * 8;
+  static constexpr int BYTES = (OFF_W + 8 * A + 31) / 32 * 32;
 };
 
 __device__ inline void dev_fail(const DView& v, int code) { atomicCAS(v.err, 0, code); }
@@ -174,10 +179,11 @@ __global__ void __launch_bounds__(256) k_select(DView v, DParams p) {
     if (idx < 0) { kind = LEAF_NEW; break; }                      // mcts.jl:205-207
     if (depth >= v.max_depth) { dev_fail(v, DERR_DEPTH); kind = LEAF_NONE; break; }
     const char* nd = pool + (size_t)idx * NL::BYTES;
-    const uint32_t amask = *(const uint32_t*)(nd + NL::OFF_MASK);
-    const int N = ((const int*)(nd + NL::OFF_N))[lane];
-    const float Pf = ((const float*)(nd + NL::OFF_P))[lane];
-    const double W = ((const double*)(nd + NL::OFF_W))[lane];
+    const uint32_t amask = Gm::mask(env);
+    const bool inrec = lane < Gm::A;
+    const int N = inrec ? ((const int*)(nd + NL::OFF_N))[lane] : 0;
+    const float Pf = inrec ? ((const float*)(nd + NL::OFF_P))[lane] : 0.0f;
+    const double W = inrec ? ((const double*)(nd + NL::OFF_W))[lane] : 0.0;
     // uct_scores (mcts.jl:180-188): Float64, evaluated left to right
     const int Ntot = group_sum<L>(N);
     const double sqrtNtot = __builtin_sqrt((double)Ntot);
@@ -337,14 +343,15 @@ __global__ void __launch_bounds__(256) k_expand_backup(DView v, DParams p) {
       Pf = av ? (float)res : 0.f;
     }
     char* nd = pool + (size_t)idx * NL::BYTES;
-    ((int*)(nd + NL::OFF_N))[lane] = 0;
-    ((float*)(nd + NL::OFF_P))[lane] = Pf;
-    ((double*)(nd + NL::OFF_W))[lane] = 0.0;
+    if (lane < Gm::A) {
+      ((int*)(nd + NL::OFF_N))[lane] = 0;
+      ((float*)(nd + NL::OFF_P))[lane] = Pf;
+      ((double*)(nd + NL::OFF_W))[lane] = 0.0;
+    }
     if (lane == 0) {
       ((unsigned long long*)nd)[0] = env.a;
       ((unsigned long long*)nd)[1] = env.b;
-      *(float*)(nd + NL::OFF_VEST) = V;
-      *(uint32_t*)(nd + NL::OFF_MASK) = m;
+      v.vest[(size_t)slot * v.cap_nodes + idx] = V;
       const unsigned long long hk = az_hash_key(env.a, env.b);
       const unsigned long long tag = (hk >> 40) & 0xffff;
       v.ht[(size_t)slot * v.ht_size + v.leaf_ins[slot]] =
@@ -410,7 +417,7 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
     }
   }
   if (!nd) { dev_fail(v, DERR_NO_ROOT); return; }
-  const uint32_t m = *(const uint32_t*)(nd + NL::OFF_MASK);
+  const uint32_t m = Gm::mask(env);
   const int* Nn = (const int*)(nd + NL::OFF_N);
   int acts[AZ_MAX_ACTIONS];
   double pi[AZ_MAX_ACTIONS], pis[AZ_MAX_ACTIONS];

@@ -253,7 +253,8 @@ function AlphaZero.simulate(simulator::Simulator, gspec::DeviceGameSpec, p::SimP
       (Ptr{Cvoid}, Int32, Int32, Ref{TraceBuf}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{SelfplayStats}),
       e.h, p.num_games, first_game_id, tb, @cfunction(c_progress, Cvoid, (Ptr{Cvoid},)), C_NULL, stats))
   end
-  nbytes = 32 + 16 * (GI.num_actions(gspec) > 8 ? 16 : 8) + 12
+  nA = GI.num_actions(gspec)
+  nbytes = cld(cld(16 + 8nA, 8) * 8 + 8nA, 32) * 32 + 4 + 12     # device node record + Vest + hash-table share
   return map(games) do g
     recs = moves[g.first_move + 1 : g.first_move + g.num_moves]
     trace = Trace(decode_state(gspec, recs[1].key))
