@@ -997,6 +997,40 @@ extern "C" int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, 
   return AZ_OK;
 }
 
+// debug aid (not part of the ABI in azhip.h): the numerics contract evaluated on the device, so that tests can
+// compare gfx950 against the host bit for bit (f64 sqrt / div, az_log / az_exp / az_pow, az_expf / az_tanhf)
+__global__ void k_debug_math(int op, const double* x, const double* y, int n, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r = 0.0;
+  switch (op) {
+    case 0: r = __builtin_sqrt(x[i]); break;
+    case 1: r = x[i] / y[i]; break;
+    case 2: r = az_log(x[i]); break;
+    case 3: r = az_exp(x[i]); break;
+    case 4: r = az_pow(x[i], y[i]); break;
+    case 5: r = (double)az_expf((float)x[i]); break;
+    case 6: r = (double)az_tanhf((float)x[i]); break;
+    case 7: r = (double)((float)x[i] / (float)y[i]); break;
+    case 8: { az_rng g = az_rng_make((uint64_t)x[i], (uint32_t)y[i], 3, AZ_RNG_NOISE); double eta[7]; az_dirichlet(&g, 7, 0.3, eta); r = eta[3]; break; }
+  }
+  out[i] = r;
+}
+extern "C" int az_debug_math(az_engine* e, int32_t op, const double* x, const double* y, int32_t n, double* out) {
+  ENGINE(e);
+  if (n < 0 || (n > 0 && (!x || !y || !out))) return fail(AZ_ERR_BAD_ARG, "NULL buffer");
+  if (n == 0) return AZ_OK;
+  double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  HIPCHK(hipMalloc(&dx, sizeof(double) * n)); HIPCHK(hipMalloc(&dy, sizeof(double) * n)); HIPCHK(hipMalloc(&dout, sizeof(double) * n));
+  HIPCHK(hipMemcpyAsync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, e->stream, (int)op, dx, dy, (int)n, dout);
+  HIPCHK(hipMemcpyAsync(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+  return AZ_OK;
+}
+
 // debug aid (not part of the ABI in azhip.h): s_memtime stamps of one tower launch on n boards
 extern "C" int az_debug_tower_timeline(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
   ENGINE(e);

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--groups", type=int, default=2, help="interleaved slot groups = num_workers / batch_size: 2 (default) overlaps the tree kernels of one half-batch with the network of the other, the reference's num_workers = 2 x batch_size; 1 = one 4096-leaf batch per wave")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 code path on a single GPU)")
     ap.add_argument("--no-prof", action="store_true", help="do not wrap launches in HIP events")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel class (default: only the dominant kernel, k_tower)")
     args = ap.parse_args()
@@ -95,17 +96,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libazhip.so has no CPU fallback)")
 
     hp = ResNetHP(num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
     blob = random_params(azhip.GAME_CONNECT_FOUR, hp, seed=2026)
     # games/connect-four/params.jl:24-30 with 400 sims (BASELINE.json configs[1])
-    eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=local_rank,
+    eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=dev_index,
                        num_workers=args.slots, batch_size=args.slots // args.groups, num_iters_per_turn=args.sims,
                        gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
                        prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
@@ -141,17 +148,17 @@ def main():
     moves = s1.moves - s0.moves
     local_evals = evals
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([sims, evals, trav, moves], dtype=torch.float64, device="cuda")
+        c = torch.tensor([sims, evals, trav, moves], dtype=torch.float64, device=red_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         sims, evals, trav, moves = [float(x) for x in c.tolist()]
     eng.selfplay_end()
 
     if rank == 0:
         out = {
-            "metric": "self-play MCTS sims/sec (Connect-Four, 4096 parallel games per GPU)",
+            "metric": "self-play MCTS sims/sec (Connect-Four, %d parallel games per GPU)" % args.slots,
             "value": sims / elapsed, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
