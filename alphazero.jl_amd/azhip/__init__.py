@@ -16,3 +16,4 @@ from .play import MctsPlayer, play_game
 from .trace import Trace
 from .memory import TrainingSample, push_trace
 from .simulations import Simulator, record_trace, self_play_measurements, simulate, simulate_distributed
+from .training import SelfPlayParams, SelfPlayReport, broadcast_params, self_play_step

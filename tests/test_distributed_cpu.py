@@ -50,3 +50,26 @@ def test_gather_records_gloo_world2(tmp_path):
         a = M0[r["first_move"]:r["first_move"] + r["num_moves"]]
         b = ref_m[q["first_move"]:q["first_move"] + q["num_moves"]]
         assert np.array_equal(a, b) and tuple(r["final_key"]) == tuple(q["final_key"])
+
+
+def _bcast_worker(rank, world, port, out_dir):
+    sys.path[:0] = [os.path.join(ROOT, "alphazero.jl_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from azhip import ConnectFourSpec, ResNet, ResNetHP, broadcast_params
+    nn = ResNet(ConnectFourSpec(), ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32), seed=100 + rank)
+    broadcast_params(nn, src=0)
+    np.save(os.path.join(out_dir, "W%d.npy" % rank), nn.params())
+    dist.destroy_process_group()
+
+
+def test_broadcast_params_gloo_world2(tmp_path):
+    """weights of rank 0 reach every rank before the self-play phase"""
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_bcast_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sys.path[:0] = [os.path.join(ROOT, "alphazero.jl_amd")]
+    from azhip.network import ResNetHP, random_params
+    w0, w1 = np.load(tmp_path / "W0.npy"), np.load(tmp_path / "W1.npy")
+    ref = random_params(0, ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32), seed=100)
+    assert np.array_equal(w0, ref) and np.array_equal(w1, ref)

@@ -114,3 +114,19 @@ def test_full_size_slot_count_independence():
     assert a == c                                            # per-slot sims, traversed, nodes identical for games 0..47
     assert sa.simulations == 4096 * 800 and sc.simulations == 48 * 800 and sa.moves == 2 * 4096
     assert sa.leaf_evals <= sa.simulations and all(x[0] == 800 for x in a)
+
+
+def test_self_play_step_report():
+    """self_play_step! (training.jl:275-300): traces pushed into the memory, Report.SelfPlay fields."""
+    import azhip
+    gspec = azhip.TicTacToeSpec()
+    nn = azhip.ResNet(gspec, _hp(1), seed=4)
+    params = azhip.SelfPlayParams(
+        mcts=azhip.MctsParams(num_iters_per_turn=16, dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0, cpuct=1.0),
+        sim=azhip.SimParams(num_games=12, num_workers=4, batch_size=2, use_gpu=True, reset_every=1))
+    mem, played = [], [0]
+    rep = azhip.self_play_step(gspec, nn, params, mem, game_played=lambda: played.__setitem__(0, played[0] + 1))
+    assert played[0] == 12 and rep.memory_size == len(mem) >= 12 * 5
+    assert rep.samples_gen_speed > 0 and 0 < rep.average_exploration_depth < 9 and rep.mcts_memory_footprint > 0
+    assert 1 <= rep.memory_num_distinct_boards <= rep.memory_size
+    assert all(abs(s.z) <= 1 and s.t >= 1 and abs(s.π.sum() - 1) < 1e-12 for s in mem)
