@@ -20,6 +20,7 @@
 #include "../../include/azhip.h"
 #include "games.h"
 #include "resnet.h"
+#include "resnet16.h"
 #include "tree.h"
 
 // ------------------------------------------------------------------------------- errors
@@ -90,6 +91,8 @@ struct az_engine {
   bool net_loaded;
   std::vector<float> blob;
   NetDev net;
+  Net16Dev net16;                // k_tower16 fragments (64 filters)
+  bool use16;                    // AZHIP_TOWER=16|32 (default 16 when num_filters == 64)
   int nn_cap;
   float* d_hfeat; float* d_X; float* d_A; float* d_P; float* d_V; float* d_Pinv;
   GEnv* d_tmp_env; int* d_iota; int* d_ntmp;
@@ -243,6 +246,8 @@ template <class Gm, int F> static int set_kernel_attrs_f() {
   return AZ_OK;
 }
 template <class Gm> static int set_kernel_attrs() {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm>::BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm>::BYTES));
   AZCHK((set_kernel_attrs_f<Gm, 64>()));
   AZCHK((set_kernel_attrs_f<Gm, 128>()));
   return AZ_OK;
@@ -339,6 +344,8 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &e->d_tmp_env, e->nn_cap)); AZCHK(dalloc(e, &e->d_iota, e->nn_cap)); AZCHK(dalloc(e, &e->d_ntmp, 1));
     hipLaunchKernelGGL(k_iota, dim3((e->nn_cap + 255) / 256), dim3(256), 0, e->stream, e->d_iota, e->nn_cap);
     memset(&e->net, 0, sizeof e->net);
+    memset(&e->net16, 0, sizeof e->net16);
+    { const char* tw = getenv("AZHIP_TOWER"); e->use16 = (c->num_filters == 64) && !(tw && atoi(tw) == 32); }
     DISPATCH_GAME(c->game, AZCHK(set_kernel_attrs<Gm>()));
     // slot groups
     int ng = c->batch_size > 0 ? G / c->batch_size : 1;
@@ -515,6 +522,31 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
     bn_fold(w + (size_t)9 * F * F, w + (size_t)9 * F * F + F, F, conv_ss.data() + (size_t)l * 2 * F, conv_ss.data() + (size_t)l * 2 * F + F);
     w += (size_t)9 * F * F + 5 * F;
   }
+  // k_tower16 fragments (16x16x4 MFMA): lane l of step s = 4 sq + q supplies channel c = (g&1)*32 + 2s + (g>>1),
+  // g = l >> 4, for output column ct*16 + (l & 15)
+  std::vector<float> c16_w(4), s16_w(4);
+  if (F == 64) {
+    c16_w.assign((size_t)2 * nb * 9 * 16 * 64 * 4 + 4, 0.0f);
+    const float* wc = blob + (size_t)9 * C * F + 5 * F;
+    for (int l = 0; l < 2 * nb; ++l) {
+      for (int t = 0; t < 9; ++t) {
+        int dy = t / 3 - 1, dx = t % 3 - 1, wi = 1 - dx, wj = 1 - dy;
+        for (int ct = 0; ct < 4; ++ct) for (int sq = 0; sq < 4; ++sq) for (int ln = 0; ln < 64; ++ln) for (int q = 0; q < 4; ++q) {
+          int s = 4 * sq + q, g = ln >> 4, ci = (g & 1) * 32 + 2 * s + (g >> 1), co = ct * 16 + (ln & 15);
+          c16_w[(((((size_t)l * 9 + t) * 4 + ct) * 4 + sq) * 64 + ln) * 4 + q] = wc[wi + 3 * (wj + 3 * (ci + (size_t)F * co))];
+        }
+      }
+      wc += (size_t)9 * F * F + 5 * F;
+    }
+    const int KK = 9 * C, K2s = (KK + 1) / 2, NS = (2 * K2s + 3) / 4;
+    s16_w.assign((size_t)4 * NS * 64, 0.0f);
+    for (int ct = 0; ct < 4; ++ct) for (int s = 0; s < NS; ++s) for (int ln = 0; ln < 64; ++ln) {
+      int p = 4 * s + (ln >> 4), k = (p & 1) * K2s + (p >> 1), co = ct * 16 + (ln & 15);
+      if (k >= KK || p >= 2 * K2s) continue;
+      int t = k / C, ci = k % C, dy = t / 3 - 1, dx = t % 3 - 1, wi = 1 - dx, wj = 1 - dy;
+      s16_w[((size_t)ct * NS + s) * 64 + ln] = blob[wi + 3 * (wj + 3 * (ci + (size_t)C * co))];
+    }
+  }
   // heads: concatenate the two 1x1 convolutions along the output channel
   std::vector<float> hw((size_t)F * HF, 0.0f), hb(HF, 0.0f), hbn((size_t)4 * HF, 0.0f), head_w((size_t)(HF / 32) * (F / 8) * 64 * 4), head_ss(2 * HF);
   for (int i = 0; i < HF; ++i) { hbn[i] = 0.0f; hbn[3 * HF + i] = 1.0f; }   // padded channels: gamma 0, var 1
@@ -534,6 +566,14 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
     for (int k = 0; k < 4; ++k) hbn[(size_t)k * HF + npf + co] = vbn[(size_t)k * nvf + co];
   }
   pack_conv(hw.data(), 1, F, HF, HF, head_w.data());
+  std::vector<float> h16_w(4);
+  if (F == 64) {
+    h16_w.assign((size_t)16 * 64 * 4, 0.0f);
+    for (int ct = 0; ct < 4; ++ct) for (int sq = 0; sq < 4; ++sq) for (int ln = 0; ln < 64; ++ln) for (int q = 0; q < 4; ++q) {
+      int s = 4 * sq + q, g = ln >> 4, ci = (g & 1) * 32 + 2 * s + (g >> 1), co = ct * 16 + (ln & 15);
+      h16_w[((((size_t)ct) * 4 + sq) * 64 + ln) * 4 + q] = hw[ci + (size_t)F * co];
+    }
+  }
   bn_fold(hb.data(), hbn.data(), HF, head_ss.data(), head_ss.data() + HF);
   // dense layers, k-major with k = p*nf + f; Flux Dense W[out + nout*(p + P*f)]
   std::vector<float> pol_w((size_t)P * npf * L, 0.0f), pol_b(L, 0.0f), val_w((size_t)P * nvf * F), val_b(F), val2_w(F);
@@ -589,6 +629,15 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   nd.val2_b = *v2b;
   AZCHK(up(hd_w, &tmp)); nd.hd_w = (const float2*)tmp;
   nd.hd_ok = hd_ok ? 1 : 0;
+  Net16Dev n16;
+  memset(&n16, 0, sizeof n16);
+  if (F == 64) {
+    n16.nblocks = nb;
+    AZCHK(up(s16_w, &n16.stem_w)); n16.stem_ss = nd.stem_ss;
+    AZCHK(up(c16_w, &tmp)); n16.conv_w = (const float4*)tmp; n16.conv_ss = nd.conv_ss;
+    AZCHK(up(h16_w, &tmp)); n16.head_w = (const float4*)tmp; n16.head_ss = nd.head_ss;
+  }
+  e->net16 = n16;
   HIPCHK(hipStreamSynchronize(e->stream));
   e->net = nd;
   e->net_loaded = true;
@@ -609,7 +658,10 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
   constexpr int TB = TOWER_ROWS / Gm::P;
   const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
   if (gt == 0) return AZ_OK;
-  LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, F, FROM_PLANES>), gt, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
+  if (F == 64 && e->use16)
+    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, FROM_PLANES>), (n_max + T16<Gm>::TB - 1) / T16<Gm>::TB, 256, T16<Gm>::BYTES, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
+  else
+    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, F, FROM_PLANES>), gt, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
   if (e->net.hd_ok)
     LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, F>), (n_max + 31) / 32, 64 * (F / 32 + 1), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
   else
@@ -674,7 +726,10 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   hipStream_t st = e->gs[g], sn = e->gt[g];
   const int G = v.G;
   if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
-  LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower<Gm, F, false>), (G + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
+  if (F == 64 && e->use16)
+    LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower16<Gm, false>), (G + T16<Gm>::TB - 1) / T16<Gm>::TB, 256, T16<Gm>::BYTES, e->net16, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
+  else
+    LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower<Gm, F, false>), (G + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
   if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
   if (e->net.hd_ok)
     LAUNCH_ON(e, st, AZ_K_HEADS, G, (k_heads_mfma<Gm, F>), (G + 31) / 32, 64 * (F / 32 + 1), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);

@@ -1,0 +1,233 @@
+// resnet16.h -- k_tower16: the 64-filter residual tower on v_mfma_f32_16x16x4_f32 with 16x16 work units.
+//
+// Why a second tower kernel.  k_tower (resnet.h) quantises the batch in workgroups of 3 boards x 2 per CU:
+// 4096 boards are 2.67 "rounds" that cost 3 (-11 %).  Here a workgroup owns TB = 4 Connect-Four boards =
+// 168 rows = 10.5 -> 11 row tiles of 16, and keeps ONE activation buffer in LDS (48 KB, so two workgroups
+// still share a CU): 4096 boards = 1024 workgroups = exactly two full rounds of 512.  Wave w owns the 16 output
+// channels w*16..w*16+15 of every row tile: 11 accumulators of 4 VGPRs, 176 MFMAs per tap against 4 weight
+// loads (k_tower: 64 MFMAs against 8 loads), so the VMEM issue cost of the weight stream disappears.
+//
+// Single-buffer schedule of one residual block (resnet.jl:53-63):
+//   conv1: read X (LDS) -> acc            | barrier | own X values -> registers (residual), T = relu(bn(acc)) -> LDS | barrier
+//   conv2: read T (LDS) -> acc            | barrier | y = relu(bn(acc) + X registers) -> LDS                        | barrier
+//
+// fp32 contract (include/azhip.h) unchanged: v_mfma_f32_16x16x4_f32 is a k-ordered fma chain with k = lane >> 4
+// (probe: tools/probes/mfma16_chain.hip), and step s of a 64-channel tap feeds it the channels
+// (2s, 32+2s, 2s+1, 32+2s+1) = the contract's order j, 32+j.  To make each lane's 16 values of a tap contiguous,
+// LDS stores channel c at position pos(c) = ((c >> 5) + 2 (c & 1)) * 16 + ((c & 31) >> 1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/az_numerics.h"
+#include "games.h"
+#include "resnet.h"
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct Net16Dev {
+  int nblocks;
+  const float* stem_w;      // [4 col tiles][K2s steps][64] : W[k(4s + g)][col]
+  const float* stem_ss;     // [2][64]
+  const float4* conv_w;     // [2*nblocks][9][4 col tiles][4][64] float4
+  const float* conv_ss;     // [2*nblocks][2][64]
+  const float4* head_w;     // [4 col tiles][4][64] float4
+  const float* head_ss;     // [2][64]
+};
+
+template <class Gm> struct T16 {
+  static constexpr int NTILE = 11, RPAD = NTILE * 16;
+  static constexpr int TB = RPAD / Gm::P;            // 4 Connect-Four boards, 19 Tic-tac-toe, 12 Mancala
+  static constexpr int ROWS = TB * Gm::P;
+  static constexpr int STRIDE = 68;
+  static constexpr int BUF = (RPAD + 1) * STRIDE;    // row RPAD = zeros
+  static constexpr int PLANES = (RPAD + 1) * Gm::C;
+  static constexpr int BYTES = (BUF + PLANES) * 4;
+};
+
+__device__ __forceinline__ int pos64(int c) { return ((c >> 5) + 2 * (c & 1)) * 16 + ((c & 31) >> 1); }
+
+// one 64 -> 64 convolution (NTAP = 9: 3x3, NTAP = 1: 1x1) into the 11 accumulators of this wave
+template <class Gm, int NTAP>
+__device__ __forceinline__ void conv16(const float* __restrict__ buf, const float4* __restrict__ wl,
+                                       f32x4v (&acc)[11], const uint32_t (&vm)[11], int lrow, int g) {
+  using T = T16<Gm>;
+  constexpr int STRIDE = T::STRIDE;
+  float4 b0[4], b1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) b0[q] = wl[(size_t)q * 64];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    const int tap = NTAP == 1 ? 4 : t;
+    const int delta = (tap / 3 - 1) * Gm::W + (tap % 3 - 1);
+    float4 (&bc)[4] = (t & 1) ? b1 : b0;
+    float4 (&bn)[4] = (t & 1) ? b0 : b1;
+    if (t + 1 < NTAP) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bn[q] = wl[(size_t)((t + 1) * 16 + q) * 64];
+    }
+    // row tiles in groups of 2 (last group 3) so that consecutive MFMAs never hit the same accumulator
+#pragma unroll
+    for (int t0 = 0; t0 < 11; t0 += 2) {
+      constexpr int dummy = 0; (void)dummy;
+      const int ng = (t0 == 8) ? 3 : 2;
+      float4 a[3][4];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (u < ng) {
+          const int tile = t0 + u;
+          const bool ok = (vm[tile] >> tap) & 1;
+          const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
+          const float* p = buf + row * STRIDE + g * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[u][q] = *(const float4*)(p + q * 4);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) if (u < ng) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].x, bc[q].x, acc[t0 + u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) if (u < ng) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].y, bc[q].y, acc[t0 + u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) if (u < ng) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].z, bc[q].z, acc[t0 + u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) if (u < ng) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].w, bc[q].w, acc[t0 + u], 0, 0, 0);
+      }
+      if (t0 == 8) break;
+    }
+  }
+}
+
+template <class Gm, bool FROM_PLANES>
+__global__ void __launch_bounds__(256, 2)
+k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+          const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
+  using T = T16<Gm>;
+  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, C = Gm::C, TB = T::TB, STRIDE = T::STRIDE, F = 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* buf = lds;
+  float* planes = lds + T::BUF;
+  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
+  const int board0 = blockIdx.x * TB;
+  if (board0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, g = lane >> 4;
+
+  // ---- input planes [RPAD + 1][C] and the zero row of the activation buffer ----------------------
+  for (int i = tid; i < T::PLANES; i += 256) {
+    const int row = i / C, c = i % C;
+    const int b = row / P, q = row % P;
+    float val = 0.0f;
+    if (row < T::ROWS && board0 + b < n) {
+      if (FROM_PLANES) val = X[((size_t)(board0 + b) * C + c) * P + q];
+      else val = Gm::plane(leaf_env[eval_slots[board0 + b]], q, c);
+    }
+    planes[i] = val;
+  }
+  for (int i = tid; i < STRIDE; i += 256) buf[T::RPAD * STRIDE + i] = 0.0f;
+  // validity of the 9 taps for this lane's row of every tile
+  uint32_t vm[11];
+#pragma unroll
+  for (int tile = 0; tile < 11; ++tile) {
+    const int row = tile * 16 + lrow;
+    const int q = row % P, x = q % W, y = q / W;
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = (row < T::ROWS) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
+      m |= (uint32_t)ok << t;
+    }
+    vm[tile] = m;
+  }
+  // this lane's output element (tile, i): row = tile*16 + g*4 + i, channel = wave*16 + lrow
+  const int ch = wave * 16 + lrow;
+  const int opos = pos64(ch);
+  __syncthreads();
+
+  f32x4v acc[11];
+  // ---- stem: Conv(3x3, C => 64) + BN + ReLU, K = 9C padded to a multiple of 4 -------------------------
+  {
+    constexpr int KK = 9 * C, K2 = (KK + 1) / 2, NS = (2 * K2 + 3) / 4;
+#pragma unroll
+    for (int t = 0; t < 11; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      // sequence position p = 4s + g -> k = (p & 1) * K2 + (p >> 1)   (the paired order of the contract)
+      const float bw = net.stem_w[(size_t)(wave * NS + s) * 64 + lane];
+      const int p = 4 * s + g;
+      const int k = (p & 1) * K2 + (p >> 1);
+      const bool kin = k < KK && p < 2 * K2;
+      const int tap = kin ? k / C : 4, c = kin ? k % C : 0;
+      const int delta = (tap / 3 - 1) * W + (tap % 3 - 1);
+#pragma unroll
+      for (int tile = 0; tile < 11; ++tile) {
+        const bool ok = kin && ((vm[tile] >> tap) & 1);
+        const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
+        const float a = planes[row * C + c];
+        acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[tile], 0, 0, 0);
+      }
+    }
+    const float sc = net.stem_ss[ch], sh = net.stem_ss[F + ch];
+#pragma unroll
+    for (int tile = 0; tile < 11; ++tile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = az_fmaf(acc[tile][i], sc, sh);
+        buf[(tile * 16 + g * 4 + i) * STRIDE + opos] = v > 0.0f ? v : 0.0f;
+      }
+  }
+  __syncthreads();
+
+  // ---- residual tower ---------------------------------------------------------------------------------
+  float xres[11][4];
+  const size_t LAYER_W = (size_t)9 * 16 * 64;       // float4 per layer
+  for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
+#pragma unroll
+    for (int t = 0; t < 11; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    conv16<Gm, 9>(buf, net.conv_w + (size_t)layer * LAYER_W + (size_t)wave * 4 * 64 + lane, acc, vm, lrow, g);
+    const float sc = net.conv_ss[(size_t)layer * 2 * F + ch], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch];
+    __builtin_amdgcn_s_setprio(2);
+    __syncthreads();                                 // every wave has finished reading the buffer
+    if (!(layer & 1)) {
+#pragma unroll
+      for (int tile = 0; tile < 11; ++tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int a = (tile * 16 + g * 4 + i) * STRIDE + opos;
+          xres[tile][i] = buf[a];                    // block input, kept for the skip connection
+          const float v = az_fmaf(acc[tile][i], sc, sh);
+          buf[a] = v > 0.0f ? v : 0.0f;
+        }
+    } else {
+#pragma unroll
+      for (int tile = 0; tile < 11; ++tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int a = (tile * 16 + g * 4 + i) * STRIDE + opos;
+          float v = az_fmaf(acc[tile][i], sc, sh);
+          v = v + xres[tile][i];
+          buf[a] = v > 0.0f ? v : 0.0f;
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+  }
+  // ---- both 1x1 head convolutions + BN + ReLU as one 64 => 64 GEMM ------------------------------------
+#pragma unroll
+  for (int t = 0; t < 11; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  conv16<Gm, 1>(buf, net.head_w + (size_t)wave * 4 * 64 + lane, acc, vm, lrow, g);
+  {
+    const float sc = net.head_ss[ch], sh = net.head_ss[F + ch];
+    // head features straight from the accumulators to HBM, [board][P][64] in natural channel order
+    const int nb = (n - board0) < TB ? (n - board0) : TB;
+#pragma unroll
+    for (int tile = 0; tile < 11; ++tile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = tile * 16 + g * 4 + i;
+        const float v = az_fmaf(acc[tile][i], sc, sh);
+        if (row < nb * P) hfeat[((size_t)board0 * P + row) * F + ch] = v > 0.0f ? v : 0.0f;
+      }
+  }
+}
