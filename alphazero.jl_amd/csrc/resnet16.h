@@ -44,58 +44,84 @@ template <class Gm> struct T16 {
   static constexpr int BYTES = (BUF + PLANES) * 4;
 };
 
+// tap-validity bits of this lane's row in tile `tile`: 9 bits per tile, 3 tiles per word
+__device__ __forceinline__ uint32_t vmask(const uint32_t (&vm)[4], int tile) { return vm[tile / 3] >> (9 * (tile % 3)); }
 __device__ __forceinline__ int pos64(int c) { return ((c >> 5) + 2 * (c & 1)) * 16 + ((c & 31) >> 1); }
 
-// one 64 -> 64 convolution (NTAP = 9: 3x3, NTAP = 1: 1x1) into the 11 accumulators of this wave
-template <class Gm, int NTAP>
-__device__ __forceinline__ void conv16(const float* __restrict__ buf, const float4* __restrict__ wl,
-                                       f32x4v (&acc)[11], const uint32_t (&vm)[11], int lrow, int g) {
+// One 64 -> 64 convolution (NTAP = 9: 3x3, NTAP = 1: 1x1) into the 11 accumulators of this wave.
+// The work is a fully unrolled sequence of steps (tap, tile pair); the A rows of step k+1 are read from LDS and
+// (at the first pair of a tap) the B fragments of the next tap requested from L2 while the MFMAs of step k issue.
+// Tiles go in pairs so that consecutive MFMAs never hit the same accumulator (v_mfma_f32_16x16x4_f32: 32-cycle
+// issue, 40-cycle dependent latency); the 11th tile rides alone.  sched_barrier(0) after every step keeps hipcc
+// from hoisting further loads, which bounds the live A registers to two pairs (the kernel must stay near 200
+// VGPRs so that the tree kernels of the other slot group can co-reside on the SIMD).
+template <class Gm>
+__device__ __forceinline__ void load_pair16(const float* __restrict__ buf, const uint32_t (&vm)[4], int tap, int pair,
+                                            int lrow, int g, float4 (&a)[2][4]) {
   using T = T16<Gm>;
-  constexpr int STRIDE = T::STRIDE;
-  float4 b0[4], b1[4];
+  const int delta = (tap / 3 - 1) * Gm::W + (tap % 3 - 1);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) b0[q] = wl[(size_t)q * 64];
+  for (int u = 0; u < 2; ++u) {
+    const int tile = pair * 2 + u;
+    if (tile < 11) {
+      const bool ok = (vmask(vm, tile) >> tap) & 1;
+      const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
+      const float* p = buf + row * T::STRIDE + g * 16;
 #pragma unroll
-  for (int t = 0; t < NTAP; ++t) {
-    const int tap = NTAP == 1 ? 4 : t;
-    const int delta = (tap / 3 - 1) * Gm::W + (tap % 3 - 1);
+      for (int q = 0; q < 4; ++q) a[u][q] = *(const float4*)(p + q * 4);
+    }
+  }
+}
+template <int PAIR>
+__device__ __forceinline__ void mfma_pair16(const float4 (&a)[2][4], const float4 (&b)[4], f32x4v (&acc)[11]) {
+  constexpr int t0 = PAIR * 2;
+  constexpr bool two = t0 + 1 < 11;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].x, b[q].x, acc[t0], 0, 0, 0);
+    if (two) acc[t0 + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].x, b[q].x, acc[t0 + (two ? 1 : 0)], 0, 0, 0);
+    acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].y, b[q].y, acc[t0], 0, 0, 0);
+    if (two) acc[t0 + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].y, b[q].y, acc[t0 + (two ? 1 : 0)], 0, 0, 0);
+    acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].z, b[q].z, acc[t0], 0, 0, 0);
+    if (two) acc[t0 + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].z, b[q].z, acc[t0 + (two ? 1 : 0)], 0, 0, 0);
+    acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].w, b[q].w, acc[t0], 0, 0, 0);
+    if (two) acc[t0 + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].w, b[q].w, acc[t0 + (two ? 1 : 0)], 0, 0, 0);
+  }
+}
+template <class Gm, int NTAP, int K>
+__device__ __forceinline__ void conv16_steps(const float* __restrict__ buf, const float4* __restrict__ wl, f32x4v (&acc)[11],
+                                             const uint32_t (&vm)[4], int lrow, int g, float4 (&b0)[4], float4 (&b1)[4],
+                                             float4 (&aA)[2][4], float4 (&aB)[2][4]) {
+  if constexpr (K < NTAP * 6) {
+    constexpr int t = K / 6, p = K % 6;
+    constexpr int tap = NTAP == 1 ? 4 : t;
+    float4 (&cur)[2][4] = (K & 1) ? aB : aA;
+    float4 (&nxt)[2][4] = (K & 1) ? aA : aB;
     float4 (&bc)[4] = (t & 1) ? b1 : b0;
     float4 (&bn)[4] = (t & 1) ? b0 : b1;
-    if (t + 1 < NTAP) {
+    if constexpr (p == 0 && t + 1 < NTAP) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) bn[q] = wl[(size_t)((t + 1) * 16 + q) * 64];
     }
-    // row tiles in groups of 2 (last group 3) so that consecutive MFMAs never hit the same accumulator
-#pragma unroll
-    for (int t0 = 0; t0 < 11; t0 += 2) {
-      constexpr int dummy = 0; (void)dummy;
-      const int ng = (t0 == 8) ? 3 : 2;
-      float4 a[3][4];
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        if (u < ng) {
-          const int tile = t0 + u;
-          const bool ok = (vm[tile] >> tap) & 1;
-          const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
-          const float* p = buf + row * STRIDE + g * 16;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) a[u][q] = *(const float4*)(p + q * 4);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) if (u < ng) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].x, bc[q].x, acc[t0 + u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 3; ++u) if (u < ng) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].y, bc[q].y, acc[t0 + u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 3; ++u) if (u < ng) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].z, bc[q].z, acc[t0 + u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 3; ++u) if (u < ng) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].w, bc[q].w, acc[t0 + u], 0, 0, 0);
-      }
-      if (t0 == 8) break;
+    if constexpr (K + 1 < NTAP * 6) {
+      constexpr int t1 = (K + 1) / 6, p1 = (K + 1) % 6;
+      load_pair16<Gm>(buf, vm, NTAP == 1 ? 4 : t1, p1, lrow, g, nxt);
     }
+    (void)tap;
+    mfma_pair16<p>(cur, bc, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    conv16_steps<Gm, NTAP, K + 1>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
   }
+}
+template <class Gm, int NTAP>
+__device__ __forceinline__ void conv16(const float* __restrict__ buf, const float4* __restrict__ wl,
+                                       f32x4v (&acc)[11], const uint32_t (&vm)[4], int lrow, int g) {
+  float4 b0[4], b1[4], aA[2][4], aB[2][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) b0[q] = wl[(size_t)q * 64];
+  load_pair16<Gm>(buf, vm, NTAP == 1 ? 4 : 0, 0, lrow, g, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  conv16_steps<Gm, NTAP, 0>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
 }
 
 template <class Gm, bool FROM_PLANES>
@@ -126,7 +152,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   }
   for (int i = tid; i < STRIDE; i += 256) buf[T::RPAD * STRIDE + i] = 0.0f;
   // validity of the 9 taps for this lane's row of every tile
-  uint32_t vm[11];
+  uint32_t vm[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int tile = 0; tile < 11; ++tile) {
     const int row = tile * 16 + lrow;
@@ -138,7 +164,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
       const bool ok = (row < T::ROWS) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
       m |= (uint32_t)ok << t;
     }
-    vm[tile] = m;
+    vm[tile / 3] |= m << (9 * (tile % 3));
   }
   // this lane's output element (tile, i): row = tile*16 + g*4 + i, channel = wave*16 + lrow
   const int ch = wave * 16 + lrow;
@@ -162,7 +188,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
       const int delta = (tap / 3 - 1) * W + (tap % 3 - 1);
 #pragma unroll
       for (int tile = 0; tile < 11; ++tile) {
-        const bool ok = kin && ((vm[tile] >> tap) & 1);
+        const bool ok = kin && ((vmask(vm, tile) >> tap) & 1);
         const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
         const float a = planes[row * C + c];
         acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[tile], 0, 0, 0);
@@ -185,7 +211,11 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
 #pragma unroll
     for (int t = 0; t < 11; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    conv16<Gm, 9>(buf, net.conv_w + (size_t)layer * LAYER_W + (size_t)wave * 4 * 64 + lane, acc, vm, lrow, g);
+    // opaque copy: stops hipcc from hoisting the 99 loop-invariant (tap, tile) LDS addresses out of the layer
+    // loop, which would cost ~100 VGPRs for the whole kernel
+    int lrow_l = lrow;
+    asm volatile("" : "+v"(lrow_l));
+    conv16<Gm, 9>(buf, net.conv_w + (size_t)layer * LAYER_W + (size_t)wave * 4 * 64 + lane, acc, vm, lrow_l, g);
     const float sc = net.conv_ss[(size_t)layer * 2 * F + ch], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch];
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();                                 // every wave has finished reading the buffer
