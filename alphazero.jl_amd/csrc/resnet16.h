@@ -55,15 +55,21 @@ __device__ __forceinline__ int pos64(int c) { return ((c >> 5) + 2 * (c & 1)) * 
 // issue, 40-cycle dependent latency); the 11th tile rides alone.  sched_barrier(0) after every step keeps hipcc
 // from hoisting further loads, which bounds the live A registers to two pairs (the kernel must stay near 200
 // VGPRs so that the tree kernels of the other slot group can co-reside on the SIMD).
+#ifndef AZ_T16_LAST3
+#define AZ_T16_LAST3 0     // 1: tile groups 2,2,2,2,3 (5 steps per tap); 0: 2,2,2,2,2,1 (6 steps, 16 fewer VGPRs)
+#endif
+static constexpr int T16_STEPS = AZ_T16_LAST3 ? 5 : 6;
+static constexpr int T16_GMAX = AZ_T16_LAST3 ? 3 : 2;
+__device__ __forceinline__ constexpr int t16_gsize(int pair) { return AZ_T16_LAST3 ? (pair == 4 ? 3 : 2) : (pair == 5 ? 1 : 2); }
 template <class Gm>
 __device__ __forceinline__ void load_pair16(const float* __restrict__ buf, const uint32_t (&vm)[4], int tap, int pair,
-                                            int lrow, int g, float4 (&a)[2][4]) {
+                                            int lrow, int g, float4 (&a)[T16_GMAX][4]) {
   using T = T16<Gm>;
   const int delta = (tap / 3 - 1) * Gm::W + (tap % 3 - 1);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < T16_GMAX; ++u) {
     const int tile = pair * 2 + u;
-    if (tile < 11) {
+    if (u < t16_gsize(pair)) {
       const bool ok = (vmask(vm, tile) >> tap) & 1;
       const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
       const float* p = buf + row * T::STRIDE + g * 16;
@@ -73,50 +79,52 @@ __device__ __forceinline__ void load_pair16(const float* __restrict__ buf, const
   }
 }
 template <int PAIR>
-__device__ __forceinline__ void mfma_pair16(const float4 (&a)[2][4], const float4 (&b)[4], f32x4v (&acc)[11]) {
-  constexpr int t0 = PAIR * 2;
-  constexpr bool two = t0 + 1 < 11;
+__device__ __forceinline__ void mfma_pair16(const float4 (&a)[T16_GMAX][4], const float4 (&b)[4], f32x4v (&acc)[11]) {
+  constexpr int t0 = PAIR * 2, ng = t16_gsize(PAIR);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].x, b[q].x, acc[t0], 0, 0, 0);
-    if (two) acc[t0 + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].x, b[q].x, acc[t0 + (two ? 1 : 0)], 0, 0, 0);
-    acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].y, b[q].y, acc[t0], 0, 0, 0);
-    if (two) acc[t0 + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].y, b[q].y, acc[t0 + (two ? 1 : 0)], 0, 0, 0);
-    acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].z, b[q].z, acc[t0], 0, 0, 0);
-    if (two) acc[t0 + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].z, b[q].z, acc[t0 + (two ? 1 : 0)], 0, 0, 0);
-    acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].w, b[q].w, acc[t0], 0, 0, 0);
-    if (two) acc[t0 + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].w, b[q].w, acc[t0 + (two ? 1 : 0)], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].x, b[q].x, acc[t0 + u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].y, b[q].y, acc[t0 + u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].z, b[q].z, acc[t0 + u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].w, b[q].w, acc[t0 + u], 0, 0, 0);
   }
 }
 template <class Gm, int NTAP, int K>
 __device__ __forceinline__ void conv16_steps(const float* __restrict__ buf, const float4* __restrict__ wl, f32x4v (&acc)[11],
                                              const uint32_t (&vm)[4], int lrow, int g, float4 (&b0)[4], float4 (&b1)[4],
-                                             float4 (&aA)[2][4], float4 (&aB)[2][4]) {
-  if constexpr (K < NTAP * 6) {
-    constexpr int t = K / 6, p = K % 6;
+                                             float4 (&aA)[T16_GMAX][4], float4 (&aB)[T16_GMAX][4]) {
+  if constexpr (K < NTAP * T16_STEPS) {
+    constexpr int t = K / T16_STEPS, p = K % T16_STEPS;
     constexpr int tap = NTAP == 1 ? 4 : t;
-    float4 (&cur)[2][4] = (K & 1) ? aB : aA;
-    float4 (&nxt)[2][4] = (K & 1) ? aA : aB;
+    float4 (&cur)[T16_GMAX][4] = (K & 1) ? aB : aA;
+    float4 (&nxt)[T16_GMAX][4] = (K & 1) ? aA : aB;
     float4 (&bc)[4] = (t & 1) ? b1 : b0;
     float4 (&bn)[4] = (t & 1) ? b0 : b1;
     if constexpr (p == 0 && t + 1 < NTAP) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) bn[q] = wl[(size_t)((t + 1) * 16 + q) * 64];
     }
-    if constexpr (K + 1 < NTAP * 6) {
-      constexpr int t1 = (K + 1) / 6, p1 = (K + 1) % 6;
+    if constexpr (K + 1 < NTAP * T16_STEPS) {
+      constexpr int t1 = (K + 1) / T16_STEPS, p1 = (K + 1) % T16_STEPS;
       load_pair16<Gm>(buf, vm, NTAP == 1 ? 4 : t1, p1, lrow, g, nxt);
     }
     (void)tap;
     mfma_pair16<p>(cur, bc, acc);
-    __builtin_amdgcn_sched_barrier(0);
+#ifndef AZ_T16_FENCE
+#define AZ_T16_FENCE 1     // fence the scheduler every N steps
+#endif
+    if constexpr (K % AZ_T16_FENCE == AZ_T16_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
     conv16_steps<Gm, NTAP, K + 1>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
   }
 }
 template <class Gm, int NTAP>
 __device__ __forceinline__ void conv16(const float* __restrict__ buf, const float4* __restrict__ wl,
                                        f32x4v (&acc)[11], const uint32_t (&vm)[4], int lrow, int g) {
-  float4 b0[4], b1[4], aA[2][4], aB[2][4];
+  float4 b0[4], b1[4], aA[T16_GMAX][4], aB[T16_GMAX][4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) b0[q] = wl[(size_t)q * 64];
   load_pair16<Gm>(buf, vm, NTAP == 1 ? 4 : 0, 0, lrow, g, aA);
