@@ -92,7 +92,8 @@ struct az_engine {
   std::vector<float> blob;
   NetDev net;
   Net16Dev net16;                // k_tower16 fragments (64 filters)
-  bool use16;                    // AZHIP_TOWER=16|32 (default 16 when num_filters == 64)
+  int tower_pick;                // AZHIP_TOWER=16|32 forces a tower kernel; 0 = choose per launch (pick16)
+  int num_cu;
   int nn_cap;
   float* d_hfeat; float* d_X; float* d_A; float* d_P; float* d_V; float* d_Pinv;
   GEnv* d_tmp_env; int* d_iota; int* d_ntmp;
@@ -345,7 +346,8 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     hipLaunchKernelGGL(k_iota, dim3((e->nn_cap + 255) / 256), dim3(256), 0, e->stream, e->d_iota, e->nn_cap);
     memset(&e->net, 0, sizeof e->net);
     memset(&e->net16, 0, sizeof e->net16);
-    { const char* tw = getenv("AZHIP_TOWER"); e->use16 = (c->num_filters == 64) && !(tw && atoi(tw) == 32); }
+    { const char* tw = getenv("AZHIP_TOWER"); e->tower_pick = tw ? atoi(tw) : 0; }
+    { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); e->num_cu = pr.multiProcessorCount; }
     DISPATCH_GAME(c->game, AZCHK(set_kernel_attrs<Gm>()));
     // slot groups
     int ng = c->batch_size > 0 ? G / c->batch_size : 1;
@@ -652,13 +654,25 @@ extern "C" int az_net_get_params(const az_engine* e, float* blob, int64_t n) {
 }
 
 // launches tower + heads on `n` boards (device count in n_ptr when n < 0)
+// Which 64-filter tower serves a launch of up to n boards: both keep two workgroups per CU, so the cost is
+// (rounds of 2 x CUs workgroups) x (rows per workgroup); k_tower16 packs 176 rows (4 Connect-Four boards) per
+// workgroup, k_tower 128 (3 boards).  4096 Connect-Four leaves: 2 x 176 against 3 x 128.
+template <class Gm> static bool pick16(const az_engine* e, int n) {
+  if (e->cfg.num_filters != 64) return false;
+  if (e->tower_pick == 16) return true;
+  if (e->tower_pick == 32) return false;
+  const long slots = 2L * e->num_cu;
+  const long b16 = (n + T16<Gm>::TB - 1) / T16<Gm>::TB, b32 = (n + TOWER_ROWS / Gm::P - 1) / (TOWER_ROWS / Gm::P);
+  const long c16 = ((b16 + slots - 1) / slots) * T16<Gm>::RPAD, c32 = ((b32 + slots - 1) / slots) * TOWER_ROWS;
+  return c16 <= c32;
+}
 template <class Gm, int F, bool FROM_PLANES>
 static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
                         const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
   constexpr int TB = TOWER_ROWS / Gm::P;
   const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
   if (gt == 0) return AZ_OK;
-  if (F == 64 && e->use16)
+  if (F == 64 && pick16<Gm>(e, n_max))
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, FROM_PLANES>), (n_max + T16<Gm>::TB - 1) / T16<Gm>::TB, 256, T16<Gm>::BYTES, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
   else
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, F, FROM_PLANES>), gt, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
@@ -726,7 +740,7 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   hipStream_t st = e->gs[g], sn = e->gt[g];
   const int G = v.G;
   if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
-  if (F == 64 && e->use16)
+  if (F == 64 && pick16<Gm>(e, G))
     LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower16<Gm, false>), (G + T16<Gm>::TB - 1) / T16<Gm>::TB, 256, T16<Gm>::BYTES, e->net16, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
   else
     LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower<Gm, F, false>), (G + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
