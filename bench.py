@@ -31,11 +31,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md: v_mf
 
 
 def pmc_traffic(boards_per_launch):
-    """HBM bytes per k_tower launch from the committed PMC passes (profiles/r1/r1c_pmc_summary_groups1.json:
+    """HBM bytes per k_tower launch from the committed PMC passes (profiles/r1/r1d_pmc_summary_groups1.json:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this workload at 4096 boards per launch; KB units,
     FETCH doubled on gfx950 as MI355X_MICROARCH.md prescribes).  The write side (head features) scales with
     the boards of a launch, the read side (weights, once per XCD L2) does not.  None if the file is absent."""
-    p = os.path.join(ROOT, "profiles", "r1", "r1c_pmc_summary_groups1.json")
+    p = os.path.join(ROOT, "profiles", "r1", "r1d_pmc_summary_groups1.json")
     try:
         d = json.load(open(p))
         k = [v for name, v in d.items() if "k_tower" in name][0]
@@ -177,7 +177,7 @@ def main():
             flops = local_evals * TOWER_FLOP
             achieved = flops / (tw["ms"] * 1e-3) / 1e12 if tw["ms"] > 0 else 0.0
             out["roofline"] = {
-                "kernel": "k_tower<ConnectFour,64,false>", "bound": "mfma", "achieved": achieved,
+                "kernel": "k_tower16<ConnectFour,false>", "bound": "mfma", "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": pmc_traffic(local_evals / max(tw["launches"], 1)),
                 "flop_per_board": TOWER_FLOP, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
