@@ -130,3 +130,31 @@ def test_self_play_step_report():
     assert rep.samples_gen_speed > 0 and 0 < rep.average_exploration_depth < 9 and rep.mcts_memory_footprint > 0
     assert 1 <= rep.memory_num_distinct_boards <= rep.memory_size
     assert all(abs(s.z) <= 1 and s.t >= 1 and abs(s.π.sum() - 1) < 1e-12 for s in mem)
+
+
+def test_shards_by_first_game_id_equal_the_unsharded_run():
+    """a rank simulates a contiguous range of GLOBAL game ids (first_game_id); the union of the
+    shards is the single-engine run, whatever the number of ranks (reset_every = 1)."""
+    import azhip
+    from azhip.network import random_params
+    hp = _hp(1)
+    blob = random_params(azhip.GAME_CONNECT_FOUR, hp, seed=8)
+    kw = dict(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, num_workers=6, batch_size=3, num_iters_per_turn=24,
+              cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=((0, 8), (1.0, 0.4)), reset_every=1,
+              seed=9, num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+
+    def run(first, count, workers):
+        k = dict(kw, num_workers=workers, batch_size=workers)
+        with azhip.Engine(**k) as e:
+            e.net_set_params(blob)
+            g, m, ng, nm, _ = e.selfplay_run(count, first_game_id=first)
+            return [(g[i].game_id, [(tuple(m[g[i].first_move + k].key), list(m[g[i].first_move + k].N), m[g[i].first_move + k].action)
+                                    for k in range(g[i].num_moves)]) for i in range(ng)]
+    whole = run(0, 11, 6)
+    from azhip.simulations import shard_games
+    parts = []
+    for r in range(3):
+        first, count = shard_games(11, 3, r)
+        parts += run(first, count, 4)
+    assert [g for g, _ in whole] == list(range(11)) == [g for g, _ in parts]
+    assert whole == parts
