@@ -242,13 +242,13 @@ extern "C" int az_engine_destroy(az_engine* e) {
 }
 
 template <class Gm, int F> static int set_kernel_attrs_f() {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   return AZ_OK;
 }
 template <class Gm> static int set_kernel_attrs() {
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm>::BYTES));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm>::BYTES));
   AZCHK((set_kernel_attrs_f<Gm, 64>()));
   AZCHK((set_kernel_attrs_f<Gm, 128>()));
   return AZ_OK;
@@ -527,22 +527,23 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   // k_tower16 fragments (16x16x4 MFMA): lane l of step s = 4 sq + q supplies channel c = (g&1)*32 + 2s + (g>>1),
   // g = l >> 4, for output column ct*16 + (l & 15)
   std::vector<float> c16_w(4), s16_w(4);
-  if (F == 64) {
-    c16_w.assign((size_t)2 * nb * 9 * 16 * 64 * 4 + 4, 0.0f);
+  const int CT = F / 16;                     // column tiles = waves = float4 of B per tap and lane
+  {
+    c16_w.assign((size_t)2 * nb * 9 * CT * CT * 64 * 4 + 4, 0.0f);
     const float* wc = blob + (size_t)9 * C * F + 5 * F;
     for (int l = 0; l < 2 * nb; ++l) {
       for (int t = 0; t < 9; ++t) {
         int dy = t / 3 - 1, dx = t % 3 - 1, wi = 1 - dx, wj = 1 - dy;
-        for (int ct = 0; ct < 4; ++ct) for (int sq = 0; sq < 4; ++sq) for (int ln = 0; ln < 64; ++ln) for (int q = 0; q < 4; ++q) {
-          int s = 4 * sq + q, g = ln >> 4, ci = (g & 1) * 32 + 2 * s + (g >> 1), co = ct * 16 + (ln & 15);
-          c16_w[(((((size_t)l * 9 + t) * 4 + ct) * 4 + sq) * 64 + ln) * 4 + q] = wc[wi + 3 * (wj + 3 * (ci + (size_t)F * co))];
+        for (int ct = 0; ct < CT; ++ct) for (int sq = 0; sq < CT; ++sq) for (int ln = 0; ln < 64; ++ln) for (int q = 0; q < 4; ++q) {
+          int s = 4 * sq + q, g = ln >> 4, ci = (g & 1) * (F / 2) + 2 * s + (g >> 1), co = ct * 16 + (ln & 15);
+          c16_w[(((((size_t)l * 9 + t) * CT + ct) * CT + sq) * 64 + ln) * 4 + q] = wc[wi + 3 * (wj + 3 * (ci + (size_t)F * co))];
         }
       }
       wc += (size_t)9 * F * F + 5 * F;
     }
     const int KK = 9 * C, K2s = (KK + 1) / 2, NS = (2 * K2s + 3) / 4;
-    s16_w.assign((size_t)4 * NS * 64, 0.0f);
-    for (int ct = 0; ct < 4; ++ct) for (int s = 0; s < NS; ++s) for (int ln = 0; ln < 64; ++ln) {
+    s16_w.assign((size_t)CT * NS * 64, 0.0f);
+    for (int ct = 0; ct < CT; ++ct) for (int s = 0; s < NS; ++s) for (int ln = 0; ln < 64; ++ln) {
       int p = 4 * s + (ln >> 4), k = (p & 1) * K2s + (p >> 1), co = ct * 16 + (ln & 15);
       if (k >= KK || p >= 2 * K2s) continue;
       int t = k / C, ci = k % C, dy = t / 3 - 1, dx = t % 3 - 1, wi = 1 - dx, wj = 1 - dy;
@@ -568,13 +569,10 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
     for (int k = 0; k < 4; ++k) hbn[(size_t)k * HF + npf + co] = vbn[(size_t)k * nvf + co];
   }
   pack_conv(hw.data(), 1, F, HF, HF, head_w.data());
-  std::vector<float> h16_w(4);
-  if (F == 64) {
-    h16_w.assign((size_t)16 * 64 * 4, 0.0f);
-    for (int ct = 0; ct < 4; ++ct) for (int sq = 0; sq < 4; ++sq) for (int ln = 0; ln < 64; ++ln) for (int q = 0; q < 4; ++q) {
-      int s = 4 * sq + q, g = ln >> 4, ci = (g & 1) * 32 + 2 * s + (g >> 1), co = ct * 16 + (ln & 15);
-      h16_w[((((size_t)ct) * 4 + sq) * 64 + ln) * 4 + q] = hw[ci + (size_t)F * co];
-    }
+  std::vector<float> h16_w((size_t)CT * CT * 64 * 4, 0.0f);
+  for (int ct = 0; ct < CT; ++ct) for (int sq = 0; sq < CT; ++sq) for (int ln = 0; ln < 64; ++ln) for (int q = 0; q < 4; ++q) {
+    int s = 4 * sq + q, g = ln >> 4, ci = (g & 1) * (F / 2) + 2 * s + (g >> 1), co = ct * 16 + (ln & 15);
+    h16_w[((((size_t)ct) * CT + sq) * 64 + ln) * 4 + q] = hw[ci + (size_t)F * co];
   }
   bn_fold(hb.data(), hbn.data(), HF, head_ss.data(), head_ss.data() + HF);
   // dense layers, k-major with k = p*nf + f; Flux Dense W[out + nout*(p + P*f)]
@@ -633,7 +631,7 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   nd.hd_ok = hd_ok ? 1 : 0;
   Net16Dev n16;
   memset(&n16, 0, sizeof n16);
-  if (F == 64) {
+  {
     n16.nblocks = nb;
     AZCHK(up(s16_w, &n16.stem_w)); n16.stem_ss = nd.stem_ss;
     AZCHK(up(c16_w, &tmp)); n16.conv_w = (const float4*)tmp; n16.conv_ss = nd.conv_ss;
@@ -658,10 +656,9 @@ extern "C" int az_net_get_params(const az_engine* e, float* blob, int64_t n) {
 // (rounds of 2 x CUs workgroups) x (rows per workgroup); k_tower16 packs 176 rows (4 Connect-Four boards) per
 // workgroup, k_tower 128 (3 boards).  4096 Connect-Four leaves: 2 x 176 against 3 x 128.
 template <class Gm> static bool pick16(const az_engine* e, int n) {
-  if (e->cfg.num_filters != 64) return false;
   if (e->tower_pick == 16) return true;
   if (e->tower_pick == 32) return false;
-  const long slots = 2L * e->num_cu;
+  const long slots = (e->cfg.num_filters == 64 ? 2L : 1L) * e->num_cu;      // resident workgroups (LDS-limited)
   const long b16 = (n + T16<Gm>::TB - 1) / T16<Gm>::TB, b32 = (n + TOWER_ROWS / Gm::P - 1) / (TOWER_ROWS / Gm::P);
   const long c16 = ((b16 + slots - 1) / slots) * T16<Gm>::RPAD, c32 = ((b32 + slots - 1) / slots) * TOWER_ROWS;
   return c16 <= c32;
@@ -672,8 +669,9 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
   constexpr int TB = TOWER_ROWS / Gm::P;
   const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
   if (gt == 0) return AZ_OK;
-  if (F == 64 && pick16<Gm>(e, n_max))
-    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, FROM_PLANES>), (n_max + T16<Gm>::TB - 1) / T16<Gm>::TB, 256, T16<Gm>::BYTES, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
+  constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
+  if (pick16<Gm>(e, n_max))
+    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES>), (n_max + TB16 - 1) / TB16, THR16, LDS16, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
   else
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, F, FROM_PLANES>), gt, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
   if (e->net.hd_ok)
@@ -740,8 +738,9 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   hipStream_t st = e->gs[g], sn = e->gt[g];
   const int G = v.G;
   if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
-  if (F == 64 && pick16<Gm>(e, G))
-    LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower16<Gm, false>), (G + T16<Gm>::TB - 1) / T16<Gm>::TB, 256, T16<Gm>::BYTES, e->net16, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
+  constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
+  if (pick16<Gm>(e, G))
+    LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower16<Gm, F, false>), (G + TB16 - 1) / TB16, THR16, LDS16, e->net16, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
   else
     LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower<Gm, F, false>), (G + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
   if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }

@@ -34,19 +34,22 @@ struct Net16Dev {
   const float* head_ss;     // [2][64]
 };
 
-template <class Gm> struct T16 {
+template <class Gm, int F = 64> struct T16 {
   static constexpr int NTILE = 11, RPAD = NTILE * 16;
   static constexpr int TB = RPAD / Gm::P;            // 4 Connect-Four boards, 19 Tic-tac-toe, 12 Mancala
   static constexpr int ROWS = TB * Gm::P;
-  static constexpr int STRIDE = 68;
+  static constexpr int STRIDE = F + 4;
   static constexpr int BUF = (RPAD + 1) * STRIDE;    // row RPAD = zeros
   static constexpr int PLANES = (RPAD + 1) * Gm::C;
-  static constexpr int BYTES = (BUF + PLANES) * 4;
+  static constexpr int BYTES = (BUF + PLANES) * 4;   // 50 KB at F = 64 (2 workgroups per CU), 96 KB at F = 128 (1)
+  static constexpr int WAVES = F / 16, THREADS = 64 * WAVES;
+  static constexpr int KH = F / 64;                  // 64-channel halves of a tap (one pipeline step each)
+  static constexpr int SQ = F / 16;                  // float4 of B per tap and lane
 };
 
 // tap-validity bits of this lane's row in tile `tile`: 9 bits per tile, 3 tiles per word
 __device__ __forceinline__ uint32_t vmask(const uint32_t (&vm)[4], int tile) { return vm[tile / 3] >> (9 * (tile % 3)); }
-__device__ __forceinline__ int pos64(int c) { return ((c >> 5) + 2 * (c & 1)) * 16 + ((c & 31) >> 1); }
+template <int F> __device__ __forceinline__ int posF(int c) { return ((c >= F / 2 ? 1 : 0) + 2 * (c & 1)) * (F / 4) + ((c % (F / 2)) >> 1); }
 
 // One 64 -> 64 convolution (NTAP = 9: 3x3, NTAP = 1: 1x1) into the 11 accumulators of this wave.
 // The work is a fully unrolled sequence of steps (tap, tile pair); the A rows of step k+1 are read from LDS and
@@ -61,10 +64,10 @@ __device__ __forceinline__ int pos64(int c) { return ((c >> 5) + 2 * (c & 1)) * 
 static constexpr int T16_STEPS = AZ_T16_LAST3 ? 5 : 6;
 static constexpr int T16_GMAX = AZ_T16_LAST3 ? 3 : 2;
 __device__ __forceinline__ constexpr int t16_gsize(int pair) { return AZ_T16_LAST3 ? (pair == 4 ? 3 : 2) : (pair == 5 ? 1 : 2); }
-template <class Gm>
-__device__ __forceinline__ void load_pair16(const float* __restrict__ buf, const uint32_t (&vm)[4], int tap, int pair,
+template <class Gm, int F>
+__device__ __forceinline__ void load_pair16(const float* __restrict__ buf, const uint32_t (&vm)[4], int tap, int pair, int kh,
                                             int lrow, int g, float4 (&a)[T16_GMAX][4]) {
-  using T = T16<Gm>;
+  using T = T16<Gm, F>;
   const int delta = (tap / 3 - 1) * Gm::W + (tap % 3 - 1);
 #pragma unroll
   for (int u = 0; u < T16_GMAX; ++u) {
@@ -72,15 +75,16 @@ __device__ __forceinline__ void load_pair16(const float* __restrict__ buf, const
     if (u < t16_gsize(pair)) {
       const bool ok = (vmask(vm, tile) >> tap) & 1;
       const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
-      const float* p = buf + row * T::STRIDE + g * 16;
+      const float* p = buf + row * T::STRIDE + g * (F / 4) + kh * 16;
 #pragma unroll
       for (int q = 0; q < 4; ++q) a[u][q] = *(const float4*)(p + q * 4);
     }
   }
 }
-template <int PAIR>
-__device__ __forceinline__ void mfma_pair16(const float4 (&a)[T16_GMAX][4], const float4 (&b)[4], f32x4v (&acc)[11]) {
+template <int PAIR, int KHI, int SQ>
+__device__ __forceinline__ void mfma_pair16(const float4 (&a)[T16_GMAX][4], const float4 (&bfull)[SQ], f32x4v (&acc)[11]) {
   constexpr int t0 = PAIR * 2, ng = t16_gsize(PAIR);
+  const float4* b = bfull + KHI * 4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -93,51 +97,52 @@ __device__ __forceinline__ void mfma_pair16(const float4 (&a)[T16_GMAX][4], cons
     for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].w, b[q].w, acc[t0 + u], 0, 0, 0);
   }
 }
-template <class Gm, int NTAP, int K>
+template <class Gm, int F, int NTAP, int K>
 __device__ __forceinline__ void conv16_steps(const float* __restrict__ buf, const float4* __restrict__ wl, f32x4v (&acc)[11],
-                                             const uint32_t (&vm)[4], int lrow, int g, float4 (&b0)[4], float4 (&b1)[4],
+                                             const uint32_t (&vm)[4], int lrow, int g, float4 (&b0)[F / 16], float4 (&b1)[F / 16],
                                              float4 (&aA)[T16_GMAX][4], float4 (&aB)[T16_GMAX][4]) {
-  if constexpr (K < NTAP * T16_STEPS) {
-    constexpr int t = K / T16_STEPS, p = K % T16_STEPS;
-    constexpr int tap = NTAP == 1 ? 4 : t;
+  using T = T16<Gm, F>;
+  constexpr int SPT = T16_STEPS * T::KH;            // pipeline steps per tap: (64-channel half, tile pair)
+  if constexpr (K < NTAP * SPT) {
+    constexpr int t = K / SPT, kh = (K % SPT) / T16_STEPS, p = K % T16_STEPS;
     float4 (&cur)[T16_GMAX][4] = (K & 1) ? aB : aA;
     float4 (&nxt)[T16_GMAX][4] = (K & 1) ? aA : aB;
-    float4 (&bc)[4] = (t & 1) ? b1 : b0;
-    float4 (&bn)[4] = (t & 1) ? b0 : b1;
-    if constexpr (p == 0 && t + 1 < NTAP) {
+    float4 (&bc)[F / 16] = (t & 1) ? b1 : b0;
+    float4 (&bn)[F / 16] = (t & 1) ? b0 : b1;
+    if constexpr (K % SPT == 0 && t + 1 < NTAP) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bn[q] = wl[(size_t)((t + 1) * 16 + q) * 64];
+      for (int q = 0; q < T::SQ; ++q) bn[q] = wl[(size_t)((t + 1) * T::WAVES * T::SQ + q) * 64];
     }
-    if constexpr (K + 1 < NTAP * T16_STEPS) {
-      constexpr int t1 = (K + 1) / T16_STEPS, p1 = (K + 1) % T16_STEPS;
-      load_pair16<Gm>(buf, vm, NTAP == 1 ? 4 : t1, p1, lrow, g, nxt);
+    if constexpr (K + 1 < NTAP * SPT) {
+      constexpr int t1 = (K + 1) / SPT, kh1 = ((K + 1) % SPT) / T16_STEPS, p1 = (K + 1) % T16_STEPS;
+      load_pair16<Gm, F>(buf, vm, NTAP == 1 ? 4 : t1, p1, kh1, lrow, g, nxt);
     }
-    (void)tap;
-    mfma_pair16<p>(cur, bc, acc);
+    mfma_pair16<p, kh, F / 16>(cur, bc, acc);
 #ifndef AZ_T16_FENCE
 #define AZ_T16_FENCE 1     // fence the scheduler every N steps
 #endif
     if constexpr (K % AZ_T16_FENCE == AZ_T16_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
-    conv16_steps<Gm, NTAP, K + 1>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
+    conv16_steps<Gm, F, NTAP, K + 1>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
   }
 }
-template <class Gm, int NTAP>
+template <class Gm, int F, int NTAP>
 __device__ __forceinline__ void conv16(const float* __restrict__ buf, const float4* __restrict__ wl,
                                        f32x4v (&acc)[11], const uint32_t (&vm)[4], int lrow, int g) {
-  float4 b0[4], b1[4], aA[T16_GMAX][4], aB[T16_GMAX][4];
+  float4 b0[F / 16], b1[F / 16], aA[T16_GMAX][4], aB[T16_GMAX][4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) b0[q] = wl[(size_t)q * 64];
-  load_pair16<Gm>(buf, vm, NTAP == 1 ? 4 : 0, 0, lrow, g, aA);
+  for (int q = 0; q < F / 16; ++q) b0[q] = wl[(size_t)q * 64];
+  load_pair16<Gm, F>(buf, vm, NTAP == 1 ? 4 : 0, 0, 0, lrow, g, aA);
   __builtin_amdgcn_sched_barrier(0);
-  conv16_steps<Gm, NTAP, 0>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
+  conv16_steps<Gm, F, NTAP, 0>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
 }
 
-template <class Gm, bool FROM_PLANES>
-__global__ void __launch_bounds__(256, 2)
+template <int F> struct T16Threads { static constexpr int V = 64 * (F / 16); };
+template <class Gm, int F, bool FROM_PLANES>
+__global__ void __launch_bounds__(T16Threads<F>::V, 2)
 k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
           const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
-  using T = T16<Gm>;
-  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, C = Gm::C, TB = T::TB, STRIDE = T::STRIDE, F = 64;
+  using T = T16<Gm, F>;
+  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, C = Gm::C, TB = T::TB, STRIDE = T::STRIDE, NTHR = T::THREADS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
   float* planes = lds + T::BUF;
@@ -148,7 +153,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   const int lrow = lane & 15, g = lane >> 4;
 
   // ---- input planes [RPAD + 1][C] and the zero row of the activation buffer ----------------------
-  for (int i = tid; i < T::PLANES; i += 256) {
+  for (int i = tid; i < T::PLANES; i += NTHR) {
     const int row = i / C, c = i % C;
     const int b = row / P, q = row % P;
     float val = 0.0f;
@@ -158,7 +163,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
     }
     planes[i] = val;
   }
-  for (int i = tid; i < STRIDE; i += 256) buf[T::RPAD * STRIDE + i] = 0.0f;
+  for (int i = tid; i < STRIDE; i += NTHR) buf[T::RPAD * STRIDE + i] = 0.0f;
   // validity of the 9 taps for this lane's row of every tile
   uint32_t vm[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -176,7 +181,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   }
   // this lane's output element (tile, i): row = tile*16 + g*4 + i, channel = wave*16 + lrow
   const int ch = wave * 16 + lrow;
-  const int opos = pos64(ch);
+  const int opos = posF<F>(ch);
   __syncthreads();
 
   f32x4v acc[11];
@@ -215,7 +220,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
 
   // ---- residual tower ---------------------------------------------------------------------------------
   float xres[11][4];
-  const size_t LAYER_W = (size_t)9 * 16 * 64;       // float4 per layer
+  const size_t LAYER_W = (size_t)9 * T::WAVES * T::SQ * 64;       // float4 per layer
   for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
 #pragma unroll
     for (int t = 0; t < 11; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -223,7 +228,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
     // loop, which would cost ~100 VGPRs for the whole kernel
     int lrow_l = lrow;
     asm volatile("" : "+v"(lrow_l));
-    conv16<Gm, 9>(buf, net.conv_w + (size_t)layer * LAYER_W + (size_t)wave * 4 * 64 + lane, acc, vm, lrow_l, g);
+    conv16<Gm, F, 9>(buf, net.conv_w + (size_t)layer * LAYER_W + (size_t)wave * T::SQ * 64 + lane, acc, vm, lrow_l, g);
     const float sc = net.conv_ss[(size_t)layer * 2 * F + ch], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch];
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();                                 // every wave has finished reading the buffer
@@ -254,7 +259,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   // ---- both 1x1 head convolutions + BN + ReLU as one 64 => 64 GEMM ------------------------------------
 #pragma unroll
   for (int t = 0; t < 11; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  conv16<Gm, 1>(buf, net.head_w + (size_t)wave * 4 * 64 + lane, acc, vm, lrow, g);
+  conv16<Gm, F, 1>(buf, net.head_w + (size_t)wave * T::SQ * 64 + lane, acc, vm, lrow, g);
   {
     const float sc = net.head_ss[ch], sh = net.head_ss[F + ch];
     // head features straight from the accumulators to HBM, [board][P][64] in natural channel order
