@@ -1,21 +1,24 @@
-// resnet.h -- the two-headed ResNet oracle (src/networks/architectures/resnet.jl:53-92, test
-// mode) as two CDNA4 kernels.
+// resnet.h -- the two-headed ResNet oracle (src/networks/architectures/resnet.jl:53-92, test mode): the first
+// tower kernel (k_tower, 32x32x2 MFMA; still used for launch sizes it quantises better, see pick16 in azhip.hip),
+// and the dense heads.  The 16x16x4 tower lives in resnet16.h.
 //
-//  k_tower   one workgroup (4 wavefronts) owns TB = 128/P whole boards (3 Connect-Four boards =
-//            126 of 128 GEMM rows) and runs stem + every residual block + the two 1x1 head
-//            convolutions WITHOUT leaving the CU: activations live in two LDS buffers
-//            ([129 rows][F + 4 pad] fp32, row 128 = zeros for the padding taps), so the tower's
-//            only HBM traffic is 16 B of state in and P*64 fp32 of head features out per board.
-//            Every 3x3 convolution is an implicit GEMM on v_mfma_f32_32x32x2_f32: wavefront w owns
-//            rows 32w..32w+31 and all F output channels (F/32 accumulators of 16 VGPRs); the A
-//            operand (activations) is a ds_read_b128 of 4 consecutive channels of the tap-shifted
-//            row, the B operand (weights) a coalesced 1 KiB global_load_dwordx4 from a buffer
-//            pre-packed in fragment order (L2-resident: 147 KB per layer).  BatchNorm (folded to
-//            scale/shift), residual add and ReLU are the accumulator epilogue.
+//  k_tower   one workgroup owns TB = 128/P whole boards (3 Connect-Four boards = 126 of 128 GEMM rows) and runs
+//            stem + every residual block + the two 1x1 head convolutions WITHOUT leaving the CU: activations
+//            live in two LDS buffers ([129 rows][F + 4 pad] fp32, row 128 = zeros for the padding taps), so the
+//            tower's only HBM traffic is 16 B of state in and P*F fp32 of head features out per board.
+//            Every convolution (stem included) is an implicit GEMM on v_mfma_f32_32x32x2_f32: wave (rh, nh)
+//            owns rows rh*64..+63 x output channels nh*32..+31 (two accumulators sharing one weight-fragment
+//            stream); the A operand (activations) is a ds_read_b128 of 4 consecutive channels of the tap-shifted
+//            row, the B operand (weights) a coalesced 1 KiB global_load_dwordx4 from a buffer pre-packed in
+//            fragment order (L2-resident), requested one tap ahead and threaded through the MFMA stream.
+//            BatchNorm (folded to scale/shift), residual add and ReLU are the accumulator epilogue.
 //            The MFMA K order is the fp32 contract of include/azhip.h: lanes 0-31 carry channel j,
 //            lanes 32-63 channel F/2 + j, so each output is the fma chain the oracle restates.
-//  k_heads   flatten + Dense layers + softmax / tanh + Network.forward_normalized
-//            (src/networks/network.jl:264-271), one thread per output, sequential fp32 chain.
+//  k_heads_mfma / k_heads
+//            flatten + Dense layers + softmax / tanh + Network.forward_normalized
+//            (src/networks/network.jl:264-271): K = P*nf ascending chain per output, on MFMA (32-board tiles)
+//            or, for head widths that are not multiples of 4, one VALU thread per output.
+//  Debug/ablation switches (timing experiments only): AZ_STAGGER, AZ_ABLATE_A, AZ_ABLATE_B, NetDev::dbg stamps.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
