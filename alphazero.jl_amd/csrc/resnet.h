@@ -18,7 +18,7 @@
 //            flatten + Dense layers + softmax / tanh + Network.forward_normalized
 //            (src/networks/network.jl:264-271): K = P*nf ascending chain per output, on MFMA (32-board tiles)
 //            or, for head widths that are not multiples of 4, one VALU thread per output.
-//  Debug/ablation switches (timing experiments only): AZ_STAGGER, AZ_ABLATE_A, AZ_ABLATE_B, NetDev::dbg stamps.
+//  Debug/ablation switches (timing experiments only): AZ_STAGGER, AZ_ABLATE_B, NetDev::dbg stamps.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
