@@ -116,8 +116,6 @@ class GameEnv:
         return self._reward
 
     def actions_mask(self):
-        if self._terminated and self._spec.game_id == L.GAME_TICTACTOE:
-            pass
         _, A = self._spec._eng().encode([self._state])
         return A[0] > 0
 
