@@ -96,6 +96,7 @@ SYMBOLS = {
     "az_selfplay_get_stats": [_VP, C.POINTER(SelfplayStats)],
     "az_selfplay_active": [_VP, C.POINTER(_I32)],
     "az_selfplay_end": [_VP],
+    "az_arena_run": [_VP, _VP, _I32, _I32, _I32, C.POINTER(TraceBuf), _VP, C.POINTER(C.c_double), PROGRESS_CB, _VP],
     "az_push_trace": [_VP, _I32, C.c_double, _VP, _VP],
     "az_prof_enable": [_VP, _I32],
     "az_prof_get": [_VP, C.POINTER(Prof)],

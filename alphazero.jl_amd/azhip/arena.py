@@ -1,0 +1,91 @@
+"""Arena mirror: pit_networks / compare_networks (src/training.jl:130-172) over the device engines.
+
+The reference pits TwoPlayers(MctsPlayer(contender), MctsPlayer(baseline)) through `simulate` with a
+two-network inference server (simulations.jl:70-99).  Here each network gets its own engine (its own trees
+per worker) and az_arena_run steps both: every ply the workers are split by the player to move and each engine
+explores its share.  SimParams.flip_probability and alternate_colors are honoured (play.jl:305-307,
+simulations.jl:221-223)."""
+import time
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Engine
+from .mcts import oracle_kind
+from .network import copy as network_copy
+from .params import ArenaParams, engine_options
+from .play import MctsPlayer, TwoPlayers
+from .trace import Trace
+
+
+@dataclass
+class Evaluation:
+    """Report.Evaluation, report.jl:73-80"""
+    legend: str
+    avgr: float
+    redundancy: float
+    rewards: np.ndarray
+    baseline_rewards: Optional[np.ndarray]
+    time: float
+
+
+def _engine(gspec, player: MctsPlayer, sim, device, seed):
+    kind = oracle_kind(player.oracle)
+    kw = engine_options(player.params, sim, seed=seed, arena=True)
+    if kind == L.ORACLE_RESNET:
+        kw.update(player.oracle.engine_options())
+    e = Engine(game=gspec.game_id, oracle=kind, device=device, **kw)
+    if kind == L.ORACLE_RESNET:
+        e.net_set_params(player.oracle.params())
+    return e
+
+
+def arena_traces(games, moves, ngames, num_actions):
+    """records -> [(Trace, colors_flipped is NOT stored: derive from the game id)].  Trace.states are the
+    un-flipped states like the reference's; policies are full-width visit frequencies of the state the
+    player actually saw (the reference pairs them with the un-flipped state too, play.jl:305-313)."""
+    out = []
+    for i in range(ngames):
+        g = games[i]
+        t = Trace((int(moves[g.first_move].key[0]), int(moves[g.first_move].key[1])))
+        for k in range(g.num_moves):
+            m = moves[g.first_move + k]
+            n = np.array(m.N[:num_actions], dtype=np.float64)
+            nxt = (int(moves[g.first_move + k + 1].key[0]), int(moves[g.first_move + k + 1].key[1])) \
+                if k + 1 < g.num_moves else (int(g.final_key[0]), int(g.final_key[1]))
+            t.push(n / n.sum(), float(m.reward), nxt)
+        out.append(t)
+    return out
+
+
+def pit_players(gspec, players: TwoPlayers, sim, game_simulated=None, device=0, seed=1, first_game_id=0):
+    """simulate(Simulator(make_oracles, record_trace) do ... TwoPlayers(white, black)) + rewards_and_redundancy:
+    returns (rewards from players.white's side, redundancy, traces)."""
+    if not gspec.two_players():
+        raise ValueError("pit_players needs a two-player game")
+    if not (isinstance(players.white, MctsPlayer) and isinstance(players.black, MctsPlayer)):
+        raise TypeError("the device arena pits two MctsPlayers")
+    with _engine(gspec, players.white, sim, device, seed) as ec, _engine(gspec, players.black, sim, device, seed) as eb:
+        games, moves, ng, nm, rewards, red = ec.arena_run(eb, sim.num_games, first_game_id=first_game_id,
+                                                          alternate_colors=sim.alternate_colors,
+                                                          progress=game_simulated)
+    return rewards, red, arena_traces(games, moves, ng, gspec.num_actions())
+
+
+def pit_networks(gspec, contender, baseline, params: ArenaParams, handler=None, device=0, seed=1):
+    """training.jl:130-144 -> (rewards vector, redundancy)"""
+    white = MctsPlayer(gspec, network_copy(contender, on_gpu=params.sim.use_gpu, test_mode=True), params.mcts)
+    black = MctsPlayer(gspec, network_copy(baseline, on_gpu=params.sim.use_gpu, test_mode=True), params.mcts)
+    cb = (lambda: handler.checkpoint_game_played()) if handler is not None else None
+    rewards, red, _ = pit_players(gspec, TwoPlayers(white, black), params.sim, cb, device, seed)
+    return rewards, red
+
+
+def compare_networks(gspec, contender, baseline, params: ArenaParams, handler=None, device=0, seed=1):
+    """training.jl:159-172 (two-player branch; the device games are all two-player)"""
+    t0 = time.perf_counter()
+    rewards, red = pit_networks(gspec, contender, baseline, params, handler, device, seed)
+    return Evaluation("Most recent NN versus best NN so far", float(np.mean(rewards)), red, rewards, None,
+                      time.perf_counter() - t0)

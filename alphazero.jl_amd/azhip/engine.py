@@ -225,3 +225,15 @@ class Engine:
 
     def selfplay_end(self):
         check(lib().az_selfplay_end(self._h))
+
+    # ---- arena ----------------------------------------------------------------------------------
+    def arena_run(self, baseline, num_games, first_game_id=0, alternate_colors=False, progress=None, traces=True):
+        """pit_networks: self = contender's engine, baseline = the other player's engine.
+        Returns (games, moves, ngames, nmoves, rewards, redundancy)."""
+        tb, games, moves = self._trace_buf(num_games, num_games * self.max_moves()) if traces else (None, None, None)
+        rewards = np.zeros(num_games, dtype=np.float64)
+        red = C.c_double()
+        cb = L.PROGRESS_CB((lambda user: progress()) if progress else (lambda user: None))
+        check(lib().az_arena_run(self._h, baseline._h, num_games, first_game_id, 1 if alternate_colors else 0,
+                                 C.byref(tb) if traces else None, _vp(rewards), C.byref(red), cb, None))
+        return games, moves, (tb.num_games if traces else 0), (tb.num_moves if traces else 0), rewards, red.value

@@ -59,6 +59,14 @@ class MctsParams:
 
 
 @dataclass
+class ArenaParams:
+    """params.jl:139-143"""
+    mcts: "MctsParams"
+    sim: "SimParams"
+    update_threshold: float
+
+
+@dataclass
 class SimParams:
     """params.jl:92-101"""
     num_games: int
@@ -71,17 +79,19 @@ class SimParams:
     alternate_colors: bool = False
 
 
-def check_sim_params(p: SimParams):
+def check_sim_params(p: SimParams, arena=False):
     """the part of check_params (params.jl:361-384) that concerns this path"""
     if p.batch_size > p.num_workers:
         raise ValueError("batch_size must be <= num_workers")
-    if p.flip_probability != 0.0:
-        raise ValueError("flip_probability > 0 is not supported on the device self-play path")
+    if not 0.0 <= p.flip_probability <= 1.0:
+        raise ValueError("flip_probability must be in [0, 1]")
+    if p.flip_probability != 0.0 and not arena:
+        raise ValueError("flip_probability > 0 is not supported on the device self-play path (arena only)")
 
 
-def engine_options(mcts: MctsParams, sim: SimParams, seed=1):
+def engine_options(mcts: MctsParams, sim: SimParams, seed=1, arena=False):
     """MctsParams + SimParams -> az_engine_cfg fields (SURVEY.md §8b 'Config mapping')."""
-    check_sim_params(sim)
+    check_sim_params(sim, arena=arena)
     xs, ys = mcts.temperature.breakpoints()
     return dict(gamma=mcts.gamma, cpuct=mcts.cpuct, dirichlet_noise_eps=mcts.dirichlet_noise_ϵ,
                 dirichlet_noise_alpha=mcts.dirichlet_noise_α, prior_temperature=mcts.prior_temperature,

@@ -71,6 +71,31 @@ class MctsPlayer:
             self._mcts.reset()
 
 
+class TwoPlayers:
+    """TwoPlayers(white, black), play.jl:248-282: behaves as `white` when white is to play, else as `black`."""
+
+    def __init__(self, white, black):
+        self.white, self.black = white, black
+
+    def _cur(self, game):
+        return self.white if game.white_playing() else self.black
+
+    def think(self, game):
+        return self._cur(game).think(game)
+
+    def player_temperature(self, game, turn):
+        return self._cur(game).player_temperature(game, turn)
+
+    def reset_player(self):
+        self.white.reset_player()
+        self.black.reset_player()
+
+
+def flipped_colors(p: TwoPlayers):
+    """play.jl:253"""
+    return TwoPlayers(p.black, p.white)
+
+
 def play_game(gspec, player, flip_probability=0.0, rng=None):
     """play_game, play.jl:298-315 -- host-stepped (one device search per move).  Self-play at scale goes
     through simulations.simulate instead, which runs this loop for thousands of games on the GPU."""

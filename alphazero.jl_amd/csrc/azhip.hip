@@ -15,6 +15,7 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <unordered_set>
 
 #include "../../include/az_numerics.h"
 #include "../../include/azhip.h"
@@ -92,7 +93,7 @@ struct az_engine {
   std::vector<float> blob;
   NetDev net;
   Net16Dev net16;                // k_tower16 fragments (64 filters)
-  int tower_pick;                // AZHIP_TOWER=16|32 forces a tower kernel; 0 = choose per launch (pick16)
+  int tower_pick;                // AZHIP_TOWER=16|32|3 forces a tower kernel (3 = k_tower16 with 3 row tiles); 0 = choose per launch
   int num_cu;
   int nn_cap;
   float* d_hfeat; float* d_X; float* d_A; float* d_P; float* d_V; float* d_Pinv;
@@ -101,6 +102,7 @@ struct az_engine {
   int* d_slots; uint32_t* d_gids; GEnv* d_roots; uint32_t* d_moves; double* d_eta; int* d_offsets;
   az_move_rec* d_stage; unsigned long long* d_keys; int* d_actions; unsigned long long* d_next; signed char* d_term; float* d_reward;
   char* d_nodebuf;
+  int* d_visits;
   int io_cap;
   // self-play state
   bool running;
@@ -273,7 +275,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   if (c->num_workers < 1) return fail(AZ_ERR_BAD_ARG, "num_workers must be >= 1");
   if (c->batch_size > c->num_workers) return fail(AZ_ERR_BAD_ARG, "batch_size (%d) must be <= num_workers (%d) (src/params.jl:361-384)", c->batch_size, c->num_workers);
   if (c->num_iters_per_turn < 2) return fail(AZ_ERR_BAD_ARG, "num_iters_per_turn must be >= 2 (with 1 the policy is 0/0, src/mcts.jl:267)");
-  if (c->flip_probability != 0.0) return fail(AZ_ERR_BAD_ARG, "flip_probability != 0 is not supported on the device path");
+  if (!(c->flip_probability >= 0.0 && c->flip_probability <= 1.0)) return fail(AZ_ERR_BAD_ARG, "flip_probability must be in [0, 1]");
   if (c->temperature_len < 1 || c->temperature_len > AZ_SCHED_MAX) return fail(AZ_ERR_BAD_ARG, "temperature schedule needs 1..%d breakpoints", AZ_SCHED_MAX);
   if (c->reset_every < 0) return fail(AZ_ERR_BAD_ARG, "reset_every must be >= 0");
   if (!(c->prior_temperature >= 0.0)) return fail(AZ_ERR_BAD_ARG, "prior_temperature must be >= 0");
@@ -337,6 +339,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &e->d_keys, (size_t)2 * e->io_cap)); AZCHK(dalloc(e, &e->d_actions, e->io_cap));
     AZCHK(dalloc(e, &e->d_next, (size_t)2 * e->io_cap)); AZCHK(dalloc(e, &e->d_term, e->io_cap)); AZCHK(dalloc(e, &e->d_reward, e->io_cap));
     AZCHK(dalloc(e, &e->d_nodebuf, 512));
+    AZCHK(dalloc(e, &e->d_visits, (size_t)e->io_cap * (AZ_MAX_ACTIONS + 1)));
     // network buffers
     e->nn_cap = e->io_cap;
     AZCHK(dalloc(e, &e->d_hfeat, (size_t)e->nn_cap * gi.P * std::max(64, c->num_filters), false));
@@ -652,19 +655,25 @@ extern "C" int az_net_get_params(const az_engine* e, float* blob, int64_t n) {
 }
 
 // launches tower + heads on `n` boards (device count in n_ptr when n < 0)
-// Which 64-filter tower serves a launch of up to n boards: both keep two workgroups per CU, so the cost is
-// (rounds of 2 x CUs workgroups) x (rows per workgroup); k_tower16 packs 176 rows (4 Connect-Four boards) per
-// workgroup, k_tower 128 (3 boards).  4096 Connect-Four leaves: 2 x 176 against 3 x 128.
-template <class Gm> static bool pick16(const az_engine* e, int n) {
-  if (e->tower_pick == 16) return true;
-  if (e->tower_pick == 32) return false;
-  // 128 filters, several slot groups: one workgroup per CU either way and the groups' towers already fill each
-  // other's partial rounds, where k_tower's smaller workgroups pack slightly better (measured 1.10 vs 1.07 M sims/s)
-  if (e->cfg.num_filters == 128 && e->ngroups > 1) return false;
-  const long slots = (e->cfg.num_filters == 64 ? 2L : 1L) * e->num_cu;      // resident workgroups (LDS-limited)
-  const long b16 = (n + T16<Gm>::TB - 1) / T16<Gm>::TB, b32 = (n + TOWER_ROWS / Gm::P - 1) / (TOWER_ROWS / Gm::P);
-  const long c16 = ((b16 + slots - 1) / slots) * T16<Gm>::RPAD, c32 = ((b32 + slots - 1) / slots) * TOWER_ROWS;
-  return c16 <= c32;
+// Which tower kernel serves a launch of up to n boards.  A workgroup's layer chain is sequential and the MFMA
+// pipe of a CU is shared by its resident workgroups, so the launch costs (workgroups per CU, rounded up) x (rows
+// per workgroup): k_tower16 packs 176 rows (4 Connect-Four boards), k_tower 128 (3 boards), k_tower16 with 3 row
+// tiles 48 (1 board; +10 %: a third of the weight reuse, more barriers per row).  4096 Connect-Four leaves:
+// 4 x 176 < 6 x 128; 128 leaves: 1 x 48 << 1 x 128 (measured tools/small_batch.sh: 0.39 vs 0.80 ms per wave at
+// 128 filters).  Returns 16, 32 or 3.
+template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
+  if (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3) return e->tower_pick;
+  const long cu = e->num_cu > 0 ? e->num_cu : 256;
+  const long b16 = (n + T16<Gm, F>::TB - 1) / T16<Gm, F>::TB, b32 = (n + TOWER_ROWS / Gm::P - 1) / (TOWER_ROWS / Gm::P);
+  const long b3 = (n + T16<Gm, F, 3>::TB - 1) / T16<Gm, F, 3>::TB;
+  const double c16 = (double)((b16 + cu - 1) / cu) * T16<Gm, F>::RPAD;
+  double c32 = (double)((b32 + cu - 1) / cu) * TOWER_ROWS;
+  const double c3 = 1.1 * (double)((b3 + cu - 1) / cu) * T16<Gm, F, 3>::RPAD;
+  // 128 filters, several slot groups: the groups' towers fill each other's partial rounds and k_tower's smaller
+  // workgroups pack slightly better (measured 1.10 vs 1.07 M sims/s at 2 x 2048)
+  if (F == 128 && e->ngroups > 1) c32 *= 0.9;
+  if (c3 <= c16 && c3 <= c32) return 3;
+  return c16 <= c32 ? 16 : 32;
 }
 template <class Gm, int F, bool FROM_PLANES>
 static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
@@ -673,7 +682,11 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
   const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
   if (gt == 0) return AZ_OK;
   constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
-  if (pick16<Gm>(e, n_max))
+  constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
+  const int tw = pick_tower<Gm, F>(e, n_max);
+  if (tw == 3)
+    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES, 3>), (n_max + TB3 - 1) / TB3, THR16, LDS3, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
+  else if (tw == 16)
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES>), (n_max + TB16 - 1) / TB16, THR16, LDS16, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
   else
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, F, FROM_PLANES>), gt, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
@@ -742,7 +755,11 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   const int G = v.G;
   if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
   constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
-  if (pick16<Gm>(e, G))
+  constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
+  const int tw = pick_tower<Gm, F>(e, G);
+  if (tw == 3)
+    LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower16<Gm, F, false, 3>), (G + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
+  else if (tw == 16)
     LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower16<Gm, F, false>), (G + TB16 - 1) / TB16, THR16, LDS16, e->net16, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
   else
     LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower<Gm, F, false>), (G + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
@@ -803,6 +820,41 @@ extern "C" int az_mcts_reset(az_engine* e) {
   return AZ_OK;
 }
 
+// MCTS.explore! (mcts.jl:239-245) for a list of slots, in three steps so that two engines can be driven
+// concurrently (arena): begin (roots + noise), nsims lock-step waves (asynchronous launches), end (sync + checks).
+// The other slots keep their trees.
+template <class Gm>
+static int explore_begin(az_engine* e, const std::vector<int>& slots, const std::vector<GEnv>& roots,
+                         const std::vector<uint32_t>& gids, const std::vector<uint32_t>& mv, const double* eta, int* nga) {
+  const int n = (int)slots.size();
+  *nga = 0;
+  if (!n) return AZ_OK;
+  int maxslot = 0;
+  for (int s : slots) maxslot = std::max(maxslot, s);
+  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
+  AZCHK(start_games<Gm>(e, slots, gids, &roots, 0, 0));
+  HIPCHK(hipMemcpyAsync(e->d_moves, mv.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
+  if (eta) HIPCHK(hipMemcpyAsync(e->d_eta, eta, sizeof(double) * (size_t)n * AZ_MAX_ACTIONS, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL((k_arm_noise<Gm>), dim3((n + 255) / 256), dim3(256), 0, e->stream, e->v, e->p, e->d_slots, e->d_moves, eta ? e->d_eta : nullptr, n);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *nga = std::min(e->ngroups, maxslot / e->gv[0].G + 1);
+  return AZ_OK;
+}
+static int explore_end(az_engine* e, int nga) {
+  if (!nga) return AZ_OK;
+  AZCHK(sync_groups(e));
+  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
+  return check_device_error(e);
+}
+template <class Gm>
+static int explore_slots(az_engine* e, const std::vector<int>& slots, const std::vector<GEnv>& roots,
+                         const std::vector<uint32_t>& gids, const std::vector<uint32_t>& mv, const double* eta, int nsims) {
+  int nga = 0;
+  AZCHK(explore_begin<Gm>(e, slots, roots, gids, mv, eta, &nga));
+  if (nga) for (int i = 0; i < nsims; ++i) AZCHK(wave<Gm>(e, nga));
+  return explore_end(e, nga);
+}
+
 extern "C" int az_mcts_explore(az_engine* e, const uint64_t* root_keys, int32_t nslots, int32_t nsims,
                                const double* eta, const uint32_t* game_ids, const uint32_t* moves) {
   ENGINE(e);
@@ -820,17 +872,8 @@ extern "C" int az_mcts_explore(az_engine* e, const uint64_t* root_keys, int32_t 
       if (roots[i].fin & 1) return fail(AZ_ERR_BAD_ARG, "root state %d is terminal", i);
     }
   });
-  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
-  DISPATCH_GAME(e->cfg.game, AZCHK(start_games<Gm>(e, slots, gids, &roots, 0, 0)));
-  HIPCHK(hipMemcpyAsync(e->d_moves, mv.data(), sizeof(uint32_t) * nslots, hipMemcpyHostToDevice, e->stream));
-  if (eta) HIPCHK(hipMemcpyAsync(e->d_eta, eta, sizeof(double) * (size_t)nslots * AZ_MAX_ACTIONS, hipMemcpyHostToDevice, e->stream));
-  DISPATCH_GAME(e->cfg.game, hipLaunchKernelGGL((k_arm_noise<Gm>), dim3((nslots + 255) / 256), dim3(256), 0, e->stream, e->v, e->p, e->d_slots, e->d_moves, eta ? e->d_eta : nullptr, nslots));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  const int nga = std::min(e->ngroups, (nslots + e->gv[0].G - 1) / e->gv[0].G);
-  for (int i = 0; i < nsims; ++i) DISPATCH_GAME(e->cfg.game, AZCHK(wave<Gm>(e, nga)));
-  AZCHK(sync_groups(e));
-  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
-  return check_device_error(e);
+  DISPATCH_GAME(e->cfg.game, AZCHK(explore_slots<Gm>(e, slots, roots, gids, mv, eta, nsims)));
+  return AZ_OK;
 }
 
 template <class Gm>
@@ -903,6 +946,7 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   ENGINE(e);
   if (e->running) return fail(AZ_ERR_STATE, "self-play already in progress");
   if (num_games == 0) return fail(AZ_ERR_BAD_ARG, "num_games must be != 0");
+  if (e->cfg.flip_probability != 0.0) return fail(AZ_ERR_BAD_ARG, "flip_probability != 0 is honoured by az_arena_run only (self-play configs use 0: the reference's traces pair the un-flipped state with the flipped policy, play.jl:305-313)");
   if (e->cfg.oracle == AZ_ORACLE_RESNET && !e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
   const int G = e->v.G;
   // a fresh player per worker (simulations.jl:217-218): empty trees, zero counters
@@ -1054,6 +1098,166 @@ extern "C" int az_selfplay_run(az_engine* e, int32_t num_games, int32_t first_ga
   az_selfplay_end(e);
   if (st != AZ_OK) g_err = keep;
   return st;
+}
+
+// =========================================================================================
+// arena: pit_networks (training.jl:130-144) = simulate (simulations.jl:207-244) over
+// TwoPlayers(MctsPlayer(contender), MctsPlayer(baseline)) (play.jl:248-282).  The two players
+// keep separate trees (one engine each); every ply the slots are split by the player to move,
+// each engine explores its share (MCTS.explore! on a slot list), and the host applies
+// play_game's loop body (flip, temperature, sample, play!, play.jl:305-313) with the same
+// select_action / Gm::play code the device self-play uses.
+// =========================================================================================
+namespace {
+struct ArenaSlot {
+  GEnv env;
+  uint32_t gid = 0;
+  int nmoves = 0, worker_sim_id = 0;
+  bool active = false;
+  std::vector<az_move_rec> moves;
+};
+struct KeyHash { size_t operator()(const std::pair<uint64_t, uint64_t>& k) const { return (size_t)az_hash_key(k.first, k.second); } };
+}
+
+template <class Gm>
+static int root_visits(az_engine* e, const std::vector<int>& slots, const std::vector<GEnv>& roots, std::vector<int>& out) {
+  const int n = (int)slots.size();
+  out.assign((size_t)n * (AZ_MAX_ACTIONS + 1), 0);
+  if (!n) return AZ_OK;
+  HIPCHK(hipMemcpyAsync(e->d_slots, slots.data(), sizeof(int) * n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_roots, roots.data(), sizeof(GEnv) * n, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL((k_root_visits<Gm>), dim3((n + 255) / 256), dim3(256), 0, e->stream, e->v, e->d_slots, e->d_roots, n, e->d_visits);
+  HIPCHK(hipMemcpyAsync(out.data(), e->d_visits, sizeof(int) * out.size(), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return AZ_OK;
+}
+static int reset_slots(az_engine* e, const std::vector<int>& slots) {
+  const int n = (int)slots.size();
+  if (!n) return AZ_OK;
+  HIPCHK(hipMemcpyAsync(e->d_slots, slots.data(), sizeof(int) * n, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_reset_slots, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->v, e->d_slots, n);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return AZ_OK;
+}
+
+template <class Gm>
+static int arena_run(az_engine* ec, az_engine* eb, int num_games, int first_game_id, bool alternate, az_trace_buf* out,
+                     double* rewards, double* redundancy, az_progress_cb cb, void* user) {
+  const int G = std::min(ec->v.G, num_games);
+  const double flip_p = ec->cfg.flip_probability;
+  if (flip_p != 0.0 && Gm::NSYM == 0) return fail(AZ_ERR_BAD_ARG, "flip_probability != 0 but no symmetries were declared for this game (game.jl:332)");
+  AZCHK(az_mcts_reset(ec));                                        // a fresh player per worker (simulations.jl:217-218)
+  AZCHK(az_mcts_reset(eb));
+  std::vector<ArenaSlot> sl(G);
+  int next_game = 0, finished = 0;
+  for (int s = 0; s < G; ++s) { sl[s].env = Gm::init(); sl[s].gid = (uint32_t)(first_game_id + next_game++); sl[s].active = true; }
+  if (out) { out->num_games = 0; out->num_moves = 0; }
+  std::unordered_set<std::pair<uint64_t, uint64_t>, KeyHash> uniq;
+  int64_t nstates = 0;
+  std::vector<int> slots[2], visits[2], fin;
+  std::vector<GEnv> roots[2];
+  std::vector<uint32_t> gids[2], mvs[2];
+  az_engine* eng[2] = {ec, eb};
+  while (finished < num_games) {
+    for (int k = 0; k < 2; ++k) { slots[k].clear(); roots[k].clear(); gids[k].clear(); mvs[k].clear(); }
+    for (int s = 0; s < G; ++s) {
+      ArenaSlot& a = sl[s];
+      if (!a.active) continue;
+      if (a.nmoves >= ec->v.max_moves) return fail(AZ_ERR_CAPACITY, "game %u exceeds max_moves_per_game = %d", a.gid, ec->v.max_moves);
+      az_move_rec rec;
+      memset(&rec, 0, sizeof rec);
+      rec.key[0] = a.env.a; rec.key[1] = a.env.b;                  // trace.states[i]: the state BEFORE the flip
+      if (flip_p != 0.0) {                                         // play.jl:305-307
+        az_rng r = az_rng_make(ec->p.seed, a.gid, (uint32_t)a.nmoves, AZ_RNG_FLIP);
+        if (az_rng_f64(&r) < flip_p) {
+          int k = (int)(az_rng_f64(&r) * (double)Gm::NSYM);
+          if (k >= Gm::NSYM) k = Gm::NSYM - 1;
+          a.env = Gm::sym(a.env, k);
+          rec.N[AZ_MAX_ACTIONS] = k + 1;
+        }
+      }
+      a.moves.push_back(rec);
+      // simulations.jl:221-223: sim_id is 1-based, colors are flipped for odd sim_id
+      const bool colors_flipped = alternate && ((a.gid + 1) % 2 == 1);
+      const int who = (Gm::white_playing(a.env) != colors_flipped) ? 0 : 1;   // 0 contender, 1 baseline
+      slots[who].push_back(s); roots[who].push_back(a.env); gids[who].push_back(a.gid); mvs[who].push_back((uint32_t)a.nmoves);
+    }
+    // think (play.jl:196-206): the two engines' waves are enqueued alternately on their own streams, so the
+    // contender's and the baseline's searches overlap on the GPU (each has only part of the workers)
+    int nga[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(explore_begin<Gm>(eng[k], slots[k], roots[k], gids[k], mvs[k], nullptr, &nga[k])); }
+    for (int i = 0; i < std::max(ec->p.nsims, eb->p.nsims); ++i)
+      for (int k = 0; k < 2; ++k) if (nga[k] && i < eng[k]->p.nsims) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(wave<Gm>(eng[k], nga[k])); }
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipSetDevice(eng[k]->device));
+      AZCHK(explore_end(eng[k], nga[k]));
+      AZCHK(root_visits<Gm>(eng[k], slots[k], roots[k], visits[k]));
+    }
+    for (int k = 0; k < 2; ++k) for (size_t i = 0; i < slots[k].size(); ++i) {
+      ArenaSlot& a = sl[slots[k][i]];
+      const int* vis = &visits[k][i * (AZ_MAX_ACTIONS + 1)];
+      if (!vis[0]) return fail(AZ_ERR_STATE, "root of slot %d missing after explore", slots[k][i]);
+      az_move_rec& rec = a.moves.back();
+      const uint32_t m = Gm::mask(a.env);
+      for (int x = 0; x < AZ_MAX_ACTIONS; ++x) rec.N[x] = vis[1 + x];
+      const int act = select_action<Gm>(eng[k]->p, vis + 1, m, (uint32_t)a.nmoves, a.gid);
+      Gm::play(a.env, act);
+      rec.action = act;
+      rec.reward = Gm::white_reward(a.env);
+      a.nmoves++;
+    }
+    // end-of-round bookkeeping in worker order (simulations.jl:231-240)
+    fin.clear();
+    for (int s = 0; s < G; ++s) {
+      ArenaSlot& a = sl[s];
+      if (!a.active || !(a.env.fin & 1)) continue;
+      const int gi = (int)a.gid - first_game_id;
+      const bool colors_flipped = alternate && ((a.gid + 1) % 2 == 1);
+      double wr = 0.0, gp = 1.0;                                   // total_reward (trace.jl:45-47)
+      for (const az_move_rec& r : a.moves) { wr += gp * (double)r.reward; gp *= ec->p.gamma; }
+      if (rewards) rewards[gi] = colors_flipped ? -wr : wr;        // rewards_and_redundancy, simulations.jl:304-307
+      for (const az_move_rec& r : a.moves) uniq.insert({r.key[0], r.key[1]});
+      uniq.insert({a.env.a, a.env.b});
+      nstates += (int64_t)a.moves.size() + 1;
+      if (out) {
+        if (gi >= out->games_cap || out->num_moves + (int64_t)a.moves.size() > out->moves_cap) return fail(AZ_ERR_CAPACITY, "trace buffer too small");
+        az_game_rec& g = out->games[gi];
+        memset(&g, 0, sizeof g);
+        g.game_id = (int32_t)a.gid; g.slot = s; g.num_moves = a.nmoves; g.first_move = (int32_t)out->num_moves;
+        g.final_key[0] = a.env.a; g.final_key[1] = a.env.b;
+        memcpy(out->moves + out->num_moves, a.moves.data(), sizeof(az_move_rec) * a.moves.size());
+        out->num_moves += (int64_t)a.moves.size();
+        out->num_games++;
+      }
+      a.worker_sim_id++;
+      if (ec->p.reset_every > 0 && a.worker_sim_id % ec->p.reset_every == 0) fin.push_back(s);   // reset_player!
+      finished++;
+      if (cb) cb(user);
+      a.moves.clear(); a.nmoves = 0;
+      if (next_game < num_games) { a.gid = (uint32_t)(first_game_id + next_game++); a.env = Gm::init(); }
+      else a.active = false;
+    }
+    for (int k = 0; k < 2; ++k) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(reset_slots(eng[k], fin)); }
+  }
+  if (redundancy) *redundancy = nstates ? 1.0 - (double)uniq.size() / (double)nstates : 0.0;   // simulations.jl:296-299
+  return AZ_OK;
+}
+
+extern "C" int az_arena_run(az_engine* contender, az_engine* baseline, int32_t num_games, int32_t first_game_id,
+                            int32_t alternate_colors, az_trace_buf* out, double* rewards, double* redundancy,
+                            az_progress_cb cb, void* user) {
+  ENGINE(contender);
+  ENGINE(baseline);
+  if (contender == baseline) return fail(AZ_ERR_BAD_ARG, "contender and baseline must be two engines (two trees per worker, play.jl:248-251)");
+  if (contender->running || baseline->running) return fail(AZ_ERR_STATE, "self-play in progress");
+  if (contender->cfg.game != baseline->cfg.game) return fail(AZ_ERR_BAD_ARG, "the two engines play different games");
+  if (num_games < 1) return fail(AZ_ERR_BAD_ARG, "num_games must be >= 1");
+  if (baseline->v.G < std::min(contender->v.G, (int)num_games)) return fail(AZ_ERR_BAD_ARG, "baseline engine has fewer workers (%d) than the arena needs (%d)", baseline->v.G, std::min(contender->v.G, (int)num_games));
+  for (az_engine* e : {contender, baseline})
+    if (e->cfg.oracle == AZ_ORACLE_RESNET && !e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
+  if (out && (!out->games || !out->moves)) return fail(AZ_ERR_BAD_ARG, "NULL trace buffers");
+  DISPATCH_GAME(contender->cfg.game, AZCHK(arena_run<Gm>(contender, baseline, num_games, first_game_id, alternate_colors != 0, out, rewards, redundancy, cb, user)));
+  return AZ_OK;
 }
 
 extern "C" int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, double* z, double* t) {

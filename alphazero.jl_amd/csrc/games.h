@@ -79,6 +79,17 @@ struct ConnectFour {
     uint32_t wn = g.fin >> 1;
     return (g.fin & 1) ? (wn == 1 ? 1.f : wn == 2 ? -1.f : 0.f) : 0.f;
   }
+  // GI.symmetries, game.jl:243-257: ONE symmetry, the column mirror (sigma = 7..1)
+  static constexpr int NSYM = 1;
+  AZ_GHD static uint64_t mirror(uint64_t x) {
+    uint64_t out = 0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) out |= ((x >> (7 * c)) & 0x7f) << (7 * (6 - c));
+    return out;
+  }
+  AZ_GHD static GEnv sym(const GEnv& g, int) {
+    return GEnv{mirror(g.a & ~AZ_BLACK_BIT) | (g.a & AZ_BLACK_BIT), mirror(g.b), g.fin};
+  }
   // vectorize_state, game.jl:226-241: plane c in (EMPTY, player to move, opponent)
   AZ_GHD static float plane(const GEnv& g, int p /* x + 7*y */, int c) {
     int x = p % 7, y = p / 7;
@@ -121,6 +132,26 @@ struct TicTacToe {
   AZ_GHD static float white_reward(const GEnv& g) {
     uint32_t wn = g.fin >> 1;
     return (g.fin & 1) ? (wn == 1 ? 1.f : wn == 2 ? -1.f : 0.f) : 0.f;
+  }
+  // GI.symmetries, game.jl:149-168: the 7 non-trivial dihedral maps in the reference's order
+  // (rot, rot2, rot3, flip, flip.rot, flip.rot2, flip.rot3); new board[p] = board[src(k, p)], where
+  // src = pos_of_xy . f . xy_of_pos with rot(x,y) = (y, 2-x), flip(x,y) = (x, 2-y) (0-based).
+  static constexpr int NSYM = 7;
+  AZ_GHD static int sym_src(int k, int p) {
+    int x = p % 3, y = p / 3;
+    const int nrot = k < 3 ? k + 1 : k - 3;
+    for (int r = 0; r < nrot; ++r) { int t = x; x = y; y = 2 - t; }
+    if (k >= 3) y = 2 - y;
+    return y * 3 + x;
+  }
+  AZ_GHD static GEnv sym(const GEnv& g, int k) {
+    uint64_t na = g.a & AZ_BLACK_BIT, nb = 0;
+    for (int p = 0; p < 9; ++p) {
+      const int q = sym_src(k, p);
+      na |= ((g.a >> q) & 1) << p;
+      nb |= ((g.b >> q) & 1) << p;
+    }
+    return GEnv{na, nb, g.fin};
   }
   AZ_GHD static float plane(const GEnv& g, int p, int c) {  // vectorize_state, game.jl:126-143
     bool wp = white_playing(g);
@@ -204,6 +235,8 @@ struct Mancala {
     uint32_t nw = byte_at(g.a, 6), nb = byte_at(g.b, 6);
     return nw > nb ? 1.f : nw < nb ? -1.f : 0.f;
   }
+  static constexpr int NSYM = 0;                        // no GI.symmetries method: apply_random_symmetry! asserts
+  AZ_GHD static GEnv sym(const GEnv& g, int) { return g; }
   // vectorize_state, game.jl:224-257, BUG-COMPATIBLE: when BLACK is to move flip_colors returns
   // the INITIAL board.  Positions: WHITE houses 6..1, WHITE store, BLACK houses 6..1, BLACK store.
   AZ_GHD static float plane(const GEnv& g, int p, int c) {

@@ -1,5 +1,5 @@
 // resnet.h -- the two-headed ResNet oracle (src/networks/architectures/resnet.jl:53-92, test mode): the first
-// tower kernel (k_tower, 32x32x2 MFMA; still used for launch sizes it quantises better, see pick16 in azhip.hip),
+// tower kernel (k_tower, 32x32x2 MFMA; still used for launch sizes it quantises better, see pick_tower in azhip.hip),
 // and the dense heads.  The 16x16x4 tower lives in resnet16.h.
 //
 //  k_tower   one workgroup owns TB = 128/P whole boards (3 Connect-Four boards = 126 of 128 GEMM rows) and runs

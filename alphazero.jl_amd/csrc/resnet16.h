@@ -34,9 +34,13 @@ struct Net16Dev {
   const float* head_ss;     // [2][64]
 };
 
-template <class Gm, int F = 64> struct T16 {
-  static constexpr int NTILE = 11, RPAD = NTILE * 16;
-  static constexpr int TB = RPAD / Gm::P;            // 4 Connect-Four boards, 19 Tic-tac-toe, 12 Mancala
+// NT = row tiles per workgroup: 11 (throughput: 4 Connect-Four boards, 2 workgroups per CU at 64 filters) or 3
+// (latency: ONE Connect-Four board per workgroup, so a small batch spreads over 4x as many CUs and the
+// sequential layer chain of a workgroup is 3.7x shorter -- the reference's 128-worker configurations).
+template <class Gm, int F = 64, int NT = 11> struct T16 {
+  static constexpr int NTILE = NT, RPAD = NTILE * 16;
+  static constexpr int TB = RPAD / Gm::P;            // NT = 11: 4 Connect-Four boards, 19 Tic-tac-toe, 12 Mancala; NT = 3: 1, 5, 3
+  static constexpr int STEPS = (NT + 1) / 2;         // tile pairs per (tap, 64-channel half); the last pair is a single tile when NT is odd
   static constexpr int ROWS = TB * Gm::P;
   static constexpr int STRIDE = F + 4;
   static constexpr int BUF = (RPAD + 1) * STRIDE;    // row RPAD = zeros
@@ -58,21 +62,17 @@ template <int F> __device__ __forceinline__ int posF(int c) { return ((c >= F / 
 // issue, 40-cycle dependent latency); the 11th tile rides alone.  sched_barrier(0) after every step keeps hipcc
 // from hoisting further loads, which bounds the live A registers to two pairs (the kernel must stay near 200
 // VGPRs so that the tree kernels of the other slot group can co-reside on the SIMD).
-#ifndef AZ_T16_LAST3
-#define AZ_T16_LAST3 0     // 1: tile groups 2,2,2,2,3 (5 steps per tap); 0: 2,2,2,2,2,1 (6 steps, 16 fewer VGPRs)
-#endif
-static constexpr int T16_STEPS = AZ_T16_LAST3 ? 5 : 6;
-static constexpr int T16_GMAX = AZ_T16_LAST3 ? 3 : 2;
-__device__ __forceinline__ constexpr int t16_gsize(int pair) { return AZ_T16_LAST3 ? (pair == 4 ? 3 : 2) : (pair == 5 ? 1 : 2); }
-template <class Gm, int F>
+static constexpr int T16_GMAX = 2;
+template <int NT> __device__ __forceinline__ constexpr int t16_gsize(int pair) { return 2 * pair + 1 < NT ? 2 : 1; }
+template <class Gm, int F, int NT>
 __device__ __forceinline__ void load_pair16(const float* __restrict__ buf, const uint32_t (&vm)[4], int tap, int pair, int kh,
                                             int lrow, int g, float4 (&a)[T16_GMAX][4]) {
-  using T = T16<Gm, F>;
+  using T = T16<Gm, F, NT>;
   const int delta = (tap / 3 - 1) * Gm::W + (tap % 3 - 1);
 #pragma unroll
   for (int u = 0; u < T16_GMAX; ++u) {
     const int tile = pair * 2 + u;
-    if (u < t16_gsize(pair)) {
+    if (u < t16_gsize<NT>(pair)) {
       const bool ok = (vmask(vm, tile) >> tap) & 1;
       const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
       const float* p = buf + row * T::STRIDE + g * (F / 4) + kh * 16;
@@ -81,9 +81,9 @@ __device__ __forceinline__ void load_pair16(const float* __restrict__ buf, const
     }
   }
 }
-template <int PAIR, int KHI, int SQ>
-__device__ __forceinline__ void mfma_pair16(const float4 (&a)[T16_GMAX][4], const float4 (&bfull)[SQ], f32x4v (&acc)[11]) {
-  constexpr int t0 = PAIR * 2, ng = t16_gsize(PAIR);
+template <int PAIR, int KHI, int SQ, int NT>
+__device__ __forceinline__ void mfma_pair16(const float4 (&a)[T16_GMAX][4], const float4 (&bfull)[SQ], f32x4v (&acc)[NT]) {
+  constexpr int t0 = PAIR * 2, ng = t16_gsize<NT>(PAIR);
   const float4* b = bfull + KHI * 4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -97,14 +97,14 @@ __device__ __forceinline__ void mfma_pair16(const float4 (&a)[T16_GMAX][4], cons
     for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].w, b[q].w, acc[t0 + u], 0, 0, 0);
   }
 }
-template <class Gm, int F, int NTAP, int K>
-__device__ __forceinline__ void conv16_steps(const float* __restrict__ buf, const float4* __restrict__ wl, f32x4v (&acc)[11],
+template <class Gm, int F, int NT, int NTAP, int K>
+__device__ __forceinline__ void conv16_steps(const float* __restrict__ buf, const float4* __restrict__ wl, f32x4v (&acc)[NT],
                                              const uint32_t (&vm)[4], int lrow, int g, float4 (&b0)[F / 16], float4 (&b1)[F / 16],
                                              float4 (&aA)[T16_GMAX][4], float4 (&aB)[T16_GMAX][4]) {
-  using T = T16<Gm, F>;
-  constexpr int SPT = T16_STEPS * T::KH;            // pipeline steps per tap: (64-channel half, tile pair)
+  using T = T16<Gm, F, NT>;
+  constexpr int SPT = T::STEPS * T::KH;             // pipeline steps per tap: (64-channel half, tile pair)
   if constexpr (K < NTAP * SPT) {
-    constexpr int t = K / SPT, kh = (K % SPT) / T16_STEPS, p = K % T16_STEPS;
+    constexpr int t = K / SPT, kh = (K % SPT) / T::STEPS, p = K % T::STEPS;
     float4 (&cur)[T16_GMAX][4] = (K & 1) ? aB : aA;
     float4 (&nxt)[T16_GMAX][4] = (K & 1) ? aA : aB;
     float4 (&bc)[F / 16] = (t & 1) ? b1 : b0;
@@ -114,34 +114,34 @@ __device__ __forceinline__ void conv16_steps(const float* __restrict__ buf, cons
       for (int q = 0; q < T::SQ; ++q) bn[q] = wl[(size_t)((t + 1) * T::WAVES * T::SQ + q) * 64];
     }
     if constexpr (K + 1 < NTAP * SPT) {
-      constexpr int t1 = (K + 1) / SPT, kh1 = ((K + 1) % SPT) / T16_STEPS, p1 = (K + 1) % T16_STEPS;
-      load_pair16<Gm, F>(buf, vm, NTAP == 1 ? 4 : t1, p1, kh1, lrow, g, nxt);
+      constexpr int t1 = (K + 1) / SPT, kh1 = ((K + 1) % SPT) / T::STEPS, p1 = (K + 1) % T::STEPS;
+      load_pair16<Gm, F, NT>(buf, vm, NTAP == 1 ? 4 : t1, p1, kh1, lrow, g, nxt);
     }
-    mfma_pair16<p, kh, F / 16>(cur, bc, acc);
+    mfma_pair16<p, kh, F / 16, NT>(cur, bc, acc);
 #ifndef AZ_T16_FENCE
 #define AZ_T16_FENCE 1     // fence the scheduler every N steps
 #endif
     if constexpr (K % AZ_T16_FENCE == AZ_T16_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
-    conv16_steps<Gm, F, NTAP, K + 1>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
+    conv16_steps<Gm, F, NT, NTAP, K + 1>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
   }
 }
-template <class Gm, int F, int NTAP>
+template <class Gm, int F, int NT, int NTAP>
 __device__ __forceinline__ void conv16(const float* __restrict__ buf, const float4* __restrict__ wl,
-                                       f32x4v (&acc)[11], const uint32_t (&vm)[4], int lrow, int g) {
+                                       f32x4v (&acc)[NT], const uint32_t (&vm)[4], int lrow, int g) {
   float4 b0[F / 16], b1[F / 16], aA[T16_GMAX][4], aB[T16_GMAX][4];
 #pragma unroll
   for (int q = 0; q < F / 16; ++q) b0[q] = wl[(size_t)q * 64];
-  load_pair16<Gm, F>(buf, vm, NTAP == 1 ? 4 : 0, 0, 0, lrow, g, aA);
+  load_pair16<Gm, F, NT>(buf, vm, NTAP == 1 ? 4 : 0, 0, 0, lrow, g, aA);
   __builtin_amdgcn_sched_barrier(0);
-  conv16_steps<Gm, F, NTAP, 0>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
+  conv16_steps<Gm, F, NT, NTAP, 0>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
 }
 
 template <int F> struct T16Threads { static constexpr int V = 64 * (F / 16); };
-template <class Gm, int F, bool FROM_PLANES>
+template <class Gm, int F, bool FROM_PLANES, int NT = 11>
 __global__ void __launch_bounds__(T16Threads<F>::V, 2)
 k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
           const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
-  using T = T16<Gm, F>;
+  using T = T16<Gm, F, NT>;
   constexpr int P = Gm::P, W = Gm::W, H = Gm::H, C = Gm::C, TB = T::TB, STRIDE = T::STRIDE, NTHR = T::THREADS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
@@ -167,7 +167,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   // validity of the 9 taps for this lane's row of every tile
   uint32_t vm[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int tile = 0; tile < 11; ++tile) {
+  for (int tile = 0; tile < NT; ++tile) {
     const int row = tile * 16 + lrow;
     const int q = row % P, x = q % W, y = q / W;
     uint32_t m = 0;
@@ -184,12 +184,12 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   const int opos = posF<F>(ch);
   __syncthreads();
 
-  f32x4v acc[11];
+  f32x4v acc[NT];
   // ---- stem: Conv(3x3, C => 64) + BN + ReLU, K = 9C padded to a multiple of 4 -------------------------
   {
     constexpr int KK = 9 * C, K2 = (KK + 1) / 2, NS = (2 * K2 + 3) / 4;
 #pragma unroll
-    for (int t = 0; t < 11; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       // sequence position p = 4s + g -> k = (p & 1) * K2 + (p >> 1)   (the paired order of the contract)
@@ -200,7 +200,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
       const int tap = kin ? k / C : 4, c = kin ? k % C : 0;
       const int delta = (tap / 3 - 1) * W + (tap % 3 - 1);
 #pragma unroll
-      for (int tile = 0; tile < 11; ++tile) {
+      for (int tile = 0; tile < NT; ++tile) {
         const bool ok = kin && ((vmask(vm, tile) >> tap) & 1);
         const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
         const float a = planes[row * C + c];
@@ -209,7 +209,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
     }
     const float sc = net.stem_ss[ch], sh = net.stem_ss[F + ch];
 #pragma unroll
-    for (int tile = 0; tile < 11; ++tile)
+    for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float v = az_fmaf(acc[tile][i], sc, sh);
@@ -219,22 +219,22 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   __syncthreads();
 
   // ---- residual tower ---------------------------------------------------------------------------------
-  float xres[11][4];
+  float xres[NT][4];
   const size_t LAYER_W = (size_t)9 * T::WAVES * T::SQ * 64;       // float4 per layer
   for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
 #pragma unroll
-    for (int t = 0; t < 11; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
     // opaque copy: stops hipcc from hoisting the 99 loop-invariant (tap, tile) LDS addresses out of the layer
     // loop, which would cost ~100 VGPRs for the whole kernel
     int lrow_l = lrow;
     asm volatile("" : "+v"(lrow_l));
-    conv16<Gm, F, 9>(buf, net.conv_w + (size_t)layer * LAYER_W + (size_t)wave * T::SQ * 64 + lane, acc, vm, lrow_l, g);
+    conv16<Gm, F, NT, 9>(buf, net.conv_w + (size_t)layer * LAYER_W + (size_t)wave * T::SQ * 64 + lane, acc, vm, lrow_l, g);
     const float sc = net.conv_ss[(size_t)layer * 2 * F + ch], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch];
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();                                 // every wave has finished reading the buffer
     if (!(layer & 1)) {
 #pragma unroll
-      for (int tile = 0; tile < 11; ++tile)
+      for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int a = (tile * 16 + g * 4 + i) * STRIDE + opos;
@@ -244,7 +244,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
         }
     } else {
 #pragma unroll
-      for (int tile = 0; tile < 11; ++tile)
+      for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int a = (tile * 16 + g * 4 + i) * STRIDE + opos;
@@ -258,14 +258,14 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   }
   // ---- both 1x1 head convolutions + BN + ReLU as one 64 => 64 GEMM ------------------------------------
 #pragma unroll
-  for (int t = 0; t < 11; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  conv16<Gm, F, 1>(buf, net.head_w + (size_t)wave * T::SQ * 64 + lane, acc, vm, lrow, g);
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  conv16<Gm, F, NT, 1>(buf, net.head_w + (size_t)wave * T::SQ * 64 + lane, acc, vm, lrow, g);
   {
     const float sc = net.head_ss[ch], sh = net.head_ss[F + ch];
     // head features straight from the accumulators to HBM, [board][P][64] in natural channel order
     const int nb = (n - board0) < TB ? (n - board0) : TB;
 #pragma unroll
-    for (int tile = 0; tile < 11; ++tile)
+    for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = tile * 16 + g * 4 + i;

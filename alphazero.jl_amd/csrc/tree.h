@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) k_expand_backup(DView v, DParams p) {
 // move: MCTS.policy (mcts.jl:255-271) + the body of play_game's loop (play.jl:308-313) +
 // end-of-game bookkeeping of simulate (simulations.jl:231-240)
 // =========================================================================================
-__device__ inline double pl_schedule(const DParams& p, int i) {   // schedule.jl:64-80
+__host__ __device__ inline double pl_schedule(const DParams& p, int i) {   // schedule.jl:64-80
   int pt = -1;
   for (int k = 0; k < p.temp_len; ++k) if (p.temp_xs[k] <= i) pt = k;
   if (pt < 0) return p.temp_ys[0];
@@ -392,33 +392,34 @@ __device__ inline double pl_schedule(const DParams& p, int i) {   // schedule.jl
   return y0 + (y1 - y0) / (x1 - x0) * ((double)i - x0);
 }
 
+// tree[state] of one slot (serial probe, one lane): node record or nullptr
 template <class Gm>
-__global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
-  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
+__device__ inline const char* find_node(const DView& v, int slot, unsigned long long ka, unsigned long long kb,
+                                        uint32_t* idx_out = nullptr) {
   using NL = NodeL<Gm>;
-  constexpr int L = Gm::APAD;
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;       // one lane per slot: n <= 9, serial
-  if (slot >= v.G || !v.active[slot]) return;
-  GEnv env = v.root[slot];
-  // tree[state] must exist after explore!
   const uint32_t epoch = v.epoch[slot];
-  const unsigned long long hk = az_hash_key(env.a, env.b);
+  const unsigned long long hk = az_hash_key(ka, kb);
   const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
   const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
-  const char* nd = nullptr;
   for (uint32_t i = 0; i <= H1; ++i) {
     unsigned long long e = tab[((uint32_t)hk + i) & H1];
     uint32_t idx1 = (uint32_t)e;
     if (!((uint32_t)(e >> 48) == epoch && idx1 != 0)) break;
     if (((uint32_t)(e >> 32) & 0xffff) == tag) {
       const unsigned long long* k = (const unsigned long long*)(pool + (size_t)(idx1 - 1) * NL::BYTES);
-      if (k[0] == env.a && k[1] == env.b) { nd = (const char*)k; break; }
+      if (k[0] == ka && k[1] == kb) { if (idx_out) *idx_out = idx1 - 1; return (const char*)k; }
     }
   }
-  if (!nd) { dev_fail(v, DERR_NO_ROOT); return; }
-  const uint32_t m = Gm::mask(env);
-  const int* Nn = (const int*)(nd + NL::OFF_N);
+  return nullptr;
+}
+
+// MCTS.policy (mcts.jl:255-271) -> apply_temperature (play.jl:309-310) -> fix_probvec + rand_categorical
+// (util.jl:68-90) for one root: Nn = visit counts by full action index, m = availability mask, mv = number of
+// moves already played (temperature index, play.jl:309).  Shared by k_move and the arena's host loop, so the
+// device and the host draw the same action from the same counts.
+template <class Gm>
+__host__ __device__ inline int select_action(const DParams& p, const int* Nn, uint32_t m, uint32_t mv, uint32_t game_id) {
   int acts[AZ_MAX_ACTIONS];
   double pi[AZ_MAX_ACTIONS], pis[AZ_MAX_ACTIONS];
   int n = 0;
@@ -427,12 +428,6 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
   double s = 0.0;
   for (int i = 0; i < n; ++i) { pi[i] = (double)Nn[acts[i]] / (double)ntot; s += pi[i]; }
   for (int i = 0; i < n; ++i) pi[i] = pi[i] / s;
-  const uint32_t mv = v.move_idx[slot];
-  if ((int)mv >= v.max_moves) { dev_fail(v, DERR_MOVES); return; }
-  az_move_rec* rec = v.trace + (size_t)slot * v.max_moves + mv;
-  rec->key[0] = env.a; rec->key[1] = env.b;
-  for (int a = 0; a < AZ_MAX_ACTIONS + 1; ++a) rec->N[a] = (a < Gm::A && ((m >> a) & 1)) ? Nn[a] : 0;
-  // temperature index = number of moves already played (play.jl:309)
   const double tau = pl_schedule(p, (int)mv);
   if (tau == 1.0) for (int i = 0; i < n; ++i) pis[i] = pi[i];
   else if (tau == 0.0) {
@@ -446,7 +441,6 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
     for (int i = 0; i < n; ++i) { pis[i] = az_pow(pi[i], inv); t += pis[i]; }
     for (int i = 0; i < n; ++i) pis[i] = pis[i] / t;
   }
-  // fix_probvec + rand_categorical (util.jl:68-90)
   float pf[AZ_MAX_ACTIONS];
   float fs = 0.f;
   for (int i = 0; i < n; ++i) { pf[i] = (float)pis[i]; fs += pf[i]; }
@@ -455,8 +449,29 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
     if (fs == 0.0f) for (int i = 0; i < n; ++i) pf[i] = 1.0f / (float)n;
     else for (int i = 0; i < n; ++i) pf[i] = pf[i] / fs;
   }
-  az_rng r = az_rng_make(p.seed, v.game_id[slot], mv, AZ_RNG_MOVE);
-  const int act = acts[az_categorical_f32(pf, n, az_rng_f32(&r))];
+  az_rng r = az_rng_make(p.seed, game_id, mv, AZ_RNG_MOVE);
+  return acts[az_categorical_f32(pf, n, az_rng_f32(&r))];
+}
+
+template <class Gm>
+__global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
+  using NL = NodeL<Gm>;
+  constexpr int L = Gm::APAD;
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;       // one lane per slot: n <= 9, serial
+  if (slot >= v.G || !v.active[slot]) return;
+  GEnv env = v.root[slot];
+  const uint32_t epoch = v.epoch[slot];
+  const char* nd = find_node<Gm>(v, slot, env.a, env.b);          // tree[state] must exist after explore!
+  if (!nd) { dev_fail(v, DERR_NO_ROOT); return; }
+  const uint32_t m = Gm::mask(env);
+  const int* Nn = (const int*)(nd + NL::OFF_N);
+  const uint32_t mv = v.move_idx[slot];
+  if ((int)mv >= v.max_moves) { dev_fail(v, DERR_MOVES); return; }
+  az_move_rec* rec = v.trace + (size_t)slot * v.max_moves + mv;
+  rec->key[0] = env.a; rec->key[1] = env.b;
+  for (int a = 0; a < AZ_MAX_ACTIONS + 1; ++a) rec->N[a] = (a < Gm::A && ((m >> a) & 1)) ? Nn[a] : 0;
+  const int act = select_action<Gm>(p, Nn, m, mv, v.game_id[slot]);
   Gm::play(env, act);
   rec->action = act;
   rec->reward = Gm::white_reward(env);
@@ -519,6 +534,33 @@ __global__ void __launch_bounds__(256) k_arm_noise(DView v, DParams p, const int
   if (moves) v.move_idx[slot] = moves[i];
   if (eta_in) { for (int a = 0; a < L; ++a) v.eta[(size_t)slot * L + a] = a < AZ_MAX_ACTIONS ? eta_in[(size_t)i * AZ_MAX_ACTIONS + a] : 0.0; }
   else arm_noise<Gm>(v, p, slot, v.root[slot]);
+}
+
+// root visit counts of a list of slots (MCTS.policy's input, mcts.jl:255-271): out[i] = {found, N[0..AZ_MAX_ACTIONS)}
+template <class Gm>
+__global__ void __launch_bounds__(256) k_root_visits(DView v, const int* slots, const GEnv* roots, int n, int* out) {
+  using NL = NodeL<Gm>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int* o = out + (size_t)i * (AZ_MAX_ACTIONS + 1);
+  const char* nd = find_node<Gm>(v, slots[i], roots[i].a, roots[i].b);
+  o[0] = nd != nullptr;
+  const uint32_t m = Gm::mask(roots[i]);
+  for (int a = 0; a < AZ_MAX_ACTIONS; ++a) o[1 + a] = (nd && a < Gm::A && ((m >> a) & 1)) ? ((const int*)(nd + NL::OFF_N))[a] : 0;
+}
+// MCTS.reset! (mcts.jl:278-281) on a list of slots: a new epoch empties the slot's table in O(1)
+__global__ void __launch_bounds__(256) k_reset_slots(DView v, const int* slots, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int slot = slots[i];
+  uint32_t ep = v.epoch[slot] + 1;
+  if (ep >= 0xffff) {
+    unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
+    for (int k = 0; k < v.ht_size; ++k) tab[k] = 0;
+    ep = 1;
+  }
+  v.epoch[slot] = ep;
+  v.node_count[slot] = 0;
 }
 
 // gather the move records of finished games into one contiguous staging area

@@ -154,6 +154,8 @@ AZ_HD void az_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32
 /* Purposes (third counter word): one independent stream per use site. */
 #define AZ_RNG_NOISE 1u   /* Dirichlet noise of explore!   (src/mcts.jl:228-232,240) */
 #define AZ_RNG_MOVE 2u    /* categorical move sampling     (src/play.jl:311, src/util.jl:87-90) */
+#define AZ_RNG_FLIP 3u    /* play_game's random symmetry    (src/play.jl:305-307, src/game.jl:329-336):
+                             draw 0: rand() < flip_probability, draw 1: floor(u * #symmetries) */
 
 typedef struct {
   uint32_t key[2];   /* 64-bit seed */

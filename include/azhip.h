@@ -96,7 +96,7 @@ typedef struct {
                                  evaluates every pending leaf of a wave in one pass */
   int32_t reset_every;        /* reset a slot's tree every n games; 0 = never (`nothing`) */
   int32_t fill_batches;       /* accepted, no effect: test-mode BN is per sample (Appendix A.13) */
-  double flip_probability;    /* must be 0 on the device path (self-play configs use 0) */
+  double flip_probability;    /* play.jl:305-307; honoured by az_arena_run, self-play requires 0 */
   uint64_t seed;
   /* capacities; 0 = derive from the game and num_iters_per_turn */
   int32_t max_nodes_per_slot;
@@ -210,6 +210,21 @@ int az_selfplay_collect(az_engine* e, az_trace_buf* out);   /* finished, not yet
 int az_selfplay_get_stats(az_engine* e, az_selfplay_stats* stats);
 int az_selfplay_active(az_engine* e, int32_t* active_slots);
 int az_selfplay_end(az_engine* e);
+
+/* ---- arena (pit_networks, src/training.jl:130-144; TwoPlayers, src/play.jl:248-282) ------ */
+/* simulate() over TwoPlayers(MctsPlayer(contender), MctsPlayer(baseline)): each engine is one
+ * player (its own network, MctsParams and per-worker trees); workers = min(contender's
+ * num_workers, num_games); reset_every, flip_probability, gamma and the flip RNG seed are the
+ * contender's.  alternate_colors != 0 swaps the colours of the games with odd 1-based sim_id
+ * (simulations.jl:221-223), i.e. even global game id.  rewards[i] (may be NULL) = total reward of
+ * game first_game_id+i from the CONTENDER's side (rewards_and_redundancy, simulations.jl:302-311),
+ * *redundancy = 1 - #unique states / #states over all traces.  `out` (may be NULL) receives the
+ * traces sorted by game id: az_move_rec.key is trace.states[i] (the state BEFORE the turn's random
+ * symmetry), N / action refer to the state the player saw (after it), N[AZ_MAX_ACTIONS] = 1 + index
+ * of the symmetry applied that turn (0: none); az_game_rec.nodes / total_* are 0. */
+int az_arena_run(az_engine* contender, az_engine* baseline, int32_t num_games, int32_t first_game_id,
+                 int32_t alternate_colors, az_trace_buf* out, double* rewards, double* redundancy,
+                 az_progress_cb cb, void* user);
 
 /* push_trace! (src/memory.jl:74-87): z (discounted, side relative) and t per move record. */
 int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, double* z, double* t);

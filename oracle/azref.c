@@ -966,6 +966,139 @@ int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
   return nm;
 }
 
+/* ================================ arena ================================== */
+/* GI.symmetries: connect-four has ONE (column mirror, games/connect-four/game.jl:243-257),
+ * tic-tac-toe the 7 non-trivial dihedral maps in the order rot, rot2, rot3, flip, flip.rot,
+ * flip.rot2, flip.rot3 (games/tictactoe/game.jl:149-168), mancala declares none. */
+int azr_num_symmetries(int game) { return game == AZR_C4 ? 1 : game == AZR_TTT ? 7 : 0; }
+static void ttt_rot(int* x, int* y) { int nx = *y, ny = 3 - *x + 1; *x = nx; *y = ny; }   /* rot((x,y)) = (y, N-x+1) */
+static void ttt_flip(int* x, int* y) { (void)x; *y = 3 - *y + 1; }                        /* flip((x,y)) = (x, N-y+1) */
+void azr_symmetry(int game, const azr_state* st, int k, azr_state* out) {
+  *out = *st;
+  if (game == AZR_C4) {
+    /* flipped_board: board[col,row] for col in reverse(1:NUM_COLS) */
+    for (int col = 0; col < C4_COLS; ++col) for (int row = 0; row < C4_ROWS; ++row)
+      C4(out->cells, col, row) = C4(st->cells, C4_COLS - 1 - col, row);
+  } else if (game == AZR_TTT) {
+    /* Board(s.board[sym]) with sym[p] = pos_of_xy(f(xy_of_pos(p))), 1-based positions */
+    for (int p = 1; p <= 9; ++p) {
+      int x = (p - 1) % 3 + 1, y = (p - 1) / 3 + 1;
+      int nrot = k < 3 ? k + 1 : k - 3;            /* (f . g)(xy) = f(g(xy)): the rotations act first */
+      for (int r = 0; r < nrot; ++r) ttt_rot(&x, &y);
+      if (k >= 3) ttt_flip(&x, &y);
+      out->cells[p - 1] = st->cells[(y - 1) * 3 + (x - 1)];
+    }
+  }
+}
+/* apply_random_symmetry! (src/game.jl:329-336), index chosen by the caller */
+static void apply_symmetry(azr_env* g, int k) {
+  azr_state st;
+  azr_symmetry(g->game, &g->s, k, &st);
+  azr_init_state(g, g->game, &st);
+}
+static int cmp_key(const void* a, const void* b) { return memcmp(a, b, 16); }
+
+/* pit_networks (src/training.jl:130-144): simulate (src/simulations.jl:207-244) over
+ * TwoPlayers(MctsPlayer(contender), MctsPlayer(baseline)) (src/play.jl:248-282), lock-step
+ * workers as in azr_simulate.  pc holds the contender's MctsParams / network and the SimParams
+ * (num_games, num_workers, reset_every, seed for the flips); pb the baseline's MctsParams /
+ * network.  Writes traces (key = state BEFORE the turn's flip, N / action in the flipped frame,
+ * N[AZR_AMAX] = 1 + symmetry index), rewards from the contender's side and the redundancy
+ * (rewards_and_redundancy, simulations.jl:296-311).  Returns the number of move records. */
+int64_t azr_arena(const azr_sim_params* pc, const azr_sim_params* pb, int alternate_colors, double flip_probability,
+                  int first_game_id, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap, double* rewards,
+                  double* redundancy) {
+  int G = pc->num_workers < pc->num_games ? pc->num_workers : pc->num_games;
+  const azr_sim_params* pp[2] = {pc, pb};
+  azr_slot* slots = calloc((size_t)G, sizeof(azr_slot));
+  azr_mcts** trees[2];
+  for (int k = 0; k < 2; ++k) {
+    trees[k] = calloc((size_t)G, sizeof(azr_mcts*));
+    for (int s = 0; s < G; ++s) {
+      const azr_sim_params* p = pp[k];
+      trees[k][s] = azr_mcts_new(pc->game, p->oracle_kind, p->gamma, p->cpuct, p->noise_eps, p->noise_alpha, p->prior_temperature);
+      if (p->oracle_kind == AZR_ORACLE_NET) azr_mcts_set_net(trees[k][s], p->nblocks, p->F, p->npf, p->nvf, p->blob);
+    }
+  }
+  int64_t nm = 0;
+  int next_game = 0, finished = 0, maxlen = 512;
+  for (int s = 0; s < G; ++s) { slots[s].game_id = first_game_id + next_game++; slots[s].active = 1; azr_init(&slots[s].game, pc->game); }
+  azr_move_rec* stage = calloc((size_t)G * maxlen, sizeof(azr_move_rec));
+  int nsym = azr_num_symmetries(pc->game);
+  if (flip_probability != 0. && nsym == 0) { fprintf(stderr, "azref: no symmetries were declared for this game\n"); abort(); }
+  while (finished < pc->num_games) {
+    for (int s = 0; s < G; ++s) {
+      azr_slot* sl = &slots[s];
+      if (!sl->active) continue;
+      azr_move_rec* mr = &stage[(size_t)s * maxlen + sl->nmoves];
+      memset(mr, 0, sizeof *mr);
+      azr_pack_key(pc->game, &sl->game.s, mr->key);
+      if (flip_probability != 0.) {                                   /* play.jl:305-307 */
+        az_rng r = az_rng_make(pc->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, AZ_RNG_FLIP);
+        if (az_rng_f64(&r) < flip_probability) {
+          int k = (int)(az_rng_f64(&r) * (double)nsym);
+          if (k >= nsym) k = nsym - 1;
+          apply_symmetry(&sl->game, k);
+          mr->N[AZR_AMAX] = k + 1;
+        }
+      }
+      int colors_flipped = alternate_colors && ((sl->game_id + 1) % 2 == 1);   /* simulations.jl:221-223 */
+      int who = (azr_white_playing(&sl->game) != colors_flipped) ? 0 : 1;      /* think(::TwoPlayers), play.jl:255-261 */
+      const azr_sim_params* p = pp[who];
+      azr_mcts* m = trees[who][s];
+      azr_mcts_explore(m, &sl->game, p->num_iters_per_turn, 0, p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves);
+      int acts[AZR_AMAX]; double pi[AZR_AMAX], pis[AZR_AMAX];
+      int n = azr_mcts_policy(m, &sl->game, acts, pi);
+      { azr_node* nd = tree_find(m, &sl->game.s, 0);
+        for (int i = 0; i < n; ++i) mr->N[acts[i]] = (int32_t)nd->N[i]; }
+      double tau = azr_plschedule(p->temp_xs, p->temp_ys, p->temp_len, sl->nmoves);   /* player_temperature, play.jl:276-282 */
+      apply_temperature(pi, n, tau, pis);
+      az_rng r = az_rng_make(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, AZ_RNG_MOVE);
+      int a = acts[azr_rand_categorical(pis, n, az_rng_f32(&r))];
+      azr_play(&sl->game, a);
+      mr->action = a; mr->reward = (float)azr_white_reward(&sl->game);
+      sl->nmoves++;
+      if (sl->nmoves >= maxlen) { fprintf(stderr, "azref: game too long\n"); abort(); }
+    }
+    for (int s = 0; s < G; ++s) {
+      azr_slot* sl = &slots[s];
+      if (!sl->active || !azr_terminated(&sl->game)) continue;
+      int gi = sl->game_id - first_game_id;
+      azr_game_rec* gr = &games[gi];
+      memset(gr, 0, sizeof *gr);
+      gr->game_id = sl->game_id; gr->slot = s; gr->num_moves = sl->nmoves; gr->first_move = (int32_t)nm;
+      if (nm + sl->nmoves > moves_cap) { fprintf(stderr, "azref: move buffer too small\n"); abort(); }
+      memcpy(moves + nm, stage + (size_t)s * maxlen, sizeof(azr_move_rec) * (size_t)sl->nmoves);
+      azr_pack_key(pc->game, &sl->game.s, gr->final_key);
+      /* total_reward (src/trace.jl:45-47), sign by colors_flipped (simulations.jl:304-307) */
+      double wr = 0., gp = 1.;
+      for (int i = 0; i < sl->nmoves; ++i) { wr += gp * (double)moves[nm + i].reward; gp *= pc->gamma; }
+      int colors_flipped = alternate_colors && ((sl->game_id + 1) % 2 == 1);
+      if (rewards) rewards[gi] = colors_flipped ? -wr : wr;
+      nm += sl->nmoves;
+      sl->worker_sim_id++;
+      if (pc->reset_every > 0 && sl->worker_sim_id % pc->reset_every == 0) { azr_mcts_reset(trees[0][s]); azr_mcts_reset(trees[1][s]); }
+      finished++;
+      if (next_game < pc->num_games) { sl->game_id = first_game_id + next_game++; sl->nmoves = 0; azr_init(&sl->game, pc->game); }
+      else sl->active = 0;
+    }
+  }
+  if (redundancy) {                                                   /* compute_redundancy, simulations.jl:296-299 */
+    int64_t ns = nm + pc->num_games, j = 0;
+    uint64_t* keys = malloc((size_t)ns * 16);
+    for (int64_t i = 0; i < nm; ++i) { keys[2 * j] = moves[i].key[0]; keys[2 * j + 1] = moves[i].key[1]; ++j; }
+    for (int g = 0; g < pc->num_games; ++g) { keys[2 * j] = games[g].final_key[0]; keys[2 * j + 1] = games[g].final_key[1]; ++j; }
+    qsort(keys, (size_t)ns, 16, cmp_key);
+    int64_t uniq = ns > 0;
+    for (int64_t i = 1; i < ns; ++i) if (memcmp(keys + 2 * i, keys + 2 * (i - 1), 16)) uniq++;
+    *redundancy = 1. - (double)uniq / (double)ns;
+    free(keys);
+  }
+  for (int k = 0; k < 2; ++k) { for (int s = 0; s < G; ++s) azr_mcts_free(trees[k][s]); free(trees[k]); }
+  free(slots); free(stage);
+  return nm;
+}
+
 /* push_trace! (src/memory.jl:74-87): discounted side-relative z and t for each position */
 void azr_push_trace(int game, const azr_move_rec* moves, int n, double gamma, double* z, double* t) {
   double wr = 0.;

@@ -248,9 +248,8 @@ def net_forward_normalized(game, hp, blob, X, A):
     return P, V, Pinv
 
 
-def simulate(game, oracle, num_games, num_workers, nsims, gamma=1.0, cpuct=1.0, noise_eps=0.0, noise_alpha=1.0,
-             prior_temperature=1.0, temp_xs=(0,), temp_ys=(1.0,), reset_every=1, seed=1, net=None):
-    """simulate (src/simulations.jl:207-244) in lock-step; returns (games, moves) record arrays."""
+def _sim_params(game, oracle, num_games, num_workers, nsims, gamma=1.0, cpuct=1.0, noise_eps=0.0, noise_alpha=1.0,
+                prior_temperature=1.0, temp_xs=(0,), temp_ys=(1.0,), reset_every=1, seed=1, net=None):
     p = SimParams()
     p.gamma, p.cpuct, p.noise_eps, p.noise_alpha, p.prior_temperature = gamma, cpuct, noise_eps, noise_alpha, prior_temperature
     p.num_iters_per_turn = nsims
@@ -264,8 +263,50 @@ def simulate(game, oracle, num_games, num_workers, nsims, gamma=1.0, cpuct=1.0, 
     if net is not None:
         p.nblocks, p.F, p.npf, p.nvf, blob = net[0], net[1], net[2], net[3], np.ascontiguousarray(net[4], dtype=np.float32)
         p.blob = blob.ctypes.data_as(C.POINTER(C.c_float))
+    return p, blob
+
+
+def simulate(game, oracle, num_games, num_workers, nsims, **kw):
+    """simulate (src/simulations.jl:207-244) in lock-step; returns (games, moves) record arrays."""
+    p, blob = _sim_params(game, oracle, num_games, num_workers, nsims, **kw)
     games = (GameRec * num_games)()
     cap = num_games * 512
     moves = (MoveRec * cap)()
     nm = lib().azr_simulate(C.byref(p), games, moves, cap)
     return games, moves, nm
+
+
+def arena(game, num_games, num_workers, contender, baseline, alternate_colors=False, flip_probability=0.0,
+          reset_every=1, seed=1, first_game_id=0):
+    """pit_networks (src/training.jl:130-144).  contender / baseline: dicts of _sim_params keywords
+    (oracle, nsims, cpuct, noise_eps, ..., temp_xs, temp_ys, net, seed).
+    Returns (games, moves, num_moves, rewards, redundancy)."""
+    ps, keep = [], []
+    for pl in (contender, baseline):
+        kw = dict(pl)
+        oracle, nsims = kw.pop("oracle"), kw.pop("nsims")
+        kw.setdefault("seed", seed)
+        p, blob = _sim_params(game, oracle, num_games, num_workers, nsims, reset_every=reset_every, **kw)
+        ps.append(p)
+        keep.append(blob)
+    games = (GameRec * num_games)()
+    cap = num_games * 512
+    moves = (MoveRec * cap)()
+    rewards = np.zeros(num_games, dtype=np.float64)
+    red = C.c_double()
+    lib().azr_arena.restype = C.c_int64
+    lib().azr_arena.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                C.c_void_p, C.c_void_p]
+    nm = lib().azr_arena(C.byref(ps[0]), C.byref(ps[1]), int(alternate_colors), float(flip_probability), first_game_id,
+                         games, moves, cap, rewards.ctypes.data_as(C.c_void_p), C.byref(red))
+    return games, moves, nm, rewards, red.value
+
+
+def symmetry(game, state_cells, curplayer, k):
+    """GI.symmetries(gspec, state)[k] on raw cells (for tests)."""
+    st, out = State(), State()
+    for i, c in enumerate(state_cells):
+        st.cells[i] = c
+    st.curplayer = curplayer
+    lib().azr_symmetry(game, C.byref(st), k, C.byref(out))
+    return list(out.cells), out.curplayer

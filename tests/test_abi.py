@@ -64,7 +64,7 @@ def test_errors_are_statuses_not_crashes():
     lib = L.lib()
     h = C.c_void_p()
     for kw, frag in ((dict(batch_size=300), b"batch_size"), (dict(num_iters_per_turn=1), b"num_iters_per_turn"),
-                     (dict(flip_probability=0.5), b"flip_probability"), (dict(game=7), b"game")):
+                     (dict(flip_probability=1.5), b"flip_probability"), (dict(game=7), b"game")):
         cfg = default_cfg(**kw)
         assert lib.az_engine_create(C.byref(cfg), C.byref(h)) == L.AZ_ERR_BAD_ARG
         assert frag in lib.az_last_error() and not h.value

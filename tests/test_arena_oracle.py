@@ -1,0 +1,83 @@
+"""CPU checks of the oracle's arena restatement (oracle/azref.c azr_arena; src/training.jl:130-144,
+src/simulations.jl:207-244,296-311, src/play.jl:248-315): symmetries against the reference's definitions,
+reward / colour bookkeeping, redundancy, replay of every recorded game through the game rules."""
+import numpy as np
+
+import azref as R
+
+# games/tictactoe/game.jl:149-160 evaluated by hand: sym[p] (0-based) for rot, rot2, rot3, flip, flip.rot, ...
+TTT_SYMS = [[6, 3, 0, 7, 4, 1, 8, 5, 2], [8, 7, 6, 5, 4, 3, 2, 1, 0], [2, 5, 8, 1, 4, 7, 0, 3, 6], [6, 7, 8, 3, 4, 5, 0, 1, 2],
+            [0, 3, 6, 1, 4, 7, 2, 5, 8], [2, 1, 0, 5, 4, 3, 8, 7, 6], [8, 5, 2, 7, 4, 1, 6, 3, 0]]
+
+
+def test_symmetries_follow_the_reference_definitions():
+    cells = list(range(10, 19))
+    for k in range(7):
+        out, cur = R.symmetry(R.TTT, cells, 2, k)
+        assert out[:9] == [cells[q] for q in TTT_SYMS[k]] and cur == 2
+    c4 = [(i * 7) % 3 for i in range(42)]
+    out, cur = R.symmetry(R.C4, c4, 1, 0)                       # flipped_board, games/connect-four/game.jl:243-250
+    assert all(out[c + 7 * r] == c4[6 - c + 7 * r] for c in range(7) for r in range(6)) and cur == 1
+
+
+def _replay(game, g, moves):
+    """re-run one recorded arena game through the oracle's game rules, applying the recorded symmetries"""
+    env = R.Game(game)
+    for k in range(g.num_moves):
+        m = moves[g.first_move + k]
+        assert env.key() == (m.key[0], m.key[1])
+        sym = m.N[R.AMAX]
+        if sym:
+            cells, cur = R.symmetry(game, list(env.state().cells), env.state().curplayer, sym - 1)
+            st = R.State()
+            for i, c in enumerate(cells):
+                st.cells[i] = c
+            st.curplayer = cur
+            env = R.Game(game, st)
+        mask = env.actions_mask()
+        assert mask[m.action] and sum(m.N[a] for a in range(R.NUM_ACTIONS[game])) > 0
+        assert all(m.N[a] == 0 for a in range(R.NUM_ACTIONS[game]) if not mask[a])
+        env.play(m.action)
+        assert abs(env.white_reward() - m.reward) == 0
+    assert env.terminated() and env.key() == (g.final_key[0], g.final_key[1])
+    return env.white_reward()
+
+
+def test_arena_bookkeeping():
+    pl = dict(oracle=R.ORACLE_HASH, nsims=30, cpuct=2.0, noise_eps=0.05, noise_alpha=1.0, temp_xs=(0,), temp_ys=(0.2,))
+    for game, flip in ((R.TTT, 0.5), (R.C4, 0.5), (R.MANCALA, 0.0)):
+        n = 12
+        games, moves, nm, rewards, red = R.arena(game, n, 5, pl, dict(pl, nsims=8), alternate_colors=True,
+                                                 flip_probability=flip, reset_every=2, seed=3)
+        keys = []
+        for i in range(n):
+            g = games[i]
+            assert g.game_id == i
+            wr = _replay(game, g, moves)
+            flipped = (i + 1) % 2 == 1                            # simulations.jl:221-223 (sim_id is 1-based)
+            assert rewards[i] == (-wr if flipped else wr)
+            keys += [(moves[g.first_move + k].key[0], moves[g.first_move + k].key[1]) for k in range(g.num_moves)]
+            keys.append((g.final_key[0], g.final_key[1]))
+        assert abs(red - (1.0 - len(set(keys)) / len(keys))) < 1e-15
+        assert nm == sum(games[i].num_moves for i in range(n))
+        if flip:
+            assert any(moves[i].N[R.AMAX] for i in range(nm)) and not all(moves[i].N[R.AMAX] for i in range(nm))
+    # the stronger searcher wins the series on tic-tac-toe regardless of colours
+    _, _, _, rewards, _ = R.arena(R.TTT, 40, 8, dict(pl, nsims=60), dict(pl, nsims=3), alternate_colors=True, seed=4)
+    assert np.mean(rewards) > 0.3
+
+
+def test_arena_without_flips_or_swaps_is_white_vs_black():
+    """alternate_colors=false, flip 0: the contender is always WHITE, so its first-move tree statistics equal a
+    plain explore! from the initial state (mcts.jl:239-245) with the game's noise stream."""
+    pl = dict(oracle=R.ORACLE_HASH, nsims=25, cpuct=1.5, noise_eps=0.25, noise_alpha=1.0)
+    games, moves, nm, rewards, red = R.arena(R.C4, 3, 3, pl, dict(pl, nsims=10), seed=9)
+    for i in range(3):
+        m = moves[games[i].first_move]
+        e = R.Mcts(R.C4, R.ORACLE_HASH, cpuct=1.5, noise_eps=0.25, noise_alpha=1.0)
+        g0 = R.Game(R.C4)
+        e.explore(g0, 25, seed=9, game_id=i, move=0)
+        N = e.root_stats(g0)[0]
+        assert list(m.N[:7]) == [int(x) for x in N]
+        wr = _replay(R.C4, games[i], moves)
+        assert rewards[i] == wr

@@ -27,6 +27,9 @@ def test_engine_options_mapping():
         check_sim_params(SimParams(10, 4, 8))                  # batch_size <= num_workers, params.jl:361-384
     with pytest.raises(ValueError):
         check_sim_params(SimParams(10, 8, 8, flip_probability=0.3))
+    check_sim_params(SimParams(10, 8, 8, flip_probability=0.3), arena=True)    # the arena honours flips (play.jl:305-307)
+    with pytest.raises(ValueError):
+        check_sim_params(SimParams(10, 8, 8, flip_probability=1.3), arena=True)
 
 
 def test_shard_games_is_the_reference_split():
