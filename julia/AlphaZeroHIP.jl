@@ -127,9 +127,9 @@ schedule_points(s::PLSchedule) = (Int32.(s.xs), Float64.(s.ys))
 pad8(v, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), 8)
 
 "MctsParams + SimParams + ResNetHP -> az_engine_cfg (SURVEY.md §8b config mapping)"
-function make_cfg(gspec, mcts::MctsParams, sim::SimParams, hp; oracle=2, seed=1, device=0)
+function make_cfg(gspec, mcts::MctsParams, sim::SimParams, hp; oracle=2, seed=1, device=0, arena=false)
   xs, ys = schedule_points(mcts.temperature)
-  @assert iszero(sim.flip_probability) "flip_probability > 0 is not supported on the device path"
+  @assert arena || iszero(sim.flip_probability) "flip_probability > 0 is honoured by the arena only"
   EngineCfg(Int32(sizeof(EngineCfg)), device, game_id(gspec), oracle,
     mcts.gamma, mcts.cpuct, mcts.dirichlet_noise_ϵ, mcts.dirichlet_noise_α, mcts.prior_temperature,
     mcts.num_iters_per_turn, length(xs), pad8(xs, Int32), pad8(ys, Float64),
@@ -266,6 +266,32 @@ function AlphaZero.simulate(simulator::Simulator, gspec::DeviceGameSpec, p::SimP
     end
     simulator.measure(trace, false, WorkerView(WorkerStats(g.nodes, g.total_simulations, g.total_nodes_traversed, nbytes)))
   end
+end
+
+# ---- arena: pit_networks (src/training.jl:130-144) --------------------------------------------------------
+"""
+    pit_networks(gspec::DeviceGameSpec, contender::HipResNet, baseline::HipResNet, params::ArenaParams, handler)
+
+More specific method of the reference's own function: one engine per network, az_arena_run plays
+`params.sim.num_games` games of TwoPlayers(MctsPlayer(contender), MctsPlayer(baseline)) honouring
+`flip_probability` and `alternate_colors`, and returns `(rewards, redundancy)` like rewards_and_redundancy.
+"""
+function AlphaZero.pit_networks(gspec::DeviceGameSpec, contender::HipResNet, baseline::HipResNet, params, handler;
+                                seed=1)
+  engines = map((contender, baseline)) do nn
+    e = Engine(make_cfg(gspec, params.mcts, params.sim, nn.hyper; seed=seed, arena=true))
+    check(ccall((:az_net_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, nn.blob, length(nn.blob)))
+    e
+  end
+  n = params.sim.num_games
+  rewards = Vector{Float64}(undef, n)
+  redundancy = Ref{Float64}(0.0)
+  progress_cb[] = () -> AlphaZero.Handlers.checkpoint_game_played(handler)
+  check(ccall((:az_arena_run, LIB), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ptr{Cvoid}, Ptr{Cvoid}),
+    engines[1].h, engines[2].h, n, 0, params.sim.alternate_colors ? 1 : 0, C_NULL, rewards, redundancy,
+    @cfunction(c_progress, Cvoid, (Ptr{Cvoid},)), C_NULL))
+  return rewards, redundancy[]
 end
 
 end # module
