@@ -6,15 +6,16 @@ include/azhip.h (libazhip.so, hand-written HIP for gfx950).  There is no CPU fal
 """
 from . import _lib
 from ._lib import (AzError, GAME_CONNECT_FOUR, GAME_MANCALA, GAME_TICTACTOE, ORACLE_HASH, ORACLE_RESNET,
-                   ORACLE_UNIFORM)
+                   ORACLE_ROLLOUT, ORACLE_UNIFORM)
 from .engine import Engine, default_cfg
 from .params import ArenaParams, ConstSchedule, MctsParams, PLSchedule, SimParams
 from .game import ConnectFourSpec, GameEnv, GameSpec, MancalaSpec, TicTacToeSpec
 from .network import ResNet, ResNetHP
 from . import mcts as MCTS
-from .play import MctsPlayer, TwoPlayers, flipped_colors, play_game
+from .play import MctsPlayer, NetworkPlayer, PlayerWithTemperature, TwoPlayers, flipped_colors, play_game
 from .trace import Trace
 from .memory import TrainingSample, push_trace
 from .simulations import Simulator, record_trace, self_play_measurements, simulate, simulate_distributed
 from .training import SelfPlayParams, SelfPlayReport, broadcast_params, self_play_step
 from .arena import Evaluation, compare_networks, pit_networks, pit_players
+from . import benchmark as Benchmark

@@ -15,8 +15,8 @@ from . import _lib as L
 from .engine import Engine
 from .mcts import oracle_kind
 from .network import copy as network_copy
-from .params import ArenaParams, engine_options
-from .play import MctsPlayer, TwoPlayers
+from .params import ArenaParams, ConstSchedule, MctsParams, engine_options
+from .play import MctsPlayer, NetworkPlayer, PlayerWithTemperature, TwoPlayers
 from .trace import Trace
 
 
@@ -31,14 +31,26 @@ class Evaluation:
     time: float
 
 
-def _engine(gspec, player: MctsPlayer, sim, device, seed):
-    kind = oracle_kind(player.oracle)
-    kw = engine_options(player.params, sim, seed=seed, arena=True)
+def _engine(gspec, player, sim, device, seed):
+    """one engine per player: MctsPlayer (any device oracle) or PlayerWithTemperature(NetworkPlayer(nn), schedule)
+    -- the latter is an engine without search (num_iters_per_turn = 0)."""
+    if isinstance(player, MctsPlayer):
+        oracle, params = player.oracle, player.params
+    elif isinstance(player, PlayerWithTemperature) and isinstance(player.player, NetworkPlayer):
+        oracle = player.player.network
+        params = MctsParams(num_iters_per_turn=0, dirichlet_noise_ϵ=0.0, dirichlet_noise_α=1.0, temperature=player.temperature)
+    elif isinstance(player, NetworkPlayer):
+        oracle = player.network
+        params = MctsParams(num_iters_per_turn=0, dirichlet_noise_ϵ=0.0, dirichlet_noise_α=1.0, temperature=ConstSchedule(1.0))
+    else:
+        raise TypeError("the device arena pits MctsPlayers and NetworkPlayers (MinMax / Human players stay on the host)")
+    kind = oracle_kind(oracle)
+    kw = engine_options(params, sim, seed=seed, arena=True)
     if kind == L.ORACLE_RESNET:
-        kw.update(player.oracle.engine_options())
+        kw.update(oracle.engine_options())
     e = Engine(game=gspec.game_id, oracle=kind, device=device, **kw)
     if kind == L.ORACLE_RESNET:
-        e.net_set_params(player.oracle.params())
+        e.net_set_params(oracle.params())
     return e
 
 
@@ -52,7 +64,8 @@ def arena_traces(games, moves, ngames, num_actions):
         t = Trace((int(moves[g.first_move].key[0]), int(moves[g.first_move].key[1])))
         for k in range(g.num_moves):
             m = moves[g.first_move + k]
-            n = np.array(m.N[:num_actions], dtype=np.float64)
+            n = np.array(m.N[:num_actions], dtype=np.int32)
+            n = n.view(np.float32).astype(np.float64) if m.N[L.MAX_ACTIONS] & 0x100 else n.astype(np.float64)   # NetworkPlayer: f32 policy bits
             nxt = (int(moves[g.first_move + k + 1].key[0]), int(moves[g.first_move + k + 1].key[1])) \
                 if k + 1 < g.num_moves else (int(g.final_key[0]), int(g.final_key[1]))
             t.push(n / n.sum(), float(m.reward), nxt)
@@ -65,8 +78,6 @@ def pit_players(gspec, players: TwoPlayers, sim, game_simulated=None, device=0, 
     returns (rewards from players.white's side, redundancy, traces)."""
     if not gspec.two_players():
         raise ValueError("pit_players needs a two-player game")
-    if not (isinstance(players.white, MctsPlayer) and isinstance(players.black, MctsPlayer)):
-        raise TypeError("the device arena pits two MctsPlayers")
     with _engine(gspec, players.white, sim, device, seed) as ec, _engine(gspec, players.black, sim, device, seed) as eb:
         games, moves, ng, nm, rewards, red = ec.arena_run(eb, sim.num_games, first_game_id=first_game_id,
                                                           alternate_colors=sim.alternate_colors,

@@ -17,6 +17,17 @@ class RandomOracle:
         self.gspec = gspec
 
 
+class RolloutOracle:
+    """MCTS.RolloutOracle(gspec) (mcts.jl:35-60): uniform prior, V = outcome of one uniformly random playout
+    (gamma = 1, the value Benchmark.MctsRollouts builds it with)."""
+    kind = L.ORACLE_ROLLOUT
+
+    def __init__(self, gspec=None, gamma=1.0):
+        if gamma != 1.0:
+            raise ValueError("the device rollout oracle implements gamma = 1")
+        self.gspec = gspec
+
+
 class HashOracle:
     """Synthetic exact oracle (priors/value derived from the state key); for parity tests."""
     kind = L.ORACLE_HASH
@@ -29,9 +40,9 @@ def oracle_kind(oracle):
     from .network import ResNet
     if isinstance(oracle, ResNet):
         return L.ORACLE_RESNET
-    if isinstance(oracle, (RandomOracle, HashOracle)):
+    if isinstance(oracle, (RandomOracle, HashOracle, RolloutOracle)):
         return oracle.kind
-    raise TypeError("oracle must be a ResNet, MCTS.RandomOracle or MCTS.HashOracle: arbitrary host callables "
+    raise TypeError("oracle must be a ResNet, MCTS.RandomOracle, MCTS.RolloutOracle or MCTS.HashOracle: arbitrary host callables "
                     "cannot run inside the device search (use the reference's CPU MCTS with ResNet.evaluate_batch)")
 
 

@@ -71,6 +71,39 @@ class MctsPlayer:
             self._mcts.reset()
 
 
+class NetworkPlayer:
+    """NetworkPlayer(nn) (play.jl:226-235): plays the network's policy directly, no search."""
+
+    def __init__(self, network):
+        self.network = network
+
+    def think(self, game):
+        P, _ = self.network.evaluate(game.current_state())
+        return game.available_actions(), np.asarray(P)
+
+    def player_temperature(self, game, turn):
+        return 1.0
+
+    def reset_player(self):
+        pass
+
+
+class PlayerWithTemperature:
+    """PlayerWithTemperature(player, temperature) (play.jl:136-150): overrides the move-selection temperature."""
+
+    def __init__(self, player, temperature):
+        self.player, self.temperature = player, temperature
+
+    def think(self, game):
+        return self.player.think(game)
+
+    def player_temperature(self, game, turn):
+        return self.temperature[turn]
+
+    def reset_player(self):
+        self.player.reset_player()
+
+
 class TwoPlayers:
     """TwoPlayers(white, black), play.jl:248-282: behaves as `white` when white is to play, else as `black`."""
 

@@ -271,10 +271,12 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   if (c->struct_size != (int32_t)sizeof(az_engine_cfg)) return fail(AZ_ERR_BAD_ARG, "az_engine_cfg size mismatch (%d vs %zu): call az_engine_cfg_init", c->struct_size, sizeof(az_engine_cfg));
   GameInfo gi;
   if (!game_info(c->game, &gi)) return fail(AZ_ERR_BAD_ARG, "unknown game id %d", c->game);
-  if (c->oracle < AZ_ORACLE_UNIFORM || c->oracle > AZ_ORACLE_RESNET) return fail(AZ_ERR_BAD_ARG, "unknown oracle kind %d", c->oracle);
+  if (c->oracle < AZ_ORACLE_UNIFORM || c->oracle > AZ_ORACLE_ROLLOUT) return fail(AZ_ERR_BAD_ARG, "unknown oracle kind %d", c->oracle);
   if (c->num_workers < 1) return fail(AZ_ERR_BAD_ARG, "num_workers must be >= 1");
   if (c->batch_size > c->num_workers) return fail(AZ_ERR_BAD_ARG, "batch_size (%d) must be <= num_workers (%d) (src/params.jl:361-384)", c->batch_size, c->num_workers);
-  if (c->num_iters_per_turn < 2) return fail(AZ_ERR_BAD_ARG, "num_iters_per_turn must be >= 2 (with 1 the policy is 0/0, src/mcts.jl:267)");
+  // 0 = no search: the engine is a NetworkPlayer (play.jl:226-235) for az_arena_run
+  if (!(c->num_iters_per_turn >= 2 || (c->num_iters_per_turn == 0 && c->oracle == AZ_ORACLE_RESNET)))
+    return fail(AZ_ERR_BAD_ARG, "num_iters_per_turn must be >= 2 (with 1 the policy is 0/0, src/mcts.jl:267), or 0 with the ResNet oracle (NetworkPlayer, arena only)");
   if (!(c->flip_probability >= 0.0 && c->flip_probability <= 1.0)) return fail(AZ_ERR_BAD_ARG, "flip_probability must be in [0, 1]");
   if (c->temperature_len < 1 || c->temperature_len > AZ_SCHED_MAX) return fail(AZ_ERR_BAD_ARG, "temperature schedule needs 1..%d breakpoints", AZ_SCHED_MAX);
   if (c->reset_every < 0) return fail(AZ_ERR_BAD_ARG, "reset_every must be >= 0");
@@ -724,6 +726,24 @@ extern "C" int az_net_forward(az_engine* e, const float* X, const float* A, int3
   return AZ_OK;
 }
 
+// Network.evaluate_batch on device-twin states: P [n][A] (masked, normalised), V [n]
+static int evaluate_envs(az_engine* e, const std::vector<GEnv>& envs, std::vector<float>& P, std::vector<float>& V) {
+  const GameInfo& gi = e->gi;
+  const int N = (int)envs.size();
+  P.assign((size_t)N * gi.A, 0.f); V.assign(N, 0.f);
+  for (int off = 0; off < N; off += e->nn_cap) {
+    int m = std::min(e->nn_cap, N - off);
+    HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data() + off, sizeof(GEnv) * m, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_ntmp, &m, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, false>(e, e->stream, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A))));
+    HIPCHK(hipMemcpyAsync(P.data() + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(V.data() + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  HIPCHK(hipGetLastError());
+  return AZ_OK;
+}
+
 extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t N, float* P, float* V) {
   ENGINE(e);
   if (!e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
@@ -773,7 +793,8 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
 template <class Gm> static int wave_net(az_engine* e, int g, bool split) {
   return e->cfg.num_filters == 128 ? wave_net_f<Gm, 128>(e, g, split) : wave_net_f<Gm, 64>(e, g, split);
 }
-template <class Gm> static int wave(az_engine* e, int ngroups_active) {
+// sim_idx: index of this simulation within the current explore! (keys the rollout oracle's RNG stream)
+template <class Gm> static int wave(az_engine* e, int ngroups_active, uint32_t sim_idx) {
   constexpr int L = Gm::APAD;
   for (int g = 0; g < ngroups_active; ++g) {
     const DView& v = e->gv[g];
@@ -787,7 +808,7 @@ template <class Gm> static int wave(az_engine* e, int ngroups_active) {
     if (e->cfg.oracle == AZ_ORACLE_RESNET) {
       AZCHK((wave_net<Gm>(e, g, split)));
     } else {
-      LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p);
+      LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p, sim_idx);
     }
     LAUNCH_ON(e, st, AZ_K_EXPAND, G, (k_expand_backup<Gm>), gb, 256, 0, v, e->p);
   }
@@ -851,7 +872,7 @@ static int explore_slots(az_engine* e, const std::vector<int>& slots, const std:
                          const std::vector<uint32_t>& gids, const std::vector<uint32_t>& mv, const double* eta, int nsims) {
   int nga = 0;
   AZCHK(explore_begin<Gm>(e, slots, roots, gids, mv, eta, &nga));
-  if (nga) for (int i = 0; i < nsims; ++i) AZCHK(wave<Gm>(e, nga));
+  if (nga) for (int i = 0; i < nsims; ++i) AZCHK(wave<Gm>(e, nga, (uint32_t)i));
   return explore_end(e, nga);
 }
 
@@ -946,6 +967,7 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   ENGINE(e);
   if (e->running) return fail(AZ_ERR_STATE, "self-play already in progress");
   if (num_games == 0) return fail(AZ_ERR_BAD_ARG, "num_games must be != 0");
+  if (e->p.nsims < 2) return fail(AZ_ERR_BAD_ARG, "num_iters_per_turn = 0 (NetworkPlayer) is for az_arena_run only");
   if (e->cfg.flip_probability != 0.0) return fail(AZ_ERR_BAD_ARG, "flip_probability != 0 is honoured by az_arena_run only (self-play configs use 0: the reference's traces pair the un-flipped state with the flipped policy, play.jl:305-313)");
   if (e->cfg.oracle == AZ_ORACLE_RESNET && !e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
   const int G = e->v.G;
@@ -1016,7 +1038,7 @@ extern "C" int az_selfplay_step(az_engine* e, int32_t nwaves) {
   if (!e->running) return fail(AZ_ERR_STATE, "az_selfplay_begin has not been called");
   for (int w = 0; w < nwaves; ++w) {
     if (e->active_slots == 0) break;
-    DISPATCH_GAME(e->cfg.game, AZCHK(wave<Gm>(e, e->ngroups)));
+    DISPATCH_GAME(e->cfg.game, AZCHK(wave<Gm>(e, e->ngroups, (uint32_t)e->wave_in_move)));
     if (++e->wave_in_move == e->p.nsims) {
       e->wave_in_move = 0;
       DISPATCH_GAME(e->cfg.game, AZCHK(move_round<Gm>(e)));
@@ -1155,6 +1177,7 @@ static int arena_run(az_engine* ec, az_engine* eb, int num_games, int first_game
   std::unordered_set<std::pair<uint64_t, uint64_t>, KeyHash> uniq;
   int64_t nstates = 0;
   std::vector<int> slots[2], visits[2], fin;
+  std::vector<float> netP[2], netV[2];
   std::vector<GEnv> roots[2];
   std::vector<uint32_t> gids[2], mvs[2];
   az_engine* eng[2] = {ec, eb};
@@ -1185,22 +1208,34 @@ static int arena_run(az_engine* ec, az_engine* eb, int num_games, int first_game
     // think (play.jl:196-206): the two engines' waves are enqueued alternately on their own streams, so the
     // contender's and the baseline's searches overlap on the GPU (each has only part of the workers)
     int nga[2] = {0, 0};
-    for (int k = 0; k < 2; ++k) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(explore_begin<Gm>(eng[k], slots[k], roots[k], gids[k], mvs[k], nullptr, &nga[k])); }
+    for (int k = 0; k < 2; ++k) if (eng[k]->p.nsims > 0) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(explore_begin<Gm>(eng[k], slots[k], roots[k], gids[k], mvs[k], nullptr, &nga[k])); }
     for (int i = 0; i < std::max(ec->p.nsims, eb->p.nsims); ++i)
-      for (int k = 0; k < 2; ++k) if (nga[k] && i < eng[k]->p.nsims) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(wave<Gm>(eng[k], nga[k])); }
+      for (int k = 0; k < 2; ++k) if (nga[k] && i < eng[k]->p.nsims) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(wave<Gm>(eng[k], nga[k], (uint32_t)i)); }
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipSetDevice(eng[k]->device));
-      AZCHK(explore_end(eng[k], nga[k]));
-      AZCHK(root_visits<Gm>(eng[k], slots[k], roots[k], visits[k]));
+      if (eng[k]->p.nsims > 0) {
+        AZCHK(explore_end(eng[k], nga[k]));
+        AZCHK(root_visits<Gm>(eng[k], slots[k], roots[k], visits[k]));
+      } else {
+        AZCHK(evaluate_envs(eng[k], roots[k], netP[k], netV[k]));   // NetworkPlayer.think (play.jl:230-235)
+      }
     }
     for (int k = 0; k < 2; ++k) for (size_t i = 0; i < slots[k].size(); ++i) {
       ArenaSlot& a = sl[slots[k][i]];
-      const int* vis = &visits[k][i * (AZ_MAX_ACTIONS + 1)];
-      if (!vis[0]) return fail(AZ_ERR_STATE, "root of slot %d missing after explore", slots[k][i]);
       az_move_rec& rec = a.moves.back();
       const uint32_t m = Gm::mask(a.env);
-      for (int x = 0; x < AZ_MAX_ACTIONS; ++x) rec.N[x] = vis[1 + x];
-      const int act = select_action<Gm>(eng[k]->p, vis + 1, m, (uint32_t)a.nmoves, a.gid);
+      int act;
+      if (eng[k]->p.nsims > 0) {
+        const int* vis = &visits[k][i * (AZ_MAX_ACTIONS + 1)];
+        if (!vis[0]) return fail(AZ_ERR_STATE, "root of slot %d missing after explore", slots[k][i]);
+        for (int x = 0; x < AZ_MAX_ACTIONS; ++x) rec.N[x] = vis[1 + x];
+        act = select_action<Gm>(eng[k]->p, vis + 1, m, (uint32_t)a.nmoves, a.gid);
+      } else {
+        const float* P = &netP[k][i * (size_t)Gm::A];
+        for (int x = 0; x < Gm::A; ++x) memcpy(&rec.N[x], &P[x], 4);      // the policy's Float32 bits
+        rec.N[AZ_MAX_ACTIONS] |= 0x100;
+        act = select_action_net<Gm>(eng[k]->p, P, m, (uint32_t)a.nmoves, a.gid);
+      }
       Gm::play(a.env, act);
       rec.action = act;
       rec.reward = Gm::white_reward(a.env);

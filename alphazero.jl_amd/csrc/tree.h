@@ -273,9 +273,31 @@ __global__ void __launch_bounds__(1024) k_compact_assign(DView v) {
   }
 }
 
-// NN-free oracles: MCTS.RandomOracle (src/mcts.jl:62-72) and the synthetic hash oracle
+// rollout! (src/mcts.jl:41-50) from a leaf, value from the leaf's player (mcts.jl:52-60): uniform random
+// available actions from the RNG contract's rollout stream of simulation `sim` of (game, move)
 template <class Gm>
-__global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p) {
+__host__ __device__ inline float rollout_value(GEnv g, uint64_t seed, uint32_t game_id, uint32_t move, uint32_t sim) {
+  const bool wp = Gm::white_playing(g);
+  az_rng r = az_rng_make(seed, game_id, move, AZ_RNG_ROLLOUT);
+  r.ctr[3] = sim * 1024u;
+  double wr = 0.0;
+  // rewards are 0 before the end in all three games, so wr + 1.0 * rollout!(...) unwinds to the final reward
+  // (gamma = 1: every step of the recursion is 0.0 + 1.0 * x, exact)
+  for (int ply = 0; ply < 1024 && !(g.fin & 1); ++ply) {
+    const uint32_t m = Gm::mask(g);
+    int acts[AZ_MAX_ACTIONS], n = 0;
+    for (int a = 0; a < Gm::A; ++a) if ((m >> a) & 1) acts[n++] = a;
+    int k = (int)(az_rng_f64(&r) * (double)n);
+    if (k >= n) k = n - 1;
+    Gm::play(g, acts[k]);
+    wr = (double)Gm::white_reward(g);
+  }
+  return (float)(wp ? wr : -wr);
+}
+
+// NN-free oracles: MCTS.RandomOracle (src/mcts.jl:62-72), MCTS.RolloutOracle (:35-60) and the synthetic hash oracle
+template <class Gm>
+__global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p, uint32_t sim_idx) {
   __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   constexpr int L = Gm::APAD;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,9 +306,13 @@ __global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p) {
   const uint32_t m = Gm::mask(env);
   float P[L];
   float V = 0.f;
-  if (p.oracle == AZ_ORACLE_UNIFORM) {
+  if (p.oracle == AZ_ORACLE_UNIFORM || p.oracle == AZ_ORACLE_ROLLOUT) {
     const float u = (float)(1.0 / (double)__popc(m));             // Float32(ones(n) ./ n)
     for (int a = 0; a < L; ++a) P[a] = ((m >> a) & 1) ? u : 0.f;
+    if (p.oracle == AZ_ORACLE_ROLLOUT) {
+      const int slot = v.eval_slots[e];
+      V = rollout_value<Gm>(env, p.seed, v.game_id[slot], v.move_idx[slot], sim_idx);
+    }
   } else {
     const unsigned long long h = az_hash_key(env.a, env.b);
     float s = 0.f;
@@ -418,16 +444,9 @@ __device__ inline const char* find_node(const DView& v, int slot, unsigned long 
 // (util.jl:68-90) for one root: Nn = visit counts by full action index, m = availability mask, mv = number of
 // moves already played (temperature index, play.jl:309).  Shared by k_move and the arena's host loop, so the
 // device and the host draw the same action from the same counts.
-template <class Gm>
-__host__ __device__ inline int select_action(const DParams& p, const int* Nn, uint32_t m, uint32_t mv, uint32_t game_id) {
-  int acts[AZ_MAX_ACTIONS];
-  double pi[AZ_MAX_ACTIONS], pis[AZ_MAX_ACTIONS];
-  int n = 0;
-  long long ntot = 0;
-  for (int a = 0; a < Gm::A; ++a) if ((m >> a) & 1) { acts[n++] = a; ntot += Nn[a]; }
-  double s = 0.0;
-  for (int i = 0; i < n; ++i) { pi[i] = (double)Nn[acts[i]] / (double)ntot; s += pi[i]; }
-  for (int i = 0; i < n; ++i) pi[i] = pi[i] / s;
+// apply_temperature + sampling of a policy pi over the n available actions acts[]
+__host__ __device__ inline int sample_policy(const DParams& p, const int* acts, const double* pi, int n, uint32_t mv, uint32_t game_id) {
+  double pis[AZ_MAX_ACTIONS];
   const double tau = pl_schedule(p, (int)mv);
   if (tau == 1.0) for (int i = 0; i < n; ++i) pis[i] = pi[i];
   else if (tau == 0.0) {
@@ -451,6 +470,27 @@ __host__ __device__ inline int select_action(const DParams& p, const int* Nn, ui
   }
   az_rng r = az_rng_make(p.seed, game_id, mv, AZ_RNG_MOVE);
   return acts[az_categorical_f32(pf, n, az_rng_f32(&r))];
+}
+template <class Gm>
+__host__ __device__ inline int select_action(const DParams& p, const int* Nn, uint32_t m, uint32_t mv, uint32_t game_id) {
+  int acts[AZ_MAX_ACTIONS];
+  double pi[AZ_MAX_ACTIONS];
+  int n = 0;
+  long long ntot = 0;
+  for (int a = 0; a < Gm::A; ++a) if ((m >> a) & 1) { acts[n++] = a; ntot += Nn[a]; }
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) { pi[i] = (double)Nn[acts[i]] / (double)ntot; s += pi[i]; }
+  for (int i = 0; i < n; ++i) pi[i] = pi[i] / s;
+  return sample_policy(p, acts, pi, n, mv, game_id);
+}
+// NetworkPlayer (play.jl:226-235) under PlayerWithTemperature: the policy is the network's P over the available actions
+template <class Gm>
+__host__ __device__ inline int select_action_net(const DParams& p, const float* P, uint32_t m, uint32_t mv, uint32_t game_id) {
+  int acts[AZ_MAX_ACTIONS];
+  double pi[AZ_MAX_ACTIONS];
+  int n = 0;
+  for (int a = 0; a < Gm::A; ++a) if ((m >> a) & 1) { pi[n] = (double)P[a]; acts[n++] = a; }
+  return sample_policy(p, acts, pi, n, mv, game_id);
 }
 
 template <class Gm>

@@ -147,6 +147,7 @@ def main():
     trav = s1.nodes_traversed - s0.nodes_traversed
     moves = s1.moves - s0.moves
     local_evals = evals
+    local_elapsed = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,6 +184,9 @@ def main():
                 "flop_per_board": TOWER_FLOP, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
                 "avg_boards_per_launch": local_evals / max(tw["launches"], 1),
                 "launches": tw["launches"],
+                # the same FLOPs over the WALL time of the timed region (all kernels, both slot groups): with several
+                # groups the per-launch durations above overlap each other, this figure has no such ambiguity
+                "step_achieved": flops / local_elapsed / 1e12, "step_frac": flops / local_elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             }
             out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
         if world == 1 and not args.no_cpu_baseline:

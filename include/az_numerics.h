@@ -157,6 +157,9 @@ AZ_HD void az_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32
 #define AZ_RNG_FLIP 3u    /* play_game's random symmetry    (src/play.jl:305-307, src/game.jl:329-336):
                              draw 0: rand() < flip_probability, draw 1: floor(u * #symmetries) */
 
+#define AZ_RNG_ROLLOUT 4u /* MCTS.RolloutOracle's random playout (src/mcts.jl:41-50): simulation i of an explore!
+                             owns draws i*1024 .. i*1024+1023; ply k picks available action floor(u_k * n) */
+
 typedef struct {
   uint32_t key[2];   /* 64-bit seed */
   uint32_t ctr[4];   /* game id, move index, purpose, draw index */

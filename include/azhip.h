@@ -67,7 +67,9 @@ typedef enum { AZ_GAME_CONNECT_FOUR = 0, AZ_GAME_TICTACTOE = 1, AZ_GAME_MANCALA 
 typedef enum {
   AZ_ORACLE_UNIFORM = 0, /* MCTS.RandomOracle (src/mcts.jl:62-72): uniform prior, V = 0 */
   AZ_ORACLE_HASH = 1,    /* synthetic, exact: priors/value derived from the state key (tests) */
-  AZ_ORACLE_RESNET = 2   /* the two-headed ResNet (src/networks/architectures/resnet.jl) */
+  AZ_ORACLE_RESNET = 2,  /* the two-headed ResNet (src/networks/architectures/resnet.jl) */
+  AZ_ORACLE_ROLLOUT = 3  /* MCTS.RolloutOracle (src/mcts.jl:35-60), gamma = 1 as Benchmark.MctsRollouts builds it
+                            (src/benchmark.jl:141-143): uniform prior, V = outcome of one random playout */
 } az_oracle_kind;
 
 #define AZ_MAX_ACTIONS 9
@@ -86,7 +88,7 @@ typedef struct {
   double dirichlet_noise_eps;
   double dirichlet_noise_alpha;
   double prior_temperature;
-  int32_t num_iters_per_turn;
+  int32_t num_iters_per_turn; /* >= 2; 0 = NetworkPlayer, no search (az_arena_run only, ResNet oracle) */
   int32_t temperature_len;    /* PLSchedule breakpoints; 1 == ConstSchedule */
   int32_t temperature_xs[AZ_SCHED_MAX];
   double temperature_ys[AZ_SCHED_MAX];
@@ -221,7 +223,11 @@ int az_selfplay_end(az_engine* e);
  * *redundancy = 1 - #unique states / #states over all traces.  `out` (may be NULL) receives the
  * traces sorted by game id: az_move_rec.key is trace.states[i] (the state BEFORE the turn's random
  * symmetry), N / action refer to the state the player saw (after it), N[AZ_MAX_ACTIONS] = 1 + index
- * of the symmetry applied that turn (0: none); az_game_rec.nodes / total_* are 0. */
+ * of the symmetry applied that turn (0: none); az_game_rec.nodes / total_* are 0.
+ * Benchmark.Duel players (src/benchmark.jl:124-192): Full = ResNet oracle, MctsRollouts = AZ_ORACLE_ROLLOUT,
+ * NetworkOnly(tau) = an engine with num_iters_per_turn = 0 (NetworkPlayer, src/play.jl:226-235, under
+ * PlayerWithTemperature(ConstSchedule(tau))): its moves carry the policy's Float32 bits in N[0..A) and
+ * bit 8 of N[AZ_MAX_ACTIONS]. */
 int az_arena_run(az_engine* contender, az_engine* baseline, int32_t num_games, int32_t first_game_id,
                  int32_t alternate_colors, az_trace_buf* out, double* rewards, double* redundancy,
                  az_progress_cb cb, void* user);

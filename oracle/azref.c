@@ -607,6 +607,7 @@ typedef struct {
 #define AZR_ORACLE_UNIFORM 0   /* MCTS.RandomOracle, src/mcts.jl:62-72 */
 #define AZR_ORACLE_HASH 1      /* synthetic: priors/value derived from the packed key */
 #define AZR_ORACLE_NET 2       /* Network.evaluate, src/networks/network.jl:287-298 */
+#define AZR_ORACLE_ROLLOUT 3   /* MCTS.RolloutOracle, src/mcts.jl:35-60 (gamma = 1, src/benchmark.jl:141-143) */
 
 typedef struct {
   int game;
@@ -619,6 +620,8 @@ typedef struct {
   double gamma, cpuct, noise_eps, noise_alpha, prior_temperature;
   int64_t total_simulations, total_nodes_traversed;
   int64_t oracle_calls;
+  /* RNG context of the running simulation (rollout oracle): seed, game id, move, simulation index */
+  uint64_t rng_seed; uint32_t rng_game, rng_move, rng_sim;
 } azr_mcts;
 
 static uint64_t state_hash(const azr_state* s) {
@@ -688,6 +691,17 @@ void azr_hash_oracle(int game, const azr_state* st, const uint8_t* mask, float* 
   *V = (float)((int)(az_mix64(h + 99) & 0xffff) - 32768) / 65536.0f;
 }
 
+/* rollout! (src/mcts.jl:41-50); rand(available_actions) = action floor(u * n) of the RNG contract */
+static double rollout(azr_env* g, double gamma, az_rng* r) {
+  int acts[AZR_AMAX]; int n = available(g, acts);
+  int k = (int)(az_rng_f64(r) * (double)n);
+  if (k >= n) k = n - 1;
+  azr_play(g, acts[k]);
+  double wr = azr_white_reward(g);
+  if (azr_terminated(g)) return wr;
+  return wr + gamma * rollout(g, gamma, r);
+}
+
 /* oracle(state) -> (P over available actions, V); src/mcts.jl:6-17 */
 static void call_oracle(azr_mcts* e, const azr_state* st, float* P, float* V) {
   azr_env g; azr_init_state(&g, e->game, st);       /* GI.init(gspec, state) */
@@ -696,6 +710,14 @@ static void call_oracle(azr_mcts* e, const azr_state* st, float* P, float* V) {
   if (e->oracle_kind == AZR_ORACLE_UNIFORM) {
     for (int i = 0; i < n; ++i) P[i] = (float)(1.0 / (double)n);   /* ones(n) ./ n -> Float32(p) */
     *V = 0.0f;
+  } else if (e->oracle_kind == AZR_ORACLE_ROLLOUT) {
+    /* (r::RolloutOracle)(state), src/mcts.jl:52-60 */
+    int wp = azr_white_playing(&g);
+    for (int i = 0; i < n; ++i) P[i] = (float)(1.0 / (double)n);
+    az_rng r = az_rng_make(e->rng_seed, e->rng_game, e->rng_move, AZ_RNG_ROLLOUT);
+    r.ctr[3] = e->rng_sim * 1024u;
+    double wr = rollout(&g, 1.0, &r);
+    *V = (float)(wp ? wr : -wr);
   } else if (e->oracle_kind == AZR_ORACLE_HASH) {
     float pf[AZR_AMAX];
     azr_hash_oracle(e->game, st, g.amask, pf, V);
@@ -796,7 +818,9 @@ void azr_mcts_explore(azr_mcts* e, const azr_env* game, int nsims, const double*
   int acts[AZR_AMAX]; int n = available(game, acts);
   if (eta_in) memcpy(eta, eta_in, sizeof(double) * (size_t)n);
   else { az_rng r = az_rng_make(seed, game_id, move, AZ_RNG_NOISE); az_dirichlet(&r, n, e->noise_alpha, eta); }
+  e->rng_seed = seed; e->rng_game = game_id; e->rng_move = move;
   for (int i = 0; i < nsims; ++i) {
+    e->rng_sim = (uint32_t)i;
     e->total_simulations += 1;
     azr_env clone = *game;                       /* GI.clone */
     run_simulation(e, &clone, eta, 1);
@@ -1046,12 +1070,21 @@ int64_t azr_arena(const azr_sim_params* pc, const azr_sim_params* pb, int altern
       int who = (azr_white_playing(&sl->game) != colors_flipped) ? 0 : 1;      /* think(::TwoPlayers), play.jl:255-261 */
       const azr_sim_params* p = pp[who];
       azr_mcts* m = trees[who][s];
-      azr_mcts_explore(m, &sl->game, p->num_iters_per_turn, 0, p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves);
       int acts[AZR_AMAX]; double pi[AZR_AMAX], pis[AZR_AMAX];
-      int n = azr_mcts_policy(m, &sl->game, acts, pi);
-      { azr_node* nd = tree_find(m, &sl->game.s, 0);
-        for (int i = 0; i < n; ++i) mr->N[acts[i]] = (int32_t)nd->N[i]; }
-      double tau = azr_plschedule(p->temp_xs, p->temp_ys, p->temp_len, sl->nmoves);   /* player_temperature, play.jl:276-282 */
+      int n;
+      if (p->num_iters_per_turn > 0) {                                /* MctsPlayer.think, play.jl:196-206 */
+        azr_mcts_explore(m, &sl->game, p->num_iters_per_turn, 0, p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves);
+        n = azr_mcts_policy(m, &sl->game, acts, pi);
+        azr_node* nd = tree_find(m, &sl->game.s, 0);
+        for (int i = 0; i < n; ++i) mr->N[acts[i]] = (int32_t)nd->N[i];
+      } else {                                                        /* NetworkPlayer.think, play.jl:230-235 */
+        float P[AZR_AMAX], V;
+        n = available(&sl->game, acts);
+        call_oracle(m, &sl->game.s, P, &V);
+        for (int i = 0; i < n; ++i) { pi[i] = (double)P[i]; memcpy(&mr->N[acts[i]], &P[i], 4); }
+        mr->N[AZR_AMAX] |= 0x100;
+      }
+      double tau = azr_plschedule(p->temp_xs, p->temp_ys, p->temp_len, sl->nmoves);   /* player_temperature, play.jl:276-282; PlayerWithTemperature */
       apply_temperature(pi, n, tau, pis);
       az_rng r = az_rng_make(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, AZ_RNG_MOVE);
       int a = acts[azr_rand_categorical(pis, n, az_rng_f32(&r))];

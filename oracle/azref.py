@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libazref.so")
 
 C4, TTT, MANCALA = 0, 1, 2
-ORACLE_UNIFORM, ORACLE_HASH, ORACLE_NET = 0, 1, 2
+ORACLE_UNIFORM, ORACLE_HASH, ORACLE_NET, ORACLE_ROLLOUT = 0, 1, 2, 3
 AMAX = 9
 CELLS = 42
 

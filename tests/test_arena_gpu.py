@@ -106,3 +106,58 @@ def test_arena_errors():
         with pytest.raises(L.AzError, match="fewer workers"):
             a.arena_run(b, 8)
         a.arena_run(b, 2)                                         # 2 workers suffice for 2 games
+
+
+@pytest.mark.parametrize("player", ["full", "network_only"])
+def test_benchmark_duels_match_oracle(player):
+    """The shipped connect-four benchmark in miniature (games/connect-four/params.jl:66-100): Benchmark.Duel(Full |
+    NetworkOnly(0.5), MctsRollouts) through Benchmark.run -- az_arena_run with a rollout-oracle engine and, for
+    NetworkOnly, an engine without search -- equals the oracle's arena."""
+    import azhip
+    from azhip import Benchmark
+    gspec = azhip.ConnectFourSpec()
+    hp = azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    nn = azhip.ResNet(gspec, hp, seed=9)
+    arena_mcts = azhip.MctsParams(num_iters_per_turn=20, cpuct=2.0, dirichlet_noise_ϵ=0.05, dirichlet_noise_α=1.0,
+                                  temperature=azhip.ConstSchedule(0.2))
+    base_mcts = azhip.MctsParams(num_iters_per_turn=50, cpuct=1.0, dirichlet_noise_ϵ=0.05, dirichlet_noise_α=1.0,
+                                 temperature=azhip.ConstSchedule(0.2))
+    sim = azhip.SimParams(num_games=10, num_workers=5, batch_size=5, use_gpu=True, reset_every=2, flip_probability=0.5,
+                          alternate_colors=False)
+    pl = Benchmark.Full(arena_mcts) if player == "full" else Benchmark.NetworkOnly(τ=0.5)
+    duel = Benchmark.Duel(pl, Benchmark.MctsRollouts(base_mcts), sim)
+    count = [0]
+    ev = Benchmark.run(gspec, nn, duel, progress=lambda: count.__setitem__(0, count[0] + 1), seed=17)
+    net = (1, 64, 32, 32, nn.params())
+    c = dict(oracle=R.ORACLE_NET, nsims=20, cpuct=2.0, noise_eps=0.05, noise_alpha=1.0, temp_xs=(0,), temp_ys=(0.2,), net=net) \
+        if player == "full" else dict(oracle=R.ORACLE_NET, nsims=0, noise_eps=0.0, temp_xs=(0,), temp_ys=(0.5,), net=net)
+    b = dict(oracle=R.ORACLE_ROLLOUT, nsims=50, cpuct=1.0, noise_eps=0.05, noise_alpha=1.0, temp_xs=(0,), temp_ys=(0.2,))
+    _, _, _, rew_ref, red_ref = R.arena(R.C4, 10, 5, c, b, alternate_colors=False, flip_probability=0.5, reset_every=2, seed=17)
+    assert count[0] == 10 and np.array_equal(ev.rewards, rew_ref) and ev.redundancy == red_ref
+    assert ev.legend == ("AlphaZero / MCTS (50 rollouts)" if player == "full" else "Network Only / MCTS (50 rollouts)")
+    st = Benchmark.TernaryOutcomeStatistics.of(ev.rewards)
+    assert st.num_won + st.num_draw + st.num_lost == 10
+
+
+def test_network_player_records_and_errors():
+    """records of a NetworkPlayer engine carry the Float32 policy; self-play and explore refuse an engine without search"""
+    import azhip
+    from azhip import _lib as L
+    hp = dict(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    from azhip.network import ResNetHP, random_params
+    blob = random_params(R.TTT, ResNetHP(1, 64, (3, 3), 32, 32), seed=3)
+    kw = dict(game=L.GAME_TICTACTOE, num_workers=4, batch_size=4, temperature=([0], [0.5]), seed=8, cpuct=1.0, reset_every=1, **hp)
+    with azhip.Engine(oracle=L.ORACLE_RESNET, num_iters_per_turn=0, **kw) as a, \
+            azhip.Engine(oracle=L.ORACLE_ROLLOUT, num_iters_per_turn=40, dirichlet_noise_eps=0.05, **kw) as b:
+        a.net_set_params(blob)
+        games, moves, ng, nm, rew, red = a.arena_run(b, 6, alternate_colors=True)
+        g_ref, m_ref, nm_ref, rew_ref, red_ref = R.arena(
+            R.TTT, 6, 4, dict(oracle=R.ORACLE_NET, nsims=0, temp_xs=(0,), temp_ys=(0.5,), net=(1, 64, 32, 32, blob), seed=8),
+            dict(oracle=R.ORACLE_ROLLOUT, nsims=40, noise_eps=0.05, temp_xs=(0,), temp_ys=(0.5,), seed=8), alternate_colors=True, seed=8)
+        _same_records(games, moves, ng, g_ref, m_ref, nm_ref, 9)
+        assert np.array_equal(rew, rew_ref) and red == red_ref
+        assert any(moves[i].N[L.MAX_ACTIONS] & 0x100 for i in range(nm))
+        with pytest.raises(L.AzError, match="NetworkPlayer"):
+            a.selfplay_run(2)
+    with pytest.raises(L.AzError, match="num_iters_per_turn"):
+        azhip.Engine(oracle=L.ORACLE_HASH, num_iters_per_turn=0, game=L.GAME_TICTACTOE, num_workers=4, batch_size=4)

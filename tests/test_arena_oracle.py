@@ -81,3 +81,94 @@ def test_arena_without_flips_or_swaps_is_white_vs_black():
         assert list(m.N[:7]) == [int(x) for x in N]
         wr = _replay(R.C4, games[i], moves)
         assert rewards[i] == wr
+
+
+def _u64(seed, game, move, purpose, draw):
+    """one az_rng_f64 draw restated from the RNG contract (include/az_numerics.h): Philox block -> 52-bit uniform"""
+    import ctypes as C
+    c = (C.c_uint32 * 4)(game, move, purpose, draw)
+    k = (C.c_uint32 * 2)(seed & 0xffffffff, seed >> 32)
+    o = (C.c_uint32 * 4)()
+    R.lib().azr_philox(c, k, o)
+    return ((((o[0] << 32) | o[1]) >> 12) + 0.5) * 2.0 ** -52
+
+
+def test_rollout_oracle_against_python_restatement():
+    """MCTS.RolloutOracle (mcts.jl:35-60): the C oracle's tree after explore! equals an independent Python MCTS
+    (oracle/pyref.py games + search) whose oracle plays the rollout with draws taken from the Philox contract."""
+    import pyref
+    seed, gid, move = 5, 3, 2
+    for game in (R.C4, R.TTT, R.MANCALA):
+        G = pyref.GAMES[game]
+        sim = [0]
+
+        def rollout_oracle(G_, g):
+            acts = [a for a, ok in enumerate(G_.mask(g)) if ok]
+            P = [np.float32(1.0 / len(acts))] * len(acts)
+            wp = pyref.white_playing(G_, g)
+            draw = sim[0] * 1024
+            wr = 0.0
+            while not pyref.finished(G_, g):                       # rollout!, mcts.jl:41-50 (rewards are 0 before the end)
+                av = [a for a, ok in enumerate(G_.mask(g)) if ok]
+                k = min(int(_u64(seed, gid, move, 4, draw) * len(av)), len(av) - 1)
+                draw += 1
+                g = G_.play(g, av[k])
+                wr = G_.reward(g)
+            return P, np.float32(wr if wp else -wr)
+        m = pyref.Mcts(G, rollout_oracle, gamma=1.0, cpuct=1.3)
+        g0 = G.init()
+        for a in ((3, 3, 2) if game == R.C4 else (4, 0) if game == R.TTT else (2, 5)):
+            g0 = G.play(g0, a)
+        for i in range(80):
+            sim[0] = i
+            m.explore(g0, 1, None)
+        e = R.Mcts(game, R.ORACLE_ROLLOUT, cpuct=1.3)
+        env = R.Game(game)
+        for a in ((3, 3, 2) if game == R.C4 else (4, 0) if game == R.TTT else (2, 5)):
+            env.play(a)
+        e.explore(env, 80, eta=np.zeros(9), seed=seed, game_id=gid, move=move)
+        N, W, P, V = e.root_stats(env)
+        Np, Wp, Pp, Vp = m.root_stats(g0)
+        assert [int(x) for x in N] == Np and [float(x) for x in W] == Wp and float(V) == float(Vp), game
+
+
+def test_network_only_and_rollout_players_in_the_arena():
+    """Benchmark.Duel(NetworkOnly / Full, MctsRollouts) (benchmark.jl:124-192) through the oracle's arena: games
+    replay through the rules, NetworkPlayer moves carry the policy bits, rollout players beat the random net."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "alphazero.jl_amd"))
+    from azhip.network import ResNetHP, random_params
+    hp = ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    blob = random_params(R.TTT, hp, seed=3)
+    net = (1, 64, 32, 32, blob)
+    netonly = dict(oracle=R.ORACLE_NET, nsims=0, temp_xs=(0,), temp_ys=(0.5,), net=net)
+    roll = dict(oracle=R.ORACLE_ROLLOUT, nsims=40, cpuct=1.0, noise_eps=0.05, noise_alpha=1.0, temp_xs=(0,), temp_ys=(0.2,))
+    games, moves, nm, rewards, red = R.arena(R.TTT, 16, 8, netonly, roll, alternate_colors=True, flip_probability=0.5, seed=8)
+    nnet = 0
+    for i in range(16):
+        _replay_any(R.TTT, games[i], moves)
+        for k in range(games[i].num_moves):
+            m = moves[games[i].first_move + k]
+            if m.N[R.AMAX] & 0x100:
+                nnet += 1
+                P = np.array(m.N[:9], dtype=np.int32).view(np.float32)
+                assert abs(float(P.sum()) - 1.0) < 1e-5 and (P >= 0).all()
+    assert nnet > 0 and np.mean(rewards) < 0        # 40 rollouts per move beat an untrained policy
+
+
+def _replay_any(game, g, moves):
+    env = R.Game(game)
+    for k in range(g.num_moves):
+        m = moves[g.first_move + k]
+        assert env.key() == (m.key[0], m.key[1])
+        sym = m.N[R.AMAX] & 0xff
+        if sym:
+            cells, cur = R.symmetry(game, list(env.state().cells), env.state().curplayer, sym - 1)
+            st = R.State()
+            for i, c in enumerate(cells):
+                st.cells[i] = c
+            st.curplayer = cur
+            env = R.Game(game, st)
+        assert env.actions_mask()[m.action]
+        env.play(m.action)
+    assert env.terminated() and env.key() == (g.final_key[0], g.final_key[1])

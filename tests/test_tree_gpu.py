@@ -32,9 +32,11 @@ def test_appendix_d_root_counts(game, cpuct, nsims, expect):
 
 
 @pytest.mark.parametrize("game", [0, 1, 2])
-@pytest.mark.parametrize("oracle", [0, 1])
+@pytest.mark.parametrize("oracle", [0, 1, 3])
 def test_explore_matches_oracle(game, oracle):
-    """explore! from random reachable roots, hash/uniform oracle, given eta: N, W, P, Vest equal bit for bit."""
+    """explore! from random reachable roots, uniform / hash / rollout oracle (MCTS.RolloutOracle, mcts.jl:35-60: the
+    playouts draw from the RNG contract's stream of (seed, game, move, simulation)), given eta: N, W, P, Vest equal
+    bit for bit."""
     rng = np.random.default_rng(7 + game)
     nslots, nsims = 8, 200
     roots, envs = [], []
@@ -57,10 +59,10 @@ def test_explore_matches_oracle(game, oracle):
         etas.append(eta)
         eta_full[s, acts] = eta
     with _engine(game, oracle, cpuct=1.7, dirichlet_noise_eps=0.25, gamma=0.97) as e:
-        e.mcts_explore(roots, nsims, eta=eta_full)
+        e.mcts_explore(roots, nsims, eta=eta_full, game_ids=np.arange(nslots) + 40, moves=np.arange(nslots) % 3)
         for s, g in enumerate(envs):
             m = R.Mcts(game, oracle=oracle, gamma=0.97, cpuct=1.7, noise_eps=0.25)
-            m.explore(g, nsims, eta=etas[s])
+            m.explore(g, nsims, eta=etas[s], seed=1, game_id=s + 40, move=s % 3)
             N, W, P, V = m.root_stats(g)
             Nd, Wd, Pd, Vd, mask = e.mcts_node_stats(s, roots[s])
             acts = g.available_actions()
@@ -74,7 +76,7 @@ def test_explore_matches_oracle(game, oracle):
 
 @pytest.mark.parametrize("game,nsims,ngames,workers,batch", [(1, 64, 32, 32, 32), (0, 100, 24, 8, 8), (2, 60, 12, 8, 8),
                                                               (1, 64, 40, 32, 8), (0, 100, 24, 8, 4)])
-@pytest.mark.parametrize("oracle", [0, 1])
+@pytest.mark.parametrize("oracle", [0, 1, 3])
 def test_selfplay_traces_match_oracle(game, nsims, ngames, workers, batch, oracle):
     """Whole self-play phase (simulate): every move record, visit count, action, reward, node count.
     batch < workers runs workers/batch interleaved slot groups on separate streams: same results."""
