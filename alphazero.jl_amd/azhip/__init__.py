@@ -14,8 +14,9 @@ from .network import ResNet, ResNetHP
 from . import mcts as MCTS
 from .play import MctsPlayer, NetworkPlayer, PlayerWithTemperature, TwoPlayers, flipped_colors, play_game
 from .trace import Trace
-from .memory import TrainingSample, push_trace
+from .memory import Dataset, MemoryBuffer, TrainingSample, push_trace
 from .simulations import Simulator, record_trace, self_play_measurements, simulate, simulate_distributed
 from .training import SelfPlayParams, SelfPlayReport, broadcast_params, self_play_step
 from .arena import Evaluation, compare_networks, pit_networks, pit_players
 from . import benchmark as Benchmark
+from .learning import (CONSTANT_WEIGHT, LINEAR_WEIGHT, LOG_WEIGHT, LearningParams, LearningStatus, Loss, Samples, Trainer)

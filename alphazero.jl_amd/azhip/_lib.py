@@ -65,6 +65,23 @@ class Prof(C.Structure):
     _fields_ = [("launches", C.c_int64 * PROF_NUM), ("ms", C.c_double * PROF_NUM), ("units", C.c_int64 * PROF_NUM)]
 
 
+class Sample(C.Structure):
+    """az_sample = TrainingSample (memory.jl:20-26), pi by full action index"""
+    _fields_ = [("key", C.c_uint64 * 2), ("pi", C.c_double * MAX_ACTIONS), ("z", C.c_double), ("t", C.c_double),
+                ("n", C.c_int64)]
+
+
+class DatasetInfo(C.Structure):
+    _fields_ = [("num_samples", C.c_int64), ("sum_n", C.c_int64), ("Wtot", C.c_double), ("Wmean", C.c_float),
+                ("Hp", C.c_float)]
+
+
+class LearningStatusRec(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("L", "Lp", "Lv", "Lreg", "Linv", "Hp", "Hpnet")]
+
+
+WEIGHT_CONSTANT, WEIGHT_LOG, WEIGHT_LINEAR = 0, 1, 2
+
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p)
 
 # every symbol include/azhip.h declares: name -> argtypes (restype is int unless noted)
@@ -98,6 +115,17 @@ SYMBOLS = {
     "az_selfplay_end": [_VP],
     "az_arena_run": [_VP, _VP, _I32, _I32, _I32, C.POINTER(TraceBuf), _VP, C.POINTER(C.c_double), PROGRESS_CB, _VP],
     "az_push_trace": [_VP, _I32, C.c_double, _VP, _VP],
+    "az_memory_create": [_I32, _I32, _I64, C.POINTER(_VP)],
+    "az_memory_destroy": [_VP],
+    "az_memory_push": [_VP, C.POINTER(TraceBuf), C.c_double],
+    "az_memory_length": [_VP, C.POINTER(_I64), C.POINTER(_I64)],
+    "az_memory_new_batch": [_VP],
+    "az_memory_empty": [_VP],
+    "az_dataset_create": [_VP, _I32, _I32, _I32, _I32, C.POINTER(_VP)],
+    "az_dataset_destroy": [_VP],
+    "az_dataset_get_info": [_VP, C.POINTER(DatasetInfo)],
+    "az_dataset_read": [_VP, _I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP],
+    "az_learning_status": [_VP, _VP, C.c_double, C.c_double, C.c_double, _I64, C.POINTER(LearningStatusRec)],
     "az_prof_enable": [_VP, _I32],
     "az_prof_get": [_VP, C.POINTER(Prof)],
     "az_prof_reset": [_VP],

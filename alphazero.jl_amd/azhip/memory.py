@@ -55,3 +55,117 @@ def pack_samples(games, moves, ngames, num_actions, gamma):
             r["n"] = 1
         k += g.num_moves
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MemoryBuffer on the device (memory.jl:34-60) and the Trainer's data (learning.jl:98-121)
+import ctypes as _C
+
+from . import _lib as _L
+
+
+class MemoryBuffer:
+    """MemoryBuffer(gspec, size): a circular buffer of TrainingSamples in HBM (az_memory_*).
+
+    push_records takes the packed records of a self-play phase (Engine.selfplay_run / gather_records) and does
+    push_trace! for every game on the device; get_experience() / last_batch() return device data sets."""
+
+    def __init__(self, gspec, size, device=0):
+        self.gspec = gspec
+        h = _C.c_void_p()
+        _L.check(_L.lib().az_memory_create(gspec.game_id, device, int(size), _C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _L.lib().az_memory_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def push_records(self, games, moves, ngames, nmoves, gamma):
+        tb = _L.TraceBuf()
+        tb.games, tb.games_cap, tb.num_games = games, ngames, ngames
+        tb.moves, tb.moves_cap, tb.num_moves = moves, nmoves, nmoves
+        _L.check(_L.lib().az_memory_push(self._h, _C.byref(tb), float(gamma)))
+
+    def _lens(self):
+        a, b = _C.c_int64(), _C.c_int64()
+        _L.check(_L.lib().az_memory_length(self._h, _C.byref(a), _C.byref(b)))
+        return a.value, b.value
+
+    def __len__(self):
+        return self._lens()[0]
+
+    def cur_batch_size(self):
+        return self._lens()[1]
+
+    def new_batch(self):
+        _L.check(_L.lib().az_memory_new_batch(self._h))
+
+    def empty(self):
+        _L.check(_L.lib().az_memory_empty(self._h))
+
+    def dataset(self, last_batch=False, use_symmetries=False, use_position_averaging=False, weighing_policy=_L.WEIGHT_CONSTANT):
+        return Dataset(self, last_batch, use_symmetries, use_position_averaging, weighing_policy)
+
+    def get_experience(self):
+        """get_experience(mem) as TrainingSample list (host copy; the device path keeps working on Dataset)"""
+        with self.dataset() as d:
+            return d.samples()
+
+    def last_batch(self):
+        with self.dataset(last_batch=True) as d:
+            return d.samples()
+
+
+class Dataset:
+    """The (W, X, A, P, V) data of a Trainer plus its samples, resident on the device (az_dataset_*)."""
+
+    def __init__(self, mem, last_batch, use_symmetries, use_position_averaging, weighing_policy):
+        self.gspec = mem.gspec
+        h = _C.c_void_p()
+        _L.check(_L.lib().az_dataset_create(mem._h, 1 if last_batch else 0, 1 if use_symmetries else 0,
+                                            1 if use_position_averaging else 0, int(weighing_policy), _C.byref(h)))
+        self._h = h
+        info = _L.DatasetInfo()
+        _L.check(_L.lib().az_dataset_get_info(h, _C.byref(info)))
+        self.num_samples, self.sum_n, self.Wtot, self.Wmean, self.Hp = info.num_samples, info.sum_n, info.Wtot, info.Wmean, info.Hp
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _L.lib().az_dataset_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __len__(self):
+        return self.num_samples
+
+    def raw_samples(self):
+        n = self.num_samples
+        out = (_L.Sample * max(n, 1))()
+        _L.check(_L.lib().az_dataset_read(self._h, 0, n, out, None, None, None, None, None))
+        return out
+
+    def samples(self):
+        nA = self.gspec.num_actions()
+        raw = self.raw_samples()
+        return [TrainingSample((int(raw[i].key[0]), int(raw[i].key[1])), np.array(raw[i].pi[:nA]), raw[i].z, raw[i].t, int(raw[i].n))
+                for i in range(self.num_samples)]
+
+    def tensors(self):
+        """convert_samples: (W, X, A, P, V) Float32 arrays, sample index first (= the reference's last dimension)"""
+        n, nA = self.num_samples, self.gspec.num_actions()
+        w, h, c = self.gspec.state_dim()
+        W = np.zeros(n, dtype=np.float32); X = np.zeros((n, c, h, w), dtype=np.float32)
+        A = np.zeros((n, nA), dtype=np.float32); P = np.zeros((n, nA), dtype=np.float32); V = np.zeros(n, dtype=np.float32)
+        vp = lambda a: a.ctypes.data_as(_C.c_void_p)
+        _L.check(_L.lib().az_dataset_read(self._h, 0, n, None, vp(W), vp(X), vp(A), vp(P), vp(V)))
+        return W, X, A, P, V

@@ -1307,6 +1307,8 @@ extern "C" int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, 
   return AZ_OK;
 }
 
+#include "memory.h"
+
 // debug aid (not part of the ABI in azhip.h): the numerics contract evaluated on the device, so that tests can
 // compare gfx950 against the host bit for bit (f64 sqrt / div, az_log / az_exp / az_pow, az_expf / az_tanhf)
 __global__ void k_debug_math(int op, const double* x, const double* y, int n, double* out) {

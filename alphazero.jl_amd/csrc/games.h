@@ -90,6 +90,7 @@ struct ConnectFour {
   AZ_GHD static GEnv sym(const GEnv& g, int) {
     return GEnv{mirror(g.a & ~AZ_BLACK_BIT) | (g.a & AZ_BLACK_BIT), mirror(g.b), g.fin};
   }
+  AZ_GHD static int sym_action(int, int j) { return 6 - j; }   // aperm: pi'[j] = pi[sigma[j]], memory.jl:122-126
   // vectorize_state, game.jl:226-241: plane c in (EMPTY, player to move, opponent)
   AZ_GHD static float plane(const GEnv& g, int p /* x + 7*y */, int c) {
     int x = p % 7, y = p / 7;
@@ -153,6 +154,7 @@ struct TicTacToe {
     }
     return GEnv{na, nb, g.fin};
   }
+  AZ_GHD static int sym_action(int k, int j) { return sym_src(k, j); }   // the action permutation is the board permutation
   AZ_GHD static float plane(const GEnv& g, int p, int c) {  // vectorize_state, game.jl:126-143
     bool wp = white_playing(g);
     uint32_t w = (uint32_t)g.a & 0x1ff, k = (uint32_t)g.b & 0x1ff;
@@ -237,6 +239,7 @@ struct Mancala {
   }
   static constexpr int NSYM = 0;                        // no GI.symmetries method: apply_random_symmetry! asserts
   AZ_GHD static GEnv sym(const GEnv& g, int) { return g; }
+  AZ_GHD static int sym_action(int, int j) { return j; }
   // vectorize_state, game.jl:224-257, BUG-COMPATIBLE: when BLACK is to move flip_colors returns
   // the INITIAL board.  Positions: WHITE houses 6..1, WHITE store, BLACK houses 6..1, BLACK store.
   AZ_GHD static float plane(const GEnv& g, int p, int c) {

@@ -104,6 +104,16 @@ AZ_HD double az_log(double x) {
   return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
+/* log2 for finite x >= 1: exponent + log(mantissa) / ln 2 -- exact on powers of two (LOG_WEIGHT, learning.jl:25) */
+AZ_HD double az_log2(double x) {
+  uint64_t u = az_d2u(x);
+  int k = (int)((u >> 52) & 0x7ff) - 1023;
+  double m = az_u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+  return (double)k + az_log(m) * 1.44269504088896338700e+00;
+}
+/* Float32 log of the loss terms (learning.jl:63-65): the f64 log rounded once */
+AZ_HD float az_logf(float x) { return (float)az_log((double)x); }
+
 /* ------------------------------------------------------------------ f64 exp */
 AZ_HD double az_exp(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,

@@ -235,6 +235,49 @@ int az_arena_run(az_engine* contender, az_engine* baseline, int32_t num_games, i
 /* push_trace! (src/memory.jl:74-87): z (discounted, side relative) and t per move record. */
 int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, double* z, double* t);
 
+/* ---- replay memory (src/memory.jl) and learning status (src/learning.jl) on the device ---- */
+typedef struct az_memory az_memory;      /* MemoryBuffer (src/memory.jl:34-45): circular buffer of samples in HBM */
+typedef struct az_dataset az_dataset;    /* Trainer's converted data (src/learning.jl:98-121), device resident */
+/* TrainingSample (src/memory.jl:20-26); pi by FULL action index (0 where the action is unavailable). 112 bytes. */
+typedef struct {
+  uint64_t key[2];
+  double pi[AZ_MAX_ACTIONS];
+  double z, t;
+  int64_t n;
+} az_sample;
+typedef enum { AZ_WEIGHT_CONSTANT = 0, AZ_WEIGHT_LOG = 1, AZ_WEIGHT_LINEAR = 2 } az_weighing_policy;   /* params.jl:177 */
+int az_memory_create(int32_t game, int32_t device, int64_t capacity, az_memory** out);
+int az_memory_destroy(az_memory* m);
+/* push_trace!(mem, trace, gamma) (src/memory.jl:74-87) for every game of `traces` in buffer order: one sample
+ * per move record, pi = MCTS.policy of the recorded visit counts, z / t as az_push_trace. */
+int az_memory_push(az_memory* m, const az_trace_buf* traces, double gamma);
+int az_memory_length(az_memory* m, int64_t* length, int64_t* cur_batch_size);   /* length, cur_batch_size (:53-59) */
+int az_memory_new_batch(az_memory* m);                                            /* new_batch! (:55) */
+int az_memory_empty(az_memory* m);                                                /* empty! (:57-60) */
+/* The data of a Trainer: which = 0 get_experience / 1 last_batch (:47-51); use_symmetries =
+ * augment_with_symmetries (:116-138, applied by learning_step!, src/training.jl:199-202) ; use_position_averaging =
+ * merge_by_state (:98-114; samples of a state are averaged in buffer order, output sorted by key);
+ * convert_samples (src/learning.jl:17-51) with the weighing policy.  Everything stays on the device. */
+int az_dataset_create(az_memory* m, int32_t which, int32_t use_symmetries, int32_t use_position_averaging,
+                      int32_t weighing_policy, az_dataset** out);
+int az_dataset_destroy(az_dataset* d);
+typedef struct {
+  int64_t num_samples;   /* length(samples) after symmetries / merging (= num_boards when merged) */
+  int64_t sum_n;         /* sum(e.n), Report.Samples.num_samples (src/learning.jl:186) */
+  double Wtot;           /* sum(W) */
+  float Wmean, Hp;       /* mean(W), entropy_wmean(P, W) (src/learning.jl:110-111) */
+} az_dataset_info;
+int az_dataset_get_info(az_dataset* d, az_dataset_info* out);
+/* samples / tensors [first, first+count) to host buffers (any pointer may be NULL): W [n], X [n][C][H][W]
+ * (= Julia WHCN memory), A [n][nA], P [n][nA], V [n] */
+int az_dataset_read(az_dataset* d, int64_t first, int64_t count, az_sample* samples, float* W, float* X, float* A,
+                    float* P, float* V);
+/* learning_status(tr) (src/learning.jl:158-181): `losses` (:67-90) per batch of loss_computation_batch_size samples
+ * (partial last batch kept) with the engine's network in test mode, batches weighted by their total weight. */
+typedef struct { float L, Lp, Lv, Lreg, Linv, Hp, Hpnet; } az_learning_status_t;   /* Report.LearningStatus */
+int az_learning_status(az_engine* e, az_dataset* d, double l2_regularization, double nonvalidity_penalty,
+                       double rewards_renormalization, int64_t loss_computation_batch_size, az_learning_status_t* out);
+
 /* ---- profiling (bench.py roofline): HIP-event time per kernel class ---------------------- */
 #define AZ_PROF_NUM 8
 typedef enum {

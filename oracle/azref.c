@@ -1144,6 +1144,187 @@ void azr_push_trace(int game, const azr_move_rec* moves, int n, double gamma, do
   }
 }
 
+/* ===================== replay memory + learning status ==================== */
+/* TrainingSample (src/memory.jl:20-26); pi by FULL action index (0 where unavailable) */
+typedef struct {
+  uint64_t key[2];
+  double pi[AZR_AMAX];
+  double z, t;
+  int64_t n;
+} azr_sample;
+
+/* push_trace! (src/memory.jl:74-87): one sample per position, pushed from the LAST position to the first;
+ * pi = MCTS.policy of the recorded visit counts (src/mcts.jl:255-271).  Returns the number of samples. */
+int azr_samples_from_trace(int game, const azr_move_rec* moves, int n, double gamma, azr_sample* out) {
+  double wr = 0.;
+  int A = azr_num_actions_(game);
+  for (int i = n - 1; i >= 0; --i) {
+    wr = gamma * wr + (double)moves[i].reward;
+    azr_state st; azr_unpack_key(game, moves[i].key, &st);
+    azr_env g; azr_init_state(&g, game, &st);
+    azr_sample* e = &out[n - 1 - i];
+    memset(e, 0, sizeof *e);
+    e->key[0] = moves[i].key[0]; e->key[1] = moves[i].key[1];
+    double ntot = 0.;
+    for (int a = 0; a < A; ++a) if (g.amask[a]) ntot += (double)moves[i].N[a];
+    double s = 0.;
+    for (int a = 0; a < A; ++a) if (g.amask[a]) { e->pi[a] = (double)moves[i].N[a] / ntot; s += e->pi[a]; }
+    for (int a = 0; a < A; ++a) if (g.amask[a]) e->pi[a] = e->pi[a] / s;
+    e->z = azr_white_playing(&g) ? wr : -wr;
+    e->t = (double)(n - i);
+    e->n = 1;
+  }
+  return n;
+}
+
+/* action permutation of symmetry k: pi'[j] = pi[perm[j]] (memory.jl:122-132 with the (state, aperm) pairs of
+ * GI.symmetries: connect-four sigma = 7..1, tic-tac-toe the board permutation itself) */
+static void symmetry_perm(int game, int k, int* perm) {
+  if (game == AZR_C4) { for (int j = 0; j < 7; ++j) perm[j] = 6 - j; return; }
+  for (int p = 1; p <= 9; ++p) {
+    int x = (p - 1) % 3 + 1, y = (p - 1) / 3 + 1;
+    int nrot = k < 3 ? k + 1 : k - 3;
+    for (int r = 0; r < nrot; ++r) ttt_rot(&x, &y);
+    if (k >= 3) ttt_flip(&x, &y);
+    perm[p - 1] = (y - 1) * 3 + (x - 1);
+  }
+}
+/* augment_with_symmetries (memory.jl:134-138): [samples ; (apply_symmetry(s, sym) for s in samples for sym in symmetries)] */
+int64_t azr_augment_with_symmetries(int game, const azr_sample* in, int64_t n, azr_sample* out) {
+  int nsym = azr_num_symmetries(game), A = azr_num_actions_(game);
+  memcpy(out, in, sizeof(azr_sample) * (size_t)n);
+  int64_t m = n;
+  for (int64_t i = 0; i < n; ++i) for (int k = 0; k < nsym; ++k) {
+    azr_state st, sy; azr_unpack_key(game, in[i].key, &st);
+    azr_symmetry(game, &st, k, &sy);
+    azr_sample* e = &out[m++];
+    *e = in[i];
+    azr_pack_key(game, &sy, e->key);
+    int perm[AZR_AMAX]; symmetry_perm(game, k, perm);
+    for (int j = 0; j < A; ++j) e->pi[j] = in[i].pi[perm[j]];
+  }
+  return m;
+}
+
+/* merge_by_state + merge_samples (memory.jl:89-114): samples of one state are averaged in buffer order
+ * (mean over a generator = sequential sum / count), n summed.  The reference returns them in Dict order
+ * (unspecified); here: ascending (key[0], key[1]). */
+typedef struct { uint64_t k0, k1; int64_t idx; } merge_ent;
+static int cmp_merge(const void* a, const void* b) {
+  const merge_ent *x = a, *y = b;
+  if (x->k0 != y->k0) return x->k0 < y->k0 ? -1 : 1;
+  if (x->k1 != y->k1) return x->k1 < y->k1 ? -1 : 1;
+  return x->idx < y->idx ? -1 : x->idx > y->idx;
+}
+int64_t azr_merge_by_state(int game, const azr_sample* in, int64_t n, azr_sample* out) {
+  int A = azr_num_actions_(game);
+  merge_ent* ents = malloc(sizeof(merge_ent) * (size_t)(n > 0 ? n : 1));
+  for (int64_t i = 0; i < n; ++i) { ents[i].k0 = in[i].key[0]; ents[i].k1 = in[i].key[1]; ents[i].idx = i; }
+  qsort(ents, (size_t)n, sizeof(merge_ent), cmp_merge);
+  int64_t m = 0;
+  for (int64_t i = 0; i < n;) {
+    int64_t j = i;
+    azr_sample acc = in[ents[i].idx];
+    int64_t cnt = 1;
+    for (j = i + 1; j < n && ents[j].k0 == ents[i].k0 && ents[j].k1 == ents[i].k1; ++j) {
+      const azr_sample* e = &in[ents[j].idx];
+      for (int a = 0; a < A; ++a) acc.pi[a] += e->pi[a];
+      acc.z += e->z; acc.t += e->t; acc.n += e->n;
+      cnt++;
+    }
+    for (int a = 0; a < A; ++a) acc.pi[a] = acc.pi[a] / (double)cnt;
+    acc.z = acc.z / (double)cnt; acc.t = acc.t / (double)cnt;
+    out[m++] = acc;
+    i = j;
+  }
+  free(ents);
+  return m;
+}
+
+/* convert_samples (src/learning.jl:17-51): policy 0 CONSTANT_WEIGHT, 1 LOG_WEIGHT, 2 LINEAR_WEIGHT (params.jl:177) */
+void azr_convert_samples(int game, int policy, const azr_sample* es, int64_t n, float* W, float* X, float* Am, float* P, float* V) {
+  int w, h, c; azr_state_dims(game, &w, &h, &c);
+  int A = azr_num_actions_(game);
+  size_t xs = (size_t)w * h * c;
+  for (int64_t i = 0; i < n; ++i) {
+    const azr_sample* e = &es[i];
+    W[i] = policy == 0 ? 1.0f : policy == 1 ? (float)(az_log2((double)e->n) + 1.0) : (float)e->n;
+    azr_state st; azr_unpack_key(game, e->key, &st);
+    azr_env g; azr_init_state(&g, game, &st);
+    azr_vectorize_state(game, &st, X + xs * (size_t)i);
+    for (int a = 0; a < A; ++a) { Am[(size_t)i * A + a] = g.amask[a] ? 1.0f : 0.0f; P[(size_t)i * A + a] = (float)e->pi[a]; }
+    V[i] = (float)e->z;
+  }
+}
+
+/* Sum of squares of the TRAINABLE parameters (Flux.params: everything but the BatchNorm running statistics),
+ * the L2 term of `losses` (learning.jl:68-84 regularises ALL of Network.params) */
+static double net_reg_sum(const azr_net* n) {
+  size_t P = (size_t)n->W * n->H, F = n->F;
+  const float* b = n->blob;
+  double s = 0.;
+  #define TAKE(cnt) do { for (size_t _i = 0; _i < (size_t)(cnt); ++_i) s += (double)b[_i] * (double)b[_i]; b += (cnt); } while (0)
+  #define SKIP(cnt) do { b += (cnt); } while (0)
+  TAKE(9 * (size_t)n->C * F); TAKE(F); TAKE(2 * F); SKIP(2 * F);
+  for (int l = 0; l < 2 * n->nblocks; ++l) { TAKE(9 * F * F); TAKE(F); TAKE(2 * F); SKIP(2 * F); }
+  TAKE(F * n->npf); TAKE(n->npf); TAKE(2 * (size_t)n->npf); SKIP(2 * (size_t)n->npf); TAKE((size_t)n->A * P * n->npf); TAKE(n->A);
+  TAKE(F * n->nvf); TAKE(n->nvf); TAKE(2 * (size_t)n->nvf); SKIP(2 * (size_t)n->nvf); TAKE(F * P * n->nvf); TAKE(F); TAKE(F); TAKE(1);
+  #undef TAKE
+  #undef SKIP
+  return s;
+}
+
+/* Report.LearningStatus (src/report.jl) of a converted data set: `losses` (learning.jl:67-90) per batch of
+ * loss_computation_batch_size samples (partial last batch kept), Hpnet, then mean_learning_status weighted by
+ * the batches' total weights (learning.jl:148-181).  Float32 per-sample terms, Float64 accumulators. */
+typedef struct { float L, Lp, Lv, Lreg, Linv, Hp, Hpnet, Wmean; } azr_learning_status_t;
+void azr_learning_status(int W_, int H_, int C_, int A, int nblocks, int F, int npf, int nvf, const float* blob,
+                         const float* W, const float* X, const float* Am, const float* P, const float* V, int64_t n,
+                         double l2, double cinv, double renorm, int64_t batch, azr_learning_status_t* out) {
+  azr_net net = {W_, H_, C_, A, nblocks, F, npf, nvf, blob, 0};
+  net.pk = net_pack(&net);
+  size_t xs = (size_t)W_ * H_ * C_;
+  const float epsf = 1.1920929e-07f;
+  double sw = 0., shp = 0.;
+  for (int64_t i = 0; i < n; ++i) {
+    sw += (double)W[i];
+    for (int a = 0; a < A; ++a) { float p = P[i * A + a]; shp += (double)(p * az_logf(p + epsf) * W[i]); }
+  }
+  float Wmean = (float)(sw / (double)n);                    /* mean(W), learning.jl:110 */
+  float Hp = (float)(-shp / sw);                            /* entropy_wmean(P, W), :111 */
+  float Lreg = l2 == 0. ? 0.f : (float)((double)(float)l2 * net_reg_sum(&net));
+  if (batch > n) batch = n;
+  double aL = 0., aLp = 0., aLv = 0., aLreg = 0., aLinv = 0., aHn = 0., aw = 0.;
+  for (int64_t b0 = 0; b0 < n; b0 += batch) {
+    int64_t m = n - b0 < batch ? n - b0 : batch;
+    double bw = 0., kl = 0., mse = 0., inv = 0., hn = 0.;
+    for (int64_t i = b0; i < b0 + m; ++i) {
+      float ph[AZR_AMAX], vh, pinv;
+      forward_normalized_one(&net, X + xs * (size_t)i, Am + (size_t)i * A, ph, &vh, &pinv);
+      float w = W[i];
+      bw += (double)w;
+      for (int a = 0; a < A; ++a) {
+        kl += (double)(P[i * A + a] * az_logf(ph[a] + epsf) * w);
+        hn += (double)(ph[a] * az_logf(ph[a] + epsf) * w);
+      }
+      float d = vh / (float)renorm - V[i] / (float)renorm;
+      mse += (double)(d * d * w);
+      inv += (double)(pinv * w);
+    }
+    float Lp = (float)(-kl / bw) - Hp;
+    float Lv = (float)(mse / bw);
+    float Linv = cinv == 0. ? 0.f : (float)cinv * (float)(inv / bw);
+    float L = ((float)(bw / (double)m) / Wmean) * (Lp + Lv + Lreg + Linv);
+    float Hn = (float)(-hn / bw);
+    aL += (double)L * bw; aLp += (double)Lp * bw; aLv += (double)Lv * bw; aLreg += (double)Lreg * bw;
+    aLinv += (double)Linv * bw; aHn += (double)Hn * bw; aw += bw;
+  }
+  out->L = (float)(aL / aw); out->Lp = (float)(aLp / aw); out->Lv = (float)(aLv / aw); out->Lreg = (float)(aLreg / aw);
+  out->Linv = (float)(aLinv / aw); out->Hp = Hp; out->Hpnet = (float)(aHn / aw); out->Wmean = Wmean;
+  free(net.pk);
+}
+size_t azr_sizeof_sample(void) { return sizeof(azr_sample); }
+
 /* ================================ misc =================================== */
 int azr_numerics_selftest(void) { return az_numerics_selftest(); }
 float azr_expf(float x) { return az_expf(x); }

@@ -310,3 +310,70 @@ def symmetry(game, state_cells, curplayer, k):
     st.curplayer = curplayer
     lib().azr_symmetry(game, C.byref(st), k, C.byref(out))
     return list(out.cells), out.curplayer
+
+
+# ---------------------------------------------------------------- replay memory + learning status
+class Sample(C.Structure):
+    """TrainingSample (src/memory.jl:20-26), pi by full action index"""
+    _fields_ = [("key", C.c_uint64 * 2), ("pi", C.c_double * AMAX), ("z", C.c_double), ("t", C.c_double), ("n", C.c_int64)]
+
+
+class LearningStatus(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("L", "Lp", "Lv", "Lreg", "Linv", "Hp", "Hpnet", "Wmean")]
+
+
+def samples_from_trace(game, moves, first, n, gamma=1.0):
+    """push_trace! (memory.jl:74-87) of one game's move records -> list-like (Sample * n)"""
+    out = (Sample * max(n, 1))()
+    arr = (MoveRec * max(n, 1))(*[moves[first + k] for k in range(n)])
+    lib().azr_samples_from_trace(game, arr, n, C.c_double(gamma), out)
+    return out
+
+
+def _arr(samples):
+    n = len(samples)
+    a = (Sample * max(n, 1))()
+    for i, s in enumerate(samples):
+        C.memmove(C.byref(a[i]), C.byref(s), C.sizeof(Sample))
+    return a, n
+
+
+def augment_with_symmetries(game, samples):
+    a, n = _arr(samples)
+    nsym = lib().azr_num_symmetries(game)
+    out = (Sample * max(n * (1 + nsym), 1))()
+    lib().azr_augment_with_symmetries.restype = C.c_int64
+    m = lib().azr_augment_with_symmetries(game, a, C.c_int64(n), out)
+    return [out[i] for i in range(m)]
+
+
+def merge_by_state(game, samples):
+    a, n = _arr(samples)
+    out = (Sample * max(n, 1))()
+    lib().azr_merge_by_state.restype = C.c_int64
+    m = lib().azr_merge_by_state(game, a, C.c_int64(n), out)
+    return [out[i] for i in range(m)]
+
+
+def convert_samples(game, policy, samples):
+    a, n = _arr(samples)
+    w, h, c = DIMS[game]
+    nA = NUM_ACTIONS[game]
+    W = np.zeros(n, dtype=np.float32); X = np.zeros((n, c, h, w), dtype=np.float32)
+    A = np.zeros((n, nA), dtype=np.float32); P = np.zeros((n, nA), dtype=np.float32); V = np.zeros(n, dtype=np.float32)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    lib().azr_convert_samples(game, policy, a, C.c_int64(n), vp(W), vp(X), vp(A), vp(P), vp(V))
+    return W, X, A, P, V
+
+
+def learning_status(game, hp, blob, data, l2=1e-4, nonvalidity_penalty=1.0, rewards_renormalization=1.0, batch=1024):
+    """learning_status(tr) (learning.jl:158-181) for converted data (W, X, A, P, V); hp = (nblocks, F, npf, nvf)"""
+    W, X, A, P, V = [np.ascontiguousarray(x, dtype=np.float32) for x in data]
+    w, h, c = DIMS[game]
+    blob = np.ascontiguousarray(blob, dtype=np.float32)
+    out = LearningStatus()
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    lib().azr_learning_status(w, h, c, NUM_ACTIONS[game], hp[0], hp[1], hp[2], hp[3], vp(blob), vp(W), vp(X), vp(A), vp(P), vp(V),
+                              C.c_int64(len(W)), C.c_double(l2), C.c_double(nonvalidity_penalty), C.c_double(rewards_renormalization),
+                              C.c_int64(batch), C.byref(out))
+    return out

@@ -1,0 +1,157 @@
+"""Device replay memory + learning status (GPU) against the oracle: az_memory_* / az_dataset_* / az_learning_status
+(src/memory.jl:20-138, src/learning.jl:17-121,148-190).  Samples (Float64 averages included) and the Float32
+tensors must be identical; the loss figures agree to Float32 rounding of differently ordered Float64 sums."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import azref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _selfplay(game, ngames, workers, nsims, seed):
+    import azhip
+    with azhip.Engine(game=game, oracle=azhip.ORACLE_HASH, num_workers=workers, batch_size=workers, num_iters_per_turn=nsims,
+                      dirichlet_noise_eps=0.25, cpuct=1.0, reset_every=1, temperature=([0], [1.0]), seed=seed,
+                      max_moves_per_game=200 if game == 2 else 0) as e:
+        return e.selfplay_run(ngames)
+
+
+def _oracle_samples(game, games, moves, ng, gamma):
+    S = []
+    for i in range(ng):
+        g = games[i]
+        arr = (R.MoveRec * g.num_moves)()
+        for k in range(g.num_moves):
+            m = moves[g.first_move + k]
+            arr[k].key[0], arr[k].key[1] = m.key[0], m.key[1]
+            for a in range(10):
+                arr[k].N[a] = m.N[a]
+            arr[k].action, arr[k].reward = m.action, m.reward
+        ss = R.samples_from_trace(game, arr, 0, g.num_moves, gamma)
+        S += [ss[k] for k in range(g.num_moves)]
+    return S
+
+
+def _same_samples(dev, ref, nA):
+    assert len(dev) == len(ref)
+    for a, b in zip(dev, ref):
+        assert (a.key[0], a.key[1]) == (b.key[0], b.key[1])
+        assert list(a.pi[:nA]) == list(b.pi[:nA]) and (a.z, a.t, a.n) == (b.z, b.t, b.n)
+
+
+SPECS = {0: "ConnectFourSpec", 1: "TicTacToeSpec", 2: "MancalaSpec"}
+
+
+@pytest.mark.parametrize("game", [0, 1, 2])
+def test_push_and_experience_match_oracle(game):
+    import azhip
+    gspec = getattr(azhip, SPECS[game])()
+    nA = R.NUM_ACTIONS[game]
+    games, moves, ng, nm, _ = _selfplay(game, 10, 5, 24, 5)
+    ref = _oracle_samples(game, games, moves, ng, 0.95)
+    mem = azhip.MemoryBuffer(gspec, 10000)
+    mem.push_records(games, moves, ng, nm, 0.95)
+    assert len(mem) == nm == mem.cur_batch_size()
+    with mem.dataset() as d:
+        _same_samples(d.raw_samples(), ref, nA)
+    # symmetries + merge + weights: samples and tensors identical to the oracle's
+    use_sym = game != 2
+    aug = R.augment_with_symmetries(game, ref) if use_sym else ref
+    merged = R.merge_by_state(game, aug)
+    for policy in (0, 1, 2):
+        with mem.dataset(use_symmetries=use_sym, use_position_averaging=True, weighing_policy=policy) as d:
+            _same_samples(d.raw_samples(), merged, nA)
+            W, X, A, P, V = d.tensors()
+            Wr, Xr, Ar, Pr, Vr = R.convert_samples(game, policy, merged)
+            assert all(np.array_equal(x, y) for x, y in ((W, Wr), (X, Xr), (A, Ar), (P, Pr), (V, Vr)))
+            assert d.sum_n == len(aug) and abs(d.Wtot - float(Wr.astype(np.float64).sum())) < 1e-9 * max(1.0, d.Wtot)
+            assert abs(d.Wmean - Wr.astype(np.float64).mean()) < 1e-6
+    with mem.dataset(use_symmetries=use_sym) as d:                    # no merge: [samples ; images]
+        _same_samples(d.raw_samples(), aug, nA)
+    samples = mem.get_experience()
+    assert len(samples) == nm and samples[0].s == (ref[0].key[0], ref[0].key[1]) and samples[0].n == 1
+    mem.close()
+
+
+def test_circular_buffer_semantics():
+    """CircularBuffer(size) + cur_batch_size / last_batch / new_batch! / empty! (memory.jl:34-60)"""
+    import azhip
+    gspec = azhip.TicTacToeSpec()
+    g1 = _selfplay(1, 6, 3, 16, 1)
+    g2 = _selfplay(1, 7, 3, 16, 2)
+    r1 = _oracle_samples(1, g1[0], g1[1], g1[2], 1.0)
+    r2 = _oracle_samples(1, g2[0], g2[1], g2[2], 1.0)
+    cap = len(r1) + 5
+    mem = azhip.MemoryBuffer(gspec, cap)
+    mem.push_records(g1[0], g1[1], g1[2], g1[3], 1.0)
+    mem.new_batch()
+    assert (len(mem), mem.cur_batch_size()) == (len(r1), 0)
+    mem.push_records(g2[0], g2[1], g2[2], g2[3], 1.0)
+    allref = (r1 + r2)[-cap:]
+    assert len(mem) == cap and mem.cur_batch_size() == min(len(r2), cap)
+    with mem.dataset() as d:
+        _same_samples(d.raw_samples(), allref, 9)
+    with mem.dataset(last_batch=True) as d:
+        _same_samples(d.raw_samples(), r2[-cap:], 9)
+    mem.push_records(g1[0], g1[1], g1[2], g1[3], 1.0)                # more than one wrap in total
+    with mem.dataset() as d:
+        _same_samples(d.raw_samples(), (r1 + r2 + r1)[-cap:], 9)
+    tiny = azhip.MemoryBuffer(gspec, 3)                               # one push larger than the buffer
+    tiny.push_records(g2[0], g2[1], g2[2], g2[3], 1.0)
+    with tiny.dataset() as d:
+        _same_samples(d.raw_samples(), r2[-3:], 9)
+    mem.empty()
+    assert (len(mem), mem.cur_batch_size()) == (0, 0)
+    with mem.dataset() as d:
+        assert len(d) == 0
+    mem.close(); tiny.close()
+
+
+@pytest.mark.parametrize("game,F,policy,batch", [(0, 64, 1, 64), (1, 64, 2, 1 << 20), (2, 64, 0, 37), (0, 128, 1, 500)])
+def test_learning_status_matches_oracle(game, F, policy, batch):
+    """Trainer + learning_status (learning.jl:98-121,158-181) on the device vs the oracle's Float32 restatement"""
+    import azhip
+    gspec = getattr(azhip, SPECS[game])()
+    hp = azhip.ResNetHP(num_blocks=2, num_filters=F, num_policy_head_filters=32, num_value_head_filters=32)
+    nn = azhip.ResNet(gspec, hp, seed=21)
+    games, moves, ng, nm, _ = _selfplay(game, 24, 8, 24, 9)
+    mem = azhip.MemoryBuffer(gspec, 100000)
+    mem.push_records(games, moves, ng, nm, 1.0)
+    use_sym = game != 2
+    lp = azhip.LearningParams(samples_weighing_policy=policy, l2_regularization=1e-4, loss_computation_batch_size=batch,
+                              rewards_renormalization=1.0, nonvalidity_penalty=1.0)
+    with azhip.Trainer(gspec, nn, mem, lp, use_symmetries=use_sym) as tr:
+        st = tr.learning_status()
+        rep = tr.samples_report()
+        data = tr.data.tensors()
+    ref = R.learning_status(game, (2, F, 32, 32), nn.params(), data, l2=1e-4, nonvalidity_penalty=1.0,
+                            rewards_renormalization=1.0, batch=batch)
+    got = np.array([st.loss.L, st.loss.Lp, st.loss.Lv, st.loss.Lreg, st.loss.Linv, st.Hp, st.Hpnet])
+    want = np.array([ref.L, ref.Lp, ref.Lv, ref.Lreg, ref.Linv, ref.Hp, ref.Hpnet])
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-7), (got, want)
+    assert rep.num_samples == nm * (1 + (R.lib().azr_num_symmetries(game) if use_sym else 0)) and rep.num_boards == len(data[0])
+    mem.close()
+
+
+def test_memory_errors():
+    import azhip
+    from azhip import _lib as L
+    gspec = azhip.TicTacToeSpec()
+    with pytest.raises(L.AzError, match="capacity"):
+        azhip.MemoryBuffer(gspec, 0)
+    mem = azhip.MemoryBuffer(gspec, 10)
+    with pytest.raises(L.AzError, match="policy"):
+        mem.dataset(weighing_policy=7)
+    hp = azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    lp = azhip.LearningParams(samples_weighing_policy=0, l2_regularization=0.0, loss_computation_batch_size=8)
+    with azhip.Trainer(gspec, azhip.ResNet(gspec, hp, seed=1), mem, lp) as tr:
+        with pytest.raises(L.AzError, match="empty"):
+            tr.learning_status()
+    games, moves, ng, nm, _ = _selfplay(1, 2, 2, 8, 1)
+    games[0].first_move = 10 ** 6
+    with pytest.raises(L.AzError, match="outside"):
+        mem.push_records(games, moves, ng, nm, 1.0)
+    mem.close()
