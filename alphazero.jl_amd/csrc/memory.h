@@ -113,22 +113,35 @@ __global__ void k_mem_heads(const az_sample* __restrict__ s, const unsigned int*
   }
   head[i] = h ? 1 : 0;
 }
-// merge_samples (memory.jl:89-96): the thread at a segment head accumulates its segment in buffer order
-__global__ void k_mem_merge(const az_sample* __restrict__ s, const unsigned int* __restrict__ order, const int* __restrict__ head,
-                            const int* __restrict__ segid, long long n, int A, az_sample* __restrict__ out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !head[i]) return;
-  az_sample acc = s[order[i]];
-  long long cnt = 1;
-  for (long long j = i + 1; j < n && !head[j]; ++j) {
-    const az_sample& e = s[order[j]];
-    for (int a = 0; a < A; ++a) acc.pi[a] += e.pi[a];
-    acc.z += e.z; acc.t += e.t; acc.n += e.n;
-    ++cnt;
+// merge_samples (memory.jl:89-96): 16 lanes per segment head, lane f owns the f-th 8-byte word of the sample
+// (key, key, pi[0..8], z, t, n) and accumulates it over the segment in buffer order -- every field's sum is the
+// reference's sequential one, the loads of a record coalesce over the lanes and pipeline over the (unrolled) loop.
+__global__ void __launch_bounds__(256) k_mem_merge(const az_sample* __restrict__ s, const unsigned int* __restrict__ order,
+                                                   const int* __restrict__ head, const int* __restrict__ segid, long long n,
+                                                   az_sample* __restrict__ out) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = gid >> 4;
+  const int f = (int)(gid & 15);
+  if (i >= n || !head[i] || f >= 14) return;
+  const int sg = segid[i];
+  long long lo = i + 1, hi = n;                                    // first position of the next segment
+  while (lo < hi) { const long long mid = (lo + hi) >> 1; if (segid[mid] > sg) hi = mid; else lo = mid + 1; }
+  const long long end = lo, cnt = end - i;
+  const unsigned long long* base = (const unsigned long long*)s;
+  unsigned long long* o = (unsigned long long*)(out + (sg - 1));
+  const unsigned long long w0 = base[(size_t)order[i] * 14 + f];
+  if (f < 2) { o[f] = w0; return; }
+  if (f == 13) {
+    long long acc = (long long)w0;
+#pragma unroll 8
+    for (long long j = i + 1; j < end; ++j) acc += (long long)base[(size_t)order[j] * 14 + 13];
+    o[13] = (unsigned long long)acc;
+    return;
   }
-  for (int a = 0; a < A; ++a) acc.pi[a] = acc.pi[a] / (double)cnt;
-  acc.z = acc.z / (double)cnt; acc.t = acc.t / (double)cnt;
-  out[segid[i] - 1] = acc;
+  double acc = az_u2d(w0);
+#pragma unroll 8
+  for (long long j = i + 1; j < end; ++j) acc += az_u2d(base[(size_t)order[j] * 14 + f]);
+  o[f] = az_d2u(acc / (double)cnt);
 }
 // convert_samples (learning.jl:17-51) + per-sample entropy term of Hp (learning.jl:65,111)
 template <class Gm>
@@ -182,6 +195,32 @@ __global__ void k_loss_terms(const float* __restrict__ W, const float* __restric
 __global__ void k_f32_to_f64(const float* __restrict__ in, long long n, double* __restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (double)in[i];
+}
+
+// Five sums per loss batch in one launch: block b reduces samples [b*batch, min(n, (b+1)*batch)) of the five term
+// arrays with a fixed-shape tree (thread-strided partial sums, then shared-memory halving), so the result does not
+// depend on scheduling.  out[b][0..5) = sum w, kl, hn, mse, inv.
+__global__ void __launch_bounds__(256) k_batch_sums(const double* __restrict__ tw, const double* __restrict__ tkl, const double* __restrict__ thn,
+                                                    const double* __restrict__ tmse, const double* __restrict__ tinv, long long n, long long batch,
+                                                    double* __restrict__ out) {
+  __shared__ double sh[5][256];
+  const long long b0 = (long long)blockIdx.x * batch;
+  const long long m = (n - b0) < batch ? (n - b0) : batch;
+  const double* src[5] = {tw, tkl, thn, tmse, tinv};
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (long long i = threadIdx.x; i < m; i += 256)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] += src[k][b0 + i];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x < 5) out[(size_t)blockIdx.x * 5 + threadIdx.x] = sh[threadIdx.x][0];
 }
 
 struct DevReducer {                     // hipcub::DeviceReduce::Sum over double ranges (deterministic for a given size)
@@ -319,7 +358,8 @@ static int dataset_build(az_memory* m, az_dataset* d, int which, bool use_sym, b
       HIPCHK(hipStreamSynchronize(st));
       n2 = nseg;
       AZCHK(mem_alloc(&d->allocs, &d->d_samples, (size_t)n2));
-      hipLaunchKernelGGL(k_mem_merge, dim3(gb), dim3(256), 0, st, s1, i2, head, seg, (long long)n1, Gm::A, d->d_samples);
+      static_assert(sizeof(az_sample) == 14 * 8, "k_mem_merge walks az_sample as 14 words");
+      hipLaunchKernelGGL(k_mem_merge, dim3((unsigned)((n1 * 16 + 255) / 256)), dim3(256), 0, st, s1, i2, head, seg, (long long)n1, d->d_samples);
     } else {
       AZCHK(mem_alloc(&d->allocs, &d->d_samples, (size_t)n2));
       if (n2) HIPCHK(hipMemcpyAsync(d->d_samples, s1, sizeof(az_sample) * (size_t)n2, hipMemcpyDeviceToDevice, st));
@@ -429,24 +469,32 @@ static int learning_status_run(az_engine* e, az_dataset* d, double l2, double ci
     AZCHK(mem_alloc(&tmp, &tw, (size_t)n));
     HIPCHK(hipStreamSynchronize(d->stream));
     // Network.forward_normalized (network.jl:264-271) in test mode on the device-resident states, nn_cap at a time
-    for (int64_t off = 0; off < n; off += e->nn_cap) {
-      const int m = (int)std::min<int64_t>(e->nn_cap, n - off);
-      HIPCHK(hipMemcpyAsync(e->d_ntmp, &m, sizeof(int), hipMemcpyHostToDevice, st));
-      AZCHK((launch_net<Gm, false>(e, st, e->d_hfeat, d->d_envs + off, e->d_iota, e->d_ntmp, m, nullptr, nullptr, Ph + (size_t)off * Gm::A, Vh + off, Pinv + off, Gm::A)));
-      HIPCHK(hipStreamSynchronize(st));                            // d_ntmp is reused by the next chunk
+    const int64_t nchunks = (n + e->nn_cap - 1) / e->nn_cap;
+    std::vector<int> counts((size_t)nchunks);
+    for (int64_t c = 0; c < nchunks; ++c) counts[c] = (int)std::min<int64_t>(e->nn_cap, n - c * e->nn_cap);
+    int* d_counts;
+    AZCHK(mem_alloc(&tmp, &d_counts, (size_t)nchunks));
+    HIPCHK(hipMemcpyAsync(d_counts, counts.data(), sizeof(int) * (size_t)nchunks, hipMemcpyHostToDevice, st));
+    for (int64_t c = 0; c < nchunks; ++c) {
+      const int64_t off = c * e->nn_cap;
+      AZCHK((launch_net<Gm, false>(e, st, e->d_hfeat, d->d_envs + off, e->d_iota, d_counts + c, counts[c], nullptr, nullptr, Ph + (size_t)off * Gm::A, Vh + off, Pinv + off, Gm::A)));
     }
+    HIPCHK(hipStreamSynchronize(st));                              // `counts` must outlive the copy
     hipLaunchKernelGGL(k_loss_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d->d_W, d->d_P, d->d_V, Ph, Vh, Pinv, (long long)n, Gm::A, (float)renorm, tkl, thn, tmse, tinv);
     hipLaunchKernelGGL(k_f32_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d->d_W, (long long)n, tw);
-    DevReducer red;
     if (batch > n) batch = n;
-    AZCHK(red.init(batch, st));
+    const int64_t nb = (n + batch - 1) / batch;                    // DataLoader(partial = true), learning.jl:171-176
+    double* d_sums;
+    AZCHK(mem_alloc(&tmp, &d_sums, (size_t)nb * 5));
+    hipLaunchKernelGGL(k_batch_sums, dim3((unsigned)nb), dim3(256), 0, st, tw, tkl, thn, tmse, tinv, (long long)n, (long long)batch, d_sums);
+    std::vector<double> sums((size_t)nb * 5);
+    HIPCHK(hipMemcpyAsync(sums.data(), d_sums, sizeof(double) * sums.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     const float Lreg = l2 == 0.0 ? 0.f : (float)((double)(float)l2 * reg_sum_trainable(e));
     double aL = 0., aLp = 0., aLv = 0., aLreg = 0., aLinv = 0., aHn = 0., aw = 0.;
-    for (int64_t b0 = 0; b0 < n; b0 += batch) {                    // DataLoader(partial = true), learning.jl:171-176
-      const int64_t m = std::min<int64_t>(batch, n - b0);
-      double bw, kl, hn, mse, inv;
-      AZCHK(red.sum(tw + b0, m, st, &bw)); AZCHK(red.sum(tkl + b0, m, st, &kl)); AZCHK(red.sum(thn + b0, m, st, &hn));
-      AZCHK(red.sum(tmse + b0, m, st, &mse)); AZCHK(red.sum(tinv + b0, m, st, &inv));
+    for (int64_t b = 0; b < nb; ++b) {
+      const int64_t m = std::min<int64_t>(batch, n - b * batch);
+      const double bw = sums[b * 5], kl = sums[b * 5 + 1], hn = sums[b * 5 + 2], mse = sums[b * 5 + 3], inv = sums[b * 5 + 4];
       const float Lp = (float)(-kl / bw) - d->Hp;
       const float Lv = (float)(mse / bw);
       const float Linv = cinv == 0.0 ? 0.f : (float)cinv * (float)(inv / bw);
