@@ -113,12 +113,14 @@ __global__ void k_mem_heads(const az_sample* __restrict__ s, const unsigned int*
   }
   head[i] = h ? 1 : 0;
 }
+static constexpr long long MERGE_LONG = 256;
 // merge_samples (memory.jl:89-96): 16 lanes per segment head, lane f owns the f-th 8-byte word of the sample
 // (key, key, pi[0..8], z, t, n) and accumulates it over the segment in buffer order -- every field's sum is the
 // reference's sequential one, the loads of a record coalesce over the lanes and pipeline over the (unrolled) loop.
 __global__ void __launch_bounds__(256) k_mem_merge(const az_sample* __restrict__ s, const unsigned int* __restrict__ order,
                                                    const int* __restrict__ head, const int* __restrict__ segid, long long n,
-                                                   az_sample* __restrict__ out) {
+                                                   az_sample* __restrict__ out, int* __restrict__ long_count,
+                                                   long long* __restrict__ long_list) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long i = gid >> 4;
   const int f = (int)(gid & 15);
@@ -127,6 +129,10 @@ __global__ void __launch_bounds__(256) k_mem_merge(const az_sample* __restrict__
   long long lo = i + 1, hi = n;                                    // first position of the next segment
   while (lo < hi) { const long long mid = (lo + hi) >> 1; if (segid[mid] > sg) hi = mid; else lo = mid + 1; }
   const long long end = lo, cnt = end - i;
+  if (cnt >= MERGE_LONG) {                                         // k_mem_merge_long takes the big segments
+    if (f == 0) { const int k = atomicAdd(long_count, 1); long_list[2 * k] = i; long_list[2 * k + 1] = end; }
+    return;
+  }
   const unsigned long long* base = (const unsigned long long*)s;
   unsigned long long* o = (unsigned long long*)(out + (sg - 1));
   const unsigned long long w0 = base[(size_t)order[i] * 14 + f];
@@ -142,6 +148,37 @@ __global__ void __launch_bounds__(256) k_mem_merge(const az_sample* __restrict__
 #pragma unroll 8
   for (long long j = i + 1; j < end; ++j) acc += az_u2d(base[(size_t)order[j] * 14 + f]);
   o[f] = az_d2u(acc / (double)cnt);
+}
+// Segments of MERGE_LONG or more samples (the opening positions: one sample per game): a workgroup of 14
+// wavefronts per segment, wavefront f owns word f.  The 64 lanes load 64 consecutive samples at once (all the
+// memory parallelism the serial walk lacks); the additions stay strictly in buffer order -- every lane adds the
+// 64 loaded values one after the other, broadcast with __shfl.
+__global__ void __launch_bounds__(14 * 64) k_mem_merge_long(const az_sample* __restrict__ s, const unsigned int* __restrict__ order,
+                                                            const int* __restrict__ segid, const int* __restrict__ long_count,
+                                                            const long long* __restrict__ long_list, az_sample* __restrict__ out) {
+  if ((int)blockIdx.x >= *long_count) return;
+  const long long i = long_list[2 * blockIdx.x], end = long_list[2 * blockIdx.x + 1], cnt = end - i;
+  const int f = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned long long* base = (const unsigned long long*)s;
+  unsigned long long* o = (unsigned long long*)(out + (segid[i] - 1));
+  if (f < 2) { if (lane == 0) o[f] = base[(size_t)order[i] * 14 + f]; return; }
+  double acc = 0.0;
+  long long iacc = 0;
+  for (long long j0 = i; j0 < end; j0 += 64) {
+    const long long j = j0 + lane;
+    const unsigned long long w = j < end ? base[(size_t)order[j] * 14 + f] : 0ULL;
+    const int m = (int)((end - j0) < 64 ? (end - j0) : 64);
+    if (f == 13) {
+      for (int k = 0; k < m; ++k) iacc += (long long)__shfl(w, k);
+    } else {
+      const double v = az_u2d(w);
+      for (int k = 0; k < m; ++k) {
+        const double x = __shfl(v, k);
+        acc = (j0 == i && k == 0) ? x : acc + x;                   // the sum STARTS with the first sample (keeps -0.0)
+      }
+    }
+  }
+  if (lane == 0) o[f] = f == 13 ? (unsigned long long)iacc : az_d2u(acc / (double)cnt);
 }
 // convert_samples (learning.jl:17-51) + per-sample entropy term of Hp (learning.jl:65,111)
 template <class Gm>
@@ -359,7 +396,12 @@ static int dataset_build(az_memory* m, az_dataset* d, int which, bool use_sym, b
       n2 = nseg;
       AZCHK(mem_alloc(&d->allocs, &d->d_samples, (size_t)n2));
       static_assert(sizeof(az_sample) == 14 * 8, "k_mem_merge walks az_sample as 14 words");
-      hipLaunchKernelGGL(k_mem_merge, dim3((unsigned)((n1 * 16 + 255) / 256)), dim3(256), 0, st, s1, i2, head, seg, (long long)n1, d->d_samples);
+      int* long_count; long long* long_list;
+      const long long max_long = n1 / MERGE_LONG + 1;
+      AZCHK(mem_alloc(&tmp, &long_count, 1)); AZCHK(mem_alloc(&tmp, &long_list, (size_t)(2 * max_long)));
+      HIPCHK(hipMemsetAsync(long_count, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_mem_merge, dim3((unsigned)((n1 * 16 + 255) / 256)), dim3(256), 0, st, s1, i2, head, seg, (long long)n1, d->d_samples, long_count, long_list);
+      hipLaunchKernelGGL(k_mem_merge_long, dim3((unsigned)max_long), dim3(14 * 64), 0, st, s1, i2, seg, long_count, long_list, d->d_samples);
     } else {
       AZCHK(mem_alloc(&d->allocs, &d->d_samples, (size_t)n2));
       if (n2) HIPCHK(hipMemcpyAsync(d->d_samples, s1, sizeof(az_sample) * (size_t)n2, hipMemcpyDeviceToDevice, st));

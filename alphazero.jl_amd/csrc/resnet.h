@@ -426,19 +426,34 @@ k_heads_mfma(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restric
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   const int q4 = nf / 4;
-  if (q4 == 8) {                                 // 32 head filters: fully unrolled position step
-#pragma unroll 2
-    for (int q = 0; q < P; ++q) {
+  if (q4 == 8) {
+    // 32 head filters: one board position per step (8 float4 of A, 8 float2 of B, 16 MFMAs = 1024 cycles).  The A rows
+    // come from HBM / L2 (the tower wrote them just before), so a step's loads are issued DEPTH steps ahead of its
+    // MFMAs: AZ_HEADS_DEPTH register stages (2: measured equal to 3 with fewer VGPRs) rotate through the fully unrolled position loop (the wave was latency-bound at
+    // one memory round trip per position: 73 us per workgroup against 18 us of MFMA work).
+#ifndef AZ_HEADS_DEPTH
+#define AZ_HEADS_DEPTH 2
+#endif
+    constexpr int DEPTH = AZ_HEADS_DEPTH;
+    float4 a4[DEPTH][8];
+    float2 b2[DEPTH][8];
+    auto load_step = [&](int q, int st) {
       const float* hq = hf + q * HF;
-      float4 a4[8];
-      float2 b2[8];
 #pragma unroll
-      for (int f4 = 0; f4 < 8; ++f4) { a4[f4] = *(const float4*)(hq + f4 * 4); b2[f4] = wp[(size_t)(q * 8 + f4) * 64]; }
+      for (int f4 = 0; f4 < 8; ++f4) { a4[st][f4] = *(const float4*)(hq + f4 * 4); b2[st][f4] = wp[(size_t)(q * 8 + f4) * 64]; }
+    };
+#pragma unroll
+    for (int q = 0; q < DEPTH - 1; ++q) if (q < P) load_step(q, q);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      if (q + DEPTH - 1 < P) load_step(q + DEPTH - 1, (q + DEPTH - 1) % DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int f4 = 0; f4 < 8; ++f4) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4[f4].y : a4[f4].x, b2[f4].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4[f4].w : a4[f4].z, b2[f4].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4[q % DEPTH][f4].y : a4[q % DEPTH][f4].x, b2[q % DEPTH][f4].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4[q % DEPTH][f4].w : a4[q % DEPTH][f4].z, b2[q % DEPTH][f4].y, acc, 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
     for (int q = 0; q < P; ++q) {

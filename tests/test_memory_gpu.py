@@ -76,6 +76,22 @@ def test_push_and_experience_match_oracle(game):
     mem.close()
 
 
+def test_long_segments_merge_in_buffer_order():
+    """600 short games: the opening positions (x8 symmetric images that coincide) form segments of thousands of
+    samples, which take the wavefront-parallel merge kernel; the averages must still be the sequential ones."""
+    import azhip
+    gspec = azhip.TicTacToeSpec()
+    games, moves, ng, nm, _ = _selfplay(1, 600, 64, 8, 3)
+    ref = R.merge_by_state(1, R.augment_with_symmetries(1, _oracle_samples(1, games, moves, ng, 0.9)))
+    mem = azhip.MemoryBuffer(gspec, 100000)
+    mem.push_records(games, moves, ng, nm, 0.9)
+    with mem.dataset(use_symmetries=True, use_position_averaging=True, weighing_policy=azhip.LOG_WEIGHT) as d:
+        _same_samples(d.raw_samples(), ref, 9)
+        assert max(s.n for s in ref) >= 4800 and sum(1 for s in ref if s.n >= 256) >= 3
+        assert np.array_equal(d.tensors()[0], R.convert_samples(1, 1, ref)[0])
+    mem.close()
+
+
 def test_circular_buffer_semantics():
     """CircularBuffer(size) + cur_batch_size / last_batch / new_batch! / empty! (memory.jl:34-60)"""
     import azhip
