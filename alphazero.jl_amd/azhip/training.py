@@ -65,3 +65,69 @@ def self_play_step(gspec, bestnn, params: SelfPlayParams, memory, game_played=No
                           mcts_memory_footprint=int(max(x["mem"] for x in results)),
                           memory_size=len(memory),
                           memory_num_distinct_boards=len({s.s for s in memory}))
+
+
+def repack_by_game_id(g, m):
+    """gathered (game, move) record arrays -> the same records in game-id order with contiguous move ranges, so
+    that every rank's replay memory receives the samples in the same order whatever the number of ranks"""
+    order = np.argsort(g["game_id"], kind="stable")
+    mm = np.concatenate([m[g["first_move"][i]:g["first_move"][i] + g["num_moves"][i]] for i in order]) if len(order) else m[:0]
+    g = g[order].copy()
+    if len(g):
+        g["first_move"] = np.concatenate([[0], np.cumsum(g["num_moves"])[:-1]])
+    return g, mm
+
+
+def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_played=None, seed=1, group=None):
+    """self_play_step!(env, handler) with the replay memory on the device: the packed records of the phase (gathered
+    over the ranks when torch.distributed is initialised) go straight into a `MemoryBuffer` (az_memory_push does
+    push_trace! for every game on the GPU) -- no per-sample host objects.  Returns the Report.SelfPlay numbers."""
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    from . import _lib as L
+    from .simulations import gather_records, records_to_numpy, run_local, shard_games
+
+    def make_oracle():
+        return network_copy(bestnn, on_gpu=params.sim.use_gpu, test_mode=True)
+    simulator = Simulator(lambda oracle: MctsPlayer(gspec, oracle, params.mcts), make_oracle, self_play_measurements)
+    t0 = time.perf_counter()
+    sim = params.sim
+    first, device = 0, 0
+    if dist.is_available() and dist.is_initialized():
+        import torch
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        first, count = shard_games(sim.num_games, world, rank)
+        sim = SimParams(**{**sim.__dict__, "num_games": count})
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    games, moves, ng, nm, stats, _ = run_local(simulator, gspec, sim, first, game_played, device, seed)
+    if dist.is_available() and dist.is_initialized():
+        g, mm = repack_by_game_id(*gather_records(*records_to_numpy(games, moves, ng, nm), group))
+        ng, nm = len(g), len(mm)
+        games = (L.GameRec * max(ng, 1)).from_buffer_copy(g.tobytes() or bytes(C.sizeof(L.GameRec)))
+        moves = (L.MoveRec * max(nm, 1)).from_buffer_copy(mm.tobytes() or bytes(C.sizeof(L.MoveRec)))
+    elapsed = time.perf_counter() - t0
+    memory.new_batch()
+    memory.push_records(games, moves, ng, nm, params.mcts.gamma)
+    sims = sum(games[i].total_simulations for i in range(ng))      # cumulative per worker; informative only
+    depth = float(np.mean([games[i].total_nodes_traversed / max(games[i].total_simulations, 1) for i in range(ng)])) if ng else 0.0
+    with memory.dataset(use_position_averaging=True) as d:
+        distinct = len(d)
+    del sims
+    return SelfPlayReport(samples_gen_speed=nm / elapsed, average_exploration_depth=depth,
+                          mcts_memory_footprint=int(max((games[i].nodes for i in range(ng)), default=0)),
+                          memory_size=len(memory), memory_num_distinct_boards=distinct)
+
+
+def evaluation_half_of_learning_step(gspec, curnn, bestnn, memory, learning_params, arena_params, use_symmetries=True,
+                                     handler=None, seed=1):
+    """What learning_step! (training.jl:193-259) does around the optimiser: Trainer over the (augmented, merged)
+    experience, learning_status, then the checkpoint evaluation compare_networks(curnn, bestnn) and the replacement
+    decision (avgr >= update_threshold).  Returns (LearningStatus, Evaluation, replace::bool)."""
+    from .arena import compare_networks
+    from .learning import Trainer
+    with Trainer(gspec, curnn, memory, learning_params, use_symmetries=use_symmetries) as tr:
+        status = tr.learning_status()
+    ev = compare_networks(gspec, curnn, bestnn, arena_params, handler, seed=seed)
+    return status, ev, ev.avgr >= arena_params.update_threshold

@@ -82,3 +82,24 @@ def test_trace_and_samples_from_records():
     for r in packed[:50]:
         cands = by_key[(int(r["key"][0]), int(r["key"][1]))]
         assert any(c.z == r["z"] and c.t == r["t"] for c in cands)
+
+
+def test_repack_by_game_id_orders_games_and_keeps_their_moves():
+    """the distributed self-play step feeds the replay memory in game-id order whatever the rank layout"""
+    from azhip.simulations import GAME_DTYPE, MOVE_DTYPE
+    from azhip.training import repack_by_game_id
+    # two "ranks": rank 0 played games 3,0, rank 1 played games 2,1 (finish order), gathered back to back
+    lens = {3: 2, 0: 3, 2: 1, 1: 4}
+    g = np.zeros(4, dtype=GAME_DTYPE)
+    m = np.zeros(sum(lens.values()), dtype=MOVE_DTYPE)
+    off = 0
+    for i, gid in enumerate((3, 0, 2, 1)):
+        g[i]["game_id"], g[i]["num_moves"], g[i]["first_move"] = gid, lens[gid], off
+        for k in range(lens[gid]):
+            m[off + k]["action"] = 10 * gid + k
+        off += lens[gid]
+    G, M = repack_by_game_id(g, m)
+    assert list(G["game_id"]) == [0, 1, 2, 3] and list(G["first_move"]) == [0, 3, 7, 8] and list(G["num_moves"]) == [3, 4, 1, 2]
+    assert list(M["action"]) == [0, 1, 2, 10, 11, 12, 13, 20, 30, 31]
+    G0, M0 = repack_by_game_id(g[:0], m[:0])
+    assert len(G0) == 0 and len(M0) == 0

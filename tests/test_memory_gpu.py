@@ -171,3 +171,17 @@ def test_memory_errors():
     with pytest.raises(L.AzError, match="outside"):
         mem.push_records(games, moves, ng, nm, 1.0)
     mem.close()
+
+
+def test_iteration_example_runs_end_to_end():
+    """examples/iteration.py: self-play -> device memory -> learning status -> arena, tiny sizes; deterministic"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("iteration", os.path.join(os.path.dirname(__file__), "..", "examples", "iteration.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r1 = mod.main(games=16, workers=8, sims=12, quiet=True)
+    r2 = mod.main(games=16, workers=8, sims=12, quiet=True)
+    assert r1[0].memory_size == r2[0].memory_size > 16 and r1[0].memory_num_distinct_boards <= r1[0].memory_size
+    assert r1[1] == r2[1] and np.array_equal(r1[2].rewards, r2[2].rewards) and r1[3] == r2[3]
+    assert np.isfinite([r1[1].loss.L, r1[1].Hpnet]).all() and len(r1[2].rewards) == 4
