@@ -107,6 +107,7 @@ struct az_engine {
   // self-play state
   bool running;
   int total_games, next_game, first_game_id, games_done, wave_in_move, active_slots;
+  int group_active[AZ_MAX_GROUPS];   // active slots per slot group (host count; bounds the leaves of a network launch)
   std::vector<az_game_rec> q_games;
   std::vector<az_move_rec> q_moves;
   az_selfplay_stats stats;
@@ -768,7 +769,7 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
 // ------------------------------------------------------------------------------- search waves
 // One wave = one run_simulation! for every active slot: select -> gather misses -> oracle ->
 // expand + backup.  Nothing is read back by the host.
-template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split) {
+template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split, int nmax) {
   constexpr int L = Gm::APAD, TB = TOWER_ROWS / Gm::P;
   const DView& v = e->gv[g];
   hipStream_t st = e->gs[g], sn = e->gt[g];
@@ -776,27 +777,31 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
   constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
   constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
-  const int tw = pick_tower<Gm, F>(e, G);
+  // N = upper bound of this wave's leaves: the group's active slots (a draining phase or a partial explore! launches
+  // -- and picks its tower kernel -- for what is left, not for the group's capacity)
+  const int N = std::max(1, std::min(G, nmax));
+  const int tw = pick_tower<Gm, F>(e, N);
   if (tw == 3)
-    LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower16<Gm, F, false, 3>), (G + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
+    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, 3>), (N + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);
   else if (tw == 16)
-    LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower16<Gm, F, false>), (G + TB16 - 1) / TB16, THR16, LDS16, e->net16, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
+    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false>), (N + TB16 - 1) / TB16, THR16, LDS16, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);
   else
-    LAUNCH_ON(e, sn, AZ_K_TOWER, G, (k_tower<Gm, F, false>), (G + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g]);
+    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower<Gm, F, false>), (N + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);
   if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
   if (e->net.hd_ok)
-    LAUNCH_ON(e, st, AZ_K_HEADS, G, (k_heads_mfma<Gm, F>), (G + 31) / 32, 64 * (F / 32 + 1), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
+    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads_mfma<Gm, F>), (N + 31) / 32, 64 * (F / 32 + 1), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
   else
-    LAUNCH_ON(e, st, AZ_K_HEADS, G, (k_heads<Gm, F>), (G + 3) / 4, 4 * (F + 16), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, G, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
+    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads<Gm, F>), (N + 3) / 4, 4 * (F + 16), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
   return AZ_OK;
 }
-template <class Gm> static int wave_net(az_engine* e, int g, bool split) {
-  return e->cfg.num_filters == 128 ? wave_net_f<Gm, 128>(e, g, split) : wave_net_f<Gm, 64>(e, g, split);
+template <class Gm> static int wave_net(az_engine* e, int g, bool split, int nmax) {
+  return e->cfg.num_filters == 128 ? wave_net_f<Gm, 128>(e, g, split, nmax) : wave_net_f<Gm, 64>(e, g, split, nmax);
 }
 // sim_idx: index of this simulation within the current explore! (keys the rollout oracle's RNG stream)
 template <class Gm> static int wave(az_engine* e, int ngroups_active, uint32_t sim_idx) {
   constexpr int L = Gm::APAD;
   for (int g = 0; g < ngroups_active; ++g) {
+    if (e->group_active[g] == 0) continue;                         // nothing left to search in this group
     const DView& v = e->gv[g];
     hipStream_t st = e->gs[g], sn = e->gt[g];
     const bool split = st != sn;
@@ -806,7 +811,7 @@ template <class Gm> static int wave(az_engine* e, int ngroups_active, uint32_t s
     LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact_count, (G + 1023) / 1024, 1024, 0, v);
     LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact_assign, (G + 1023) / 1024, 1024, 0, v);
     if (e->cfg.oracle == AZ_ORACLE_RESNET) {
-      AZCHK((wave_net<Gm>(e, g, split)));
+      AZCHK((wave_net<Gm>(e, g, split, e->group_active[g])));
     } else {
       LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p, sim_idx);
     }
@@ -859,6 +864,8 @@ static int explore_begin(az_engine* e, const std::vector<int>& slots, const std:
   hipLaunchKernelGGL((k_arm_noise<Gm>), dim3((n + 255) / 256), dim3(256), 0, e->stream, e->v, e->p, e->d_slots, e->d_moves, eta ? e->d_eta : nullptr, n);
   HIPCHK(hipStreamSynchronize(e->stream));
   *nga = std::min(e->ngroups, maxslot / e->gv[0].G + 1);
+  for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->group_active[g] = 0;
+  for (int sl : slots) e->group_active[sl / e->gv[0].G]++;
   return AZ_OK;
 }
 static int explore_end(az_engine* e, int nga) {
@@ -987,6 +994,8 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   for (int i = 0; i < n0; ++i) { slots[i] = i; gids[i] = (uint32_t)(first_game_id + e->next_game++); }
   DISPATCH_GAME(e->cfg.game, AZCHK(start_games<Gm>(e, slots, gids, nullptr, 1, 1)));
   e->active_slots = n0;
+  for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->group_active[g] = 0;
+  for (int i = 0; i < n0; ++i) e->group_active[i / e->gv[0].G]++;
   e->running = true;
   e->t_begin = std::chrono::steady_clock::now();
   return AZ_OK;
@@ -1023,10 +1032,12 @@ template <class Gm> static int move_round(az_engine* e) {
     e->games_done++;
     e->stats.games++;
     e->active_slots--;
+    e->group_active[fslots[i] / e->gv[0].G]--;
     if (e->total_games < 0 || e->next_game < e->total_games) {      // next id, in slot order (util.jl:181-188)
       rslots.push_back(fslots[i]);
       rgids.push_back((uint32_t)(e->first_game_id + e->next_game++));
       e->active_slots++;
+      e->group_active[fslots[i] / e->gv[0].G]++;
     }
   }
   AZCHK(start_games<Gm>(e, rslots, rgids, nullptr, 0, 1));
