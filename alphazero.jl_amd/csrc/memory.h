@@ -164,17 +164,22 @@ __global__ void __launch_bounds__(14 * 64) k_mem_merge_long(const az_sample* __r
   if (f < 2) { if (lane == 0) o[f] = base[(size_t)order[i] * 14 + f]; return; }
   double acc = 0.0;
   long long iacc = 0;
+  unsigned long long wn = i + lane < end ? base[(size_t)order[i + lane] * 14 + f] : 0ULL;
   for (long long j0 = i; j0 < end; j0 += 64) {
-    const long long j = j0 + lane;
-    const unsigned long long w = j < end ? base[(size_t)order[j] * 14 + f] : 0ULL;
+    const unsigned long long w = wn;
+    const long long jn = j0 + 64 + lane;                             // the next 64 samples travel while these are added
+    wn = jn < end ? base[(size_t)order[jn] * 14 + f] : 0ULL;
     const int m = (int)((end - j0) < 64 ? (end - j0) : 64);
-    if (f == 13) {
-      for (int k = 0; k < m; ++k) iacc += (long long)__shfl(w, k);
-    } else {
-      const double v = az_u2d(w);
-      for (int k = 0; k < m; ++k) {
-        const double x = __shfl(v, k);
-        acc = (j0 == i && k == 0) ? x : acc + x;                   // the sum STARTS with the first sample (keeps -0.0)
+    const int wlo = (int)(unsigned int)w, whi = (int)(unsigned int)(w >> 32);
+    const bool first_chunk = j0 == i;
+    // lane k's word through v_readlane (k is a compile-time constant after unrolling): two scalar reads + one add per sample
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      if (k < m) {
+        const unsigned long long x = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(whi, k) << 32) |
+                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(wlo, k);
+        if (f == 13) iacc += (long long)x;
+        else acc = (first_chunk && k == 0) ? az_u2d(x) : acc + az_u2d(x);   // the sum STARTS with the first sample (keeps -0.0)
       }
     }
   }
