@@ -294,4 +294,56 @@ function AlphaZero.pit_networks(gspec::DeviceGameSpec, contender::HipResNet, bas
   return rewards, redundancy[]
 end
 
+# ---- replay memory + learning status on the device (src/memory.jl, src/learning.jl:59-90,148-190) ------------
+"az_sample: TrainingSample with π by full action index (112 bytes)"
+struct AzSample
+  key::NTuple{2, UInt64}
+  pi::NTuple{9, Float64}
+  z::Float64
+  t::Float64
+  n::Int64
+end
+struct DatasetInfo; num_samples::Int64; sum_n::Int64; Wtot::Float64; Wmean::Float32; Hp::Float32; end
+struct LearningStatusRec; L::Float32; Lp::Float32; Lv::Float32; Lreg::Float32; Linv::Float32; Hp::Float32; Hpnet::Float32; end
+
+"MemoryBuffer whose samples live in HBM; `push_records!` takes the packed records az_selfplay_run returned"
+mutable struct DeviceMemory
+  h::Ptr{Cvoid}
+  gspec
+  function DeviceMemory(gspec, size; device=0)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:az_memory_create, LIB), Cint, (Int32, Int32, Int64, Ref{Ptr{Cvoid}}), game_id(gspec), device, size, out))
+    m = new(out[], gspec)
+    finalizer(x -> (x.h != C_NULL && ccall((:az_memory_destroy, LIB), Cint, (Ptr{Cvoid},), x.h); x.h = C_NULL), m)
+    return m
+  end
+end
+function push_records!(m::DeviceMemory, games::Vector{GameRec}, moves::Vector{MoveRec}, gamma)
+  GC.@preserve games moves begin
+    tb = TraceBuf(pointer(games), length(games), length(games), pointer(moves), length(moves), length(moves))
+    check(ccall((:az_memory_push, LIB), Cint, (Ptr{Cvoid}, Ref{TraceBuf}, Float64), m.h, tb, gamma))
+  end
+end
+
+"""
+    device_learning_status(nn::HipResNet, m::DeviceMemory, lp::LearningParams; use_symmetries, last_batch=false)
+
+`learning_status(Trainer(gspec, nn, experience, lp))` (src/learning.jl:98-121,158-181) without any sample leaving the
+GPU: augment_with_symmetries, merge_by_state, convert_samples and the losses run on the device data set.
+"""
+function device_learning_status(nn::HipResNet, m::DeviceMemory, lp; use_symmetries::Bool, last_batch::Bool=false)
+  ds = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ccall((:az_dataset_create, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+    m.h, last_batch ? 1 : 0, use_symmetries ? 1 : 0, lp.use_position_averaging ? 1 : 0, Int32(lp.samples_weighing_policy), ds))
+  try
+    out = Ref(LearningStatusRec(0, 0, 0, 0, 0, 0, 0))
+    check(ccall((:az_learning_status, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Float64, Int64, Ref{LearningStatusRec}),
+      engine!(nn).h, ds[], lp.l2_regularization, lp.nonvalidity_penalty, lp.rewards_renormalization, lp.loss_computation_batch_size, out))
+    r = out[]
+    return AlphaZero.Report.LearningStatus(AlphaZero.Report.Loss(r.L, r.Lp, r.Lv, r.Lreg, r.Linv), r.Hp, r.Hpnet)
+  finally
+    ccall((:az_dataset_destroy, LIB), Cint, (Ptr{Cvoid},), ds[])
+  end
+end
+
 end # module

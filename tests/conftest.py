@@ -11,6 +11,12 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # a fresh checkout has no binaries (they are git-ignored): build the HIP library once (hipcc cross-compiles gfx950
+    # without a GPU, ~2 min); the oracle builds itself on first use (oracle/azref.py)
+    lib = os.path.join(ROOT, "alphazero.jl_amd", "csrc", "libazhip.so")
+    if not os.path.exists(lib) and "AZHIP_LIB" not in os.environ:
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.dirname(lib), "libazhip.so"])
 
 
 def _have_gpu():
