@@ -93,7 +93,7 @@ struct az_engine {
   std::vector<float> blob;
   NetDev net;
   Net16Dev net16;                // k_tower16 fragments (64 filters)
-  int tower_pick;                // AZHIP_TOWER=16|32|3 forces a tower kernel (3 = k_tower16 with 3 row tiles); 0 = choose per launch
+  int tower_pick;                // AZHIP_TOWER=16|32|3|21 forces a tower kernel (3 = k_tower16 with 3 row tiles, 21 = k_tower16x2); 0 = choose per launch
   int num_cu;
   int nn_cap;
   float* d_hfeat; float* d_X; float* d_A; float* d_P; float* d_V; float* d_Pinv;
@@ -247,6 +247,10 @@ extern "C" int az_engine_destroy(az_engine* e) {
 template <class Gm, int F> static int set_kernel_attrs_f() {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
+  if constexpr (F == 64) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
+  }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   return AZ_OK;
@@ -665,7 +669,7 @@ extern "C" int az_net_get_params(const az_engine* e, float* blob, int64_t n) {
 // 4 x 176 < 6 x 128; 128 leaves: 1 x 48 << 1 x 128 (measured tools/small_batch.sh: 0.39 vs 0.80 ms per wave at
 // 128 filters).  Returns 16, 32 or 3.
 template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
-  if (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3) return e->tower_pick;
+  if (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64)) return e->tower_pick;
   const long cu = e->num_cu > 0 ? e->num_cu : 256;
   const long b16 = (n + T16<Gm, F>::TB - 1) / T16<Gm, F>::TB, b32 = (n + TOWER_ROWS / Gm::P - 1) / (TOWER_ROWS / Gm::P);
   const long b3 = (n + T16<Gm, F, 3>::TB - 1) / T16<Gm, F, 3>::TB;
@@ -676,6 +680,14 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
   // workgroups pack slightly better (measured 1.10 vs 1.07 M sims/s at 2 x 2048)
   if (F == 128 && e->ngroups > 1) c32 *= 0.9;
   if (c3 <= c16 && c3 <= c32) return 3;
+  // paired k_tower16x2: 336 rows = 8 boards per workgroup, no padding rows (+3 % on a 4096-leaf launch).  Only with ONE
+  // slot group: its 92 KB of LDS allow one workgroup per CU, so two groups' towers cannot interleave on a CU and the
+  // other group's heads kernel finds no gaps (measured 3.80 vs 4.11 M sims/s with two groups)
+  if (F == 64 && e->ngroups == 1) {
+    const long b21 = (n + T16P<Gm, 64>::TB - 1) / T16P<Gm, 64>::TB;
+    const double c21 = (double)((b21 + cu - 1) / cu) * T16P<Gm, 64>::RPAD;
+    if (c21 < c16 && c21 < c32) return 21;
+  }
   return c16 <= c32 ? 16 : 32;
 }
 template <class Gm, int F, bool FROM_PLANES>
@@ -686,8 +698,12 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
   if (gt == 0) return AZ_OK;
   constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
   constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
+  constexpr int TB21 = T16P<Gm, 64>::TB, THR21 = T16P<Gm, 64>::THREADS, LDS21 = T16P<Gm, 64>::BYTES;
   const int tw = pick_tower<Gm, F>(e, n_max);
-  if (tw == 3)
+  if (tw == 21) {
+    if constexpr (F == 64)
+      LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
+  } else if (tw == 3)
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES, 3>), (n_max + TB3 - 1) / TB3, THR16, LDS3, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
   else if (tw == 16)
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES>), (n_max + TB16 - 1) / TB16, THR16, LDS16, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
@@ -777,11 +793,15 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
   constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
   constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
+  constexpr int TB21 = T16P<Gm, 64>::TB, THR21 = T16P<Gm, 64>::THREADS, LDS21 = T16P<Gm, 64>::BYTES;
   // N = upper bound of this wave's leaves: the group's active slots (a draining phase or a partial explore! launches
   // -- and picks its tower kernel -- for what is left, not for the group's capacity)
   const int N = std::max(1, std::min(G, nmax));
   const int tw = pick_tower<Gm, F>(e, N);
-  if (tw == 3)
+  if (tw == 21) {
+    if constexpr (F == 64)
+      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);
+  } else if (tw == 3)
     LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, 3>), (N + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);
   else if (tw == 16)
     LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false>), (N + TB16 - 1) / TB16, THR16, LDS16, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);

@@ -40,15 +40,34 @@ struct Net16Dev {
 template <class Gm, int F = 64, int NT = 11> struct T16 {
   static constexpr int NTILE = NT, RPAD = NTILE * 16;
   static constexpr int TB = RPAD / Gm::P;            // NT = 11: 4 Connect-Four boards, 19 Tic-tac-toe, 12 Mancala; NT = 3: 1, 5, 3
-  static constexpr int STEPS = (NT + 1) / 2;         // tile pairs per (tap, 64-channel half); the last pair is a single tile when NT is odd
   static constexpr int ROWS = TB * Gm::P;
   static constexpr int STRIDE = F + 4;
   static constexpr int BUF = (RPAD + 1) * STRIDE;    // row RPAD = zeros
   static constexpr int PLANES = (RPAD + 1) * Gm::C;
   static constexpr int BYTES = (BUF + PLANES) * 4;   // 50 KB at F = 64 (2 workgroups per CU), 96 KB at F = 128 (1)
   static constexpr int WAVES = F / 16, THREADS = 64 * WAVES;
+  static constexpr int CT = F / 16;                  // channel tiles of 16 = wavefronts per row-tile set
   static constexpr int KH = F / 64;                  // 64-channel halves of a tap (one pipeline step each)
   static constexpr int SQ = F / 16;                  // float4 of B per tap and lane
+  using Game = Gm;
+  static constexpr int FILT = F;
+};
+// Paired geometry (k_tower16x2, 64 filters): TWO sets of F/16 wavefronts share one LDS buffer of 21 row tiles =
+// 336 rows = exactly 8 Connect-Four boards (24 Mancala, 37 Tic-tac-toe).  Set 0 owns tiles 0..10, set 1 tiles
+// 11..20: 21 tile-units per 8 boards instead of the 22 (2 x 11, 8 padding rows per 4 boards) of two k_tower16
+// workgroups -- the same two wavefronts per SIMD, 4.5 % fewer MFMAs per board.  92 KB of LDS, one workgroup per CU.
+template <class Gm, int F = 64> struct T16P {
+  static constexpr int NT0 = 11, NT1 = 10, NTW = NT0 + NT1, RPAD = NTW * 16;
+  static constexpr int TB = RPAD / Gm::P;
+  static constexpr int ROWS = TB * Gm::P;
+  static constexpr int STRIDE = F + 4;
+  static constexpr int BUF = (RPAD + 1) * STRIDE;
+  static constexpr int PLANES = (RPAD + 1) * Gm::C;
+  static constexpr int BYTES = (BUF + PLANES) * 4;
+  static constexpr int CT = F / 16, WAVES = 2 * CT, THREADS = 64 * WAVES;
+  static constexpr int KH = F / 64, SQ = F / 16;
+  using Game = Gm;
+  static constexpr int FILT = F;
 };
 
 // tap-validity bits of this lane's row in tile `tile`: 9 bits per tile, 3 tiles per word
@@ -64,10 +83,11 @@ template <int F> __device__ __forceinline__ int posF(int c) { return ((c >= F / 
 // VGPRs so that the tree kernels of the other slot group can co-reside on the SIMD).
 static constexpr int T16_GMAX = 2;
 template <int NT> __device__ __forceinline__ constexpr int t16_gsize(int pair) { return 2 * pair + 1 < NT ? 2 : 1; }
-template <class Gm, int F, int NT>
+template <class T, int NT>
 __device__ __forceinline__ void load_pair16(const float* __restrict__ buf, const uint32_t (&vm)[4], int tap, int pair, int kh,
                                             int lrow, int g, float4 (&a)[T16_GMAX][4]) {
-  using T = T16<Gm, F, NT>;
+  using Gm = typename T::Game;
+  constexpr int F = T::FILT;
   const int delta = (tap / 3 - 1) * Gm::W + (tap % 3 - 1);
 #pragma unroll
   for (int u = 0; u < T16_GMAX; ++u) {
@@ -97,78 +117,63 @@ __device__ __forceinline__ void mfma_pair16(const float4 (&a)[T16_GMAX][4], cons
     for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].w, b[q].w, acc[t0 + u], 0, 0, 0);
   }
 }
-template <class Gm, int F, int NT, int NTAP, int K>
+template <class T, int NT, int NTAP, int K>
 __device__ __forceinline__ void conv16_steps(const float* __restrict__ buf, const float4* __restrict__ wl, f32x4v (&acc)[NT],
-                                             const uint32_t (&vm)[4], int lrow, int g, float4 (&b0)[F / 16], float4 (&b1)[F / 16],
+                                             const uint32_t (&vm)[4], int lrow, int g, float4 (&b0)[T::FILT / 16], float4 (&b1)[T::FILT / 16],
                                              float4 (&aA)[T16_GMAX][4], float4 (&aB)[T16_GMAX][4]) {
-  using T = T16<Gm, F, NT>;
-  constexpr int SPT = T::STEPS * T::KH;             // pipeline steps per tap: (64-channel half, tile pair)
+  constexpr int F = T::FILT;
+  constexpr int STEPS = (NT + 1) / 2;               // tile pairs per (tap, 64-channel half); the last pair is a single tile when NT is odd
+  constexpr int SPT = STEPS * T::KH;                // pipeline steps per tap: (64-channel half, tile pair)
   if constexpr (K < NTAP * SPT) {
-    constexpr int t = K / SPT, kh = (K % SPT) / T::STEPS, p = K % T::STEPS;
+    constexpr int t = K / SPT, kh = (K % SPT) / STEPS, p = K % STEPS;
     float4 (&cur)[T16_GMAX][4] = (K & 1) ? aB : aA;
     float4 (&nxt)[T16_GMAX][4] = (K & 1) ? aA : aB;
     float4 (&bc)[F / 16] = (t & 1) ? b1 : b0;
     float4 (&bn)[F / 16] = (t & 1) ? b0 : b1;
     if constexpr (K % SPT == 0 && t + 1 < NTAP) {
 #pragma unroll
-      for (int q = 0; q < T::SQ; ++q) bn[q] = wl[(size_t)((t + 1) * T::WAVES * T::SQ + q) * 64];
+      for (int q = 0; q < T::SQ; ++q) bn[q] = wl[(size_t)((t + 1) * T::CT * T::SQ + q) * 64];
     }
     if constexpr (K + 1 < NTAP * SPT) {
-      constexpr int t1 = (K + 1) / SPT, kh1 = ((K + 1) % SPT) / T::STEPS, p1 = (K + 1) % T::STEPS;
-      load_pair16<Gm, F, NT>(buf, vm, NTAP == 1 ? 4 : t1, p1, kh1, lrow, g, nxt);
+      constexpr int t1 = (K + 1) / SPT, kh1 = ((K + 1) % SPT) / STEPS, p1 = (K + 1) % STEPS;
+      load_pair16<T, NT>(buf, vm, NTAP == 1 ? 4 : t1, p1, kh1, lrow, g, nxt);
     }
     mfma_pair16<p, kh, F / 16, NT>(cur, bc, acc);
 #ifndef AZ_T16_FENCE
 #define AZ_T16_FENCE 1     // fence the scheduler every N steps
 #endif
     if constexpr (K % AZ_T16_FENCE == AZ_T16_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
-    conv16_steps<Gm, F, NT, NTAP, K + 1>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
+    conv16_steps<T, NT, NTAP, K + 1>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
   }
 }
-template <class Gm, int F, int NT, int NTAP>
+template <class T, int NT, int NTAP>
 __device__ __forceinline__ void conv16(const float* __restrict__ buf, const float4* __restrict__ wl,
                                        f32x4v (&acc)[NT], const uint32_t (&vm)[4], int lrow, int g) {
+  constexpr int F = T::FILT;
   float4 b0[F / 16], b1[F / 16], aA[T16_GMAX][4], aB[T16_GMAX][4];
 #pragma unroll
   for (int q = 0; q < F / 16; ++q) b0[q] = wl[(size_t)q * 64];
-  load_pair16<Gm, F, NT>(buf, vm, NTAP == 1 ? 4 : 0, 0, 0, lrow, g, aA);
+  load_pair16<T, NT>(buf, vm, NTAP == 1 ? 4 : 0, 0, 0, lrow, g, aA);
   __builtin_amdgcn_sched_barrier(0);
-  conv16_steps<Gm, F, NT, NTAP, 0>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
+  conv16_steps<T, NT, NTAP, 0>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
 }
 
 template <int F> struct T16Threads { static constexpr int V = 64 * (F / 16); };
-template <class Gm, int F, bool FROM_PLANES, int NT = 11>
-__global__ void __launch_bounds__(T16Threads<F>::V, 2)
-k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
-          const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
-  using T = T16<Gm, F, NT>;
-  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, C = Gm::C, TB = T::TB, STRIDE = T::STRIDE, NTHR = T::THREADS;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* buf = lds;
-  float* planes = lds + T::BUF;
-  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
-  const int board0 = blockIdx.x * TB;
-  if (board0 >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lrow = lane & 15, g = lane >> 4;
 
-  // ---- input planes [RPAD + 1][C] and the zero row of the activation buffer ----------------------
-  for (int i = tid; i < T::PLANES; i += NTHR) {
-    const int row = i / C, c = i % C;
-    const int b = row / P, q = row % P;
-    float val = 0.0f;
-    if (row < T::ROWS && board0 + b < n) {
-      if (FROM_PLANES) val = X[((size_t)(board0 + b) * C + c) * P + q];
-      else val = Gm::plane(leaf_env[eval_slots[board0 + b]], q, c);
-    }
-    planes[i] = val;
-  }
-  for (int i = tid; i < STRIDE; i += NTHR) buf[T::RPAD * STRIDE + i] = 0.0f;
+// One wavefront's share of the tower: its NT row tiles start at row tile TILE0 of the workgroup's LDS buffer, it
+// owns the 16 output channels of channel tile cw.  The caller has filled `planes`, zeroed the buffer's zero row
+// and synchronised; every wavefront of the workgroup runs the same number of barriers.
+template <class T, bool FROM_PLANES, int NT, int TILE0>
+__device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restrict__ buf, const float* __restrict__ planes, int cw,
+                                             int lane, int n, int board0, float* __restrict__ hfeat) {
+  using Gm = typename T::Game;
+  constexpr int F = T::FILT, P = Gm::P, W = Gm::W, H = Gm::H, C = Gm::C, TB = T::TB, STRIDE = T::STRIDE, R0 = TILE0 * 16;
+  const int lrow = lane & 15, g = lane >> 4;
   // validity of the 9 taps for this lane's row of every tile
   uint32_t vm[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int tile = 0; tile < NT; ++tile) {
-    const int row = tile * 16 + lrow;
+    const int row = R0 + tile * 16 + lrow;
     const int q = row % P, x = q % W, y = q / W;
     uint32_t m = 0;
 #pragma unroll
@@ -179,10 +184,9 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
     }
     vm[tile / 3] |= m << (9 * (tile % 3));
   }
-  // this lane's output element (tile, i): row = tile*16 + g*4 + i, channel = wave*16 + lrow
-  const int ch = wave * 16 + lrow;
+  // this lane's output element (tile, i): row = R0 + tile*16 + g*4 + i, channel = cw*16 + lrow
+  const int ch = cw * 16 + lrow;
   const int opos = posF<F>(ch);
-  __syncthreads();
 
   f32x4v acc[NT];
   // ---- stem: Conv(3x3, C => 64) + BN + ReLU, K = 9C padded to a multiple of 4 -------------------------
@@ -193,7 +197,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       // sequence position p = 4s + g -> k = (p & 1) * K2 + (p >> 1)   (the paired order of the contract)
-      const float bw = net.stem_w[(size_t)(wave * NS + s) * 64 + lane];
+      const float bw = net.stem_w[(size_t)(cw * NS + s) * 64 + lane];
       const int p = 4 * s + g;
       const int k = (p & 1) * K2 + (p >> 1);
       const bool kin = k < KK && p < 2 * K2;
@@ -202,7 +206,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
 #pragma unroll
       for (int tile = 0; tile < NT; ++tile) {
         const bool ok = kin && ((vmask(vm, tile) >> tap) & 1);
-        const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
+        const int row = ok ? R0 + tile * 16 + lrow + delta : T::RPAD;
         const float a = planes[row * C + c];
         acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[tile], 0, 0, 0);
       }
@@ -213,22 +217,22 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float v = az_fmaf(acc[tile][i], sc, sh);
-        buf[(tile * 16 + g * 4 + i) * STRIDE + opos] = v > 0.0f ? v : 0.0f;
+        buf[(R0 + tile * 16 + g * 4 + i) * STRIDE + opos] = v > 0.0f ? v : 0.0f;
       }
   }
   __syncthreads();
 
   // ---- residual tower ---------------------------------------------------------------------------------
   float xres[NT][4];
-  const size_t LAYER_W = (size_t)9 * T::WAVES * T::SQ * 64;       // float4 per layer
+  const size_t LAYER_W = (size_t)9 * T::CT * T::SQ * 64;          // float4 per layer
   for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
     // opaque copy: stops hipcc from hoisting the 99 loop-invariant (tap, tile) LDS addresses out of the layer
     // loop, which would cost ~100 VGPRs for the whole kernel
-    int lrow_l = lrow;
+    int lrow_l = lrow + R0;
     asm volatile("" : "+v"(lrow_l));
-    conv16<Gm, F, NT, 9>(buf, net.conv_w + (size_t)layer * LAYER_W + (size_t)wave * T::SQ * 64 + lane, acc, vm, lrow_l, g);
+    conv16<T, NT, 9>(buf, net.conv_w + (size_t)layer * LAYER_W + (size_t)cw * T::SQ * 64 + lane, acc, vm, lrow_l, g);
     const float sc = net.conv_ss[(size_t)layer * 2 * F + ch], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch];
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();                                 // every wave has finished reading the buffer
@@ -237,7 +241,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
       for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int a = (tile * 16 + g * 4 + i) * STRIDE + opos;
+          const int a = (R0 + tile * 16 + g * 4 + i) * STRIDE + opos;
           xres[tile][i] = buf[a];                    // block input, kept for the skip connection
           const float v = az_fmaf(acc[tile][i], sc, sh);
           buf[a] = v > 0.0f ? v : 0.0f;
@@ -247,7 +251,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
       for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int a = (tile * 16 + g * 4 + i) * STRIDE + opos;
+          const int a = (R0 + tile * 16 + g * 4 + i) * STRIDE + opos;
           float v = az_fmaf(acc[tile][i], sc, sh);
           v = v + xres[tile][i];
           buf[a] = v > 0.0f ? v : 0.0f;
@@ -259,7 +263,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   // ---- both 1x1 head convolutions + BN + ReLU as one 64 => 64 GEMM ------------------------------------
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  conv16<Gm, F, NT, 1>(buf, net.head_w + (size_t)wave * T::SQ * 64 + lane, acc, vm, lrow, g);
+  conv16<T, NT, 1>(buf, net.head_w + (size_t)cw * T::SQ * 64 + lane, acc, vm, lrow + R0, g);
   {
     const float sc = net.head_ss[ch], sh = net.head_ss[F + ch];
     // head features straight from the accumulators to HBM, [board][P][64] in natural channel order
@@ -268,9 +272,63 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
     for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = tile * 16 + g * 4 + i;
+        const int row = R0 + tile * 16 + g * 4 + i;
         const float v = az_fmaf(acc[tile][i], sc, sh);
         if (row < nb * P) hfeat[((size_t)board0 * P + row) * F + ch] = v > 0.0f ? v : 0.0f;
       }
   }
+}
+
+// input planes [RPAD + 1][C] and the zero row of the activation buffer, by all threads of the workgroup
+template <class T, bool FROM_PLANES>
+__device__ __forceinline__ void tower16_fill(float* __restrict__ buf, float* __restrict__ planes, const GEnv* __restrict__ leaf_env,
+                                             const int* __restrict__ eval_slots, const float* __restrict__ X, int n, int board0, int tid) {
+  using Gm = typename T::Game;
+  constexpr int P = Gm::P, C = Gm::C;
+  for (int i = tid; i < T::PLANES; i += T::THREADS) {
+    const int row = i / C, c = i % C;
+    const int b = row / P, q = row % P;
+    float val = 0.0f;
+    if (row < T::ROWS && board0 + b < n) {
+      if (FROM_PLANES) val = X[((size_t)(board0 + b) * C + c) * P + q];
+      else val = Gm::plane(leaf_env[eval_slots[board0 + b]], q, c);
+    }
+    planes[i] = val;
+  }
+  for (int i = tid; i < T::STRIDE; i += T::THREADS) buf[T::RPAD * T::STRIDE + i] = 0.0f;
+}
+
+template <class Gm, int F, bool FROM_PLANES, int NT = 11>
+__global__ void __launch_bounds__(T16Threads<F>::V, 2)
+k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+          const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
+  using T = T16<Gm, F, NT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* buf = lds;
+  float* planes = lds + T::BUF;
+  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
+  const int board0 = blockIdx.x * T::TB;
+  if (board0 >= n) return;
+  tower16_fill<T, FROM_PLANES>(buf, planes, leaf_env, eval_slots, X, n, board0, threadIdx.x);
+  __syncthreads();
+  tower16_wave<T, FROM_PLANES, NT, 0>(net, buf, planes, threadIdx.x >> 6, threadIdx.x & 63, n, board0, hfeat);
+}
+
+// The paired form (T16P): wavefronts 0..CT-1 run tiles 0..10, wavefronts CT..2CT-1 tiles 11..20 of ONE buffer.
+template <class Gm, int F, bool FROM_PLANES>
+__global__ void __launch_bounds__(2 * T16Threads<F>::V, 1)
+k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
+  using T = T16P<Gm, F>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* buf = lds;
+  float* planes = lds + T::BUF;
+  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
+  const int board0 = blockIdx.x * T::TB;
+  if (board0 >= n) return;
+  tower16_fill<T, FROM_PLANES>(buf, planes, leaf_env, eval_slots, X, n, board0, threadIdx.x);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave < T::CT) tower16_wave<T, FROM_PLANES, T::NT0, 0>(net, buf, planes, wave, lane, n, board0, hfeat);
+  else tower16_wave<T, FROM_PLANES, T::NT1, T::NT0>(net, buf, planes, wave - T::CT, lane, n, board0, hfeat);
 }

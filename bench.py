@@ -178,7 +178,9 @@ def main():
             flops = local_evals * TOWER_FLOP
             achieved = flops / (tw["ms"] * 1e-3) / 1e12 if tw["ms"] > 0 else 0.0
             out["roofline"] = {
-                "kernel": "k_tower16<ConnectFour,64,false,11>", "bound": "mfma", "achieved": achieved,
+                # one slot group: the paired 21-row-tile kernel; several groups: the 11-tile kernel (pick_tower, azhip.hip)
+                "kernel": "k_tower16x2<ConnectFour,64,false>" if args.groups == 1 else "k_tower16<ConnectFour,64,false,11>",
+                "bound": "mfma", "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": pmc_traffic(local_evals / max(tw["launches"], 1)),
                 "flop_per_board": TOWER_FLOP, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
