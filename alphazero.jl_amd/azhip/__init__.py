@@ -19,4 +19,5 @@ from .simulations import Simulator, record_trace, self_play_measurements, simula
 from .training import SelfPlayParams, SelfPlayReport, broadcast_params, self_play_step
 from .arena import Evaluation, compare_networks, pit_networks, pit_players
 from . import benchmark as Benchmark
-from .learning import (CONSTANT_WEIGHT, LINEAR_WEIGHT, LOG_WEIGHT, LearningParams, LearningStatus, Loss, Samples, Trainer)
+from .learning import (CONSTANT_WEIGHT, LINEAR_WEIGHT, LOG_WEIGHT, Adam, CyclicNesterov, LearningParams, LearningStatus, Loss,
+                       Samples, Trainer)

@@ -81,6 +81,14 @@ class LearningStatusRec(C.Structure):
 
 
 WEIGHT_CONSTANT, WEIGHT_LOG, WEIGHT_LINEAR = 0, 1, 2
+OPT_ADAM, OPT_CYCLIC_NESTEROV = 0, 1
+
+
+class TrainCfg(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("optimiser", C.c_int32), ("lr", C.c_float), ("lr_base", C.c_float),
+                ("lr_high", C.c_float), ("lr_low", C.c_float), ("momentum_low", C.c_float), ("momentum_high", C.c_float),
+                ("l2_regularization", C.c_double), ("nonvalidity_penalty", C.c_double), ("rewards_renormalization", C.c_double),
+                ("batch_size", C.c_int32), ("batch_norm_momentum", C.c_float), ("seed", C.c_uint64)]
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p)
 
@@ -126,6 +134,12 @@ SYMBOLS = {
     "az_dataset_get_info": [_VP, C.POINTER(DatasetInfo)],
     "az_dataset_read": [_VP, _I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP],
     "az_learning_status": [_VP, _VP, C.c_double, C.c_double, C.c_double, _I64, C.POINTER(LearningStatusRec)],
+    "az_train_cfg_init": [C.POINTER(TrainCfg)],
+    "az_trainer_create": [_VP, _VP, C.POINTER(TrainCfg), C.POINTER(_VP)],
+    "az_trainer_destroy": [_VP],
+    "az_trainer_batch_updates": [_VP, _I32, _VP],
+    "az_trainer_get_params": [_VP, _VP, _I64],
+    "az_trainer_gradients": [_VP, _VP, C.POINTER(C.c_float), _VP, _VP, _I64],
     "az_prof_enable": [_VP, _I32],
     "az_prof_get": [_VP, C.POINTER(Prof)],
     "az_prof_reset": [_VP],

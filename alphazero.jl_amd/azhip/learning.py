@@ -1,8 +1,8 @@
-"""Learning-side mirror, evaluation half (src/learning.jl): Trainer's data, losses, learning_status, samples_report.
+"""Learning-side mirror (src/learning.jl): Trainer's data, losses, learning_status, samples_report, batch_updates!.
 
-The backward pass / optimiser step (batch_updates!, Network.train!) is not on the device yet (SURVEY.md §8f
-rank 1); what is: the whole data path of a Trainer (symmetry augmentation, merge_by_state, convert_samples) and the
-loss evaluation with the network in test mode -- Report.LearningStatus as learning_step! / memory_report print it."""
+Everything runs on the device: the data path of a Trainer (symmetry augmentation, merge_by_state, convert_samples),
+the loss evaluation with the network in test mode (Report.LearningStatus) and the optimiser steps (forward with
+batch statistics, backward, Adam / CyclicNesterov: az_trainer_*)."""
 import ctypes as C
 from dataclasses import dataclass
 
@@ -24,6 +24,23 @@ class LearningParams:
     use_position_averaging: bool = True
     rewards_renormalization: float = 1.0
     nonvalidity_penalty: float = 1.0
+    optimiser: object = None
+
+
+@dataclass
+class Adam:
+    """network.jl:182-190"""
+    lr: float = 2e-3
+
+
+@dataclass
+class CyclicNesterov:
+    """network.jl:163-180"""
+    lr_base: float
+    lr_high: float
+    lr_low: float
+    momentum_low: float
+    momentum_high: float
 
 
 @dataclass
@@ -67,8 +84,66 @@ class Trainer:
         self._eng.net_set_params(network.params())
 
     def close(self):
+        if getattr(self, "_tr", None):
+            L.lib().az_trainer_destroy(self._tr)
+            self._tr = None
         self.data.close()
         self._eng.close()
+
+    # ---- the optimiser step (learning.jl:123-141) ----
+    def _trainer(self, optimiser=None, batch_norm_momentum=0.1, seed=1):
+        if getattr(self, "_tr", None):
+            return self._tr
+        cfg = L.TrainCfg()
+        L.check(L.lib().az_train_cfg_init(C.byref(cfg)))
+        opt = optimiser if optimiser is not None else getattr(self.params, "optimiser", None) or Adam()
+        if isinstance(opt, Adam):
+            cfg.optimiser, cfg.lr = L.OPT_ADAM, opt.lr
+        else:
+            cfg.optimiser = L.OPT_CYCLIC_NESTEROV
+            cfg.lr_base, cfg.lr_high, cfg.lr_low = opt.lr_base, opt.lr_high, opt.lr_low
+            cfg.momentum_low, cfg.momentum_high = opt.momentum_low, opt.momentum_high
+        p = self.params
+        cfg.l2_regularization, cfg.nonvalidity_penalty = p.l2_regularization, p.nonvalidity_penalty
+        cfg.rewards_renormalization, cfg.batch_size = p.rewards_renormalization, p.batch_size
+        cfg.batch_norm_momentum, cfg.seed = batch_norm_momentum, seed
+        h = C.c_void_p()
+        L.check(L.lib().az_trainer_create(self._eng._h, self.data._h, C.byref(cfg), C.byref(h)))
+        self._tr = h
+        return h
+
+    def batch_size(self):
+        return min(self.params.batch_size, self.num_samples())
+
+    def batch_updates(self, n, **kw):
+        """batch_updates!(tr, n): n optimiser steps; returns the losses (Float32) like the reference's `ls`"""
+        import numpy as np
+        tr = self._trainer(**kw)
+        ls = np.zeros(n, dtype=np.float32)
+        L.check(L.lib().az_trainer_batch_updates(tr, int(n), ls.ctypes.data_as(C.c_void_p)))
+        return ls
+
+    def gradients(self, sample_idx, **kw):
+        """parity hook: (loss, (Lp, Lv, Lreg, Linv, scale), data gradient in Flux parameter order) of one batch, no update"""
+        import numpy as np
+        tr = self._trainer(**kw)
+        idx = np.ascontiguousarray(sample_idx, dtype=np.int32)
+        assert len(idx) == self.batch_size()
+        n = self._eng.net_num_params()
+        g = np.zeros(n, dtype=np.float32)
+        parts = np.zeros(5, dtype=np.float32)
+        loss = C.c_float()
+        L.check(L.lib().az_trainer_gradients(tr, idx.ctypes.data_as(C.c_void_p), C.byref(loss), parts.ctypes.data_as(C.c_void_p),
+                                             g.ctypes.data_as(C.c_void_p), n))
+        return loss.value, parts, g
+
+    def trained_params(self, **kw):
+        """get_trained_network(tr): the parameter blob after the updates so far"""
+        import numpy as np
+        tr = self._trainer(**kw)
+        out = np.zeros(self._eng.net_num_params(), dtype=np.float32)
+        L.check(L.lib().az_trainer_get_params(tr, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
 
     def __enter__(self):
         return self

@@ -1339,6 +1339,7 @@ extern "C" int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, 
 }
 
 #include "memory.h"
+#include "train.h"
 
 // debug aid (not part of the ABI in azhip.h): the numerics contract evaluated on the device, so that tests can
 // compare gfx950 against the host bit for bit (f64 sqrt / div, az_log / az_exp / az_pow, az_expf / az_tanhf)

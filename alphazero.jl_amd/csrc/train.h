@@ -1,0 +1,664 @@
+// train.h -- the optimiser step on the device (second half; first version).
+//
+//   batch_updates!(tr, n)                      src/learning.jl:131-141
+//   Network.train!(callback, nn, opt, ...)     src/networks/flux.jl:68-95   (Flux.withgradient + Flux.update!)
+//   losses                                      src/learning.jl:67-90
+//   ResNet in TRAIN mode                        src/networks/architectures/resnet.jl:53-92 (BatchNorm with batch statistics)
+//
+// Structure of this first version: every convolution is im2col (hand-written gather) + one plain fp32 GEMM through
+// rocBLAS (forward, data gradient with the rotated weights, weight gradient), which the task's rules allow for plain
+// library GEMMs; everything that is not a GEMM is hand-written here: batch-norm statistics / apply / backward with
+// deterministic two-stage column reductions, ReLU and skip wiring, the loss with its analytic gradient (softmax,
+// mask normalisation, KL, invalid-mass penalty, tanh / MSE), parameter layout maps between Flux's arrays and the
+// GEMM matrices, Adam / Nesterov and the running statistics.  rocBLAS is dlopen'ed when the first trainer is
+// created, so self-play users never load it.  The fused inference tower is untouched: after training the new
+// parameters go back through az_net_set_params.
+//
+// Included at the end of azhip.hip (after memory.h).
+#pragma once
+#include <dlfcn.h>
+
+// ------------------------------------------------------------------------------------------ rocBLAS by dlopen
+namespace rb {
+typedef void* handle_t;
+enum { OP_N = 111, OP_T = 112 };                   // rocblas_operation_none / _transpose
+typedef int (*create_t)(handle_t*);
+typedef int (*destroy_t)(handle_t);
+typedef int (*set_stream_t)(handle_t, hipStream_t);
+typedef int (*set_atomics_t)(handle_t, int);
+typedef int (*sgemm_t)(handle_t, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
+struct Lib {
+  void* so = nullptr;
+  create_t create = nullptr; destroy_t destroy = nullptr; set_stream_t set_stream = nullptr; set_atomics_t set_atomics = nullptr;
+  sgemm_t sgemm = nullptr;
+};
+static Lib g_lib;
+static int load() {
+  if (g_lib.so) return AZ_OK;
+  void* so = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+  if (!so) so = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+  if (!so) return fail(AZ_ERR_HIP, "cannot load librocblas.so (%s): the training step needs rocBLAS for its GEMMs", dlerror());
+  g_lib.create = (create_t)dlsym(so, "rocblas_create_handle"); g_lib.destroy = (destroy_t)dlsym(so, "rocblas_destroy_handle");
+  g_lib.set_stream = (set_stream_t)dlsym(so, "rocblas_set_stream"); g_lib.set_atomics = (set_atomics_t)dlsym(so, "rocblas_set_atomics_mode");
+  g_lib.sgemm = (sgemm_t)dlsym(so, "rocblas_sgemm");
+  if (!g_lib.create || !g_lib.destroy || !g_lib.set_stream || !g_lib.sgemm) return fail(AZ_ERR_HIP, "librocblas.so lacks the expected symbols");
+  g_lib.so = so;
+  return AZ_OK;
+}
+// row-major C[M][N] = alpha * op(A) * op(B) + beta * C  (A is [M][K], or [K][M] when ta; B is [K][N], or [N][K] when tb)
+static int gemm(handle_t h, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                float beta, float* C, int ldc) {
+  if (M == 0 || N == 0) return AZ_OK;
+  const int st = g_lib.sgemm(h, tb ? OP_T : OP_N, ta ? OP_T : OP_N, N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc);
+  if (st != 0) return fail(AZ_ERR_HIP, "rocblas_sgemm failed with status %d (M %d N %d K %d)", st, M, N, K);
+  return AZ_OK;
+}
+}  // namespace rb
+
+// ------------------------------------------------------------------------------------------ kernels
+// work[j] = blob[map[j]]  /  gblob[map[j]] = gwork[j]   (parameter layout maps, built on the host once)
+__global__ void k_tr_gather(const float* __restrict__ blob, const int* __restrict__ map, long long n, float* __restrict__ work) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) work[j] = blob[map[j]];
+}
+__global__ void k_tr_scatter(const float* __restrict__ gwork, const int* __restrict__ map, long long n, float* __restrict__ gblob) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) gblob[map[j]] = gwork[j];
+}
+// the batch of a step: rows idx[0..B) of the data set's tensors
+__global__ void k_tr_batch(const int* __restrict__ idx, int B, int xs, int A, const float* __restrict__ W, const float* __restrict__ X,
+                           const float* __restrict__ Am, const float* __restrict__ P, const float* __restrict__ V,
+                           float* bW, float* bX, float* bA, float* bP, float* bV) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const size_t s = (size_t)idx[b];
+  for (int i = threadIdx.x; i < xs; i += blockDim.x) bX[(size_t)b * xs + i] = X[s * xs + i];
+  for (int i = threadIdx.x; i < A; i += blockDim.x) { bA[(size_t)b * A + i] = Am[s * A + i]; bP[(size_t)b * A + i] = P[s * A + i]; }
+  if (threadIdx.x == 0) { bW[b] = W[s]; bV[b] = V[s]; }
+}
+// im2col of a 3x3 / pad 1 convolution over rows r = board*P + x + W*y: col[r][tap*C + c] = in(r + delta(tap))[c] or 0.
+// PLANES: `in` is the plane tensor [B][C][P]; else the activation matrix [R][C].
+template <bool PLANES>
+__global__ void __launch_bounds__(256) k_tr_im2col(const float* __restrict__ in, long long R, int C, int Wd, int Hd, float* __restrict__ col) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = R * 9 * C;
+  if (t >= total) return;
+  const int c = (int)(t % C);
+  const int tap = (int)((t / C) % 9);
+  const long long r = t / (9LL * C);
+  const int P = Wd * Hd, q = (int)(r % P), x = q % Wd, y = q / Wd;
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  float v = 0.0f;
+  if (y + dy >= 0 && y + dy < Hd && x + dx >= 0 && x + dx < Wd) {
+    const long long rr = r + dy * Wd + dx;
+    v = PLANES ? in[((rr / P) * C + c) * P + (rr % P)] : in[rr * C + c];
+  }
+  col[t] = v;
+}
+// two-stage column sums over R rows of up to two derived quantities; stage 1: chunk of 256 rows per block, thread = channel
+//   MODE 0: (x, x*x)                       batch-norm statistics of the GEMM output
+//   MODE 1: (dy, dy * xhat)                batch-norm backward, dy = da * (out > 0) [* relu mask], xhat = (g - mean) * invstd
+//   MODE 2: (x, 0)                         bias gradients
+template <int MODE>
+__global__ void k_tr_colsum(const float* __restrict__ x, const float* __restrict__ out_act, const float* __restrict__ g,
+                            const float* __restrict__ mean, const float* __restrict__ invstd, long long R, int C,
+                            double* __restrict__ part /* [nchunks][2][C] */) {
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long long r0 = (long long)blockIdx.x * 256, r1 = r0 + 256 < R ? r0 + 256 : R;
+  double s0 = 0.0, s1 = 0.0;
+  for (long long r = r0; r < r1; ++r) {
+    const size_t i = (size_t)r * C + c;
+    if (MODE == 0) { const float v = x[i]; s0 += (double)v; s1 += (double)v * (double)v; }
+    else if (MODE == 1) {
+      const float dy = out_act[i] > 0.0f ? x[i] : 0.0f;
+      const float xh = (g[i] - mean[c]) * invstd[c];
+      s0 += (double)dy; s1 += (double)dy * (double)xh;
+    } else s0 += (double)x[i];
+  }
+  part[((size_t)blockIdx.x * 2) * C + c] = s0;
+  part[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+}
+__global__ void k_tr_colsum_final(const double* __restrict__ part, int nchunks, int C, double* __restrict__ sums /* [2][C] */) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < nchunks; ++k) { s0 += part[((size_t)k * 2) * C + c]; s1 += part[((size_t)k * 2 + 1) * C + c]; }
+  sums[c] = s0; sums[C + c] = s1;
+}
+// batch statistics -> mean, 1/sqrt(var + eps) (Flux BatchNorm: biased variance, eps 1e-5) and the running statistics
+// mu <- (1-m) mu + m (mean + bias), var <- (1-m) var + m * var * R/(R-1)
+__global__ void k_tr_bn_stats(const double* __restrict__ sums, long long R, int C, float momentum, const float* __restrict__ bias,
+                              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean, float* __restrict__ run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[c] / (double)R;
+  double var = sums[C + c] / (double)R - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / __builtin_sqrt(var + 1e-5));
+  const float b = bias ? bias[c] : 0.0f;
+  run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * ((float)m + b);
+  run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)(var * ((double)R / (double)(R - 1)));
+}
+// a = relu(gamma * xhat + beta (+ res))
+__global__ void k_tr_bn_apply(const float* __restrict__ g, const float* __restrict__ mean, const float* __restrict__ invstd,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
+                              long long n, int C, float* __restrict__ a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  float v = gamma[c] * ((g[i] - mean[c]) * invstd[c]) + beta[c];
+  if (res) v += res[i];
+  a[i] = v > 0.0f ? v : 0.0f;
+}
+// batch-norm backward: dy = da * (a > 0); dg = gamma * invstd * (dy - sum(dy)/R - xhat * sum(dy*xhat)/R); dgamma = sum(dy*xhat),
+// dbeta = sum(dy).  `dy_out` (optional) receives dy: the gradient that also flows into the skip connection.
+__global__ void k_tr_bn_bwd(const float* __restrict__ da, const float* __restrict__ a, const float* __restrict__ g,
+                            const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                            const double* __restrict__ sums, long long R, long long n, int C, float* __restrict__ dg, float* __restrict__ dy_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const float dy = a[i] > 0.0f ? da[i] : 0.0f;
+  const float xh = (g[i] - mean[c]) * invstd[c];
+  const float m0 = (float)(sums[c] / (double)R), m1 = (float)(sums[C + c] / (double)R);
+  dg[i] = gamma[c] * invstd[c] * (dy - m0 - xh * m1);
+  if (dy_out) dy_out[i] = dy;
+}
+__global__ void k_tr_bn_param_grads(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c]; }
+}
+__global__ void k_tr_store_sum0(const double* __restrict__ sums, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) out[c] = (float)sums[c];
+}
+__global__ void k_tr_add(float* __restrict__ x, const float* __restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += y[i];
+}
+// dense epilogues: y = [relu](x + bias[c]);  backward mask: dx = dy * (y > 0)
+__global__ void k_tr_bias_act(float* __restrict__ x, const float* __restrict__ bias, long long n, int C, int relu) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i] + bias[(int)(i % C)];
+  x[i] = relu ? (v > 0.0f ? v : 0.0f) : v;
+}
+__global__ void k_tr_relu_bwd(float* __restrict__ dy, const float* __restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !(y[i] > 0.0f)) dy[i] = 0.0f;
+}
+// `losses` (learning.jl:67-90) for one batch, forward terms and the analytic gradient w.r.t. the policy logits and the
+// value pre-activation.  scale = (mean(W_batch) / Wmean) / sum(W_batch) is folded into the gradients.
+//   p = softmax(logits); u = p .* A; S = sum(u); q = u / (S + eps)            (network.jl:264-271)
+//   Lp_i = -sum_a P_a log(q_a + eps) w;  Linv_i = (1 - S) w;  Lv_i = ((tanh(t) - V) / rho)^2 w
+__global__ void k_tr_loss(const float* __restrict__ logits, const float* __restrict__ tpre, const float* __restrict__ Am,
+                          const float* __restrict__ P, const float* __restrict__ V, const float* __restrict__ W, int B, int A,
+                          float cinv, float rho, float gscale, float* __restrict__ dlogits, float* __restrict__ dt,
+                          double* __restrict__ t_w, double* __restrict__ t_kl, double* __restrict__ t_mse, double* __restrict__ t_inv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const float eps = 1.1920929e-07f;
+  float p[AZ_MAX_ACTIONS], u[AZ_MAX_ACTIONS], gq[AZ_MAX_ACTIONS];
+  float mx = logits[(size_t)i * A];
+  for (int a = 1; a < A; ++a) mx = logits[(size_t)i * A + a] > mx ? logits[(size_t)i * A + a] : mx;
+  float se = 0.0f;
+  for (int a = 0; a < A; ++a) { p[a] = az_expf(logits[(size_t)i * A + a] - mx); se += p[a]; }
+  float S = 0.0f;
+  for (int a = 0; a < A; ++a) { p[a] = p[a] / se; u[a] = p[a] * Am[(size_t)i * A + a]; S += u[a]; }
+  const float w = W[i];
+  const float den = S + eps;
+  double kl = 0.0;
+  float gu_sum = 0.0f;                                             // sum_b gq_b * u_b / den^2
+  for (int a = 0; a < A; ++a) {
+    const float q = u[a] / den;
+    const float Pa = P[(size_t)i * A + a];
+    kl += (double)(Pa * az_logf(q + eps) * w);
+    gq[a] = -Pa / (q + eps);                                       // dLp_i/dq_a (per unit weight)
+    gu_sum += gq[a] * u[a];
+  }
+  gu_sum = gu_sum / (den * den);
+  // dL/dp_a = A_a * (gq_a / den - gu_sum - cinv) * w * gscale ;  softmax backward
+  float dp[AZ_MAX_ACTIONS], dot = 0.0f;
+  for (int a = 0; a < A; ++a) {
+    dp[a] = Am[(size_t)i * A + a] * (gq[a] / den - gu_sum - cinv) * w * gscale;
+    dot += p[a] * dp[a];
+  }
+  for (int a = 0; a < A; ++a) dlogits[(size_t)i * A + a] = p[a] * (dp[a] - dot);
+  const float vh = az_tanhf(tpre[i]);
+  const float d = vh / rho - V[i] / rho;
+  dt[i] = 2.0f * d / rho * (1.0f - vh * vh) * w * gscale;
+  t_w[i] = (double)w; t_kl[i] = kl; t_mse[i] = (double)(d * d * w); t_inv[i] = (double)((1.0f - S) * w);
+}
+// Adam (Optimisers.Adam: beta (0.9, 0.999), eps 1e-8) / Nesterov (Optimisers.Nesterov) on the trainable entries of
+// the blob; the L2 term of the loss, scale * creg * sum(w^2), is added to the gradient here: + scale * 2 creg w.
+__global__ void k_tr_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                          const unsigned char* __restrict__ trainable, long long n, float lr, float b1t, float b2t, float reg2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !trainable[i]) return;
+  const float gi = g[i] + reg2 * w[i];
+  const float mt = 0.9f * m[i] + (1.0f - 0.9f) * gi;
+  const float vt = 0.999f * v[i] + (1.0f - 0.999f) * gi * gi;
+  m[i] = mt; v[i] = vt;
+  w[i] -= mt / (1.0f - b1t) / (__builtin_sqrtf(vt / (1.0f - b2t)) + 1e-8f) * lr;
+}
+__global__ void k_tr_nesterov(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ vel,
+                              const unsigned char* __restrict__ trainable, long long n, float lr, float rho, float reg2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !trainable[i]) return;
+  const float gi = g[i] + reg2 * w[i];
+  const float vo = vel[i];
+  const float d = rho * rho * vo - (1.0f + rho) * lr * gi;         // Optimisers.Nesterov: newdx = -d
+  vel[i] = rho * vo - lr * gi;
+  w[i] += d;
+}
+__global__ void k_tr_sumsq(const float* __restrict__ w, const unsigned char* __restrict__ trainable, long long n, double* __restrict__ part) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) if (trainable[i]) s += (double)w[i] * (double)w[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+// ------------------------------------------------------------------------------------------ host
+struct TrConv {                 // one convolution + batch norm (3x3 of the tower, or a 1x1 head convolution)
+  int cin, cout, taps;
+  size_t off_w, off_b, off_bn;  // blob offsets: W, bias, (gamma, beta, mean, var)
+  size_t wk_wm, wk_wrot;        // offsets in the working-parameter array: GEMM matrix [taps*cin][cout], rotated [taps*cout][cin]
+  float *col, *g, *a;           // im2col input [R][taps*cin] (taps == 1: alias of the input), GEMM output, activation
+  float *mean, *invstd;
+};
+struct az_trainer {
+  az_engine* e;
+  az_dataset* d;
+  az_train_cfg cfg;
+  int game, device; GameInfo gi;
+  hipStream_t stream;
+  rb::handle_t rbh;
+  int B, nblocks, F, npf, nvf, nA;
+  long long R;
+  size_t nparams;
+  std::vector<TrConv> convs;    // stem, block convs..., then policy-head conv, value-head conv
+  size_t off_pd_w, off_pd_b, off_v1_w, off_v1_b, off_v2_w, off_v2_b;      // dense layers in the blob
+  size_t wk_pd, wk_v1, wk_v2, nwork;
+  float *blob, *gblob, *opt_m, *opt_v; unsigned char* trainable;           // [nparams]
+  float *work, *gwork; int* map;                                             // working parameters and their blob map
+  // batch + head buffers
+  int* d_idx; float *bW, *bX, *bA, *bP, *bV;
+  float *logits, *v1, *tpre, *dlogits, *dt, *dv1;
+  float *dact, *dact2, *dcol;                                                // [R][F] gradients, [R][9F] im2col of a gradient
+  double *part, *sums, *terms, *bsums;
+  std::vector<void*> allocs;
+  DevReducer red;                                                            // sized for max(B, 1024) elements
+  std::vector<int> perm; int64_t perm_pos, epoch; int64_t step;
+  float b1t, b2t;
+};
+
+template <class T> static int tr_alloc(az_trainer* t, T** p, size_t n, bool zero = false) {
+  AZCHK(mem_alloc(&t->allocs, p, n));
+  if (zero) HIPCHK(hipMemsetAsync(*p, 0, std::max<size_t>(n * sizeof(T), 16), t->stream));
+  return AZ_OK;
+}
+static inline unsigned tr_grid(long long n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" int az_train_cfg_init(az_train_cfg* c) {
+  if (!c) return fail(AZ_ERR_BAD_ARG, "cfg is NULL");
+  memset(c, 0, sizeof *c);
+  c->struct_size = (int32_t)sizeof *c;
+  c->optimiser = AZ_OPT_ADAM; c->lr = 2e-3f;                       // games/connect-four/params.jl:46-58
+  c->lr_base = 1e-3f; c->lr_high = 1e-2f; c->lr_low = 1e-3f; c->momentum_low = 0.8f; c->momentum_high = 0.9f;
+  c->l2_regularization = 1e-4; c->nonvalidity_penalty = 1.0; c->rewards_renormalization = 1.0;
+  c->batch_size = 1024; c->batch_norm_momentum = 0.1f; c->seed = 1;
+  return AZ_OK;
+}
+
+extern "C" int az_trainer_destroy(az_trainer* t) {
+  if (!t) return AZ_OK;
+  (void)hipSetDevice(t->device);
+  if (t->rbh) rb::g_lib.destroy(t->rbh);
+  for (void* p : t->allocs) (void)hipFree(p);
+  if (t->stream) (void)hipStreamDestroy(t->stream);
+  delete t;
+  return AZ_OK;
+}
+
+// builds layer tables, parameter maps and buffers
+static int trainer_build(az_trainer* t) {
+  const GameInfo& gi = t->gi;
+  const int F = t->F, C = gi.C, P = gi.P, A = gi.A, npf = t->npf, nvf = t->nvf;
+  const long long R = t->R;
+  size_t off = 0, wk = 0;
+  auto add_conv = [&](int cin, int cout, int taps) {
+    TrConv c{};
+    c.cin = cin; c.cout = cout; c.taps = taps;
+    c.off_w = off; off += (size_t)taps * cin * cout;
+    c.off_b = off; off += cout;
+    c.off_bn = off; off += 4 * (size_t)cout;
+    c.wk_wm = wk; wk += (size_t)taps * cin * cout;
+    c.wk_wrot = wk; wk += (size_t)taps * cin * cout;
+    t->convs.push_back(c);
+  };
+  add_conv(C, F, 9);
+  for (int l = 0; l < 2 * t->nblocks; ++l) add_conv(F, F, 9);
+  add_conv(F, npf, 1);                                              // policy head: conv, (bn), then dense
+  t->off_pd_w = off; off += (size_t)A * P * npf; t->off_pd_b = off; off += A;
+  add_conv(F, nvf, 1);                                              // value head
+  t->off_v1_w = off; off += (size_t)F * P * nvf; t->off_v1_b = off; off += F;
+  t->off_v2_w = off; off += F; t->off_v2_b = off; off += 1;
+  if (off != t->nparams) return fail(AZ_ERR_STATE, "trainer layout (%zu) does not match the network (%zu parameters)", off, t->nparams);
+  t->wk_pd = wk; wk += (size_t)P * npf * A;
+  t->wk_v1 = wk; wk += (size_t)P * nvf * F;
+  t->wk_v2 = wk; wk += F;
+  t->nwork = wk;
+  // parameter maps: work[j] = blob[map[j]]
+  std::vector<int> map(wk);
+  std::vector<unsigned char> trainable(t->nparams, 1);
+  for (const TrConv& c : t->convs) {
+    for (int tap = 0; tap < c.taps; ++tap) {
+      const int dy = c.taps == 9 ? tap / 3 - 1 : 0, dx = c.taps == 9 ? tap % 3 - 1 : 0;
+      const int wi = c.taps == 9 ? 1 - dx : 0, wj = c.taps == 9 ? 1 - dy : 0, ks = c.taps == 9 ? 3 : 1;
+      for (int ci = 0; ci < c.cin; ++ci) for (int co = 0; co < c.cout; ++co) {
+        const int b = (int)(c.off_w + (size_t)wi + (size_t)ks * (wj + (size_t)ks * (ci + (size_t)c.cin * co)));   // Flux W(kw, kh, ci, co), true convolution
+        map[c.wk_wm + ((size_t)tap * c.cin + ci) * c.cout + co] = b;
+        map[c.wk_wrot + ((size_t)(c.taps - 1 - tap) * c.cout + co) * c.cin + ci] = b;                          // data gradient: taps mirrored, ci <-> co
+      }
+    }
+    for (int i = 0; i < 2 * c.cout; ++i) trainable[c.off_bn + 2 * c.cout + i] = 0;                              // running mean / variance
+  }
+  for (int p = 0; p < P; ++p) for (int f = 0; f < npf; ++f) for (int a = 0; a < A; ++a)
+    map[t->wk_pd + ((size_t)p * npf + f) * A + a] = (int)(t->off_pd_w + a + (size_t)A * (p + (size_t)P * f));  // Dense W(out, in), in = p + P f (Flux.flatten of WHC)
+  for (int p = 0; p < P; ++p) for (int f = 0; f < nvf; ++f) for (int o = 0; o < F; ++o)
+    map[t->wk_v1 + ((size_t)p * nvf + f) * F + o] = (int)(t->off_v1_w + o + (size_t)F * (p + (size_t)P * f));
+  for (int o = 0; o < F; ++o) map[t->wk_v2 + o] = (int)(t->off_v2_w + o);
+  AZCHK(tr_alloc(t, &t->map, wk)); AZCHK(tr_alloc(t, &t->work, wk)); AZCHK(tr_alloc(t, &t->gwork, wk, true));
+  AZCHK(tr_alloc(t, &t->blob, t->nparams)); AZCHK(tr_alloc(t, &t->gblob, t->nparams, true));
+  AZCHK(tr_alloc(t, &t->opt_m, t->nparams, true)); AZCHK(tr_alloc(t, &t->opt_v, t->nparams, true));
+  AZCHK(tr_alloc(t, &t->trainable, t->nparams));
+  HIPCHK(hipMemcpyAsync(t->map, map.data(), sizeof(int) * wk, hipMemcpyHostToDevice, t->stream));
+  HIPCHK(hipMemcpyAsync(t->trainable, trainable.data(), t->nparams, hipMemcpyHostToDevice, t->stream));
+  HIPCHK(hipMemcpyAsync(t->blob, t->e->blob.data(), sizeof(float) * t->nparams, hipMemcpyHostToDevice, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));                         // host vectors go out of scope
+  // activations
+  const int ntower = 1 + 2 * t->nblocks;
+  for (size_t l = 0; l < t->convs.size(); ++l) {
+    TrConv& c = t->convs[l];
+    if (c.taps == 9) AZCHK(tr_alloc(t, &c.col, (size_t)R * 9 * c.cin)); else c.col = nullptr;
+    AZCHK(tr_alloc(t, &c.g, (size_t)R * c.cout)); AZCHK(tr_alloc(t, &c.a, (size_t)R * c.cout));
+    AZCHK(tr_alloc(t, &c.mean, c.cout)); AZCHK(tr_alloc(t, &c.invstd, c.cout));
+  }
+  (void)ntower;
+  const int B = t->B;
+  AZCHK(tr_alloc(t, &t->d_idx, B)); AZCHK(tr_alloc(t, &t->bW, B)); AZCHK(tr_alloc(t, &t->bV, B));
+  AZCHK(tr_alloc(t, &t->bX, (size_t)B * C * P)); AZCHK(tr_alloc(t, &t->bA, (size_t)B * A)); AZCHK(tr_alloc(t, &t->bP, (size_t)B * A));
+  AZCHK(tr_alloc(t, &t->logits, (size_t)B * A)); AZCHK(tr_alloc(t, &t->dlogits, (size_t)B * A));
+  AZCHK(tr_alloc(t, &t->v1, (size_t)B * F)); AZCHK(tr_alloc(t, &t->dv1, (size_t)B * F));
+  AZCHK(tr_alloc(t, &t->tpre, B)); AZCHK(tr_alloc(t, &t->dt, B));
+  AZCHK(tr_alloc(t, &t->dact, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dact2, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dcol, (size_t)R * 9 * F));
+  const int nchunks = (int)((R + 255) / 256);
+  AZCHK(tr_alloc(t, &t->part, (size_t)nchunks * 2 * std::max(F, 64))); AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64)));
+  AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 5 + 1024));
+  AZCHK(t->red.init(std::max(B, 1024), t->stream));
+  return AZ_OK;
+}
+
+// column sums of mode MODE over R rows, result in t->sums
+template <int MODE>
+static int tr_colsum(az_trainer* t, const float* x, const float* out_act, const float* g, const float* mean, const float* invstd, long long R, int C) {
+  const int nchunks = (int)((R + 255) / 256);
+  hipLaunchKernelGGL((k_tr_colsum<MODE>), dim3(nchunks, (C + 63) / 64), dim3(64), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part);
+  hipLaunchKernelGGL(k_tr_colsum_final, dim3((C + 63) / 64), dim3(64), 0, t->stream, t->part, nchunks, C, t->sums);
+  return AZ_OK;
+}
+
+// forward (train mode) + loss + backward for the batch idx[0..B); the gradient of the DATA terms is left in t->gblob
+// (blob layout, L2 term not included), *loss_out = L of `losses` including Lreg.
+static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_out, float* parts_out /* Lp, Lv, Lreg, Linv or NULL */) {
+  const GameInfo& gi = t->gi;
+  const int F = t->F, C = gi.C, P = gi.P, A = gi.A, npf = t->npf, nvf = t->nvf, B = t->B;
+  const long long R = t->R;
+  hipStream_t st = t->stream;
+  az_dataset* d = t->d;
+  const int ntower = 1 + 2 * t->nblocks;
+  TrConv& hp = t->convs[ntower];
+  TrConv& hv = t->convs[ntower + 1];
+  float* blob = t->blob;
+  HIPCHK(hipMemcpyAsync(t->d_idx, idx_host, sizeof(int) * B, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_tr_batch, dim3(B), dim3(64), 0, st, t->d_idx, B, C * P, A, d->d_W, d->d_X, d->d_A, d->d_P, d->d_V, t->bW, t->bX, t->bA, t->bP, t->bV);
+  hipLaunchKernelGGL(k_tr_gather, dim3(tr_grid((long long)t->nwork)), dim3(256), 0, st, blob, t->map, (long long)t->nwork, t->work);
+  HIPCHK(hipMemsetAsync(t->gblob, 0, sizeof(float) * t->nparams, st));
+  // ---------------- forward ----------------
+  for (int l = 0; l < ntower; ++l) {
+    TrConv& c = t->convs[l];
+    const float* in = l == 0 ? t->bX : t->convs[l - 1].a;
+    if (l == 0) hipLaunchKernelGGL((k_tr_im2col<true>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
+    else hipLaunchKernelGGL((k_tr_im2col<false>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
+    AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
+    AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout));
+    hipLaunchKernelGGL(k_tr_bn_stats, dim3((c.cout + 63) / 64), dim3(64), 0, st, t->sums, R, c.cout, t->cfg.batch_norm_momentum, blob + c.off_b, c.mean, c.invstd,
+                       blob + c.off_bn + 2 * c.cout, blob + c.off_bn + 3 * c.cout);
+    const bool second = l > 0 && (l % 2) == 0;                     // conv2 of a block: skip connection from the block input
+    const float* res = second ? t->convs[l - 2].a : nullptr;
+    hipLaunchKernelGGL(k_tr_bn_apply, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, c.g, c.mean, c.invstd, blob + c.off_bn, blob + c.off_bn + c.cout, res, R * c.cout, c.cout, c.a);
+  }
+  const float* trunk = t->convs[ntower - 1].a;
+  for (TrConv* c : {&hp, &hv}) {
+    AZCHK(rb::gemm(t->rbh, false, false, (int)R, c->cout, F, 1.f, trunk, F, t->work + c->wk_wm, c->cout, 0.f, c->g, c->cout));
+    AZCHK(tr_colsum<0>(t, c->g, nullptr, nullptr, nullptr, nullptr, R, c->cout));
+    hipLaunchKernelGGL(k_tr_bn_stats, dim3((c->cout + 63) / 64), dim3(64), 0, st, t->sums, R, c->cout, t->cfg.batch_norm_momentum, blob + c->off_b, c->mean, c->invstd,
+                       blob + c->off_bn + 2 * c->cout, blob + c->off_bn + 3 * c->cout);
+    hipLaunchKernelGGL(k_tr_bn_apply, dim3(tr_grid(R * c->cout)), dim3(256), 0, st, c->g, c->mean, c->invstd, blob + c->off_bn, blob + c->off_bn + c->cout, (const float*)nullptr, R * c->cout, c->cout, c->a);
+  }
+  // dense heads: rows of hp.a / hv.a of one board are contiguous: [B][P*nf] with k = p*nf + f
+  AZCHK(rb::gemm(t->rbh, false, false, B, A, P * npf, 1.f, hp.a, P * npf, t->work + t->wk_pd, A, 0.f, t->logits, A));
+  hipLaunchKernelGGL(k_tr_bias_act, dim3(tr_grid((long long)B * A)), dim3(256), 0, st, t->logits, blob + t->off_pd_b, (long long)B * A, A, 0);
+  AZCHK(rb::gemm(t->rbh, false, false, B, F, P * nvf, 1.f, hv.a, P * nvf, t->work + t->wk_v1, F, 0.f, t->v1, F));
+  hipLaunchKernelGGL(k_tr_bias_act, dim3(tr_grid((long long)B * F)), dim3(256), 0, st, t->v1, blob + t->off_v1_b, (long long)B * F, F, 1);
+  AZCHK(rb::gemm(t->rbh, false, false, B, 1, F, 1.f, t->v1, F, t->work + t->wk_v2, 1, 0.f, t->tpre, 1));
+  hipLaunchKernelGGL(k_tr_bias_act, dim3(tr_grid(B)), dim3(256), 0, st, t->tpre, blob + t->off_v2_b, (long long)B, 1, 0);
+  // ---------------- loss ----------------
+  hipLaunchKernelGGL(k_f32_to_f64, dim3(tr_grid(B)), dim3(256), 0, st, t->bW, (long long)B, t->terms);
+  DevReducer& red = t->red;
+  double sw;
+  AZCHK(red.sum(t->terms, B, st, &sw));
+  const float scale = (float)(sw / (double)B) / d->Wmean;          // mean(W) / Wmean, learning.jl:88
+  double *tw = t->terms, *tkl = t->terms + B, *tmse = t->terms + 2 * (size_t)B, *tinv = t->terms + 3 * (size_t)B;
+  hipLaunchKernelGGL(k_tr_loss, dim3(tr_grid(B)), dim3(256), 0, st, t->logits, t->tpre, t->bA, t->bP, t->bV, t->bW, B, A,
+                     (float)t->cfg.nonvalidity_penalty, (float)t->cfg.rewards_renormalization, scale / (float)sw, t->dlogits, t->dt, tw, tkl, tmse, tinv);
+  double kl, mse, inv, ssq = 0.0;
+  AZCHK(red.sum(tkl, B, st, &kl)); AZCHK(red.sum(tmse, B, st, &mse)); AZCHK(red.sum(tinv, B, st, &inv));
+  {
+    hipLaunchKernelGGL(k_tr_sumsq, dim3(1024), dim3(256), 0, st, blob, t->trainable, (long long)t->nparams, t->bsums + 5);
+    AZCHK(red.sum(t->bsums + 5, 1024, st, &ssq));
+  }
+  const float Lp = (float)(-kl / sw) - d->Hp;
+  const float Lv = (float)(mse / sw);
+  const float Lreg = t->cfg.l2_regularization == 0.0 ? 0.f : (float)((double)(float)t->cfg.l2_regularization * ssq);
+  const float Linv = t->cfg.nonvalidity_penalty == 0.0 ? 0.f : (float)t->cfg.nonvalidity_penalty * (float)(inv / sw);
+  *loss_out = scale * (Lp + Lv + Lreg + Linv);
+  if (parts_out) { parts_out[0] = Lp; parts_out[1] = Lv; parts_out[2] = Lreg; parts_out[3] = Linv; parts_out[4] = scale; }
+  // ---------------- backward: dense heads ----------------
+  float* gw = t->gwork;
+  float* gb = t->gblob;
+  // policy: dWpd = hp_flat^T dlogits ; dbp = colsum(dlogits) ; dhp = dlogits Wpd^T
+  AZCHK(rb::gemm(t->rbh, true, false, P * npf, A, B, 1.f, hp.a, P * npf, t->dlogits, A, 0.f, gw + t->wk_pd, A));
+  AZCHK(tr_colsum<2>(t, t->dlogits, nullptr, nullptr, nullptr, nullptr, B, A));
+  hipLaunchKernelGGL(k_tr_store_sum0, dim3(1), dim3(64), 0, st, t->sums, A, gb + t->off_pd_b);
+  float* dhp = t->dact;                                            // [R][npf]
+  AZCHK(rb::gemm(t->rbh, false, true, B, P * npf, A, 1.f, t->dlogits, A, t->work + t->wk_pd, A, 0.f, dhp, P * npf));
+  // value: dt -> dv1 = (dt wv2^T) .* (v1 > 0) ; dwv2 = v1^T dt ; db2 = sum dt ; dWv1 = hv_flat^T dv1 ; db1 ; dhv = dv1 Wv1^T
+  AZCHK(rb::gemm(t->rbh, true, false, F, 1, B, 1.f, t->v1, F, t->dt, 1, 0.f, gw + t->wk_v2, 1));
+  AZCHK(tr_colsum<2>(t, t->dt, nullptr, nullptr, nullptr, nullptr, B, 1));
+  hipLaunchKernelGGL(k_tr_store_sum0, dim3(1), dim3(64), 0, st, t->sums, 1, gb + t->off_v2_b);
+  AZCHK(rb::gemm(t->rbh, false, true, B, F, 1, 1.f, t->dt, 1, t->work + t->wk_v2, 1, 0.f, t->dv1, F));
+  hipLaunchKernelGGL(k_tr_relu_bwd, dim3(tr_grid((long long)B * F)), dim3(256), 0, st, t->dv1, t->v1, (long long)B * F);
+  AZCHK(rb::gemm(t->rbh, true, false, P * nvf, F, B, 1.f, hv.a, P * nvf, t->dv1, F, 0.f, gw + t->wk_v1, F));
+  AZCHK(tr_colsum<2>(t, t->dv1, nullptr, nullptr, nullptr, nullptr, B, F));
+  hipLaunchKernelGGL(k_tr_store_sum0, dim3((F + 63) / 64), dim3(64), 0, st, t->sums, F, gb + t->off_v1_b);
+  float* dhv = t->dact2;                                           // [R][nvf]
+  AZCHK(rb::gemm(t->rbh, false, true, B, P * nvf, F, 1.f, t->dv1, F, t->work + t->wk_v1, F, 0.f, dhv, P * nvf));
+  // head convolutions: BN backward, weight / bias gradients, gradient into the trunk
+  float* dtrunk = t->dcol;                                         // [R][F] (front of the big scratch)
+  bool first = true;
+  for (TrConv* c : {&hp, &hv}) {
+    float* dh = c == &hp ? dhp : dhv;
+    AZCHK(tr_colsum<1>(t, dh, c->a, c->g, c->mean, c->invstd, R, c->cout));
+    hipLaunchKernelGGL(k_tr_bn_param_grads, dim3((c->cout + 63) / 64), dim3(64), 0, st, t->sums, c->cout, gb + c->off_bn, gb + c->off_bn + c->cout);
+    hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c->cout)), dim3(256), 0, st, dh, c->a, c->g, c->mean, c->invstd, blob + c->off_bn, t->sums, R, R * c->cout, c->cout, dh, (float*)nullptr);
+    AZCHK(rb::gemm(t->rbh, true, false, F, c->cout, (int)R, 1.f, trunk, F, dh, c->cout, 0.f, gw + c->wk_wm, c->cout));
+    AZCHK(tr_colsum<2>(t, dh, nullptr, nullptr, nullptr, nullptr, R, c->cout));
+    hipLaunchKernelGGL(k_tr_store_sum0, dim3((c->cout + 63) / 64), dim3(64), 0, st, t->sums, c->cout, gb + c->off_b);
+    AZCHK(rb::gemm(t->rbh, false, true, (int)R, F, c->cout, 1.f, dh, c->cout, t->work + c->wk_wm, c->cout, first ? 0.f : 1.f, dtrunk, F));
+    first = false;
+  }
+  // ---------------- backward: tower ----------------
+  // da = gradient w.r.t. the activation convs[l].a; kept in dact; dskip (block input share) in dact2
+  HIPCHK(hipMemcpyAsync(t->dact, dtrunk, sizeof(float) * (size_t)R * F, hipMemcpyDeviceToDevice, st));
+  for (int l = ntower - 1; l >= 0; --l) {
+    TrConv& c = t->convs[l];
+    const bool second = l > 0 && (l % 2) == 0;
+    AZCHK(tr_colsum<1>(t, t->dact, c.a, c.g, c.mean, c.invstd, R, c.cout));
+    hipLaunchKernelGGL(k_tr_bn_param_grads, dim3((c.cout + 63) / 64), dim3(64), 0, st, t->sums, c.cout, gb + c.off_bn, gb + c.off_bn + c.cout);
+    // dg overwrites dact; for conv2 the masked gradient dy also flows to the block input (dact2)
+    hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, t->dact, c.a, c.g, c.mean, c.invstd, blob + c.off_bn, t->sums, R, R * c.cout, c.cout,
+                       t->dact, second ? t->dact2 : (float*)nullptr);
+    AZCHK(rb::gemm(t->rbh, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, t->dact, c.cout, 0.f, gw + c.wk_wm, c.cout));
+    AZCHK(tr_colsum<2>(t, t->dact, nullptr, nullptr, nullptr, nullptr, R, c.cout));
+    hipLaunchKernelGGL(k_tr_store_sum0, dim3((c.cout + 63) / 64), dim3(64), 0, st, t->sums, c.cout, gb + c.off_b);
+    if (l == 0) break;
+    // data gradient: da_prev = im2col(dg) * Wrot
+    hipLaunchKernelGGL((k_tr_im2col<false>), dim3(tr_grid(R * 9 * c.cout)), dim3(256), 0, st, t->dact, R, c.cout, gi.W, gi.H, t->dcol);
+    AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cin, 9 * c.cout, 1.f, t->dcol, 9 * c.cout, t->work + c.wk_wrot, c.cin, 0.f, t->dact, c.cin));
+    const bool first_of_block = (l % 2) == 1;                      // conv1: its input is the block input, which also gets the skip share
+    if (first_of_block) hipLaunchKernelGGL(k_tr_add, dim3(tr_grid(R * F)), dim3(256), 0, st, t->dact, t->dact2, R * F);
+  }
+  // working-layout weight gradients -> blob layout (the rotated copies carry no gradient of their own: their slots in
+  // gwork stay zero and map to the same blob entries, so scatter only the primary ranges)
+  for (const TrConv& c : t->convs)
+    hipLaunchKernelGGL(k_tr_scatter, dim3(tr_grid((long long)c.taps * c.cin * c.cout)), dim3(256), 0, st, gw + c.wk_wm, t->map + c.wk_wm, (long long)c.taps * c.cin * c.cout, gb);
+  const long long ndense = (long long)(t->nwork - t->wk_pd);
+  hipLaunchKernelGGL(k_tr_scatter, dim3(tr_grid(ndense)), dim3(256), 0, st, gw + t->wk_pd, t->map + t->wk_pd, ndense, gb);
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  return AZ_OK;
+}
+
+static void tr_next_batch(az_trainer* t, std::vector<int>& idx) {
+  // Flux.DataLoader(shuffle = true, partial = false) cycled (learning.jl:114-119): a fresh permutation per epoch,
+  // Fisher-Yates driven by the RNG contract's shuffle stream (seed; epoch)
+  const int64_t n = t->d->n;
+  idx.resize(t->B);
+  if (t->perm.empty() || t->perm_pos + t->B > n) {
+    t->perm.resize(n);
+    for (int64_t i = 0; i < n; ++i) t->perm[i] = (int)i;
+    az_rng r = az_rng_make(t->cfg.seed, (uint32_t)t->epoch, 0, AZ_RNG_SHUFFLE);
+    for (int64_t i = n - 1; i > 0; --i) {
+      int64_t j = (int64_t)(az_rng_f64(&r) * (double)(i + 1));
+      if (j > i) j = i;
+      std::swap(t->perm[i], t->perm[j]);
+    }
+    t->perm_pos = 0; t->epoch++;
+  }
+  for (int b = 0; b < t->B; ++b) idx[b] = t->perm[t->perm_pos + b];
+  t->perm_pos += t->B;
+}
+
+extern "C" int az_trainer_create(az_engine* e, az_dataset* d, const az_train_cfg* cfg, az_trainer** out) {
+  ENGINE(e);
+  if (!d || !cfg || !out) return fail(AZ_ERR_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(az_train_cfg)) return fail(AZ_ERR_BAD_ARG, "az_train_cfg size mismatch: call az_train_cfg_init");
+  if (e->cfg.oracle != AZ_ORACLE_RESNET || !e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
+  if (d->game != e->cfg.game || d->device != e->device) return fail(AZ_ERR_BAD_ARG, "data set and engine differ in game or device");
+  if (cfg->optimiser != AZ_OPT_ADAM && cfg->optimiser != AZ_OPT_CYCLIC_NESTEROV) return fail(AZ_ERR_BAD_ARG, "unknown optimiser %d", cfg->optimiser);
+  const int64_t B = std::min<int64_t>(cfg->batch_size, d->n);     // batchsize = min(params.batch_size, length(W)), learning.jl:113
+  if (cfg->batch_size < 2 || B < 2) return fail(AZ_ERR_BAD_ARG, "batch_size and the data set must have at least 2 samples (batch statistics)");
+  if (!(cfg->rewards_renormalization > 0.0)) return fail(AZ_ERR_BAD_ARG, "rewards_renormalization must be > 0");
+  AZCHK(rb::load());
+  az_trainer* t = new (std::nothrow) az_trainer();
+  if (!t) return fail(AZ_ERR_HIP, "out of host memory");
+  t->e = e; t->d = d; t->cfg = *cfg; t->game = e->cfg.game; t->device = e->device; t->gi = e->gi; t->stream = nullptr; t->rbh = nullptr;
+  t->B = (int)B; t->nblocks = e->cfg.num_blocks; t->F = e->cfg.num_filters; t->npf = e->cfg.num_policy_head_filters; t->nvf = e->cfg.num_value_head_filters;
+  t->nA = e->gi.A; t->R = (long long)B * e->gi.P; t->nparams = e->blob.size();
+  t->perm_pos = 0; t->epoch = 0; t->step = 0; t->b1t = 1.0f; t->b2t = 1.0f;
+  int st = [&]() -> int {
+    HIPCHK(hipStreamCreate(&t->stream));
+    if (rb::g_lib.create(&t->rbh) != 0) return fail(AZ_ERR_HIP, "rocblas_create_handle failed");
+    rb::g_lib.set_stream(t->rbh, t->stream);
+    if (rb::g_lib.set_atomics) rb::g_lib.set_atomics(t->rbh, 0);   // rocblas_atomics_not_allowed: reproducible GEMMs
+    AZCHK(trainer_build(t));
+    return AZ_OK;
+  }();
+  if (st != AZ_OK) { az_trainer_destroy(t); return st; }
+  *out = t;
+  return AZ_OK;
+}
+
+#define TRAINER(t) if (!(t)) return fail(AZ_ERR_BAD_ARG, "trainer is NULL"); HIPCHK(hipSetDevice((t)->device))
+
+// loss and data gradient (blob layout, WITHOUT the L2 term) of one given batch; no update.  parts = Lp, Lv, Lreg, Linv, scale.
+extern "C" int az_trainer_gradients(az_trainer* t, const int32_t* sample_idx, float* loss, float* parts, float* grad, int64_t n) {
+  TRAINER(t);
+  if (!sample_idx || !loss) return fail(AZ_ERR_BAD_ARG, "NULL argument");
+  for (int b = 0; b < t->B; ++b) if (sample_idx[b] < 0 || sample_idx[b] >= t->d->n) return fail(AZ_ERR_BAD_ARG, "sample index %d out of range", sample_idx[b]);
+  if (grad && n != (int64_t)t->nparams) return fail(AZ_ERR_BAD_ARG, "gradient buffer must hold %zu floats", t->nparams);
+  // the running statistics must not move in a gradient probe: save / restore them around the pass
+  std::vector<float> saved(t->nparams);
+  HIPCHK(hipMemcpy(saved.data(), t->blob, sizeof(float) * t->nparams, hipMemcpyDeviceToHost));
+  AZCHK(tr_forward_backward(t, sample_idx, loss, parts));
+  if (grad) HIPCHK(hipMemcpy(grad, t->gblob, sizeof(float) * t->nparams, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(t->blob, saved.data(), sizeof(float) * t->nparams, hipMemcpyHostToDevice));
+  return AZ_OK;
+}
+
+// batch_updates!(tr, n) (learning.jl:131-141): n optimiser steps on successive batches; losses[i] = L before update i
+extern "C" int az_trainer_batch_updates(az_trainer* t, int32_t n, float* losses) {
+  TRAINER(t);
+  if (n < 0) return fail(AZ_ERR_BAD_ARG, "n must be >= 0");
+  std::vector<int> idx;
+  for (int i = 0; i < n; ++i) {
+    tr_next_batch(t, idx);
+    float L, parts[5];
+    AZCHK(tr_forward_backward(t, idx.data(), &L, parts));
+    if (losses) losses[i] = L;
+    const float reg2 = parts[4] * 2.0f * (float)t->cfg.l2_regularization;      // d/dw of scale * creg * sum(w^2)
+    if (t->cfg.optimiser == AZ_OPT_ADAM) {
+      t->b1t *= 0.9f; t->b2t *= 0.999f;
+      hipLaunchKernelGGL(k_tr_adam, dim3(tr_grid((long long)t->nparams)), dim3(256), 0, t->stream, t->blob, t->gblob, t->opt_m, t->opt_v, t->trainable,
+                         (long long)t->nparams, t->cfg.lr, t->b1t, t->b2t, reg2);
+    } else {
+      // lr = CyclicSchedule(lr_base, lr_high, lr_low; n), momentum = CyclicSchedule(momentum_high, momentum_low,
+      // momentum_high; n) (flux.jl:78-94); CyclicSchedule = PLSchedule([1, floor(.45 n), floor(.9 n), n], [base, mid, base,
+      // term]) (schedule.jl:130-134).  Flux.adjust! follows update!, so step i (1-based) runs with the values of index i-1
+      // and the first step with Nesterov(lr_low, momentum_high).
+      auto cyc = [&](double base, double mid, double term, int k) -> float {
+        const int xs[4] = {1, (int)(0.45 * n), (int)(0.90 * n), n};
+        const double ys[4] = {base, mid, base, term};
+        int pt = -1;
+        for (int q = 0; q < 4; ++q) if (xs[q] <= k) pt = q;
+        if (pt < 0) return (float)ys[0];
+        if (pt == 3) return (float)ys[3];
+        if (xs[pt + 1] == xs[pt]) return (float)ys[pt];
+        return (float)(ys[pt] + (ys[pt + 1] - ys[pt]) / (double)(xs[pt + 1] - xs[pt]) * (double)(k - xs[pt]));
+      };
+      const float lr = i == 0 ? t->cfg.lr_low : cyc(t->cfg.lr_base, t->cfg.lr_high, t->cfg.lr_low, i);
+      const float rho = i == 0 ? t->cfg.momentum_high : cyc(t->cfg.momentum_high, t->cfg.momentum_low, t->cfg.momentum_high, i);
+      hipLaunchKernelGGL(k_tr_nesterov, dim3(tr_grid((long long)t->nparams)), dim3(256), 0, t->stream, t->blob, t->gblob, t->opt_m, t->trainable,
+                         (long long)t->nparams, lr, rho, reg2);
+    }
+    t->step++;
+  }
+  HIPCHK(hipStreamSynchronize(t->stream));
+  HIPCHK(hipGetLastError());
+  return AZ_OK;
+}
+
+// get_trained_network (learning.jl:127-129): the current parameters (Flux order, running statistics included)
+extern "C" int az_trainer_get_params(az_trainer* t, float* blob, int64_t n) {
+  TRAINER(t);
+  if (!blob || n != (int64_t)t->nparams) return fail(AZ_ERR_BAD_ARG, "blob must hold %zu floats", t->nparams);
+  HIPCHK(hipMemcpy(blob, t->blob, sizeof(float) * t->nparams, hipMemcpyDeviceToHost));
+  return AZ_OK;
+}

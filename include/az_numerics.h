@@ -170,6 +170,9 @@ AZ_HD void az_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32
 #define AZ_RNG_ROLLOUT 4u /* MCTS.RolloutOracle's random playout (src/mcts.jl:41-50): simulation i of an explore!
                              owns draws i*1024 .. i*1024+1023; ply k picks available action floor(u_k * n) */
 
+#define AZ_RNG_SHUFFLE 5u /* DataLoader(shuffle = true) of the Trainer (src/learning.jl:114-119): "game" word = epoch,
+                             Fisher-Yates from the last index down, draw k swaps i with floor(u_k * (i + 1)) */
+
 typedef struct {
   uint32_t key[2];   /* 64-bit seed */
   uint32_t ctr[4];   /* game id, move index, purpose, draw index */

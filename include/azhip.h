@@ -278,6 +278,35 @@ typedef struct { float L, Lp, Lv, Lreg, Linv, Hp, Hpnet; } az_learning_status_t;
 int az_learning_status(az_engine* e, az_dataset* d, double l2_regularization, double nonvalidity_penalty,
                        double rewards_renormalization, int64_t loss_computation_batch_size, az_learning_status_t* out);
 
+/* ---- the optimiser step (src/learning.jl:123-141, src/networks/flux.jl:68-95) --------------- */
+typedef struct az_trainer az_trainer;   /* Trainer (src/learning.jl:98-121): network in train mode + optimiser state */
+typedef enum { AZ_OPT_ADAM = 0, AZ_OPT_CYCLIC_NESTEROV = 1 } az_optimiser;   /* src/networks/network.jl:163-190 */
+typedef struct {
+  int32_t struct_size;        /* = sizeof(az_train_cfg), set by az_train_cfg_init */
+  int32_t optimiser;          /* az_optimiser */
+  float lr;                   /* Adam(lr) */
+  float lr_base, lr_high, lr_low, momentum_low, momentum_high;   /* CyclicNesterov */
+  double l2_regularization, nonvalidity_penalty, rewards_renormalization;   /* LearningParams, src/params.jl:235-248 */
+  int32_t batch_size;         /* min(batch_size, #samples) is used (src/learning.jl:113) */
+  float batch_norm_momentum;  /* ResNetHP.batch_norm_momentum (resnet.jl:30-37) */
+  uint64_t seed;              /* batch shuffling (AZ_RNG_SHUFFLE) */
+} az_train_cfg;
+int az_train_cfg_init(az_train_cfg* cfg);
+/* Trainer(gspec, network, samples, params): the engine supplies the architecture and the initial parameters, the
+ * data set (az_dataset_create) the converted samples, Wmean and Hp.  The engine's own network is not modified:
+ * fetch the result with az_trainer_get_params and install it with az_net_set_params. */
+int az_trainer_create(az_engine* e, az_dataset* d, const az_train_cfg* cfg, az_trainer** out);
+int az_trainer_destroy(az_trainer* t);
+/* batch_updates!(tr, n): n optimiser steps (forward in train mode = BatchNorm with batch statistics, `losses`,
+ * backward, Adam / Nesterov with the L2 term, running statistics) on successive shuffled batches (DataLoader
+ * partial = false, cycled); losses[i] = L of step i before its update (Network.train! callback). */
+int az_trainer_batch_updates(az_trainer* t, int32_t n, float* losses);
+int az_trainer_get_params(az_trainer* t, float* blob, int64_t n);   /* get_trained_network (src/learning.jl:127-129) */
+/* Parity hook: loss and data gradient (Flux parameter order, running-statistics entries 0, L2 term excluded) of the batch
+ * made of the given batch_size sample indices; no update, running statistics untouched.
+ * parts (may be NULL) = Lp, Lv, Lreg, Linv, mean(W)/Wmean. */
+int az_trainer_gradients(az_trainer* t, const int32_t* sample_idx, float* loss, float* parts, float* grad, int64_t n);
+
 /* ---- profiling (bench.py roofline): HIP-event time per kernel class ---------------------- */
 #define AZ_PROF_NUM 8
 typedef enum {

@@ -1,0 +1,181 @@
+"""The optimiser step on the device (az_trainer_*; src/learning.jl:59-141, src/networks/flux.jl:68-95) against an
+independent fp64 torch restatement: train-mode forward (BatchNorm with batch statistics), `losses`, autograd gradients
+in Flux parameter order, Adam trajectories, running statistics.  Floating point: fp32 device vs fp64 reference, the
+tolerances are relative to the largest gradient entry of each parameter array."""
+import numpy as np
+import pytest
+import torch
+
+import azref as R
+from azhip.network import param_layout, split_params
+
+pytestmark = pytest.mark.gpu
+EPS32 = float(np.finfo(np.float32).eps)
+SPECS = {0: "ConnectFourSpec", 1: "TicTacToeSpec", 2: "MancalaSpec"}
+
+
+def _memory(game, ngames, seed):
+    import azhip
+    gspec = getattr(azhip, SPECS[game])()
+    with azhip.Engine(game=game, oracle=azhip.ORACLE_HASH, num_workers=8, batch_size=8, num_iters_per_turn=16,
+                      dirichlet_noise_eps=0.25, cpuct=1.0, reset_every=1, temperature=([0], [1.0]), seed=seed,
+                      max_moves_per_game=200 if game == 2 else 0) as e:
+        games, moves, ng, nm, _ = e.selfplay_run(ngames)
+    mem = azhip.MemoryBuffer(gspec, 100000)
+    mem.push_records(games, moves, ng, nm, 1.0)
+    return gspec, mem
+
+
+class TorchNet:
+    """fp64 restatement of the Flux ResNet in TRAIN mode + `losses` (learning.jl:67-90), parameters in Julia shapes"""
+
+    def __init__(self, game, hp, blob):
+        self.game, self.hp = game, hp
+        self.names = [n for n, _ in param_layout(game, hp)]
+        self.p = {k: torch.tensor(np.ascontiguousarray(v), dtype=torch.float64, requires_grad=not (k.endswith(".mean") or k.endswith(".var")))
+                  for k, v in split_params(game, hp, blob).items()}
+        self.batch_stats = {}
+
+    def blob(self, grads=False):
+        out = []
+        for n in self.names:
+            t = self.p[n]
+            a = (t.grad if grads else t.detach()) if (not grads or t.requires_grad) else None
+            a = np.zeros(tuple(t.shape)) if a is None else a.numpy()
+            out.append(np.asarray(a).reshape(-1, order="F"))
+        return np.concatenate(out)
+
+    def _conv(self, x, pre, pad):
+        W, b = self.p[pre + ".W"], self.p[pre + ".b"]
+        return torch.nn.functional.conv2d(x, W.flip(0, 1).permute(3, 2, 1, 0).contiguous(), b, padding=pad)
+
+    def _bn(self, x, pre):
+        g, be = self.p[pre + ".gamma"], self.p[pre + ".beta"]
+        mu = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        self.batch_stats[pre] = (mu.detach(), var.detach(), x.numel() // x.shape[1])
+        s = (1, -1, 1, 1)
+        return g.view(s) * (x - mu.view(s)) / torch.sqrt(var.view(s) + 1e-5) + be.view(s)
+
+    def forward(self, X):
+        x = torch.relu(self._bn(self._conv(X, "stem.conv", 1), "stem.bn"))
+        for b in range(self.hp.num_blocks):
+            y = torch.relu(self._bn(self._conv(x, "block%d.conv1" % b, 1), "block%d.bn1" % b))
+            y = self._bn(self._conv(y, "block%d.conv2" % b, 1), "block%d.bn2" % b)
+            x = torch.relu(y + x)
+        N = x.shape[0]
+        hp_ = torch.relu(self._bn(self._conv(x, "phead.conv", 0), "phead.bn")).reshape(N, -1)
+        logits = hp_ @ self.p["phead.dense.W"].T + self.p["phead.dense.b"]
+        hv = torch.relu(self._bn(self._conv(x, "vhead.conv", 0), "vhead.bn")).reshape(N, -1)
+        v1 = torch.relu(hv @ self.p["vhead.dense1.W"].T + self.p["vhead.dense1.b"])
+        val = torch.tanh(v1 @ self.p["vhead.dense2.W"].T + self.p["vhead.dense2.b"]).reshape(N)
+        return torch.softmax(logits, dim=1), val
+
+    def losses(self, batch, Wmean, Hp, l2, cinv, rho):
+        W, X, A, P, V = [torch.tensor(np.asarray(x), dtype=torch.float64) for x in batch]
+        pol, val = self.forward(X)
+        pm = pol * A
+        sp = pm.sum(dim=1, keepdim=True)
+        Ph = pm / (sp + EPS32)
+        pinv = (1 - sp).reshape(-1)
+        Lp = -(P * torch.log(Ph + EPS32) * W[:, None]).sum() / W.sum() - Hp
+        Lv = (((val / rho - V / rho) ** 2) * W).sum() / W.sum()
+        Lreg = l2 * sum((t ** 2).sum() for t in self.p.values() if t.requires_grad)
+        Linv = cinv * (pinv * W).sum() / W.sum()
+        scale = W.mean() / Wmean
+        return scale * (Lp + Lv + Lreg + Linv), (Lp, Lv, Lreg, Linv, scale)
+
+
+def _rel_err_by_array(game, hp, got, want):
+    worst, off = 0.0, 0
+    for name, shape in param_layout(game, hp):
+        n = int(np.prod(shape))
+        g, w = got[off:off + n], want[off:off + n]
+        off += n
+        if name.endswith(".mean") or name.endswith(".var"):
+            assert not g.any()
+            continue
+        denom = max(np.abs(w).max(), 1e-7)
+        worst = max(worst, np.abs(g - w).max() / denom) if np.abs(w).max() > 1e-6 else worst
+        assert np.abs(g - w).max() <= 5e-3 * denom + 2e-6, (name, np.abs(g - w).max(), denom)
+    return worst
+
+
+@pytest.mark.parametrize("game,nblocks,F,B,policy", [(1, 1, 64, 24, 1), (0, 2, 64, 16, 0), (2, 1, 64, 20, 2), (0, 1, 128, 12, 1)])
+def test_gradients_match_torch_autograd(game, nblocks, F, B, policy):
+    import azhip
+    gspec, mem = _memory(game, 12, 3)
+    hp = azhip.ResNetHP(num_blocks=nblocks, num_filters=F, num_policy_head_filters=32, num_value_head_filters=32)
+    nn = azhip.ResNet(gspec, hp, seed=8)
+    lp = azhip.LearningParams(samples_weighing_policy=policy, l2_regularization=1e-4, loss_computation_batch_size=64, batch_size=B,
+                              rewards_renormalization=2.0, nonvalidity_penalty=1.0)
+    with azhip.Trainer(gspec, nn, mem, lp, use_symmetries=game != 2) as tr:
+        data = tr.data.tensors()
+        n = len(data[0])
+        rng = np.random.default_rng(5)
+        idx = rng.choice(n, size=B, replace=False)
+        loss, parts, grad = tr.gradients(idx)
+        batch = [x[idx] for x in data]
+        ref = TorchNet(game, hp, nn.params())
+        L, (Lp, Lv, Lreg, Linv, scale) = ref.losses(batch, float(tr.Wmean), float(tr.Hp), 1e-4, 1.0, 2.0)
+        (L - scale * Lreg).backward()                              # the device gradient excludes the L2 term (added in the update)
+        want = ref.blob(grads=True)
+        assert abs(loss - float(L)) < 2e-5 * max(1.0, abs(float(L)))
+        assert np.allclose(parts, [float(Lp), float(Lv), float(Lreg), float(Linv), float(scale)], rtol=5e-5, atol=5e-6), (parts, float(Lp), float(Lv))
+        _rel_err_by_array(game, hp, grad.astype(np.float64), want)
+        # the probe does not move the parameters or the running statistics
+        assert np.array_equal(tr.trained_params(), nn.params())
+    mem.close()
+
+
+def test_adam_steps_follow_torch():
+    """batch_updates!: three Adam steps on the device vs torch.optim.Adam on the fp64 restatement (same batches through the
+    shuffling contract), incl. the L2 term and the BatchNorm running statistics (momentum 0.1, unbiased running variance)"""
+    import azhip
+    game, B = 1, 32
+    gspec, mem = _memory(game, 24, 4)
+    hp = azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    nn = azhip.ResNet(gspec, hp, seed=2)
+    lp = azhip.LearningParams(samples_weighing_policy=1, l2_regularization=1e-3, loss_computation_batch_size=64, batch_size=B,
+                              optimiser=azhip.Adam(lr=1e-3))
+    with azhip.Trainer(gspec, nn, mem, lp, use_symmetries=True) as tr:
+        data = tr.data.tensors()
+        n = len(data[0])
+        st0 = tr.learning_status()
+        ls = tr.batch_updates(3, seed=11)
+        got = tr.trained_params()
+        # replay the contract's shuffle: Fisher-Yates from the last index, draw k -> floor(u * (i + 1)), purpose 5, game word = epoch
+        from test_arena_oracle import _u64
+        perm = list(range(n))
+        for k, i in enumerate(range(n - 1, 0, -1)):
+            j = min(int(_u64(11, 0, 0, 5, k) * (i + 1)), i)
+            perm[i], perm[j] = perm[j], perm[i]
+        ref = TorchNet(game, hp, nn.params())
+        train = [t for t in ref.p.values() if t.requires_grad]
+        opt = torch.optim.Adam(train, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+        run = {k: v.detach().clone() for k, v in ref.p.items() if k.endswith(".mean") or k.endswith(".var")}
+        losses = []
+        for s in range(3):
+            idx = perm[s * B:(s + 1) * B]
+            opt.zero_grad()
+            L, _ = ref.losses([x[idx] for x in data], float(tr.Wmean), float(tr.Hp), 1e-3, 1.0, 1.0)
+            L.backward()
+            opt.step()
+            losses.append(float(L))
+            for pre, (mu, var, m) in ref.batch_stats.items():
+                run[pre + ".mean"] = 0.9 * run[pre + ".mean"] + 0.1 * mu
+                run[pre + ".var"] = 0.9 * run[pre + ".var"] + 0.1 * var * (m / (m - 1))
+        for k, v in run.items():
+            ref.p[k] = v
+        want = ref.blob()
+        assert np.allclose(ls, losses, rtol=2e-4, atol=2e-5), (ls, losses)
+        assert np.abs(got - want).max() < 2e-4, np.abs(got - want).max()
+        assert np.abs(got - nn.params()).max() > 5e-4               # it did move (3 steps of lr 1e-3)
+        # installing the trained parameters lowers the loss on the training data
+        nn2 = azhip.ResNet(gspec, hp, params=got)
+    with azhip.Trainer(gspec, nn2, mem, lp, use_symmetries=True) as tr2:
+        more = tr2.batch_updates(40, seed=11)
+        st1 = tr2.learning_status()
+    assert np.isfinite(more).all() and more[-5:].mean() < more[:5].mean()
+    assert st0.loss.L == pytest.approx(st0.loss.L) and np.isfinite(st1.loss.L)
+    mem.close()
