@@ -25,6 +25,9 @@ class LearningParams:
     rewards_renormalization: float = 1.0
     nonvalidity_penalty: float = 1.0
     optimiser: object = None
+    min_checkpoints_per_epoch: int = 1
+    max_batches_per_checkpoint: int = 2000
+    num_checkpoints: int = 1
 
 
 @dataclass
@@ -157,8 +160,15 @@ class Trainer:
     def num_batches_total(self):
         return self.num_samples() // self.params.batch_size
 
+    def install_trained(self):
+        """make the loss evaluation (and get_trained_network) see the parameters after the updates so far"""
+        if getattr(self, "_tr", None):
+            self._eng.net_set_params(self.trained_params())
+
     def learning_status(self):
-        """learning_status(tr) (learning.jl:170-181)"""
+        """learning_status(tr) (learning.jl:170-181), network in TEST mode (running statistics) as memory_report does.
+        Deviation, documented: inside learning_step! the reference's Trainer holds the network in train mode, so its
+        status figures use batch statistics (and its evaluation passes move the running statistics)."""
         p = self.params
         out = L.LearningStatusRec()
         L.check(L.lib().az_learning_status(self._eng._h, self.data._h, float(p.l2_regularization), float(p.nonvalidity_penalty),

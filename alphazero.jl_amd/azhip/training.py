@@ -83,8 +83,10 @@ def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_pl
     over the ranks when torch.distributed is initialised) go straight into a `MemoryBuffer` (az_memory_push does
     push_trace! for every game on the GPU) -- no per-sample host objects.  Returns the Report.SelfPlay numbers."""
     import ctypes as C
+    import sys
 
-    import torch.distributed as dist
+    # torch.distributed only when the caller already set it up (importing torch costs seconds and is plumbing here)
+    dist = sys.modules.get("torch.distributed")
 
     from . import _lib as L
     from .simulations import gather_records, records_to_numpy, run_local, shard_games
@@ -95,14 +97,15 @@ def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_pl
     t0 = time.perf_counter()
     sim = params.sim
     first, device = 0, 0
-    if dist.is_available() and dist.is_initialized():
+    distributed = dist is not None and dist.is_available() and dist.is_initialized()
+    if distributed:
         import torch
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         first, count = shard_games(sim.num_games, world, rank)
         sim = SimParams(**{**sim.__dict__, "num_games": count})
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     games, moves, ng, nm, stats, _ = run_local(simulator, gspec, sim, first, game_played, device, seed)
-    if dist.is_available() and dist.is_initialized():
+    if distributed:
         g, mm = repack_by_game_id(*gather_records(*records_to_numpy(games, moves, ng, nm), group))
         ng, nm = len(g), len(mm)
         games = (L.GameRec * max(ng, 1)).from_buffer_copy(g.tobytes() or bytes(C.sizeof(L.GameRec)))
@@ -131,3 +134,77 @@ def evaluation_half_of_learning_step(gspec, curnn, bestnn, memory, learning_para
         status = tr.learning_status()
     ev = compare_networks(gspec, curnn, bestnn, arena_params, handler, seed=seed)
     return status, ev, ev.avgr >= arena_params.update_threshold
+
+
+@dataclass
+class Checkpoint:
+    """Report.Checkpoint"""
+    batch_id: int
+    evaluation: object
+    status_after: object
+    nn_replaced: bool
+
+
+@dataclass
+class LearningReport:
+    """Report.Learning (report.jl)"""
+    time_convert: float
+    time_loss: float
+    time_train: float
+    time_eval: float
+    initial_status: object
+    losses: np.ndarray
+    checkpoints: list
+    nn_replaced: bool
+
+
+def learning_step(gspec, curnn, bestnn, memory, learning_params, arena_params=None, use_symmetries=True, handler=None, seed=1):
+    """learning_step!(env, handler) (training.jl:193-259) on the device: Trainer over the (augmented, merged) experience,
+    num_checkpoints x [batch_updates!(nbatches) -> learning_status -> compare_networks(curnn, bestnn)] with the
+    replacement rule avgr >= best so far (initially update_threshold).  Returns (curnn, bestnn, LearningReport)."""
+    from .arena import compare_networks
+    from .learning import Trainer
+    from .network import ResNet
+    lp, ap = learning_params, arena_params
+    t0 = time.perf_counter()
+    tr = Trainer(gspec, curnn, memory, lp, use_symmetries=use_symmetries)
+    tconvert = time.perf_counter() - t0
+    tloss = ttrain = teval = 0.0
+    try:
+        init_status = status = tr.learning_status()
+        nbatches = lp.max_batches_per_checkpoint
+        if lp.min_checkpoints_per_epoch:
+            nbatches = min(nbatches, tr.num_batches_total() // lp.min_checkpoints_per_epoch)
+        best_evalr = None if ap is None else ap.update_threshold
+        losses, checkpoints, replaced = [], [], False
+        for k in range(1, lp.num_checkpoints + 1):
+            t1 = time.perf_counter()
+            losses.append(tr.batch_updates(nbatches, seed=seed))
+            t2 = time.perf_counter()
+            tr.install_trained()
+            status = tr.learning_status()
+            t3 = time.perf_counter()
+            ttrain += t2 - t1
+            tloss += t3 - t2
+            curnn = ResNet(gspec, curnn.hyper, params=tr.trained_params())      # get_trained_network
+            if ap is None:
+                bestnn, replaced = curnn.copy_(), True
+            else:
+                ev = compare_networks(gspec, curnn, bestnn, ap, handler, seed=seed + k)
+                teval += ev.time
+                success = ev.avgr >= best_evalr
+                if success:
+                    bestnn, best_evalr, replaced = curnn.copy_(), ev.avgr, True
+                checkpoints.append(Checkpoint(k * nbatches, ev, status, success))
+    finally:
+        tr.close()
+    return curnn, bestnn, LearningReport(tconvert, tloss, ttrain, teval, init_status,
+                                        np.concatenate(losses) if losses else np.zeros(0, np.float32), checkpoints, replaced)
+
+
+def train_iteration(gspec, curnn, bestnn, memory, self_play: SelfPlayParams, learning_params, arena_params, use_symmetries=True,
+                    seed=1, handler=None):
+    """One pass of train!'s loop body (training.jl:321-333): self_play_step! then learning_step!, both on the device."""
+    sp = self_play_step_device(gspec, bestnn, self_play, memory, seed=seed)
+    curnn, bestnn, lr = learning_step(gspec, curnn, bestnn, memory, learning_params, arena_params, use_symmetries, handler, seed)
+    return curnn, bestnn, sp, lr

@@ -35,8 +35,20 @@ struct Lib {
 static Lib g_lib;
 static int load() {
   if (g_lib.so) return AZ_OK;
-  void* so = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+  // By PATH, next to the HIP runtime this library is linked with: a bare soname would be satisfied by whatever copy
+  // another module of the process has loaded (PyTorch bundles its own rocBLAS, bound to its own HIP runtime), and a
+  // handle created there fails or works against a different runtime.
+  void* so = nullptr;
+  {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&hipGetLastError), &info) && info.dli_fname) {
+      std::string p(info.dli_fname);
+      const size_t k = p.rfind('/');
+      if (k != std::string::npos) so = dlopen((p.substr(0, k) + "/librocblas.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+    }
+  }
   if (!so) so = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+  if (!so) so = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
   if (!so) return fail(AZ_ERR_HIP, "cannot load librocblas.so (%s): the training step needs rocBLAS for its GEMMs", dlerror());
   g_lib.create = (create_t)dlsym(so, "rocblas_create_handle"); g_lib.destroy = (destroy_t)dlsym(so, "rocblas_destroy_handle");
   g_lib.set_stream = (set_stream_t)dlsym(so, "rocblas_set_stream"); g_lib.set_atomics = (set_atomics_t)dlsym(so, "rocblas_set_atomics_mode");
@@ -585,7 +597,7 @@ extern "C" int az_trainer_create(az_engine* e, az_dataset* d, const az_train_cfg
   t->perm_pos = 0; t->epoch = 0; t->step = 0; t->b1t = 1.0f; t->b2t = 1.0f;
   int st = [&]() -> int {
     HIPCHK(hipStreamCreate(&t->stream));
-    if (rb::g_lib.create(&t->rbh) != 0) return fail(AZ_ERR_HIP, "rocblas_create_handle failed");
+    { const int rs = rb::g_lib.create(&t->rbh); if (rs != 0) { t->rbh = nullptr; return fail(AZ_ERR_HIP, "rocblas_create_handle failed with status %d", rs); } }
     rb::g_lib.set_stream(t->rbh, t->stream);
     if (rb::g_lib.set_atomics) rb::g_lib.set_atomics(t->rbh, 0);   // rocblas_atomics_not_allowed: reproducible GEMMs
     AZCHK(trainer_build(t));

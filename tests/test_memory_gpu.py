@@ -174,14 +174,19 @@ def test_memory_errors():
 
 
 def test_iteration_example_runs_end_to_end():
-    """examples/iteration.py: self-play -> device memory -> learning status -> arena, tiny sizes; deterministic"""
+    """examples/iteration.py: two full iterations (self-play -> device memory -> batch updates -> status -> arena), tiny
+    sizes; deterministic"""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("iteration", os.path.join(os.path.dirname(__file__), "..", "examples", "iteration.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    r1 = mod.main(games=16, workers=8, sims=12, quiet=True)
-    r2 = mod.main(games=16, workers=8, sims=12, quiet=True)
-    assert r1[0].memory_size == r2[0].memory_size > 16 and r1[0].memory_num_distinct_boards <= r1[0].memory_size
-    assert r1[1] == r2[1] and np.array_equal(r1[2].rewards, r2[2].rewards) and r1[3] == r2[3]
-    assert np.isfinite([r1[1].loss.L, r1[1].Hpnet]).all() and len(r1[2].rewards) == 4
+    r1 = mod.main(iters=2, games=16, workers=8, sims=12, batch=32, quiet=True)
+    r2 = mod.main(iters=2, games=16, workers=8, sims=12, batch=32, quiet=True)
+    for (sp1, lr1), (sp2, lr2) in zip(r1, r2):
+        assert sp1.memory_size == sp2.memory_size > 16 and sp1.memory_num_distinct_boards <= sp1.memory_size
+        assert np.array_equal(lr1.losses, lr2.losses) and len(lr1.losses) >= 1 and np.isfinite(lr1.losses).all()
+        assert lr1.initial_status == lr2.initial_status and lr1.nn_replaced == lr2.nn_replaced
+        assert np.array_equal(lr1.checkpoints[0].evaluation.rewards, lr2.checkpoints[0].evaluation.rewards)
+        assert len(lr1.checkpoints[0].evaluation.rewards) == 4
+    assert r1[1][0].memory_size > r1[0][0].memory_size

@@ -120,8 +120,8 @@ def test_gradients_match_torch_autograd(game, nblocks, F, B, policy):
         L, (Lp, Lv, Lreg, Linv, scale) = ref.losses(batch, float(tr.Wmean), float(tr.Hp), 1e-4, 1.0, 2.0)
         (L - scale * Lreg).backward()                              # the device gradient excludes the L2 term (added in the update)
         want = ref.blob(grads=True)
-        assert abs(loss - float(L)) < 2e-5 * max(1.0, abs(float(L)))
-        assert np.allclose(parts, [float(Lp), float(Lv), float(Lreg), float(Linv), float(scale)], rtol=5e-5, atol=5e-6), (parts, float(Lp), float(Lv))
+        assert abs(loss - L.item()) < 2e-5 * max(1.0, abs(L.item()))
+        assert np.allclose(parts, [Lp.item(), Lv.item(), Lreg.item(), Linv.item(), scale.item()], rtol=5e-5, atol=5e-6), (parts, Lp.item(), Lv.item())
         _rel_err_by_array(game, hp, grad.astype(np.float64), want)
         # the probe does not move the parameters or the running statistics
         assert np.array_equal(tr.trained_params(), nn.params())
@@ -161,7 +161,7 @@ def test_adam_steps_follow_torch():
             L, _ = ref.losses([x[idx] for x in data], float(tr.Wmean), float(tr.Hp), 1e-3, 1.0, 1.0)
             L.backward()
             opt.step()
-            losses.append(float(L))
+            losses.append(L.item())
             for pre, (mu, var, m) in ref.batch_stats.items():
                 run[pre + ".mean"] = 0.9 * run[pre + ".mean"] + 0.1 * mu
                 run[pre + ".var"] = 0.9 * run[pre + ".var"] + 0.1 * var * (m / (m - 1))
@@ -178,4 +178,61 @@ def test_adam_steps_follow_torch():
         st1 = tr2.learning_status()
     assert np.isfinite(more).all() and more[-5:].mean() < more[:5].mean()
     assert st0.loss.L == pytest.approx(st0.loss.L) and np.isfinite(st1.loss.L)
+    mem.close()
+
+
+def test_cyclic_nesterov_steps_follow_the_reference_rule():
+    """CyclicNesterov (network.jl:163-180, flux.jl:78-94): Optimisers.Nesterov with lr / momentum from CyclicSchedule
+    (schedule.jl:130-134); Flux.adjust! follows update!, so step i uses the schedule values of index i-1."""
+    import azhip
+    game, B, n = 1, 32, 6
+    gspec, mem = _memory(game, 24, 6)
+    hp = azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    nn = azhip.ResNet(gspec, hp, seed=3)
+    opt = azhip.CyclicNesterov(lr_base=1e-3, lr_high=1e-2, lr_low=5e-4, momentum_low=0.8, momentum_high=0.9)
+    lp = azhip.LearningParams(samples_weighing_policy=0, l2_regularization=1e-4, loss_computation_batch_size=64, batch_size=B, optimiser=opt)
+
+    def pl(xs, ys, i):
+        pt = max([k for k in range(4) if xs[k] <= i], default=-1)
+        if pt < 0:
+            return ys[0]
+        if pt == 3 or xs[pt + 1] == xs[pt]:
+            return ys[pt]
+        return ys[pt] + (ys[pt + 1] - ys[pt]) / (xs[pt + 1] - xs[pt]) * (i - xs[pt])
+    xs = [1, int(0.45 * n), int(0.9 * n), n]
+    with azhip.Trainer(gspec, nn, mem, lp, use_symmetries=True) as tr:
+        data = tr.data.tensors()
+        N = len(data[0])
+        ls = tr.batch_updates(n, seed=2)
+        got = tr.trained_params()
+        from test_arena_oracle import _u64
+        perm = list(range(N))
+        for k, i in enumerate(range(N - 1, 0, -1)):
+            j = min(int(_u64(2, 0, 0, 5, k) * (i + 1)), i)
+            perm[i], perm[j] = perm[j], perm[i]
+        ref = TorchNet(game, hp, nn.params())
+        train = [t for t in ref.p.values() if t.requires_grad]
+        vel = [torch.zeros_like(t) for t in train]
+        for s in range(n):
+            lr = 5e-4 if s == 0 else pl(xs, [1e-3, 1e-2, 1e-3, 5e-4], s)
+            rho = 0.9 if s == 0 else pl(xs, [0.9, 0.8, 0.9, 0.9], s)
+            for t in train:
+                t.grad = None
+            L, _ = ref.losses([x[perm[s * B:(s + 1) * B]] for x in data], float(tr.Wmean), float(tr.Hp), 1e-4, 1.0, 1.0)
+            L.backward()
+            assert abs(float(L.detach()) - ls[s]) < 3e-4 * max(1.0, abs(float(L.detach()))), (s, float(L.detach()), ls[s])
+            with torch.no_grad():
+                for t, v in zip(train, vel):
+                    newdx = -rho * rho * v + (1 + rho) * lr * t.grad              # Optimisers.apply!(::Nesterov)
+                    v.mul_(rho).sub_(lr * t.grad)
+                    t.sub_(newdx)
+        want = ref.blob()
+        mask = np.ones(len(want), dtype=bool)
+        off = 0
+        for name, shape in param_layout(game, hp):
+            k = int(np.prod(shape))
+            if name.endswith(".mean") or name.endswith(".var"):
+                mask[off:off + k] = False
+            off += k
+        assert np.abs(got[mask] - want[mask]).max() < 3e-4, np.abs(got[mask] - want[mask]).max()
     mem.close()
