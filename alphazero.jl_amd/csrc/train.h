@@ -90,6 +90,20 @@ __global__ void k_tr_batch(const int* __restrict__ idx, int B, int xs, int A, co
 }
 // im2col of a 3x3 / pad 1 convolution over rows r = board*P + x + W*y: col[r][tap*C + c] = in(r + delta(tap))[c] or 0.
 // PLANES: `in` is the plane tensor [B][C][P]; else the activation matrix [R][C].
+// float4 form for activation matrices (C % 4 == 0): one thread moves 4 channels of one (row, tap)
+__global__ void __launch_bounds__(256) k_tr_im2col4(const float4* __restrict__ in, long long R, int C4, int Wd, int Hd, float4* __restrict__ col) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = R * 9 * C4;
+  if (t >= total) return;
+  const int c = (int)(t % C4);
+  const int tap = (int)((t / C4) % 9);
+  const long long r = t / (9LL * C4);
+  const int P = Wd * Hd, q = (int)(r % P), x = q % Wd, y = q / Wd;
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (y + dy >= 0 && y + dy < Hd && x + dx >= 0 && x + dx < Wd) v = in[(r + dy * Wd + dx) * C4 + c];
+  col[t] = v;
+}
 template <bool PLANES>
 __global__ void __launch_bounds__(256) k_tr_im2col(const float* __restrict__ in, long long R, int C, int Wd, int Hd, float* __restrict__ col) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,36 +121,54 @@ __global__ void __launch_bounds__(256) k_tr_im2col(const float* __restrict__ in,
   }
   col[t] = v;
 }
-// two-stage column sums over R rows of up to two derived quantities; stage 1: chunk of 256 rows per block, thread = channel
+// two-stage column sums over R rows of up to two derived quantities.  Stage 1: a block = 64 channels x 4 row lanes takes
+// a chunk of 64 rows (thread: 16 rows, then the 4 lanes are added in lane order); stage 2: one block per channel adds
+// the chunk partials with a fixed-shape tree.  Deterministic, double accumulators.
 //   MODE 0: (x, x*x)                       batch-norm statistics of the GEMM output
-//   MODE 1: (dy, dy * xhat)                batch-norm backward, dy = da * (out > 0) [* relu mask], xhat = (g - mean) * invstd
-//   MODE 2: (x, 0)                         bias gradients
+//   MODE 1: (dy, dy * xhat)                batch-norm backward, dy = da * (out > 0), xhat = (g - mean) * invstd
+//   MODE 2: (x, 0)                         bias gradients of the dense layers
+constexpr int TR_CHUNK = 64;
 template <int MODE>
-__global__ void k_tr_colsum(const float* __restrict__ x, const float* __restrict__ out_act, const float* __restrict__ g,
-                            const float* __restrict__ mean, const float* __restrict__ invstd, long long R, int C,
-                            double* __restrict__ part /* [nchunks][2][C] */) {
-  const int c = blockIdx.y * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const long long r0 = (long long)blockIdx.x * 256, r1 = r0 + 256 < R ? r0 + 256 : R;
+__global__ void __launch_bounds__(256) k_tr_colsum(const float* __restrict__ x, const float* __restrict__ out_act, const float* __restrict__ g,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd, long long R, int C,
+                                                   double* __restrict__ part /* [nchunks][2][C] */) {
+  __shared__ double sh[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const long long r0 = (long long)blockIdx.x * TR_CHUNK, r1 = r0 + TR_CHUNK < R ? r0 + TR_CHUNK : R;
   double s0 = 0.0, s1 = 0.0;
-  for (long long r = r0; r < r1; ++r) {
-    const size_t i = (size_t)r * C + c;
-    if (MODE == 0) { const float v = x[i]; s0 += (double)v; s1 += (double)v * (double)v; }
-    else if (MODE == 1) {
-      const float dy = out_act[i] > 0.0f ? x[i] : 0.0f;
-      const float xh = (g[i] - mean[c]) * invstd[c];
-      s0 += (double)dy; s1 += (double)dy * (double)xh;
-    } else s0 += (double)x[i];
+  if (c < C) {
+    float mu = 0.f, is = 0.f;
+    if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+    for (long long r = r0 + rl; r < r1; r += 4) {
+      const size_t i = (size_t)r * C + c;
+      if (MODE == 0) { const float v = x[i]; s0 += (double)v; s1 += (double)v * (double)v; }
+      else if (MODE == 1) {
+        const float dy = out_act[i] > 0.0f ? x[i] : 0.0f;
+        const float xh = (g[i] - mu) * is;
+        s0 += (double)dy; s1 += (double)dy * (double)xh;
+      } else s0 += (double)x[i];
+    }
   }
-  part[((size_t)blockIdx.x * 2) * C + c] = s0;
-  part[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+  sh[0][rl][cl] = s0; sh[1][rl][cl] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    part[((size_t)blockIdx.x * 2) * C + c] = ((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl];
+    part[((size_t)blockIdx.x * 2 + 1) * C + c] = ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl];
+  }
 }
-__global__ void k_tr_colsum_final(const double* __restrict__ part, int nchunks, int C, double* __restrict__ sums /* [2][C] */) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(64) k_tr_colsum_final(const double* __restrict__ part, int nchunks, int C, double* __restrict__ sums /* [2][C] */) {
+  __shared__ double sh[2][64];
+  const int c = blockIdx.x, t = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
-  for (int k = 0; k < nchunks; ++k) { s0 += part[((size_t)k * 2) * C + c]; s1 += part[((size_t)k * 2 + 1) * C + c]; }
-  sums[c] = s0; sums[C + c] = s1;
+  for (int k = t; k < nchunks; k += 64) { s0 += part[((size_t)k * 2) * C + c]; s1 += part[((size_t)k * 2 + 1) * C + c]; }
+  sh[0][t] = s0; sh[1][t] = s1;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (t < w) { sh[0][t] += sh[0][t + w]; sh[1][t] += sh[1][t + w]; }
+    __syncthreads();
+  }
+  if (t == 0) { sums[c] = sh[0][0]; sums[C + c] = sh[1][0]; }
 }
 // batch statistics -> mean, 1/sqrt(var + eps) (Flux BatchNorm: biased variance, eps 1e-5) and the running statistics
 // mu <- (1-m) mu + m (mean + bias), var <- (1-m) var + m * var * R/(R-1)
@@ -409,7 +441,7 @@ static int trainer_build(az_trainer* t) {
   AZCHK(tr_alloc(t, &t->v1, (size_t)B * F)); AZCHK(tr_alloc(t, &t->dv1, (size_t)B * F));
   AZCHK(tr_alloc(t, &t->tpre, B)); AZCHK(tr_alloc(t, &t->dt, B));
   AZCHK(tr_alloc(t, &t->dact, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dact2, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dcol, (size_t)R * 9 * F));
-  const int nchunks = (int)((R + 255) / 256);
+  const int nchunks = (int)((R + TR_CHUNK - 1) / TR_CHUNK);
   AZCHK(tr_alloc(t, &t->part, (size_t)nchunks * 2 * std::max(F, 64))); AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64)));
   AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 5 + 1024));
   AZCHK(t->red.init(std::max(B, 1024), t->stream));
@@ -419,9 +451,9 @@ static int trainer_build(az_trainer* t) {
 // column sums of mode MODE over R rows, result in t->sums
 template <int MODE>
 static int tr_colsum(az_trainer* t, const float* x, const float* out_act, const float* g, const float* mean, const float* invstd, long long R, int C) {
-  const int nchunks = (int)((R + 255) / 256);
-  hipLaunchKernelGGL((k_tr_colsum<MODE>), dim3(nchunks, (C + 63) / 64), dim3(64), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part);
-  hipLaunchKernelGGL(k_tr_colsum_final, dim3((C + 63) / 64), dim3(64), 0, t->stream, t->part, nchunks, C, t->sums);
+  const int nchunks = (int)((R + TR_CHUNK - 1) / TR_CHUNK);
+  hipLaunchKernelGGL((k_tr_colsum<MODE>), dim3(nchunks, (C + 63) / 64), dim3(256), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part);
+  hipLaunchKernelGGL(k_tr_colsum_final, dim3(C), dim3(64), 0, t->stream, t->part, nchunks, C, t->sums);
   return AZ_OK;
 }
 
@@ -446,7 +478,7 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_o
     TrConv& c = t->convs[l];
     const float* in = l == 0 ? t->bX : t->convs[l - 1].a;
     if (l == 0) hipLaunchKernelGGL((k_tr_im2col<true>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
-    else hipLaunchKernelGGL((k_tr_im2col<false>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
+    else hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cin / 4))), dim3(256), 0, st, (const float4*)in, R, c.cin / 4, gi.W, gi.H, (float4*)c.col);
     AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
     AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout));
     hipLaunchKernelGGL(k_tr_bn_stats, dim3((c.cout + 63) / 64), dim3(64), 0, st, t->sums, R, c.cout, t->cfg.batch_norm_momentum, blob + c.off_b, c.mean, c.invstd,
@@ -520,8 +552,8 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_o
     hipLaunchKernelGGL(k_tr_bn_param_grads, dim3((c->cout + 63) / 64), dim3(64), 0, st, t->sums, c->cout, gb + c->off_bn, gb + c->off_bn + c->cout);
     hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c->cout)), dim3(256), 0, st, dh, c->a, c->g, c->mean, c->invstd, blob + c->off_bn, t->sums, R, R * c->cout, c->cout, dh, (float*)nullptr);
     AZCHK(rb::gemm(t->rbh, true, false, F, c->cout, (int)R, 1.f, trunk, F, dh, c->cout, 0.f, gw + c->wk_wm, c->cout));
-    AZCHK(tr_colsum<2>(t, dh, nullptr, nullptr, nullptr, nullptr, R, c->cout));
-    hipLaunchKernelGGL(k_tr_store_sum0, dim3((c->cout + 63) / 64), dim3(64), 0, st, t->sums, c->cout, gb + c->off_b);
+    // the bias of a convolution that feeds a train-mode BatchNorm has gradient sum(dg) = gamma invstd (sum dy - R m0 - m1 sum xhat)
+    // = 0 exactly (the batch mean absorbs it): its slot in gblob stays 0 and only the L2 term moves it
     AZCHK(rb::gemm(t->rbh, false, true, (int)R, F, c->cout, 1.f, dh, c->cout, t->work + c->wk_wm, c->cout, first ? 0.f : 1.f, dtrunk, F));
     first = false;
   }
@@ -537,11 +569,9 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_o
     hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, t->dact, c.a, c.g, c.mean, c.invstd, blob + c.off_bn, t->sums, R, R * c.cout, c.cout,
                        t->dact, second ? t->dact2 : (float*)nullptr);
     AZCHK(rb::gemm(t->rbh, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, t->dact, c.cout, 0.f, gw + c.wk_wm, c.cout));
-    AZCHK(tr_colsum<2>(t, t->dact, nullptr, nullptr, nullptr, nullptr, R, c.cout));
-    hipLaunchKernelGGL(k_tr_store_sum0, dim3((c.cout + 63) / 64), dim3(64), 0, st, t->sums, c.cout, gb + c.off_b);
     if (l == 0) break;
     // data gradient: da_prev = im2col(dg) * Wrot
-    hipLaunchKernelGGL((k_tr_im2col<false>), dim3(tr_grid(R * 9 * c.cout)), dim3(256), 0, st, t->dact, R, c.cout, gi.W, gi.H, t->dcol);
+    hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cout / 4))), dim3(256), 0, st, (const float4*)t->dact, R, c.cout / 4, gi.W, gi.H, (float4*)t->dcol);
     AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cin, 9 * c.cout, 1.f, t->dcol, 9 * c.cout, t->work + c.wk_wrot, c.cin, 0.f, t->dact, c.cin));
     const bool first_of_block = (l % 2) == 1;                      // conv1: its input is the block input, which also gets the skip share
     if (first_of_block) hipLaunchKernelGGL(k_tr_add, dim3(tr_grid(R * F)), dim3(256), 0, st, t->dact, t->dact2, R * F);
