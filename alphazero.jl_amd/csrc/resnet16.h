@@ -332,3 +332,58 @@ k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restri
   if (wave < T::CT) tower16_wave<T, FROM_PLANES, T::NT0, 0>(net, buf, planes, wave, lane, n, board0, hfeat);
   else tower16_wave<T, FROM_PLANES, T::NT1, T::NT0>(net, buf, planes, wave - T::CT, lane, n, board0, hfeat);
 }
+
+// One 3x3 F -> F convolution as a stand-alone layer (HBM -> HBM), for the optimiser step (train.h): forward
+// g = conv(a) and data gradient da = conv_rot(dg) are the same kernel with different weight fragments.  A workgroup
+// takes 4 Connect-Four boards (T16<Game, F, 11>): rows [R][F] in natural channel order go into the LDS buffer in
+// the permuted order conv16 expects, the 11 accumulator tiles of each wavefront come back out in natural order.
+// No bias, no activation: batch norm follows with batch statistics (the bias cancels there).
+template <class Gm, int F>
+__global__ void __launch_bounds__(T16Threads<F>::V, 2)
+k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, float* __restrict__ out, int nboards) {
+  using T = T16<Gm, F, 11>;
+  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, STRIDE = T::STRIDE, NT = 11;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* buf = lds;
+  const int board0 = blockIdx.x * T::TB;
+  if (board0 >= nboards) return;
+  const int nb = (nboards - board0) < T::TB ? (nboards - board0) : T::TB;
+  const int nvalid = nb * P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float4* in4 = (const float4*)(in + (size_t)board0 * P * F);
+  for (int idx = tid; idx < (T::RPAD + 1) * (F / 4); idx += T::THREADS) {
+    const int row = idx / (F / 4), c4 = idx % (F / 4);
+    const float4 v = row < nvalid ? in4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* dst = buf + row * STRIDE;
+    dst[posF<F>(c4 * 4 + 0)] = v.x; dst[posF<F>(c4 * 4 + 1)] = v.y; dst[posF<F>(c4 * 4 + 2)] = v.z; dst[posF<F>(c4 * 4 + 3)] = v.w;
+  }
+  const int lrow = lane & 15, g = lane >> 4;
+  uint32_t vm[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int tile = 0; tile < NT; ++tile) {
+    const int row = tile * 16 + lrow;
+    const int q = row % P, x = q % W, y = q / W;
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = (row < T::ROWS) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
+      m |= (uint32_t)ok << t;
+    }
+    vm[tile / 3] |= m << (9 * (tile % 3));
+  }
+  __syncthreads();
+  f32x4v acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  conv16<T, NT, 9>(buf, wfrag + (size_t)wave * T::SQ * 64 + lane, acc, vm, lrow, g);
+  const int ch = wave * 16 + lrow;
+  float* o = out + (size_t)board0 * P * F;
+#pragma unroll
+  for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = tile * 16 + g * 4 + i;
+      if (row < nvalid) o[(size_t)row * F + ch] = acc[tile][i];
+    }
+}

@@ -5,9 +5,10 @@
 //   losses                                      src/learning.jl:67-90
 //   ResNet in TRAIN mode                        src/networks/architectures/resnet.jl:53-92 (BatchNorm with batch statistics)
 //
-// Structure of this first version: every convolution is im2col (hand-written gather) + one plain fp32 GEMM through
-// rocBLAS (forward, data gradient with the rotated weights, weight gradient), which the task's rules allow for plain
-// library GEMMs; everything that is not a GEMM is hand-written here: batch-norm statistics / apply / backward with
+// Structure of this version: forward and data gradient of the F -> F tower convolutions run on k_conv16_layer
+// (resnet16.h, the tower's MFMA implicit GEMM as a stand-alone layer); weight gradients, the stem and the 1x1 / dense
+// layers are im2col (hand-written gather) + one plain fp32 GEMM through rocBLAS, which the task's rules allow for
+// plain library GEMMs; everything that is not a GEMM is hand-written here: batch-norm statistics / apply / backward with
 // deterministic two-stage column reductions, ReLU and skip wiring, the loss with its analytic gradient (softmax,
 // mask normalisation, KL, invalid-mass penalty, tanh / MSE), parameter layout maps between Flux's arrays and the
 // GEMM matrices, Adam / Nesterov and the running statistics.  rocBLAS is dlopen'ed when the first trainer is
@@ -312,6 +313,8 @@ struct TrConv {                 // one convolution + batch norm (3x3 of the towe
   int cin, cout, taps;
   size_t off_w, off_b, off_bn;  // blob offsets: W, bias, (gamma, beta, mean, var)
   size_t wk_wm, wk_wrot;        // offsets in the working-parameter array: GEMM matrix [taps*cin][cout], rotated [taps*cout][cin]
+  size_t wk_ffwd, wk_fdg;       // tower convolutions F -> F: MFMA fragments of k_conv16_layer for forward / data gradient
+  bool mfma;                    // forward and data gradient on k_conv16_layer instead of im2col + GEMM
   float *col, *g, *a;           // im2col input [R][taps*cin] (taps == 1: alias of the input), GEMM output, activation
   float *mean, *invstd;
 };
@@ -383,6 +386,9 @@ static int trainer_build(az_trainer* t) {
     c.off_bn = off; off += 4 * (size_t)cout;
     c.wk_wm = wk; wk += (size_t)taps * cin * cout;
     c.wk_wrot = wk; wk += (size_t)taps * cin * cout;
+    c.mfma = taps == 9 && cin == cout && (cin == 64 || cin == 128) && !getenv("AZHIP_TRAIN_GEMM");
+    c.wk_ffwd = c.wk_fdg = 0;
+    if (c.mfma) { c.wk_ffwd = wk; wk += (size_t)taps * cin * cout; c.wk_fdg = wk; wk += (size_t)taps * cin * cout; }
     t->convs.push_back(c);
   };
   add_conv(C, F, 9);
@@ -408,6 +414,21 @@ static int trainer_build(az_trainer* t) {
         const int b = (int)(c.off_w + (size_t)wi + (size_t)ks * (wj + (size_t)ks * (ci + (size_t)c.cin * co)));   // Flux W(kw, kh, ci, co), true convolution
         map[c.wk_wm + ((size_t)tap * c.cin + ci) * c.cout + co] = b;
         map[c.wk_wrot + ((size_t)(c.taps - 1 - tap) * c.cout + co) * c.cin + ci] = b;                          // data gradient: taps mirrored, ci <-> co
+      }
+    }
+    if (c.mfma) {
+      // fragment order of conv16 (see az_net_set_params): lane ln of float4 sq, component q, column tile ct supplies input
+      // channel ci = (g & 1) F/2 + 2 (4 sq + q) + (g >> 1), g = ln >> 4, for output channel co = 16 ct + (ln & 15)
+      const int Fc = c.cin, CT = Fc / 16;
+      auto blob_of = [&](int tap, int ci, int co) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1, wi = 1 - dx, wj = 1 - dy;
+        return (int)(c.off_w + (size_t)wi + 3 * (wj + 3 * (ci + (size_t)Fc * co)));
+      };
+      for (int tap = 0; tap < 9; ++tap) for (int ct = 0; ct < CT; ++ct) for (int sq = 0; sq < CT; ++sq) for (int ln = 0; ln < 64; ++ln) for (int q = 0; q < 4; ++q) {
+        const int sidx = 4 * sq + q, g = ln >> 4, kin = (g & 1) * (Fc / 2) + 2 * sidx + (g >> 1), nout = ct * 16 + (ln & 15);
+        const size_t j = ((((size_t)tap * CT + ct) * CT + sq) * 64 + ln) * 4 + q;
+        map[c.wk_ffwd + j] = blob_of(tap, kin, nout);                  // forward: in = ci, out = co
+        map[c.wk_fdg + j] = blob_of(8 - tap, nout, kin);               // data gradient: in = co, out = ci, taps mirrored
       }
     }
     for (int i = 0; i < 2 * c.cout; ++i) trainable[c.off_bn + 2 * c.cout + i] = 0;                              // running mean / variance
@@ -448,6 +469,19 @@ static int trainer_build(az_trainer* t) {
   return AZ_OK;
 }
 
+template <class Gm, int F> static int tr_conv16_f(az_trainer* t, const float* in, const float* frag, float* out) {
+  using T = T16<Gm, F, 11>;
+  static bool attr_done = false;
+  if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_layer<Gm, F>), hipFuncAttributeMaxDynamicSharedMemorySize, T::BYTES)); attr_done = true; }
+  hipLaunchKernelGGL((k_conv16_layer<Gm, F>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B);
+  return AZ_OK;
+}
+// 3x3 F -> F convolution of [R][F] activations on the MFMA layer kernel
+static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* out) {
+  DISPATCH_GAME(t->game, { if (t->F == 128) AZCHK((tr_conv16_f<Gm, 128>(t, in, frag, out))); else AZCHK((tr_conv16_f<Gm, 64>(t, in, frag, out))); });
+  return AZ_OK;
+}
+
 // column sums of mode MODE over R rows, result in t->sums
 template <int MODE>
 static int tr_colsum(az_trainer* t, const float* x, const float* out_act, const float* g, const float* mean, const float* invstd, long long R, int C) {
@@ -479,7 +513,8 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_o
     const float* in = l == 0 ? t->bX : t->convs[l - 1].a;
     if (l == 0) hipLaunchKernelGGL((k_tr_im2col<true>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
     else hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cin / 4))), dim3(256), 0, st, (const float4*)in, R, c.cin / 4, gi.W, gi.H, (float4*)c.col);
-    AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
+    if (c.mfma) AZCHK(tr_conv16(t, in, t->work + c.wk_ffwd, c.g));         // (the im2col above feeds the weight gradient)
+    else AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
     AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout));
     hipLaunchKernelGGL(k_tr_bn_stats, dim3((c.cout + 63) / 64), dim3(64), 0, st, t->sums, R, c.cout, t->cfg.batch_norm_momentum, blob + c.off_b, c.mean, c.invstd,
                        blob + c.off_bn + 2 * c.cout, blob + c.off_bn + 3 * c.cout);
@@ -571,8 +606,13 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_o
     AZCHK(rb::gemm(t->rbh, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, t->dact, c.cout, 0.f, gw + c.wk_wm, c.cout));
     if (l == 0) break;
     // data gradient: da_prev = im2col(dg) * Wrot
-    hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cout / 4))), dim3(256), 0, st, (const float4*)t->dact, R, c.cout / 4, gi.W, gi.H, (float4*)t->dcol);
-    AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cin, 9 * c.cout, 1.f, t->dcol, 9 * c.cout, t->work + c.wk_wrot, c.cin, 0.f, t->dact, c.cin));
+    if (c.mfma) {
+      AZCHK(tr_conv16(t, t->dact, t->work + c.wk_fdg, t->dcol));     // out of place: dcol's front [R][F] receives da
+      HIPCHK(hipMemcpyAsync(t->dact, t->dcol, sizeof(float) * (size_t)R * c.cin, hipMemcpyDeviceToDevice, st));
+    } else {
+      hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cout / 4))), dim3(256), 0, st, (const float4*)t->dact, R, c.cout / 4, gi.W, gi.H, (float4*)t->dcol);
+      AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cin, 9 * c.cout, 1.f, t->dcol, 9 * c.cout, t->work + c.wk_wrot, c.cin, 0.f, t->dact, c.cin));
+    }
     const bool first_of_block = (l % 2) == 1;                      // conv1: its input is the block input, which also gets the skip share
     if (first_of_block) hipLaunchKernelGGL(k_tr_add, dim3(tr_grid(R * F)), dim3(256), 0, st, t->dact, t->dact2, R * F);
   }
