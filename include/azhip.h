@@ -294,7 +294,8 @@ typedef struct {
 int az_train_cfg_init(az_train_cfg* cfg);
 /* Trainer(gspec, network, samples, params): the engine supplies the architecture and the initial parameters, the
  * data set (az_dataset_create) the converted samples, Wmean and Hp.  The engine's own network is not modified:
- * fetch the result with az_trainer_get_params and install it with az_net_set_params. */
+ * fetch the result with az_trainer_get_params and install it with az_net_set_params.  The engine and the data set
+ * must outlive the trainer. */
 int az_trainer_create(az_engine* e, az_dataset* d, const az_train_cfg* cfg, az_trainer** out);
 int az_trainer_destroy(az_trainer* t);
 /* batch_updates!(tr, n): n optimiser steps (forward in train mode = BatchNorm with batch statistics, `losses`,

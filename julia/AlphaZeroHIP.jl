@@ -346,4 +346,43 @@ function device_learning_status(nn::HipResNet, m::DeviceMemory, lp; use_symmetri
   end
 end
 
+# ---- the optimiser step: batch_updates! (src/learning.jl:131-141) on the device --------------------------------
+struct TrainCfg
+  struct_size::Int32; optimiser::Int32; lr::Float32
+  lr_base::Float32; lr_high::Float32; lr_low::Float32; momentum_low::Float32; momentum_high::Float32
+  l2_regularization::Float64; nonvalidity_penalty::Float64; rewards_renormalization::Float64
+  batch_size::Int32; batch_norm_momentum::Float32; seed::UInt64
+end
+train_cfg(lp, hp; seed=1) = begin
+  o = lp.optimiser
+  adam = o isa AlphaZero.Adam
+  TrainCfg(Int32(sizeof(TrainCfg)), adam ? 0 : 1, adam ? o.lr : 0f0,
+    adam ? 0f0 : o.lr_base, adam ? 0f0 : o.lr_high, adam ? 0f0 : o.lr_low, adam ? 0f0 : o.momentum_low, adam ? 0f0 : o.momentum_high,
+    lp.l2_regularization, lp.nonvalidity_penalty, lp.rewards_renormalization, lp.batch_size, hp.batch_norm_momentum, UInt64(seed))
+end
+
+"""
+    device_batch_updates!(nn::HipResNet, m::DeviceMemory, lp::LearningParams, n; use_symmetries) -> losses
+
+`batch_updates!(Trainer(gspec, nn, experience, lp), n)` on the device; `nn.blob` receives the trained parameters
+(get_trained_network).  A long-lived trainer handle would be kept across checkpoints in a real integration.
+"""
+function device_batch_updates!(nn::HipResNet, m::DeviceMemory, lp, n; use_symmetries::Bool, seed=1)
+  ds = Ref{Ptr{Cvoid}}(C_NULL); tr = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ccall((:az_dataset_create, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+    m.h, 0, use_symmetries ? 1 : 0, lp.use_position_averaging ? 1 : 0, Int32(lp.samples_weighing_policy), ds))
+  losses = Vector{Float32}(undef, n)
+  try
+    check(ccall((:az_trainer_create, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{TrainCfg}, Ref{Ptr{Cvoid}}),
+      engine!(nn).h, ds[], train_cfg(lp, nn.hyper; seed=seed), tr))
+    check(ccall((:az_trainer_batch_updates, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float32}), tr[], n, losses))
+    check(ccall((:az_trainer_get_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), tr[], nn.blob, length(nn.blob)))
+    check(ccall((:az_net_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), engine!(nn).h, nn.blob, length(nn.blob)))
+  finally
+    tr[] != C_NULL && ccall((:az_trainer_destroy, LIB), Cint, (Ptr{Cvoid},), tr[])
+    ccall((:az_dataset_destroy, LIB), Cint, (Ptr{Cvoid},), ds[])
+  end
+  return losses
+end
+
 end # module

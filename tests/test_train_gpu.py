@@ -236,3 +236,34 @@ def test_cyclic_nesterov_steps_follow_the_reference_rule():
             off += k
         assert np.abs(got[mask] - want[mask]).max() < 3e-4, np.abs(got[mask] - want[mask]).max()
     mem.close()
+
+
+def test_trainer_errors_and_lifecycle():
+    import ctypes as C
+    import azhip
+    from azhip import _lib as L
+    gspec, mem = _memory(1, 6, 1)
+    hp = azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    nn = azhip.ResNet(gspec, hp, seed=1)
+    lp = azhip.LearningParams(samples_weighing_policy=0, l2_regularization=0.0, loss_computation_batch_size=8, batch_size=1 << 20)
+    with azhip.Trainer(gspec, nn, mem, lp, use_symmetries=False) as tr:
+        assert tr.batch_size() == tr.num_samples()                  # min(batch_size, #samples), learning.jl:113
+        ls = tr.batch_updates(2)                                    # every epoch is one full batch
+        assert np.isfinite(ls).all() and tr.batch_updates(0).size == 0
+        with pytest.raises(L.AzError, match="out of range"):
+            tr.gradients(np.full(tr.batch_size(), 10 ** 6))
+        cfg = L.TrainCfg()
+        L.check(L.lib().az_train_cfg_init(C.byref(cfg)))
+        h = C.c_void_p()
+        cfg.optimiser = 7
+        assert L.lib().az_trainer_create(tr._eng._h, tr.data._h, C.byref(cfg), C.byref(h)) == L.AZ_ERR_BAD_ARG and b"optimiser" in L.lib().az_last_error()
+        cfg.optimiser, cfg.struct_size = 0, 12
+        assert L.lib().az_trainer_create(tr._eng._h, tr.data._h, C.byref(cfg), C.byref(h)) == L.AZ_ERR_BAD_ARG
+        L.check(L.lib().az_train_cfg_init(C.byref(cfg)))
+        cfg.batch_size = 1
+        assert L.lib().az_trainer_create(tr._eng._h, tr.data._h, C.byref(cfg), C.byref(h)) == L.AZ_ERR_BAD_ARG and b"batch" in L.lib().az_last_error()
+        with azhip.Engine(game=L.GAME_TICTACTOE, oracle=L.ORACLE_HASH, num_workers=4, batch_size=4, num_iters_per_turn=4) as e2:
+            L.check(L.lib().az_train_cfg_init(C.byref(cfg)))
+            assert L.lib().az_trainer_create(e2._h, tr.data._h, C.byref(cfg), C.byref(h)) == L.AZ_ERR_STATE
+    assert L.lib().az_trainer_destroy(None) == 0
+    mem.close()
