@@ -20,4 +20,4 @@ from .training import SelfPlayParams, SelfPlayReport, broadcast_params, self_pla
 from .arena import Evaluation, compare_networks, pit_networks, pit_players
 from . import benchmark as Benchmark
 from .learning import (CONSTANT_WEIGHT, LINEAR_WEIGHT, LOG_WEIGHT, Adam, CyclicNesterov, LearningParams, LearningStatus, Loss,
-                       Samples, Trainer)
+                       Samples, Trainer, memory_report)

@@ -126,6 +126,7 @@ SYMBOLS = {
     "az_memory_create": [_I32, _I32, _I64, C.POINTER(_VP)],
     "az_memory_destroy": [_VP],
     "az_memory_push": [_VP, C.POINTER(TraceBuf), C.c_double],
+    "az_memory_push_samples": [_VP, _VP, _I64],
     "az_memory_length": [_VP, C.POINTER(_I64), C.POINTER(_I64)],
     "az_memory_new_batch": [_VP],
     "az_memory_empty": [_VP],

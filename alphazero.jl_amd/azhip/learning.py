@@ -183,3 +183,47 @@ class Trainer:
         else:
             raise NotImplementedError("num_boards of an un-merged Trainer: build a second data set with use_position_averaging")
         return Samples(self.data.sum_n, num_boards, self.data.Wtot, status)
+
+
+@dataclass
+class StageSamples:
+    """Report.StageSamples"""
+    min_remaining_length: float
+    max_remaining_length: float
+    samples_stats: Samples
+
+
+@dataclass
+class Memory:
+    """Report.Memory"""
+    latest_batch: Samples
+    all_samples: Samples
+    per_game_stage: list
+
+
+def memory_report(mem: MemoryBuffer, nn, learning_params: LearningParams, num_game_stages: int, device=0):
+    """memory_report(mem, nn, learning_params, params::MemAnalysisParams) (learning.jl:192-216): samples_report of all
+    samples, of the latest batch, and of num_game_stages slices of the samples sorted by remaining game length t.
+    The network is evaluated in test mode.  Stage slices are staged through a scratch device buffer."""
+    import math
+    gspec = mem.gspec
+
+    def report(m, last_batch=False):
+        with Trainer(gspec, nn, m, learning_params, last_batch=last_batch, device=device) as tr:
+            return tr.samples_report()
+    all_samples = report(mem)
+    latest = report(mem, last_batch=True) if mem.cur_batch_size() > 0 else all_samples
+    with mem.dataset() as d:
+        raw = d.raw_samples()
+        es = sorted((raw[i] for i in range(len(d))), key=lambda e: e.t)            # sort!(es, by = e -> e.t), stable
+    csize = math.ceil(len(es) / num_game_stages)
+    stages = []
+    for k in range(0, len(es), csize):
+        part = es[k:k + csize]
+        scratch = MemoryBuffer(gspec, len(part), device=device)
+        try:
+            scratch.push_samples(part)
+            stages.append(StageSamples(min(e.t for e in part), max(e.t for e in part), report(scratch)))
+        finally:
+            scratch.close()
+    return Memory(latest, all_samples, stages)

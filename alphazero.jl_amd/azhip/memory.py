@@ -89,6 +89,20 @@ class MemoryBuffer:
         tb.moves, tb.moves_cap, tb.num_moves = moves, nmoves, nmoves
         _L.check(_L.lib().az_memory_push(self._h, _C.byref(tb), float(gamma)))
 
+    def push_samples(self, samples):
+        """push!(mem.buf, e) for host TrainingSamples (or raw _lib.Sample records)"""
+        n = len(samples)
+        arr = (_L.Sample * max(n, 1))()
+        for i, e in enumerate(samples):
+            if isinstance(e, _L.Sample):
+                _C.memmove(_C.byref(arr[i]), _C.byref(e), _C.sizeof(_L.Sample))
+                continue
+            arr[i].key[0], arr[i].key[1] = int(e.s[0]), int(e.s[1])
+            for a, p in enumerate(e.π):
+                arr[i].pi[a] = float(p)
+            arr[i].z, arr[i].t, arr[i].n = float(e.z), float(e.t), int(e.n)
+        _L.check(_L.lib().az_memory_push_samples(self._h, arr, n))
+
     def _lens(self):
         a, b = _C.c_int64(), _C.c_int64()
         _L.check(_L.lib().az_memory_length(self._h, _C.byref(a), _C.byref(b)))

@@ -349,6 +349,26 @@ extern "C" int az_memory_push(az_memory* m, const az_trace_buf* tr, double gamma
   m->cur_batch += tot;                                             // mem.cur_batch_size += n, memory.jl:86
   return AZ_OK;
 }
+// push!(mem.buf, sample) for host-resident TrainingSamples (a reference-side MemoryBuffer, or subsets such as the game
+// stages of memory_report, src/learning.jl:192-216); cur_batch_size is not advanced (push_trace! does that)
+extern "C" int az_memory_push_samples(az_memory* m, const az_sample* samples, int64_t n) {
+  MEMORY(m);
+  if (n < 0 || (n > 0 && !samples)) return fail(AZ_ERR_BAD_ARG, "NULL samples");
+  // keep only what survives in the ring, oldest first, then at most two contiguous copies
+  const int64_t skip = std::max<int64_t>(0, n - m->cap);
+  int64_t left = n - skip;
+  const az_sample* src = samples + skip;
+  int64_t seq = m->total + skip;
+  while (left > 0) {
+    const int64_t pos = seq % m->cap, run = std::min<int64_t>(left, m->cap - pos);
+    HIPCHK(hipMemcpyAsync(m->d_buf + pos, src, sizeof(az_sample) * (size_t)run, hipMemcpyHostToDevice, m->stream));
+    src += run; seq += run; left -= run;
+  }
+  HIPCHK(hipStreamSynchronize(m->stream));
+  m->total += n;
+  return AZ_OK;
+}
+
 extern "C" int az_memory_length(az_memory* m, int64_t* length, int64_t* cur_batch_size) {
   MEMORY(m);
   const int64_t len = std::min<int64_t>(m->total, m->cap);

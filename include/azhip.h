@@ -251,6 +251,9 @@ int az_memory_destroy(az_memory* m);
 /* push_trace!(mem, trace, gamma) (src/memory.jl:74-87) for every game of `traces` in buffer order: one sample
  * per move record, pi = MCTS.policy of the recorded visit counts, z / t as az_push_trace. */
 int az_memory_push(az_memory* m, const az_trace_buf* traces, double gamma);
+/* push!(mem.buf, sample) for samples that live on the host (a reference-side MemoryBuffer, a game-stage subset of
+ * memory_report, src/learning.jl:192-216); does not advance cur_batch_size. */
+int az_memory_push_samples(az_memory* m, const az_sample* samples, int64_t n);
 int az_memory_length(az_memory* m, int64_t* length, int64_t* cur_batch_size);   /* length, cur_batch_size (:53-59) */
 int az_memory_new_batch(az_memory* m);                                            /* new_batch! (:55) */
 int az_memory_empty(az_memory* m);                                                /* empty! (:57-60) */

@@ -190,3 +190,36 @@ def test_iteration_example_runs_end_to_end():
         assert np.array_equal(lr1.checkpoints[0].evaluation.rewards, lr2.checkpoints[0].evaluation.rewards)
         assert len(lr1.checkpoints[0].evaluation.rewards) == 4
     assert r1[1][0].memory_size > r1[0][0].memory_size
+
+
+def test_push_samples_and_memory_report():
+    """host TrainingSamples into the device buffer (wrap-around included) and memory_report (learning.jl:192-216)"""
+    import azhip
+    gspec = azhip.TicTacToeSpec()
+    games, moves, ng, nm, _ = _selfplay(1, 12, 4, 16, 2)
+    ref = _oracle_samples(1, games, moves, ng, 1.0)
+    mem = azhip.MemoryBuffer(gspec, 1000)
+    mem.push_records(games, moves, ng, nm, 1.0)
+    host = mem.get_experience()
+    m2 = azhip.MemoryBuffer(gspec, len(host) - 3)                     # smaller than what is pushed: the oldest fall out
+    m2.push_samples(host[:5])
+    m2.push_samples(host[5:])
+    with m2.dataset() as d:
+        _same_samples(d.raw_samples(), ref[3:], 9)
+    assert m2.cur_batch_size() == 0
+    hp = azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    nn = azhip.ResNet(gspec, hp, seed=4)
+    lp = azhip.LearningParams(samples_weighing_policy=1, l2_regularization=1e-4, loss_computation_batch_size=32)
+    rep = azhip.memory_report(mem, nn, lp, num_game_stages=3)
+    assert rep.all_samples.num_samples == nm and rep.latest_batch.num_samples == nm and len(rep.per_game_stage) == 3
+    assert sum(s.samples_stats.num_samples for s in rep.per_game_stage) == nm
+    ts = [(s.min_remaining_length, s.max_remaining_length) for s in rep.per_game_stage]
+    assert ts[0][0] == 1.0 and all(a[1] <= b[0] for a, b in zip(ts, ts[1:]))
+    # the stage statistics equal the oracle's learning status of the same slice
+    es = sorted(ref, key=lambda e: e.t)
+    csize = -(-len(es) // 3)
+    part = R.merge_by_state(1, es[:csize])
+    want = R.learning_status(1, (1, 64, 32, 32), nn.params(), R.convert_samples(1, 1, part), l2=1e-4, batch=32)
+    got = rep.per_game_stage[0].samples_stats.status
+    assert np.allclose([got.loss.L, got.loss.Lp, got.loss.Lv, got.Hp, got.Hpnet], [want.L, want.Lp, want.Lv, want.Hp, want.Hpnet], rtol=2e-6, atol=1e-7)
+    mem.close(); m2.close()
