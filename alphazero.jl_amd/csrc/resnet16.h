@@ -387,3 +387,102 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
       if (row < nvalid) o[(size_t)row * F + ch] = acc[tile][i];
     }
 }
+
+// Weight gradient of a 3x3 F -> F convolution for the optimiser step (train.h):
+//     dW[tap][ci][co] = sum over rows r of a[r + delta(tap)][ci] * dg[r][co]        (taps that leave the board contribute 0)
+// as MFMA 16x16x4 products with the ROWS as the reduction dimension: A operand = 16 input channels x 4 rows of the layer
+// input (shifted by the tap), B operand = 4 rows x 16 output channels of the output gradient.  A workgroup walks its
+// boards three at a time (126 rows + 2 zero rows in LDS, natural channel order); wavefront w owns input-channel tile w
+// and keeps accumulators for TPW taps x all F/16 output-channel tiles in registers (F = 128: 3 taps = one kernel row
+// per workgroup, blockIdx.y selects it; F = 64: all 9 taps).  Every workgroup writes its partial dW, a second kernel
+// adds the partials in a fixed order (deterministic, no atomics).
+template <int F> struct WG16 {
+  static constexpr int TPW = F == 128 ? 3 : 9;                    // taps per workgroup
+  static constexpr int TG = 9 / TPW;                              // tap groups (grid.y)
+  static constexpr int CT = F / 16, WAVES = CT, THREADS = 64 * WAVES;
+  static constexpr int NB = 3;                                    // boards per LDS chunk
+  static constexpr int RP = 128;                                  // padded rows of a chunk (3 x 42 = 126 used; other games: RP / P boards)
+  static constexpr int STRIDE = F + 16;                           // 16-bank shift per row: the 4 row groups of a fragment read use disjoint bank halves in pairs
+  static constexpr int BYTES = ((RP + 1) * STRIDE + RP * STRIDE + RP) * 4;
+};
+template <class Gm, int F>
+__global__ void __launch_bounds__(64 * (F / 16), 1)
+k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __restrict__ part, int nboards, int boards_per_wg) {
+  using G = WG16<F>;
+  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, STRIDE = G::STRIDE, RP = G::RP, CT = G::CT, TPW = G::TPW;
+  constexpr int NBC = RP / P < 1 ? 1 : RP / P;                    // boards per chunk for this game
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                                                // [(RP + 1)][STRIDE], row RP = zeros
+  float* Ds = lds + (RP + 1) * STRIDE;                            // [RP][STRIDE]
+  uint32_t* vtab = (uint32_t*)(Ds + RP * STRIDE);                 // [RP] tap validity of a chunk row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, g = lane >> 4;
+  const int b_begin = blockIdx.x * boards_per_wg;
+  const int b_end = (b_begin + boards_per_wg) < nboards ? (b_begin + boards_per_wg) : nboards;
+  const int tap0 = blockIdx.y * TPW;
+  for (int r = tid; r < RP; r += G::THREADS) {
+    uint32_t m = 0;
+    if (r < NBC * P) {
+      const int q = r % P, x = q % W, y = q / W;
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        m |= (uint32_t)((y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W)) << t;
+      }
+    }
+    vtab[r] = m;
+  }
+  for (int i = tid; i < STRIDE; i += G::THREADS) As[RP * STRIDE + i] = 0.0f;
+  f32x4v acc[TPW][CT];
+#pragma unroll
+  for (int k = 0; k < TPW; ++k)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[k][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  for (int b0 = b_begin; b0 < b_end; b0 += NBC) {
+    const int nb = (b_end - b0) < NBC ? (b_end - b0) : NBC;
+    const int nvalid = nb * P;
+    __syncthreads();                                              // the previous chunk has been consumed
+    const float4* a4 = (const float4*)(a + (size_t)b0 * P * F);
+    const float4* d4 = (const float4*)(dg + (size_t)b0 * P * F);
+    for (int idx = tid; idx < RP * (F / 4); idx += G::THREADS) {
+      const int row = idx / (F / 4), c4 = idx % (F / 4);
+      const bool ok = row < nvalid;
+      const float4 va = ok ? a4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 vd = ok ? d4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(As + row * STRIDE + c4 * 4) = va;
+      *(float4*)(Ds + row * STRIDE + c4 * 4) = vd;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int s = 0; s < RP / 4; ++s) {
+      const int row = 4 * s + g;
+      const uint32_t m = vtab[row];
+      float bv[CT];
+#pragma unroll
+      for (int j = 0; j < CT; ++j) bv[j] = Ds[row * STRIDE + j * 16 + lrow];
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int tap = tap0 + k;
+        const int delta = (tap / 3 - 1) * W + (tap % 3 - 1);
+        const int ar = ((m >> tap) & 1) ? row + delta : RP;
+        const float av = As[ar * STRIDE + wave * 16 + lrow];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[k][j], 0, 0, 0);
+      }
+    }
+  }
+  // partial dW of this workgroup: [split][tap][ci][co], ci = 16 wave + 4 g + i, co = 16 j + lrow
+  float* o = part + (size_t)blockIdx.x * 9 * F * F;
+#pragma unroll
+  for (int k = 0; k < TPW; ++k)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        o[((size_t)(tap0 + k) * F + (wave * 16 + g * 4 + i)) * F + j * 16 + lrow] = acc[k][j][i];
+}
+__global__ void k_wgrad_reduce(const float* __restrict__ part, int nsplit, long long n, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.0f;
+  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+  out[i] = s;
+}

@@ -5,10 +5,11 @@
 //   losses                                      src/learning.jl:67-90
 //   ResNet in TRAIN mode                        src/networks/architectures/resnet.jl:53-92 (BatchNorm with batch statistics)
 //
-// Structure of this version: forward and data gradient of the F -> F tower convolutions run on k_conv16_layer
-// (resnet16.h, the tower's MFMA implicit GEMM as a stand-alone layer); weight gradients, the stem and the 1x1 / dense
-// layers are im2col (hand-written gather) + one plain fp32 GEMM through rocBLAS, which the task's rules allow for
-// plain library GEMMs; everything that is not a GEMM is hand-written here: batch-norm statistics / apply / backward with
+// Structure of this version: the F -> F tower convolutions run on hand-written MFMA kernels in all three passes --
+// forward and data gradient on k_conv16_layer (the tower's implicit GEMM as a stand-alone layer), the weight gradient
+// on k_wgrad16 (resnet16.h); the stem (K = 27), the 1x1 head convolutions and the dense layers are small plain fp32
+// GEMMs through rocBLAS (im2col by a hand-written gather where needed), which the task's rules allow for plain
+// library GEMMs; everything that is not a GEMM is hand-written here: batch-norm statistics / apply / backward with
 // deterministic two-stage column reductions, ReLU and skip wiring, the loss with its analytic gradient (softmax,
 // mask normalisation, KL, invalid-mass penalty, tanh / MSE), parameter layout maps between Flux's arrays and the
 // GEMM matrices, Adam / Nesterov and the running statistics.  rocBLAS is dlopen'ed when the first trainer is
@@ -337,6 +338,7 @@ struct az_trainer {
   int* d_idx; float *bW, *bX, *bA, *bP, *bV;
   float *logits, *v1, *tpre, *dlogits, *dt, *dv1;
   float *dact, *dact2, *dcol;                                                // [R][F] gradients, [R][9F] im2col of a gradient
+  float* wg_part; int wg_splits, wg_bpw; bool wg_mfma;                       // k_wgrad16: partial dW per row split, boards per workgroup
   double *part, *sums, *terms, *bsums;
   std::vector<void*> allocs;
   DevReducer red;                                                            // sized for max(B, 1024) elements
@@ -466,6 +468,18 @@ static int trainer_build(az_trainer* t) {
   AZCHK(tr_alloc(t, &t->part, (size_t)nchunks * 2 * std::max(F, 64))); AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64)));
   AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 5 + 1024));
   AZCHK(t->red.init(std::max(B, 1024), t->stream));
+  // k_wgrad16: one round of workgroups over the chip (one per CU at 128 filters: 145 KB of LDS; two at 64)
+  t->wg_mfma = (F == 64 || F == 128) && !getenv("AZHIP_TRAIN_GEMM") && !getenv("AZHIP_TRAIN_WGRAD_GEMM");
+  t->wg_part = nullptr; t->wg_splits = 0; t->wg_bpw = 0;
+  if (t->wg_mfma) {
+    const int tg = F == 128 ? 3 : 1, per_cu = F == 128 ? 1 : 2;
+    const int nbc = std::max(1, 128 / P);
+    const int target = std::max(1, t->e->num_cu * per_cu / tg);
+    int bpw = (B + target - 1) / target;
+    bpw = (bpw + nbc - 1) / nbc * nbc;                             // whole LDS chunks
+    t->wg_bpw = bpw; t->wg_splits = (B + bpw - 1) / bpw;
+    AZCHK(tr_alloc(t, &t->wg_part, (size_t)t->wg_splits * 9 * F * F));
+  }
   return AZ_OK;
 }
 
@@ -479,6 +493,21 @@ template <class Gm, int F> static int tr_conv16_f(az_trainer* t, const float* in
 // 3x3 F -> F convolution of [R][F] activations on the MFMA layer kernel
 static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* out) {
   DISPATCH_GAME(t->game, { if (t->F == 128) AZCHK((tr_conv16_f<Gm, 128>(t, in, frag, out))); else AZCHK((tr_conv16_f<Gm, 64>(t, in, frag, out))); });
+  return AZ_OK;
+}
+
+template <class Gm, int F> static int tr_wgrad16_f(az_trainer* t, const float* a, const float* dg, float* out) {
+  using G = WG16<F>;
+  static bool attr_done = false;
+  if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16<Gm, F>), hipFuncAttributeMaxDynamicSharedMemorySize, G::BYTES)); attr_done = true; }
+  hipLaunchKernelGGL((k_wgrad16<Gm, F>), dim3(t->wg_splits, G::TG), dim3(G::THREADS), G::BYTES, t->stream, a, dg, t->wg_part, t->B, t->wg_bpw);
+  const long long n = 9LL * F * F;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(tr_grid(n)), dim3(256), 0, t->stream, t->wg_part, t->wg_splits, n, out);
+  return AZ_OK;
+}
+// weight gradient of a 3x3 F -> F convolution on the MFMA kernel: out = [9][F][F] in the Wm layout
+static int tr_wgrad16(az_trainer* t, const float* a, const float* dg, float* out) {
+  DISPATCH_GAME(t->game, { if (t->F == 128) AZCHK((tr_wgrad16_f<Gm, 128>(t, a, dg, out))); else AZCHK((tr_wgrad16_f<Gm, 64>(t, a, dg, out))); });
   return AZ_OK;
 }
 
@@ -511,8 +540,9 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_o
   for (int l = 0; l < ntower; ++l) {
     TrConv& c = t->convs[l];
     const float* in = l == 0 ? t->bX : t->convs[l - 1].a;
+    const bool need_col = !(c.mfma && t->wg_mfma);                  // the GEMM forms of forward / weight gradient read im2col(input)
     if (l == 0) hipLaunchKernelGGL((k_tr_im2col<true>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
-    else hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cin / 4))), dim3(256), 0, st, (const float4*)in, R, c.cin / 4, gi.W, gi.H, (float4*)c.col);
+    else if (need_col) hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cin / 4))), dim3(256), 0, st, (const float4*)in, R, c.cin / 4, gi.W, gi.H, (float4*)c.col);
     if (c.mfma) AZCHK(tr_conv16(t, in, t->work + c.wk_ffwd, c.g));         // (the im2col above feeds the weight gradient)
     else AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
     AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout));
@@ -603,7 +633,8 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_o
     // dg overwrites dact; for conv2 the masked gradient dy also flows to the block input (dact2)
     hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, t->dact, c.a, c.g, c.mean, c.invstd, blob + c.off_bn, t->sums, R, R * c.cout, c.cout,
                        t->dact, second ? t->dact2 : (float*)nullptr);
-    AZCHK(rb::gemm(t->rbh, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, t->dact, c.cout, 0.f, gw + c.wk_wm, c.cout));
+    if (c.mfma && t->wg_mfma) AZCHK(tr_wgrad16(t, t->convs[l - 1].a, t->dact, gw + c.wk_wm));
+    else AZCHK(rb::gemm(t->rbh, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, t->dact, c.cout, 0.f, gw + c.wk_wm, c.cout));
     if (l == 0) break;
     // data gradient: da_prev = im2col(dg) * Wrot
     if (c.mfma) {
