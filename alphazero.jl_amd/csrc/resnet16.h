@@ -451,7 +451,7 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
       *(float4*)(Ds + row * STRIDE + c4 * 4) = vd;
     }
     __syncthreads();
-#pragma unroll 2
+#pragma unroll 4
     for (int s = 0; s < RP / 4; ++s) {
       const int row = 4 * s + g;
       const uint32_t m = vtab[row];
@@ -482,7 +482,12 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
 __global__ void k_wgrad_reduce(const float* __restrict__ part, int nsplit, long long n, float* __restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float s = 0.0f;
-  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
-  out[i] = s;
+  // eight independent partial sums keep eight loads in flight; combined in a fixed order
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= nsplit; k += 8)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(k + u) * n + i];
+  for (; k < nsplit; ++k) s[0] += part[(size_t)k * n + i];
+  out[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }

@@ -468,11 +468,11 @@ static int trainer_build(az_trainer* t) {
   AZCHK(tr_alloc(t, &t->part, (size_t)nchunks * 2 * std::max(F, 64))); AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64)));
   AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 5 + 1024));
   AZCHK(t->red.init(std::max(B, 1024), t->stream));
-  // k_wgrad16: one round of workgroups over the chip (one per CU at 128 filters: 145 KB of LDS; two at 64)
+  // k_wgrad16: one round of workgroups over the chip
   t->wg_mfma = (F == 64 || F == 128) && !getenv("AZHIP_TRAIN_GEMM") && !getenv("AZHIP_TRAIN_WGRAD_GEMM");
   t->wg_part = nullptr; t->wg_splits = 0; t->wg_bpw = 0;
   if (t->wg_mfma) {
-    const int tg = F == 128 ? 3 : 1, per_cu = F == 128 ? 1 : 2;
+    const int tg = F == 128 ? 3 : 1, per_cu = 1;                    // 82 KB (64 filters) / 145 KB (128) of LDS: one workgroup per CU either way
     const int nbc = std::max(1, 128 / P);
     const int target = std::max(1, t->e->num_cu * per_cu / tg);
     int bpw = (B + target - 1) / target;
