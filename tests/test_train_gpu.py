@@ -101,10 +101,11 @@ def _rel_err_by_array(game, hp, got, want):
     return worst
 
 
-@pytest.mark.parametrize("game,nblocks,F,B,policy", [(1, 1, 64, 24, 1), (0, 2, 64, 16, 0), (2, 1, 64, 20, 2), (0, 1, 128, 12, 1)])
+@pytest.mark.parametrize("game,nblocks,F,B,policy", [(1, 1, 64, 24, 1), (0, 2, 64, 16, 0), (2, 1, 64, 20, 2), (0, 1, 128, 12, 1),
+                                                     (0, 1, 128, 203, 1), (0, 2, 64, 333, 0), (1, 1, 64, 500, 2)])   # many workgroups, ragged tails
 def test_gradients_match_torch_autograd(game, nblocks, F, B, policy):
     import azhip
-    gspec, mem = _memory(game, 12, 3)
+    gspec, mem = _memory(game, 12 if B < 100 else 60, 3)
     hp = azhip.ResNetHP(num_blocks=nblocks, num_filters=F, num_policy_head_filters=32, num_value_head_filters=32)
     nn = azhip.ResNet(gspec, hp, seed=8)
     lp = azhip.LearningParams(samples_weighing_policy=policy, l2_regularization=1e-4, loss_computation_batch_size=64, batch_size=B,
