@@ -277,12 +277,33 @@ __global__ void k_tr_loss(const float* __restrict__ logits, const float* __restr
   dt[i] = 2.0f * d / rho * (1.0f - vh * vh) * w * gscale;
   t_w[i] = (double)w; t_kl[i] = kl; t_mse[i] = (double)(d * d * w); t_inv[i] = (double)((1.0f - S) * w);
 }
+// the five sums of a step in one launch: out = (sum w, sum kl, sum mse, sum inv, sum of squares of the trainables)
+__global__ void __launch_bounds__(256) k_tr_step_sums(const double* __restrict__ tw, const double* __restrict__ tkl, const double* __restrict__ tmse,
+                                                      const double* __restrict__ tinv, int B, const double* __restrict__ ssq_part, int nssq,
+                                                      double* __restrict__ out) {
+  __shared__ double sh[5][256];
+  double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < B; i += 256) { a[0] += tw[i]; a[1] += tkl[i]; a[2] += tmse[i]; a[3] += tinv[i]; }
+  for (int i = threadIdx.x; i < nssq; i += 256) a[4] += ssq_part[i];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] = a[k];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x < 5) out[threadIdx.x] = sh[threadIdx.x][0];
+}
 // Adam (Optimisers.Adam: beta (0.9, 0.999), eps 1e-8) / Nesterov (Optimisers.Nesterov) on the trainable entries of
 // the blob; the L2 term of the loss, scale * creg * sum(w^2), is added to the gradient here: + scale * 2 creg w.
 __global__ void k_tr_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                          const unsigned char* __restrict__ trainable, long long n, float lr, float b1t, float b2t, float reg2) {
+                          const unsigned char* __restrict__ trainable, long long n, float lr, float b1t, float b2t,
+                          const double* __restrict__ sums, float reg_c /* 2 creg / (B Wmean) */) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !trainable[i]) return;
+  const float reg2 = (float)sums[0] * reg_c;                       // scale * 2 creg, scale = mean(W_batch) / Wmean
   const float gi = g[i] + reg2 * w[i];
   const float mt = 0.9f * m[i] + (1.0f - 0.9f) * gi;
   const float vt = 0.999f * v[i] + (1.0f - 0.999f) * gi * gi;
@@ -290,9 +311,11 @@ __global__ void k_tr_adam(float* __restrict__ w, const float* __restrict__ g, fl
   w[i] -= mt / (1.0f - b1t) / (__builtin_sqrtf(vt / (1.0f - b2t)) + 1e-8f) * lr;
 }
 __global__ void k_tr_nesterov(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ vel,
-                              const unsigned char* __restrict__ trainable, long long n, float lr, float rho, float reg2) {
+                              const unsigned char* __restrict__ trainable, long long n, float lr, float rho,
+                              const double* __restrict__ sums, float reg_c) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !trainable[i]) return;
+  const float reg2 = (float)sums[0] * reg_c;
   const float gi = g[i] + reg2 * w[i];
   const float vo = vel[i];
   const float d = rho * rho * vo - (1.0f + rho) * lr * gi;         // Optimisers.Nesterov: newdx = -d
@@ -341,7 +364,6 @@ struct az_trainer {
   float* wg_part; int wg_splits, wg_bpw; bool wg_mfma;                       // k_wgrad16: partial dW per row split, boards per workgroup
   double *part, *sums, *terms, *bsums;
   std::vector<void*> allocs;
-  DevReducer red;                                                            // sized for max(B, 1024) elements
   std::vector<int> perm; int64_t perm_pos, epoch; int64_t step;
   float b1t, b2t;
 };
@@ -466,8 +488,7 @@ static int trainer_build(az_trainer* t) {
   AZCHK(tr_alloc(t, &t->dact, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dact2, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dcol, (size_t)R * 9 * F));
   const int nchunks = (int)((R + TR_CHUNK - 1) / TR_CHUNK);
   AZCHK(tr_alloc(t, &t->part, (size_t)nchunks * 2 * std::max(F, 64))); AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64)));
-  AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 5 + 1024));
-  AZCHK(t->red.init(std::max(B, 1024), t->stream));
+  AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 8 + 1024));
   // k_wgrad16: one round of workgroups over the chip
   t->wg_mfma = (F == 64 || F == 128) && !getenv("AZHIP_TRAIN_GEMM") && !getenv("AZHIP_TRAIN_WGRAD_GEMM");
   t->wg_part = nullptr; t->wg_splits = 0; t->wg_bpw = 0;
@@ -521,8 +542,9 @@ static int tr_colsum(az_trainer* t, const float* x, const float* out_act, const 
 }
 
 // forward (train mode) + loss + backward for the batch idx[0..B); the gradient of the DATA terms is left in t->gblob
-// (blob layout, L2 term not included), *loss_out = L of `losses` including Lreg.
-static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_out, float* parts_out /* Lp, Lv, Lreg, Linv or NULL */) {
+// (blob layout, L2 term not included); the step's five sums (w, kl, mse, inv, sum of squares) go to d_sums (device).
+// Nothing here waits for the GPU: idx_host must stay alive until the stream has consumed it.
+static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sums) {
   const GameInfo& gi = t->gi;
   const int F = t->F, C = gi.C, P = gi.P, A = gi.A, npf = t->npf, nvf = t->nvf, B = t->B;
   const long long R = t->R;
@@ -568,26 +590,12 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_o
   AZCHK(rb::gemm(t->rbh, false, false, B, 1, F, 1.f, t->v1, F, t->work + t->wk_v2, 1, 0.f, t->tpre, 1));
   hipLaunchKernelGGL(k_tr_bias_act, dim3(tr_grid(B)), dim3(256), 0, st, t->tpre, blob + t->off_v2_b, (long long)B, 1, 0);
   // ---------------- loss ----------------
-  hipLaunchKernelGGL(k_f32_to_f64, dim3(tr_grid(B)), dim3(256), 0, st, t->bW, (long long)B, t->terms);
-  DevReducer& red = t->red;
-  double sw;
-  AZCHK(red.sum(t->terms, B, st, &sw));
-  const float scale = (float)(sw / (double)B) / d->Wmean;          // mean(W) / Wmean, learning.jl:88
+  // mean(W)/Wmean / sum(W) = 1 / (B Wmean): the gradient scale needs no reduction first (learning.jl:88)
   double *tw = t->terms, *tkl = t->terms + B, *tmse = t->terms + 2 * (size_t)B, *tinv = t->terms + 3 * (size_t)B;
   hipLaunchKernelGGL(k_tr_loss, dim3(tr_grid(B)), dim3(256), 0, st, t->logits, t->tpre, t->bA, t->bP, t->bV, t->bW, B, A,
-                     (float)t->cfg.nonvalidity_penalty, (float)t->cfg.rewards_renormalization, scale / (float)sw, t->dlogits, t->dt, tw, tkl, tmse, tinv);
-  double kl, mse, inv, ssq = 0.0;
-  AZCHK(red.sum(tkl, B, st, &kl)); AZCHK(red.sum(tmse, B, st, &mse)); AZCHK(red.sum(tinv, B, st, &inv));
-  {
-    hipLaunchKernelGGL(k_tr_sumsq, dim3(1024), dim3(256), 0, st, blob, t->trainable, (long long)t->nparams, t->bsums + 5);
-    AZCHK(red.sum(t->bsums + 5, 1024, st, &ssq));
-  }
-  const float Lp = (float)(-kl / sw) - d->Hp;
-  const float Lv = (float)(mse / sw);
-  const float Lreg = t->cfg.l2_regularization == 0.0 ? 0.f : (float)((double)(float)t->cfg.l2_regularization * ssq);
-  const float Linv = t->cfg.nonvalidity_penalty == 0.0 ? 0.f : (float)t->cfg.nonvalidity_penalty * (float)(inv / sw);
-  *loss_out = scale * (Lp + Lv + Lreg + Linv);
-  if (parts_out) { parts_out[0] = Lp; parts_out[1] = Lv; parts_out[2] = Lreg; parts_out[3] = Linv; parts_out[4] = scale; }
+                     (float)t->cfg.nonvalidity_penalty, (float)t->cfg.rewards_renormalization, 1.0f / ((float)B * d->Wmean), t->dlogits, t->dt, tw, tkl, tmse, tinv);
+  hipLaunchKernelGGL(k_tr_sumsq, dim3(1024), dim3(256), 0, st, blob, t->trainable, (long long)t->nparams, t->bsums + 8);
+  hipLaunchKernelGGL(k_tr_step_sums, dim3(1), dim3(256), 0, st, tw, tkl, tmse, tinv, B, t->bsums + 8, 1024, d_sums);
   // ---------------- backward: dense heads ----------------
   float* gw = t->gwork;
   float* gb = t->gblob;
@@ -653,9 +661,18 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, float* loss_o
     hipLaunchKernelGGL(k_tr_scatter, dim3(tr_grid((long long)c.taps * c.cin * c.cout)), dim3(256), 0, st, gw + c.wk_wm, t->map + c.wk_wm, (long long)c.taps * c.cin * c.cout, gb);
   const long long ndense = (long long)(t->nwork - t->wk_pd);
   hipLaunchKernelGGL(k_tr_scatter, dim3(tr_grid(ndense)), dim3(256), 0, st, gw + t->wk_pd, t->map + t->wk_pd, ndense, gb);
-  HIPCHK(hipStreamSynchronize(st));
-  HIPCHK(hipGetLastError());
   return AZ_OK;
+}
+// `losses` from the five sums of a step (learning.jl:67-90): L and (Lp, Lv, Lreg, Linv, mean(W)/Wmean)
+static void tr_losses(const az_trainer* t, const double* sums, float* L, float* parts) {
+  const double sw = sums[0];
+  const float scale = (float)(sw / (double)t->B) / t->d->Wmean;
+  const float Lp = (float)(-sums[1] / sw) - t->d->Hp;
+  const float Lv = (float)(sums[2] / sw);
+  const float Lreg = t->cfg.l2_regularization == 0.0 ? 0.f : (float)((double)(float)t->cfg.l2_regularization * sums[4]);
+  const float Linv = t->cfg.nonvalidity_penalty == 0.0 ? 0.f : (float)t->cfg.nonvalidity_penalty * (float)(sums[3] / sw);
+  *L = scale * (Lp + Lv + Lreg + Linv);
+  if (parts) { parts[0] = Lp; parts[1] = Lv; parts[2] = Lreg; parts[3] = Linv; parts[4] = scale; }
 }
 
 static void tr_next_batch(az_trainer* t, std::vector<int>& idx) {
@@ -720,7 +737,12 @@ extern "C" int az_trainer_gradients(az_trainer* t, const int32_t* sample_idx, fl
   // the running statistics must not move in a gradient probe: save / restore them around the pass
   std::vector<float> saved(t->nparams);
   HIPCHK(hipMemcpy(saved.data(), t->blob, sizeof(float) * t->nparams, hipMemcpyDeviceToHost));
-  AZCHK(tr_forward_backward(t, sample_idx, loss, parts));
+  AZCHK(tr_forward_backward(t, sample_idx, t->bsums));
+  double sums[5];
+  HIPCHK(hipMemcpyAsync(sums, t->bsums, sizeof sums, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  HIPCHK(hipGetLastError());
+  tr_losses(t, sums, loss, parts);
   if (grad) HIPCHK(hipMemcpy(grad, t->gblob, sizeof(float) * t->nparams, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(t->blob, saved.data(), sizeof(float) * t->nparams, hipMemcpyHostToDevice));
   return AZ_OK;
@@ -730,17 +752,23 @@ extern "C" int az_trainer_gradients(az_trainer* t, const int32_t* sample_idx, fl
 extern "C" int az_trainer_batch_updates(az_trainer* t, int32_t n, float* losses) {
   TRAINER(t);
   if (n < 0) return fail(AZ_ERR_BAD_ARG, "n must be >= 0");
-  std::vector<int> idx;
-  for (int i = 0; i < n; ++i) {
-    tr_next_batch(t, idx);
-    float L, parts[5];
-    AZCHK(tr_forward_backward(t, idx.data(), &L, parts));
-    if (losses) losses[i] = L;
-    const float reg2 = parts[4] * 2.0f * (float)t->cfg.l2_regularization;      // d/dw of scale * creg * sum(w^2)
+  if (n == 0) return AZ_OK;
+  // the n steps are enqueued back to back: no host round trip inside the loop (the step sums of every step stay on the
+  // device until the end; the batch indices of all steps stay alive in `idx`)
+  std::vector<std::vector<int>> idx((size_t)n);
+  double* d_sums = nullptr;
+  HIPCHK(hipMalloc((void**)&d_sums, sizeof(double) * 5 * (size_t)n));
+  const float reg_c = (float)(2.0 * (double)(float)t->cfg.l2_regularization / ((double)t->B * (double)t->d->Wmean));   // d/dw of scale * creg * sum(w^2) = (sum W) * reg_c * w
+  int rc = AZ_OK;
+  for (int i = 0; i < n && rc == AZ_OK; ++i) {
+    tr_next_batch(t, idx[i]);
+    double* ds = d_sums + 5 * (size_t)i;
+    rc = tr_forward_backward(t, idx[i].data(), ds);
+    if (rc != AZ_OK) break;
     if (t->cfg.optimiser == AZ_OPT_ADAM) {
       t->b1t *= 0.9f; t->b2t *= 0.999f;
       hipLaunchKernelGGL(k_tr_adam, dim3(tr_grid((long long)t->nparams)), dim3(256), 0, t->stream, t->blob, t->gblob, t->opt_m, t->opt_v, t->trainable,
-                         (long long)t->nparams, t->cfg.lr, t->b1t, t->b2t, reg2);
+                         (long long)t->nparams, t->cfg.lr, t->b1t, t->b2t, ds, reg_c);
     } else {
       // lr = CyclicSchedule(lr_base, lr_high, lr_low; n), momentum = CyclicSchedule(momentum_high, momentum_low,
       // momentum_high; n) (flux.jl:78-94); CyclicSchedule = PLSchedule([1, floor(.45 n), floor(.9 n), n], [base, mid, base,
@@ -759,12 +787,18 @@ extern "C" int az_trainer_batch_updates(az_trainer* t, int32_t n, float* losses)
       const float lr = i == 0 ? t->cfg.lr_low : cyc(t->cfg.lr_base, t->cfg.lr_high, t->cfg.lr_low, i);
       const float rho = i == 0 ? t->cfg.momentum_high : cyc(t->cfg.momentum_high, t->cfg.momentum_low, t->cfg.momentum_high, i);
       hipLaunchKernelGGL(k_tr_nesterov, dim3(tr_grid((long long)t->nparams)), dim3(256), 0, t->stream, t->blob, t->gblob, t->opt_m, t->trainable,
-                         (long long)t->nparams, lr, rho, reg2);
+                         (long long)t->nparams, lr, rho, ds, reg_c);
     }
     t->step++;
   }
-  HIPCHK(hipStreamSynchronize(t->stream));
-  HIPCHK(hipGetLastError());
+  std::vector<double> sums(5 * (size_t)n);
+  hipError_t e1 = hipMemcpyAsync(sums.data(), d_sums, sizeof(double) * sums.size(), hipMemcpyDeviceToHost, t->stream);
+  hipError_t e2 = hipStreamSynchronize(t->stream);
+  hipError_t e3 = hipGetLastError();
+  (void)hipFree(d_sums);
+  AZCHK(rc);
+  HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
+  if (losses) for (int i = 0; i < n; ++i) tr_losses(t, &sums[5 * (size_t)i], &losses[i], nullptr);
   return AZ_OK;
 }
 
