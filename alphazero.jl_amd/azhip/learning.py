@@ -81,6 +81,7 @@ class Trainer:
         self.gspec, self.params = gspec, params
         self.data = Dataset(mem, last_batch, use_symmetries, params.use_position_averaging, params.samples_weighing_policy)
         self.Wmean, self.Hp = self.data.Wmean, self.data.Hp
+        self._hyper = network.hyper
         kw = network.engine_options()
         self._eng = Engine(game=gspec.game_id, oracle=L.ORACLE_RESNET, device=device, num_workers=8, batch_size=8,
                            num_iters_per_turn=2, **kw)
@@ -94,7 +95,7 @@ class Trainer:
         self._eng.close()
 
     # ---- the optimiser step (learning.jl:123-141) ----
-    def _trainer(self, optimiser=None, batch_norm_momentum=0.1, seed=1):
+    def _trainer(self, optimiser=None, batch_norm_momentum=None, seed=1):
         if getattr(self, "_tr", None):
             return self._tr
         cfg = L.TrainCfg()
@@ -109,7 +110,8 @@ class Trainer:
         p = self.params
         cfg.l2_regularization, cfg.nonvalidity_penalty = p.l2_regularization, p.nonvalidity_penalty
         cfg.rewards_renormalization, cfg.batch_size = p.rewards_renormalization, p.batch_size
-        cfg.batch_norm_momentum, cfg.seed = batch_norm_momentum, seed
+        cfg.batch_norm_momentum = self._hyper.batch_norm_momentum if batch_norm_momentum is None else batch_norm_momentum   # ResNetHP, resnet.jl:30-37
+        cfg.seed = seed
         h = C.c_void_p()
         L.check(L.lib().az_trainer_create(self._eng._h, self.data._h, C.byref(cfg), C.byref(h)))
         self._tr = h

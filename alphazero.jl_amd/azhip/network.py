@@ -190,3 +190,31 @@ def copy(nn, on_gpu, test_mode):
 
 def with_filters(hp, **kw):
     return replace(hp, **kw)
+
+
+MAGIC = b"AZHIPNET"
+
+
+def save_params(path, nn):
+    """Raw checkpoint of a network: magic, game id, ResNetHP fields (int32), parameter count (int64), Float32 little-endian
+    blob in Flux parameter order -- the file julia/AlphaZeroHIP.jl's save_params writes (checkpoint interop)."""
+    import struct
+    h = nn.hyper
+    with open(path, "wb") as f:
+        f.write(MAGIC)
+        f.write(struct.pack("<5iq", nn.gspec.game_id, h.num_blocks, h.num_filters, h.num_policy_head_filters, h.num_value_head_filters,
+                            nn.params().size))
+        f.write(np.ascontiguousarray(nn.params(), dtype="<f4").tobytes())
+
+
+def load_params(path, gspec):
+    import struct
+    with open(path, "rb") as f:
+        if f.read(8) != MAGIC:
+            raise ValueError("not an AZHIPNET parameter file")
+        game, nb, nf, npf, nvf, n = struct.unpack("<5iq", f.read(28))
+        if game != gspec.game_id:
+            raise ValueError("parameter file is for game %d" % game)
+        blob = np.frombuffer(f.read(4 * n), dtype="<f4").astype(np.float32)
+    hp = ResNetHP(num_blocks=nb, num_filters=nf, num_policy_head_filters=npf, num_value_head_filters=nvf)
+    return ResNet(gspec, hp, params=blob)

@@ -186,6 +186,39 @@ function HipResNet(nn::AlphaZero.ResNet)
   return HipResNet(nn.gspec, nn.hyper, reduce(vcat, parts), nothing, true)
 end
 
+"""
+    flux_resnet(nn::HipResNet) -> AlphaZero.ResNet
+
+The inverse of `HipResNet(::ResNet)`: a Flux ResNet (resnet.jl:65-92) whose arrays are filled from the blob, e.g. after
+`device_batch_updates!`, so that sessions / checkpoints (`src/ui/session.jl:92-118`) keep serialising a stock network.
+"""
+function flux_resnet(nn::HipResNet)
+  out = AlphaZero.ResNet(nn.gspec, nn.hyper)
+  off = Ref(0)
+  take!(a) = (n = length(a); copyto!(a, reshape(view(nn.blob, off[]+1 : off[]+n), size(a))); off[] += n)
+  conv!(c) = (take!(c.weight); take!(c.bias))
+  bn!(b) = (take!(b.γ); take!(b.β); take!(b.μ); take!(b.σ²))
+  conv!(out.common[1]); bn!(out.common[2])
+  for i in 1:nn.hyper.num_blocks
+    inner = out.common[2 + i][1].layers
+    conv!(inner[1]); bn!(inner[2]); conv!(inner[3]); bn!(inner[4])
+  end
+  ph, vh = out.phead, out.vhead
+  conv!(ph[1]); bn!(ph[2]); take!(ph[4].weight); take!(ph[4].bias)
+  conv!(vh[1]); bn!(vh[2]); take!(vh[4].weight); take!(vh[4].bias); take!(vh[5].weight); take!(vh[5].bias)
+  @assert off[] == length(nn.blob)
+  return out
+end
+
+"Raw checkpoint of the parameter blob: magic, game id, ResNetHP fields, count, Float32 little-endian values (same file as azhip.network.save_params)"
+function save_params(path, nn::HipResNet)
+  open(path, "w") do io
+    write(io, b"AZHIPNET"); write(io, Int32(game_id(nn.gspec)), Int32(nn.hyper.num_blocks), Int32(nn.hyper.num_filters),
+      Int32(nn.hyper.num_policy_head_filters), Int32(nn.hyper.num_value_head_filters), Int64(length(nn.blob)))
+    write(io, nn.blob)
+  end
+end
+
 function engine!(nn::HipResNet)
   if isnothing(nn.engine)
     mcts = MctsParams(num_iters_per_turn=2, dirichlet_noise_ϵ=0., dirichlet_noise_α=1.)

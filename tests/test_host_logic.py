@@ -103,3 +103,15 @@ def test_repack_by_game_id_orders_games_and_keeps_their_moves():
     assert list(M["action"]) == [0, 1, 2, 10, 11, 12, 13, 20, 30, 31]
     G0, M0 = repack_by_game_id(g[:0], m[:0])
     assert len(G0) == 0 and len(M0) == 0
+
+
+def test_parameter_file_round_trip(tmp_path):
+    from azhip.game import ConnectFourSpec, TicTacToeSpec
+    from azhip.network import ResNet, ResNetHP, load_params, save_params
+    nn = ResNet(ConnectFourSpec(), ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32), seed=3)
+    p = str(tmp_path / "net.azhip")
+    save_params(p, nn)
+    back = load_params(p, ConnectFourSpec())
+    assert np.array_equal(back.params(), nn.params()) and back.hyper == nn.hyper
+    with pytest.raises(ValueError):
+        load_params(p, TicTacToeSpec())

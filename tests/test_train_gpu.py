@@ -131,7 +131,7 @@ def test_gradients_match_torch_autograd(game, nblocks, F, B, policy):
 
 def test_adam_steps_follow_torch():
     """batch_updates!: three Adam steps on the device vs torch.optim.Adam on the fp64 restatement (same batches through the
-    shuffling contract), incl. the L2 term and the BatchNorm running statistics (momentum 0.1, unbiased running variance)"""
+    shuffling contract), incl. the L2 term and the BatchNorm running statistics (ResNetHP.batch_norm_momentum, unbiased running variance)"""
     import azhip
     game, B = 1, 32
     gspec, mem = _memory(game, 24, 4)
@@ -163,9 +163,10 @@ def test_adam_steps_follow_torch():
             L.backward()
             opt.step()
             losses.append(L.item())
+            mom = hp.batch_norm_momentum                                  # ResNetHP default 0.6 (resnet.jl:30-37)
             for pre, (mu, var, m) in ref.batch_stats.items():
-                run[pre + ".mean"] = 0.9 * run[pre + ".mean"] + 0.1 * mu
-                run[pre + ".var"] = 0.9 * run[pre + ".var"] + 0.1 * var * (m / (m - 1))
+                run[pre + ".mean"] = (1 - mom) * run[pre + ".mean"] + mom * mu
+                run[pre + ".var"] = (1 - mom) * run[pre + ".var"] + mom * var * (m / (m - 1))
         for k, v in run.items():
             ref.p[k] = v
         want = ref.blob()
