@@ -436,37 +436,85 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
   for (int k = 0; k < TPW; ++k)
 #pragma unroll
     for (int j = 0; j < CT; ++j) acc[k][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  // tap validity of this lane's row in every step of a chunk (rows 4 s + g, s = 0..31), one bit per step and tap:
+  // chunk-invariant, so the operand addresses of a step need no table look-up
+  uint32_t vbits[TPW];
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) vbits[k] = 0;
+  for (int st = 0; st < RP / 4; ++st) {
+    const int r = 4 * st + g;
+    if (r < NBC * P) {
+      const int q = r % P, x = q % W, y = q / W;
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int tap = tap0 + k, dy = tap / 3 - 1, dx = tap % 3 - 1;
+        vbits[k] |= (uint32_t)((y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W)) << st;
+      }
+    }
+  }
+  // The chunk after the current one travels from HBM into registers while the MFMAs of the current one run (every
+  // workgroup reaches its chunk boundaries at the same time: without the overlap the chip alternates between a burst of
+  // loads and a burst of MFMAs); it is stored to LDS once the current chunk has been consumed.
+  constexpr int NPF = RP * (F / 4) / G::THREADS;                  // float4 per thread and array
+  static_assert(RP * (F / 4) % G::THREADS == 0, "chunk must divide over the threads");
+  float4 pa[NPF], pd[NPF];
+  auto prefetch = [&](int b0) {
+    const int nbp = (b_end - b0) < NBC ? (b_end - b0) : NBC;
+    const int nv = nbp > 0 ? nbp * P : 0;
+    const float4* a4 = (const float4*)(a + (size_t)b0 * P * F);
+    const float4* d4 = (const float4*)(dg + (size_t)b0 * P * F);
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+      const int idx = tid + q * G::THREADS, row = idx / (F / 4), c4 = idx % (F / 4);
+      const bool ok = row < nv;
+      pa[q] = ok ? a4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      pd[q] = ok ? d4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  prefetch(b_begin);
   for (int b0 = b_begin; b0 < b_end; b0 += NBC) {
     const int nb = (b_end - b0) < NBC ? (b_end - b0) : NBC;
     const int nvalid = nb * P;
     __syncthreads();                                              // the previous chunk has been consumed
-    const float4* a4 = (const float4*)(a + (size_t)b0 * P * F);
-    const float4* d4 = (const float4*)(dg + (size_t)b0 * P * F);
-    for (int idx = tid; idx < RP * (F / 4); idx += G::THREADS) {
-      const int row = idx / (F / 4), c4 = idx % (F / 4);
-      const bool ok = row < nvalid;
-      const float4 va = ok ? a4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 vd = ok ? d4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-      *(float4*)(As + row * STRIDE + c4 * 4) = va;
-      *(float4*)(Ds + row * STRIDE + c4 * 4) = vd;
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+      const int idx = tid + q * G::THREADS, row = idx / (F / 4), c4 = idx % (F / 4);
+      *(float4*)(As + row * STRIDE + c4 * 4) = pa[q];
+      *(float4*)(Ds + row * STRIDE + c4 * 4) = pd[q];
     }
     __syncthreads();
-#pragma unroll 4
-    for (int s = 0; s < RP / 4; ++s) {
-      const int row = 4 * s + g;
-      const uint32_t m = vtab[row];
-      float bv[CT];
+    if (b0 + NBC < b_end) prefetch(b0 + NBC);
+    const int nsteps = (nvalid + 15) / 16 * 4;                    // rows past the chunk's boards are zero: skip them (whole groups of 4 steps)
+    // two register stages: the LDS operands of step s+1 are requested before the 24 (36) MFMAs of step s issue
+    float bv0[CT], av0[TPW], bv1[CT], av1[TPW];
+    auto load_step = [&](int st, float (&bv)[CT], float (&av)[TPW]) {
+      const int row = 4 * st + g;
 #pragma unroll
       for (int j = 0; j < CT; ++j) bv[j] = Ds[row * STRIDE + j * 16 + lrow];
 #pragma unroll
       for (int k = 0; k < TPW; ++k) {
         const int tap = tap0 + k;
         const int delta = (tap / 3 - 1) * W + (tap % 3 - 1);
-        const int ar = ((m >> tap) & 1) ? row + delta : RP;
-        const float av = As[ar * STRIDE + wave * 16 + lrow];
-#pragma unroll
-        for (int j = 0; j < CT; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[k][j], 0, 0, 0);
+        const int ar = ((vbits[k] >> st) & 1) ? row + delta : RP;
+        av[k] = As[ar * STRIDE + wave * 16 + lrow];
       }
+    };
+    auto mfma_step = [&](const float (&bv)[CT], const float (&av)[TPW]) {
+#pragma unroll
+      for (int k = 0; k < TPW; ++k)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[j], acc[k][j], 0, 0, 0);
+    };
+    load_step(0, bv0, av0);
+    for (int s0 = 0; s0 < nsteps; s0 += 2) {
+      load_step(s0 + 1, bv1, av1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(bv0, av0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s0 + 2 < nsteps) load_step(s0 + 2, bv0, av0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(bv1, av1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // partial dW of this workgroup: [split][tap][ci][co], ci = 16 wave + 4 g + i, co = 16 j + lrow
