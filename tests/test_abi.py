@@ -94,3 +94,15 @@ def test_push_trace_host_function_matches_oracle_and_mirror():
         R.lib().azr_push_trace(R.MANCALA, C.byref(moves, g.first_move * 64), g.num_moves, C.c_double(0.9), vp(zr), vp(tr))
         assert np.array_equal(z, zr) and np.array_equal(t, tr)
         assert t[0] == g.num_moves and t[-1] == 1 and abs(z[-1]) in (0.0, 1.0)
+
+
+def test_new_record_layouts():
+    """az_sample (112 B, also the oracle's record), az_train_cfg (size written by az_train_cfg_init), the small result structs"""
+    import azref as R
+    assert C.sizeof(L.Sample) == 112 == C.sizeof(R.Sample) == R.lib().azr_sizeof_sample()
+    cfg = L.TrainCfg()
+    L.check(L.lib().az_train_cfg_init(C.byref(cfg)))
+    assert cfg.struct_size == C.sizeof(L.TrainCfg) and cfg.optimiser == L.OPT_ADAM and cfg.batch_size == 1024
+    assert abs(cfg.lr - 2e-3) < 1e-9 and cfg.l2_regularization == 1e-4       # games/connect-four/params.jl:46-58
+    assert C.sizeof(L.DatasetInfo) == 32 and C.sizeof(L.LearningStatusRec) == 28
+    assert L.lib().az_train_cfg_init(None) == L.AZ_ERR_BAD_ARG
