@@ -753,6 +753,11 @@ extern "C" int az_trainer_batch_updates(az_trainer* t, int32_t n, float* losses)
   TRAINER(t);
   if (n < 0) return fail(AZ_ERR_BAD_ARG, "n must be >= 0");
   if (n == 0) return AZ_OK;
+  // Network.train! builds a fresh optimiser state on every call (Flux.setup inside train!, flux.jl:69,83): the Adam
+  // moments / Nesterov velocities do not survive from one batch_updates! (checkpoint) to the next
+  HIPCHK(hipMemsetAsync(t->opt_m, 0, sizeof(float) * t->nparams, t->stream));
+  HIPCHK(hipMemsetAsync(t->opt_v, 0, sizeof(float) * t->nparams, t->stream));
+  t->b1t = 1.0f; t->b2t = 1.0f;
   // the n steps are enqueued back to back: no host round trip inside the loop (the step sums of every step stay on the
   // device until the end; the batch indices of all steps stay alive in `idx`)
   std::vector<std::vector<int>> idx((size_t)n);

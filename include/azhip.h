@@ -303,7 +303,8 @@ int az_trainer_create(az_engine* e, az_dataset* d, const az_train_cfg* cfg, az_t
 int az_trainer_destroy(az_trainer* t);
 /* batch_updates!(tr, n): n optimiser steps (forward in train mode = BatchNorm with batch statistics, `losses`,
  * backward, Adam / Nesterov with the L2 term, running statistics) on successive shuffled batches (DataLoader
- * partial = false, cycled); losses[i] = L of step i before its update (Network.train! callback). */
+ * partial = false, cycled); losses[i] = L of step i before its update (Network.train! callback).  Like the reference
+ * (Flux.setup inside train!), every call starts from a fresh optimiser state; the batch stream continues. */
 int az_trainer_batch_updates(az_trainer* t, int32_t n, float* losses);
 int az_trainer_get_params(az_trainer* t, float* blob, int64_t n);   /* get_trained_network (src/learning.jl:127-129) */
 /* Parity hook: loss and data gradient (Flux parameter order, running-statistics entries 0, L2 term excluded) of the batch

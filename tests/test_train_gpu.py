@@ -129,7 +129,8 @@ def test_gradients_match_torch_autograd(game, nblocks, F, B, policy):
     mem.close()
 
 
-def test_adam_steps_follow_torch():
+@pytest.mark.parametrize("reset_at", [None, 2])
+def test_adam_steps_follow_torch(reset_at):
     """batch_updates!: three Adam steps on the device vs torch.optim.Adam on the fp64 restatement (same batches through the
     shuffling contract), incl. the L2 term and the BatchNorm running statistics (ResNetHP.batch_norm_momentum, unbiased running variance)"""
     import azhip
@@ -143,7 +144,10 @@ def test_adam_steps_follow_torch():
         data = tr.data.tensors()
         n = len(data[0])
         st0 = tr.learning_status()
-        ls = tr.batch_updates(3, seed=11)
+        if reset_at is None:
+            ls = tr.batch_updates(3, seed=11)
+        else:                                                             # two calls: the optimiser state restarts, the batch stream continues
+            ls = np.concatenate([tr.batch_updates(reset_at, seed=11), tr.batch_updates(3 - reset_at)])
         got = tr.trained_params()
         # replay the contract's shuffle: Fisher-Yates from the last index, draw k -> floor(u * (i + 1)), purpose 5, game word = epoch
         from test_arena_oracle import _u64
@@ -157,6 +161,8 @@ def test_adam_steps_follow_torch():
         run = {k: v.detach().clone() for k, v in ref.p.items() if k.endswith(".mean") or k.endswith(".var")}
         losses = []
         for s in range(3):
+            if s == reset_at:                                             # Flux.setup inside train!: a fresh state per call
+                opt = torch.optim.Adam(train, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
             idx = perm[s * B:(s + 1) * B]
             opt.zero_grad()
             L, _ = ref.losses([x[idx] for x in data], float(tr.Wmean), float(tr.Hp), 1e-3, 1.0, 1.0)
