@@ -101,6 +101,27 @@ def _rel_err_by_array(game, hp, got, want):
     return worst
 
 
+def test_gradients_with_default_heads_and_no_blocks():
+    """ResNetHP defaults (2 policy / 1 value head filters, resnet.jl:30-37) and a tower without residual blocks"""
+    import azhip
+    for nblocks, heads in ((0, (32, 32)), (1, (2, 1))):
+        gspec, mem = _memory(1, 12, 5)
+        hp = azhip.ResNetHP(num_blocks=nblocks, num_filters=64, num_policy_head_filters=heads[0], num_value_head_filters=heads[1])
+        nn = azhip.ResNet(gspec, hp, seed=6)
+        lp = azhip.LearningParams(samples_weighing_policy=1, l2_regularization=1e-4, loss_computation_batch_size=64, batch_size=20)
+        with azhip.Trainer(gspec, nn, mem, lp, use_symmetries=True) as tr:
+            data = tr.data.tensors()
+            idx = np.arange(20) * 3
+            loss, parts, grad = tr.gradients(idx)
+            ref = TorchNet(1, hp, nn.params())
+            L, (Lp, Lv, Lreg, Linv, scale) = ref.losses([x[idx] for x in data], float(tr.Wmean), float(tr.Hp), 1e-4, 1.0, 1.0)
+            (L - scale * Lreg).backward()
+            assert abs(loss - L.item()) < 2e-5 * max(1.0, abs(L.item()))
+            _rel_err_by_array(1, hp, grad.astype(np.float64), ref.blob(grads=True))
+            assert np.isfinite(tr.batch_updates(3)).all()
+        mem.close()
+
+
 @pytest.mark.parametrize("game,nblocks,F,B,policy", [(1, 1, 64, 24, 1), (0, 2, 64, 16, 0), (2, 1, 64, 20, 2), (0, 1, 128, 12, 1),
                                                      (0, 1, 128, 203, 1), (0, 2, 64, 333, 0), (1, 1, 64, 500, 2)])   # many workgroups, ragged tails
 def test_gradients_match_torch_autograd(game, nblocks, F, B, policy):
