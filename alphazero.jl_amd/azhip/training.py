@@ -166,40 +166,52 @@ def learning_step(gspec, curnn, bestnn, memory, learning_params, arena_params=No
     from .learning import Trainer
     from .network import ResNet
     lp, ap = learning_params, arena_params
+
+    def call(name, *a):                                           # Handlers.<name>(handler, ...), training.jl:40-75 (all optional)
+        f = getattr(handler, name, None)
+        if f is not None:
+            f(*a)
     t0 = time.perf_counter()
     tr = Trainer(gspec, curnn, memory, lp, use_symmetries=use_symmetries)
     tconvert = time.perf_counter() - t0
     tloss = ttrain = teval = 0.0
     try:
         init_status = status = tr.learning_status()
+        call("learning_started")
         nbatches = lp.max_batches_per_checkpoint
         if lp.min_checkpoints_per_epoch:
             nbatches = min(nbatches, tr.num_batches_total() // lp.min_checkpoints_per_epoch)
         best_evalr = None if ap is None else ap.update_threshold
         losses, checkpoints, replaced = [], [], False
         for k in range(1, lp.num_checkpoints + 1):
+            call("updates_started", status)
             t1 = time.perf_counter()
             losses.append(tr.batch_updates(nbatches, seed=seed))
             t2 = time.perf_counter()
             tr.install_trained()
             status = tr.learning_status()
             t3 = time.perf_counter()
+            call("updates_finished", status)
             ttrain += t2 - t1
             tloss += t3 - t2
             curnn = ResNet(gspec, curnn.hyper, params=tr.trained_params())      # get_trained_network
             if ap is None:
                 bestnn, replaced = curnn.copy_(), True
             else:
-                ev = compare_networks(gspec, curnn, bestnn, ap, handler, seed=seed + k)
+                call("checkpoint_started")
+                ev = compare_networks(gspec, curnn, bestnn, ap, handler if hasattr(handler, "checkpoint_game_played") else None, seed=seed + k)
                 teval += ev.time
                 success = ev.avgr >= best_evalr
                 if success:
                     bestnn, best_evalr, replaced = curnn.copy_(), ev.avgr, True
                 checkpoints.append(Checkpoint(k * nbatches, ev, status, success))
+                call("checkpoint_finished", checkpoints[-1])
     finally:
         tr.close()
-    return curnn, bestnn, LearningReport(tconvert, tloss, ttrain, teval, init_status,
-                                        np.concatenate(losses) if losses else np.zeros(0, np.float32), checkpoints, replaced)
+    report = LearningReport(tconvert, tloss, ttrain, teval, init_status,
+                            np.concatenate(losses) if losses else np.zeros(0, np.float32), checkpoints, replaced)
+    call("learning_finished", report)
+    return curnn, bestnn, report
 
 
 def train_iteration(gspec, curnn, bestnn, memory, self_play: SelfPlayParams, learning_params, arena_params, use_symmetries=True,
