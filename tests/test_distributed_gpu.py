@@ -1,0 +1,61 @@
+"""The N > 1 path of the device pieces on a GPU box: two ranks (gloo group, both on cuda:0 -- the box exposes one GPU)
+run the sharded self-play step into their own device replay memory; every rank must end up with the samples of the
+unsharded run, in the same order (game ids are global, the gathered records are re-packed by id)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _params():
+    import azhip
+    from azhip.training import SelfPlayParams
+    return SelfPlayParams(
+        mcts=azhip.MctsParams(num_iters_per_turn=16, cpuct=2.0, dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0,
+                              temperature=azhip.PLSchedule([0, 4], [1.0, 0.5])),
+        sim=azhip.SimParams(num_games=10, num_workers=4, batch_size=4, use_gpu=True, reset_every=1))
+
+
+def _samples(mem):
+    with mem.dataset() as d:
+        raw = d.raw_samples()
+        return np.array([[raw[i].key[0], raw[i].key[1], raw[i].n] + [np.float64(x).view(np.uint64) for x in list(raw[i].pi) + [raw[i].z, raw[i].t]]
+                         for i in range(len(d))], dtype=np.uint64)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path[:0] = [os.path.join(ROOT, "alphazero.jl_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import azhip
+    from azhip.training import self_play_step_device
+    gspec = azhip.TicTacToeSpec()
+    nn = azhip.ResNet(gspec, azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32), seed=4)
+    mem = azhip.MemoryBuffer(gspec, 10000)
+    rep = self_play_step_device(gspec, nn, _params(), mem, seed=6)
+    np.save(os.path.join(out_dir, "S%d.npy" % rank), _samples(mem))
+    assert rep.memory_size == len(mem)
+    mem.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_self_play_step_fills_identical_memories(tmp_path):
+    port = 29700 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    import azhip
+    from azhip.training import self_play_step_device
+    gspec = azhip.TicTacToeSpec()
+    nn = azhip.ResNet(gspec, azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32), seed=4)
+    mem = azhip.MemoryBuffer(gspec, 10000)
+    self_play_step_device(gspec, nn, _params(), mem, seed=6)          # single process, all 10 games
+    want = _samples(mem)
+    mem.close()
+    S0, S1 = np.load(tmp_path / "S0.npy"), np.load(tmp_path / "S1.npy")
+    assert np.array_equal(S0, S1) and np.array_equal(S0, want)
