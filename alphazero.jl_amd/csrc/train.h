@@ -159,7 +159,15 @@ __global__ void __launch_bounds__(256) k_tr_colsum(const float* __restrict__ x, 
     part[((size_t)blockIdx.x * 2 + 1) * C + c] = ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl];
   }
 }
-__global__ void __launch_bounds__(64) k_tr_colsum_final(const double* __restrict__ part, int nchunks, int C, double* __restrict__ sums /* [2][C] */) {
+// what the one thread that holds a channel's two sums does with them (fused into the final reduction: no extra launch)
+struct TrFinal {
+  int mode;                     // 0: sums only; 1: batch-norm statistics (forward); 2: dgamma / dbeta (backward); 3: out0 = sum0 (bias gradient)
+  long long R; float momentum;
+  const float* bias; float *mean, *invstd, *run_mean, *run_var;      // mode 1
+  float *dgamma, *dbeta;                                              // mode 2
+  float* out0;                                                        // mode 3
+};
+__global__ void __launch_bounds__(64) k_tr_colsum_final(const double* __restrict__ part, int nchunks, int C, double* __restrict__ sums /* [2][C] */, TrFinal f) {
   __shared__ double sh[2][64];
   const int c = blockIdx.x, t = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
@@ -170,22 +178,23 @@ __global__ void __launch_bounds__(64) k_tr_colsum_final(const double* __restrict
     if (t < w) { sh[0][t] += sh[0][t + w]; sh[1][t] += sh[1][t + w]; }
     __syncthreads();
   }
-  if (t == 0) { sums[c] = sh[0][0]; sums[C + c] = sh[1][0]; }
-}
-// batch statistics -> mean, 1/sqrt(var + eps) (Flux BatchNorm: biased variance, eps 1e-5) and the running statistics
-// mu <- (1-m) mu + m (mean + bias), var <- (1-m) var + m * var * R/(R-1)
-__global__ void k_tr_bn_stats(const double* __restrict__ sums, long long R, int C, float momentum, const float* __restrict__ bias,
-                              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean, float* __restrict__ run_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double m = sums[c] / (double)R;
-  double var = sums[C + c] / (double)R - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[c] = (float)m;
-  invstd[c] = (float)(1.0 / __builtin_sqrt(var + 1e-5));
-  const float b = bias ? bias[c] : 0.0f;
-  run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * ((float)m + b);
-  run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)(var * ((double)R / (double)(R - 1)));
+  if (t == 0) {
+    const double s0 = sh[0][0], s1 = sh[1][0];
+    sums[c] = s0; sums[C + c] = s1;
+    if (f.mode == 1) {
+      // batch statistics -> mean, 1/sqrt(var + eps) (Flux BatchNorm: biased variance, eps 1e-5) and the running statistics
+      // mu <- (1-m) mu + m (mean + bias), var <- (1-m) var + m * var * R/(R-1)
+      const double m = s0 / (double)f.R;
+      double var = s1 / (double)f.R - m * m;
+      if (var < 0.0) var = 0.0;
+      f.mean[c] = (float)m;
+      f.invstd[c] = (float)(1.0 / __builtin_sqrt(var + 1e-5));
+      const float b = f.bias ? f.bias[c] : 0.0f;
+      f.run_mean[c] = (1.0f - f.momentum) * f.run_mean[c] + f.momentum * ((float)m + b);
+      f.run_var[c] = (1.0f - f.momentum) * f.run_var[c] + f.momentum * (float)(var * ((double)f.R / (double)(f.R - 1)));
+    } else if (f.mode == 2) { f.dbeta[c] = (float)s0; f.dgamma[c] = (float)s1; }
+    else if (f.mode == 3) f.out0[c] = (float)s0;
+  }
 }
 // a = relu(gamma * xhat + beta (+ res))
 __global__ void k_tr_bn_apply(const float* __restrict__ g, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -211,14 +220,6 @@ __global__ void k_tr_bn_bwd(const float* __restrict__ da, const float* __restric
   const float m0 = (float)(sums[c] / (double)R), m1 = (float)(sums[C + c] / (double)R);
   dg[i] = gamma[c] * invstd[c] * (dy - m0 - xh * m1);
   if (dy_out) dy_out[i] = dy;
-}
-__global__ void k_tr_bn_param_grads(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) { dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c]; }
-}
-__global__ void k_tr_store_sum0(const double* __restrict__ sums, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) out[c] = (float)sums[c];
 }
 __global__ void k_tr_add(float* __restrict__ x, const float* __restrict__ y, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -534,10 +535,11 @@ static int tr_wgrad16(az_trainer* t, const float* a, const float* dg, float* out
 
 // column sums of mode MODE over R rows, result in t->sums
 template <int MODE>
-static int tr_colsum(az_trainer* t, const float* x, const float* out_act, const float* g, const float* mean, const float* invstd, long long R, int C) {
+static int tr_colsum(az_trainer* t, const float* x, const float* out_act, const float* g, const float* mean, const float* invstd, long long R, int C,
+                     TrFinal fin = TrFinal{}) {
   const int nchunks = (int)((R + TR_CHUNK - 1) / TR_CHUNK);
   hipLaunchKernelGGL((k_tr_colsum<MODE>), dim3(nchunks, (C + 63) / 64), dim3(256), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part);
-  hipLaunchKernelGGL(k_tr_colsum_final, dim3(C), dim3(64), 0, t->stream, t->part, nchunks, C, t->sums);
+  hipLaunchKernelGGL(k_tr_colsum_final, dim3(C), dim3(64), 0, t->stream, t->part, nchunks, C, t->sums, fin);
   return AZ_OK;
 }
 
@@ -567,9 +569,9 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
     else if (need_col) hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cin / 4))), dim3(256), 0, st, (const float4*)in, R, c.cin / 4, gi.W, gi.H, (float4*)c.col);
     if (c.mfma) AZCHK(tr_conv16(t, in, t->work + c.wk_ffwd, c.g));         // (the im2col above feeds the weight gradient)
     else AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
-    AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout));
-    hipLaunchKernelGGL(k_tr_bn_stats, dim3((c.cout + 63) / 64), dim3(64), 0, st, t->sums, R, c.cout, t->cfg.batch_norm_momentum, blob + c.off_b, c.mean, c.invstd,
-                       blob + c.off_bn + 2 * c.cout, blob + c.off_bn + 3 * c.cout);
+    { TrFinal fin{}; fin.mode = 1; fin.R = R; fin.momentum = t->cfg.batch_norm_momentum; fin.bias = blob + c.off_b; fin.mean = c.mean; fin.invstd = c.invstd;
+      fin.run_mean = blob + c.off_bn + 2 * c.cout; fin.run_var = blob + c.off_bn + 3 * c.cout;
+      AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout, fin)); }
     const bool second = l > 0 && (l % 2) == 0;                     // conv2 of a block: skip connection from the block input
     const float* res = second ? t->convs[l - 2].a : nullptr;
     hipLaunchKernelGGL(k_tr_bn_apply, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, c.g, c.mean, c.invstd, blob + c.off_bn, blob + c.off_bn + c.cout, res, R * c.cout, c.cout, c.a);
@@ -577,9 +579,9 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
   const float* trunk = t->convs[ntower - 1].a;
   for (TrConv* c : {&hp, &hv}) {
     AZCHK(rb::gemm(t->rbh, false, false, (int)R, c->cout, F, 1.f, trunk, F, t->work + c->wk_wm, c->cout, 0.f, c->g, c->cout));
-    AZCHK(tr_colsum<0>(t, c->g, nullptr, nullptr, nullptr, nullptr, R, c->cout));
-    hipLaunchKernelGGL(k_tr_bn_stats, dim3((c->cout + 63) / 64), dim3(64), 0, st, t->sums, R, c->cout, t->cfg.batch_norm_momentum, blob + c->off_b, c->mean, c->invstd,
-                       blob + c->off_bn + 2 * c->cout, blob + c->off_bn + 3 * c->cout);
+    { TrFinal fin{}; fin.mode = 1; fin.R = R; fin.momentum = t->cfg.batch_norm_momentum; fin.bias = blob + c->off_b; fin.mean = c->mean; fin.invstd = c->invstd;
+      fin.run_mean = blob + c->off_bn + 2 * c->cout; fin.run_var = blob + c->off_bn + 3 * c->cout;
+      AZCHK(tr_colsum<0>(t, c->g, nullptr, nullptr, nullptr, nullptr, R, c->cout, fin)); }
     hipLaunchKernelGGL(k_tr_bn_apply, dim3(tr_grid(R * c->cout)), dim3(256), 0, st, c->g, c->mean, c->invstd, blob + c->off_bn, blob + c->off_bn + c->cout, (const float*)nullptr, R * c->cout, c->cout, c->a);
   }
   // dense heads: rows of hp.a / hv.a of one board are contiguous: [B][P*nf] with k = p*nf + f
@@ -601,19 +603,16 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
   float* gb = t->gblob;
   // policy: dWpd = hp_flat^T dlogits ; dbp = colsum(dlogits) ; dhp = dlogits Wpd^T
   AZCHK(rb::gemm(t->rbh, true, false, P * npf, A, B, 1.f, hp.a, P * npf, t->dlogits, A, 0.f, gw + t->wk_pd, A));
-  AZCHK(tr_colsum<2>(t, t->dlogits, nullptr, nullptr, nullptr, nullptr, B, A));
-  hipLaunchKernelGGL(k_tr_store_sum0, dim3(1), dim3(64), 0, st, t->sums, A, gb + t->off_pd_b);
+  { TrFinal fin{}; fin.mode = 3; fin.out0 = gb + t->off_pd_b; AZCHK(tr_colsum<2>(t, t->dlogits, nullptr, nullptr, nullptr, nullptr, B, A, fin)); }
   float* dhp = t->dact;                                            // [R][npf]
   AZCHK(rb::gemm(t->rbh, false, true, B, P * npf, A, 1.f, t->dlogits, A, t->work + t->wk_pd, A, 0.f, dhp, P * npf));
   // value: dt -> dv1 = (dt wv2^T) .* (v1 > 0) ; dwv2 = v1^T dt ; db2 = sum dt ; dWv1 = hv_flat^T dv1 ; db1 ; dhv = dv1 Wv1^T
   AZCHK(rb::gemm(t->rbh, true, false, F, 1, B, 1.f, t->v1, F, t->dt, 1, 0.f, gw + t->wk_v2, 1));
-  AZCHK(tr_colsum<2>(t, t->dt, nullptr, nullptr, nullptr, nullptr, B, 1));
-  hipLaunchKernelGGL(k_tr_store_sum0, dim3(1), dim3(64), 0, st, t->sums, 1, gb + t->off_v2_b);
+  { TrFinal fin{}; fin.mode = 3; fin.out0 = gb + t->off_v2_b; AZCHK(tr_colsum<2>(t, t->dt, nullptr, nullptr, nullptr, nullptr, B, 1, fin)); }
   AZCHK(rb::gemm(t->rbh, false, true, B, F, 1, 1.f, t->dt, 1, t->work + t->wk_v2, 1, 0.f, t->dv1, F));
   hipLaunchKernelGGL(k_tr_relu_bwd, dim3(tr_grid((long long)B * F)), dim3(256), 0, st, t->dv1, t->v1, (long long)B * F);
   AZCHK(rb::gemm(t->rbh, true, false, P * nvf, F, B, 1.f, hv.a, P * nvf, t->dv1, F, 0.f, gw + t->wk_v1, F));
-  AZCHK(tr_colsum<2>(t, t->dv1, nullptr, nullptr, nullptr, nullptr, B, F));
-  hipLaunchKernelGGL(k_tr_store_sum0, dim3((F + 63) / 64), dim3(64), 0, st, t->sums, F, gb + t->off_v1_b);
+  { TrFinal fin{}; fin.mode = 3; fin.out0 = gb + t->off_v1_b; AZCHK(tr_colsum<2>(t, t->dv1, nullptr, nullptr, nullptr, nullptr, B, F, fin)); }
   float* dhv = t->dact2;                                           // [R][nvf]
   AZCHK(rb::gemm(t->rbh, false, true, B, P * nvf, F, 1.f, t->dv1, F, t->work + t->wk_v1, F, 0.f, dhv, P * nvf));
   // head convolutions: BN backward, weight / bias gradients, gradient into the trunk
@@ -621,8 +620,8 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
   bool first = true;
   for (TrConv* c : {&hp, &hv}) {
     float* dh = c == &hp ? dhp : dhv;
-    AZCHK(tr_colsum<1>(t, dh, c->a, c->g, c->mean, c->invstd, R, c->cout));
-    hipLaunchKernelGGL(k_tr_bn_param_grads, dim3((c->cout + 63) / 64), dim3(64), 0, st, t->sums, c->cout, gb + c->off_bn, gb + c->off_bn + c->cout);
+    { TrFinal fin{}; fin.mode = 2; fin.dgamma = gb + c->off_bn; fin.dbeta = gb + c->off_bn + c->cout;
+      AZCHK(tr_colsum<1>(t, dh, c->a, c->g, c->mean, c->invstd, R, c->cout, fin)); }
     hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c->cout)), dim3(256), 0, st, dh, c->a, c->g, c->mean, c->invstd, blob + c->off_bn, t->sums, R, R * c->cout, c->cout, dh, (float*)nullptr);
     AZCHK(rb::gemm(t->rbh, true, false, F, c->cout, (int)R, 1.f, trunk, F, dh, c->cout, 0.f, gw + c->wk_wm, c->cout));
     // the bias of a convolution that feeds a train-mode BatchNorm has gradient sum(dg) = gamma invstd (sum dy - R m0 - m1 sum xhat)
@@ -636,8 +635,8 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
   for (int l = ntower - 1; l >= 0; --l) {
     TrConv& c = t->convs[l];
     const bool second = l > 0 && (l % 2) == 0;
-    AZCHK(tr_colsum<1>(t, t->dact, c.a, c.g, c.mean, c.invstd, R, c.cout));
-    hipLaunchKernelGGL(k_tr_bn_param_grads, dim3((c.cout + 63) / 64), dim3(64), 0, st, t->sums, c.cout, gb + c.off_bn, gb + c.off_bn + c.cout);
+    { TrFinal fin{}; fin.mode = 2; fin.dgamma = gb + c.off_bn; fin.dbeta = gb + c.off_bn + c.cout;
+      AZCHK(tr_colsum<1>(t, t->dact, c.a, c.g, c.mean, c.invstd, R, c.cout, fin)); }
     // dg overwrites dact; for conv2 the masked gradient dy also flows to the block input (dact2)
     hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, t->dact, c.a, c.g, c.mean, c.invstd, blob + c.off_bn, t->sums, R, R * c.cout, c.cout,
                        t->dact, second ? t->dact2 : (float*)nullptr);
