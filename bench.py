@@ -74,6 +74,35 @@ def cpu_baseline(blob, hp, nsims, seconds=12.0, threads=None):
                       % (sum(roots), nsims, threads, dt)}
 
 
+def kernel_alone(args, blob, dev_index, waves=200):
+    """The dominant kernel WITHOUT anything co-scheduled (extra evidence, outside the timed region; not part of `value`):
+    the same workload with one slot group, so every network launch takes all slots and runs alone on its stream.
+    With several groups the per-launch durations of `roofline` include time shared with the other group's kernels."""
+    import azhip
+    eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=dev_index,
+                       num_workers=args.slots, batch_size=args.slots, num_iters_per_turn=args.sims,
+                       gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
+                       prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
+                       num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    eng.net_set_params(blob)
+    eng.selfplay_begin(-1, first_game_id=1 << 28)
+    eng.selfplay_step(40)
+    s0 = eng.selfplay_stats()
+    eng.prof_reset()
+    eng.prof_enable(True, classes=("tower",))
+    eng.selfplay_step(waves)
+    s1 = eng.selfplay_stats()
+    tw = eng.prof_get()["tower"]
+    eng.prof_enable(False)
+    eng.selfplay_end()
+    eng.close()
+    evals = s1.leaf_evals - s0.leaf_evals
+    achieved = evals * TOWER_FLOP / (tw["ms"] * 1e-3) / 1e12 if tw["ms"] > 0 else 0.0
+    return {"kernel": "k_tower16x2<ConnectFour,64,false>", "slot_groups": 1, "waves": waves, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
+            "avg_boards_per_launch": evals / max(tw["launches"], 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +220,8 @@ def main():
                 "step_achieved": flops / local_elapsed / 1e12, "step_frac": flops / local_elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             }
             out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
+        if prof is not None and world == 1 and args.groups > 1:
+            out["roofline_kernel_alone"] = kernel_alone(args, blob, dev_index)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, hp, args.sims)
         print(json.dumps(out))
