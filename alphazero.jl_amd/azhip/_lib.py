@@ -145,6 +145,7 @@ SYMBOLS = {
     "az_prof_get": [_VP, C.POINTER(Prof)],
     "az_prof_reset": [_VP],
     "az_device_info": [_VP, C.c_char_p, _I32, C.POINTER(_I32), C.POINTER(_I64)],
+    "az_net_last_kernel": [_VP, C.c_char_p, _I32],
 }
 
 _lib = None

@@ -67,6 +67,12 @@ class Engine:
         check(lib().az_device_info(self._h, name, 256, C.byref(ncu), C.byref(mem)))
         return name.value.decode(), ncu.value, mem.value
 
+    def net_last_kernel(self):
+        """name of the tower kernel that served the most recent network launch"""
+        name = C.create_string_buffer(128)
+        check(lib().az_net_last_kernel(self._h, name, 128))
+        return name.value.decode()
+
     def prof_enable(self, on=True, classes=None):
         """classes: iterable of kernel class names (KERNEL_CLASSES) to time; None = all"""
         flag = 1 if on else 0

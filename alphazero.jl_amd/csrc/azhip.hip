@@ -4,29 +4,11 @@
 // Reference seams: simulate (src/simulations.jl:207-244) -> az_selfplay_*;
 // MCTS.explore!/policy/reset! (src/mcts.jl:239-281) -> az_mcts_*; Network.forward_normalized /
 // evaluate_batch (src/networks/network.jl:264-315) -> az_net_*; GameInterface -> az_game_*.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-#include <unordered_set>
-
-#include "../../include/az_numerics.h"
-#include "../../include/azhip.h"
-#include "games.h"
-#include "resnet.h"
-#include "resnet16.h"
-#include "tree.h"
+#include "engine.h"
 
 // ------------------------------------------------------------------------------- errors
 static thread_local std::string g_err;
-static int fail(int code, const char* fmt, ...) {
+int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -35,150 +17,8 @@ static int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
-#define HIPCHK(x)                                                                                   \
-  do {                                                                                              \
-    hipError_t _e = (x);                                                                            \
-    if (_e != hipSuccess) return fail(AZ_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
-  } while (0)
-#define AZCHK(x)            \
-  do {                      \
-    int _s = (x);           \
-    if (_s != AZ_OK) return _s; \
-  } while (0)
-
 extern "C" const char* az_last_error(void) { return g_err.c_str(); }
 extern "C" int az_abi_version(void) { return AZ_ABI_VERSION; }
-
-#define DISPATCH_GAME(gid, ...)                                   \
-  switch (gid) {                                                  \
-    case AZ_GAME_CONNECT_FOUR: { using Gm = ConnectFour; __VA_ARGS__; break; } \
-    case AZ_GAME_TICTACTOE: { using Gm = TicTacToe; __VA_ARGS__; break; }      \
-    case AZ_GAME_MANCALA: { using Gm = Mancala; __VA_ARGS__; break; }          \
-    default: return fail(AZ_ERR_BAD_ARG, "unknown game id %d", (int)(gid));    \
-  }
-
-struct GameInfo { int A, APAD, W, H, C, P, max_plies, node_bytes; };
-static bool game_info(int gid, GameInfo* gi) {
-  switch (gid) {
-    case AZ_GAME_CONNECT_FOUR: *gi = {ConnectFour::A, ConnectFour::APAD, ConnectFour::W, ConnectFour::H, ConnectFour::C, ConnectFour::P, ConnectFour::MAX_PLIES, NodeL<ConnectFour>::BYTES}; return true;
-    case AZ_GAME_TICTACTOE: *gi = {TicTacToe::A, TicTacToe::APAD, TicTacToe::W, TicTacToe::H, TicTacToe::C, TicTacToe::P, TicTacToe::MAX_PLIES, NodeL<TicTacToe>::BYTES}; return true;
-    case AZ_GAME_MANCALA: *gi = {Mancala::A, Mancala::APAD, Mancala::W, Mancala::H, Mancala::C, Mancala::P, Mancala::MAX_PLIES, NodeL<Mancala>::BYTES}; return true;
-  }
-  return false;
-}
-
-// ------------------------------------------------------------------------------- engine
-static constexpr int AZ_MAX_GROUPS = 4;
-struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; };
-struct az_engine {
-  az_engine_cfg cfg;
-  GameInfo gi;
-  int device;
-  hipStream_t stream;
-  DView v;                       // global view over all G slots (start / move / hooks)
-  DParams p;
-  // slot groups: num_workers / batch_size interleaved half-batches, each with its own stream, so the
-  // tree kernels of one group run under the network of another (the device form of the reference's
-  // num_workers = 2 x batch_size, games/connect-four/params.jl:18-19)
-  int ngroups;
-  DView gv[AZ_MAX_GROUPS];
-  hipStream_t gs[AZ_MAX_GROUPS];      // tree-kernel stream of the group (high priority when ngroups > 1)
-  hipStream_t gt[AZ_MAX_GROUPS];      // network stream of the group
-  hipEvent_t ev_tree[AZ_MAX_GROUPS], ev_net[AZ_MAX_GROUPS];
-  float* g_hfeat[AZ_MAX_GROUPS];
-  std::vector<void*> allocs;
-  std::vector<void*> net_allocs;   // device copies of the packed network (replaced by az_net_set_params)
-  // network
-  bool net_loaded;
-  std::vector<float> blob;
-  NetDev net;
-  Net16Dev net16;                // k_tower16 fragments (64 filters)
-  int tower_pick;                // AZHIP_TOWER=16|32|3|21 forces a tower kernel (3 = k_tower16 with 3 row tiles, 21 = k_tower16x2); 0 = choose per launch
-  int num_cu;
-  int nn_cap;
-  float* d_hfeat; float* d_X; float* d_A; float* d_P; float* d_V; float* d_Pinv;
-  GEnv* d_tmp_env; int* d_iota; int* d_ntmp;
-  // staging
-  int* d_slots; uint32_t* d_gids; GEnv* d_roots; uint32_t* d_moves; double* d_eta; int* d_offsets;
-  az_move_rec* d_stage; unsigned long long* d_keys; int* d_actions; unsigned long long* d_next; signed char* d_term; float* d_reward;
-  char* d_nodebuf;
-  int* d_visits;
-  int io_cap;
-  // self-play state
-  bool running;
-  int total_games, next_game, first_game_id, games_done, wave_in_move, active_slots;
-  int group_active[AZ_MAX_GROUPS];   // active slots per slot group (host count; bounds the leaves of a network launch)
-  std::vector<az_game_rec> q_games;
-  std::vector<az_move_rec> q_moves;
-  az_selfplay_stats stats;
-  std::chrono::steady_clock::time_point t_begin;
-  // profiling
-  bool prof_on;
-  int prof_mask;                 // 0 = every kernel class, else bit per az_kernel_class
-  std::vector<ProfRec> prof_pool;
-  size_t prof_used;
-  az_prof prof;
-  std::vector<int> h_finished;
-  std::vector<az_game_rec> h_grec;
-};
-
-template <class T> static int dalloc(az_engine* e, T** p, size_t n, bool zero = true) {
-  void* q = nullptr;
-  size_t bytes = std::max<size_t>(n * sizeof(T), 16);
-  hipError_t r = hipMalloc(&q, bytes);
-  if (r != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r));
-  e->allocs.push_back(q);
-  if (zero) HIPCHK(hipMemsetAsync(q, 0, bytes, e->stream));
-  *p = (T*)q;
-  return AZ_OK;
-}
-
-static int sync_groups(az_engine* e) {
-  for (int g = 0; g < e->ngroups; ++g) if (e->gs[g] != e->stream) {
-    HIPCHK(hipStreamSynchronize(e->gt[g]));
-    HIPCHK(hipStreamSynchronize(e->gs[g]));
-  }
-  return AZ_OK;
-}
-static int sync_all(az_engine* e) {
-  AZCHK(sync_groups(e));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return AZ_OK;
-}
-static int prof_flush(az_engine* e) {
-  if (!e->prof_used) return AZ_OK;
-  AZCHK(sync_all(e));
-  for (size_t i = 0; i < e->prof_used; ++i) {
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e->prof_pool[i].a, e->prof_pool[i].b));
-    e->prof.ms[e->prof_pool[i].cls] += ms;
-  }
-  e->prof_used = 0;
-  return AZ_OK;
-}
-static int prof_begin(az_engine* e, hipStream_t st, int cls, int64_t units) {
-  if (!e->prof_on || (e->prof_mask && !((e->prof_mask >> cls) & 1))) return AZ_OK;
-  if (e->prof_used == e->prof_pool.size()) AZCHK(prof_flush(e));
-  ProfRec& r = e->prof_pool[e->prof_used];
-  r.cls = cls;
-  e->prof.launches[cls] += 1;
-  e->prof.units[cls] += units;
-  HIPCHK(hipEventRecord(r.a, st));
-  return AZ_OK;
-}
-static int prof_end(az_engine* e, hipStream_t st, int cls) {
-  if (!e->prof_on || (e->prof_mask && !((e->prof_mask >> cls) & 1))) return AZ_OK;
-  HIPCHK(hipEventRecord(e->prof_pool[e->prof_used].b, st));
-  e->prof_used++;
-  return AZ_OK;
-}
-#define LAUNCH_ON(e, st, cls, units, kern, grid, block, shmem, ...)         \
-  do {                                                                      \
-    AZCHK(prof_begin(e, st, cls, units));                                   \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, st, __VA_ARGS__); \
-    AZCHK(prof_end(e, st, cls));                                            \
-  } while (0)
-#define LAUNCH(e, cls, units, kern, grid, block, shmem, ...) LAUNCH_ON(e, (e)->stream, cls, units, kern, grid, block, shmem, __VA_ARGS__)
 
 static int check_device_error(az_engine* e) {
   int code = 0;
@@ -244,23 +84,6 @@ extern "C" int az_engine_destroy(az_engine* e) {
   return AZ_OK;
 }
 
-template <class Gm, int F> static int set_kernel_attrs_f() {
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
-  if constexpr (F == 64) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
-  }
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
-  return AZ_OK;
-}
-template <class Gm> static int set_kernel_attrs() {
-  AZCHK((set_kernel_attrs_f<Gm, 64>()));
-  AZCHK((set_kernel_attrs_f<Gm, 128>()));
-  return AZ_OK;
-}
-
 __global__ void k_fill_u32(uint32_t* p, uint32_t val, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = val;
@@ -299,7 +122,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   az_engine* e = new (std::nothrow) az_engine();
   if (!e) return fail(AZ_ERR_HIP, "out of host memory");
   e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0;
-  e->net_loaded = false; e->running = false; e->prof_on = false; e->prof_mask = 0; e->prof_used = 0;
+  e->net_loaded = false; e->running = false; e->prof_on = false; e->last_tower[0] = 0; e->prof_mask = 0; e->prof_used = 0;
   memset(&e->prof, 0, sizeof e->prof);
   memset(&e->stats, 0, sizeof e->stats);
   int st = [&]() -> int {
@@ -312,7 +135,10 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     v.max_depth = gi.max_plies + 1;
     long long cap = c->max_nodes_per_slot;
     if (cap <= 0) {
-      long long plies = c->game == AZ_GAME_MANCALA ? 64 : gi.max_plies;
+      // Mancala has no fixed length (MAX_PLIES = 256 bounds the trace); self-play games of the shipped parameters last
+      // 30-70 plies, the pool holds 128 plies of new nodes per game between resets (288 GB of HBM pay for the margin);
+      // a longer game reports AZ_ERR_CAPACITY and max_nodes_per_slot raises the bound
+      long long plies = c->game == AZ_GAME_MANCALA ? 128 : gi.max_plies;
       cap = (long long)c->num_iters_per_turn * plies * std::max(1, c->reset_every);
       if (c->reset_every == 0) cap *= 4;
       cap = std::max<long long>(cap, 1024);
@@ -358,7 +184,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     memset(&e->net16, 0, sizeof e->net16);
     { const char* tw = getenv("AZHIP_TOWER"); e->tower_pick = tw ? atoi(tw) : 0; }
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); e->num_cu = pr.multiProcessorCount; }
-    DISPATCH_GAME(c->game, AZCHK(set_kernel_attrs<Gm>()));
+    AZCHK(net_set_kernel_attrs(c->game));
     // slot groups
     int ng = c->batch_size > 0 ? G / c->batch_size : 1;
     if (ng < 1) ng = 1;
@@ -408,9 +234,6 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   return AZ_OK;
 }
 
-#define ENGINE(e)                                              \
-  if (!(e)) return fail(AZ_ERR_BAD_ARG, "engine is NULL");      \
-  HIPCHK(hipSetDevice((e)->device))
 
 extern "C" int az_device_info(az_engine* e, char* name, int32_t name_cap, int32_t* num_cu, int64_t* hbm_bytes) {
   ENGINE(e);
@@ -613,6 +436,24 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
       d[1] = o < A ? pol_w[(4 * i + 2 + hh) * L + o] : 0.0f;
     }
   }
+  // fused dense heads of the k_tower16 family (heads16, resnet16.h): 16x16x4 B fragments, value tiles then the policy tile
+  std::vector<float> hd16_w(4);
+  if (hd_ok) {
+    const int NVT16 = F / 16;
+    const size_t vsteps = (size_t)P * nvf / 4, psteps = (size_t)P * npf / 4, vgr = (vsteps + 3) / 4, pgr = (psteps + 3) / 4;
+    hd16_w.assign((NVT16 * vgr + std::max(pgr, vgr)) * 64 * 4, 0.0f);
+    for (int t = 0; t <= NVT16; ++t) {
+      const bool pol = t == NVT16;
+      const size_t steps = pol ? psteps : vsteps, ngr = pol ? pgr : vgr;
+      for (size_t s4 = 0; s4 < ngr; ++s4) for (int ln = 0; ln < 64; ++ln) for (int j = 0; j < 4; ++j) {
+        const size_t i = 4 * s4 + j, k = 4 * i + (ln >> 4);
+        const int o = t * 16 + (ln & 15);
+        float val = 0.0f;
+        if (i < steps) val = pol ? ((ln & 15) < A ? pol_w[k * L + (ln & 15)] : 0.0f) : val_w[k * F + o];
+        hd16_w[(((size_t)t * vgr + s4) * 64 + ln) * 4 + j] = val;
+      }
+    }
+  }
   AZCHK(sync_all(e));
   for (void* q : e->net_allocs) (void)hipFree(q);
   e->net_allocs.clear();
@@ -646,11 +487,21 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
     AZCHK(up(s16_w, &n16.stem_w)); n16.stem_ss = nd.stem_ss;
     AZCHK(up(c16_w, &tmp)); n16.conv_w = (const float4*)tmp; n16.conv_ss = nd.conv_ss;
     AZCHK(up(h16_w, &tmp)); n16.head_w = (const float4*)tmp; n16.head_ss = nd.head_ss;
+    AZCHK(up(hd16_w, &tmp)); n16.hd16_w = (const float4*)tmp;
+    n16.pol_b = nd.pol_b; n16.val_b = nd.val_b; n16.val2_w = nd.val2_w; n16.val2_b = nd.val2_b;
+    n16.npf = npf; n16.nvf = nvf;
+    const char* nf = getenv("AZHIP_NO_FUSED_HEADS");                // A/B and test switch: tower -> hfeat -> k_heads_mfma
+    n16.fuse = (hd_ok && !(nf && atoi(nf))) ? 1 : 0;
   }
   e->net16 = n16;
   HIPCHK(hipStreamSynchronize(e->stream));
   e->net = nd;
   e->net_loaded = true;
+  return AZ_OK;
+}
+extern "C" int az_net_last_kernel(const az_engine* e, char* name, int32_t cap) {
+  if (!e || !name || cap < 1) return fail(AZ_ERR_BAD_ARG, "NULL");
+  snprintf(name, (size_t)cap, "%s", e->last_tower);
   return AZ_OK;
 }
 extern "C" int az_net_get_params(const az_engine* e, float* blob, int64_t n) {
@@ -659,68 +510,6 @@ extern "C" int az_net_get_params(const az_engine* e, float* blob, int64_t n) {
   if (n != (int64_t)e->blob.size()) return fail(AZ_ERR_BAD_ARG, "blob size mismatch");
   memcpy(blob, e->blob.data(), sizeof(float) * (size_t)n);
   return AZ_OK;
-}
-
-// launches tower + heads on `n` boards (device count in n_ptr when n < 0)
-// Which tower kernel serves a launch of up to n boards.  A workgroup's layer chain is sequential and the MFMA
-// pipe of a CU is shared by its resident workgroups, so the launch costs (workgroups per CU, rounded up) x (rows
-// per workgroup): k_tower16 packs 176 rows (4 Connect-Four boards), k_tower 128 (3 boards), k_tower16 with 3 row
-// tiles 48 (1 board; +10 %: a third of the weight reuse, more barriers per row).  4096 Connect-Four leaves:
-// 4 x 176 < 6 x 128; 128 leaves: 1 x 48 << 1 x 128 (measured tools/small_batch.sh: 0.39 vs 0.80 ms per wave at
-// 128 filters).  Returns 16, 32 or 3.
-template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
-  if (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64)) return e->tower_pick;
-  const long cu = e->num_cu > 0 ? e->num_cu : 256;
-  const long b16 = (n + T16<Gm, F>::TB - 1) / T16<Gm, F>::TB, b32 = (n + TOWER_ROWS / Gm::P - 1) / (TOWER_ROWS / Gm::P);
-  const long b3 = (n + T16<Gm, F, 3>::TB - 1) / T16<Gm, F, 3>::TB;
-  const double c16 = (double)((b16 + cu - 1) / cu) * T16<Gm, F>::RPAD;
-  double c32 = (double)((b32 + cu - 1) / cu) * TOWER_ROWS;
-  const double c3 = 1.1 * (double)((b3 + cu - 1) / cu) * T16<Gm, F, 3>::RPAD;
-  // 128 filters, several slot groups: the groups' towers fill each other's partial rounds and k_tower's smaller
-  // workgroups pack slightly better (measured 1.10 vs 1.07 M sims/s at 2 x 2048)
-  if (F == 128 && e->ngroups > 1) c32 *= 0.9;
-  if (c3 <= c16 && c3 <= c32) return 3;
-  // paired k_tower16x2: 336 rows = 8 boards per workgroup, no padding rows (+3 % on a 4096-leaf launch).  Only with ONE
-  // slot group: its 92 KB of LDS allow one workgroup per CU, so two groups' towers cannot interleave on a CU and the
-  // other group's heads kernel finds no gaps (measured 3.80 vs 4.11 M sims/s with two groups)
-  if (F == 64 && e->ngroups == 1) {
-    const long b21 = (n + T16P<Gm, 64>::TB - 1) / T16P<Gm, 64>::TB;
-    const double c21 = (double)((b21 + cu - 1) / cu) * T16P<Gm, 64>::RPAD;
-    if (c21 < c16 && c21 < c32) return 21;
-  }
-  return c16 <= c32 ? 16 : 32;
-}
-template <class Gm, int F, bool FROM_PLANES>
-static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
-                        const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
-  constexpr int TB = TOWER_ROWS / Gm::P;
-  const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
-  if (gt == 0) return AZ_OK;
-  constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
-  constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
-  constexpr int TB21 = T16P<Gm, 64>::TB, THR21 = T16P<Gm, 64>::THREADS, LDS21 = T16P<Gm, 64>::BYTES;
-  const int tw = pick_tower<Gm, F>(e, n_max);
-  if (tw == 21) {
-    if constexpr (F == 64)
-      LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
-  } else if (tw == 3)
-    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES, 3>), (n_max + TB3 - 1) / TB3, THR16, LDS3, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
-  else if (tw == 16)
-    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES>), (n_max + TB16 - 1) / TB16, THR16, LDS16, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
-  else
-    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, F, FROM_PLANES>), gt, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
-  if (e->net.hd_ok)
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, F>), (n_max + 31) / 32, 64 * (F / 32 + 1), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
-  else
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads<Gm, F>), gh, 4 * (F + 16), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
-  return AZ_OK;
-}
-// launches tower + heads on `n` boards (device count in n_ptr when given)
-template <class Gm, bool FROM_PLANES>
-static int launch_net(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
-                      const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
-  if (e->cfg.num_filters == 128) return launch_net_f<Gm, 128, FROM_PLANES>(e, st, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
-  return launch_net_f<Gm, 64, FROM_PLANES>(e, st, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
 }
 
 extern "C" int az_net_forward(az_engine* e, const float* X, const float* A, int32_t N, float* P, float* V, float* Pinv) {
@@ -733,7 +522,7 @@ extern "C" int az_net_forward(az_engine* e, const float* X, const float* A, int3
     int m = std::min(e->nn_cap, N - off);
     HIPCHK(hipMemcpyAsync(e->d_X, X + xs * off, sizeof(float) * xs * m, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_A, A + (size_t)gi.A * off, sizeof(float) * gi.A * m, hipMemcpyHostToDevice, e->stream));
-    DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, true>(e, e->stream, e->d_hfeat, nullptr, nullptr, nullptr, m, e->d_X, e->d_A, e->d_P, e->d_V, e->d_Pinv, gi.A))));
+    AZCHK(net_launch(e, e->stream, true, e->d_hfeat, nullptr, nullptr, nullptr, m, e->d_X, e->d_A, e->d_P, e->d_V, e->d_Pinv, gi.A));
     HIPCHK(hipMemcpyAsync(P + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(V + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
     if (Pinv) HIPCHK(hipMemcpyAsync(Pinv + off, e->d_Pinv, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
@@ -752,7 +541,7 @@ static int evaluate_envs(az_engine* e, const std::vector<GEnv>& envs, std::vecto
     int m = std::min(e->nn_cap, N - off);
     HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data() + off, sizeof(GEnv) * m, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_ntmp, &m, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, false>(e, e->stream, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A))));
+    AZCHK(net_launch(e, e->stream, false, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A));
     HIPCHK(hipMemcpyAsync(P.data() + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(V.data() + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -773,7 +562,7 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
     DISPATCH_GAME(e->cfg.game, { for (int i = 0; i < m; ++i) envs[i] = Gm::from_key(keys[2 * (size_t)(off + i)], keys[2 * (size_t)(off + i) + 1]); });
     HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * m, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_ntmp, &m, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, false>(e, e->stream, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A))));
+    AZCHK(net_launch(e, e->stream, false, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A));
     HIPCHK(hipMemcpyAsync(P + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(V + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -785,38 +574,6 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
 // ------------------------------------------------------------------------------- search waves
 // One wave = one run_simulation! for every active slot: select -> gather misses -> oracle ->
 // expand + backup.  Nothing is read back by the host.
-template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split, int nmax) {
-  constexpr int L = Gm::APAD, TB = TOWER_ROWS / Gm::P;
-  const DView& v = e->gv[g];
-  hipStream_t st = e->gs[g], sn = e->gt[g];
-  const int G = v.G;
-  if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
-  constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
-  constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
-  constexpr int TB21 = T16P<Gm, 64>::TB, THR21 = T16P<Gm, 64>::THREADS, LDS21 = T16P<Gm, 64>::BYTES;
-  // N = upper bound of this wave's leaves: the group's active slots (a draining phase or a partial explore! launches
-  // -- and picks its tower kernel -- for what is left, not for the group's capacity)
-  const int N = std::max(1, std::min(G, nmax));
-  const int tw = pick_tower<Gm, F>(e, N);
-  if (tw == 21) {
-    if constexpr (F == 64)
-      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);
-  } else if (tw == 3)
-    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, 3>), (N + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);
-  else if (tw == 16)
-    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false>), (N + TB16 - 1) / TB16, THR16, LDS16, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);
-  else
-    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower<Gm, F, false>), (N + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);
-  if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
-  if (e->net.hd_ok)
-    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads_mfma<Gm, F>), (N + 31) / 32, 64 * (F / 32 + 1), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
-  else
-    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads<Gm, F>), (N + 3) / 4, 4 * (F + 16), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
-  return AZ_OK;
-}
-template <class Gm> static int wave_net(az_engine* e, int g, bool split, int nmax) {
-  return e->cfg.num_filters == 128 ? wave_net_f<Gm, 128>(e, g, split, nmax) : wave_net_f<Gm, 64>(e, g, split, nmax);
-}
 // sim_idx: index of this simulation within the current explore! (keys the rollout oracle's RNG stream)
 template <class Gm> static int wave(az_engine* e, int ngroups_active, uint32_t sim_idx) {
   constexpr int L = Gm::APAD;
@@ -831,7 +588,7 @@ template <class Gm> static int wave(az_engine* e, int ngroups_active, uint32_t s
     LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact_count, (G + 1023) / 1024, 1024, 0, v);
     LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact_assign, (G + 1023) / 1024, 1024, 0, v);
     if (e->cfg.oracle == AZ_ORACLE_RESNET) {
-      AZCHK((wave_net<Gm>(e, g, split, e->group_active[g])));
+      AZCHK(net_wave(e, g, split, e->group_active[g]));
     } else {
       LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p, sim_idx);
     }
@@ -1146,8 +903,11 @@ extern "C" int az_selfplay_run(az_engine* e, int32_t num_games, int32_t first_ga
     if (cb) for (; reported < e->games_done; ++reported) cb(user);   // game_simulated()
   }
   if (st == AZ_OK && stats) st = az_selfplay_get_stats(e, stats);
-  if (st == AZ_OK) st = az_selfplay_collect(e, out);
   std::string keep = g_err;
+  // on an error (a capacity overflow in one slot, say) the games that did finish are still handed over: `out` then
+  // holds fewer than num_games games and the status tells why
+  const int cst = az_selfplay_collect(e, out);
+  if (st == AZ_OK) { st = cst; keep = g_err; }
   az_selfplay_end(e);
   if (st != AZ_OK) g_err = keep;
   return st;
@@ -1232,7 +992,7 @@ static int arena_run(az_engine* ec, az_engine* eb, int num_games, int first_game
       }
       a.moves.push_back(rec);
       // simulations.jl:221-223: sim_id is 1-based, colors are flipped for odd sim_id
-      const bool colors_flipped = alternate && ((a.gid + 1) % 2 == 1);
+      const bool colors_flipped = alternate && (((int)a.gid - first_game_id + 1) % 2 == 1);
       const int who = (Gm::white_playing(a.env) != colors_flipped) ? 0 : 1;   // 0 contender, 1 baseline
       slots[who].push_back(s); roots[who].push_back(a.env); gids[who].push_back(a.gid); mvs[who].push_back((uint32_t)a.nmoves);
     }
@@ -1278,7 +1038,7 @@ static int arena_run(az_engine* ec, az_engine* eb, int num_games, int first_game
       ArenaSlot& a = sl[s];
       if (!a.active || !(a.env.fin & 1)) continue;
       const int gi = (int)a.gid - first_game_id;
-      const bool colors_flipped = alternate && ((a.gid + 1) % 2 == 1);
+      const bool colors_flipped = alternate && ((gi + 1) % 2 == 1);
       double wr = 0.0, gp = 1.0;                                   // total_reward (trace.jl:45-47)
       for (const az_move_rec& r : a.moves) { wr += gp * (double)r.reward; gp *= ec->p.gamma; }
       if (rewards) rewards[gi] = colors_flipped ? -wr : wr;        // rewards_and_redundancy, simulations.jl:304-307
@@ -1338,8 +1098,6 @@ extern "C" int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, 
   return AZ_OK;
 }
 
-#include "memory.h"
-#include "train.h"
 
 // debug aid (not part of the ABI in azhip.h): the numerics contract evaluated on the device, so that tests can
 // compare gfx950 against the host bit for bit (f64 sqrt / div, az_log / az_exp / az_pow, az_expf / az_tanhf)
@@ -1372,30 +1130,6 @@ extern "C" int az_debug_math(az_engine* e, int32_t op, const double* x, const do
   HIPCHK(hipMemcpyAsync(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
-  return AZ_OK;
-}
-
-// debug aid (not part of the ABI in azhip.h): s_memtime stamps of one tower launch on n boards
-extern "C" int az_debug_tower_timeline(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
-  ENGINE(e);
-  if (!e->net_loaded || n < 1 || n > e->nn_cap) return fail(AZ_ERR_BAD_ARG, "bad n / no net");
-  if (e->cfg.game != AZ_GAME_CONNECT_FOUR || e->cfg.num_filters != 64) return fail(AZ_ERR_BAD_ARG, "connect-four with 64 filters only");
-  const int nb = (n + 2) / 3;
-  if (cap < (int64_t)nb * 16) return fail(AZ_ERR_CAPACITY, "need %d words", nb * 16);
-  unsigned long long* d = nullptr;
-  AZCHK(dalloc(e, &d, (size_t)nb * 16));
-  std::vector<GEnv> envs(n, ConnectFour::init());
-  HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * n, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->d_ntmp, &n, sizeof(int), hipMemcpyHostToDevice, e->stream));
-  NetDev nd = e->net;
-  for (int rep = 0; rep < 2; ++rep) {
-    nd.dbg = rep ? d : nullptr;
-    hipLaunchKernelGGL((k_tower<ConnectFour, 64, false>), dim3(nb), dim3(TowerCfg<64>::THREADS), TowerLds<64>::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat);
-  }
-  HIPCHK(hipMemcpyAsync(out, d, sizeof(unsigned long long) * nb * 16, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  e->allocs.pop_back();
-  (void)hipFree(d);
   return AZ_OK;
 }
 

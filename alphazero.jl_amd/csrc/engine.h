@@ -1,0 +1,210 @@
+// engine.h -- what the translation units of libazhip.so share: the engine record, error / launch macros, the
+// profiling helpers and the entry points of net.hip (network launches) used by azhip.hip, memory.hip and train.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+#include <unordered_set>
+
+#include "../../include/az_numerics.h"
+#include "../../include/azhip.h"
+#include "games.h"
+#include "resnet.h"
+#include "resnet16.h"
+#include "tree.h"
+
+// ------------------------------------------------------------------------------- errors
+int fail(int code, const char* fmt, ...);   // sets az_last_error() (thread-local), returns code; defined in azhip.hip
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t _e = (x);                                                                            \
+    if (_e != hipSuccess) return fail(AZ_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define AZCHK(x)            \
+  do {                      \
+    int _s = (x);           \
+    if (_s != AZ_OK) return _s; \
+  } while (0)
+
+
+#define DISPATCH_GAME(gid, ...)                                   \
+  switch (gid) {                                                  \
+    case AZ_GAME_CONNECT_FOUR: { using Gm = ConnectFour; __VA_ARGS__; break; } \
+    case AZ_GAME_TICTACTOE: { using Gm = TicTacToe; __VA_ARGS__; break; }      \
+    case AZ_GAME_MANCALA: { using Gm = Mancala; __VA_ARGS__; break; }          \
+    default: return fail(AZ_ERR_BAD_ARG, "unknown game id %d", (int)(gid));    \
+  }
+
+struct GameInfo { int A, APAD, W, H, C, P, max_plies, node_bytes; };
+inline bool game_info(int gid, GameInfo* gi) {
+  switch (gid) {
+    case AZ_GAME_CONNECT_FOUR: *gi = {ConnectFour::A, ConnectFour::APAD, ConnectFour::W, ConnectFour::H, ConnectFour::C, ConnectFour::P, ConnectFour::MAX_PLIES, NodeL<ConnectFour>::BYTES}; return true;
+    case AZ_GAME_TICTACTOE: *gi = {TicTacToe::A, TicTacToe::APAD, TicTacToe::W, TicTacToe::H, TicTacToe::C, TicTacToe::P, TicTacToe::MAX_PLIES, NodeL<TicTacToe>::BYTES}; return true;
+    case AZ_GAME_MANCALA: *gi = {Mancala::A, Mancala::APAD, Mancala::W, Mancala::H, Mancala::C, Mancala::P, Mancala::MAX_PLIES, NodeL<Mancala>::BYTES}; return true;
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------- engine
+static constexpr int AZ_MAX_GROUPS = 4;
+struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; };
+struct az_engine {
+  az_engine_cfg cfg;
+  GameInfo gi;
+  int device;
+  hipStream_t stream;
+  DView v;                       // global view over all G slots (start / move / hooks)
+  DParams p;
+  // slot groups: num_workers / batch_size interleaved half-batches, each with its own stream, so the
+  // tree kernels of one group run under the network of another (the device form of the reference's
+  // num_workers = 2 x batch_size, games/connect-four/params.jl:18-19)
+  int ngroups;
+  DView gv[AZ_MAX_GROUPS];
+  hipStream_t gs[AZ_MAX_GROUPS];      // tree-kernel stream of the group (high priority when ngroups > 1)
+  hipStream_t gt[AZ_MAX_GROUPS];      // network stream of the group
+  hipEvent_t ev_tree[AZ_MAX_GROUPS], ev_net[AZ_MAX_GROUPS];
+  float* g_hfeat[AZ_MAX_GROUPS];
+  std::vector<void*> allocs;
+  std::vector<void*> net_allocs;   // device copies of the packed network (replaced by az_net_set_params)
+  // network
+  bool net_loaded;
+  std::vector<float> blob;
+  NetDev net;
+  Net16Dev net16;                // k_tower16 fragments (64 filters)
+  char last_tower[96];           // name of the tower kernel that served the most recent network launch (az_net_last_kernel)
+  int tower_pick;                // AZHIP_TOWER=16|32|3|21 forces a tower kernel (3 = k_tower16 with 3 row tiles, 21 = k_tower16x2); 0 = choose per launch
+  int num_cu;
+  int nn_cap;
+  float* d_hfeat; float* d_X; float* d_A; float* d_P; float* d_V; float* d_Pinv;
+  GEnv* d_tmp_env; int* d_iota; int* d_ntmp;
+  // staging
+  int* d_slots; uint32_t* d_gids; GEnv* d_roots; uint32_t* d_moves; double* d_eta; int* d_offsets;
+  az_move_rec* d_stage; unsigned long long* d_keys; int* d_actions; unsigned long long* d_next; signed char* d_term; float* d_reward;
+  char* d_nodebuf;
+  int* d_visits;
+  int io_cap;
+  // self-play state
+  bool running;
+  int total_games, next_game, first_game_id, games_done, wave_in_move, active_slots;
+  int group_active[AZ_MAX_GROUPS];   // active slots per slot group (host count; bounds the leaves of a network launch)
+  std::vector<az_game_rec> q_games;
+  std::vector<az_move_rec> q_moves;
+  az_selfplay_stats stats;
+  std::chrono::steady_clock::time_point t_begin;
+  // profiling
+  bool prof_on;
+  int prof_mask;                 // 0 = every kernel class, else bit per az_kernel_class
+  std::vector<ProfRec> prof_pool;
+  size_t prof_used;
+  az_prof prof;
+  std::vector<int> h_finished;
+  std::vector<az_game_rec> h_grec;
+};
+
+template <class T> inline int dalloc(az_engine* e, T** p, size_t n, bool zero = true) {
+  void* q = nullptr;
+  size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+  hipError_t r = hipMalloc(&q, bytes);
+  if (r != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r));
+  e->allocs.push_back(q);
+  if (zero) HIPCHK(hipMemsetAsync(q, 0, bytes, e->stream));
+  *p = (T*)q;
+  return AZ_OK;
+}
+
+inline int sync_groups(az_engine* e) {
+  for (int g = 0; g < e->ngroups; ++g) if (e->gs[g] != e->stream) {
+    HIPCHK(hipStreamSynchronize(e->gt[g]));
+    HIPCHK(hipStreamSynchronize(e->gs[g]));
+  }
+  return AZ_OK;
+}
+inline int sync_all(az_engine* e) {
+  AZCHK(sync_groups(e));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return AZ_OK;
+}
+inline int prof_flush(az_engine* e) {
+  if (!e->prof_used) return AZ_OK;
+  AZCHK(sync_all(e));
+  for (size_t i = 0; i < e->prof_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->prof_pool[i].a, e->prof_pool[i].b));
+    e->prof.ms[e->prof_pool[i].cls] += ms;
+  }
+  e->prof_used = 0;
+  return AZ_OK;
+}
+inline int prof_begin(az_engine* e, hipStream_t st, int cls, int64_t units) {
+  if (!e->prof_on || (e->prof_mask && !((e->prof_mask >> cls) & 1))) return AZ_OK;
+  if (e->prof_used == e->prof_pool.size()) AZCHK(prof_flush(e));
+  ProfRec& r = e->prof_pool[e->prof_used];
+  r.cls = cls;
+  e->prof.launches[cls] += 1;
+  e->prof.units[cls] += units;
+  HIPCHK(hipEventRecord(r.a, st));
+  return AZ_OK;
+}
+inline int prof_end(az_engine* e, hipStream_t st, int cls) {
+  if (!e->prof_on || (e->prof_mask && !((e->prof_mask >> cls) & 1))) return AZ_OK;
+  HIPCHK(hipEventRecord(e->prof_pool[e->prof_used].b, st));
+  e->prof_used++;
+  return AZ_OK;
+}
+#define LAUNCH_ON(e, st, cls, units, kern, grid, block, shmem, ...)         \
+  do {                                                                      \
+    AZCHK(prof_begin(e, st, cls, units));                                   \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, st, __VA_ARGS__); \
+    AZCHK(prof_end(e, st, cls));                                            \
+  } while (0)
+#define LAUNCH(e, cls, units, kern, grid, block, shmem, ...) LAUNCH_ON(e, (e)->stream, cls, units, kern, grid, block, shmem, __VA_ARGS__)
+
+#define ENGINE(e)                                              \
+  if (!(e)) return fail(AZ_ERR_BAD_ARG, "engine is NULL");      \
+  HIPCHK(hipSetDevice((e)->device))
+
+// ---- net.hip: every instantiation of the tower / heads kernels lives there ----------------------------------
+int net_set_kernel_attrs(int game);
+// tower + heads on n_max boards (device count in n_ptr when given): from_planes ? X / Amask : envs[eslots[i]]
+int net_launch(az_engine* e, hipStream_t st, bool from_planes, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr,
+               int n_max, const float* X, const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride);
+// the network part of one search wave of slot group g (at most nmax leaves)
+int net_wave(az_engine* e, int g, bool split, int nmax);
+
+// ---- replay memory records shared by memory.hip and train.hip -------------------------------------------------
+struct az_memory {
+  int game, device;
+  GameInfo gi;
+  hipStream_t stream;
+  az_sample* d_buf;
+  int64_t cap, total, cur_batch;     // total = samples pushed since the last empty!; sample of sequence q sits at q % cap
+};
+struct az_dataset {
+  int game, device;
+  GameInfo gi;
+  hipStream_t stream;
+  int64_t n, sum_n;
+  double Wtot;
+  float Wmean, Hp;
+  az_sample* d_samples;
+  GEnv* d_envs;
+  float *d_W, *d_X, *d_A, *d_P, *d_V;
+  std::vector<void*> allocs;
+};
+template <class T> inline int mem_alloc(std::vector<void*>* keep, T** p, size_t n) {
+  void* q = nullptr;
+  size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+  hipError_t r = hipMalloc(&q, bytes);
+  if (r != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r));
+  if (keep) keep->push_back(q);
+  *p = (T*)q;
+  return AZ_OK;
+}

@@ -1,4 +1,4 @@
-// memory.h -- the replay memory and the learning-status evaluation on the device.
+// memory.hip -- the replay memory and the learning-status evaluation on the device.
 //
 //   MemoryBuffer / push_trace! / get_experience / last_batch            src/memory.jl:20-87
 //   augment_with_symmetries, merge_by_state                              src/memory.jl:89-138
@@ -9,39 +9,9 @@
 // buffer, the symmetric images, the by-state merge (two stable radix sorts + one segment walk, so the averages
 // are accumulated in buffer order like the reference's), the Float32 tensors and the loss terms are all device
 // arrays.  The network forward of the loss is the same fused tower + heads as self-play (test mode).
-// Included at the end of azhip.hip (it uses the engine's launch_net).
-#pragma once
+// The loss's network forward goes through net_launch (engine.h).
+#include "engine.h"
 #include <hipcub/hipcub.hpp>
-
-struct az_memory {
-  int game, device;
-  GameInfo gi;
-  hipStream_t stream;
-  az_sample* d_buf;
-  int64_t cap, total, cur_batch;     // total = samples pushed since the last empty!; sample of sequence q sits at q % cap
-};
-struct az_dataset {
-  int game, device;
-  GameInfo gi;
-  hipStream_t stream;
-  int64_t n, sum_n;
-  double Wtot;
-  float Wmean, Hp;
-  az_sample* d_samples;
-  GEnv* d_envs;
-  float *d_W, *d_X, *d_A, *d_P, *d_V;
-  std::vector<void*> allocs;
-};
-
-template <class T> static int mem_alloc(std::vector<void*>* keep, T** p, size_t n) {
-  void* q = nullptr;
-  size_t bytes = std::max<size_t>(n * sizeof(T), 16);
-  hipError_t r = hipMalloc(&q, bytes);
-  if (r != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r));
-  if (keep) keep->push_back(q);
-  *p = (T*)q;
-  return AZ_OK;
-}
 
 // push_trace! (memory.jl:74-87): one thread per game walks its records from the last position to the first
 template <class Gm>
@@ -544,7 +514,7 @@ static int learning_status_run(az_engine* e, az_dataset* d, double l2, double ci
     HIPCHK(hipMemcpyAsync(d_counts, counts.data(), sizeof(int) * (size_t)nchunks, hipMemcpyHostToDevice, st));
     for (int64_t c = 0; c < nchunks; ++c) {
       const int64_t off = c * e->nn_cap;
-      AZCHK((launch_net<Gm, false>(e, st, e->d_hfeat, d->d_envs + off, e->d_iota, d_counts + c, counts[c], nullptr, nullptr, Ph + (size_t)off * Gm::A, Vh + off, Pinv + off, Gm::A)));
+      AZCHK(net_launch(e, st, false, e->d_hfeat, d->d_envs + off, e->d_iota, d_counts + c, counts[c], nullptr, nullptr, Ph + (size_t)off * Gm::A, Vh + off, Pinv + off, Gm::A));
     }
     HIPCHK(hipStreamSynchronize(st));                              // `counts` must outlive the copy
     hipLaunchKernelGGL(k_loss_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d->d_W, d->d_P, d->d_V, Ph, Vh, Pinv, (long long)n, Gm::A, (float)renorm, tkl, thn, tmse, tinv);

@@ -1,4 +1,4 @@
-// train.h -- the optimiser step on the device (second half; first version).
+// train.hip -- the optimiser step on the device (second half; first version).
 //
 //   batch_updates!(tr, n)                      src/learning.jl:131-141
 //   Network.train!(callback, nn, opt, ...)     src/networks/flux.jl:68-95   (Flux.withgradient + Flux.update!)
@@ -16,8 +16,7 @@
 // created, so self-play users never load it.  The fused inference tower is untouched: after training the new
 // parameters go back through az_net_set_params.
 //
-// Included at the end of azhip.hip (after memory.h).
-#pragma once
+#include "engine.h"
 #include <dlfcn.h>
 
 // ------------------------------------------------------------------------------------------ rocBLAS by dlopen

@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) k_select(DView v, DParams p) {
 // order (what Batchifier.launch_server collects, src/batchifier.jl:47-81).  Two passes over 1024-slot chunks so
 // that it scales to any slot count: k_compact_count leaves each slot's rank inside its chunk in eidx[] and the
 // chunk total in chunk_cnt[]; k_compact_assign adds the totals of the chunks before it.
-__global__ void __launch_bounds__(1024) k_compact_count(DView v) {
+static __global__ void __launch_bounds__(1024) k_compact_count(DView v) {
   __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   __shared__ int wsum[16], wsims[16], wtrav[16];
   const int s = blockIdx.x * 1024 + threadIdx.x;
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(1024) k_compact_count(DView v) {
     }
   }
 }
-__global__ void __launch_bounds__(1024) k_compact_assign(DView v) {
+static __global__ void __launch_bounds__(1024) k_compact_assign(DView v) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ int red[16];
   __shared__ int s_base, s_total;
@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(256) k_root_visits(DView v, const int* slots, 
   for (int a = 0; a < AZ_MAX_ACTIONS; ++a) o[1 + a] = (nd && a < Gm::A && ((m >> a) & 1)) ? ((const int*)(nd + NL::OFF_N))[a] : 0;
 }
 // MCTS.reset! (mcts.jl:278-281) on a list of slots: a new epoch empties the slot's table in O(1)
-__global__ void __launch_bounds__(256) k_reset_slots(DView v, const int* slots, int n) {
+static __global__ void __launch_bounds__(256) k_reset_slots(DView v, const int* slots, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int slot = slots[i];
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(256) k_reset_slots(DView v, const int* slots, 
 }
 
 // gather the move records of finished games into one contiguous staging area
-__global__ void k_gather_traces(DView v, const int* slots, const int* offsets, int n, az_move_rec* out) {
+static __global__ void k_gather_traces(DView v, const int* slots, const int* offsets, int n, az_move_rec* out) {
   const int i = blockIdx.x;
   if (i >= n) return;
   const int slot = slots[i];

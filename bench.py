@@ -30,77 +30,119 @@ assert TOWER_FLOP + HEADS_FLOP == 31645952
 PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def pmc_traffic(boards_per_launch):
-    """HBM bytes per k_tower launch from the committed PMC passes (profiles/r1/r1d_pmc_summary_groups1.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this workload at 4096 boards per launch; KB units,
-    FETCH doubled on gfx950 as MI355X_MICROARCH.md prescribes).  The write side (head features) scales with
-    the boards of a launch, the read side (weights, once per XCD L2) does not.  None if the file is absent."""
-    p = os.path.join(ROOT, "profiles", "r1", "r1d_pmc_summary_groups1.json")
+PEAK_HBM_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def pmc_traffic(kernel, boards_per_launch):
+    """HBM bytes per tower launch from THIS round's PMC passes of this workload (profiles/r2/pmc_tower_summary.json,
+    written by tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs; KB units, FETCH doubled
+    on gfx950 as MI355X_MICROARCH.md prescribes).  Only used when the summary is for the kernel that actually ran;
+    None otherwise (the counters cannot be read from inside this process)."""
+    p = os.path.join(ROOT, "profiles", "r2", "pmc_tower_summary.json")
     try:
         d = json.load(open(p))
-        k = [v for name, v in d.items() if "k_tower" in name][0]
-        return 2.0 * k["FETCH_SIZE"] * 1024.0 + k["WRITE_SIZE"] * 1024.0 * boards_per_launch / 4096.0
+        if d.get("kernel") != kernel:
+            return None
+        return (2.0 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0 * boards_per_launch / d["boards_per_launch"]
     except Exception:
         return None
 
 
-def cpu_baseline(blob, hp, nsims, seconds=12.0, threads=None):
-    """The oracle (a port, not the reference: Julia is absent) on the host cores: independent Connect-Four
-    searches of `nsims` simulations each (= one move of a game) with the fp32 ResNet, one search at a time per
-    thread, started until `seconds` have elapsed (bounded sample: the default bench stays within minutes)."""
+def cpu_baseline(blob, hp, nsims, seconds=8.0):
+    """The oracle (a port, not the reference: Julia is absent) on the host cores, four bounded samples of the same
+    workload: independent Connect-Four searches of `nsims` simulations each (= one move of a game), one
+    search at a time per thread, started until the sample's time is up.  `value` = all threads with the fp32 ResNet (the
+    configuration the GPU number is quoted on); variants: 1 thread with the ResNet, and the uniform oracle
+    (MCTS.RandomOracle: tree cost only, comparable to the reference's 11 us / simulation) on 1 / all threads."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import azref as R
-    threads = threads or min(os.cpu_count() or 1, 32)
-    done = [0] * threads
-    roots = [0] * threads
     R.lib()
-    t0 = time.perf_counter()
+    ncpu = min(os.cpu_count() or 1, 32)
+    net = (hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters, blob)
 
-    def work(t):
-        r = t
-        while time.perf_counter() - t0 < seconds:
-            m = R.Mcts(R.C4, oracle=R.ORACLE_NET, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0,
-                       net=(hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters, blob))
-            m.explore(R.Game(R.C4), nsims, seed=1, game_id=r, move=0)
-            done[t] += m.total_simulations
-            roots[t] += 1
-            r += threads
-    ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
-    [t.start() for t in ths]
-    [t.join() for t in ths]
-    dt = time.perf_counter() - t0
-    return {"value": sum(done) / dt, "unit": "sims/s", "cores": threads, "kind": "port",
-            "sample": "%d Connect-Four searches x %d sims (one move each), ResNet 5x64 fp32, %d threads, %.1f s"
-                      % (sum(roots), nsims, threads, dt)}
+    def sample(threads, oracle, secs):
+        done = [0] * threads
+        roots = [0] * threads
+        t0 = time.perf_counter()
+
+        def work(t):
+            r = t
+            while time.perf_counter() - t0 < secs:
+                m = R.Mcts(R.C4, oracle=oracle, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0, net=net if oracle == R.ORACLE_NET else None)
+                m.explore(R.Game(R.C4), nsims, seed=1, game_id=r, move=0)
+                done[t] += m.total_simulations
+                roots[t] += 1
+                r += threads
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        dt = time.perf_counter() - t0
+        return {"value": sum(done) / dt, "unit": "sims/s", "cores": threads,
+                "oracle": "ResNet 5x64 fp32" if oracle == R.ORACLE_NET else "uniform (MCTS.RandomOracle)",
+                "sample": "%d Connect-Four searches x %d sims (one move each), %d threads, %.1f s" % (sum(roots), nsims, threads, dt)}
+    main = sample(ncpu, R.ORACLE_NET, seconds)
+    out = dict(main, kind="port")
+    out["sample"] = main["sample"] + ", ResNet 5x64 fp32"
+    out["variants"] = [sample(1, R.ORACLE_NET, seconds * 0.75), sample(1, R.ORACLE_UNIFORM, seconds * 0.4),
+                       sample(ncpu, R.ORACLE_UNIFORM, seconds * 0.4)]
+    out["us_per_sim_uniform_1_thread"] = 1e6 / out["variants"][1]["value"]
+    return out
 
 
-def kernel_alone(args, blob, dev_index, waves=200):
-    """The dominant kernel WITHOUT anything co-scheduled (extra evidence, outside the timed region; not part of `value`):
-    the same workload with one slot group, so every network launch takes all slots and runs alone on its stream.
-    With several groups the per-launch durations of `roofline` include time shared with the other group's kernels."""
+TOWER_CODE = {"k_tower16x2": "21", "k_tower16<": "16", "k_tower<": "32"}
+
+
+def alone_and_tree(args, blob, dev_index, kernel, waves=200):
+    """Extra evidence, measured live after the timed region (not part of `value`): the same workload with ONE slot group, so
+    nothing is co-scheduled with a launch and HIP-event durations are exclusive.  (i) the kernel of the timed region, alone
+    (forced with AZHIP_TOWER so that it is the SAME kernel, not the one a single group would pick); (ii) the search-tree
+    kernels against the HBM roofline: algorithmic bytes of SURVEY.md §8(d) without the network's share --
+    148 B per traversed node + per new leaf 16 (probe miss) + 136 (node write) + 64 (P, V written by the network, read by the expansion)."""
     import azhip
-    eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=dev_index,
-                       num_workers=args.slots, batch_size=args.slots, num_iters_per_turn=args.sims,
-                       gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
-                       prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
-                       num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    code = "3" if "NT=3" in kernel else next((v for k, v in TOWER_CODE.items() if kernel.startswith(k)), None)
+    old = os.environ.get("AZHIP_TOWER")
+    if code:
+        os.environ["AZHIP_TOWER"] = code
+    try:
+        eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=dev_index,
+                           num_workers=args.slots, batch_size=args.slots, num_iters_per_turn=args.sims,
+                           gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
+                           prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
+                           num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    finally:
+        if old is None:
+            os.environ.pop("AZHIP_TOWER", None)
+        else:
+            os.environ["AZHIP_TOWER"] = old
     eng.net_set_params(blob)
     eng.selfplay_begin(-1, first_game_id=1 << 28)
-    eng.selfplay_step(40)
+    eng.selfplay_step(args.sims + args.sims // 2)
     s0 = eng.selfplay_stats()
     eng.prof_reset()
-    eng.prof_enable(True, classes=("tower",))
+    eng.prof_enable(True)
     eng.selfplay_step(waves)
     s1 = eng.selfplay_stats()
-    tw = eng.prof_get()["tower"]
+    prof = eng.prof_get()
+    name = eng.net_last_kernel()
     eng.prof_enable(False)
     eng.selfplay_end()
     eng.close()
-    evals = s1.leaf_evals - s0.leaf_evals
-    achieved = evals * TOWER_FLOP / (tw["ms"] * 1e-3) / 1e12 if tw["ms"] > 0 else 0.0
-    return {"kernel": "k_tower16x2<ConnectFour,64,false>", "slot_groups": 1, "waves": waves, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
-            "avg_boards_per_launch": evals / max(tw["launches"], 1)}
+    evals, sims, trav = s1.leaf_evals - s0.leaf_evals, s1.simulations - s0.simulations, s1.nodes_traversed - s0.nodes_traversed
+    tw = prof["tower"]
+    flop = TOWER_FLOP + (HEADS_FLOP if name.endswith("+heads16") else 0)
+    achieved = evals * flop / (tw["ms"] * 1e-3) / 1e12 if tw["ms"] > 0 else 0.0
+    alone = {"kernel": name, "slot_groups": 1, "waves": waves, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+             "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
+             "avg_boards_per_launch": evals / max(tw["launches"], 1)}
+    tree_cls = [c for c in ("select", "compact", "expand") if prof[c]["launches"]]
+    tree_ms = sum(prof[c]["ms"] for c in tree_cls)
+    tree_bytes = 148.0 * trav + (16 + 136 + 64) * evals + 16.0 * (sims - evals)
+    gbs = tree_bytes / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+    tree = {"bound": "hbm", "kernels": {c: {"launches": prof[c]["launches"], "avg_us": 1e3 * prof[c]["ms"] / prof[c]["launches"]} for c in tree_cls},
+            "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            "bytes_per_sim": tree_bytes / max(sims, 1), "avg_exploration_depth": trav / max(sims, 1), "slots": args.slots,
+            "us_per_wave": 1e3 * tree_ms / waves, "traffic": None}
+    return alone, tree
 
 
 def main():
@@ -154,7 +196,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    eng.selfplay_step(args.warmup)
+    # steady state whatever --warmup says: every slot plays its first move and is half way through the search of its
+    # second (trees carry over between the moves of a game) before the timed region starts
+    warm = max(args.warmup, args.sims + args.sims // 2)
+    eng.selfplay_step(warm)
     s0 = eng.selfplay_stats()
     if not args.no_prof:
         eng.prof_reset()
@@ -169,6 +214,7 @@ def main():
     barrier()
     prof = eng.prof_get() if not args.no_prof else None
     eng.prof_enable(False)
+    eng_kernel = eng.net_last_kernel()
 
     elapsed = t1 - t0
     sims = s1.simulations - s0.simulations
@@ -185,11 +231,12 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         sims, evals, trav, moves = [float(x) for x in c.tolist()]
     eng.selfplay_end()
+    eng.close()                        # frees its ~10 GB before the extra legs build their own engine
 
     if rank == 0:
         out = {
             "metric": "self-play MCTS sims/sec (Connect-Four, %d parallel games per GPU)" % args.slots,
-            "value": sims / elapsed, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": sims / elapsed, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_waves_run": warm,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Connect-Four self-play, %d sims/move, %d parallel games per GPU, ResNet 5x64 fp32 "
@@ -204,24 +251,29 @@ def main():
         }
         if prof is not None:
             tw = prof["tower"]
-            flops = local_evals * TOWER_FLOP
-            achieved = flops / (tw["ms"] * 1e-3) / 1e12 if tw["ms"] > 0 else 0.0
+            kernel = eng_kernel
+            flop = TOWER_FLOP + (HEADS_FLOP if kernel.endswith("+heads16") else 0)
+            flops = local_evals * flop
+            # exclusive kernel time: with several slot groups the towers of different groups overlap, so the sum of their
+            # HIP-event durations can exceed the wall time of the region; it is clipped to it (kernel time per step <= ms_per_step)
+            wall_ms = 1e3 * local_elapsed
+            excl_ms = min(tw["ms"], wall_ms)
+            achieved = flops / (excl_ms * 1e-3) / 1e12 if excl_ms > 0 else 0.0
+            boards = local_evals / max(tw["launches"], 1)
             out["roofline"] = {
-                # one slot group: the paired 21-row-tile kernel; several groups: the 11-tile kernel (pick_tower, azhip.hip)
-                "kernel": "k_tower16x2<ConnectFour,64,false>" if args.groups == 1 else "k_tower16<ConnectFour,64,false,11>",
-                "bound": "mfma", "achieved": achieved,
+                "kernel": kernel, "bound": "mfma", "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": pmc_traffic(local_evals / max(tw["launches"], 1)),
-                "flop_per_board": TOWER_FLOP, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
-                "avg_boards_per_launch": local_evals / max(tw["launches"], 1),
-                "launches": tw["launches"],
-                # the same FLOPs over the WALL time of the timed region (all kernels, both slot groups): with several
-                # groups the per-launch durations above overlap each other, this figure has no such ambiguity
-                "step_achieved": flops / local_elapsed / 1e12, "step_frac": flops / local_elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": pmc_traffic(kernel, boards),
+                "flop_per_board": flop, "launches": tw["launches"], "avg_boards_per_launch": boards,
+                "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),          # raw HIP-event average (includes co-scheduled time)
+                "launch_ms_sum": tw["ms"], "wall_ms": wall_ms, "exclusive_ms": excl_ms,
+                "kernel_ms_per_step": excl_ms / args.steps,
             }
             out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
-        if prof is not None and world == 1 and args.groups > 1:
-            out["roofline_kernel_alone"] = kernel_alone(args, blob, dev_index)
+        if prof is not None and world == 1:
+            alone, tree = alone_and_tree(args, blob, dev_index, eng_kernel)
+            out["roofline_kernel_alone"] = alone
+            out["roofline_tree"] = tree
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, hp, args.sims)
         print(json.dumps(out))

@@ -218,7 +218,7 @@ int az_selfplay_end(az_engine* e);
  * player (its own network, MctsParams and per-worker trees); workers = min(contender's
  * num_workers, num_games); reset_every, flip_probability, gamma and the flip RNG seed are the
  * contender's.  alternate_colors != 0 swaps the colours of the games with odd 1-based sim_id
- * (simulations.jl:221-223), i.e. even global game id.  rewards[i] (may be NULL) = total reward of
+ * (simulations.jl:221-223): sim_id = game id - first_game_id + 1, the index within this call.  rewards[i] (may be NULL) = total reward of
  * game first_game_id+i from the CONTENDER's side (rewards_and_redundancy, simulations.jl:302-311),
  * *redundancy = 1 - #unique states / #states over all traces.  `out` (may be NULL) receives the
  * traces sorted by game id: az_move_rec.key is trace.states[i] (the state BEFORE the turn's random
@@ -328,6 +328,9 @@ int az_prof_enable(az_engine* e, int32_t on);   /* 1: wrap every launch in a HIP
 int az_prof_get(az_engine* e, az_prof* out);    /* synchronises, accumulates, returns totals */
 int az_prof_reset(az_engine* e);
 int az_device_info(az_engine* e, char* name, int32_t name_cap, int32_t* num_cu, int64_t* hbm_bytes);
+/* Name of the tower kernel the engine chose for its most recent network launch ("" before the first one): the
+ * kernel is picked per launch size (pick_tower, csrc/net.hip), bench.py reports the one that actually ran. */
+int az_net_last_kernel(const az_engine* e, char* name, int32_t cap);
 
 #ifdef __cplusplus
 }

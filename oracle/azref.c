@@ -893,6 +893,7 @@ typedef struct {
   uint64_t seed;
   int game, oracle_kind;
   int nblocks, F, npf, nvf; const float* blob;
+  int first_game_id;   /* azr_simulate: global id of the first game (a shard of simulate_distributed, simulations.jl:268-278) */
 } azr_sim_params;
 
 /* One trace record per move: state BEFORE the move (packed key), visit counts by action
@@ -930,7 +931,7 @@ int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
   for (int s = 0; s < G; ++s) {
     slots[s].mcts = azr_mcts_new(p->game, p->oracle_kind, p->gamma, p->cpuct, p->noise_eps, p->noise_alpha, p->prior_temperature);
     if (p->oracle_kind == AZR_ORACLE_NET) azr_mcts_set_net(slots[s].mcts, p->nblocks, p->F, p->npf, p->nvf, p->blob);
-    slots[s].game_id = next_game++; slots[s].active = 1;
+    slots[s].game_id = p->first_game_id + next_game++; slots[s].active = 1;
     azr_init(&slots[s].game, p->game);
     slots[s].first_move = -1;
   }
@@ -939,6 +940,9 @@ int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
   int maxlen = 512;
   azr_move_rec* stage = calloc((size_t)G * maxlen, sizeof(azr_move_rec));
   while (finished < p->num_games) {
+    /* the workers are independent (one tree, one game, one RNG stream each): a round's moves may run on
+     * separate host threads without changing any result */
+#pragma omp parallel for schedule(dynamic, 1)
     for (int s = 0; s < G; ++s) {
       azr_slot* sl = &slots[s];
       if (!sl->active) continue;
@@ -966,7 +970,7 @@ int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
     for (int s = 0; s < G; ++s) {
       azr_slot* sl = &slots[s];
       if (!sl->active || !azr_terminated(&sl->game)) continue;
-      azr_game_rec* gr = &games[sl->game_id];
+      azr_game_rec* gr = &games[sl->game_id - p->first_game_id];
       gr->game_id = sl->game_id; gr->slot = s; gr->num_moves = sl->nmoves; gr->first_move = (int32_t)nm;
       if (nm + sl->nmoves > moves_cap) { fprintf(stderr, "azref: move buffer too small\n"); abort(); }
       memcpy(moves + nm, stage + (size_t)s * maxlen, sizeof(azr_move_rec) * (size_t)sl->nmoves);
@@ -980,7 +984,7 @@ int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
       if (p->reset_every > 0 && sl->worker_sim_id % p->reset_every == 0) azr_mcts_reset(sl->mcts);
       finished++;
       if (next_game < p->num_games) {
-        sl->game_id = next_game++; sl->nmoves = 0;
+        sl->game_id = p->first_game_id + next_game++; sl->nmoves = 0;
         azr_init(&sl->game, p->game);
       } else sl->active = 0;
     }
@@ -1066,7 +1070,7 @@ int64_t azr_arena(const azr_sim_params* pc, const azr_sim_params* pb, int altern
           mr->N[AZR_AMAX] = k + 1;
         }
       }
-      int colors_flipped = alternate_colors && ((sl->game_id + 1) % 2 == 1);   /* simulations.jl:221-223 */
+      int colors_flipped = alternate_colors && ((sl->game_id - first_game_id + 1) % 2 == 1);   /* simulations.jl:221-223 */
       int who = (azr_white_playing(&sl->game) != colors_flipped) ? 0 : 1;      /* think(::TwoPlayers), play.jl:255-261 */
       const azr_sim_params* p = pp[who];
       azr_mcts* m = trees[who][s];
@@ -1106,7 +1110,7 @@ int64_t azr_arena(const azr_sim_params* pc, const azr_sim_params* pb, int altern
       /* total_reward (src/trace.jl:45-47), sign by colors_flipped (simulations.jl:304-307) */
       double wr = 0., gp = 1.;
       for (int i = 0; i < sl->nmoves; ++i) { wr += gp * (double)moves[nm + i].reward; gp *= pc->gamma; }
-      int colors_flipped = alternate_colors && ((sl->game_id + 1) % 2 == 1);
+      int colors_flipped = alternate_colors && ((sl->game_id - first_game_id + 1) % 2 == 1);
       if (rewards) rewards[gi] = colors_flipped ? -wr : wr;
       nm += sl->nmoves;
       sl->worker_sim_id++;
