@@ -158,8 +158,9 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &v.path, (size_t)G * v.max_depth));
     AZCHK(dalloc(e, &v.leaf_kind, G)); AZCHK(dalloc(e, &v.leaf_depth, G)); AZCHK(dalloc(e, &v.leaf_env, G));
     AZCHK(dalloc(e, &v.leaf_ins, G)); AZCHK(dalloc(e, &v.eidx, G)); AZCHK(dalloc(e, &v.eval_slots, G));
-    AZCHK(dalloc(e, &v.n_eval, AZ_MAX_GROUPS));
-    AZCHK(dalloc(e, &v.chunk_cnt, (size_t)(G + 1023) / 1024 + AZ_MAX_GROUPS));
+    AZCHK(dalloc(e, &v.n_eval, 2 * AZ_MAX_GROUPS));
+    AZCHK(dalloc(e, &v.keys, (size_t)G * cap * 2, false)); AZCHK(dalloc(e, &v.root_idx, G));
+    hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, (uint32_t*)v.root_idx, 0xffffffffu, G);
     AZCHK(dalloc(e, &v.Pout, (size_t)std::max(G, 1) * gi.APAD)); AZCHK(dalloc(e, &v.Vout, G));
     AZCHK(dalloc(e, &v.trace, (size_t)G * v.max_moves)); AZCHK(dalloc(e, &v.grec, G));
     AZCHK(dalloc(e, &v.finished, G)); AZCHK(dalloc(e, &v.err, 1)); AZCHK(dalloc(e, &v.stat, 8));
@@ -199,7 +200,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       gv.worker_sim_id += o; gv.tot_sims += o; gv.tot_trav += o; gv.eta += o * gi.APAD;
       gv.ht += o * hs; gv.nodes += o * (size_t)cap * gi.node_bytes; gv.vest += o * (size_t)cap; gv.path += o * v.max_depth;
       gv.leaf_kind += o; gv.leaf_depth += o; gv.leaf_env += o; gv.leaf_ins += o; gv.eidx += o; gv.eval_slots += o;
-      gv.n_eval += g; gv.chunk_cnt += (o + 1023) / 1024 + g; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
+      gv.n_eval += 2 * g; gv.keys += o * (size_t)cap * 2; gv.root_idx += o; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;
       if (ng == 1) { e->gs[g] = e->gt[g] = e->stream; }
       else {
@@ -436,24 +437,6 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
       d[1] = o < A ? pol_w[(4 * i + 2 + hh) * L + o] : 0.0f;
     }
   }
-  // fused dense heads of the k_tower16 family (heads16, resnet16.h): 16x16x4 B fragments, value tiles then the policy tile
-  std::vector<float> hd16_w(4);
-  if (hd_ok) {
-    const int NVT16 = F / 16;
-    const size_t vsteps = (size_t)P * nvf / 4, psteps = (size_t)P * npf / 4, vgr = (vsteps + 3) / 4, pgr = (psteps + 3) / 4;
-    hd16_w.assign((NVT16 * vgr + std::max(pgr, vgr)) * 64 * 4, 0.0f);
-    for (int t = 0; t <= NVT16; ++t) {
-      const bool pol = t == NVT16;
-      const size_t steps = pol ? psteps : vsteps, ngr = pol ? pgr : vgr;
-      for (size_t s4 = 0; s4 < ngr; ++s4) for (int ln = 0; ln < 64; ++ln) for (int j = 0; j < 4; ++j) {
-        const size_t i = 4 * s4 + j, k = 4 * i + (ln >> 4);
-        const int o = t * 16 + (ln & 15);
-        float val = 0.0f;
-        if (i < steps) val = pol ? ((ln & 15) < A ? pol_w[k * L + (ln & 15)] : 0.0f) : val_w[k * F + o];
-        hd16_w[(((size_t)t * vgr + s4) * 64 + ln) * 4 + j] = val;
-      }
-    }
-  }
   AZCHK(sync_all(e));
   for (void* q : e->net_allocs) (void)hipFree(q);
   e->net_allocs.clear();
@@ -487,11 +470,6 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
     AZCHK(up(s16_w, &n16.stem_w)); n16.stem_ss = nd.stem_ss;
     AZCHK(up(c16_w, &tmp)); n16.conv_w = (const float4*)tmp; n16.conv_ss = nd.conv_ss;
     AZCHK(up(h16_w, &tmp)); n16.head_w = (const float4*)tmp; n16.head_ss = nd.head_ss;
-    AZCHK(up(hd16_w, &tmp)); n16.hd16_w = (const float4*)tmp;
-    n16.pol_b = nd.pol_b; n16.val_b = nd.val_b; n16.val2_w = nd.val2_w; n16.val2_b = nd.val2_b;
-    n16.npf = npf; n16.nvf = nvf;
-    const char* nf = getenv("AZHIP_NO_FUSED_HEADS");                // A/B and test switch: tower -> hfeat -> k_heads_mfma
-    n16.fuse = (hd_ok && !(nf && atoi(nf))) ? 1 : 0;
   }
   e->net16 = n16;
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -572,8 +550,9 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
 }
 
 // ------------------------------------------------------------------------------- search waves
-// One wave = one run_simulation! for every active slot: select -> gather misses -> oracle ->
-// expand + backup.  Nothing is read back by the host.
+// One wave = one run_simulation! for every active slot of every group: k_tree (the previous wave's expand + backup,
+// this wave's select + leaf gathering) -> oracle.  Nothing is read back by the host.  The simulation a wave starts is
+// completed by the group's next k_tree launch: the next wave's, or flush_pending's.
 // sim_idx: index of this simulation within the current explore! (keys the rollout oracle's RNG stream)
 template <class Gm> static int wave(az_engine* e, int ngroups_active, uint32_t sim_idx) {
   constexpr int L = Gm::APAD;
@@ -584,17 +563,36 @@ template <class Gm> static int wave(az_engine* e, int ngroups_active, uint32_t s
     const bool split = st != sn;
     const int G = v.G;
     const int gb = (G * L + 255) / 256;
-    LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_select<Gm>), gb, 256, 0, v, e->p);
-    LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact_count, (G + 1023) / 1024, 1024, 0, v);
-    LAUNCH_ON(e, st, AZ_K_COMPACT, G, k_compact_assign, (G + 1023) / 1024, 1024, 0, v);
+    const int par = (e->wave_par[g] ^= 1);
+    LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_tree<Gm>), gb, 256, 0, v, e->p, e->pending[g] ? 1 : 0, 1, par);
+    e->pending[g] = true;
     if (e->cfg.oracle == AZ_ORACLE_RESNET) {
       AZCHK(net_wave(e, g, split, e->group_active[g]));
     } else {
-      LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p, sim_idx);
+      LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p, sim_idx, par);
     }
-    LAUNCH_ON(e, st, AZ_K_EXPAND, G, (k_expand_backup<Gm>), gb, 256, 0, v, e->p);
   }
   e->stats.waves++;
+  return AZ_OK;
+}
+// completes the simulations the last wave started (expand + backup only); every group, asynchronous
+template <class Gm> static int flush_pending(az_engine* e) {
+  constexpr int L = Gm::APAD;
+  for (int g = 0; g < e->ngroups; ++g) {
+    if (!e->pending[g]) continue;
+    const DView& v = e->gv[g];
+    LAUNCH_ON(e, e->gs[g], AZ_K_EXPAND, v.G, (k_tree<Gm>), (v.G * L + 255) / 256, 256, 0, v, e->p, 1, 0, e->wave_par[g]);
+    e->pending[g] = false;
+  }
+  return AZ_OK;
+}
+
+// no simulation in flight: pending leaves dropped, both leaf counters of every group zero
+static int reset_wave_state(az_engine* e) {
+  AZCHK(sync_groups(e));
+  HIPCHK(hipMemsetAsync(e->v.leaf_kind, 0, sizeof(int) * e->v.G, e->stream));
+  HIPCHK(hipMemsetAsync(e->v.n_eval, 0, sizeof(int) * 2 * AZ_MAX_GROUPS, e->stream));
+  for (int g = 0; g < AZ_MAX_GROUPS; ++g) { e->pending[g] = false; e->wave_par[g] = 0; }
   return AZ_OK;
 }
 
@@ -619,6 +617,8 @@ extern "C" int az_mcts_reset(az_engine* e) {
   HIPCHK(hipMemsetAsync(e->v.ht, 0, sizeof(unsigned long long) * (size_t)G * e->v.ht_size, e->stream));
   HIPCHK(hipMemsetAsync(e->v.node_count, 0, sizeof(int) * G, e->stream));
   hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, e->v.epoch, 1u, G);
+  hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, (uint32_t*)e->v.root_idx, 0xffffffffu, G);
+  AZCHK(reset_wave_state(e));
   HIPCHK(hipStreamSynchronize(e->stream));
   return AZ_OK;
 }
@@ -634,6 +634,7 @@ static int explore_begin(az_engine* e, const std::vector<int>& slots, const std:
   if (!n) return AZ_OK;
   int maxslot = 0;
   for (int s : slots) maxslot = std::max(maxslot, s);
+  AZCHK(reset_wave_state(e));
   HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
   AZCHK(start_games<Gm>(e, slots, gids, &roots, 0, 0));
   HIPCHK(hipMemcpyAsync(e->d_moves, mv.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
@@ -645,8 +646,9 @@ static int explore_begin(az_engine* e, const std::vector<int>& slots, const std:
   for (int sl : slots) e->group_active[sl / e->gv[0].G]++;
   return AZ_OK;
 }
-static int explore_end(az_engine* e, int nga) {
+template <class Gm> static int explore_end(az_engine* e, int nga) {
   if (!nga) return AZ_OK;
+  AZCHK(flush_pending<Gm>(e));                                     // the last simulation's expand + backup
   AZCHK(sync_groups(e));
   HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
   return check_device_error(e);
@@ -657,7 +659,7 @@ static int explore_slots(az_engine* e, const std::vector<int>& slots, const std:
   int nga = 0;
   AZCHK(explore_begin<Gm>(e, slots, roots, gids, mv, eta, &nga));
   if (nga) for (int i = 0; i < nsims; ++i) AZCHK(wave<Gm>(e, nga, (uint32_t)i));
-  return explore_end(e, nga);
+  return explore_end<Gm>(e, nga);
 }
 
 extern "C" int az_mcts_explore(az_engine* e, const uint64_t* root_keys, int32_t nslots, int32_t nsims,
@@ -689,6 +691,7 @@ __global__ void k_node_stats(DView v, int slot, unsigned long long ka, unsigned 
   const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
   const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
+  const unsigned long long* keys = v.keys + (size_t)slot * v.cap_nodes * 2;
   int* found = (int*)out;
   *found = 0;
   for (uint32_t i = 0; i <= H1; ++i) {
@@ -697,7 +700,7 @@ __global__ void k_node_stats(DView v, int slot, unsigned long long ka, unsigned 
     if (!((uint32_t)(e >> 48) == epoch && idx1 != 0)) return;
     if (((uint32_t)(e >> 32) & 0xffff) == tag) {
       const char* nd = pool + (size_t)(idx1 - 1) * NL::BYTES;
-      const unsigned long long* k = (const unsigned long long*)nd;
+      const unsigned long long* k = keys + (size_t)(idx1 - 1) * 2;
       if (k[0] == ka && k[1] == kb) {
         *found = 1;
         *(float*)(out + 4) = v.vest[(size_t)slot * v.cap_nodes + (idx1 - 1)];
@@ -720,9 +723,9 @@ extern "C" int az_mcts_node_stats(az_engine* e, int32_t slot, const uint64_t key
   int found; memcpy(&found, buf, 4);
   if (!found) return fail(AZ_ERR_BAD_ARG, "state not in the tree of slot %d", slot);
   const char* nd = buf + 16;
-  const int A = e->gi.A, offP = 16 + 4 * A, offW = (16 + 8 * A + 7) / 8 * 8;
+  const int A = e->gi.A, offP = 4 * A, offW = (8 * A + 7) / 8 * 8;   // NodeL (tree.h)
   for (int a = 0; a < A; ++a) {
-    if (N) memcpy(&N[a], nd + 16 + 4 * a, 4);
+    if (N) memcpy(&N[a], nd + 4 * a, 4);
     if (P) memcpy(&P[a], nd + offP + 4 * a, 4);
     if (W) memcpy(&W[a], nd + offW + 8 * a, 8);
   }
@@ -756,6 +759,7 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   if (e->cfg.oracle == AZ_ORACLE_RESNET && !e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
   const int G = e->v.G;
   // a fresh player per worker (simulations.jl:217-218): empty trees, zero counters
+  AZCHK(reset_wave_state(e));
   HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * G, e->stream));
   HIPCHK(hipMemsetAsync(e->v.finished, 0, sizeof(int) * G, e->stream));
   HIPCHK(hipMemsetAsync(e->v.worker_sim_id, 0, sizeof(int) * G, e->stream));
@@ -781,6 +785,7 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
 // the move step (play.jl:308-313) for every slot, then collection of finished games and refill
 template <class Gm> static int move_round(az_engine* e) {
   const int G = e->v.G;
+  AZCHK(flush_pending<Gm>(e));                                     // explore! is over: the last simulation's expand + backup
   AZCHK(sync_groups(e));
   LAUNCH(e, AZ_K_MOVE, G, (k_move<Gm>), (G + 255) / 256, 256, 0, e->v, e->p);
   HIPCHK(hipMemcpyAsync(e->h_finished.data(), e->v.finished, sizeof(int) * G, hipMemcpyDeviceToHost, e->stream));
@@ -881,7 +886,7 @@ extern "C" int az_selfplay_collect(az_engine* e, az_trace_buf* out) {
 extern "C" int az_selfplay_end(az_engine* e) {
   ENGINE(e);
   if (!e->running) return AZ_OK;
-  AZCHK(sync_groups(e));
+  AZCHK(reset_wave_state(e));                                      // an unfinished simulation (stepping form stopped mid-move) is dropped
   HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->running = false;
@@ -1005,7 +1010,7 @@ static int arena_run(az_engine* ec, az_engine* eb, int num_games, int first_game
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipSetDevice(eng[k]->device));
       if (eng[k]->p.nsims > 0) {
-        AZCHK(explore_end(eng[k], nga[k]));
+        AZCHK(explore_end<Gm>(eng[k], nga[k]));
         AZCHK(root_visits<Gm>(eng[k], slots[k], roots[k], visits[k]));
       } else {
         AZCHK(evaluate_envs(eng[k], roots[k], netP[k], netV[k]));   // NetworkPlayer.think (play.jl:230-235)

@@ -94,6 +94,8 @@ struct az_engine {
   // self-play state
   bool running;
   int total_games, next_game, first_game_id, games_done, wave_in_move, active_slots;
+  bool pending[AZ_MAX_GROUPS];       // the group's last wave awaits its expand + backup (flush_pending)
+  int wave_par[AZ_MAX_GROUPS];       // parity of the group's last wave: which of its two leaf counters is current
   int group_active[AZ_MAX_GROUPS];   // active slots per slot group (host count; bounds the leaves of a network launch)
   std::vector<az_game_rec> q_games;
   std::vector<az_move_rec> q_moves;

@@ -1,169 +1,39 @@
-// net.hip -- the translation unit that instantiates the network kernels (resnet.h, resnet16.h) and chooses which one
-// serves a launch.  azhip.hip / memory.hip reach it through net_launch / net_wave (engine.h).
+// net.hip -- dispatch of the network launches on the engine's game; the kernels are instantiated per game in
+// net_c4.hip / net_ttt.hip / net_mancala.hip (net_impl.h).  azhip.hip / memory.hip call net_launch / net_wave (engine.h).
 #include "engine.h"
 
-template <class Gm, int F> static int set_kernel_attrs_f() {
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
-  if constexpr (F == 64) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
-  }
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
-  return AZ_OK;
-}
-template <class Gm> static int set_kernel_attrs() {
-  AZCHK((set_kernel_attrs_f<Gm, 64>()));
-  AZCHK((set_kernel_attrs_f<Gm, 128>()));
-  return AZ_OK;
-}
+#define AZ_NET_DECL(sfx)                                                                                                     \
+  int net_set_kernel_attrs_##sfx();                                                                                          \
+  int net_launch_##sfx(az_engine* e, hipStream_t st, bool from_planes, float* hfeat, const GEnv* envs, const int* eslots,    \
+                       const int* n_ptr, int n_max, const float* X, const float* Amask, float* Pout, float* Vout, float* Pinv, \
+                       int pstride);                                                                                         \
+  int net_wave_##sfx(az_engine* e, int g, bool split, int nmax);
+AZ_NET_DECL(c4)
+AZ_NET_DECL(ttt)
+AZ_NET_DECL(mancala)
 
-static void note_tower(az_engine* e, int tw, int F, bool fused) {
-  static const char* const gn[] = {"ConnectFour", "TicTacToe", "Mancala"};
-  const char* g = gn[e->cfg.game];
-  if (tw == 21) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d>%s", g, F, fused ? "+heads16" : "");
-  else if (tw == 3) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=3>%s", g, F, fused ? "+heads16" : "");
-  else if (tw == 16) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=11>%s", g, F, fused ? "+heads16" : "");
-  else snprintf(e->last_tower, sizeof e->last_tower, "k_tower<%s,%d>", g, F);
-}
 int net_set_kernel_attrs(int game) {
-  DISPATCH_GAME(game, AZCHK(set_kernel_attrs<Gm>()));
-  return AZ_OK;
-}
-
-// launches tower + heads on `n` boards (device count in n_ptr when n < 0)
-// Which tower kernel serves a launch of up to n boards.  A workgroup's layer chain is sequential and the MFMA
-// pipe of a CU is shared by its resident workgroups, so the launch costs (workgroups per CU, rounded up) x (rows
-// per workgroup): k_tower16 packs 176 rows (4 Connect-Four boards), k_tower 128 (3 boards), k_tower16 with 3 row
-// tiles 48 (1 board; +10 %: a third of the weight reuse, more barriers per row).  4096 Connect-Four leaves:
-// 4 x 176 < 6 x 128; 128 leaves: 1 x 48 << 1 x 128 (measured tools/small_batch.sh: 0.39 vs 0.80 ms per wave at
-// 128 filters).  Returns 16, 32 or 3.
-template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
-  if (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64)) return e->tower_pick;
-  const long cu = e->num_cu > 0 ? e->num_cu : 256;
-  const long b16 = (n + T16<Gm, F>::TB - 1) / T16<Gm, F>::TB, b32 = (n + TOWER_ROWS / Gm::P - 1) / (TOWER_ROWS / Gm::P);
-  const long b3 = (n + T16<Gm, F, 3>::TB - 1) / T16<Gm, F, 3>::TB;
-  const double c16 = (double)((b16 + cu - 1) / cu) * T16<Gm, F>::RPAD;
-  double c32 = (double)((b32 + cu - 1) / cu) * TOWER_ROWS;
-  const double c3 = 1.1 * (double)((b3 + cu - 1) / cu) * T16<Gm, F, 3>::RPAD;
-  // 128 filters, several slot groups: the groups' towers fill each other's partial rounds and k_tower's smaller
-  // workgroups pack slightly better (measured 1.10 vs 1.07 M sims/s at 2 x 2048)
-  if (F == 128 && e->ngroups > 1) c32 *= 0.9;
-  if (c3 <= c16 && c3 <= c32) return 3;
-  // paired k_tower16x2: 336 rows = 8 boards per workgroup, no padding rows (+3 % on a 4096-leaf launch).  Only with ONE
-  // slot group: its 92 KB of LDS allow one workgroup per CU, so two groups' towers cannot interleave on a CU and the
-  // other group's heads kernel finds no gaps (measured 3.80 vs 4.11 M sims/s with two groups)
-  if (F == 64 && e->ngroups == 1) {
-    const long b21 = (n + T16P<Gm, 64>::TB - 1) / T16P<Gm, 64>::TB;
-    const double c21 = (double)((b21 + cu - 1) / cu) * T16P<Gm, 64>::RPAD;
-    if (c21 < c16 && c21 < c32) return 21;
+  switch (game) {
+    case AZ_GAME_CONNECT_FOUR: return net_set_kernel_attrs_c4();
+    case AZ_GAME_TICTACTOE: return net_set_kernel_attrs_ttt();
+    case AZ_GAME_MANCALA: return net_set_kernel_attrs_mancala();
   }
-  return c16 <= c32 ? 16 : 32;
+  return fail(AZ_ERR_BAD_ARG, "unknown game id %d", game);
 }
-template <class Gm, int F, bool FROM_PLANES>
-static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
-                        const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
-  constexpr int TB = TOWER_ROWS / Gm::P;
-  const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
-  if (gt == 0) return AZ_OK;
-  constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
-  constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
-  constexpr int TB21 = T16P<Gm, 64>::TB, THR21 = T16P<Gm, 64>::THREADS, LDS21 = T16P<Gm, 64>::BYTES;
-  const int tw = pick_tower<Gm, F>(e, n_max);
-  note_tower(e, tw, F, tw != 32 && e->net16.fuse);
-  const HeadIO io = {Amask, Pout, Vout, Pinv, pstride};
-  if (tw == 21) {
-    if constexpr (F == 64)
-      LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat, io);
-  } else if (tw == 3)
-    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES, 3>), (n_max + TB3 - 1) / TB3, THR16, LDS3, e->net16, envs, eslots, n_ptr, n_max, X, hfeat, io);
-  else if (tw == 16)
-    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES>), (n_max + TB16 - 1) / TB16, THR16, LDS16, e->net16, envs, eslots, n_ptr, n_max, X, hfeat, io);
-  else
-    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, F, FROM_PLANES>), gt, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
-  if (tw != 32 && e->net16.fuse) return AZ_OK;                      // heads16 ran inside the tower kernel
-  if (e->net.hd_ok)
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, F>), (n_max + 31) / 32, 64 * (F / 32 + 1), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
-  else
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads<Gm, F>), gh, 4 * (F + 16), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
-  return AZ_OK;
-}
-// launches tower + heads on `n` boards (device count in n_ptr when given)
-template <class Gm, bool FROM_PLANES>
-static int launch_net(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
-                      const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
-  if (e->cfg.num_filters == 128) return launch_net_f<Gm, 128, FROM_PLANES>(e, st, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
-  return launch_net_f<Gm, 64, FROM_PLANES>(e, st, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
-}
-
 int net_launch(az_engine* e, hipStream_t st, bool from_planes, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr,
                int n_max, const float* X, const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
-  if (from_planes) { DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, true>(e, st, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride)))); }
-  else { DISPATCH_GAME(e->cfg.game, AZCHK((launch_net<Gm, false>(e, st, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride)))); }
-  return AZ_OK;
-}
-
-template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split, int nmax) {
-  constexpr int L = Gm::APAD, TB = TOWER_ROWS / Gm::P;
-  const DView& v = e->gv[g];
-  hipStream_t st = e->gs[g], sn = e->gt[g];
-  const int G = v.G;
-  if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
-  constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
-  constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
-  constexpr int TB21 = T16P<Gm, 64>::TB, THR21 = T16P<Gm, 64>::THREADS, LDS21 = T16P<Gm, 64>::BYTES;
-  // N = upper bound of this wave's leaves: the group's active slots (a draining phase or a partial explore! launches
-  // -- and picks its tower kernel -- for what is left, not for the group's capacity)
-  const int N = std::max(1, std::min(G, nmax));
-  const int tw = pick_tower<Gm, F>(e, N);
-  note_tower(e, tw, F, tw != 32 && e->net16.fuse);
-  const HeadIO io = {nullptr, v.Pout, v.Vout, nullptr, L};
-  if (tw == 21) {
-    if constexpr (F == 64)
-      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g], io);
-  } else if (tw == 3)
-    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, 3>), (N + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g], io);
-  else if (tw == 16)
-    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false>), (N + TB16 - 1) / TB16, THR16, LDS16, e->net16, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g], io);
-  else
-    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower<Gm, F, false>), (N + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g]);
-  if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
-  if (tw != 32 && e->net16.fuse) return AZ_OK;                      // heads16 ran inside the tower kernel
-  if (e->net.hd_ok)
-    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads_mfma<Gm, F>), (N + 31) / 32, 64 * (F / 32 + 1), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
-  else
-    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads<Gm, F>), (N + 3) / 4, 4 * (F + 16), 0, e->net, v.leaf_env, v.eval_slots, v.n_eval, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
-  return AZ_OK;
-}
-template <class Gm> static int wave_net(az_engine* e, int g, bool split, int nmax) {
-  return e->cfg.num_filters == 128 ? wave_net_f<Gm, 128>(e, g, split, nmax) : wave_net_f<Gm, 64>(e, g, split, nmax);
+  switch (e->cfg.game) {
+    case AZ_GAME_CONNECT_FOUR: return net_launch_c4(e, st, from_planes, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
+    case AZ_GAME_TICTACTOE: return net_launch_ttt(e, st, from_planes, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
+    case AZ_GAME_MANCALA: return net_launch_mancala(e, st, from_planes, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
+  }
+  return fail(AZ_ERR_BAD_ARG, "unknown game id %d", e->cfg.game);
 }
 int net_wave(az_engine* e, int g, bool split, int nmax) {
-  DISPATCH_GAME(e->cfg.game, AZCHK((wave_net<Gm>(e, g, split, nmax))));
-  return AZ_OK;
-}
-
-// debug aid (not part of the ABI in azhip.h): s_memtime stamps of one tower launch on n boards
-extern "C" int az_debug_tower_timeline(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
-  ENGINE(e);
-  if (!e->net_loaded || n < 1 || n > e->nn_cap) return fail(AZ_ERR_BAD_ARG, "bad n / no net");
-  if (e->cfg.game != AZ_GAME_CONNECT_FOUR || e->cfg.num_filters != 64) return fail(AZ_ERR_BAD_ARG, "connect-four with 64 filters only");
-  const int nb = (n + 2) / 3;
-  if (cap < (int64_t)nb * 16) return fail(AZ_ERR_CAPACITY, "need %d words", nb * 16);
-  unsigned long long* d = nullptr;
-  AZCHK(dalloc(e, &d, (size_t)nb * 16));
-  std::vector<GEnv> envs(n, ConnectFour::init());
-  HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * n, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->d_ntmp, &n, sizeof(int), hipMemcpyHostToDevice, e->stream));
-  NetDev nd = e->net;
-  for (int rep = 0; rep < 2; ++rep) {
-    nd.dbg = rep ? d : nullptr;
-    hipLaunchKernelGGL((k_tower<ConnectFour, 64, false>), dim3(nb), dim3(TowerCfg<64>::THREADS), TowerLds<64>::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat);
+  switch (e->cfg.game) {
+    case AZ_GAME_CONNECT_FOUR: return net_wave_c4(e, g, split, nmax);
+    case AZ_GAME_TICTACTOE: return net_wave_ttt(e, g, split, nmax);
+    case AZ_GAME_MANCALA: return net_wave_mancala(e, g, split, nmax);
   }
-  HIPCHK(hipMemcpyAsync(out, d, sizeof(unsigned long long) * nb * 16, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  e->allocs.pop_back();
-  (void)hipFree(d);
-  return AZ_OK;
+  return fail(AZ_ERR_BAD_ARG, "unknown game id %d", e->cfg.game);
 }

@@ -395,27 +395,23 @@ k_heads(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
   }
 }
 
-// Dense heads on MFMA.  One 32-board tile per workgroup; wavefront w < F/32 computes value-hidden
-// outputs 32w..32w+31, the last wavefront the (padded) policy logits.  The A operand is the board's
-// head-feature row (K = P*nf values, read as float4 = k 4i..4i+3), the B operand the dense matrix
-// pre-packed per MFMA as (W[4i+h][o], W[4i+2+h][o]) with h = lane >> 5: v_mfma_f32_32x32x2_f32
-// consumes k = 2j (lanes 0-31) then 2j+1 (lanes 32-63), i.e. the ascending-k chain of the contract.
+// Dense heads on MFMA.  One 32-board tile per call; wavefront w < F/32 computes value-hidden
+// outputs 32w..32w+31, wavefront F/32 the (padded) policy logits (further wavefronts only take part in the
+// barrier).  The A operand is the board's head-feature row (K = P*nf values, read as float4 = k 4i..4i+3), the
+// B operand the dense matrix pre-packed per MFMA as (W[4i+h][o], W[4i+2+h][o]) with h = lane >> 5:
+// v_mfma_f32_32x32x2_f32 consumes k = 2j (lanes 0-31) then 2j+1 (lanes 32-63), i.e. the ascending-k chain of the
+// contract.  Called by every thread of a workgroup (k_heads_mfma; the last tower workgroup of a tile group,
+// resnet16.h); s_vh [32][F + 1] and s_logit [32][16] are LDS scratch.
 template <class Gm, int F>
-__global__ void __launch_bounds__(64 * (F / 32 + 1))
-k_heads_mfma(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
-             const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ Amask,
-             const float* __restrict__ hfeat, float* __restrict__ Pout, float* __restrict__ Vout,
-             float* __restrict__ Pinv, int pstride) {
-  constexpr int P = Gm::P, A = Gm::A, NVT = F / 32;
-  __builtin_amdgcn_s_setprio(3);   // few workgroups on the critical path of the group's next wave
-  __shared__ float s_vh[32][F + 1];
-  __shared__ float s_logit[32][16];
-  const int n = n_eval_ptr ? *n_eval_ptr : n_fixed;
-  const int board0 = blockIdx.x * 32;
-  if (board0 >= n) return;
+__device__ __forceinline__ void heads_mfma_tile(const NetDev& net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+                                                int n, const float* __restrict__ Amask, const float* __restrict__ hfeat,
+                                                float* __restrict__ Pout, float* __restrict__ Vout, float* __restrict__ Pinv, int pstride,
+                                                int board0, float* __restrict__ s_vh, float* __restrict__ s_logit) {
+  constexpr int P = Gm::P, A = Gm::A, NVT = F / 32, SV = F + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
   const int HF = net.HF;
   const bool is_pol = wave == NVT;
+  if (wave <= NVT) {
   const int nf = is_pol ? net.npf : net.nvf, foff = is_pol ? 0 : net.npf;
   int e = board0 + (lane & 31);
   if (e >= n) e = n - 1;                         // clamp: rows past the batch are computed and dropped
@@ -470,25 +466,26 @@ k_heads_mfma(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restric
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (is_pol) { if (col < A) s_logit[row][col] = acc[r] + net.pol_b[col]; }
+    if (is_pol) { if (col < A) s_logit[row * 16 + col] = acc[r] + net.pol_b[col]; }
     else {
       const int o = wave * 32 + col;
       const float v = acc[r] + net.val_b[o];
-      s_vh[row][o] = v > 0.0f ? v : 0.0f;
+      s_vh[row * SV + o] = v > 0.0f ? v : 0.0f;
     }
+  }
   }
   __syncthreads();
   const int b = threadIdx.x;
   if (b < 32 && board0 + b < n) {
-    e = board0 + b;
+    const int e = board0 + b;
     float pr[A];
-    float mx = s_logit[b][0];
-    for (int a = 1; a < A; ++a) mx = s_logit[b][a] > mx ? s_logit[b][a] : mx;
+    float mx = s_logit[b * 16];
+    for (int a = 1; a < A; ++a) mx = s_logit[b * 16 + a] > mx ? s_logit[b * 16 + a] : mx;
     float s = 0.0f;
-    for (int a = 0; a < A; ++a) { pr[a] = az_expf(s_logit[b][a] - mx); s += pr[a]; }
+    for (int a = 0; a < A; ++a) { pr[a] = az_expf(s_logit[b * 16 + a] - mx); s += pr[a]; }
     for (int a = 0; a < A; ++a) pr[a] = pr[a] / s;
     float av = 0.0f;
-    for (int k = 0; k < F; ++k) av = az_fmaf(s_vh[b][k], net.val2_w[k], av);
+    for (int k = 0; k < F; ++k) av = az_fmaf(s_vh[b * SV + k], net.val2_w[k], av);
     av = av + net.val2_b;
     const float val = az_tanhf(av);
     float sp = 0.0f;
@@ -504,4 +501,18 @@ k_heads_mfma(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restric
     Vout[e] = val;
     if (Pinv) Pinv[e] = 1.0f - sp;
   }
+}
+template <class Gm, int F>
+__global__ void __launch_bounds__(64 * (F / 32 + 1))
+k_heads_mfma(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+             const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ Amask,
+             const float* __restrict__ hfeat, float* __restrict__ Pout, float* __restrict__ Vout,
+             float* __restrict__ Pinv, int pstride) {
+  __builtin_amdgcn_s_setprio(3);   // few workgroups on the critical path of the group's next wave
+  __shared__ float s_vh[32 * (F + 1)];
+  __shared__ float s_logit[32 * 16];
+  const int n = n_eval_ptr ? *n_eval_ptr : n_fixed;
+  const int board0 = blockIdx.x * 32;
+  if (board0 >= n) return;
+  heads_mfma_tile<Gm, F>(net, leaf_env, eval_slots, n, Amask, hfeat, Pout, Vout, Pinv, pstride, board0, s_vh, s_logit);
 }

@@ -32,25 +32,8 @@ struct Net16Dev {
   const float* conv_ss;     // [2*nblocks][2][64]
   const float4* head_w;     // [4 col tiles][4][64] float4
   const float* head_ss;     // [2][64]
-  // dense heads fused into the tower (fuse = 1: head widths are multiples of 4): 16x16x4 B fragments of the value
-  // matrix (F/16 column tiles) followed by the policy matrix (one tile), per tile [ceil(K/16)][64] float4 where lane l
-  // of group s holds W[k = 4 (4 s + j) + (l >> 4)][o = 16 tile + (l & 15)] for j = 0..3 (zero past K / past A)
-  const float4* hd16_w;
-  const float* pol_b;       // [APAD]
-  const float* val_b;       // [F]
-  const float* val2_w;      // [F]
-  float val2_b;
-  int npf, nvf, fuse;
+  unsigned long long* dbg;  // optional [workgroups][8] s_memtime stamps (az_debug_tower_timeline): start, stem, tower, head conv + features, end
 };
-// where the fused heads read the availability masks and write forward_normalized's outputs
-struct HeadIO {
-  const float* Amask;       // [n][A] or nullptr (mask from the leaf state)
-  float* P;                 // [n][pstride]
-  float* V;                 // [n]
-  float* Pinv;              // [n] or nullptr
-  int pstride;
-};
-
 // NT = row tiles per workgroup: 11 (throughput: 4 Connect-Four boards, 2 workgroups per CU at 64 filters) or 3
 // (latency: ONE Connect-Four board per workgroup, so a small batch spreads over 4x as many CUs and the
 // sequential layer chain of a workgroup is 3.7x shorter -- the reference's 128-worker configurations).
@@ -61,8 +44,7 @@ template <class Gm, int F = 64, int NT = 11> struct T16 {
   static constexpr int STRIDE = F + 4;
   static constexpr int BUF = (RPAD + 1) * STRIDE;    // row RPAD = zeros
   static constexpr int PLANES = (RPAD + 1) * Gm::C;
-  static constexpr int HEADX = TB * (F + 1 + 16);    // fused dense heads: value-hidden units [TB][F + 1] and logits [TB][16]
-  static constexpr int BYTES = (BUF + PLANES + HEADX) * 4;   // 52 KB at F = 64 (2 workgroups per CU), 98 KB at F = 128 (1)
+  static constexpr int BYTES = (BUF + PLANES) * 4;   // 50 KB at F = 64 (2 workgroups per CU), 96 KB at F = 128 (1)
   static constexpr int WAVES = F / 16, THREADS = 64 * WAVES;
   static constexpr int CT = F / 16;                  // channel tiles of 16 = wavefronts per row-tile set
   static constexpr int KH = F / 64;                  // 64-channel halves of a tap (one pipeline step each)
@@ -81,8 +63,7 @@ template <class Gm, int F = 64> struct T16P {
   static constexpr int STRIDE = F + 4;
   static constexpr int BUF = (RPAD + 1) * STRIDE;
   static constexpr int PLANES = (RPAD + 1) * Gm::C;
-  static constexpr int HEADX = TB * (F + 1 + 16);
-  static constexpr int BYTES = (BUF + PLANES + HEADX) * 4;
+  static constexpr int BYTES = (BUF + PLANES) * 4;
   static constexpr int CT = F / 16, WAVES = 2 * CT, THREADS = 64 * WAVES;
   static constexpr int KH = F / 64, SQ = F / 16;
   using Game = Gm;
@@ -188,6 +169,9 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
   using Gm = typename T::Game;
   constexpr int F = T::FILT, P = Gm::P, W = Gm::W, H = Gm::H, C = Gm::C, TB = T::TB, STRIDE = T::STRIDE, R0 = TILE0 * 16;
   const int lrow = lane & 15, g = lane >> 4;
+  unsigned long long* dbg = (net.dbg && threadIdx.x == 0) ? net.dbg + (size_t)blockIdx.x * 8 : nullptr;
+#define AZ_STAMP16(i) do { if (dbg) dbg[i] = __builtin_readcyclecounter(); } while (0)
+  AZ_STAMP16(0);
   // validity of the 9 taps for this lane's row of every tile
   uint32_t vm[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -240,6 +224,7 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
       }
   }
   __syncthreads();
+  AZ_STAMP16(1);
 
   // ---- residual tower ---------------------------------------------------------------------------------
   float xres[NT][4];
@@ -279,32 +264,19 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
   }
+  AZ_STAMP16(2);
   // ---- both 1x1 head convolutions + BN + ReLU as one 64 => 64 GEMM ------------------------------------
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
   conv16<T, NT, 1>(buf, net.head_w + (size_t)cw * T::SQ * 64 + lane, acc, vm, lrow + R0, g);
   {
     const float sc = net.head_ss[ch], sh = net.head_ss[F + ch];
-    if (net.fuse) {
-      // head features stay in LDS for heads16: row = board * P + position; head filter f of the policy (value) head
-      // at column (f & 3) * (nf / 4) + (f >> 2) (+ npf), so that the 4 features a lane feeds to 4 successive MFMAs
-      // of the dense chain (k = 4 i + g) are one ds_read_b128
-      const int npf = net.npf, nvf = net.nvf;
-      int hcol = -1;
-      if (ch < npf) hcol = (ch & 3) * (npf >> 2) + (ch >> 2);
-      else if (ch < npf + nvf) hcol = npf + ((ch - npf) & 3) * (nvf >> 2) + ((ch - npf) >> 2);
-      __syncthreads();                               // every wave has finished reading the tower's output
-      if (hcol >= 0) {
-#pragma unroll
-        for (int tile = 0; tile < NT; ++tile)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float v = az_fmaf(acc[tile][i], sc, sh);
-            buf[(R0 + tile * 16 + g * 4 + i) * STRIDE + hcol] = v > 0.0f ? v : 0.0f;
-          }
-      }
-    } else {
-      // head features straight from the accumulators to HBM, [board][P][64] in natural channel order (k_heads)
+    {
+      // head features straight from the accumulators to HBM / L2, [board][P][64] in natural channel order.  (The dense
+      // heads stay a separate launch with 32-board MFMA tiles: computing them here per workgroup -- tried on MFMA and on
+      // the vector ALU, from LDS-resident features -- makes each of the 1024 workgroups stream the 382 KB of dense
+      // weights through L2, 65 us per 4096-board launch against 41 us for k_heads_mfma; handing a 32-board tile to the
+      // last of 8 workgroups needs device-scope fences across XCDs and cost 190 us.  DESIGN.md §4.)
       const int nb = (n - board0) < TB ? (n - board0) : TB;
 #pragma unroll
       for (int tile = 0; tile < NT; ++tile)
@@ -316,111 +288,8 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
         }
     }
   }
-}
-
-// Dense heads + softmax / tanh + Network.forward_normalized (resnet.jl:82-84,88-90; network.jl:264-271) on the head
-// features tower16_wave left in LDS, by the whole workgroup: the boards of the buffer are the M rows of
-// v_mfma_f32_16x16x4_f32 (MT = ceil(TB / 16) row tiles; with Connect-Four's 4 boards 12 of the 16 rows idle, which costs
-// 1 % of the tower's MFMA time), column tile j < F/16 = value-hidden units 16 j .. 16 j + 15, tile F/16 = the policy
-// logits; tile-jobs go round-robin over the wavefronts.  Each output is the ascending-k chain of the fp32 contract
-// (k = position * nf + filter: MFMA step i feeds k = 4 i + (lane >> 4)).  The caller synchronises before the call.
-template <class T>
-__device__ __forceinline__ void heads16(const Net16Dev& net, const float* __restrict__ buf, float* __restrict__ s_vh,
-                                        float* __restrict__ s_logit, int n, int board0, const HeadIO& io,
-                                        const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots) {
-  using Gm = typename T::Game;
-  constexpr int F = T::FILT, P = Gm::P, A = Gm::A, TB = T::TB, STRIDE = T::STRIDE, NW = T::THREADS / 64;
-  constexpr int MT = (TB + 15) / 16, NVT = F / 16, NJ = NVT + 1, SV = F + 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lrow = lane & 15, g = lane >> 4;
-  const int npf = net.npf, nvf = net.nvf;
-  const int vgroups = (P * nvf / 4 + 3) / 4;                       // float4 groups of the value matrix per tile
-  for (int job = wave; job < NJ; job += NW) {
-    const bool is_pol = job == NVT;
-    const int nf = is_pol ? npf : nvf, foff = is_pol ? 0 : npf, nq = nf >> 2;
-    const float4* wp = net.hd16_w + (size_t)job * vgroups * 64 + lane;   // the policy tile follows the NVT value tiles
-    f32x4v acc[MT];
-    int rb[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      acc[mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      const int b = (mt * 16 + lrow) < TB ? (mt * 16 + lrow) : TB - 1;   // rows past the buffer's boards: computed, dropped
-      rb[mt] = b * P * STRIDE + foff + g * nq;
-    }
-    if ((nf & 15) == 0) {
-      const int hq = nf >> 4;                                       // groups of 4 steps per board position
-      for (int q = 0; q < P; ++q)
-        for (int h = 0; h < hq; ++h) {
-          const float4 b4 = wp[(size_t)(q * hq + h) * 64];
-          float4 a4[MT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a4[mt] = *(const float4*)(buf + rb[mt] + q * STRIDE + 4 * h);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt].x, b4.x, acc[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt].y, b4.y, acc[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt].z, b4.z, acc[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt].w, b4.w, acc[mt], 0, 0, 0);
-        }
-    } else {
-      const int steps = P * nq, ngr = (steps + 3) / 4;              // the fragments are zero past `steps`
-      for (int s4 = 0; s4 < ngr; ++s4) {
-        const float4 b4 = wp[(size_t)s4 * 64];
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = (4 * s4 + j) < steps ? (4 * s4 + j) : steps - 1;
-          const int q = i / nq, r = i % nq;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[rb[mt] + q * STRIDE + r], bb[j], acc[mt], 0, 0, 0);
-        }
-      }
-    }
-    // D layout: row (board) = 4 g + i, column (output) = lrow
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int b = mt * 16 + g * 4 + i;
-        if (b < TB) {
-          if (is_pol) { if (lrow < A) s_logit[b * 16 + lrow] = acc[mt][i] + net.pol_b[lrow]; }
-          else {
-            const int o = job * 16 + lrow;
-            const float v = acc[mt][i] + net.val_b[o];
-            s_vh[b * SV + o] = v > 0.0f ? v : 0.0f;                // Dense(P*nvf => F, relu), resnet.jl:89
-          }
-        }
-      }
-  }
-  __syncthreads();
-  const int b = threadIdx.x;
-  if (b < TB && board0 + b < n) {
-    const int e = board0 + b;
-    float pr[A];
-    float mx = s_logit[b * 16];
-    for (int a = 1; a < A; ++a) mx = s_logit[b * 16 + a] > mx ? s_logit[b * 16 + a] : mx;
-    float s = 0.0f;
-    for (int a = 0; a < A; ++a) { pr[a] = az_expf(s_logit[b * 16 + a] - mx); s += pr[a]; }
-    for (int a = 0; a < A; ++a) pr[a] = pr[a] / s;                 // softmax, resnet.jl:84
-    float av = 0.0f;
-    for (int k = 0; k < F; ++k) av = az_fmaf(s_vh[b * SV + k], net.val2_w[k], av);
-    av = av + net.val2_b;
-    const float val = az_tanhf(av);                                // Dense(F => 1, tanh), resnet.jl:90
-    float sp = 0.0f;                                               // forward_normalized, network.jl:264-271
-    for (int a = 0; a < A; ++a) {
-      float mk;
-      if (io.Amask) mk = io.Amask[(size_t)e * A + a];
-      else mk = (float)((Gm::mask(leaf_env[eval_slots[e]]) >> a) & 1);
-      pr[a] = pr[a] * mk;
-      sp += pr[a];
-    }
-    for (int a = 0; a < A; ++a) io.P[(size_t)e * io.pstride + a] = pr[a] / (sp + 1.1920929e-7f);
-    for (int a = A; a < io.pstride; ++a) io.P[(size_t)e * io.pstride + a] = 0.0f;
-    io.V[e] = val;
-    if (io.Pinv) io.Pinv[e] = 1.0f - sp;
-  }
+  AZ_STAMP16(3);
+#undef AZ_STAMP16
 }
 
 // input planes [RPAD + 1][C] and the zero row of the activation buffer, by all threads of the workgroup
@@ -445,7 +314,7 @@ __device__ __forceinline__ void tower16_fill(float* __restrict__ buf, float* __r
 template <class Gm, int F, bool FROM_PLANES, int NT = 11>
 __global__ void __launch_bounds__(T16Threads<F>::V, 2)
 k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
-          const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat, HeadIO io) {
+          const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
   using T = T16<Gm, F, NT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
@@ -456,18 +325,14 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   tower16_fill<T, FROM_PLANES>(buf, planes, leaf_env, eval_slots, X, n, board0, threadIdx.x);
   __syncthreads();
   tower16_wave<T, FROM_PLANES, NT, 0>(net, buf, planes, threadIdx.x >> 6, threadIdx.x & 63, n, board0, hfeat);
-  if (net.fuse) {
-    __syncthreads();
-    float* s_vh = planes + T::PLANES;
-    heads16<T>(net, buf, s_vh, s_vh + T::TB * (F + 1), n, board0, io, leaf_env, eval_slots);
-  }
+  if (net.dbg && threadIdx.x == 0) net.dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_readcyclecounter();
 }
 
 // The paired form (T16P): wavefronts 0..CT-1 run tiles 0..10, wavefronts CT..2CT-1 tiles 11..20 of ONE buffer.
 template <class Gm, int F, bool FROM_PLANES>
 __global__ void __launch_bounds__(2 * T16Threads<F>::V, 1)
 k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
-            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat, HeadIO io) {
+            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
   using T = T16P<Gm, F>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
@@ -480,11 +345,7 @@ k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restri
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave < T::CT) tower16_wave<T, FROM_PLANES, T::NT0, 0>(net, buf, planes, wave, lane, n, board0, hfeat);
   else tower16_wave<T, FROM_PLANES, T::NT1, T::NT0>(net, buf, planes, wave - T::CT, lane, n, board0, hfeat);
-  if (net.fuse) {
-    __syncthreads();
-    float* s_vh = planes + T::PLANES;
-    heads16<T>(net, buf, s_vh, s_vh + T::TB * (F + 1), n, board0, io, leaf_env, eval_slots);
-  }
+  if (net.dbg && threadIdx.x == 0) net.dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_readcyclecounter();
 }
 
 // One 3x3 F -> F convolution as a stand-alone layer (HBM -> HBM), for the optimiser step (train.h): forward

@@ -4,12 +4,19 @@
 // Layout in HBM (one engine = G game slots, every array is slot-major):
 //   nodes  [G][cap][NODE_BYTES]   one record per stored state (the reference's StateInfo +
 //                                 Vector{ActionStats}, src/mcts.jl:78-87), full action width:
-//                                   +0 key a,b (16 B)   +16 N i32[A]   then P f32[A]   then W f64[A]
+//                                   N i32[A] | P f32[A] | W f64[A] | child links (18 bit per action)
 //                                 (128 B for 7 actions: one cache line per visit);  vest [G][cap] f32
+//   keys   [G][cap][2] u64        the state of every node (only hash probes read it)
 //   ht     [G][H] u64             the Dict{State,StateInfo} of src/mcts.jl:126 as an open-addressed
 //                                 table: epoch(16) | tag(16) | node index+1 (32); an entry is live
 //                                 only if its epoch equals the slot's epoch, so MCTS.reset! is O(1)
 //   path   [G][max_depth] u64     explicit stack replacing the recursion of run_simulation!
+//
+// Child links.  tree[state] is a pure function of the state for as long as the tree is not reset, so the node a
+// (node, action) edge leads to is memoised in the parent's record the first time the Dict lookup answers it (at
+// expansion, or when a probe finds a transposition).  A descent then costs ONE dependent 128-byte load per ply; the
+// hash table is probed only on edges never taken before.  Results cannot change: a link is the answer the probe
+// would give (tests compare every visit count with the oracle's Dict walk).
 //
 // Thread mapping: APAD lanes per slot (8 for 7/6 actions, 16 for 9), lane a owns action a.  A
 // 64-wide wavefront therefore advances 8 (or 4) slots; N/P/W rows are read as one coalesced
@@ -17,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/az_numerics.h"
 #include "../../include/azhip.h"
 #include "games.h"
@@ -47,6 +55,8 @@ struct DView {
   double* eta;            // [G][APAD] by full action index
   unsigned long long* ht;
   char* nodes;
+  unsigned long long* keys; // [G][cap][2] state of every node
+  int* root_idx;          // [G] node index of the slot's current root, -1 = not looked up yet this move
   float* vest;            // [G][cap] StateInfo.Vest (src/mcts.jl:86), off the hot path
   unsigned long long* path;
   int* leaf_kind;
@@ -55,8 +65,7 @@ struct DView {
   uint32_t* leaf_ins;
   int* eidx;              // slot -> index in the evaluation batch
   int* eval_slots;        // evaluation batch -> slot
-  int* n_eval;            // device scalar
-  int* chunk_cnt;         // [ceil(G/1024)] new leaves per 1024-slot chunk (compaction)
+  int* n_eval;            // [2] leaves of the wave, double-buffered by wave parity (k_tree zeroes the other one)
   float* Pout;            // [n_eval][APAD] masked-normalised priors, full width
   float* Vout;            // [n_eval]
   az_move_rec* trace;     // [G][max_moves]
@@ -66,15 +75,21 @@ struct DView {
   long long* stat;        // [0] simulations [1] nodes traversed [2] leaf evals [3] moves
 };
 
-// Node record: key (16 B) | N i32[A] | P f32[A] | W f64[A], padded to a multiple of 32 B.  With A = 7 that is
-// exactly 128 B = ONE cache line per visited node (Connect-Four; 128 B for Mancala's A = 6, 160 B for A = 9).
-// Vest (only read by the explorer hook) lives in a side array; the availability mask is recomputed from the
-// state in registers.
+// Node record: N i32[A] | P f32[A] | W f64[A] | LO u16[A] | HI, padded to a multiple of 32 B.  With A = 7 that is
+// exactly 128 B = ONE cache line per visited node (Connect-Four; 128 B for Mancala's A = 6, 192 B for A = 9).
+// Child link of action a = LO[a] | ((HI >> 2a) & 3) << 16 = 1 + node index of the state the action leads to, 0 =
+// not known yet (18 bits: pools above LINK_MAX nodes per slot simply never write links and always probe).
+// Vest (only read by the explorer hook) and the state keys live in side arrays; the availability mask is recomputed
+// from the state in registers.
 template <class Gm> struct NodeL {
   static constexpr int A = Gm::A;
-  static constexpr int OFF_N = 16, OFF_P = 16 + 4 * A, OFF_W = (16 + 8 * A + 7) / 8 * 8;
-  static constexpr int BYTES = (OFF_W + 8 * A + 31) / 32 * 32;
+  static constexpr int OFF_N = 0, OFF_P = 4 * A, OFF_W = (8 * A + 7) / 8 * 8, OFF_LO = OFF_W + 8 * A;
+  static constexpr int HI_BYTES = A <= 8 ? 2 : 4;
+  static constexpr int OFF_HI = (OFF_LO + 2 * A + HI_BYTES - 1) / HI_BYTES * HI_BYTES;
+  static constexpr int BYTES = (OFF_HI + HI_BYTES + 31) / 32 * 32;
+  using hi_t = typename std::conditional<A <= 8, uint16_t, uint32_t>::type;
 };
+static constexpr int LINK_MAX = (1 << 18) - 2;
 
 __device__ inline void dev_fail(const DView& v, int code) { atomicCAS(v.err, 0, code); }
 
@@ -107,13 +122,12 @@ template <class Gm>
 __device__ inline int ht_lookup(const DView& v, int slot, int lane, unsigned long long ka,
                                 unsigned long long kb, uint32_t epoch, uint32_t* ins) {
   constexpr int L = Gm::APAD;
-  constexpr int NB = NodeL<Gm>::BYTES;
   const unsigned long long hk = az_hash_key(ka, kb);
   const uint32_t H1 = (uint32_t)v.ht_size - 1;
   const uint32_t h0 = (uint32_t)hk & H1;
   const uint32_t tag = (uint32_t)(hk >> 40) & 0xffff;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
-  const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NB;
+  const unsigned long long* keys = v.keys + (size_t)slot * v.cap_nodes * 2;
   const int iters = v.ht_size / L;
   for (int i = 0; i < iters; ++i) {
     uint32_t pos = (h0 + (uint32_t)(i * L + lane)) & H1;
@@ -122,7 +136,7 @@ __device__ inline int ht_lookup(const DView& v, int slot, int lane, unsigned lon
     bool live = ((uint32_t)(e >> 48) == epoch) && idx1 != 0;
     bool match = false;
     if (live && ((uint32_t)(e >> 32) & 0xffff) == tag) {
-      const unsigned long long* k = (const unsigned long long*)(pool + (size_t)(idx1 - 1) * NB);
+      const unsigned long long* k = keys + (size_t)(idx1 - 1) * 2;
       match = (k[0] == ka) && (k[1] == kb);
     }
     unsigned mb = group_ballot<L>(match), db = group_ballot<L>(!live);
@@ -155,121 +169,217 @@ __device__ inline void arm_noise(const DView& v, const DParams& p, int slot, con
   }
 }
 
+// write the child link of (node, act): lane-0 work of a slot's lane group
+template <class Gm> __device__ inline void set_link(char* nd, int act, uint32_t link) {
+  using NL = NodeL<Gm>;
+  ((uint16_t*)(nd + NL::OFF_LO))[act] = (uint16_t)(link & 0xffff);
+  typename NL::hi_t* hp = (typename NL::hi_t*)(nd + NL::OFF_HI);
+  *hp = (typename NL::hi_t)((*hp & ~((typename NL::hi_t)3 << (2 * act))) | ((typename NL::hi_t)(link >> 16) << (2 * act)));
+}
+
 // =========================================================================================
-// select: the descent of run_simulation! (src/mcts.jl:199-226) until a miss or a terminal state
+// k_tree: ONE kernel per search wave and slot group.
+//   phase A (do_backup): the second half of the previous wave's run_simulation! -- init_state_info for the new leaf
+//           with the oracle's answer (mcts.jl:157-161, util.jl:98-110), update_state_info! along the path
+//           (mcts.jl:190-194, 218-223)
+//   phase B (do_select): the descent of this wave's run_simulation! (mcts.jl:199-217) until an unseen or a terminal
+//           state, and the compaction of the new leaves into the evaluation batch (Batchifier.launch_server,
+//           batchifier.jl:47-81; the batch order is arbitrary -- test-mode evaluations are independent, Appendix A.13)
+// The network runs between two launches; the last simulation of an explore! is completed by a launch with do_select = 0.
+// APAD lanes per slot (lane = action).  Dependent loads: phase A path -> statistics of the path's nodes (all at once,
+// one lane per ply); phase B one node record per ply (child links), a table probe only on edges never taken before.
 // =========================================================================================
 template <class Gm>
-__global__ void __launch_bounds__(256) k_select(DView v, DParams p) {
+__global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_backup, int do_select, int par) {   // 8 waves per SIMD = 64 VGPRs: fits beside two tower waves (2 x 224)
   __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   constexpr int L = Gm::APAD;
   using NL = NodeL<Gm>;
+  __shared__ int s_new[4], s_sims[4], s_trav[4], s_base;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int slot = tid / L, lane = tid % L;
-  if (slot >= v.G) return;
-  if (!v.active[slot]) { if (lane == 0) v.leaf_kind[slot] = LEAF_NONE; return; }
-  GEnv env = v.root[slot];
-  const uint32_t epoch = v.epoch[slot];
-  const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
-  unsigned long long* path = v.path + (size_t)slot * v.max_depth;
-  int depth = 0, kind = LEAF_NONE;
-  uint32_t ins = 0;
-  for (;;) {
-    if (env.fin & 1) { kind = LEAF_TERMINAL; break; }             // mcts.jl:200-201
-    int idx = ht_lookup<Gm>(v, slot, lane, env.a, env.b, epoch, &ins);
-    if (idx < 0) { kind = LEAF_NEW; break; }                      // mcts.jl:205-207
-    if (depth >= v.max_depth) { dev_fail(v, DERR_DEPTH); kind = LEAF_NONE; break; }
-    const char* nd = pool + (size_t)idx * NL::BYTES;
-    const uint32_t amask = Gm::mask(env);
-    const bool inrec = lane < Gm::A;
-    const int N = inrec ? ((const int*)(nd + NL::OFF_N))[lane] : 0;
-    const float Pf = inrec ? ((const float*)(nd + NL::OFF_P))[lane] : 0.0f;
-    const double W = inrec ? ((const double*)(nd + NL::OFF_W))[lane] : 0.0;
-    // uct_scores (mcts.jl:180-188): Float64, evaluated left to right
-    const int Ntot = group_sum<L>(N);
-    const double sqrtNtot = __builtin_sqrt((double)Ntot);
-    const double Q = W / (double)(N > 1 ? N : 1);
-    double Pd = (double)Pf;
-    if (depth == 0 && p.eps != 0.0) Pd = (1.0 - p.eps) * Pd + p.eps * v.eta[(size_t)slot * L + lane];
-    double sc = Q + p.cpuct * Pd * sqrtNtot / (double)(N + 1);
-    if (!((amask >> lane) & 1)) sc = -__builtin_inf();
-    const int act = group_argmax<L>(sc, lane);
-    const bool wp = Gm::white_playing(env);
-    Gm::play(env, act);                                           // mcts.jl:213-217
-    const float wr = Gm::white_reward(env);
-    const int r = (int)(wp ? wr : -wr);
-    const bool psw = wp != Gm::white_playing(env);
-    if (lane == 0)
-      path[depth] = (unsigned long long)(uint32_t)idx | ((unsigned long long)act << 32) |
-                    ((unsigned long long)(psw ? 1 : 0) << 40) | ((unsigned long long)(r + 1) << 41);
-    depth++;
-  }
-  if (lane == 0) {
-    v.leaf_kind[slot] = kind;
-    v.leaf_depth[slot] = depth;
-    v.leaf_env[slot] = env;
-    v.leaf_ins[slot] = ins;
-  }
-}
+  const int wl = threadIdx.x & 63, w = threadIdx.x >> 6, gbase = wl & ~(L - 1);
+  const bool live = slot < v.G;
+  char* pool = v.nodes + (size_t)(live ? slot : 0) * v.cap_nodes * NL::BYTES;
+  unsigned long long* path = v.path + (size_t)(live ? slot : 0) * v.max_depth;
+  const bool links_ok = v.cap_nodes <= LINK_MAX;
 
-// Compaction of the slots whose simulation ended on an unseen state -> evaluation batch in ascending slot
-// order (what Batchifier.launch_server collects, src/batchifier.jl:47-81).  Two passes over 1024-slot chunks so
-// that it scales to any slot count: k_compact_count leaves each slot's rank inside its chunk in eidx[] and the
-// chunk total in chunk_cnt[]; k_compact_assign adds the totals of the chunks before it.
-static __global__ void __launch_bounds__(1024) k_compact_count(DView v) {
-  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
-  __shared__ int wsum[16], wsims[16], wtrav[16];
-  const int s = blockIdx.x * 1024 + threadIdx.x;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int kind = s < v.G ? v.leaf_kind[s] : LEAF_NONE;
-  const bool isnew = kind == LEAF_NEW;
-  const unsigned long long bal = __ballot(isnew);
-  const int rank = __popcll(bal & ((1ULL << lane) - 1ULL));
-  // statistics of the wave: simulations (src/mcts.jl:242) and traversed nodes (src/mcts.jl:222)
-  int sims = kind != LEAF_NONE ? 1 : 0, trav = kind != LEAF_NONE ? v.leaf_depth[s] : 0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { sims += __shfl_down(sims, o); trav += __shfl_down(trav, o); }
-  if (lane == 0) { wsum[w] = __popcll(bal); wsims[w] = sims; wtrav[w] = trav; }
-  __syncthreads();
-  int base = 0;
-  for (int i = 0; i < w; ++i) base += wsum[i];
-  if (s < v.G) v.eidx[s] = isnew ? base + rank : -1;
-  if (threadIdx.x == 0) {
-    int tot = 0, ts = 0, tt = 0;
-    for (int i = 0; i < 16; ++i) { tot += wsum[i]; ts += wsims[i]; tt += wtrav[i]; }
-    v.chunk_cnt[blockIdx.x] = tot;
-    if (ts) {                                   // one atomic pair per 1024 slots
-      atomicAdd((unsigned long long*)&v.stat[0], (unsigned long long)ts);
-      atomicAdd((unsigned long long*)&v.stat[1], (unsigned long long)tt);
+  // ------------------------------------------------------------------ phase A: expand + backup
+  if (do_backup && live) {
+    const int kind = v.leaf_kind[slot];
+    if (kind != LEAF_NONE) {
+      const int depth = v.leaf_depth[slot];
+      double q = 0.0;                                               // terminal: return 0.
+      bool ok = true;
+      if (kind == LEAF_NEW) {
+        const int e = v.eidx[slot];
+        const int idx = v.node_count[slot];
+        if (idx >= v.cap_nodes) { dev_fail(v, DERR_NODE_POOL); ok = false; }
+        else {
+          const GEnv env = v.leaf_env[slot];
+          const uint32_t m = Gm::mask(env);
+          float Pf = v.Pout[(size_t)e * L + lane];
+          const float V = v.Vout[e];
+          if (p.prior_temp != 1.0) {                                // Util.apply_temperature, util.jl:98-110
+            const bool av = (m >> lane) & 1;
+            double res;
+            if (p.prior_temp == 0.0) {
+              int am = group_argmax<L>(av ? (double)Pf : -__builtin_inf(), lane);
+              res = (lane == am) ? 1.0 : 0.0;
+            } else {
+              double pw = av ? az_pow((double)Pf, 1.0 / p.prior_temp) : 0.0;
+              double sm = 0.0;
+              for (int a = 0; a < Gm::A; ++a) { double t = __shfl(pw, gbase + a); if ((m >> a) & 1) sm += t; }
+              res = pw / sm;
+            }
+            Pf = av ? (float)res : 0.f;
+          }
+          char* nd = pool + (size_t)idx * NL::BYTES;
+          if (lane < Gm::A) {
+            ((int*)(nd + NL::OFF_N))[lane] = 0;
+            ((float*)(nd + NL::OFF_P))[lane] = Pf;
+            ((double*)(nd + NL::OFF_W))[lane] = 0.0;
+            ((uint16_t*)(nd + NL::OFF_LO))[lane] = 0;
+          }
+          if (lane == 0) {
+            *(typename NL::hi_t*)(nd + NL::OFF_HI) = 0;
+            unsigned long long* kk = v.keys + ((size_t)slot * v.cap_nodes + idx) * 2;
+            kk[0] = env.a; kk[1] = env.b;
+            v.vest[(size_t)slot * v.cap_nodes + idx] = V;
+            const unsigned long long hk = az_hash_key(env.a, env.b);
+            const unsigned long long tag = (hk >> 40) & 0xffff;
+            v.ht[(size_t)slot * v.ht_size + v.leaf_ins[slot]] =
+                ((unsigned long long)v.epoch[slot] << 48) | (tag << 32) | (unsigned long long)(idx + 1);
+            v.node_count[slot] = idx + 1;
+            if (depth == 0) v.root_idx[slot] = idx;
+            else if (links_ok) {                                    // memoise tree[state] on the edge that reached it
+              const unsigned long long st = path[depth - 1];
+              set_link<Gm>(pool + (size_t)(uint32_t)st * NL::BYTES, (int)((st >> 32) & 0xff), (uint32_t)(idx + 1));
+            }
+          }
+          q = (double)V;                                            // return info.Vest
+        }
+      }
+      if (ok) {
+        // unwinding (mcts.jl:218-223): q_k = r_k + gamma * (pswitch_k ? -q_{k+1} : q_{k+1}); the chain is register
+        // arithmetic on shuffled path entries, the read-modify-writes of a chunk of L plies go out together
+        for (int c = (depth - 1) / L; c >= 0 && depth > 0; --c) {
+          const int k0 = c * L, kn = (depth - k0) < L ? (depth - k0) : L;
+          const unsigned long long st = lane < kn ? path[k0 + lane] : 0ULL;
+          double qmine = 0.0;
+          for (int k = kn - 1; k >= 0; --k) {
+            const unsigned long long sk = __shfl(st, gbase + k);
+            const bool psw = (sk >> 40) & 1;
+            const double r = (double)((int)((sk >> 41) & 3) - 1);
+            q = psw ? -q : q;
+            q = r + p.gamma * q;                                    // mcts.jl:219-220
+            if (lane == k) qmine = q;
+          }
+          if (lane < kn) {
+            char* nd = pool + (size_t)(uint32_t)st * NL::BYTES;
+            const int act = (int)((st >> 32) & 0xff);
+            ((double*)(nd + NL::OFF_W))[act] += qmine;              // update_state_info!, mcts.jl:190-194
+            ((int*)(nd + NL::OFF_N))[act] += 1;
+          }
+        }
+        if (lane == 0) {
+          v.tot_trav[slot] += depth;                                // mcts.jl:222
+          v.tot_sims[slot] += 1;                                    // mcts.jl:242
+        }
+      }
+    }
+    if (!do_select && lane == 0) v.leaf_kind[slot] = LEAF_NONE;     // the pending simulation has been completed
+  }
+  if (!do_select) return;
+  __threadfence_block();            // phase A's stores (other lanes of the group) are ordered before phase B's loads
+
+  // ------------------------------------------------------------------ phase B: select
+  int depth = 0, kind = LEAF_NONE;
+  if (live && v.active[slot]) {
+    GEnv env = v.root[slot];
+    const uint32_t epoch = v.epoch[slot];
+    int idx = v.root_idx[slot];
+    bool probe = idx < 0;
+    uint32_t ins = 0;
+    int pidx = 0, pact = 0;
+    for (;;) {
+      if (env.fin & 1) { kind = LEAF_TERMINAL; break; }             // mcts.jl:200-201
+      if (probe) {                                                  // haskey(env.tree, state), mcts.jl:165-174
+        idx = ht_lookup<Gm>(v, slot, lane, env.a, env.b, epoch, &ins);
+        if (idx < 0) { kind = LEAF_NEW; break; }                    // mcts.jl:205-207
+        if (lane == 0) {
+          if (depth == 0) v.root_idx[slot] = idx;
+          else if (links_ok) set_link<Gm>(pool + (size_t)pidx * NL::BYTES, pact, (uint32_t)(idx + 1));
+        }
+      }
+      if (depth >= v.max_depth) { dev_fail(v, DERR_DEPTH); kind = LEAF_NONE; break; }
+      const char* nd = pool + (size_t)idx * NL::BYTES;
+      const uint32_t amask = Gm::mask(env);
+      const bool inrec = lane < Gm::A;
+      const int N = inrec ? ((const int*)(nd + NL::OFF_N))[lane] : 0;
+      const float Pf = inrec ? ((const float*)(nd + NL::OFF_P))[lane] : 0.0f;
+      const double W = inrec ? ((const double*)(nd + NL::OFF_W))[lane] : 0.0;
+      const uint32_t lo = inrec ? ((const uint16_t*)(nd + NL::OFF_LO))[lane] : 0;
+      const uint32_t hi = *(const typename NL::hi_t*)(nd + NL::OFF_HI);
+      const int link = (int)(lo | (((hi >> (2 * lane)) & 3u) << 16));
+      // uct_scores (mcts.jl:180-188): Float64, evaluated left to right
+      const int Ntot = group_sum<L>(N);
+      const double sqrtNtot = __builtin_sqrt((double)Ntot);
+      const double Q = W / (double)(N > 1 ? N : 1);
+      double Pd = (double)Pf;
+      if (depth == 0 && p.eps != 0.0) Pd = (1.0 - p.eps) * Pd + p.eps * v.eta[(size_t)slot * L + lane];
+      double sc = Q + p.cpuct * Pd * sqrtNtot / (double)(N + 1);
+      if (!((amask >> lane) & 1)) sc = -__builtin_inf();
+      const int act = group_argmax<L>(sc, lane);
+      const int nxt = __shfl(link, gbase + act);
+      const bool wp = Gm::white_playing(env);
+      Gm::play(env, act);                                           // mcts.jl:213-217
+      const float wr = Gm::white_reward(env);
+      const int r = (int)(wp ? wr : -wr);
+      const bool psw = wp != Gm::white_playing(env);
+      if (lane == 0)
+        path[depth] = (unsigned long long)(uint32_t)idx | ((unsigned long long)act << 32) |
+                      ((unsigned long long)(psw ? 1 : 0) << 40) | ((unsigned long long)(r + 1) << 41);
+      pidx = idx; pact = act;
+      depth++;
+      probe = nxt == 0;
+      idx = nxt - 1;
+    }
+    if (lane == 0) {
+      v.leaf_depth[slot] = depth;
+      v.leaf_env[slot] = env;
+      v.leaf_ins[slot] = ins;
     }
   }
-}
-static __global__ void __launch_bounds__(1024) k_compact_assign(DView v) {
-  __builtin_amdgcn_s_setprio(3);
-  __shared__ int red[16];
-  __shared__ int s_base, s_total;
-  const int nchunks = (v.G + 1023) / 1024;
-  // exclusive sum of the chunk totals before this chunk (and the grand total in chunk 0)
-  int before = 0, all = 0;
-  for (int c = threadIdx.x; c < nchunks; c += 1024) { const int x = v.chunk_cnt[c]; all += x; if (c < (int)blockIdx.x) before += x; }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (live && lane == 0) v.leaf_kind[slot] = kind;
+
+  // ------------------------------------------------------------------ evaluation batch + statistics of the wave
+  const bool head = live && lane == 0;
+  const bool isnew = head && kind == LEAF_NEW;
+  const unsigned long long bal = __ballot(isnew);
+  int sims = (head && kind != LEAF_NONE) ? 1 : 0, trav = (head && kind != LEAF_NONE) ? depth : 0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { before += __shfl_down(before, o); all += __shfl_down(all, o); }
-  if (lane == 0) red[w] = before;
+  for (int o = 32; o > 0; o >>= 1) { sims += __shfl_down(sims, o); trav += __shfl_down(trav, o); }
+  if (wl == 0) { s_new[w] = __popcll(bal); s_sims[w] = sims; s_trav[w] = trav; }
   __syncthreads();
-  if (threadIdx.x == 0) { int b = 0; for (int i = 0; i < 16; ++i) b += red[i]; s_base = b; }
-  __syncthreads();
-  if (lane == 0) red[w] = all;
-  __syncthreads();
-  if (threadIdx.x == 0) { int a = 0; for (int i = 0; i < 16; ++i) a += red[i]; s_total = a; }
-  __syncthreads();
-  const int s = blockIdx.x * 1024 + threadIdx.x;
-  if (s < v.G) {
-    const int r = v.eidx[s];
-    if (r >= 0) { const int e = s_base + r; v.eidx[s] = e; v.eval_slots[e] = s; }
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    int tot = 0, ts = 0, tt = 0;
+    for (int i = 0; i < nw; ++i) { tot += s_new[i]; ts += s_sims[i]; tt += s_trav[i]; }
+    s_base = tot ? atomicAdd(v.n_eval + par, tot) : 0;
+    if (ts) {                                                       // statistics: simulations (mcts.jl:242), traversed nodes (:222), oracle calls
+      atomicAdd((unsigned long long*)&v.stat[0], (unsigned long long)ts);
+      atomicAdd((unsigned long long*)&v.stat[1], (unsigned long long)tt);
+      if (tot) atomicAdd((unsigned long long*)&v.stat[2], (unsigned long long)tot);
+    }
+    if (blockIdx.x == 0) v.n_eval[par ^ 1] = 0;                     // the next wave's counter
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *v.n_eval = s_total;
-    atomicAdd((unsigned long long*)&v.stat[2], (unsigned long long)s_total);
+  __syncthreads();
+  if (isnew) {
+    int base = s_base;
+    for (int i = 0; i < w; ++i) base += s_new[i];
+    const int e = base + __popcll(bal & ((1ULL << wl) - 1ULL));
+    v.eidx[slot] = e;
+    v.eval_slots[e] = slot;
   }
 }
 
@@ -297,11 +407,11 @@ __host__ __device__ inline float rollout_value(GEnv g, uint64_t seed, uint32_t g
 
 // NN-free oracles: MCTS.RandomOracle (src/mcts.jl:62-72), MCTS.RolloutOracle (:35-60) and the synthetic hash oracle
 template <class Gm>
-__global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p, uint32_t sim_idx) {
+__global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p, uint32_t sim_idx, int par) {
   __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   constexpr int L = Gm::APAD;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= *v.n_eval) return;
+  if (e >= v.n_eval[par]) return;
   const GEnv env = v.leaf_env[v.eval_slots[e]];
   const uint32_t m = Gm::mask(env);
   float P[L];
@@ -329,83 +439,6 @@ __global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p, uint32
 }
 
 // =========================================================================================
-// expand + backup: init_state_info (mcts.jl:157-161), update_state_info! (mcts.jl:190-194) and
-// the unwinding half of run_simulation! (mcts.jl:218-223)
-// =========================================================================================
-template <class Gm>
-__global__ void __launch_bounds__(256) k_expand_backup(DView v, DParams p) {
-  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
-  constexpr int L = Gm::APAD;
-  using NL = NodeL<Gm>;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int slot = tid / L, lane = tid % L;
-  if (slot >= v.G) return;
-  const int kind = v.leaf_kind[slot];
-  if (kind == LEAF_NONE) return;
-  char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
-  const int depth = v.leaf_depth[slot];
-  double q = 0.0;                                                 // terminal: return 0.
-  if (kind == LEAF_NEW) {
-    const int e = v.eidx[slot];
-    const int idx = v.node_count[slot];
-    if (idx >= v.cap_nodes) { dev_fail(v, DERR_NODE_POOL); return; }
-    const GEnv env = v.leaf_env[slot];
-    const uint32_t m = Gm::mask(env);
-    float Pf = v.Pout[(size_t)e * L + lane];
-    const float V = v.Vout[e];
-    if (p.prior_temp != 1.0) {                                    // Util.apply_temperature, util.jl:98-110
-      const bool av = (m >> lane) & 1;
-      const int base = (threadIdx.x & 63) & ~(L - 1);
-      double res;
-      if (p.prior_temp == 0.0) {
-        int am = group_argmax<L>(av ? (double)Pf : -__builtin_inf(), lane);
-        res = (lane == am) ? 1.0 : 0.0;
-      } else {
-        double pw = av ? az_pow((double)Pf, 1.0 / p.prior_temp) : 0.0;
-        double s = 0.0;
-        for (int a = 0; a < Gm::A; ++a) { double t = __shfl(pw, base + a); if ((m >> a) & 1) s += t; }
-        res = pw / s;
-      }
-      Pf = av ? (float)res : 0.f;
-    }
-    char* nd = pool + (size_t)idx * NL::BYTES;
-    if (lane < Gm::A) {
-      ((int*)(nd + NL::OFF_N))[lane] = 0;
-      ((float*)(nd + NL::OFF_P))[lane] = Pf;
-      ((double*)(nd + NL::OFF_W))[lane] = 0.0;
-    }
-    if (lane == 0) {
-      ((unsigned long long*)nd)[0] = env.a;
-      ((unsigned long long*)nd)[1] = env.b;
-      v.vest[(size_t)slot * v.cap_nodes + idx] = V;
-      const unsigned long long hk = az_hash_key(env.a, env.b);
-      const unsigned long long tag = (hk >> 40) & 0xffff;
-      v.ht[(size_t)slot * v.ht_size + v.leaf_ins[slot]] =
-          ((unsigned long long)v.epoch[slot] << 48) | (tag << 32) | (unsigned long long)(idx + 1);
-      v.node_count[slot] = idx + 1;
-    }
-    q = (double)V;                                                // return info.Vest
-  }
-  if (lane == 0) {
-    const unsigned long long* path = v.path + (size_t)slot * v.max_depth;
-    for (int k = depth - 1; k >= 0; --k) {
-      const unsigned long long st = path[k];
-      const uint32_t idx = (uint32_t)st;
-      const int act = (int)((st >> 32) & 0xff);
-      const bool psw = (st >> 40) & 1;
-      const double r = (double)((int)((st >> 41) & 3) - 1);
-      q = psw ? -q : q;
-      q = r + p.gamma * q;                                        // mcts.jl:219-220
-      char* nd = pool + (size_t)idx * NL::BYTES;
-      ((double*)(nd + NL::OFF_W))[act] += q;
-      ((int*)(nd + NL::OFF_N))[act] += 1;
-    }
-    v.tot_trav[slot] += depth;                                    // mcts.jl:222
-    v.tot_sims[slot] += 1;                                        // mcts.jl:242
-  }
-}
-
-// =========================================================================================
 // move: MCTS.policy (mcts.jl:255-271) + the body of play_game's loop (play.jl:308-313) +
 // end-of-game bookkeeping of simulate (simulations.jl:231-240)
 // =========================================================================================
@@ -428,13 +461,14 @@ __device__ inline const char* find_node(const DView& v, int slot, unsigned long 
   const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
   const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
+  const unsigned long long* keys = v.keys + (size_t)slot * v.cap_nodes * 2;
   for (uint32_t i = 0; i <= H1; ++i) {
     unsigned long long e = tab[((uint32_t)hk + i) & H1];
     uint32_t idx1 = (uint32_t)e;
     if (!((uint32_t)(e >> 48) == epoch && idx1 != 0)) break;
     if (((uint32_t)(e >> 32) & 0xffff) == tag) {
-      const unsigned long long* k = (const unsigned long long*)(pool + (size_t)(idx1 - 1) * NL::BYTES);
-      if (k[0] == ka && k[1] == kb) { if (idx_out) *idx_out = idx1 - 1; return (const char*)k; }
+      const unsigned long long* k = keys + (size_t)(idx1 - 1) * 2;
+      if (k[0] == ka && k[1] == kb) { if (idx_out) *idx_out = idx1 - 1; return pool + (size_t)(idx1 - 1) * NL::BYTES; }
     }
   }
   return nullptr;
@@ -516,6 +550,7 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
   rec->action = act;
   rec->reward = Gm::white_reward(env);
   v.root[slot] = env;
+  v.root_idx[slot] = -1;
   v.move_idx[slot] = mv + 1;
   if (env.fin & 1) {
     az_game_rec* g = v.grec + slot;
@@ -550,6 +585,8 @@ __global__ void __launch_bounds__(256) k_start_games(DView v, DParams p, const i
   const int slot = slots[i];
   GEnv env = roots ? roots[i] : Gm::init();
   v.root[slot] = env;
+  v.root_idx[slot] = -1;
+  v.leaf_kind[slot] = LEAF_NONE;
   v.game_id[slot] = game_ids ? game_ids[i] : 0;
   v.move_idx[slot] = 0;
   v.active[slot] = 1;
@@ -601,6 +638,7 @@ static __global__ void __launch_bounds__(256) k_reset_slots(DView v, const int* 
   }
   v.epoch[slot] = ep;
   v.node_count[slot] = 0;
+  v.root_idx[slot] = -1;
 }
 
 // gather the move records of finished games into one contiguous staging area

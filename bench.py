@@ -129,7 +129,7 @@ def alone_and_tree(args, blob, dev_index, kernel, waves=200):
     eng.close()
     evals, sims, trav = s1.leaf_evals - s0.leaf_evals, s1.simulations - s0.simulations, s1.nodes_traversed - s0.nodes_traversed
     tw = prof["tower"]
-    flop = TOWER_FLOP + (HEADS_FLOP if name.endswith("+heads16") else 0)
+    flop = TOWER_FLOP
     achieved = evals * flop / (tw["ms"] * 1e-3) / 1e12 if tw["ms"] > 0 else 0.0
     alone = {"kernel": name, "slot_groups": 1, "waves": waves, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
              "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
@@ -252,7 +252,7 @@ def main():
         if prof is not None:
             tw = prof["tower"]
             kernel = eng_kernel
-            flop = TOWER_FLOP + (HEADS_FLOP if kernel.endswith("+heads16") else 0)
+            flop = TOWER_FLOP
             flops = local_evals * flop
             # exclusive kernel time: with several slot groups the towers of different groups overlap, so the sum of their
             # HIP-event durations can exceed the wall time of the region; it is clipped to it (kernel time per step <= ms_per_step)

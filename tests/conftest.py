@@ -16,7 +16,7 @@ def pytest_configure(config):
     lib = os.path.join(ROOT, "alphazero.jl_amd", "csrc", "libazhip.so")
     if not os.path.exists(lib) and "AZHIP_LIB" not in os.environ:
         import subprocess
-        subprocess.check_call(["make", "-C", os.path.dirname(lib), "libazhip.so"])
+        subprocess.check_call(["make", "-j8", "-C", os.path.dirname(lib), "libazhip.so"])
 
 
 def _have_gpu():

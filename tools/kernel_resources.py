@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-kernel VGPR / AGPR / LDS / spill figures of libazhip.so's gfx950 code object (no GPU needed).
+"""Per-kernel VGPR / AGPR / LDS / spill figures of the gfx950 code objects in csrc/*.o (no GPU needed).
 
 usage: tools/kernel_resources.py [substring ...]   -- only kernels whose demangled name contains every substring
 """
@@ -14,13 +14,18 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def main():
-    lib = os.environ.get("AZHIP_LIB", os.path.join(ROOT, "alphazero.jl_amd", "csrc", "libazhip.so"))
+    import glob
+    csrc = os.path.join(ROOT, "alphazero.jl_amd", "csrc")
+    notes = ""
     with tempfile.TemporaryDirectory() as d:
-        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "az.co")
-        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
-        subprocess.check_call([LLVM + "/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                               "--input=" + fat, "--output=" + co, "--unbundle"])
-        notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+        for obj in sorted(glob.glob(os.path.join(csrc, "*.o"))):      # one fat binary per translation unit
+            fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "az.co")
+            subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+            r = subprocess.run([LLVM + "/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                "--input=" + fat, "--output=" + co, "--unbundle"], capture_output=True)
+            if r.returncode != 0:
+                continue                                                # a unit without kernels (net.o)
+            notes += subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
     rows = []
     for e in re.split(r"\n\s+- \.agpr_count", notes)[1:]:
         g = lambda k: re.search(r"\." + k + r":\s+(\S+)", e).group(1)

@@ -1,4 +1,4 @@
-"""Debug aid: per-workgroup s_memtime stamps of one k_tower launch (az_debug_tower_timeline)."""
+"""Debug aid: per-workgroup s_memtime stamps of one k_tower16 launch (az_debug_tower_timeline)."""
 import ctypes as C
 import os
 import sys
@@ -18,17 +18,16 @@ e.net_set_params(random_params(0, hp))
 f = lib().az_debug_tower_timeline
 f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
-for n in (4096, 1536, 768):
-    nb = (n + 2) // 3
-    out = np.zeros((nb, 16), dtype=np.uint64)
+for n in (4096, 2048, 1024):
+    nb = (n + 3) // 4
+    out = np.zeros((nb, 8), dtype=np.uint64)
     check(f(e._h, n, out.ctypes.data_as(C.c_void_p), out.size))
-    t = out[:, :9].astype(np.int64)
+    t = out[:, :4].astype(np.int64)
+    last = 3
     t0 = t[:, 0].min()
-    start, end = t[:, 0] - t0, t[:, 8] - t0
-    dur = t[:, 8] - t[:, 0]
-    print("n", n, "blocks", nb, "kernel span", end.max(), "block dur mean/min/max", dur.mean().round(), dur.min(), dur.max())
-    print(" segments mean (stem, blk0..4, head, store):", np.diff(t, axis=1).mean(axis=0).round())
+    start, end = t[:, 0] - t0, t[:, last] - t0
+    dur = t[:, last] - t[:, 0]
+    print("n", n, "workgroups", nb, "kernel span", end.max(), "workgroup duration mean/min/max", dur.mean().round(), dur.min(), dur.max(), "(100 MHz ticks)")
+    print(" segments mean (stem, tower, head conv + feature store):", np.diff(t[:, :last + 1], axis=1).mean(axis=0).round())
     print(" start quantiles", np.percentile(start, [0, 25, 50, 75, 90, 100]).round())
     print(" end quantiles", np.percentile(end, [0, 25, 50, 75, 90, 100]).round())
-    s = out[:, 9:13].astype(np.int64)
-    print(" blk1.conv1 (mfma, epilogue, barrier):", np.diff(s, axis=1).mean(axis=0).round())

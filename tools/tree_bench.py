@@ -1,4 +1,4 @@
-"""Tree kernels alone (NN-free hash oracle) at increasing slot counts: HIP-event time per kernel class and the
+"""The tree kernel alone (NN-free hash oracle) at increasing slot counts: HIP-event time of k_tree and the
 algorithmic HBM bytes of SURVEY.md §8(d) (148 B per traversed node + per-leaf terms without the network part)."""
 import os
 import sys
@@ -23,11 +23,9 @@ for G in (4096, 65536, 262144, 1048576):
     trav = s1.nodes_traversed - s0.nodes_traversed
     evals = s1.leaf_evals - s0.leaf_evals
     d = trav / sims
-    sel_bytes = 148 * trav + 16 * sims          # probes + node reads + path (per traversed node), final probe miss
-    exp_bytes = 160 * evals + 12 * trav + 32 * evals   # node write + W,N read-modify-write per path step + oracle answer read
-    print("G=%7d depth %.2f | select %.1f us/wave %.0f GB/s | expand+backup %.1f us/wave %.0f GB/s | compact %.1f us | synth %.1f us | %.1f M sims/s tree-only"
-          % (G, d, 1e3 * p["select"]["ms"] / waves, sel_bytes / (p["select"]["ms"] * 1e-3) / 1e9,
-             1e3 * p["expand"]["ms"] / waves, exp_bytes / (p["expand"]["ms"] * 1e-3) / 1e9,
-             1e3 * p["compact"]["ms"] / waves, 1e3 * p["synth"]["ms"] / waves,
-             sims / (sum(v["ms"] for v in p.values()) * 1e-3) / 1e6))
+    tree_bytes = 148 * trav + (16 + 136 + 64) * evals + 16 * (sims - evals)   # bench.py's roofline_tree figure
+    t_ms = p["select"]["ms"] + p["expand"]["ms"]
+    print("G=%7d depth %.2f | k_tree %.1f us/wave %.0f GB/s (%.1f %% of 8 TB/s) | synth %.1f us | %.1f M sims/s tree-only"
+          % (G, d, 1e3 * t_ms / waves, tree_bytes / (t_ms * 1e-3) / 1e9, 100 * tree_bytes / (t_ms * 1e-3) / 8e12,
+             1e3 * p["synth"]["ms"] / waves, sims / (sum(v["ms"] for v in p.values()) * 1e-3) / 1e6))
     e.close()
