@@ -185,7 +185,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     memset(&e->net16, 0, sizeof e->net16);
     { const char* tw = getenv("AZHIP_TOWER"); e->tower_pick = tw ? atoi(tw) : 0; }
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); e->num_cu = pr.multiProcessorCount; }
-    AZCHK(net_set_kernel_attrs(c->game));
+    AZCHK(net_set_kernel_attrs(e));
     // slot groups
     int ng = c->batch_size > 0 ? G / c->batch_size : 1;
     if (ng < 1) ng = 1;
@@ -470,6 +470,7 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
     AZCHK(up(s16_w, &n16.stem_w)); n16.stem_ss = nd.stem_ss;
     AZCHK(up(c16_w, &tmp)); n16.conv_w = (const float4*)tmp; n16.conv_ss = nd.conv_ss;
     AZCHK(up(h16_w, &tmp)); n16.head_w = (const float4*)tmp; n16.head_ss = nd.head_ss;
+    for (int k = 0; k < 3; ++k) n16.geo[k] = e->d_geo[k];
   }
   e->net16 = n16;
   HIPCHK(hipStreamSynchronize(e->stream));

@@ -79,6 +79,7 @@ struct az_engine {
   std::vector<float> blob;
   NetDev net;
   Net16Dev net16;                // k_tower16 fragments (64 filters)
+  uint16_t* d_geo[3];            // Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h)
   char last_tower[96];           // name of the tower kernel that served the most recent network launch (az_net_last_kernel)
   int tower_pick;                // AZHIP_TOWER=16|32|3|21 forces a tower kernel (3 = k_tower16 with 3 row tiles, 21 = k_tower16x2); 0 = choose per launch
   int num_cu;
@@ -174,7 +175,7 @@ inline int prof_end(az_engine* e, hipStream_t st, int cls) {
   HIPCHK(hipSetDevice((e)->device))
 
 // ---- net.hip: every instantiation of the tower / heads kernels lives there ----------------------------------
-int net_set_kernel_attrs(int game);
+int net_set_kernel_attrs(az_engine* e);   // + uploads the row permutation tables of the tower kernels (e->d_geo)
 // tower + heads on n_max boards (device count in n_ptr when given): from_planes ? X / Amask : envs[eslots[i]]
 int net_launch(az_engine* e, hipStream_t st, bool from_planes, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr,
                int n_max, const float* X, const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride);

@@ -3,22 +3,23 @@
 #include "engine.h"
 
 #define AZ_NET_DECL(sfx)                                                                                                     \
-  int net_set_kernel_attrs_##sfx();                                                                                          \
+  int net_set_kernel_attrs_##sfx(az_engine* e);                                                                                       \
   int net_launch_##sfx(az_engine* e, hipStream_t st, bool from_planes, float* hfeat, const GEnv* envs, const int* eslots,    \
                        const int* n_ptr, int n_max, const float* X, const float* Amask, float* Pout, float* Vout, float* Pinv, \
                        int pstride);                                                                                         \
-  int net_wave_##sfx(az_engine* e, int g, bool split, int nmax);
+  int net_wave_##sfx(az_engine* e, int g, bool split, int nmax);                                                             \
+  int net_geometry_##sfx(int which, uint16_t* out, int64_t cap, int* rows, int* products);
 AZ_NET_DECL(c4)
 AZ_NET_DECL(ttt)
 AZ_NET_DECL(mancala)
 
-int net_set_kernel_attrs(int game) {
-  switch (game) {
-    case AZ_GAME_CONNECT_FOUR: return net_set_kernel_attrs_c4();
-    case AZ_GAME_TICTACTOE: return net_set_kernel_attrs_ttt();
-    case AZ_GAME_MANCALA: return net_set_kernel_attrs_mancala();
+int net_set_kernel_attrs(az_engine* e) {
+  switch (e->cfg.game) {
+    case AZ_GAME_CONNECT_FOUR: return net_set_kernel_attrs_c4(e);
+    case AZ_GAME_TICTACTOE: return net_set_kernel_attrs_ttt(e);
+    case AZ_GAME_MANCALA: return net_set_kernel_attrs_mancala(e);
   }
-  return fail(AZ_ERR_BAD_ARG, "unknown game id %d", game);
+  return fail(AZ_ERR_BAD_ARG, "unknown game id %d", e->cfg.game);
 }
 int net_launch(az_engine* e, hipStream_t st, bool from_planes, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr,
                int n_max, const float* X, const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
@@ -36,4 +37,16 @@ int net_wave(az_engine* e, int g, bool split, int nmax) {
     case AZ_GAME_MANCALA: return net_wave_mancala(e, g, split, nmax);
   }
   return fail(AZ_ERR_BAD_ARG, "unknown game id %d", e->cfg.game);
+}
+
+// debug aid (not part of the ABI in azhip.h): the row permutation of a tower kernel (which = 0: 11 tiles, 1: 3 tiles,
+// 2: 21 tiles): out = pos [rows] then nbr [9][rows] (Geo16, resnet16.h), *products = (tile, tap) products per convolution
+extern "C" int az_debug_tower_geometry(int32_t game, int32_t which, uint16_t* out, int64_t cap, int32_t* rows, int32_t* products) {
+  if (!out || !rows || !products || which < 0 || which > 2) return fail(AZ_ERR_BAD_ARG, "bad argument");
+  switch (game) {
+    case AZ_GAME_CONNECT_FOUR: return net_geometry_c4(which, out, cap, rows, products);
+    case AZ_GAME_TICTACTOE: return net_geometry_ttt(which, out, cap, rows, products);
+    case AZ_GAME_MANCALA: return net_geometry_mancala(which, out, cap, rows, products);
+  }
+  return fail(AZ_ERR_BAD_ARG, "unknown game id %d", game);
 }

@@ -16,9 +16,31 @@ template <class Gm, int F> static int set_kernel_attrs_f() {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   return AZ_OK;
 }
-template <class Gm> static int set_kernel_attrs() {
+// the row permutation tables of the three k_tower16 geometries (Geo16, resnet16.h) go to the device once per engine
+template <class G> static int upload_geo(az_engine* e, int which) {
+  std::vector<uint16_t> h((size_t)10 * G::RPAD);
+  for (int i = 0; i < G::RPAD; ++i) h[i] = G::tab.pos[i];
+  for (int i = 0; i < 9 * G::RPAD; ++i) h[G::RPAD + i] = G::tab.nbr[i];
+  uint16_t* d = nullptr;
+  AZCHK(dalloc(e, &d, h.size(), false));
+  HIPCHK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->d_geo[which] = d;
+  return AZ_OK;
+}
+template <class G> static int geometry_out(uint16_t* out, int64_t cap, int* rows, int* products) {
+  if (cap < (int64_t)10 * G::RPAD) return fail(AZ_ERR_CAPACITY, "need %d words", 10 * G::RPAD);
+  for (int i = 0; i < G::RPAD; ++i) out[i] = G::tab.pos[i];
+  for (int i = 0; i < 9 * G::RPAD; ++i) out[G::RPAD + i] = G::tab.nbr[i];
+  *rows = G::RPAD; *products = G::tab.cost;
+  return AZ_OK;
+}
+template <class Gm> static int set_kernel_attrs(az_engine* e) {
   AZCHK((set_kernel_attrs_f<Gm, 64>()));
   AZCHK((set_kernel_attrs_f<Gm, 128>()));
+  AZCHK((upload_geo<typename T16<Gm, 64, 11>::Geo>(e, 0)));
+  AZCHK((upload_geo<typename T16<Gm, 64, 3>::Geo>(e, 1)));
+  AZCHK((upload_geo<typename T16P<Gm, 64>::Geo>(e, 2)));
   return AZ_OK;
 }
 
@@ -132,11 +154,16 @@ template <class Gm> static int wave_net(az_engine* e, int g, bool split, int nma
 
 // the three entry points of one game's translation unit
 #define AZ_NET_GAME_TU(Gm, sfx)                                                                                              \
-  int net_set_kernel_attrs_##sfx() { return set_kernel_attrs<Gm>(); }                                                        \
+  int net_set_kernel_attrs_##sfx(az_engine* e) { return set_kernel_attrs<Gm>(e); }                                                      \
   int net_launch_##sfx(az_engine* e, hipStream_t st, bool from_planes, float* hfeat, const GEnv* envs, const int* eslots,    \
                        const int* n_ptr, int n_max, const float* X, const float* Amask, float* Pout, float* Vout, float* Pinv, \
                        int pstride) {                                                                                        \
     return from_planes ? launch_net<Gm, true>(e, st, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride)  \
                        : launch_net<Gm, false>(e, st, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride); \
   }                                                                                                                          \
-  int net_wave_##sfx(az_engine* e, int g, bool split, int nmax) { return wave_net<Gm>(e, g, split, nmax); }
+  int net_wave_##sfx(az_engine* e, int g, bool split, int nmax) { return wave_net<Gm>(e, g, split, nmax); }                  \
+  int net_geometry_##sfx(int which, uint16_t* out, int64_t cap, int* rows, int* products) {                                  \
+    return which == 0 ? geometry_out<typename T16<Gm, 64, 11>::Geo>(out, cap, rows, products)                                \
+         : which == 1 ? geometry_out<typename T16<Gm, 64, 3>::Geo>(out, cap, rows, products)                                 \
+                      : geometry_out<typename T16P<Gm, 64>::Geo>(out, cap, rows, products);                                  \
+  }

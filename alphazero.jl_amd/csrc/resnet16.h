@@ -32,8 +32,120 @@ struct Net16Dev {
   const float* conv_ss;     // [2*nblocks][2][64]
   const float4* head_w;     // [4 col tiles][4][64] float4
   const float* head_ss;     // [2][64]
+  const uint16_t* geo[3];   // row permutation tables (Geo16: pos [RPAD], nbr [9][RPAD]) of the 11-tile, 3-tile and 21-tile kernels
   unsigned long long* dbg;  // optional [workgroups][8] s_memtime stamps (az_debug_tower_timeline): start, stem, tower, head conv + features, end
 };
+// ---------------------------------------------------------------------------------------------------------------
+// Row permutation of the tower kernels: skipping the taps that fall off the board.
+//
+// A 3x3 convolution on a W x H board multiplies zeros for every (position, tap) whose neighbour is outside: 19.6 % of
+// the pairs on 7x6 (Connect-Four), two thirds on 14x1 (Mancala).  The implicit GEMM works on tiles of 16 rows, so a tap
+// can be dropped for a tile only if it is outside for ALL 16 rows.  The rows of a workgroup's buffer are therefore
+// ordered by border class instead of by position: interior cells first (every tap inside), then the left column, the
+// right column, the bottom row, the top row (order of the four edge classes and the place of the padding rows chosen
+// at compile time to minimise the number of (tile, tap) products).  Connect-Four, 4 boards in 11 tiles: 85 products
+// instead of 99 (-14 %); 8 boards in 21 tiles: 159 instead of 189 (-16 %); Mancala: 31 of 99.  A skipped product would
+// have added 0 x w to the accumulator, which leaves every fp32 chain of the contract bit-for-bit unchanged (the
+// accumulators start at +0 and never become -0).
+// What changes in the kernel: the tap-shifted row of a lane is no longer `row + delta` but a table look-up
+// (nbr[tap][row], buffer offset of the neighbour or of the zero row; built on the host from the same constexpr
+// function, staged in LDS), read one pipeline step ahead of the activation rows it addresses; the list of
+// (tap, tile pair) steps is a compile-time list, so the unrolled MFMA stream simply has fewer steps.
+template <class Gm, int NTILES, int TBOARDS> struct Geo16 {
+  static constexpr int P = Gm::P, W = Gm::W, H = Gm::H, RPAD = NTILES * 16, ROWS = TBOARDS * P, NPADR = RPAD - ROWS;
+  static_assert(NPADR >= 0, "boards do not fit the tiles");
+  struct Tab {
+    uint16_t pos[RPAD];            // buffer row -> board * P + position, 0xffff = padding row
+    uint16_t nbr[9 * RPAD];        // [tap][row] -> buffer row of the neighbour, RPAD = the zero row
+    uint16_t tapmask[NTILES];      // bit t: tap t is inside the board for at least one row of the tile
+    int cost;                      // sum of popcount(tapmask)
+  };
+  static constexpr int cls(int q) {
+    const int x = q % W, y = q / W;
+    if (W >= 2 && x == 0) return 1;
+    if (W >= 2 && x == W - 1) return 2;
+    if (y == 0) return H == 1 ? 0 : 3;
+    if (y == H - 1) return 4;
+    return 0;
+  }
+  // validity bits of the 9 taps at board position q
+  static constexpr int valid9(int q) {
+    int m = 0;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int x = q % W + (tap % 3 - 1), y = q / W + (tap / 3 - 1);
+      if (x >= 0 && x < W && y >= 0 && y < H) m |= 1 << tap;
+    }
+    return m;
+  }
+  struct Order { int ord[5]; };
+  static constexpr Order order_of(int order_code) {     // order_code in 0..23 -> interior first, then a permutation of the edge classes
+    Order o{{0, 1, 2, 3, 4}};
+    int pool[4] = {1, 2, 3, 4}, n = 4, code = order_code;
+    for (int i = 0; i < 4; ++i) {
+      const int k = code % n; code /= n;
+      o.ord[1 + i] = pool[k];
+      for (int j = k; j + 1 < n; ++j) pool[j] = pool[j + 1];
+      --n;
+    }
+    return o;
+  }
+  // number of (tile, tap) products of a candidate layout (no tables built: the search stays cheap for the compiler)
+  static constexpr int cost_of(int order_code, int padpos) {
+    const Order o = order_of(order_code);
+    int v9[P] = {}, ncls[5] = {};
+    for (int q = 0; q < P; ++q) { v9[q] = valid9(q); ncls[cls(q)]++; }
+    int cost = 0, r = 0, mask = 0;
+    auto put = [&](int m, int count) {
+      for (int k = 0; k < count; ++k) {
+        mask |= m;
+        if (++r % 16 == 0) { for (int t = 0; t < 9; ++t) cost += (mask >> t) & 1; mask = 0; }
+      }
+    };
+    for (int ci = 0; ci < 5; ++ci) {
+      for (int b = 0; b < TBOARDS; ++b)
+        for (int q = 0; q < P; ++q) if (cls(q) == o.ord[ci]) put(v9[q], 1);
+      if (ci == padpos) put(0, NPADR);
+    }
+    return cost;
+  }
+  static constexpr Tab build(int order_code, int padpos) {
+    Tab t{};
+    const Order o = order_of(order_code);
+    int r = 0;
+    for (int ci = 0; ci < 5; ++ci) {
+      for (int b = 0; b < TBOARDS; ++b)
+        for (int q = 0; q < P; ++q) if (cls(q) == o.ord[ci]) t.pos[r++] = (uint16_t)(b * P + q);
+      if (ci == padpos) for (int k = 0; k < NPADR; ++k) t.pos[r++] = 0xffff;
+    }
+    uint16_t row_of[ROWS > 0 ? ROWS : 1] = {};
+    for (int i = 0; i < RPAD; ++i) if (t.pos[i] != 0xffff) row_of[t.pos[i]] = (uint16_t)i;
+    for (int i = 0; i < NTILES; ++i) t.tapmask[i] = 0;
+    for (int i = 0; i < RPAD; ++i) {
+      for (int tap = 0; tap < 9; ++tap) {
+        int nb = RPAD;
+        if (t.pos[i] != 0xffff) {
+          const int b = t.pos[i] / P, q = t.pos[i] % P, x = q % W + (tap % 3 - 1), y = q / W + (tap / 3 - 1);
+          if (x >= 0 && x < W && y >= 0 && y < H) { nb = row_of[b * P + y * W + x]; t.tapmask[i / 16] |= (uint16_t)(1u << tap); }
+        }
+        t.nbr[tap * RPAD + i] = (uint16_t)nb;
+      }
+    }
+    t.cost = 0;
+    for (int i = 0; i < NTILES; ++i) for (int tap = 0; tap < 9; ++tap) t.cost += (t.tapmask[i] >> tap) & 1;
+    return t;
+  }
+  static constexpr Tab best() {
+    int bo = 0, bp = 4, bc = cost_of(0, 4);
+    for (int oc = 0; oc < 24; ++oc)
+      for (int pp = 0; pp < 5; ++pp) {
+        const int c = cost_of(oc, pp);
+        if (c < bc) { bc = c; bo = oc; bp = pp; }
+      }
+    return build(bo, bp);
+  }
+  static constexpr Tab tab = best();
+};
+
 // NT = row tiles per workgroup: 11 (throughput: 4 Connect-Four boards, 2 workgroups per CU at 64 filters) or 3
 // (latency: ONE Connect-Four board per workgroup, so a small batch spreads over 4x as many CUs and the
 // sequential layer chain of a workgroup is 3.7x shorter -- the reference's 128-worker configurations).
@@ -44,12 +156,14 @@ template <class Gm, int F = 64, int NT = 11> struct T16 {
   static constexpr int STRIDE = F + 4;
   static constexpr int BUF = (RPAD + 1) * STRIDE;    // row RPAD = zeros
   static constexpr int PLANES = (RPAD + 1) * Gm::C;
-  static constexpr int BYTES = (BUF + PLANES) * 4;   // 50 KB at F = 64 (2 workgroups per CU), 96 KB at F = 128 (1)
+  static constexpr int TABLE = (10 * RPAD + 1) / 2;  // floats holding nbr [9][RPAD] + pos [RPAD] as u16 (Geo16)
+  static constexpr int BYTES = (BUF + PLANES + TABLE) * 4;   // 54 KB at F = 64 (2 workgroups per CU), 99 KB at F = 128 (1)
   static constexpr int WAVES = F / 16, THREADS = 64 * WAVES;
   static constexpr int CT = F / 16;                  // channel tiles of 16 = wavefronts per row-tile set
   static constexpr int KH = F / 64;                  // 64-channel halves of a tap (one pipeline step each)
   static constexpr int SQ = F / 16;                  // float4 of B per tap and lane
   using Game = Gm;
+  using Geo = Geo16<Gm, NTILE, TB>;
   static constexpr int FILT = F;
 };
 // Paired geometry (k_tower16x2, 64 filters): TWO sets of F/16 wavefronts share one LDS buffer of 21 row tiles =
@@ -63,10 +177,12 @@ template <class Gm, int F = 64> struct T16P {
   static constexpr int STRIDE = F + 4;
   static constexpr int BUF = (RPAD + 1) * STRIDE;
   static constexpr int PLANES = (RPAD + 1) * Gm::C;
-  static constexpr int BYTES = (BUF + PLANES) * 4;
+  static constexpr int TABLE = (10 * RPAD + 1) / 2;
+  static constexpr int BYTES = (BUF + PLANES + TABLE) * 4;
   static constexpr int CT = F / 16, WAVES = 2 * CT, THREADS = 64 * WAVES;
   static constexpr int KH = F / 64, SQ = F / 16;
   using Game = Gm;
+  using Geo = Geo16<Gm, NTW, TB>;
   static constexpr int FILT = F;
 };
 
@@ -158,41 +274,153 @@ __device__ __forceinline__ void conv16(const float* __restrict__ buf, const floa
   conv16_steps<T, NT, NTAP, 0>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
 }
 
+// Compile-time list of the pipeline steps of one convolution for a wavefront that owns tiles TILE0 .. TILE0 + NT - 1:
+// (tap, 64-channel half, tile pair).  Tiles go in pairs so that consecutive MFMAs never hit the same accumulator.
+template <class G, int NT, int TILE0, int KH, int NTAP> struct Steps16 {
+  static constexpr int MAXS = 9 * KH * ((NT + 1) / 2);
+  struct L {
+    int n;
+    int8_t tap[MAXS], kh[MAXS], t0[MAXS], t1[MAXS];   // t1 = -1: single tile
+    int8_t first[MAXS];                                 // first step of its tap: the next tap's weights are requested here
+    int8_t next_tap[MAXS];                              // tap whose weights to request (-1: none)
+    int8_t ord[MAXS];                                   // ordinal of the tap among the taps that have steps (weight stage = ord & 1)
+    int8_t first_tap;
+  };
+  static constexpr L make() {
+    L l{};
+    l.n = 0; l.first_tap = -1;
+    int taps[9] = {}, ntaps = 0;
+    for (int tap = 0; tap < 9; ++tap) {
+      if (NTAP == 1 && tap != 4) continue;
+      bool any = false;
+      for (int t = 0; t < NT; ++t) any = any || ((G::tab.tapmask[TILE0 + t] >> tap) & 1);
+      if (any) taps[ntaps++] = tap;
+    }
+    for (int ti = 0; ti < ntaps; ++ti) {
+      const int tap = taps[ti];
+      if (l.first_tap < 0) l.first_tap = (int8_t)tap;
+      int act[NT] = {}, na = 0;
+      for (int t = 0; t < NT; ++t) if ((G::tab.tapmask[TILE0 + t] >> tap) & 1) act[na++] = t;
+      for (int kh = 0; kh < KH; ++kh)
+        for (int i = 0; i < na; i += 2) {
+          const int k = l.n++;
+          l.tap[k] = (int8_t)tap; l.kh[k] = (int8_t)kh; l.t0[k] = (int8_t)act[i]; l.t1[k] = (int8_t)(i + 1 < na ? act[i + 1] : -1);
+          l.first[k] = (kh == 0 && i == 0);
+          l.next_tap[k] = (int8_t)(ti + 1 < ntaps ? taps[ti + 1] : -1);
+          l.ord[k] = (int8_t)ti;
+        }
+    }
+    return l;
+  }
+  static constexpr L list = make();
+};
+
+// activation rows of one step: 4 float4 (16 channels of this lane's k group) per tile; `off` = float offsets of the two
+// tap-shifted rows in the buffer (from the nbr table)
+template <class T>
+__device__ __forceinline__ void load_rows16p(const float* __restrict__ buf, int off0, int off1, bool two, int kh, int g, float4 (&a)[T16_GMAX][4]) {
+  constexpr int F = T::FILT;
+  const float* p0 = buf + off0 + g * (F / 4) + kh * 16;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[0][q] = *(const float4*)(p0 + q * 4);
+  if (two) {
+    const float* p1 = buf + off1 + g * (F / 4) + kh * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[1][q] = *(const float4*)(p1 + q * 4);
+  }
+}
+template <int T0, int T1, int KHI, int SQ, int NT>
+__device__ __forceinline__ void mfma_tiles16(const float4 (&a)[T16_GMAX][4], const float4 (&bfull)[SQ], f32x4v (&acc)[NT]) {
+  const float4* b = bfull + KHI * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    acc[T0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].x, b[q].x, acc[T0], 0, 0, 0);
+    if constexpr (T1 >= 0) acc[T1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].x, b[q].x, acc[T1], 0, 0, 0);
+    acc[T0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].y, b[q].y, acc[T0], 0, 0, 0);
+    if constexpr (T1 >= 0) acc[T1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].y, b[q].y, acc[T1], 0, 0, 0);
+    acc[T0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].z, b[q].z, acc[T0], 0, 0, 0);
+    if constexpr (T1 >= 0) acc[T1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].z, b[q].z, acc[T1], 0, 0, 0);
+    acc[T0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][q].w, b[q].w, acc[T0], 0, 0, 0);
+    if constexpr (T1 >= 0) acc[T1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][q].w, b[q].w, acc[T1], 0, 0, 0);
+  }
+}
+// look-up of the tap-shifted rows of step K for this lane -> float offsets row * STRIDE
+template <class T, class SL, int K, int TILE0>
+__device__ __forceinline__ void load_idx16p(const uint16_t* __restrict__ nbr, int lrow, int (&idx)[2]) {
+  if constexpr (K < SL::list.n) {
+    constexpr int tap = SL::list.tap[K], t0 = SL::list.t0[K], t1 = SL::list.t1[K];
+    idx[0] = (int)nbr[tap * T::RPAD + (TILE0 + t0) * 16 + lrow] * T::STRIDE;
+    if constexpr (t1 >= 0) idx[1] = (int)nbr[tap * T::RPAD + (TILE0 + t1) * 16 + lrow] * T::STRIDE;
+  }
+}
+template <class T, class SL, int NT, int TILE0, int K>
+__device__ __forceinline__ void conv16p_steps(const float* __restrict__ buf, const uint16_t* __restrict__ nbr, const float4* __restrict__ wl,
+                                              f32x4v (&acc)[NT], int lrow, int g, float4 (&b0)[T::FILT / 16], float4 (&b1)[T::FILT / 16],
+                                              float4 (&aA)[T16_GMAX][4], float4 (&aB)[T16_GMAX][4], int (&idx)[2]) {
+  constexpr int F = T::FILT;
+  if constexpr (K < SL::list.n) {
+    constexpr int kh = SL::list.kh[K], t0 = SL::list.t0[K], t1 = SL::list.t1[K], ord = SL::list.ord[K];
+    float4 (&cur)[T16_GMAX][4] = (K & 1) ? aB : aA;
+    float4 (&nxt)[T16_GMAX][4] = (K & 1) ? aA : aB;
+    float4 (&bc)[F / 16] = (ord & 1) ? b1 : b0;
+    float4 (&bn)[F / 16] = (ord & 1) ? b0 : b1;
+    if constexpr (SL::list.first[K] && SL::list.next_tap[K] >= 0) {
+      constexpr int ntap = SL::list.next_tap[K];
+#pragma unroll
+      for (int q = 0; q < T::SQ; ++q) bn[q] = wl[(size_t)(ntap * T::CT * T::SQ + q) * 64];
+    }
+    if constexpr (K + 1 < SL::list.n) {
+      // rows of step K + 1 (their offsets were looked up during step K - 1), then the offsets of step K + 2
+      load_rows16p<T>(buf, idx[0], idx[1], SL::list.t1[K + 1] >= 0, SL::list.kh[K + 1], g, nxt);
+      load_idx16p<T, SL, K + 2, TILE0>(nbr, lrow, idx);
+    }
+    mfma_tiles16<t0, t1, kh, F / 16, NT>(cur, bc, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    conv16p_steps<T, SL, NT, TILE0, K + 1>(buf, nbr, wl, acc, lrow, g, b0, b1, aA, aB, idx);
+  }
+}
+// One F -> F convolution (NTAP = 9: 3x3, NTAP = 1: 1x1) into the NT accumulators of this wave, permuted rows.
+template <class T, class G, int NT, int TILE0, int NTAP>
+__device__ __forceinline__ void conv16p(const float* __restrict__ buf, const uint16_t* __restrict__ nbr, const float4* __restrict__ wl,
+                                        f32x4v (&acc)[NT], int lrow, int g) {
+  constexpr int F = T::FILT;
+  using SL = Steps16<G, NT, TILE0, T::KH, NTAP>;
+  if constexpr (SL::list.n > 0) {
+    float4 b0[F / 16], b1[F / 16], aA[T16_GMAX][4], aB[T16_GMAX][4];
+    int idx[2] = {0, 0};
+    constexpr int tap0 = NTAP == 1 ? 0 : SL::list.first_tap;       // a 1x1 convolution has one weight tap (its rows are tap 4, the centre)
+#pragma unroll
+    for (int q = 0; q < F / 16; ++q) b0[q] = wl[(size_t)(tap0 * T::CT * T::SQ + q) * 64];
+    load_idx16p<T, SL, 0, TILE0>(nbr, lrow, idx);
+    load_rows16p<T>(buf, idx[0], idx[1], SL::list.t1[0] >= 0, SL::list.kh[0], g, aA);
+    load_idx16p<T, SL, 1, TILE0>(nbr, lrow, idx);
+    __builtin_amdgcn_sched_barrier(0);
+    conv16p_steps<T, SL, NT, TILE0, 0>(buf, nbr, wl, acc, lrow, g, b0, b1, aA, aB, idx);
+  }
+}
+
 template <int F> struct T16Threads { static constexpr int V = 64 * (F / 16); };
 
-// One wavefront's share of the tower: its NT row tiles start at row tile TILE0 of the workgroup's LDS buffer, it
-// owns the 16 output channels of channel tile cw.  The caller has filled `planes`, zeroed the buffer's zero row
-// and synchronised; every wavefront of the workgroup runs the same number of barriers.
+// One wavefront's share of the tower: its NT row tiles start at row tile TILE0 of the workgroup's LDS buffer (rows in
+// Geo16's permuted order), it owns the 16 output channels of channel tile cw.  The caller has filled `planes` and the
+// tables, zeroed the buffer's zero row and synchronised; every wavefront of the workgroup runs the same number of barriers.
 template <class T, bool FROM_PLANES, int NT, int TILE0>
-__device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restrict__ buf, const float* __restrict__ planes, int cw,
+__device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restrict__ buf, const float* __restrict__ planes,
+                                             const uint16_t* __restrict__ nbr, const uint16_t* __restrict__ pos, int cw,
                                              int lane, int n, int board0, float* __restrict__ hfeat) {
   using Gm = typename T::Game;
-  constexpr int F = T::FILT, P = Gm::P, W = Gm::W, H = Gm::H, C = Gm::C, TB = T::TB, STRIDE = T::STRIDE, R0 = TILE0 * 16;
+  using G = typename T::Geo;
+  constexpr int F = T::FILT, P = Gm::P, C = Gm::C, TB = T::TB, STRIDE = T::STRIDE, R0 = TILE0 * 16;
   const int lrow = lane & 15, g = lane >> 4;
   unsigned long long* dbg = (net.dbg && threadIdx.x == 0) ? net.dbg + (size_t)blockIdx.x * 8 : nullptr;
 #define AZ_STAMP16(i) do { if (dbg) dbg[i] = __builtin_readcyclecounter(); } while (0)
   AZ_STAMP16(0);
-  // validity of the 9 taps for this lane's row of every tile
-  uint32_t vm[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int tile = 0; tile < NT; ++tile) {
-    const int row = R0 + tile * 16 + lrow;
-    const int q = row % P, x = q % W, y = q / W;
-    uint32_t m = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int dy = t / 3 - 1, dx = t % 3 - 1;
-      const bool ok = (row < T::ROWS) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
-      m |= (uint32_t)ok << t;
-    }
-    vm[tile / 3] |= m << (9 * (tile % 3));
-  }
   // this lane's output element (tile, i): row = R0 + tile*16 + g*4 + i, channel = cw*16 + lrow
   const int ch = cw * 16 + lrow;
   const int opos = posF<F>(ch);
 
   f32x4v acc[NT];
-  // ---- stem: Conv(3x3, C => 64) + BN + ReLU, K = 9C padded to a multiple of 4 -------------------------
+  // ---- stem: Conv(3x3, C => F) + BN + ReLU, K = 9C padded to a multiple of 4 (every tap: its k order mixes them) ----
   {
     constexpr int KK = 9 * C, K2 = (KK + 1) / 2, NS = (2 * K2 + 3) / 4;
 #pragma unroll
@@ -205,11 +433,9 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
       const int k = (p & 1) * K2 + (p >> 1);
       const bool kin = k < KK && p < 2 * K2;
       const int tap = kin ? k / C : 4, c = kin ? k % C : 0;
-      const int delta = (tap / 3 - 1) * W + (tap % 3 - 1);
 #pragma unroll
       for (int tile = 0; tile < NT; ++tile) {
-        const bool ok = kin && ((vmask(vm, tile) >> tap) & 1);
-        const int row = ok ? R0 + tile * 16 + lrow + delta : T::RPAD;
+        const int row = kin ? (int)nbr[tap * T::RPAD + R0 + tile * 16 + lrow] : T::RPAD;
         const float a = planes[row * C + c];
         acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[tile], 0, 0, 0);
       }
@@ -232,11 +458,11 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
   for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    // opaque copy: stops hipcc from hoisting the 99 loop-invariant (tap, tile) LDS addresses out of the layer
-    // loop, which would cost ~100 VGPRs for the whole kernel
-    int lrow_l = lrow + R0;
+    // opaque copy: stops hipcc from hoisting the loop-invariant (tap, tile) table look-ups out of the layer loop,
+    // which would cost ~100 VGPRs for the whole kernel
+    int lrow_l = lrow;
     asm volatile("" : "+v"(lrow_l));
-    conv16<T, NT, 9>(buf, net.conv_w + (size_t)layer * LAYER_W + (size_t)cw * T::SQ * 64 + lane, acc, vm, lrow_l, g);
+    conv16p<T, G, NT, TILE0, 9>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)cw * T::SQ * 64 + lane, acc, lrow_l, g);
     const float sc = net.conv_ss[(size_t)layer * 2 * F + ch], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch];
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();                                 // every wave has finished reading the buffer
@@ -265,50 +491,55 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
     __builtin_amdgcn_s_setprio(0);
   }
   AZ_STAMP16(2);
-  // ---- both 1x1 head convolutions + BN + ReLU as one 64 => 64 GEMM ------------------------------------
+  // ---- both 1x1 head convolutions + BN + ReLU as one F => F GEMM ------------------------------------
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  conv16<T, NT, 1>(buf, net.head_w + (size_t)cw * T::SQ * 64 + lane, acc, vm, lrow + R0, g);
+  conv16p<T, G, NT, TILE0, 1>(buf, nbr, net.head_w + (size_t)cw * T::SQ * 64 + lane, acc, lrow, g);
   {
     const float sc = net.head_ss[ch], sh = net.head_ss[F + ch];
-    {
-      // head features straight from the accumulators to HBM / L2, [board][P][64] in natural channel order.  (The dense
-      // heads stay a separate launch with 32-board MFMA tiles: computing them here per workgroup -- tried on MFMA and on
-      // the vector ALU, from LDS-resident features -- makes each of the 1024 workgroups stream the 382 KB of dense
-      // weights through L2, 65 us per 4096-board launch against 41 us for k_heads_mfma; handing a 32-board tile to the
-      // last of 8 workgroups needs device-scope fences across XCDs and cost 190 us.  DESIGN.md §4.)
-      const int nb = (n - board0) < TB ? (n - board0) : TB;
+    // head features straight from the accumulators to HBM / L2, [board][P][F] in natural position and channel order.
+    // (The dense heads stay a separate launch with 32-board MFMA tiles: computing them here per workgroup -- tried on
+    // MFMA and on the vector ALU, from LDS-resident features -- makes each of the 1024 workgroups stream the 382 KB of
+    // dense weights through L2, 65 us per 4096-board launch against 41 us for k_heads_mfma; handing a 32-board tile to
+    // the last of 8 workgroups needs device-scope fences across XCDs and cost 190 us.  DESIGN.md §4.)
+    const int nvalid = ((n - board0) < TB ? (n - board0) : TB) * P;
 #pragma unroll
-      for (int tile = 0; tile < NT; ++tile)
+    for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = R0 + tile * 16 + g * 4 + i;
-          const float v = az_fmaf(acc[tile][i], sc, sh);
-          if (row < nb * P) hfeat[((size_t)board0 * P + row) * F + ch] = v > 0.0f ? v : 0.0f;
-        }
-    }
+      for (int i = 0; i < 4; ++i) {
+        const int ps = pos[R0 + tile * 16 + g * 4 + i];             // board * P + position of this buffer row (0xffff: padding)
+        const float v = az_fmaf(acc[tile][i], sc, sh);
+        if (ps < nvalid) hfeat[((size_t)board0 * P + ps) * F + ch] = v > 0.0f ? v : 0.0f;
+      }
   }
   AZ_STAMP16(3);
 #undef AZ_STAMP16
 }
 
-// input planes [RPAD + 1][C] and the zero row of the activation buffer, by all threads of the workgroup
+// input planes [RPAD + 1][C] in the permuted row order, the zero row of the activation buffer and the LDS copies of the
+// permutation tables, by all threads of the workgroup
 template <class T, bool FROM_PLANES>
-__device__ __forceinline__ void tower16_fill(float* __restrict__ buf, float* __restrict__ planes, const GEnv* __restrict__ leaf_env,
+__device__ __forceinline__ void tower16_fill(float* __restrict__ buf, float* __restrict__ planes, uint16_t* __restrict__ nbr,
+                                             uint16_t* __restrict__ pos, const uint16_t* __restrict__ geo, const GEnv* __restrict__ leaf_env,
                                              const int* __restrict__ eval_slots, const float* __restrict__ X, int n, int board0, int tid) {
   using Gm = typename T::Game;
   constexpr int P = Gm::P, C = Gm::C;
   for (int i = tid; i < T::PLANES; i += T::THREADS) {
     const int row = i / C, c = i % C;
-    const int b = row / P, q = row % P;
     float val = 0.0f;
-    if (row < T::ROWS && board0 + b < n) {
-      if (FROM_PLANES) val = X[((size_t)(board0 + b) * C + c) * P + q];
-      else val = Gm::plane(leaf_env[eval_slots[board0 + b]], q, c);
+    if (row < T::RPAD) {
+      const int ps = geo[row];
+      if (ps != 0xffff && board0 + ps / P < n) {
+        const int b = ps / P, q = ps % P;
+        if (FROM_PLANES) val = X[((size_t)(board0 + b) * C + c) * P + q];
+        else val = Gm::plane(leaf_env[eval_slots[board0 + b]], q, c);
+      }
     }
     planes[i] = val;
   }
   for (int i = tid; i < T::STRIDE; i += T::THREADS) buf[T::RPAD * T::STRIDE + i] = 0.0f;
+  for (int i = tid; i < T::RPAD; i += T::THREADS) pos[i] = geo[i];
+  for (int i = tid; i < 9 * T::RPAD; i += T::THREADS) nbr[i] = geo[T::RPAD + i];
 }
 
 template <class Gm, int F, bool FROM_PLANES, int NT = 11>
@@ -319,13 +550,14 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
   float* planes = lds + T::BUF;
+  uint16_t* nbr = (uint16_t*)(planes + T::PLANES);
+  uint16_t* pos = nbr + 9 * T::RPAD;
   const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
   const int board0 = blockIdx.x * T::TB;
   if (board0 >= n) return;
-  tower16_fill<T, FROM_PLANES>(buf, planes, leaf_env, eval_slots, X, n, board0, threadIdx.x);
+  tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[NT == 11 ? 0 : 1], leaf_env, eval_slots, X, n, board0, threadIdx.x);
   __syncthreads();
-  tower16_wave<T, FROM_PLANES, NT, 0>(net, buf, planes, threadIdx.x >> 6, threadIdx.x & 63, n, board0, hfeat);
-  if (net.dbg && threadIdx.x == 0) net.dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_readcyclecounter();
+  tower16_wave<T, FROM_PLANES, NT, 0>(net, buf, planes, nbr, pos, threadIdx.x >> 6, threadIdx.x & 63, n, board0, hfeat);
 }
 
 // The paired form (T16P): wavefronts 0..CT-1 run tiles 0..10, wavefronts CT..2CT-1 tiles 11..20 of ONE buffer.
@@ -337,15 +569,16 @@ k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restri
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
   float* planes = lds + T::BUF;
+  uint16_t* nbr = (uint16_t*)(planes + T::PLANES);
+  uint16_t* pos = nbr + 9 * T::RPAD;
   const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
   const int board0 = blockIdx.x * T::TB;
   if (board0 >= n) return;
-  tower16_fill<T, FROM_PLANES>(buf, planes, leaf_env, eval_slots, X, n, board0, threadIdx.x);
+  tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[2], leaf_env, eval_slots, X, n, board0, threadIdx.x);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (wave < T::CT) tower16_wave<T, FROM_PLANES, T::NT0, 0>(net, buf, planes, wave, lane, n, board0, hfeat);
-  else tower16_wave<T, FROM_PLANES, T::NT1, T::NT0>(net, buf, planes, wave - T::CT, lane, n, board0, hfeat);
-  if (net.dbg && threadIdx.x == 0) net.dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_readcyclecounter();
+  if (wave < T::CT) tower16_wave<T, FROM_PLANES, T::NT0, 0>(net, buf, planes, nbr, pos, wave, lane, n, board0, hfeat);
+  else tower16_wave<T, FROM_PLANES, T::NT1, T::NT0>(net, buf, planes, nbr, pos, wave - T::CT, lane, n, board0, hfeat);
 }
 
 // One 3x3 F -> F convolution as a stand-alone layer (HBM -> HBM), for the optimiser step (train.h): forward

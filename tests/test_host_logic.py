@@ -115,3 +115,52 @@ def test_parameter_file_round_trip(tmp_path):
     assert np.array_equal(back.params(), nn.params()) and back.hyper == nn.hyper
     with pytest.raises(ValueError):
         load_params(p, TicTacToeSpec())
+
+
+def test_tower_row_permutation_tables():
+    """Geo16 (csrc/resnet16.h): the tower kernels order a workgroup's rows by border class so that taps which fall off
+    the board for a whole 16-row tile are skipped.  Host-side check of the tables the kernels use: the permutation is a
+    bijection onto (board, position), every neighbour entry is the row of the true neighbour or the zero row, and the
+    product counts are the ones DESIGN.md quotes (Connect-Four: 85 of 99 for 4 boards, 159 of 189 for 8; Mancala 31 of 99)."""
+    import ctypes as C
+    import numpy as np
+    from azhip import _lib as L
+    lib = L.lib()
+    f = lib.az_debug_tower_geometry
+    f.restype = C.c_int
+    f.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    dims = {0: (7, 6), 1: (3, 3), 2: (14, 1)}
+    expect = {(0, 0): 85, (0, 1): 26, (0, 2): 159, (2, 0): 31}
+    for game, (W, H) in dims.items():
+        P = W * H
+        for which, ntiles in ((0, 11), (1, 3), (2, 21)):
+            out = np.zeros(10 * 21 * 16, dtype=np.uint16)
+            rows, prod = C.c_int32(), C.c_int32()
+            L.check(f(game, which, out.ctypes.data_as(C.c_void_p), out.size, C.byref(rows), C.byref(prod)))
+            R = rows.value
+            assert R == ntiles * 16
+            pos, nbr = out[:R].astype(int), out[R:10 * R].astype(int).reshape(9, R)
+            TB = R // P
+            real = pos[pos != 0xffff]
+            assert sorted(real) == list(range(TB * P))                       # every (board, position) exactly once
+            row_of = {int(p): i for i, p in enumerate(pos) if p != 0xffff}
+            products = 0
+            for tile in range(ntiles):
+                for tap in range(9):
+                    dy, dx = tap // 3 - 1, tap % 3 - 1
+                    used = False
+                    for r in range(tile * 16, tile * 16 + 16):
+                        want = R                                              # the zero row
+                        if pos[r] != 0xffff:
+                            b, q = divmod(int(pos[r]), P)
+                            x, y = q % W + dx, q // W + dy
+                            if 0 <= x < W and 0 <= y < H:
+                                want = row_of[b * P + y * W + x]
+                                used = True
+                        assert nbr[tap, r] == want, (game, which, tile, tap, r)
+                    products += used
+            assert products == prod.value <= 9 * ntiles
+            if (game, which) in expect:
+                assert prod.value == expect[(game, which)]
+            if game == 2:
+                assert prod.value <= 3 * ntiles                              # 14x1 board: the six taps with dy != 0 never apply
