@@ -90,16 +90,30 @@ class MemoryBuffer:
         _L.check(_L.lib().az_memory_push(self._h, _C.byref(tb), float(gamma)))
 
     def push_samples(self, samples):
-        """push!(mem.buf, e) for host TrainingSamples (or raw _lib.Sample records)"""
+        """push!(mem.buf, e) for host TrainingSamples (or raw _lib.Sample records).
+
+        az_sample.pi is indexed by FULL action index.  A host TrainingSample carries either a full-width π (what
+        Dataset.samples() returns) or the reference's compact π over the AVAILABLE actions only (what push_trace builds
+        from a Trace, memory.jl:74-87): the compact form is scattered through the state's action mask; any other length
+        is an error."""
         n = len(samples)
+        nA = self.gspec.num_actions()
         arr = (_L.Sample * max(n, 1))()
         for i, e in enumerate(samples):
             if isinstance(e, _L.Sample):
                 _C.memmove(_C.byref(arr[i]), _C.byref(e), _C.sizeof(_L.Sample))
                 continue
             arr[i].key[0], arr[i].key[1] = int(e.s[0]), int(e.s[1])
-            for a, p in enumerate(e.π):
-                arr[i].pi[a] = float(p)
+            pi = np.asarray(e.π, dtype=np.float64)
+            if len(pi) != nA:
+                mask = np.asarray(self.gspec.init((int(e.s[0]), int(e.s[1]))).actions_mask(), dtype=bool)
+                if len(pi) != int(mask.sum()):
+                    raise ValueError("sample %d: π has %d entries, the state has %d available actions of %d" % (i, len(pi), int(mask.sum()), nA))
+                full = np.zeros(nA)
+                full[mask] = pi
+                pi = full
+            for a in range(nA):
+                arr[i].pi[a] = float(pi[a])
             arr[i].z, arr[i].t, arr[i].n = float(e.z), float(e.t), int(e.n)
         _L.check(_L.lib().az_memory_push_samples(self._h, arr, n))
 

@@ -28,6 +28,17 @@ TOWER_FLOP = 2 * 42 * 64 * (27 + 10 * 576 + 64)     # stem + 10 tower convs + bo
 HEADS_FLOP = 2 * (1344 * 7 + 1344 * 64 + 64)
 assert TOWER_FLOP + HEADS_FLOP == 31645952
 PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# The tower kernels skip the (16-row tile, tap) products whose tap falls off the board for the whole tile (Geo16,
+# csrc/resnet16.h): of the 9 x tiles products of a 3x3 convolution they execute 85 of 99 (k_tower16, 4 boards per workgroup),
+# 159 of 189 (k_tower16x2, 8 boards), 26 of 27 (one board per workgroup); k_tower (32x32x2) executes all of them.  The
+# ALGORITHMIC work (every tap of every position, what a dense convolution does) stays the numerator of
+# roofline.achieved; mfma_executed_frac says how busy the matrix pipes really were.
+EXECUTED_TAPS = {"k_tower16x2": 159.0 / 189.0, "NT=11": 85.0 / 99.0, "NT=3": 26.0 / 27.0}
+
+
+def executed_flop(kernel):
+    r = next((v for k, v in EXECUTED_TAPS.items() if k in kernel), 1.0)
+    return 2 * 42 * 64 * (27 + 10 * 576 * r + 64)
 
 
 PEAK_HBM_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -133,7 +144,8 @@ def alone_and_tree(args, blob, dev_index, kernel, waves=200):
     achieved = evals * flop / (tw["ms"] * 1e-3) / 1e12 if tw["ms"] > 0 else 0.0
     alone = {"kernel": name, "slot_groups": 1, "waves": waves, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
              "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
-             "avg_boards_per_launch": evals / max(tw["launches"], 1)}
+             "avg_boards_per_launch": evals / max(tw["launches"], 1),
+             "mfma_executed_frac": achieved / PEAK_FP32_MFMA_TFLOPS * executed_flop(name) / flop}
     tree_cls = [c for c in ("select", "compact", "expand") if prof[c]["launches"]]
     tree_ms = sum(prof[c]["ms"] for c in tree_cls)
     tree_bytes = 148.0 * trav + (16 + 136 + 64) * evals + 16.0 * (sims - evals)
@@ -268,6 +280,9 @@ def main():
                 "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),          # raw HIP-event average (includes co-scheduled time)
                 "launch_ms_sum": tw["ms"], "wall_ms": wall_ms, "exclusive_ms": excl_ms,
                 "kernel_ms_per_step": excl_ms / args.steps,
+                # products with the zero padding are skipped: fraction of the fp32 MFMA peak the executed products amount to
+                "mfma_executed_frac": achieved / PEAK_FP32_MFMA_TFLOPS * executed_flop(kernel) / flop,
+                "executed_flop_per_board": executed_flop(kernel),
             }
             out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
         if prof is not None and world == 1:

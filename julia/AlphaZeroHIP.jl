@@ -287,7 +287,8 @@ function AlphaZero.simulate(simulator::Simulator, gspec::DeviceGameSpec, p::SimP
       e.h, p.num_games, first_game_id, tb, @cfunction(c_progress, Cvoid, (Ptr{Cvoid},)), C_NULL, stats))
   end
   nA = GI.num_actions(gspec)
-  nbytes = cld(cld(16 + 8nA, 8) * 8 + 8nA, 32) * 32 + 4 + 12     # device node record + Vest + hash-table share
+  hb = nA <= 8 ? 2 : 4                                            # width of the child-link high bits (NodeL, csrc/tree.h)
+  nbytes = cld(cld(cld(8nA, 8) * 8 + 8nA + 2nA, hb) * hb + hb, 32) * 32 + 16 + 4 + 12   # node record + key + Vest + hash-table share
   return map(games) do g
     recs = moves[g.first_move + 1 : g.first_move + g.num_moves]
     trace = Trace(decode_state(gspec, recs[1].key))

@@ -223,3 +223,29 @@ def test_push_samples_and_memory_report():
     got = rep.per_game_stage[0].samples_stats.status
     assert np.allclose([got.loss.L, got.loss.Lp, got.loss.Lv, got.Hp, got.Hpnet], [want.L, want.Lp, want.Lv, want.Hp, want.Hpnet], rtol=2e-6, atol=1e-7)
     mem.close(); m2.close()
+
+
+def test_push_trace_samples_with_unavailable_actions_reach_the_device_full_width():
+    """push_trace() builds TrainingSamples whose π covers the AVAILABLE actions only (memory.jl:74-87) while
+    az_sample.pi is indexed by full action index.  MemoryBuffer.push_samples scatters the compact π through the state's
+    action mask: the device samples equal the ones az_memory_push derives from the same records (Tic-tac-toe: every
+    state after the first move has an unavailable action)."""
+    import azhip
+    from azhip.memory import push_trace
+    from azhip.trace import trace_from_records
+    gspec = azhip.TicTacToeSpec()
+    games, moves, ng, nm, _ = _selfplay(1, 6, 3, 16, 1)
+    host = []
+    for i in range(ng):
+        tr = trace_from_records(games[i], moves, 9, lambda key: gspec.init(key).actions_mask())
+        assert any(len(p) < 9 for p in tr.policies)
+        push_trace(host, tr, 1.0)
+    a, b = azhip.MemoryBuffer(gspec, 1000), azhip.MemoryBuffer(gspec, 1000)
+    a.push_records(games, moves, ng, nm, 1.0)
+    b.push_samples(host)
+    with a.dataset() as da, b.dataset() as db:
+        _same_samples(db.raw_samples(), [da.raw_samples()[i] for i in range(nm)], 9)
+    with pytest.raises(ValueError):
+        bad = host[1]
+        b.push_samples([type(bad)(bad.s, bad.π[:-1], bad.z, bad.t, bad.n)])
+    a.close(); b.close()

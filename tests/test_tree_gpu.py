@@ -96,4 +96,12 @@ def test_selfplay_traces_match_oracle(game, nsims, ngames, workers, batch, oracl
             x, y = moves[a.first_move + k], dm[b.first_move + k]
             assert tuple(x.key) == tuple(y.key) and list(x.N) == list(y.N), (i, k)
             assert x.action == y.action and x.reward == y.reward, (i, k)
-    assert stats.simulations == sum(g.total_simulations for g in []) or stats.games == ngames
+    # phase statistics: every wave runs one simulation per active slot, so simulations = nsims x move records; a leaf is
+    # evaluated at most once per simulation; total_simulations is cumulative per worker, so its sum over the workers' last
+    # games is the phase total
+    assert stats.games == ngames and stats.moves == nm and stats.simulations == nsims * nm
+    assert 0 < stats.leaf_evals <= stats.simulations
+    last = {}
+    for g in games:
+        last[g.slot] = max(last.get(g.slot, 0), g.total_simulations)
+    assert sum(last.values()) == stats.simulations
