@@ -7,7 +7,8 @@ include/azhip.h (libazhip.so, hand-written HIP for gfx950).  There is no CPU fal
 from . import _lib
 from ._lib import (AzError, GAME_CONNECT_FOUR, GAME_MANCALA, GAME_TICTACTOE, ORACLE_HASH, ORACLE_RESNET,
                    ORACLE_ROLLOUT, ORACLE_UNIFORM)
-from .engine import Engine, default_cfg
+from .engine import Engine, cached_engine, clear_engine_cache, default_cfg
+from .comm import Comm
 from .params import ArenaParams, ConstSchedule, MctsParams, PLSchedule, SimParams
 from .game import ConnectFourSpec, GameEnv, GameSpec, MancalaSpec, TicTacToeSpec
 from .network import ResNet, ResNetHP

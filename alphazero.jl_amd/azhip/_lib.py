@@ -94,6 +94,13 @@ PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p)
 
 # every symbol include/azhip.h declares: name -> argtypes (restype is int unless noted)
 _VP, _I32, _I64, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+class GatherStats(C.Structure):
+    _fields_ = [("games", C.c_int64), ("moves", C.c_int64), ("bytes", C.c_int64), ("gather_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+AZ_ERR_COMM = -5
+COMM_ID_BYTES = 128
+
 SYMBOLS = {
     "az_last_error": None,
     "az_abi_version": [],
@@ -146,6 +153,12 @@ SYMBOLS = {
     "az_prof_reset": [_VP],
     "az_device_info": [_VP, C.c_char_p, _I32, C.POINTER(_I32), C.POINTER(_I64)],
     "az_net_last_kernel": [_VP, C.c_char_p, _I32],
+    "az_memory_push_engine": [_VP, _VP, C.c_double],
+    "az_comm_unique_id": [_VP],
+    "az_comm_init": [_I32, _I32, _I32, _VP, C.POINTER(_VP)],
+    "az_comm_destroy": [_VP],
+    "az_comm_gather_push": [_VP, _VP, _VP, C.c_double, C.POINTER(GatherStats)],
+    "az_comm_broadcast_params": [_VP, _VP, _I32],
 }
 
 _lib = None

@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib as L
-from .engine import Engine
+from .engine import cached_engine
 from .mcts import oracle_kind
 from .network import copy as network_copy
 from .params import ArenaParams, ConstSchedule, MctsParams, engine_options
@@ -31,7 +31,7 @@ class Evaluation:
     time: float
 
 
-def _engine(gspec, player, sim, device, seed):
+def _engine(gspec, player, sim, device, seed, role):
     """one engine per player: MctsPlayer (any device oracle) or PlayerWithTemperature(NetworkPlayer(nn), schedule)
     -- the latter is an engine without search (num_iters_per_turn = 0)."""
     if isinstance(player, MctsPlayer):
@@ -48,7 +48,7 @@ def _engine(gspec, player, sim, device, seed):
     kw = engine_options(params, sim, seed=seed, arena=True)
     if kind == L.ORACLE_RESNET:
         kw.update(oracle.engine_options())
-    e = Engine(game=gspec.game_id, oracle=kind, device=device, **kw)
+    e = cached_engine(role, game=gspec.game_id, oracle=kind, device=device, **kw)   # kept across checkpoints (engine.py)
     if kind == L.ORACLE_RESNET:
         e.net_set_params(oracle.params())
     return e
@@ -78,10 +78,9 @@ def pit_players(gspec, players: TwoPlayers, sim, game_simulated=None, device=0, 
     returns (rewards from players.white's side, redundancy, traces)."""
     if not gspec.two_players():
         raise ValueError("pit_players needs a two-player game")
-    with _engine(gspec, players.white, sim, device, seed) as ec, _engine(gspec, players.black, sim, device, seed) as eb:
-        games, moves, ng, nm, rewards, red = ec.arena_run(eb, sim.num_games, first_game_id=first_game_id,
-                                                          alternate_colors=sim.alternate_colors,
-                                                          progress=game_simulated)
+    ec, eb = _engine(gspec, players.white, sim, device, seed, "arena-white"), _engine(gspec, players.black, sim, device, seed, "arena-black")
+    games, moves, ng, nm, rewards, red = ec.arena_run(eb, sim.num_games, first_game_id=first_game_id,
+                                                      alternate_colors=sim.alternate_colors, progress=game_simulated)
     return rewards, red, arena_traces(games, moves, ng, gspec.num_actions())
 
 

@@ -200,9 +200,13 @@ class Engine:
             return self.cfg.max_moves_per_game
         return {L.GAME_CONNECT_FOUR: 42, L.GAME_TICTACTOE: 9, L.GAME_MANCALA: 256}[self.cfg.game]
 
-    def selfplay_run(self, num_games, first_game_id=0, progress=None):
-        """simulate(): returns (games, moves, stats); games sorted by game id."""
-        tb, games, moves = self._trace_buf(num_games, num_games * self.max_moves())
+    def selfplay_run(self, num_games, first_game_id=0, progress=None, device_only=False):
+        """simulate(): returns (games, moves, ngames, nmoves, stats); games sorted by game id.
+        device_only: the move records stay in HBM (MemoryBuffer.push_engine / Comm.gather_push read them there);
+        only the game records come back (moves is None, nmoves 0)."""
+        tb, games, moves = self._trace_buf(num_games, 0 if device_only else num_games * self.max_moves())
+        if device_only:
+            tb.moves, moves = None, None
         stats = SelfplayStats()
         cb = L.PROGRESS_CB((lambda user: progress()) if progress else (lambda user: None))
         check(lib().az_selfplay_run(self._h, num_games, first_game_id, C.byref(tb), cb, None, C.byref(stats)))
@@ -243,3 +247,31 @@ class Engine:
         check(lib().az_arena_run(self._h, baseline._h, num_games, first_game_id, 1 if alternate_colors else 0,
                                  C.byref(tb) if traces else None, _vp(rewards), C.byref(red), cb, None))
         return games, moves, (tb.num_games if traces else 0), (tb.num_moves if traces else 0), rewards, red.value
+
+
+# ---- engine cache --------------------------------------------------------------------------------------------------
+# An engine owns its slots' node pools (10 GB at 4096 Connect-Four slots x 400 simulations): building one per
+# self_play_step / pit_networks / Trainer call pays hipMalloc + table clears every time and can hold several at once.
+# Engines are therefore kept by configuration (the az_engine_cfg bytes + a role, so that the two players of an arena
+# get two engines) and only their parameters are replaced between phases (az_net_set_params = Network.copy per phase,
+# training.jl:278-279).  At most CACHE_MAX stay alive, least recently used first out.
+CACHE_MAX = 4
+_cache = {}
+
+
+def cached_engine(role="", **kw):
+    import ctypes
+    cfg = default_cfg(**kw)
+    key = (role, bytes(ctypes.string_at(ctypes.addressof(cfg), ctypes.sizeof(cfg))))
+    e = _cache.pop(key, None)
+    if e is None or e._h is None:
+        while len(_cache) >= CACHE_MAX:
+            _cache.pop(next(iter(_cache))).close()
+        e = Engine(cfg=cfg)
+    _cache[key] = e                                                 # most recently used last
+    return e
+
+
+def clear_engine_cache():
+    while _cache:
+        _cache.popitem()[1].close()

@@ -89,6 +89,10 @@ class MemoryBuffer:
         tb.moves, tb.moves_cap, tb.num_moves = moves, nmoves, nmoves
         _L.check(_L.lib().az_memory_push(self._h, _C.byref(tb), float(gamma)))
 
+    def push_engine(self, engine, gamma):
+        """push_trace! for every game of the engine's last bounded self-play phase, from its device-resident records"""
+        _L.check(_L.lib().az_memory_push_engine(self._h, engine._h, float(gamma)))
+
     def push_samples(self, samples):
         """push!(mem.buf, e) for host TrainingSamples (or raw _lib.Sample records).
 

@@ -7,7 +7,7 @@ process per GPU) and gathers the packed records with all_gather (RCCL over xGMI 
 import numpy as np
 
 from . import _lib as L
-from .engine import Engine
+from .engine import Engine, cached_engine
 from .mcts import memory_footprint_per_node, oracle_kind
 from .params import SimParams, engine_options
 from .play import MctsPlayer
@@ -55,18 +55,19 @@ def _engine_for(gspec, player, p, device, seed):
     kw = engine_options(player.params, p, seed=seed)
     if kind == L.ORACLE_RESNET:
         kw.update(player.oracle.engine_options())
-    e = Engine(game=gspec.game_id, oracle=kind, device=device, **kw)
+    e = cached_engine("selfplay", game=gspec.game_id, oracle=kind, device=device, **kw)   # kept across phases (engine.py)
     if kind == L.ORACLE_RESNET:
         e.net_set_params(player.oracle.params())
     return e
 
 
-def run_local(simulator, gspec, p: SimParams, first_game_id=0, game_simulated=None, device=0, seed=1):
-    """The body of simulate(): returns the engine's raw (games, moves, ngames, nmoves, stats)."""
+def run_local(simulator, gspec, p: SimParams, first_game_id=0, game_simulated=None, device=0, seed=1, device_only=False):
+    """The body of simulate(): returns the engine's raw (games, moves, ngames, nmoves, stats) and the (cached, live) engine.
+    device_only: the move records stay in the engine's HBM phase buffer (moves is None)."""
     oracles = simulator.make_oracles()
     player = simulator.make_player(oracles)
-    with _engine_for(gspec, player, p, device, seed) as e:
-        return e.selfplay_run(p.num_games, first_game_id=first_game_id, progress=game_simulated) + (e,)
+    e = _engine_for(gspec, player, p, device, seed)
+    return e.selfplay_run(p.num_games, first_game_id=first_game_id, progress=game_simulated, device_only=device_only) + (e,)
 
 
 def results_from_records(simulator, gspec, games, moves, ngames, mask_engine=None):

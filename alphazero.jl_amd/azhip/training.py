@@ -78,10 +78,14 @@ def repack_by_game_id(g, m):
     return g, mm
 
 
-def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_played=None, seed=1, group=None):
-    """self_play_step!(env, handler) with the replay memory on the device: the packed records of the phase (gathered
-    over the ranks when torch.distributed is initialised) go straight into a `MemoryBuffer` (az_memory_push does
-    push_trace! for every game on the GPU) -- no per-sample host objects.  Returns the Report.SelfPlay numbers."""
+def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_played=None, seed=1, group=None, comm=None):
+    """self_play_step!(env, handler) with the replay memory on the device.  Returns the Report.SelfPlay numbers.
+
+    One process: the phase runs device-only -- the move records never leave HBM (the engine's phase buffer ->
+    az_memory_push_engine does push_trace! for every game on the GPU); the host sees the game records (56 B per game).
+    Several ranks with a native communicator (`comm`: azhip.comm.Comm, RCCL behind the C ABI): every rank simulates its
+    shard device-only and az_comm_gather_push all-gathers the records device to device into every rank's memory.
+    Several ranks with only a torch.distributed group (the gloo CPU tests): records are gathered through torch."""
     import ctypes as C
     import sys
 
@@ -97,27 +101,35 @@ def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_pl
     t0 = time.perf_counter()
     sim = params.sim
     first, device = 0, 0
-    distributed = dist is not None and dist.is_available() and dist.is_initialized()
-    if distributed:
+    torch_group = comm is None and dist is not None and dist.is_available() and dist.is_initialized()
+    if comm is not None:
+        first, count = shard_games(sim.num_games, comm.world, comm.rank)
+        sim = SimParams(**{**sim.__dict__, "num_games": count})
+        device = getattr(comm, "device", 0)
+    elif torch_group:
         import torch
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         first, count = shard_games(sim.num_games, world, rank)
         sim = SimParams(**{**sim.__dict__, "num_games": count})
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-    games, moves, ng, nm, stats, _ = run_local(simulator, gspec, sim, first, game_played, device, seed)
-    if distributed:
+    games, moves, ng, nm, stats, eng = run_local(simulator, gspec, sim, first, game_played, device, seed, device_only=not torch_group)
+    memory.new_batch()
+    if comm is not None:
+        gs = comm.gather_push(eng, memory, params.mcts.gamma)
+        nm = gs.moves
+    elif torch_group:
         g, mm = repack_by_game_id(*gather_records(*records_to_numpy(games, moves, ng, nm), group))
         ng, nm = len(g), len(mm)
         games = (L.GameRec * max(ng, 1)).from_buffer_copy(g.tobytes() or bytes(C.sizeof(L.GameRec)))
         moves = (L.MoveRec * max(nm, 1)).from_buffer_copy(mm.tobytes() or bytes(C.sizeof(L.MoveRec)))
+        memory.push_records(games, moves, ng, nm, params.mcts.gamma)
+    else:
+        memory.push_engine(eng, params.mcts.gamma)
+        nm = stats.moves
     elapsed = time.perf_counter() - t0
-    memory.new_batch()
-    memory.push_records(games, moves, ng, nm, params.mcts.gamma)
-    sims = sum(games[i].total_simulations for i in range(ng))      # cumulative per worker; informative only
     depth = float(np.mean([games[i].total_nodes_traversed / max(games[i].total_simulations, 1) for i in range(ng)])) if ng else 0.0
     with memory.dataset(use_position_averaging=True) as d:
         distinct = len(d)
-    del sims
     return SelfPlayReport(samples_gen_speed=nm / elapsed, average_exploration_depth=depth,
                           mcts_memory_footprint=int(max((games[i].nodes for i in range(ng)), default=0)),
                           memory_size=len(memory), memory_num_distinct_boards=distinct)

@@ -79,6 +79,7 @@ extern "C" int az_engine_destroy(az_engine* e) {
   for (auto& r : e->prof_pool) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
   for (void* q : e->net_allocs) (void)hipFree(q);
   for (void* q : e->allocs) (void)hipFree(q);
+  if (e->d_phase) (void)hipFree(e->d_phase);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return AZ_OK;
@@ -122,7 +123,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   az_engine* e = new (std::nothrow) az_engine();
   if (!e) return fail(AZ_ERR_HIP, "out of host memory");
   e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0;
-  e->net_loaded = false; e->running = false; e->prof_on = false; e->last_tower[0] = 0; e->prof_mask = 0; e->prof_used = 0;
+  e->net_loaded = false; e->running = false; e->prof_on = false; e->d_phase = nullptr; e->phase_cap = 0; e->phase_n = 0; e->host_moves = true; e->last_tower[0] = 0; e->prof_mask = 0; e->prof_used = 0;
   memset(&e->prof, 0, sizeof e->prof);
   memset(&e->stats, 0, sizeof e->stats);
   int st = [&]() -> int {
@@ -769,6 +770,17 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   HIPCHK(hipMemsetAsync(e->v.stat, 0, sizeof(long long) * 8, e->stream));
   e->total_games = num_games; e->first_game_id = first_game_id; e->next_game = 0; e->games_done = 0; e->wave_in_move = 0;
   e->q_games.clear(); e->q_moves.clear();
+  e->ph_games.clear(); e->ph_off.clear(); e->phase_n = 0;
+  {
+    // the phase's move records also stay on the device (az_memory_push_engine, az_comm_gather_push): a bounded phase only
+    const int64_t want = num_games > 0 ? (int64_t)num_games * e->v.max_moves : 0;
+    if (want > e->phase_cap || want == 0) { if (e->d_phase) (void)hipFree(e->d_phase); e->d_phase = nullptr; e->phase_cap = 0; }
+    if (want > 0 && !e->d_phase) {
+      if (want * (int64_t)sizeof(az_move_rec) > (16LL << 30)) return fail(AZ_ERR_CAPACITY, "num_games x max_moves_per_game move records exceed the 16 GB phase buffer: split the phase");
+      HIPCHK(hipMalloc((void**)&e->d_phase, sizeof(az_move_rec) * (size_t)want));
+      e->phase_cap = want;
+    }
+  }
   memset(&e->stats, 0, sizeof e->stats);
   const int n0 = num_games < 0 ? G : std::min(G, (int)num_games);
   std::vector<int> slots(n0);
@@ -800,10 +812,16 @@ template <class Gm> static int move_round(az_engine* e) {
   const int nf = (int)fslots.size();
   HIPCHK(hipMemcpyAsync(e->d_slots, fslots.data(), sizeof(int) * nf, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(e->d_offsets, offs.data(), sizeof(int) * nf, hipMemcpyHostToDevice, e->stream));
-  hipLaunchKernelGGL(k_gather_traces, dim3(nf), dim3(64), 0, e->stream, e->v, e->d_slots, e->d_offsets, nf, e->d_stage);
+  // the finished games' records: packed behind the phase's earlier games in HBM (or into the staging area when the
+  // phase is unbounded), and from there to the host only if the caller wants host traces
+  if (e->d_phase && e->phase_n + total > e->phase_cap) return fail(AZ_ERR_CAPACITY, "phase buffer overflow");
+  az_move_rec* dst = e->d_phase ? e->d_phase + e->phase_n : e->d_stage;
+  hipLaunchKernelGGL(k_gather_traces, dim3(nf), dim3(64), 0, e->stream, e->v, e->d_slots, e->d_offsets, nf, dst);
   const size_t m0 = e->q_moves.size();
-  e->q_moves.resize(m0 + total);
-  HIPCHK(hipMemcpyAsync(e->q_moves.data() + m0, e->d_stage, sizeof(az_move_rec) * total, hipMemcpyDeviceToHost, e->stream));
+  if (e->host_moves || !e->d_phase) {
+    e->q_moves.resize(m0 + total);
+    HIPCHK(hipMemcpyAsync(e->q_moves.data() + m0, dst, sizeof(az_move_rec) * total, hipMemcpyDeviceToHost, e->stream));
+  }
   HIPCHK(hipMemsetAsync(e->v.finished, 0, sizeof(int) * G, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   std::vector<int> rslots;
@@ -811,6 +829,7 @@ template <class Gm> static int move_round(az_engine* e) {
   for (int i = 0; i < nf; ++i) {
     az_game_rec g = e->h_grec[fslots[i]];
     g.first_move = (int32_t)(m0 + offs[i]);
+    if (e->d_phase) { e->ph_games.push_back(g); e->ph_off.push_back(e->phase_n + offs[i]); }
     e->q_games.push_back(g);
     e->games_done++;
     e->stats.games++;
@@ -823,6 +842,7 @@ template <class Gm> static int move_round(az_engine* e) {
       e->group_active[fslots[i] / e->gv[0].G]++;
     }
   }
+  if (e->d_phase) e->phase_n += total;
   AZCHK(start_games<Gm>(e, rslots, rgids, nullptr, 0, 1));
   return AZ_OK;
 }
@@ -865,6 +885,16 @@ extern "C" int az_selfplay_collect(az_engine* e, az_trace_buf* out) {
   ENGINE(e);
   if (!out) return fail(AZ_ERR_BAD_ARG, "NULL");
   const int64_t ng = (int64_t)e->q_games.size(), nm = (int64_t)e->q_moves.size();
+  if (!e->host_moves && e->d_phase) {                              // device-only phase: game records only, first_move = -1
+    if (ng > out->games_cap || (ng && !out->games)) return fail(AZ_ERR_CAPACITY, "trace buffer too small: need %lld games", (long long)ng);
+    std::vector<int> ord(ng);
+    for (int i = 0; i < ng; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return e->q_games[a].game_id < e->q_games[b].game_id; });
+    for (int64_t i = 0; i < ng; ++i) { out->games[i] = e->q_games[ord[i]]; out->games[i].first_move = -1; }
+    out->num_games = ng; out->num_moves = 0;
+    e->q_games.clear();
+    return AZ_OK;
+  }
   if (ng > out->games_cap || nm > out->moves_cap || (ng && !out->games) || (nm && !out->moves))
     return fail(AZ_ERR_CAPACITY, "trace buffer too small: need %lld games / %lld moves", (long long)ng, (long long)nm);
   // sorted by game id, move records re-packed in that order
@@ -900,7 +930,11 @@ extern "C" int az_selfplay_run(az_engine* e, int32_t num_games, int32_t first_ga
   ENGINE(e);
   if (num_games < 1 || !out) return fail(AZ_ERR_BAD_ARG, "num_games must be >= 1 and out non-NULL");
   if (out->games_cap < num_games) return fail(AZ_ERR_CAPACITY, "games_cap %lld < num_games %d", (long long)out->games_cap, num_games);
-  AZCHK(az_selfplay_begin(e, num_games, first_game_id));
+  // out->moves == NULL: device-only phase -- the move records stay in HBM for az_memory_push_engine / az_comm_gather_push,
+  // only the game records (56 B per game) come back
+  e->host_moves = out->moves != nullptr;
+  const int bst = az_selfplay_begin(e, num_games, first_game_id);
+  if (bst != AZ_OK) { e->host_moves = true; return bst; }
   int reported = 0;
   int st = AZ_OK;
   while (e->games_done < num_games) {
@@ -915,6 +949,7 @@ extern "C" int az_selfplay_run(az_engine* e, int32_t num_games, int32_t first_ga
   const int cst = az_selfplay_collect(e, out);
   if (st == AZ_OK) { st = cst; keep = g_err; }
   az_selfplay_end(e);
+  e->host_moves = true;
   if (st != AZ_OK) g_err = keep;
   return st;
 }

@@ -100,6 +100,11 @@ struct az_engine {
   int group_active[AZ_MAX_GROUPS];   // active slots per slot group (host count; bounds the leaves of a network launch)
   std::vector<az_game_rec> q_games;
   std::vector<az_move_rec> q_moves;
+  // device-resident records of the current phase (az_selfplay_run / begin with num_games > 0): the move records of every
+  // finished game stay in HBM (d_phase, game after game in finishing order)
+  az_move_rec* d_phase; int64_t phase_cap, phase_n; bool host_moves;
+  std::vector<az_game_rec> ph_games;
+  std::vector<int64_t> ph_off;       // offset of each ph_games entry's first move record in d_phase
   az_selfplay_stats stats;
   std::chrono::steady_clock::time_point t_begin;
   // profiling
@@ -202,6 +207,8 @@ struct az_dataset {
   float *d_W, *d_X, *d_A, *d_P, *d_V;
   std::vector<void*> allocs;
 };
+// push_trace! (memory.jl:74-87) of ng games whose move records are ALREADY on the device: game g = d_moves[first[g] .. +cnt[g])
+int memory_push_device(az_memory* m, const az_move_rec* d_moves, const std::vector<long long>& first, const std::vector<int>& cnt, double gamma);
 template <class T> inline int mem_alloc(std::vector<void*>* keep, T** p, size_t n) {
   void* q = nullptr;
   size_t bytes = std::max<size_t>(n * sizeof(T), 16);

@@ -15,7 +15,7 @@
 
 // push_trace! (memory.jl:74-87): one thread per game walks its records from the last position to the first
 template <class Gm>
-__global__ void __launch_bounds__(256) k_mem_push(const az_move_rec* __restrict__ moves, const int* __restrict__ first,
+__global__ void __launch_bounds__(256) k_mem_push(const az_move_rec* __restrict__ moves, const long long* __restrict__ first,
                                                   const int* __restrict__ nmoves, const long long* __restrict__ seq0, int ngames,
                                                   double gamma, az_sample* __restrict__ buf, long long cap, long long min_seq) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,26 +285,18 @@ extern "C" int az_memory_destroy(az_memory* m) {
   delete m;
   return AZ_OK;
 }
-extern "C" int az_memory_push(az_memory* m, const az_trace_buf* tr, double gamma) {
-  MEMORY(m);
-  if (!tr || tr->num_games < 0 || (tr->num_games > 0 && (!tr->games || !tr->moves))) return fail(AZ_ERR_BAD_ARG, "NULL trace buffers");
-  const int ng = (int)tr->num_games;
+int memory_push_device(az_memory* m, const az_move_rec* d_moves, const std::vector<long long>& first, const std::vector<int>& cnt, double gamma) {
+  const int ng = (int)first.size();
   if (!ng) return AZ_OK;
-  std::vector<int> first(ng), cnt(ng);
   std::vector<long long> seq0(ng);
   long long tot = 0;
-  for (int g = 0; g < ng; ++g) {
-    const az_game_rec& r = tr->games[g];
-    if (r.num_moves < 0 || r.first_move < 0 || (int64_t)r.first_move + r.num_moves > tr->num_moves) return fail(AZ_ERR_BAD_ARG, "game record %d points outside the move records", g);
-    first[g] = r.first_move; cnt[g] = r.num_moves; seq0[g] = m->total + tot; tot += r.num_moves;
-  }
-  az_move_rec* d_moves; int *d_first, *d_cnt; long long* d_seq;
+  for (int g = 0; g < ng; ++g) { seq0[g] = m->total + tot; tot += cnt[g]; }
+  long long *d_first, *d_seq; int* d_cnt;
   std::vector<void*> tmp;
   auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); };
   int st = [&]() -> int {
-    AZCHK(mem_alloc(&tmp, &d_moves, (size_t)tr->num_moves)); AZCHK(mem_alloc(&tmp, &d_first, ng)); AZCHK(mem_alloc(&tmp, &d_cnt, ng)); AZCHK(mem_alloc(&tmp, &d_seq, ng));
-    HIPCHK(hipMemcpyAsync(d_moves, tr->moves, sizeof(az_move_rec) * (size_t)tr->num_moves, hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipMemcpyAsync(d_first, first.data(), sizeof(int) * ng, hipMemcpyHostToDevice, m->stream));
+    AZCHK(mem_alloc(&tmp, &d_first, ng)); AZCHK(mem_alloc(&tmp, &d_cnt, ng)); AZCHK(mem_alloc(&tmp, &d_seq, ng));
+    HIPCHK(hipMemcpyAsync(d_first, first.data(), sizeof(long long) * ng, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(d_cnt, cnt.data(), sizeof(int) * ng, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(d_seq, seq0.data(), sizeof(long long) * ng, hipMemcpyHostToDevice, m->stream));
     const long long min_seq = std::max<long long>(0, m->total + tot - m->cap);
@@ -318,6 +310,46 @@ extern "C" int az_memory_push(az_memory* m, const az_trace_buf* tr, double gamma
   m->total += tot;
   m->cur_batch += tot;                                             // mem.cur_batch_size += n, memory.jl:86
   return AZ_OK;
+}
+extern "C" int az_memory_push(az_memory* m, const az_trace_buf* tr, double gamma) {
+  MEMORY(m);
+  if (!tr || tr->num_games < 0 || (tr->num_games > 0 && (!tr->games || !tr->moves))) return fail(AZ_ERR_BAD_ARG, "NULL trace buffers");
+  const int ng = (int)tr->num_games;
+  if (!ng) return AZ_OK;
+  std::vector<long long> first(ng);
+  std::vector<int> cnt(ng);
+  for (int g = 0; g < ng; ++g) {
+    const az_game_rec& r = tr->games[g];
+    if (r.num_moves < 0 || r.first_move < 0 || (int64_t)r.first_move + r.num_moves > tr->num_moves) return fail(AZ_ERR_BAD_ARG, "game record %d points outside the move records", g);
+    first[g] = r.first_move; cnt[g] = r.num_moves;
+  }
+  az_move_rec* d_moves = nullptr;
+  HIPCHK(hipMalloc((void**)&d_moves, sizeof(az_move_rec) * (size_t)std::max<int64_t>(tr->num_moves, 1)));
+  int st = [&]() -> int {
+    HIPCHK(hipMemcpyAsync(d_moves, tr->moves, sizeof(az_move_rec) * (size_t)tr->num_moves, hipMemcpyHostToDevice, m->stream));
+    return memory_push_device(m, d_moves, first, cnt, gamma);
+  }();
+  (void)hipFree(d_moves);
+  return st;
+}
+// push_trace! for every game of the engine's last self-play phase, in game-id order, straight from the engine's
+// device-resident move records (src/training.jl:284-299 -> src/memory.jl:74-87 without the 64 B per position ever
+// visiting the host)
+extern "C" int az_memory_push_engine(az_memory* m, az_engine* e, double gamma) {
+  MEMORY(m);
+  if (!e) return fail(AZ_ERR_BAD_ARG, "engine is NULL");
+  if (e->running) return fail(AZ_ERR_STATE, "self-play in progress");
+  if (e->cfg.game != m->game || e->device != m->device) return fail(AZ_ERR_BAD_ARG, "memory and engine differ in game or device");
+  if (!e->d_phase) return fail(AZ_ERR_STATE, "the engine holds no device-resident phase (az_selfplay_run / az_selfplay_begin with num_games > 0 first)");
+  const size_t ng = e->ph_games.size();
+  std::vector<int> ord(ng);
+  for (size_t i = 0; i < ng; ++i) ord[i] = (int)i;
+  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return e->ph_games[a].game_id < e->ph_games[b].game_id; });
+  std::vector<long long> first(ng);
+  std::vector<int> cnt(ng);
+  for (size_t i = 0; i < ng; ++i) { first[i] = e->ph_off[ord[i]]; cnt[i] = e->ph_games[ord[i]].num_moves; }
+  AZCHK(sync_all(e));
+  return memory_push_device(m, e->d_phase, first, cnt, gamma);
 }
 // push!(mem.buf, sample) for host-resident TrainingSamples (a reference-side MemoryBuffer, or subsets such as the game
 // stages of memory_report, src/learning.jl:192-216); cur_batch_size is not advanced (push_trace! does that)

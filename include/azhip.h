@@ -58,7 +58,8 @@ typedef enum {
   AZ_ERR_BAD_ARG = -1,   /* invalid argument / unsupported configuration */
   AZ_ERR_CAPACITY = -2,  /* node pool, hash table, path, trace or caller buffer too small */
   AZ_ERR_HIP = -3,       /* a HIP runtime call failed */
-  AZ_ERR_STATE = -4      /* call made in the wrong engine state */
+  AZ_ERR_STATE = -4,     /* call made in the wrong engine state */
+  AZ_ERR_COMM = -5       /* an RCCL call failed / librccl.so could not be loaded */
 } az_status;
 
 typedef enum { AZ_GAME_CONNECT_FOUR = 0, AZ_GAME_TICTACTOE = 1, AZ_GAME_MANCALA = 2 } az_game_id;
@@ -235,6 +236,9 @@ int az_arena_run(az_engine* contender, az_engine* baseline, int32_t num_games, i
 /* push_trace! (src/memory.jl:74-87): z (discounted, side relative) and t per move record. */
 int az_push_trace(const az_move_rec* moves, int32_t n, double gamma, double* z, double* t);
 
+/* Device-only phase: az_selfplay_run with out->moves == NULL keeps the move records in HBM (the engine's phase buffer) and
+ * returns the game records only (first_move = -1); az_memory_push_engine / az_comm_gather_push consume them there. */
+
 /* ---- replay memory (src/memory.jl) and learning status (src/learning.jl) on the device ---- */
 typedef struct az_memory az_memory;      /* MemoryBuffer (src/memory.jl:34-45): circular buffer of samples in HBM */
 typedef struct az_dataset az_dataset;    /* Trainer's converted data (src/learning.jl:98-121), device resident */
@@ -251,6 +255,10 @@ int az_memory_destroy(az_memory* m);
 /* push_trace!(mem, trace, gamma) (src/memory.jl:74-87) for every game of `traces` in buffer order: one sample
  * per move record, pi = MCTS.policy of the recorded visit counts, z / t as az_push_trace. */
 int az_memory_push(az_memory* m, const az_trace_buf* traces, double gamma);
+/* self_play_step!'s push loop (src/training.jl:284-299) without the host hop: push_trace!(mem, trace, gamma) for every game
+ * of the engine's last bounded self-play phase (az_selfplay_run, or az_selfplay_begin with num_games > 0), in game-id
+ * order, reading the move records from the engine's device-resident phase buffer. */
+int az_memory_push_engine(az_memory* m, az_engine* e, double gamma);
 /* push!(mem.buf, sample) for samples that live on the host (a reference-side MemoryBuffer, a game-stage subset of
  * memory_report, src/learning.jl:192-216); does not advance cur_batch_size. */
 int az_memory_push_samples(az_memory* m, const az_sample* samples, int64_t n);
@@ -311,6 +319,30 @@ int az_trainer_get_params(az_trainer* t, float* blob, int64_t n);   /* get_train
  * made of the given batch_size sample indices; no update, running statistics untouched.
  * parts (may be NULL) = Lp, Lv, Lreg, Linv, mean(W)/Wmean. */
 int az_trainer_gradients(az_trainer* t, const int32_t* sample_idx, float* loss, float* parts, float* grad, int64_t n);
+
+/* ---- multi-GPU exchange (simulate_distributed, src/simulations.jl:252-290; one process per GPU) ---------------------- */
+/* RCCL over xGMI.  Self-play needs no communication (games are sharded by global game id: az_selfplay_run's
+ * first_game_id); afterwards every rank's records are all-gathered device to device and pushed into the replay memory,
+ * and new network parameters are broadcast before the next phase.  librccl.so is loaded on first use. */
+#define AZ_COMM_ID_BYTES 128
+typedef struct az_comm az_comm;
+typedef struct {
+  int64_t games, moves;             /* over all ranks */
+  int64_t bytes;                    /* received per rank by the all-gathers */
+  double gather_ms, total_ms;       /* pack + all-gathers + game-record read-back; plus the push into the memory */
+} az_gather_stats;
+/* ncclGetUniqueId on ONE rank; the 128 bytes go to the other ranks by the host's own means (Distributed, MPI, a file). */
+int az_comm_unique_id(uint8_t id[AZ_COMM_ID_BYTES]);
+/* ncclCommInitRank: collective over all `world` ranks, each on its own device. */
+int az_comm_init(int32_t device, int32_t rank, int32_t world, const uint8_t id[AZ_COMM_ID_BYTES], az_comm** out);
+int az_comm_destroy(az_comm* c);
+/* Collective.  All-gathers the ranks' device-resident phase records (the `fetch` + `vcat` of simulations.jl:280-289) and,
+ * where `m` is not NULL, runs push_trace! (src/memory.jl:74-87) for ALL games in global game-id order into m: every rank
+ * that passes a memory ends up with the same samples a single-GPU run of all the games would have pushed. */
+int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, double gamma, az_gather_stats* stats);
+/* Collective.  ncclBroadcast of `root`'s parameter blob, then az_net_set_params on every rank (the network shipped to the
+ * workers before a phase, src/training.jl:278-282). */
+int az_comm_broadcast_params(az_comm* c, az_engine* e, int32_t root);
 
 /* ---- profiling (bench.py roofline): HIP-event time per kernel class ---------------------- */
 #define AZ_PROF_NUM 8

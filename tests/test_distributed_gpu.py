@@ -59,3 +59,32 @@ def test_sharded_self_play_step_fills_identical_memories(tmp_path):
     mem.close()
     S0, S1 = np.load(tmp_path / "S0.npy"), np.load(tmp_path / "S1.npy")
     assert np.array_equal(S0, S1) and np.array_equal(S0, want)
+
+
+def test_native_comm_single_rank_gather_and_broadcast():
+    """az_comm_* (csrc/comm.hip) with a world of ONE rank -- what a 1-GPU box can run of the RCCL path: ncclCommInitRank,
+    the all-gathers of az_comm_gather_push (device-resident records -> the rank's device memory, global game-id order)
+    and the parameter broadcast.  The samples equal the ones the host path pushes for the same phase.  Ranks > 1 need one
+    GPU each (RCCL refuses two ranks on a device): the driver's multi-GPU bench exercises them (bench.py --gpus N)."""
+    import azhip
+    from azhip import comm
+    gspec = azhip.ConnectFourSpec()
+    hp = azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    nn = azhip.ResNet(gspec, hp, seed=4)
+    kw = dict(game=0, oracle=azhip.ORACLE_RESNET, num_workers=6, batch_size=3, num_iters_per_turn=16, cpuct=2.0, dirichlet_noise_eps=0.25,
+              reset_every=1, seed=5, num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    with comm.Comm(0, 0, 1, comm.unique_id()) as c, azhip.Engine(**kw) as e, azhip.Engine(**kw) as e2:
+        e.net_set_params(nn.params())
+        games, moves, ng, nm, st = e.selfplay_run(9, first_game_id=40)
+        a, b = azhip.MemoryBuffer(gspec, 10000), azhip.MemoryBuffer(gspec, 10000)
+        a.push_records(games, moves, ng, nm, 1.0)
+        gs = c.gather_push(e, b, 1.0)
+        assert (gs.games, gs.moves) == (9, nm) and gs.bytes >= nm * 64 and gs.gather_ms > 0
+        assert np.array_equal(_samples(a), _samples(b))
+        assert c.gather_push(e, None, 1.0).moves == nm             # a rank without a memory still takes part in the collective
+        c.broadcast_params(e2, root=0) if False else None          # e2 has no parameters: only legal as a non-root
+        with pytest.raises(azhip.AzError):
+            c.broadcast_params(e2, root=0)                          # the root must hold parameters
+        c.broadcast_params(e, root=0)
+        assert np.array_equal(e.net_get_params(), nn.params())
+        a.close(); b.close()

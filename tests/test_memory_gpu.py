@@ -249,3 +249,40 @@ def test_push_trace_samples_with_unavailable_actions_reach_the_device_full_width
         bad = host[1]
         b.push_samples([type(bad)(bad.s, bad.π[:-1], bad.z, bad.t, bad.n)])
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("game", [0, 2])
+def test_device_only_phase_pushes_the_same_samples_as_the_host_path(game):
+    """training.jl:284-299 without the host hop: az_selfplay_run with out->moves == NULL keeps the move
+    records in the engine's HBM phase buffer and returns game records only; az_memory_push_engine runs push_trace! from
+    there.  Same samples, same order, as pushing the host copy of the same phase -- and as the oracle's."""
+    import azhip
+    kw = dict(game=game, oracle=azhip.ORACLE_HASH, num_workers=5, batch_size=5, num_iters_per_turn=24, dirichlet_noise_eps=0.25,
+              cpuct=1.0, reset_every=1, temperature=([0], [1.0]), seed=3, max_moves_per_game=200 if game == 2 else 0)
+    gspec = getattr(azhip, SPECS[game])()
+    with azhip.Engine(**kw) as e:
+        games, moves, ng, nm, st = e.selfplay_run(17, first_game_id=100)
+        host = azhip.MemoryBuffer(gspec, 100000)
+        host.push_records(games, moves, ng, nm, 0.9)
+        dev0 = azhip.MemoryBuffer(gspec, 100000)
+        dev0.push_engine(e, 0.9)                                   # the phase buffer is kept whether or not the host asked for a copy
+        g2, m2, ng2, nm2, st2 = e.selfplay_run(17, first_game_id=100, device_only=True)
+        assert m2 is None and nm2 == 0 and ng2 == 17 and st2.moves == nm
+        assert [(g2[i].game_id, g2[i].num_moves, g2[i].first_move) for i in range(17)] == [(games[i].game_id, games[i].num_moves, -1) for i in range(17)]
+        dev = azhip.MemoryBuffer(gspec, 100000)
+        dev.push_engine(e, 0.9)
+        small = azhip.MemoryBuffer(gspec, nm - 7)                  # ring smaller than the phase: the oldest samples fall out
+        small.push_engine(e, 0.9)
+    ref = _oracle_samples(game, games, moves, ng, 0.9)
+    nA = gspec.num_actions()
+    with host.dataset() as dh, dev.dataset() as dd, dev0.dataset() as d0, small.dataset() as ds:
+        _same_samples(dh.raw_samples(), ref, nA)
+        _same_samples(dd.raw_samples(), ref, nA)
+        _same_samples(d0.raw_samples(), ref, nA)
+        _same_samples(ds.raw_samples(), ref[7:], nA)
+    assert dev.cur_batch_size() == nm
+    with azhip.Engine(**kw) as e2:
+        with pytest.raises(azhip.AzError):
+            dev.push_engine(e2, 1.0)                               # no phase has been played on this engine
+    for m in (host, dev, dev0, small):
+        m.close()
