@@ -157,6 +157,35 @@ def alone_and_tree(args, blob, dev_index, kernel, waves=200):
     return alone, tree
 
 
+def gather_leg(azhip, blob, dev_index, rank, world, games_per_rank=512, nsims=48):
+    """RCCL trace gather (BASELINE configs[2]'s exchange step) on a short phase: `games_per_rank` Connect-Four games per
+    rank with global game ids, device-only; then one collective puts every rank's samples into every rank's memory."""
+    from azhip import comm
+    c = comm.Comm(dev_index, rank, world, comm.torch_broadcast_id(rank))
+    eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=dev_index, num_workers=games_per_rank,
+                       batch_size=games_per_rank, num_iters_per_turn=nsims, cpuct=2.0, dirichlet_noise_eps=0.25,
+                       dirichlet_noise_alpha=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
+                       num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    if rank == 0:
+        eng.net_set_params(blob)
+    c.broadcast_params(eng, root=0)                                 # the weights reach the other ranks over RCCL
+    mem = azhip.MemoryBuffer(azhip.ConnectFourSpec(), 1 << 22, device=dev_index)
+    eng.selfplay_run(games_per_rank, first_game_id=rank * games_per_rank, device_only=True)
+    c.gather_push(eng, mem, 1.0)                                    # warm-up of the communicator's rings
+    mem.empty()
+    t0 = time.perf_counter()
+    gs = c.gather_push(eng, mem, 1.0)
+    dt = time.perf_counter() - t0
+    out = {"collective": "ncclAllGather (RCCL) of device-resident az_move_rec / az_game_rec + push_trace! on the device",
+           "ranks": world, "games": gs.games, "samples": gs.moves, "bytes_received_per_rank": gs.bytes,
+           "gather_ms": gs.gather_ms, "gather_and_push_ms": gs.total_ms, "wall_ms": 1e3 * dt, "memory_length": len(mem),
+           "GB_per_s_per_rank": gs.bytes / max(gs.gather_ms, 1e-9) / 1e6}
+    mem.close()
+    eng.close()
+    c.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,6 +217,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=args.backend)
+    elif os.environ.get("AZ_BENCH_GATHER"):
+        # single-GPU rehearsal of the N > 1 exchange leg (a world of one rank; the collective code path is the same)
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500), rank=0, world_size=1)
+        args.backend = "gloo"
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libazhip.so has no CPU fallback)")
@@ -245,6 +279,16 @@ def main():
     eng.selfplay_end()
     eng.close()                        # frees its ~10 GB before the extra legs build their own engine
 
+    # After the timed region (N > 1): the exchange step of the path -- every rank plays a short bounded phase device-only
+    # and az_comm_gather_push all-gathers the records over RCCL straight into every rank's device replay memory
+    # (simulate_distributed's fetch + push_trace!, src/simulations.jl:280-289, src/memory.jl:74-87).  Not part of `value`.
+    gather = None
+    if dist is not None:
+        try:
+            gather = gather_leg(azhip, blob, dev_index, rank, world)
+        except Exception as ex:                                     # the headline number must survive a failing extra leg
+            gather = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
     if rank == 0:
         out = {
             "metric": "self-play MCTS sims/sec (Connect-Four, %d parallel games per GPU)" % args.slots,
@@ -289,6 +333,8 @@ def main():
             alone, tree = alone_and_tree(args, blob, dev_index, eng_kernel)
             out["roofline_kernel_alone"] = alone
             out["roofline_tree"] = tree
+        if gather is not None:
+            out["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, hp, args.sims)
         print(json.dumps(out))

@@ -82,7 +82,6 @@ def test_native_comm_single_rank_gather_and_broadcast():
         assert (gs.games, gs.moves) == (9, nm) and gs.bytes >= nm * 64 and gs.gather_ms > 0
         assert np.array_equal(_samples(a), _samples(b))
         assert c.gather_push(e, None, 1.0).moves == nm             # a rank without a memory still takes part in the collective
-        c.broadcast_params(e2, root=0) if False else None          # e2 has no parameters: only legal as a non-root
         with pytest.raises(azhip.AzError):
             c.broadcast_params(e2, root=0)                          # the root must hold parameters
         c.broadcast_params(e, root=0)
