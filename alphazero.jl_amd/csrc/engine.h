@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <map>
 #include <vector>
 #include <unordered_set>
 
@@ -95,6 +96,9 @@ struct az_engine {
   // self-play state
   bool running;
   int total_games, next_game, first_game_id, games_done, wave_in_move, active_slots;
+  // hipGraphs of wave pairs (one slot group only): key = upper bound of the leaves of a launch (decides the tower kernel and
+  // its grid); rebuilt after az_net_set_params (new device pointers)
+  std::map<int, hipGraphExec_t> wave_graphs; int use_graphs;
   bool pending[AZ_MAX_GROUPS];       // the group's last wave awaits its expand + backup (flush_pending)
   int wave_par[AZ_MAX_GROUPS];       // parity of the group's last wave: which of its two leaf counters is current
   int group_active[AZ_MAX_GROUPS];   // active slots per slot group (host count; bounds the leaves of a network launch)

@@ -77,10 +77,12 @@ def test_explore_matches_oracle(game, oracle):
 @pytest.mark.parametrize("game,nsims,ngames,workers,batch", [(1, 64, 32, 32, 32), (0, 100, 24, 8, 8), (2, 60, 12, 8, 8),
                                                               (1, 64, 40, 32, 8), (0, 100, 24, 8, 4)])
 @pytest.mark.parametrize("oracle", [0, 1, 3])
-def test_selfplay_traces_match_oracle(game, nsims, ngames, workers, batch, oracle):
+def test_selfplay_traces_match_oracle(game, nsims, ngames, workers, batch, oracle, monkeypatch):
     """Whole self-play phase (simulate): every move record, visit count, action, reward, node count.
     batch < workers runs workers/batch interleaved slot groups on separate streams: same results."""
     kw = dict(gamma=1.0, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0, temp_xs=(0, 4, 8), temp_ys=(1.0, 1.0, 0.3))
+    if oracle == 1 and batch == workers:
+        monkeypatch.setenv("AZHIP_GRAPH", "1")        # the opt-in hipGraph replay of wave pairs (single slot group) gives the same records
     games, moves, nm = R.simulate(game, oracle, ngames, workers, nsims, reset_every=2, seed=11, **kw)
     with _engine(game, oracle, num_workers=workers, batch_size=batch, num_iters_per_turn=nsims, cpuct=2.0,
                  dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=((0, 4, 8), (1.0, 1.0, 0.3)),
