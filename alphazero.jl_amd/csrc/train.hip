@@ -8,65 +8,21 @@
 // Structure of this version: the F -> F tower convolutions run on hand-written MFMA kernels in all three passes --
 // forward and data gradient on k_conv16_layer (the tower's implicit GEMM as a stand-alone layer), the weight gradient
 // on k_wgrad16 (resnet16.h); the stem (K = 27), the 1x1 head convolutions and the dense layers are small plain fp32
-// GEMMs through rocBLAS (im2col by a hand-written gather where needed), which the task's rules allow for plain
-// library GEMMs; everything that is not a GEMM is hand-written here: batch-norm statistics / apply / backward with
+// GEMMs on a hand-written MFMA kernel (gemm.h; im2col by a hand-written gather where needed);
+// everything that is not a GEMM is hand-written here too: batch-norm statistics / apply / backward with
 // deterministic two-stage column reductions, ReLU and skip wiring, the loss with its analytic gradient (softmax,
 // mask normalisation, KL, invalid-mass penalty, tanh / MSE), parameter layout maps between Flux's arrays and the
-// GEMM matrices, Adam / Nesterov and the running statistics.  rocBLAS is dlopen'ed when the first trainer is
-// created, so self-play users never load it.  The fused inference tower is untouched: after training the new
+// GEMM matrices, Adam / Nesterov and the running statistics.  No library call is left in the step (round 1 used a
+// dlopen'ed rocBLAS for the small GEMMs).  The fused inference tower is untouched: after training the new
 // parameters go back through az_net_set_params.
 //
 #include "engine.h"
-#include <dlfcn.h>
 
-// ------------------------------------------------------------------------------------------ rocBLAS by dlopen
-namespace rb {
-typedef void* handle_t;
-enum { OP_N = 111, OP_T = 112 };                   // rocblas_operation_none / _transpose
-typedef int (*create_t)(handle_t*);
-typedef int (*destroy_t)(handle_t);
-typedef int (*set_stream_t)(handle_t, hipStream_t);
-typedef int (*set_atomics_t)(handle_t, int);
-typedef int (*sgemm_t)(handle_t, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
-struct Lib {
-  void* so = nullptr;
-  create_t create = nullptr; destroy_t destroy = nullptr; set_stream_t set_stream = nullptr; set_atomics_t set_atomics = nullptr;
-  sgemm_t sgemm = nullptr;
-};
-static Lib g_lib;
-static int load() {
-  if (g_lib.so) return AZ_OK;
-  // By PATH, next to the HIP runtime this library is linked with: a bare soname would be satisfied by whatever copy
-  // another module of the process has loaded (PyTorch bundles its own rocBLAS, bound to its own HIP runtime), and a
-  // handle created there fails or works against a different runtime.
-  void* so = nullptr;
-  {
-    Dl_info info;
-    if (dladdr(reinterpret_cast<void*>(&hipGetLastError), &info) && info.dli_fname) {
-      std::string p(info.dli_fname);
-      const size_t k = p.rfind('/');
-      if (k != std::string::npos) so = dlopen((p.substr(0, k) + "/librocblas.so").c_str(), RTLD_NOW | RTLD_LOCAL);
-    }
-  }
-  if (!so) so = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
-  if (!so) so = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-  if (!so) return fail(AZ_ERR_HIP, "cannot load librocblas.so (%s): the training step needs rocBLAS for its GEMMs", dlerror());
-  g_lib.create = (create_t)dlsym(so, "rocblas_create_handle"); g_lib.destroy = (destroy_t)dlsym(so, "rocblas_destroy_handle");
-  g_lib.set_stream = (set_stream_t)dlsym(so, "rocblas_set_stream"); g_lib.set_atomics = (set_atomics_t)dlsym(so, "rocblas_set_atomics_mode");
-  g_lib.sgemm = (sgemm_t)dlsym(so, "rocblas_sgemm");
-  if (!g_lib.create || !g_lib.destroy || !g_lib.set_stream || !g_lib.sgemm) return fail(AZ_ERR_HIP, "librocblas.so lacks the expected symbols");
-  g_lib.so = so;
-  return AZ_OK;
-}
-// row-major C[M][N] = alpha * op(A) * op(B) + beta * C  (A is [M][K], or [K][M] when ta; B is [K][N], or [N][K] when tb)
-static int gemm(handle_t h, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
-                float beta, float* C, int ldc) {
-  if (M == 0 || N == 0) return AZ_OK;
-  const int st = g_lib.sgemm(h, tb ? OP_T : OP_N, ta ? OP_T : OP_N, N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc);
-  if (st != 0) return fail(AZ_ERR_HIP, "rocblas_sgemm failed with status %d (M %d N %d K %d)", st, M, N, K);
-  return AZ_OK;
-}
-}  // namespace rb
+// ------------------------------------------------------------------------------------------ small GEMMs
+#include "gemm.h"
+struct az_trainer;
+static int tr_gemm(az_trainer* t, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                   float beta, float* C, int ldc);
 
 // ------------------------------------------------------------------------------------------ kernels
 // work[j] = blob[map[j]]  /  gblob[map[j]] = gwork[j]   (parameter layout maps, built on the host once)
@@ -348,7 +304,7 @@ struct az_trainer {
   az_train_cfg cfg;
   int game, device; GameInfo gi;
   hipStream_t stream;
-  rb::handle_t rbh;
+  float* gemm_ws; size_t gemm_ws_floats;                                     // split-reduction workspace of gemm_f32
   int B, nblocks, F, npf, nvf, nA;
   long long R;
   size_t nparams;
@@ -374,6 +330,11 @@ template <class T> static int tr_alloc(az_trainer* t, T** p, size_t n, bool zero
   return AZ_OK;
 }
 static inline unsigned tr_grid(long long n) { return (unsigned)((n + 255) / 256); }
+static int tr_gemm(az_trainer* t, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                   float beta, float* C, int ldc) {
+  gemm_f32(t->stream, t->gemm_ws, t->gemm_ws_floats, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+  return AZ_OK;
+}
 
 extern "C" int az_train_cfg_init(az_train_cfg* c) {
   if (!c) return fail(AZ_ERR_BAD_ARG, "cfg is NULL");
@@ -389,7 +350,6 @@ extern "C" int az_train_cfg_init(az_train_cfg* c) {
 extern "C" int az_trainer_destroy(az_trainer* t) {
   if (!t) return AZ_OK;
   (void)hipSetDevice(t->device);
-  if (t->rbh) rb::g_lib.destroy(t->rbh);
   for (void* p : t->allocs) (void)hipFree(p);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;
@@ -567,7 +527,7 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
     if (l == 0) hipLaunchKernelGGL((k_tr_im2col<true>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
     else if (need_col) hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cin / 4))), dim3(256), 0, st, (const float4*)in, R, c.cin / 4, gi.W, gi.H, (float4*)c.col);
     if (c.mfma) AZCHK(tr_conv16(t, in, t->work + c.wk_ffwd, c.g));         // (the im2col above feeds the weight gradient)
-    else AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
+    else AZCHK(tr_gemm(t, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
     { TrFinal fin{}; fin.mode = 1; fin.R = R; fin.momentum = t->cfg.batch_norm_momentum; fin.bias = blob + c.off_b; fin.mean = c.mean; fin.invstd = c.invstd;
       fin.run_mean = blob + c.off_bn + 2 * c.cout; fin.run_var = blob + c.off_bn + 3 * c.cout;
       AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout, fin)); }
@@ -577,18 +537,18 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
   }
   const float* trunk = t->convs[ntower - 1].a;
   for (TrConv* c : {&hp, &hv}) {
-    AZCHK(rb::gemm(t->rbh, false, false, (int)R, c->cout, F, 1.f, trunk, F, t->work + c->wk_wm, c->cout, 0.f, c->g, c->cout));
+    AZCHK(tr_gemm(t, false, false, (int)R, c->cout, F, 1.f, trunk, F, t->work + c->wk_wm, c->cout, 0.f, c->g, c->cout));
     { TrFinal fin{}; fin.mode = 1; fin.R = R; fin.momentum = t->cfg.batch_norm_momentum; fin.bias = blob + c->off_b; fin.mean = c->mean; fin.invstd = c->invstd;
       fin.run_mean = blob + c->off_bn + 2 * c->cout; fin.run_var = blob + c->off_bn + 3 * c->cout;
       AZCHK(tr_colsum<0>(t, c->g, nullptr, nullptr, nullptr, nullptr, R, c->cout, fin)); }
     hipLaunchKernelGGL(k_tr_bn_apply, dim3(tr_grid(R * c->cout)), dim3(256), 0, st, c->g, c->mean, c->invstd, blob + c->off_bn, blob + c->off_bn + c->cout, (const float*)nullptr, R * c->cout, c->cout, c->a);
   }
   // dense heads: rows of hp.a / hv.a of one board are contiguous: [B][P*nf] with k = p*nf + f
-  AZCHK(rb::gemm(t->rbh, false, false, B, A, P * npf, 1.f, hp.a, P * npf, t->work + t->wk_pd, A, 0.f, t->logits, A));
+  AZCHK(tr_gemm(t, false, false, B, A, P * npf, 1.f, hp.a, P * npf, t->work + t->wk_pd, A, 0.f, t->logits, A));
   hipLaunchKernelGGL(k_tr_bias_act, dim3(tr_grid((long long)B * A)), dim3(256), 0, st, t->logits, blob + t->off_pd_b, (long long)B * A, A, 0);
-  AZCHK(rb::gemm(t->rbh, false, false, B, F, P * nvf, 1.f, hv.a, P * nvf, t->work + t->wk_v1, F, 0.f, t->v1, F));
+  AZCHK(tr_gemm(t, false, false, B, F, P * nvf, 1.f, hv.a, P * nvf, t->work + t->wk_v1, F, 0.f, t->v1, F));
   hipLaunchKernelGGL(k_tr_bias_act, dim3(tr_grid((long long)B * F)), dim3(256), 0, st, t->v1, blob + t->off_v1_b, (long long)B * F, F, 1);
-  AZCHK(rb::gemm(t->rbh, false, false, B, 1, F, 1.f, t->v1, F, t->work + t->wk_v2, 1, 0.f, t->tpre, 1));
+  AZCHK(tr_gemm(t, false, false, B, 1, F, 1.f, t->v1, F, t->work + t->wk_v2, 1, 0.f, t->tpre, 1));
   hipLaunchKernelGGL(k_tr_bias_act, dim3(tr_grid(B)), dim3(256), 0, st, t->tpre, blob + t->off_v2_b, (long long)B, 1, 0);
   // ---------------- loss ----------------
   // mean(W)/Wmean / sum(W) = 1 / (B Wmean): the gradient scale needs no reduction first (learning.jl:88)
@@ -601,19 +561,19 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
   float* gw = t->gwork;
   float* gb = t->gblob;
   // policy: dWpd = hp_flat^T dlogits ; dbp = colsum(dlogits) ; dhp = dlogits Wpd^T
-  AZCHK(rb::gemm(t->rbh, true, false, P * npf, A, B, 1.f, hp.a, P * npf, t->dlogits, A, 0.f, gw + t->wk_pd, A));
+  AZCHK(tr_gemm(t, true, false, P * npf, A, B, 1.f, hp.a, P * npf, t->dlogits, A, 0.f, gw + t->wk_pd, A));
   { TrFinal fin{}; fin.mode = 3; fin.out0 = gb + t->off_pd_b; AZCHK(tr_colsum<2>(t, t->dlogits, nullptr, nullptr, nullptr, nullptr, B, A, fin)); }
   float* dhp = t->dact;                                            // [R][npf]
-  AZCHK(rb::gemm(t->rbh, false, true, B, P * npf, A, 1.f, t->dlogits, A, t->work + t->wk_pd, A, 0.f, dhp, P * npf));
+  AZCHK(tr_gemm(t, false, true, B, P * npf, A, 1.f, t->dlogits, A, t->work + t->wk_pd, A, 0.f, dhp, P * npf));
   // value: dt -> dv1 = (dt wv2^T) .* (v1 > 0) ; dwv2 = v1^T dt ; db2 = sum dt ; dWv1 = hv_flat^T dv1 ; db1 ; dhv = dv1 Wv1^T
-  AZCHK(rb::gemm(t->rbh, true, false, F, 1, B, 1.f, t->v1, F, t->dt, 1, 0.f, gw + t->wk_v2, 1));
+  AZCHK(tr_gemm(t, true, false, F, 1, B, 1.f, t->v1, F, t->dt, 1, 0.f, gw + t->wk_v2, 1));
   { TrFinal fin{}; fin.mode = 3; fin.out0 = gb + t->off_v2_b; AZCHK(tr_colsum<2>(t, t->dt, nullptr, nullptr, nullptr, nullptr, B, 1, fin)); }
-  AZCHK(rb::gemm(t->rbh, false, true, B, F, 1, 1.f, t->dt, 1, t->work + t->wk_v2, 1, 0.f, t->dv1, F));
+  AZCHK(tr_gemm(t, false, true, B, F, 1, 1.f, t->dt, 1, t->work + t->wk_v2, 1, 0.f, t->dv1, F));
   hipLaunchKernelGGL(k_tr_relu_bwd, dim3(tr_grid((long long)B * F)), dim3(256), 0, st, t->dv1, t->v1, (long long)B * F);
-  AZCHK(rb::gemm(t->rbh, true, false, P * nvf, F, B, 1.f, hv.a, P * nvf, t->dv1, F, 0.f, gw + t->wk_v1, F));
+  AZCHK(tr_gemm(t, true, false, P * nvf, F, B, 1.f, hv.a, P * nvf, t->dv1, F, 0.f, gw + t->wk_v1, F));
   { TrFinal fin{}; fin.mode = 3; fin.out0 = gb + t->off_v1_b; AZCHK(tr_colsum<2>(t, t->dv1, nullptr, nullptr, nullptr, nullptr, B, F, fin)); }
   float* dhv = t->dact2;                                           // [R][nvf]
-  AZCHK(rb::gemm(t->rbh, false, true, B, P * nvf, F, 1.f, t->dv1, F, t->work + t->wk_v1, F, 0.f, dhv, P * nvf));
+  AZCHK(tr_gemm(t, false, true, B, P * nvf, F, 1.f, t->dv1, F, t->work + t->wk_v1, F, 0.f, dhv, P * nvf));
   // head convolutions: BN backward, weight / bias gradients, gradient into the trunk
   float* dtrunk = t->dcol;                                         // [R][F] (front of the big scratch)
   bool first = true;
@@ -622,10 +582,10 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
     { TrFinal fin{}; fin.mode = 2; fin.dgamma = gb + c->off_bn; fin.dbeta = gb + c->off_bn + c->cout;
       AZCHK(tr_colsum<1>(t, dh, c->a, c->g, c->mean, c->invstd, R, c->cout, fin)); }
     hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c->cout)), dim3(256), 0, st, dh, c->a, c->g, c->mean, c->invstd, blob + c->off_bn, t->sums, R, R * c->cout, c->cout, dh, (float*)nullptr);
-    AZCHK(rb::gemm(t->rbh, true, false, F, c->cout, (int)R, 1.f, trunk, F, dh, c->cout, 0.f, gw + c->wk_wm, c->cout));
+    AZCHK(tr_gemm(t, true, false, F, c->cout, (int)R, 1.f, trunk, F, dh, c->cout, 0.f, gw + c->wk_wm, c->cout));
     // the bias of a convolution that feeds a train-mode BatchNorm has gradient sum(dg) = gamma invstd (sum dy - R m0 - m1 sum xhat)
     // = 0 exactly (the batch mean absorbs it): its slot in gblob stays 0 and only the L2 term moves it
-    AZCHK(rb::gemm(t->rbh, false, true, (int)R, F, c->cout, 1.f, dh, c->cout, t->work + c->wk_wm, c->cout, first ? 0.f : 1.f, dtrunk, F));
+    AZCHK(tr_gemm(t, false, true, (int)R, F, c->cout, 1.f, dh, c->cout, t->work + c->wk_wm, c->cout, first ? 0.f : 1.f, dtrunk, F));
     first = false;
   }
   // ---------------- backward: tower ----------------
@@ -640,7 +600,7 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
     hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, t->dact, c.a, c.g, c.mean, c.invstd, blob + c.off_bn, t->sums, R, R * c.cout, c.cout,
                        t->dact, second ? t->dact2 : (float*)nullptr);
     if (c.mfma && t->wg_mfma) AZCHK(tr_wgrad16(t, t->convs[l - 1].a, t->dact, gw + c.wk_wm));
-    else AZCHK(rb::gemm(t->rbh, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, t->dact, c.cout, 0.f, gw + c.wk_wm, c.cout));
+    else AZCHK(tr_gemm(t, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, t->dact, c.cout, 0.f, gw + c.wk_wm, c.cout));
     if (l == 0) break;
     // data gradient: da_prev = im2col(dg) * Wrot
     if (c.mfma) {
@@ -648,7 +608,7 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
       HIPCHK(hipMemcpyAsync(t->dact, t->dcol, sizeof(float) * (size_t)R * c.cin, hipMemcpyDeviceToDevice, st));
     } else {
       hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cout / 4))), dim3(256), 0, st, (const float4*)t->dact, R, c.cout / 4, gi.W, gi.H, (float4*)t->dcol);
-      AZCHK(rb::gemm(t->rbh, false, false, (int)R, c.cin, 9 * c.cout, 1.f, t->dcol, 9 * c.cout, t->work + c.wk_wrot, c.cin, 0.f, t->dact, c.cin));
+      AZCHK(tr_gemm(t, false, false, (int)R, c.cin, 9 * c.cout, 1.f, t->dcol, 9 * c.cout, t->work + c.wk_wrot, c.cin, 0.f, t->dact, c.cin));
     }
     const bool first_of_block = (l % 2) == 1;                      // conv1: its input is the block input, which also gets the skip share
     if (first_of_block) hipLaunchKernelGGL(k_tr_add, dim3(tr_grid(R * F)), dim3(256), 0, st, t->dact, t->dact2, R * F);
@@ -704,18 +664,16 @@ extern "C" int az_trainer_create(az_engine* e, az_dataset* d, const az_train_cfg
   const int64_t B = std::min<int64_t>(cfg->batch_size, d->n);     // batchsize = min(params.batch_size, length(W)), learning.jl:113
   if (cfg->batch_size < 2 || B < 2) return fail(AZ_ERR_BAD_ARG, "batch_size and the data set must have at least 2 samples (batch statistics)");
   if (!(cfg->rewards_renormalization > 0.0)) return fail(AZ_ERR_BAD_ARG, "rewards_renormalization must be > 0");
-  AZCHK(rb::load());
   az_trainer* t = new (std::nothrow) az_trainer();
   if (!t) return fail(AZ_ERR_HIP, "out of host memory");
-  t->e = e; t->d = d; t->cfg = *cfg; t->game = e->cfg.game; t->device = e->device; t->gi = e->gi; t->stream = nullptr; t->rbh = nullptr;
+  t->e = e; t->d = d; t->cfg = *cfg; t->game = e->cfg.game; t->device = e->device; t->gi = e->gi; t->stream = nullptr; t->gemm_ws = nullptr; t->gemm_ws_floats = 0;
   t->B = (int)B; t->nblocks = e->cfg.num_blocks; t->F = e->cfg.num_filters; t->npf = e->cfg.num_policy_head_filters; t->nvf = e->cfg.num_value_head_filters;
   t->nA = e->gi.A; t->R = (long long)B * e->gi.P; t->nparams = e->blob.size();
   t->perm_pos = 0; t->epoch = 0; t->step = 0; t->b1t = 1.0f; t->b2t = 1.0f;
   int st = [&]() -> int {
     HIPCHK(hipStreamCreate(&t->stream));
-    { const int rs = rb::g_lib.create(&t->rbh); if (rs != 0) { t->rbh = nullptr; return fail(AZ_ERR_HIP, "rocblas_create_handle failed with status %d", rs); } }
-    rb::g_lib.set_stream(t->rbh, t->stream);
-    if (rb::g_lib.set_atomics) rb::g_lib.set_atomics(t->rbh, 0);   // rocblas_atomics_not_allowed: reproducible GEMMs
+    t->gemm_ws_floats = (size_t)4 << 20;                            // 16 MB: partial tiles of the split weight-gradient reductions
+    AZCHK(tr_alloc(t, &t->gemm_ws, t->gemm_ws_floats));
     AZCHK(trainer_build(t));
     return AZ_OK;
   }();

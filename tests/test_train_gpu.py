@@ -97,7 +97,7 @@ def _rel_err_by_array(game, hp, got, want):
             continue
         denom = max(np.abs(w).max(), 1e-7)
         worst = max(worst, np.abs(g - w).max() / denom) if np.abs(w).max() > 1e-6 else worst
-        assert np.abs(g - w).max() <= 5e-3 * denom + 2e-6, (name, np.abs(g - w).max(), denom)
+        assert np.abs(g - w).max() <= 1e-3 * denom + 2e-6, (name, np.abs(g - w).max(), denom)
     return worst
 
 
