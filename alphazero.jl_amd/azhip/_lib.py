@@ -36,7 +36,7 @@ class EngineCfg(C.Structure):
         ("fill_batches", C.c_int32), ("flip_probability", C.c_double), ("seed", C.c_uint64),
         ("max_nodes_per_slot", C.c_int32), ("max_moves_per_game", C.c_int32),
         ("num_blocks", C.c_int32), ("num_filters", C.c_int32),
-        ("num_policy_head_filters", C.c_int32), ("num_value_head_filters", C.c_int32),
+        ("num_policy_head_filters", C.c_int32), ("num_value_head_filters", C.c_int32), ("net_bf16", C.c_int32),
     ]
 
 

@@ -87,10 +87,12 @@ class ResNet:
 
     HyperParams = ResNetHP
 
-    def __init__(self, gspec, hyper, params=None, seed=2026, device=0):
+    def __init__(self, gspec, hyper, params=None, seed=2026, device=0, bf16=False):
+        """bf16: evaluate the residual tower in bfloat16 (az_engine_cfg.net_bf16, csrc/resnet16b.h); the parameters stay fp32"""
         self.gspec = gspec
         self.hyper = hyper
         self.device = device
+        self.bf16 = bool(bf16)
         self._params = random_params(gspec.game_id, hyper, seed) if params is None else np.asarray(params, dtype=np.float32).copy()
         if self._params.size != num_parameters(gspec.game_id, hyper):
             raise ValueError("parameter blob has the wrong size")
@@ -134,7 +136,7 @@ class ResNet:
         self._test_mode = bool(mode)
 
     def copy_(self):
-        nn = ResNet(self.gspec, self.hyper, params=self._params, device=self.device)
+        nn = ResNet(self.gspec, self.hyper, params=self._params, device=self.device, bf16=self.bf16)
         nn._on_gpu, nn._test_mode = self._on_gpu, self._test_mode
         return nn
 
@@ -153,7 +155,7 @@ class ResNet:
             raise ValueError("only 3x3 kernels are supported")
         return dict(num_blocks=h.num_blocks, num_filters=h.num_filters,
                     num_policy_head_filters=h.num_policy_head_filters,
-                    num_value_head_filters=h.num_value_head_filters)
+                    num_value_head_filters=h.num_value_head_filters, net_bf16=1 if self.bf16 else 0)
 
     def _eng(self):
         if self._engine is None:

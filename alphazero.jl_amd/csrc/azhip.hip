@@ -117,6 +117,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     int hf = c->num_policy_head_filters + c->num_value_head_filters;
     if (c->num_policy_head_filters < 1 || c->num_value_head_filters < 1 || hf > c->num_filters) return fail(AZ_ERR_BAD_ARG, "head filters %d/%d unsupported (policy + value must be <= num_filters)", c->num_policy_head_filters, c->num_value_head_filters);
     if (c->num_blocks < 0 || c->num_blocks > 64) return fail(AZ_ERR_BAD_ARG, "num_blocks out of range");
+    if (c->net_bf16 != 0 && c->net_bf16 != 1) return fail(AZ_ERR_BAD_ARG, "net_bf16 must be 0 or 1");
   }
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
@@ -388,6 +389,29 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
       s16_w[((size_t)ct * NS + s) * 64 + ln] = blob[wi + 3 * (wj + 3 * (ci + (size_t)C * co))];
     }
   }
+  // k_tower16b fragments (bf16, 16x16x32 MFMA): lane l of k step ks supplies input channels ks*32 + (l >> 4)*8 + e, e = 0..7,
+  // for output column ct*16 + (l & 15); values rounded to nearest even
+  auto to_bf16 = [](float f) -> uint16_t {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  };
+  std::vector<uint16_t> c16b_w(8), h16b_w(8);
+  const int KSB = F / 32;
+  if (c.net_bf16) {
+    c16b_w.assign((size_t)2 * nb * 9 * CT * KSB * 64 * 8 + 8, 0);
+    const float* wc = blob + (size_t)9 * C * F + 5 * F;
+    for (int l = 0; l < 2 * nb; ++l) {
+      for (int t = 0; t < 9; ++t) {
+        int dy = t / 3 - 1, dx = t % 3 - 1, wi = 1 - dx, wj = 1 - dy;
+        for (int ct = 0; ct < CT; ++ct) for (int ks = 0; ks < KSB; ++ks) for (int ln = 0; ln < 64; ++ln) for (int el = 0; el < 8; ++el) {
+          int ci = ks * 32 + (ln >> 4) * 8 + el, co = ct * 16 + (ln & 15);
+          c16b_w[(((((size_t)l * 9 + t) * CT + ct) * KSB + ks) * 64 + ln) * 8 + el] = to_bf16(wc[wi + 3 * (wj + 3 * (ci + (size_t)F * co))]);
+        }
+      }
+      wc += (size_t)9 * F * F + 5 * F;
+    }
+  }
   // heads: concatenate the two 1x1 convolutions along the output channel
   std::vector<float> hw((size_t)F * HF, 0.0f), hb(HF, 0.0f), hbn((size_t)4 * HF, 0.0f), head_w((size_t)(HF / 32) * (F / 8) * 64 * 4), head_ss(2 * HF);
   for (int i = 0; i < HF; ++i) { hbn[i] = 0.0f; hbn[3 * HF + i] = 1.0f; }   // padded channels: gamma 0, var 1
@@ -411,6 +435,13 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   for (int ct = 0; ct < CT; ++ct) for (int sq = 0; sq < CT; ++sq) for (int ln = 0; ln < 64; ++ln) for (int q = 0; q < 4; ++q) {
     int s = 4 * sq + q, g = ln >> 4, ci = (g & 1) * (F / 2) + 2 * s + (g >> 1), co = ct * 16 + (ln & 15);
     h16_w[((((size_t)ct) * CT + sq) * 64 + ln) * 4 + q] = hw[ci + (size_t)F * co];
+  }
+  if (c.net_bf16) {
+    h16b_w.assign((size_t)CT * KSB * 64 * 8, 0);
+    for (int ct = 0; ct < CT; ++ct) for (int ks = 0; ks < KSB; ++ks) for (int ln = 0; ln < 64; ++ln) for (int el = 0; el < 8; ++el) {
+      int ci = ks * 32 + (ln >> 4) * 8 + el, co = ct * 16 + (ln & 15);
+      h16b_w[((((size_t)ct) * KSB + ks) * 64 + ln) * 8 + el] = to_bf16(hw[ci + (size_t)F * co]);
+    }
   }
   bn_fold(hb.data(), hbn.data(), HF, head_ss.data(), head_ss.data() + HF);
   // dense layers, k-major with k = p*nf + f; Flux Dense W[out + nout*(p + P*f)]
@@ -478,6 +509,25 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
     for (int k = 0; k < 3; ++k) n16.geo[k] = e->d_geo[k];
   }
   e->net16 = n16;
+  {
+    Net16bDev nbd;
+    memset(&nbd, 0, sizeof nbd);
+    nbd.nblocks = nb; nbd.stem_w = n16.stem_w; nbd.stem_ss = n16.stem_ss; nbd.conv_ss = n16.conv_ss; nbd.head_ss = n16.head_ss;
+    for (int k = 0; k < 3; ++k) nbd.geo[k] = e->d_geo[k];
+    if (c.net_bf16) {
+      auto up16 = [&](const std::vector<uint16_t>& h, const bf16x8v** d) -> int {
+        uint16_t* q = nullptr;
+        AZCHK(dalloc(e, &q, h.size(), false));
+        e->allocs.pop_back();
+        e->net_allocs.push_back(q);
+        HIPCHK(hipMemcpyAsync(q, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
+        *d = (const bf16x8v*)q;
+        return AZ_OK;
+      };
+      AZCHK(up16(c16b_w, &nbd.conv_w)); AZCHK(up16(h16b_w, &nbd.head_w));
+    }
+    e->net16b = nbd;
+  }
   HIPCHK(hipStreamSynchronize(e->stream));
   e->net = nd;
   e->net_loaded = true;

@@ -20,6 +20,7 @@
 #include "games.h"
 #include "resnet.h"
 #include "resnet16.h"
+#include "resnet16b.h"
 #include "tree.h"
 
 // ------------------------------------------------------------------------------- errors
@@ -79,6 +80,7 @@ struct az_engine {
   bool net_loaded;
   std::vector<float> blob;
   NetDev net;
+  Net16bDev net16b;              // bf16 fragments (cfg.net_bf16)
   Net16Dev net16;                // k_tower16 fragments (64 filters)
   uint16_t* d_geo[3];            // Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h)
   char last_tower[96];           // name of the tower kernel that served the most recent network launch (az_net_last_kernel)

@@ -12,6 +12,10 @@ template <class Gm, int F> static int set_kernel_attrs_f() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
   }
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 3>::BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 3>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   return AZ_OK;
@@ -47,6 +51,7 @@ template <class Gm> static int set_kernel_attrs(az_engine* e) {
 static void note_tower(az_engine* e, int tw, int F) {
   static const char* const gn[] = {"ConnectFour", "TicTacToe", "Mancala"};
   const char* g = gn[e->cfg.game];
+  if (e->cfg.net_bf16) { snprintf(e->last_tower, sizeof e->last_tower, "k_tower16b<%s,%d,NT=%d>", g, F, tw == 3 ? 3 : 11); return; }
   if (tw == 21) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d>", g, F);
   else if (tw == 3) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=3>", g, F);
   else if (tw == 16) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=11>", g, F);
@@ -61,7 +66,16 @@ static void note_tower(az_engine* e, int tw, int F) {
 // 4 x 176 < 6 x 128; 128 leaves: 1 x 48 << 1 x 128 (measured tools/small_batch.sh: 0.39 vs 0.80 ms per wave at
 // 128 filters).  Returns 16, 32 or 3.
 template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
-  if (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64)) return e->tower_pick;
+  if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64))) return e->tower_pick;
+  if (e->cfg.net_bf16) {                                           // k_tower16b: 11 or 3 row tiles
+    if (e->tower_pick == 3 || e->tower_pick == 16) return e->tower_pick;
+    const long cu2 = e->num_cu > 0 ? e->num_cu : 256;
+    const long a16 = (n + T16B<Gm, F>::TB - 1) / T16B<Gm, F>::TB, a3 = (n + T16B<Gm, F, 3>::TB - 1) / T16B<Gm, F, 3>::TB;
+    const long per = F == 64 ? 2 : 1;                               // workgroups per CU
+    const double d16 = (double)((a16 + per * cu2 - 1) / (per * cu2)) * T16B<Gm, F>::RPAD;
+    const double d3 = 1.1 * (double)((a3 + per * cu2 - 1) / (per * cu2)) * T16B<Gm, F, 3>::RPAD;
+    return d3 <= d16 ? 3 : 16;
+  }
   const long cu = e->num_cu > 0 ? e->num_cu : 256;
   const long b16 = (n + T16<Gm, F>::TB - 1) / T16<Gm, F>::TB, b32 = (n + TOWER_ROWS / Gm::P - 1) / (TOWER_ROWS / Gm::P);
   const long b3 = (n + T16<Gm, F, 3>::TB - 1) / T16<Gm, F, 3>::TB;
@@ -93,7 +107,11 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
   constexpr int TB21 = T16P<Gm, 64>::TB, THR21 = T16P<Gm, 64>::THREADS, LDS21 = T16P<Gm, 64>::BYTES;
   const int tw = pick_tower<Gm, F>(e, n_max);
   note_tower(e, tw, F);
-  if (tw == 21) {
+  if (e->cfg.net_bf16) {
+    constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, 3>::TB, LDSb3 = T16B<Gm, F, 3>::BYTES;
+    if (tw == 3) LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b<Gm, F, FROM_PLANES, 3>), (n_max + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
+    else LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b<Gm, F, FROM_PLANES, 11>), (n_max + TBb - 1) / TBb, THRb, LDSb, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
+  } else if (tw == 21) {
     if constexpr (F == 64)
       LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
   } else if (tw == 3)
@@ -132,7 +150,11 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   const int* nev = v.n_eval + e->wave_par[g];                      // the leaf counter of this wave (k_tree)
   const int tw = pick_tower<Gm, F>(e, N);
   note_tower(e, tw, F);
-  if (tw == 21) {
+  if (e->cfg.net_bf16) {
+    constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, 3>::TB, LDSb3 = T16B<Gm, F, 3>::BYTES;
+    if (tw == 3) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 3>), (N + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+    else LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 11>), (N + TBb - 1) / TBb, THRb, LDSb, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+  } else if (tw == 21) {
     if constexpr (F == 64)
       LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   } else if (tw == 3)

@@ -1,0 +1,240 @@
+// resnet16b.h -- k_tower16b: the residual tower in bfloat16 on v_mfma_f32_16x16x32_bf16 (BASELINE configs[4]: "ResNet-10x128 bf16").
+//
+// Same shape as k_tower16 (resnet16.h): a workgroup owns TB whole boards = NT row tiles of 16 in ONE LDS activation
+// buffer, rows in Geo16's border-class order (taps that fall off the board skipped per tile), wavefront w owns output
+// channels 16 w .. 16 w + 15 of every tile, stem + every residual block + both 1x1 head convolutions without leaving the CU.
+// What differs:
+//   * activations live in LDS as bf16 ([RPAD + 1][F + 8], 272-byte rows at F = 128: twice the boards-per-byte of fp32, so
+//     the 128-filter tower keeps two workgroups per CU), weights are bf16 fragments, accumulation is fp32 in the MFMA;
+//     the folded batch norm, the residual add and the ReLU run in fp32 on the accumulators and the result is rounded to
+//     bf16 (round to nearest even, v_cvt_pk_bf16_f32) when it is written back -- the skip connection adds the ROUNDED
+//     block input, i.e. exactly what the next convolution reads;
+//   * one MFMA consumes 32 input channels: lane (row r = lane & 15, group g = lane >> 4) supplies channels
+//     32 ks + 8 g .. + 7 of row r as one ds_read_b128, and the matching weight fragment holds W[those channels][co]; the
+//     hardware's pairing of k within a group is irrelevant because A and B use the same one;
+//   * the stem (K = 27) stays on the fp32 MFMA with the fp32 planes (it is 0.1 % of the work), the head features leave
+//     in fp32 for k_heads_mfma, so everything outside the tower is unchanged.
+// Numerics: NOT the fp32 contract.  tests/test_net_bf16_gpu.py holds it to (a) a torch emulation of exactly this scheme
+// (bf16-rounded weights and activations, wide accumulation) within 2e-3 and (b) the fp32 oracle within the stated bf16
+// tolerance; searches run with it are deterministic but not comparable move for move with the fp32 oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "resnet16.h"
+
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+
+struct Net16bDev {
+  int nblocks;
+  const float* stem_w;      // fp32 fragments of the stem, as Net16Dev
+  const float* stem_ss;     // [2][F]
+  const bf16x8v* conv_w;    // [2*nblocks][9][F/16 col tiles][F/32 k steps][64] x 8 bf16
+  const float* conv_ss;     // [2*nblocks][2][F]
+  const bf16x8v* head_w;    // [F/16][F/32][64] x 8 bf16
+  const float* head_ss;     // [2][F]
+  const uint16_t* geo[3];   // Geo16 tables (11-tile, 3-tile geometry; [2] unused)
+};
+
+template <class Gm, int F = 128, int NT = 11> struct T16B {
+  static constexpr int NTILE = NT, RPAD = NTILE * 16;
+  static constexpr int TB = RPAD / Gm::P, ROWS = TB * Gm::P;
+  static constexpr int SH = F + 8;                       // bf16 elements per buffer row (16 bytes of padding: the 4 k groups of a read hit different banks)
+  static constexpr int BUFH = (RPAD + 1) * SH;           // row RPAD = zeros
+  static constexpr int PLANES = (RPAD + 1) * Gm::C;      // fp32 input planes for the stem
+  static constexpr int TABLE = (10 * RPAD + 1) / 2;
+  static constexpr int BYTES = BUFH * 2 + (PLANES + TABLE) * 4;
+  static constexpr int WAVES = F / 16, THREADS = 64 * WAVES, CT = F / 16, KS = F / 32;
+  using Game = Gm;
+  using Geo = Geo16<Gm, NTILE, TB>;
+  static constexpr int FILT = F;
+  static_assert(BUFH * 2 % 16 == 0 && (SH * 2) % 16 == 0, "rows must stay 16-byte aligned");
+};
+
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+// activation rows of one step: KS fragments of 8 channels per tile
+template <class T>
+__device__ __forceinline__ void load_rows16b(const uint16_t* __restrict__ buf, int off0, int off1, bool two, int g, bf16x8v (&a)[2][T::KS]) {
+  const uint16_t* p0 = buf + off0 + g * 8;
+#pragma unroll
+  for (int ks = 0; ks < T::KS; ++ks) a[0][ks] = *(const bf16x8v*)(p0 + ks * 32);
+  if (two) {
+    const uint16_t* p1 = buf + off1 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < T::KS; ++ks) a[1][ks] = *(const bf16x8v*)(p1 + ks * 32);
+  }
+}
+template <class T, class SL, int K, int TILE0>
+__device__ __forceinline__ void load_idx16b(const uint16_t* __restrict__ nbr, int lrow, int (&idx)[2]) {
+  if constexpr (K < SL::list.n) {
+    constexpr int tap = SL::list.tap[K], t0 = SL::list.t0[K], t1 = SL::list.t1[K];
+    idx[0] = (int)nbr[tap * T::RPAD + (TILE0 + t0) * 16 + lrow] * T::SH;
+    if constexpr (t1 >= 0) idx[1] = (int)nbr[tap * T::RPAD + (TILE0 + t1) * 16 + lrow] * T::SH;
+  }
+}
+template <class T, class SL, int NT, int TILE0, int NTAP, int K>
+__device__ __forceinline__ void conv16b_steps(const uint16_t* __restrict__ buf, const uint16_t* __restrict__ nbr, const bf16x8v* __restrict__ wl,
+                                              f32x4v (&acc)[NT], int lrow, int g, bf16x8v (&b0)[T::KS], bf16x8v (&b1)[T::KS],
+                                              bf16x8v (&aA)[2][T::KS], bf16x8v (&aB)[2][T::KS], int (&idx)[2]) {
+  if constexpr (K < SL::list.n) {
+    constexpr int t0 = SL::list.t0[K], t1 = SL::list.t1[K], ord = SL::list.ord[K];
+    bf16x8v (&cur)[2][T::KS] = (K & 1) ? aB : aA;
+    bf16x8v (&nxt)[2][T::KS] = (K & 1) ? aA : aB;
+    bf16x8v (&bc)[T::KS] = (ord & 1) ? b1 : b0;
+    bf16x8v (&bn)[T::KS] = (ord & 1) ? b0 : b1;
+    if constexpr (SL::list.first[K] && SL::list.next_tap[K] >= 0) {
+      constexpr int ntap = NTAP == 1 ? 0 : SL::list.next_tap[K];
+#pragma unroll
+      for (int ks = 0; ks < T::KS; ++ks) bn[ks] = wl[(size_t)(ntap * T::CT * T::KS + ks) * 64];
+    }
+    if constexpr (K + 1 < SL::list.n) {
+      load_rows16b<T>(buf, idx[0], idx[1], SL::list.t1[K + 1] >= 0, g, nxt);
+      load_idx16b<T, SL, K + 2, TILE0>(nbr, lrow, idx);
+    }
+#pragma unroll
+    for (int ks = 0; ks < T::KS; ++ks) {
+      acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[0][ks], bc[ks], acc[t0], 0, 0, 0);
+      if constexpr (t1 >= 0) acc[t1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[1][ks], bc[ks], acc[t1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    conv16b_steps<T, SL, NT, TILE0, NTAP, K + 1>(buf, nbr, wl, acc, lrow, g, b0, b1, aA, aB, idx);
+  }
+}
+// One F -> F convolution (NTAP = 9: 3x3, NTAP = 1: 1x1) into the NT accumulators of this wave: bf16 in, fp32 out.
+template <class T, class G, int NT, int TILE0, int NTAP>
+__device__ __forceinline__ void conv16b(const uint16_t* __restrict__ buf, const uint16_t* __restrict__ nbr, const bf16x8v* __restrict__ wl,
+                                        f32x4v (&acc)[NT], int lrow, int g) {
+  using SL = Steps16<G, NT, TILE0, 1, NTAP>;                        // one step = (tap, tile pair), all F channels
+  if constexpr (SL::list.n > 0) {
+    bf16x8v b0[T::KS], b1[T::KS], aA[2][T::KS], aB[2][T::KS];
+    int idx[2] = {0, 0};
+    constexpr int tap0 = NTAP == 1 ? 0 : SL::list.first_tap;
+#pragma unroll
+    for (int ks = 0; ks < T::KS; ++ks) b0[ks] = wl[(size_t)(tap0 * T::CT * T::KS + ks) * 64];
+    load_idx16b<T, SL, 0, TILE0>(nbr, lrow, idx);
+    load_rows16b<T>(buf, idx[0], idx[1], SL::list.t1[0] >= 0, g, aA);
+    load_idx16b<T, SL, 1, TILE0>(nbr, lrow, idx);
+    __builtin_amdgcn_sched_barrier(0);
+    conv16b_steps<T, SL, NT, TILE0, NTAP, 0>(buf, nbr, wl, acc, lrow, g, b0, b1, aA, aB, idx);
+  }
+}
+
+template <class Gm, int F, bool FROM_PLANES, int NT = 11>
+__global__ void __launch_bounds__(64 * (F / 16), F == 64 ? 2 : 1)
+k_tower16b(Net16bDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+           const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
+  using T = T16B<Gm, F, NT>;
+  using G = typename T::Geo;
+  constexpr int P = Gm::P, C = Gm::C, TB = T::TB, SH = T::SH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  uint16_t* buf = (uint16_t*)ldsb;
+  float* planes = (float*)(ldsb + (size_t)T::BUFH * 2);
+  uint16_t* nbr = (uint16_t*)(planes + T::PLANES);
+  uint16_t* pos = nbr + 9 * T::RPAD;
+  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
+  const int board0 = blockIdx.x * TB;
+  if (board0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, cw = tid >> 6, lrow = lane & 15, g = lane >> 4;
+  const uint16_t* geo = net.geo[NT == 11 ? 0 : 1];
+  // ---- input planes (fp32, permuted row order), tables, the buffer's zero row -------------------------------------------
+  for (int i = tid; i < T::PLANES; i += T::THREADS) {
+    const int row = i / C, c = i % C;
+    float val = 0.0f;
+    if (row < T::RPAD) {
+      const int ps = geo[row];
+      if (ps != 0xffff && board0 + ps / P < n) {
+        const int b = ps / P, q = ps % P;
+        if (FROM_PLANES) val = X[((size_t)(board0 + b) * C + c) * P + q];
+        else val = Gm::plane(leaf_env[eval_slots[board0 + b]], q, c);
+      }
+    }
+    planes[i] = val;
+  }
+  for (int i = tid; i < SH; i += T::THREADS) buf[T::RPAD * SH + i] = 0;
+  for (int i = tid; i < T::RPAD; i += T::THREADS) pos[i] = geo[i];
+  for (int i = tid; i < 9 * T::RPAD; i += T::THREADS) nbr[i] = geo[T::RPAD + i];
+  __syncthreads();
+
+  const int ch = cw * 16 + lrow;                                    // this lane's output channel; rows tile*16 + 4 g + i
+  f32x4v acc[NT];
+  // ---- stem on the fp32 MFMA (K = 9 C), output rounded to bf16 -------------------------------------------------------------
+  {
+    constexpr int KK = 9 * C, K2 = (KK + 1) / 2, NS = (2 * K2 + 3) / 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float bw = net.stem_w[(size_t)(cw * NS + s) * 64 + lane];
+      const int p = 4 * s + g;
+      const int k = (p & 1) * K2 + (p >> 1);
+      const bool kin = k < KK && p < 2 * K2;
+      const int tap = kin ? k / C : 4, c = kin ? k % C : 0;
+#pragma unroll
+      for (int tile = 0; tile < NT; ++tile) {
+        const int row = kin ? (int)nbr[tap * T::RPAD + tile * 16 + lrow] : T::RPAD;
+        acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(planes[row * C + c], bw, acc[tile], 0, 0, 0);
+      }
+    }
+    const float sc = net.stem_ss[ch], sh = net.stem_ss[F + ch];
+#pragma unroll
+    for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = az_fmaf(acc[tile][i], sc, sh);
+        buf[(tile * 16 + g * 4 + i) * SH + ch] = f32_to_bf16_bits(v > 0.0f ? v : 0.0f);
+      }
+  }
+  __syncthreads();
+
+  // ---- residual tower -------------------------------------------------------------------------------------------------------
+  float xres[NT][4];
+  const size_t LAYER_W = (size_t)9 * T::CT * T::KS * 64;            // fragments (16 B) per layer
+  for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    int lrow_l = lrow;
+    asm volatile("" : "+v"(lrow_l));                                // keeps the table look-ups inside the layer loop (registers)
+    conv16b<T, G, NT, 0, 9>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)cw * T::KS * 64 + lane, acc, lrow_l, g);
+    const float sc = net.conv_ss[(size_t)layer * 2 * F + ch], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch];
+    __syncthreads();                                                // every wave has finished reading the buffer
+    if (!(layer & 1)) {
+#pragma unroll
+      for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int a = (tile * 16 + g * 4 + i) * SH + ch;
+          xres[tile][i] = bf16_bits_to_f32(buf[a]);                 // block input as the convolution saw it
+          const float v = az_fmaf(acc[tile][i], sc, sh);
+          buf[a] = f32_to_bf16_bits(v > 0.0f ? v : 0.0f);
+        }
+    } else {
+#pragma unroll
+      for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int a = (tile * 16 + g * 4 + i) * SH + ch;
+          float v = az_fmaf(acc[tile][i], sc, sh);
+          v = v + xres[tile][i];
+          buf[a] = f32_to_bf16_bits(v > 0.0f ? v : 0.0f);
+        }
+    }
+    __syncthreads();
+  }
+  // ---- both 1x1 head convolutions + BN + ReLU, features out in fp32 -------------------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  conv16b<T, G, NT, 0, 1>(buf, nbr, net.head_w + (size_t)cw * T::KS * 64 + lane, acc, lrow, g);
+  {
+    const float sc = net.head_ss[ch], sh = net.head_ss[F + ch];
+    const int nvalid = ((n - board0) < TB ? (n - board0) : TB) * P;
+#pragma unroll
+    for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ps = pos[tile * 16 + g * 4 + i];
+        const float v = az_fmaf(acc[tile][i], sc, sh);
+        if (ps < nvalid) hfeat[((size_t)board0 * P + ps) * F + ch] = v > 0.0f ? v : 0.0f;
+      }
+  }
+}

@@ -109,6 +109,10 @@ typedef struct {
   int32_t num_filters;
   int32_t num_policy_head_filters;
   int32_t num_value_head_filters;
+  /* 0: fp32 tower, the fp32 contract above (default).  1: the residual tower runs in bfloat16 (weights and activations
+   * rounded to bf16, fp32 accumulation, csrc/resnet16b.h) -- BASELINE configs[4] "ResNet 10x128 bf16"; outputs agree with
+   * the fp32 network to bf16 accuracy, not bit for bit, so searches are not comparable move for move with the oracle. */
+  int32_t net_bf16;
 } az_engine_cfg;
 
 typedef struct az_engine az_engine;

@@ -29,6 +29,7 @@ struct EngineCfg
   flip_probability::Float64; seed::UInt64
   max_nodes_per_slot::Int32; max_moves_per_game::Int32
   num_blocks::Int32; num_filters::Int32; num_policy_head_filters::Int32; num_value_head_filters::Int32
+  net_bf16::Int32
 end
 struct MoveRec
   key::NTuple{2,UInt64}; N::NTuple{10,Int32}; action::Int32; reward::Float32
@@ -46,7 +47,7 @@ mutable struct SelfplayStats
   seconds::Float64
   SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0)
 end
-@assert sizeof(EngineCfg) == 216 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56
+@assert sizeof(EngineCfg) == 224 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56
 
 last_error() = unsafe_string(ccall((:az_last_error, LIB), Cstring, ()))
 check(status::Integer) = status == 0 ? nothing : error("azhip status $status: $(last_error())")
@@ -127,7 +128,7 @@ schedule_points(s::PLSchedule) = (Int32.(s.xs), Float64.(s.ys))
 pad8(v, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), 8)
 
 "MctsParams + SimParams + ResNetHP -> az_engine_cfg (SURVEY.md §8b config mapping)"
-function make_cfg(gspec, mcts::MctsParams, sim::SimParams, hp; oracle=2, seed=1, device=0, arena=false)
+function make_cfg(gspec, mcts::MctsParams, sim::SimParams, hp; oracle=2, seed=1, device=0, arena=false, bf16=false)
   xs, ys = schedule_points(mcts.temperature)
   @assert arena || iszero(sim.flip_probability) "flip_probability > 0 is honoured by the arena only"
   EngineCfg(Int32(sizeof(EngineCfg)), device, game_id(gspec), oracle,
@@ -135,7 +136,7 @@ function make_cfg(gspec, mcts::MctsParams, sim::SimParams, hp; oracle=2, seed=1,
     mcts.num_iters_per_turn, length(xs), pad8(xs, Int32), pad8(ys, Float64),
     sim.num_workers, sim.batch_size, isnothing(sim.reset_every) ? 0 : sim.reset_every, sim.fill_batches ? 1 : 0,
     sim.flip_probability, UInt64(seed), 0, 0,
-    hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters)
+    hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters, bf16 ? 1 : 0)
 end
 
 # ---- seam 3: the network plugin -------------------------------------------------------------------------
