@@ -5,7 +5,7 @@ simulate, simulate_distributed, Trace, push_trace ...); every call ends in the C
 include/azhip.h (libazhip.so, hand-written HIP for gfx950).  There is no CPU fallback.
 """
 from . import _lib
-from ._lib import (AzError, GAME_CONNECT_FOUR, GAME_MANCALA, GAME_TICTACTOE, ORACLE_HASH, ORACLE_RESNET,
+from ._lib import (AzError, GAME_CONNECT_FOUR, GAME_GO9_PLANES, GAME_MANCALA, GAME_TICTACTOE, ORACLE_HASH, ORACLE_RESNET,
                    ORACLE_ROLLOUT, ORACLE_UNIFORM)
 from .engine import Engine, cached_engine, clear_engine_cache, default_cfg
 from .comm import Comm

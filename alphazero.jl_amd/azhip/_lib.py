@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("AZHIP_LIB", os.path.join(CSRC, "libazhip.so"))   # ov
 
 AZ_OK, AZ_ERR_BAD_ARG, AZ_ERR_CAPACITY, AZ_ERR_HIP, AZ_ERR_STATE = 0, -1, -2, -3, -4
 GAME_CONNECT_FOUR, GAME_TICTACTOE, GAME_MANCALA = 0, 1, 2
+GAME_GO9_PLANES = 3          # network-only geometry (9, 9, 4), 82 actions: az_net_forward for host-stepped 9x9 Go
 ORACLE_UNIFORM, ORACLE_HASH, ORACLE_RESNET, ORACLE_ROLLOUT = 0, 1, 2, 3
 MAX_ACTIONS = 9
 SCHED_MAX = 8

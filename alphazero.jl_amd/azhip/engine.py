@@ -198,7 +198,7 @@ class Engine:
     def max_moves(self):
         if self.cfg.max_moves_per_game > 0:
             return self.cfg.max_moves_per_game
-        return {L.GAME_CONNECT_FOUR: 42, L.GAME_TICTACTOE: 9, L.GAME_MANCALA: 256}[self.cfg.game]
+        return {L.GAME_CONNECT_FOUR: 42, L.GAME_TICTACTOE: 9, L.GAME_MANCALA: 256, L.GAME_GO9_PLANES: 1}[self.cfg.game]
 
     def selfplay_run(self, num_games, first_game_id=0, progress=None, device_only=False):
         """simulate(): returns (games, moves, ngames, nmoves, stats); games sorted by game id.

@@ -23,7 +23,8 @@ class ResNetHP:
     batch_norm_momentum: float = 0.6
 
 
-_DIMS = {L.GAME_CONNECT_FOUR: (7, 6, 3, 7), L.GAME_TICTACTOE: (3, 3, 3, 9), L.GAME_MANCALA: (14, 1, 5, 6)}
+_DIMS = {L.GAME_CONNECT_FOUR: (7, 6, 3, 7), L.GAME_TICTACTOE: (3, 3, 3, 9), L.GAME_MANCALA: (14, 1, 5, 6),
+         L.GAME_GO9_PLANES: (9, 9, 4, 82)}
 
 
 def param_layout(game, hp):

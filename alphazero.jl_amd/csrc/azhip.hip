@@ -103,6 +103,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   GameInfo gi;
   if (!game_info(c->game, &gi)) return fail(AZ_ERR_BAD_ARG, "unknown game id %d", c->game);
   if (c->oracle < AZ_ORACLE_UNIFORM || c->oracle > AZ_ORACLE_ROLLOUT) return fail(AZ_ERR_BAD_ARG, "unknown oracle kind %d", c->oracle);
+  if (c->game == AZ_GAME_GO9_PLANES && c->oracle != AZ_ORACLE_RESNET) return fail(AZ_ERR_BAD_ARG, "the 9x9x4 plane geometry has no device twin: it serves az_net_forward only (ResNet oracle)");
   if (c->num_workers < 1) return fail(AZ_ERR_BAD_ARG, "num_workers must be >= 1");
   if (c->batch_size > c->num_workers) return fail(AZ_ERR_BAD_ARG, "batch_size (%d) must be <= num_workers (%d) (src/params.jl:361-384)", c->batch_size, c->num_workers);
   // 0 = no search: the engine is a NetworkPlayer (play.jl:226-235) for az_arena_run
@@ -183,7 +184,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     e->nn_cap = e->io_cap;
     AZCHK(dalloc(e, &e->d_hfeat, (size_t)e->nn_cap * gi.P * std::max(64, c->num_filters), false));
     AZCHK(dalloc(e, &e->d_X, (size_t)e->nn_cap * gi.C * gi.P)); AZCHK(dalloc(e, &e->d_A, (size_t)e->nn_cap * gi.A));
-    AZCHK(dalloc(e, &e->d_P, (size_t)e->nn_cap * 16)); AZCHK(dalloc(e, &e->d_V, e->nn_cap)); AZCHK(dalloc(e, &e->d_Pinv, e->nn_cap));
+    AZCHK(dalloc(e, &e->d_P, (size_t)e->nn_cap * std::max(16, gi.APAD))); AZCHK(dalloc(e, &e->d_V, e->nn_cap)); AZCHK(dalloc(e, &e->d_Pinv, e->nn_cap));
     AZCHK(dalloc(e, &e->d_tmp_env, e->nn_cap)); AZCHK(dalloc(e, &e->d_iota, e->nn_cap)); AZCHK(dalloc(e, &e->d_ntmp, 1));
     hipLaunchKernelGGL(k_iota, dim3((e->nn_cap + 255) / 256), dim3(256), 0, e->stream, e->d_iota, e->nn_cap);
     memset(&e->net, 0, sizeof e->net);
@@ -458,16 +459,17 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   std::vector<float> hd_w(4);
   if (hd_ok) {
     const size_t vsteps = (size_t)P * nvf / 4, psteps = (size_t)P * npf / 4;
-    hd_w.assign((NVT * vsteps + psteps) * 64 * 2, 0.0f);
+    const int NPT = (A + 31) / 32;                                  // 32-column policy tiles (1 for the device games, 3 for 82 actions)
+    hd_w.assign((NVT * vsteps + NPT * psteps) * 64 * 2, 0.0f);
     for (int t = 0; t < NVT; ++t) for (size_t i = 0; i < vsteps; ++i) for (int l = 0; l < 64; ++l) {
       int hh = l >> 5, o = t * 32 + (l & 31);
       float* d = &hd_w[((t * vsteps + i) * 64 + l) * 2];
       d[0] = val_w[(4 * i + hh) * F + o];
       d[1] = val_w[(4 * i + 2 + hh) * F + o];
     }
-    for (size_t i = 0; i < psteps; ++i) for (int l = 0; l < 64; ++l) {
-      int hh = l >> 5, o = l & 31;
-      float* d = &hd_w[((NVT * vsteps + i) * 64 + l) * 2];
+    for (int pt = 0; pt < NPT; ++pt) for (size_t i = 0; i < psteps; ++i) for (int l = 0; l < 64; ++l) {
+      int hh = l >> 5, o = pt * 32 + (l & 31);
+      float* d = &hd_w[((NVT * vsteps + pt * psteps + i) * 64 + l) * 2];
       d[0] = o < A ? pol_w[(4 * i + hh) * L + o] : 0.0f;
       d[1] = o < A ? pol_w[(4 * i + 2 + hh) * L + o] : 0.0f;
     }

@@ -51,6 +51,7 @@ inline bool game_info(int gid, GameInfo* gi) {
     case AZ_GAME_CONNECT_FOUR: *gi = {ConnectFour::A, ConnectFour::APAD, ConnectFour::W, ConnectFour::H, ConnectFour::C, ConnectFour::P, ConnectFour::MAX_PLIES, NodeL<ConnectFour>::BYTES}; return true;
     case AZ_GAME_TICTACTOE: *gi = {TicTacToe::A, TicTacToe::APAD, TicTacToe::W, TicTacToe::H, TicTacToe::C, TicTacToe::P, TicTacToe::MAX_PLIES, NodeL<TicTacToe>::BYTES}; return true;
     case AZ_GAME_MANCALA: *gi = {Mancala::A, Mancala::APAD, Mancala::W, Mancala::H, Mancala::C, Mancala::P, Mancala::MAX_PLIES, NodeL<Mancala>::BYTES}; return true;
+    case AZ_GAME_GO9_PLANES: *gi = {Go9Planes::A, Go9Planes::APAD, Go9Planes::W, Go9Planes::H, Go9Planes::C, Go9Planes::P, Go9Planes::MAX_PLIES, 64}; return true;   // network-only geometry: no tree
   }
   return false;
 }
@@ -83,6 +84,7 @@ struct az_engine {
   Net16bDev net16b;              // bf16 fragments (cfg.net_bf16)
   Net16Dev net16;                // k_tower16 fragments (64 filters)
   uint16_t* d_geo[3];            // Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h)
+  int nts;                       // row tiles of the game's latency tower variant (NTS<Game>, resnet16.h)
   char last_tower[96];           // name of the tower kernel that served the most recent network launch (az_net_last_kernel)
   int tower_pick;                // AZHIP_TOWER=16|32|3|21 forces a tower kernel (3 = k_tower16 with 3 row tiles, 21 = k_tower16x2); 0 = choose per launch
   int num_cu;

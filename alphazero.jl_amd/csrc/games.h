@@ -257,3 +257,19 @@ struct Mancala {
     return (store && player == 1) ? 1.f : 0.f;
   }
 };
+
+
+// ------------------------------------------------------------------ 9x9 boards with 4 planes and 82 actions (network only)
+// BASELINE configs[4]: OpenSpiel 9x9 Go through src/openspiel.jl.  Foreign rules cannot run on the device: such games keep
+// their rules and their tree on the host and use the network through az_net_forward (planes in, policy / value out --
+// Network.forward_normalized, src/networks/network.jl:264-271).  This type only carries the tensor geometry the network
+// kernels are instantiated for: GI.state_dim = (9, 9, 4) (OpenSpiel's go observation tensor: black, white, empty, to-play /
+// komi plane), GI.num_actions = 82 (81 points + pass).  There is no device twin: plane / mask are never called (the
+// FROM_PLANES = false kernels are not instantiated for it) and every search entry point rejects the game id.
+struct Go9Planes {
+  static constexpr int ID = 3, A = 82, APAD = 88, W = 9, H = 9, C = 4, P = 81;
+  static constexpr int MAX_PLIES = 1;
+  static constexpr int NSYM = 0;
+  AZ_GHD static float plane(const GEnv&, int, int) { return 0.f; }
+  AZ_GHD static uint32_t mask(const GEnv&) { return 0; }
+};

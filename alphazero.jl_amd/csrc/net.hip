@@ -12,12 +12,14 @@
 AZ_NET_DECL(c4)
 AZ_NET_DECL(ttt)
 AZ_NET_DECL(mancala)
+AZ_NET_DECL(go9)
 
 int net_set_kernel_attrs(az_engine* e) {
   switch (e->cfg.game) {
     case AZ_GAME_CONNECT_FOUR: return net_set_kernel_attrs_c4(e);
     case AZ_GAME_TICTACTOE: return net_set_kernel_attrs_ttt(e);
     case AZ_GAME_MANCALA: return net_set_kernel_attrs_mancala(e);
+    case AZ_GAME_GO9_PLANES: return net_set_kernel_attrs_go9(e);
   }
   return fail(AZ_ERR_BAD_ARG, "unknown game id %d", e->cfg.game);
 }
@@ -27,6 +29,7 @@ int net_launch(az_engine* e, hipStream_t st, bool from_planes, float* hfeat, con
     case AZ_GAME_CONNECT_FOUR: return net_launch_c4(e, st, from_planes, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
     case AZ_GAME_TICTACTOE: return net_launch_ttt(e, st, from_planes, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
     case AZ_GAME_MANCALA: return net_launch_mancala(e, st, from_planes, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
+    case AZ_GAME_GO9_PLANES: return net_launch_go9(e, st, from_planes, hfeat, envs, eslots, n_ptr, n_max, X, Amask, Pout, Vout, Pinv, pstride);
   }
   return fail(AZ_ERR_BAD_ARG, "unknown game id %d", e->cfg.game);
 }
@@ -35,6 +38,7 @@ int net_wave(az_engine* e, int g, bool split, int nmax) {
     case AZ_GAME_CONNECT_FOUR: return net_wave_c4(e, g, split, nmax);
     case AZ_GAME_TICTACTOE: return net_wave_ttt(e, g, split, nmax);
     case AZ_GAME_MANCALA: return net_wave_mancala(e, g, split, nmax);
+    case AZ_GAME_GO9_PLANES: return net_wave_go9(e, g, split, nmax);
   }
   return fail(AZ_ERR_BAD_ARG, "unknown game id %d", e->cfg.game);
 }
@@ -47,6 +51,7 @@ extern "C" int az_debug_tower_geometry(int32_t game, int32_t which, uint16_t* ou
     case AZ_GAME_CONNECT_FOUR: return net_geometry_c4(which, out, cap, rows, products);
     case AZ_GAME_TICTACTOE: return net_geometry_ttt(which, out, cap, rows, products);
     case AZ_GAME_MANCALA: return net_geometry_mancala(which, out, cap, rows, products);
+    case AZ_GAME_GO9_PLANES: return net_geometry_go9(which, out, cap, rows, products);
   }
   return fail(AZ_ERR_BAD_ARG, "unknown game id %d", game);
 }

@@ -5,7 +5,7 @@
 #pragma once
 #include "engine.h"
 
-template <class Gm, int F> static int set_kernel_attrs_f() {
+template <class Gm, int F, bool PLANES_ONLY = false> static int set_kernel_attrs_f() {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
   if constexpr (F == 64) {
@@ -14,8 +14,8 @@ template <class Gm, int F> static int set_kernel_attrs_f() {
   }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 3>::BYTES));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 3>::BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, NTS<Gm>>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, NTS<Gm>>::BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, NTS<Gm>>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, NTS<Gm>>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   return AZ_OK;
@@ -40,20 +40,21 @@ template <class G> static int geometry_out(uint16_t* out, int64_t cap, int* rows
   return AZ_OK;
 }
 template <class Gm> static int set_kernel_attrs(az_engine* e) {
+  e->nts = NTS<Gm>;
   AZCHK((set_kernel_attrs_f<Gm, 64>()));
   AZCHK((set_kernel_attrs_f<Gm, 128>()));
   AZCHK((upload_geo<typename T16<Gm, 64, 11>::Geo>(e, 0)));
-  AZCHK((upload_geo<typename T16<Gm, 64, 3>::Geo>(e, 1)));
+  AZCHK((upload_geo<typename T16<Gm, 64, NTS<Gm>>::Geo>(e, 1)));
   AZCHK((upload_geo<typename T16P<Gm, 64>::Geo>(e, 2)));
   return AZ_OK;
 }
 
 static void note_tower(az_engine* e, int tw, int F) {
-  static const char* const gn[] = {"ConnectFour", "TicTacToe", "Mancala"};
+  static const char* const gn[] = {"ConnectFour", "TicTacToe", "Mancala", "Go9Planes"};
   const char* g = gn[e->cfg.game];
-  if (e->cfg.net_bf16) { snprintf(e->last_tower, sizeof e->last_tower, "k_tower16b<%s,%d,NT=%d>", g, F, tw == 3 ? 3 : 11); return; }
+  if (e->cfg.net_bf16) { snprintf(e->last_tower, sizeof e->last_tower, "k_tower16b<%s,%d,NT=%d>", g, F, tw == 3 ? e->nts : 11); return; }
   if (tw == 21) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d>", g, F);
-  else if (tw == 3) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=3>", g, F);
+  else if (tw == 3) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=%d>", g, F, e->nts);
   else if (tw == 16) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=11>", g, F);
   else snprintf(e->last_tower, sizeof e->last_tower, "k_tower<%s,%d>", g, F);
 }
@@ -61,37 +62,37 @@ static void note_tower(az_engine* e, int tw, int F) {
 // launches tower + heads on `n` boards (device count in n_ptr when n < 0)
 // Which tower kernel serves a launch of up to n boards.  A workgroup's layer chain is sequential and the MFMA
 // pipe of a CU is shared by its resident workgroups, so the launch costs (workgroups per CU, rounded up) x (rows
-// per workgroup): k_tower16 packs 176 rows (4 Connect-Four boards), k_tower 128 (3 boards), k_tower16 with 3 row
-// tiles 48 (1 board; +10 %: a third of the weight reuse, more barriers per row).  4096 Connect-Four leaves:
-// 4 x 176 < 6 x 128; 128 leaves: 1 x 48 << 1 x 128 (measured tools/small_batch.sh: 0.39 vs 0.80 ms per wave at
-// 128 filters).  Returns 16, 32 or 3.
+// per workgroup) x (fraction of the tile-tap products it executes): k_tower16 packs 176 rows (4 Connect-Four boards),
+// k_tower 128 (3 boards, every tap), k_tower16 with 3 row tiles 48 (1 board; +10 %: a third of the weight reuse, more
+// barriers per row).  Measured round 2 (tools/run_config.py): Mancala 8192 slots 13.5 M sims/s on k_tower, 21.5 M on
+// k_tower16 (31 of 99 products); 5x128 two groups 1.10 vs 1.20 M.  Returns 16, 21, 32 or 3.
 template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
   if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64))) return e->tower_pick;
   if (e->cfg.net_bf16) {                                           // k_tower16b: 11 or 3 row tiles
     if (e->tower_pick == 3 || e->tower_pick == 16) return e->tower_pick;
     const long cu2 = e->num_cu > 0 ? e->num_cu : 256;
-    const long a16 = (n + T16B<Gm, F>::TB - 1) / T16B<Gm, F>::TB, a3 = (n + T16B<Gm, F, 3>::TB - 1) / T16B<Gm, F, 3>::TB;
+    const long a16 = (n + T16B<Gm, F>::TB - 1) / T16B<Gm, F>::TB, a3 = (n + T16B<Gm, F, NTS<Gm>>::TB - 1) / T16B<Gm, F, NTS<Gm>>::TB;
     const long per = F == 64 ? 2 : 1;                               // workgroups per CU
     const double d16 = (double)((a16 + per * cu2 - 1) / (per * cu2)) * T16B<Gm, F>::RPAD;
-    const double d3 = 1.1 * (double)((a3 + per * cu2 - 1) / (per * cu2)) * T16B<Gm, F, 3>::RPAD;
+    const double d3 = 1.1 * (double)((a3 + per * cu2 - 1) / (per * cu2)) * T16B<Gm, F, NTS<Gm>>::RPAD;
     return d3 <= d16 ? 3 : 16;
   }
   const long cu = e->num_cu > 0 ? e->num_cu : 256;
   const long b16 = (n + T16<Gm, F>::TB - 1) / T16<Gm, F>::TB, b32 = (n + TOWER_ROWS / Gm::P - 1) / (TOWER_ROWS / Gm::P);
-  const long b3 = (n + T16<Gm, F, 3>::TB - 1) / T16<Gm, F, 3>::TB;
-  const double c16 = (double)((b16 + cu - 1) / cu) * T16<Gm, F>::RPAD;
-  double c32 = (double)((b32 + cu - 1) / cu) * TOWER_ROWS;
-  const double c3 = 1.1 * (double)((b3 + cu - 1) / cu) * T16<Gm, F, 3>::RPAD;
-  // 128 filters, several slot groups: the groups' towers fill each other's partial rounds and k_tower's smaller
-  // workgroups pack slightly better (measured 1.10 vs 1.07 M sims/s at 2 x 2048)
-  if (F == 128 && e->ngroups > 1) c32 *= 0.9;
+  const long b3 = (n + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB;
+  // the k_tower16 family executes only the (tile, tap) products that touch the board (Geo16): cost x executed fraction
+  constexpr double f16 = T16<Gm, F>::Geo::tab.cost / (9.0 * T16<Gm, F>::NTILE), f3 = T16<Gm, F, NTS<Gm>>::Geo::tab.cost / (9.0 * NTS<Gm>),
+                   f21 = T16P<Gm, 64>::Geo::tab.cost / (9.0 * T16P<Gm, 64>::NTW);
+  const double c16 = (double)((b16 + cu - 1) / cu) * T16<Gm, F>::RPAD * f16;
+  const double c32 = (double)((b32 + cu - 1) / cu) * TOWER_ROWS;     // k_tower (32x32x2) computes every tap
+  const double c3 = 1.1 * (double)((b3 + cu - 1) / cu) * T16<Gm, F, NTS<Gm>>::RPAD * f3;
   if (c3 <= c16 && c3 <= c32) return 3;
-  // paired k_tower16x2: 336 rows = 8 boards per workgroup, no padding rows (+3 % on a 4096-leaf launch).  Only with ONE
-  // slot group: its 92 KB of LDS allow one workgroup per CU, so two groups' towers cannot interleave on a CU and the
-  // other group's heads kernel finds no gaps (measured 3.80 vs 4.11 M sims/s with two groups)
-  if (F == 64 && e->ngroups == 1) {
+  // paired k_tower16x2: 336 rows = 8 Connect-Four boards per workgroup, no padding rows.  Its 92 KB of LDS allow one
+  // workgroup per CU, so with several slot groups the groups' towers cannot interleave on a CU (Connect-Four, two groups:
+  // 3.80 vs 4.11 M sims/s in round 1): +8 % on its cost there
+  if (F == 64) {
     const long b21 = (n + T16P<Gm, 64>::TB - 1) / T16P<Gm, 64>::TB;
-    const double c21 = (double)((b21 + cu - 1) / cu) * T16P<Gm, 64>::RPAD;
+    const double c21 = (double)((b21 + cu - 1) / cu) * T16P<Gm, 64>::RPAD * f21 * (e->ngroups > 1 ? 1.08 : 1.0);
     if (c21 < c16 && c21 < c32) return 21;
   }
   return c16 <= c32 ? 16 : 32;
@@ -103,27 +104,27 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
   const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
   if (gt == 0) return AZ_OK;
   constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
-  constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
+  constexpr int TB3 = T16<Gm, F, NTS<Gm>>::TB, LDS3 = T16<Gm, F, NTS<Gm>>::BYTES;
   constexpr int TB21 = T16P<Gm, 64>::TB, THR21 = T16P<Gm, 64>::THREADS, LDS21 = T16P<Gm, 64>::BYTES;
   const int tw = pick_tower<Gm, F>(e, n_max);
   note_tower(e, tw, F);
   if (e->cfg.net_bf16) {
-    constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, 3>::TB, LDSb3 = T16B<Gm, F, 3>::BYTES;
-    if (tw == 3) LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b<Gm, F, FROM_PLANES, 3>), (n_max + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
+    constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, NTS<Gm>>::TB, LDSb3 = T16B<Gm, F, NTS<Gm>>::BYTES;
+    if (tw == 3) LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b<Gm, F, FROM_PLANES, NTS<Gm>>), (n_max + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
     else LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b<Gm, F, FROM_PLANES, 11>), (n_max + TBb - 1) / TBb, THRb, LDSb, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
   } else if (tw == 21) {
     if constexpr (F == 64)
       LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
   } else if (tw == 3)
-    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES, 3>), (n_max + TB3 - 1) / TB3, THR16, LDS3, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
+    LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES, NTS<Gm>>), (n_max + TB3 - 1) / TB3, THR16, LDS3, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
   else if (tw == 16)
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES>), (n_max + TB16 - 1) / TB16, THR16, LDS16, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
   else
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, F, FROM_PLANES>), gt, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
   if (e->net.hd_ok)
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, F>), (n_max + 31) / 32, 64 * (F / 32 + 1), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, F>), (n_max + 31) / 32, 64 * (F / 32 + HEADS_NPT<Gm>), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
   else
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads<Gm, F>), gh, 4 * (F + 16), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads<Gm, F>), gh, 4 * (F + HEADS_LP<Gm>), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
   return AZ_OK;
 }
 // launches tower + heads on `n` boards (device count in n_ptr when given)
@@ -142,7 +143,7 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   const int G = v.G;
   if (split) { HIPCHK(hipEventRecord(e->ev_tree[g], st)); HIPCHK(hipStreamWaitEvent(sn, e->ev_tree[g], 0)); }
   constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
-  constexpr int TB3 = T16<Gm, F, 3>::TB, LDS3 = T16<Gm, F, 3>::BYTES;
+  constexpr int TB3 = T16<Gm, F, NTS<Gm>>::TB, LDS3 = T16<Gm, F, NTS<Gm>>::BYTES;
   constexpr int TB21 = T16P<Gm, 64>::TB, THR21 = T16P<Gm, 64>::THREADS, LDS21 = T16P<Gm, 64>::BYTES;
   // N = upper bound of this wave's leaves: the group's active slots (a draining phase or a partial explore! launches
   // -- and picks its tower kernel -- for what is left, not for the group's capacity)
@@ -151,23 +152,23 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   const int tw = pick_tower<Gm, F>(e, N);
   note_tower(e, tw, F);
   if (e->cfg.net_bf16) {
-    constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, 3>::TB, LDSb3 = T16B<Gm, F, 3>::BYTES;
-    if (tw == 3) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 3>), (N + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+    constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, NTS<Gm>>::TB, LDSb3 = T16B<Gm, F, NTS<Gm>>::BYTES;
+    if (tw == 3) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, NTS<Gm>>), (N + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
     else LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 11>), (N + TBb - 1) / TBb, THRb, LDSb, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   } else if (tw == 21) {
     if constexpr (F == 64)
       LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   } else if (tw == 3)
-    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, 3>), (N + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, NTS<Gm>>), (N + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   else if (tw == 16)
     LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false>), (N + TB16 - 1) / TB16, THR16, LDS16, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   else
     LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower<Gm, F, false>), (N + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
   if (e->net.hd_ok)
-    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads_mfma<Gm, F>), (N + 31) / 32, 64 * (F / 32 + 1), 0, e->net, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
+    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads_mfma<Gm, F>), (N + 31) / 32, 64 * (F / 32 + HEADS_NPT<Gm>), 0, e->net, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
   else
-    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads<Gm, F>), (N + 3) / 4, 4 * (F + 16), 0, e->net, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
+    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads<Gm, F>), (N + 3) / 4, 4 * (F + HEADS_LP<Gm>), 0, e->net, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
   return AZ_OK;
 }
 template <class Gm> static int wave_net(az_engine* e, int g, bool split, int nmax) {
@@ -186,6 +187,6 @@ template <class Gm> static int wave_net(az_engine* e, int g, bool split, int nma
   int net_wave_##sfx(az_engine* e, int g, bool split, int nmax) { return wave_net<Gm>(e, g, split, nmax); }                  \
   int net_geometry_##sfx(int which, uint16_t* out, int64_t cap, int* rows, int* products) {                                  \
     return which == 0 ? geometry_out<typename T16<Gm, 64, 11>::Geo>(out, cap, rows, products)                                \
-         : which == 1 ? geometry_out<typename T16<Gm, 64, 3>::Geo>(out, cap, rows, products)                                 \
+         : which == 1 ? geometry_out<typename T16<Gm, 64, NTS<Gm>>::Geo>(out, cap, rows, products)                                 \
                       : geometry_out<typename T16P<Gm, 64>::Geo>(out, cap, rows, products);                                  \
   }

@@ -329,15 +329,17 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
 
 // Dense heads, softmax, tanh, forward_normalized.  HB boards per 4(F+16)-thread workgroup; thread
 // (b, o): o < F -> value hidden unit, F <= o < F + A -> policy logit.
+template <class Gm> constexpr int HEADS_LP = (Gm::A + 15) / 16 * 16;          // logit slots per board (16 for the device games, 96 for 82 actions)
+template <class Gm> constexpr int HEADS_NPT = (Gm::A + 31) / 32;              // 32-column policy tiles of k_heads_mfma
 template <class Gm, int F>
-__global__ void __launch_bounds__(4 * (F + 16))
+__global__ void __launch_bounds__(4 * (F + HEADS_LP<Gm>))
 k_heads(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
         const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ Amask,
         const float* __restrict__ hfeat, float* __restrict__ Pout, float* __restrict__ Vout,
         float* __restrict__ Pinv, int pstride) {
-  constexpr int P = Gm::P, A = Gm::A, HB = 4, PER = F + 16;   // F value-hidden units + up to 16 logits per board
-  static_assert(F + Gm::APAD <= PER || F + A <= PER, "thread map");
-  __shared__ float s_logit[HB][16];
+  constexpr int P = Gm::P, A = Gm::A, HB = 4, PER = F + HEADS_LP<Gm>;   // F value-hidden units + the logits of a board
+  static_assert(F + A <= PER, "thread map");
+  __shared__ float s_logit[HB][HEADS_LP<Gm>];
   __shared__ float s_vh[HB][F];
   const int n = n_eval_ptr ? *n_eval_ptr : n_fixed;
   const int board0 = blockIdx.x * HB;
@@ -396,7 +398,7 @@ k_heads(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
 }
 
 // Dense heads on MFMA.  One 32-board tile per call; wavefront w < F/32 computes value-hidden
-// outputs 32w..32w+31, wavefront F/32 the (padded) policy logits (further wavefronts only take part in the
+// outputs 32w..32w+31, the next ceil(A / 32) wavefronts the (padded) policy logits (further wavefronts only take part in the
 // barrier).  The A operand is the board's head-feature row (K = P*nf values, read as float4 = k 4i..4i+3), the
 // B operand the dense matrix pre-packed per MFMA as (W[4i+h][o], W[4i+2+h][o]) with h = lane >> 5:
 // v_mfma_f32_32x32x2_f32 consumes k = 2j (lanes 0-31) then 2j+1 (lanes 32-63), i.e. the ascending-k chain of the
@@ -407,17 +409,18 @@ __device__ __forceinline__ void heads_mfma_tile(const NetDev& net, const GEnv* _
                                                 int n, const float* __restrict__ Amask, const float* __restrict__ hfeat,
                                                 float* __restrict__ Pout, float* __restrict__ Vout, float* __restrict__ Pinv, int pstride,
                                                 int board0, float* __restrict__ s_vh, float* __restrict__ s_logit) {
-  constexpr int P = Gm::P, A = Gm::A, NVT = F / 32, SV = F + 1;
+  constexpr int P = Gm::P, A = Gm::A, NVT = F / 32, SV = F + 1, NPT = HEADS_NPT<Gm>, LP = HEADS_LP<Gm>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
   const int HF = net.HF;
-  const bool is_pol = wave == NVT;
-  if (wave <= NVT) {
+  const bool is_pol = wave >= NVT;
+  const int pt = wave - NVT;                       // policy tile: logits 32 pt .. 32 pt + 31
+  if (wave < NVT + NPT) {
   const int nf = is_pol ? net.npf : net.nvf, foff = is_pol ? 0 : net.npf;
   int e = board0 + (lane & 31);
   if (e >= n) e = n - 1;                         // clamp: rows past the batch are computed and dropped
   const float* hf = hfeat + (size_t)e * P * HF + foff;
   // fragment pointer: value tiles first (each P*nvf/4 steps), then the policy tile
-  const float2* wp = net.hd_w + ((size_t)(is_pol ? NVT * (P * net.nvf / 4) : wave * (P * net.nvf / 4))) * 64 + lane;
+  const float2* wp = net.hd_w + ((size_t)(is_pol ? NVT * (P * net.nvf / 4) + pt * (P * net.npf / 4) : wave * (P * net.nvf / 4))) * 64 + lane;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -466,7 +469,7 @@ __device__ __forceinline__ void heads_mfma_tile(const NetDev& net, const GEnv* _
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (is_pol) { if (col < A) s_logit[row * 16 + col] = acc[r] + net.pol_b[col]; }
+    if (is_pol) { if (pt * 32 + col < A) s_logit[row * LP + pt * 32 + col] = acc[r] + net.pol_b[pt * 32 + col]; }
     else {
       const int o = wave * 32 + col;
       const float v = acc[r] + net.val_b[o];
@@ -479,10 +482,10 @@ __device__ __forceinline__ void heads_mfma_tile(const NetDev& net, const GEnv* _
   if (b < 32 && board0 + b < n) {
     const int e = board0 + b;
     float pr[A];
-    float mx = s_logit[b * 16];
-    for (int a = 1; a < A; ++a) mx = s_logit[b * 16 + a] > mx ? s_logit[b * 16 + a] : mx;
+    float mx = s_logit[b * LP];
+    for (int a = 1; a < A; ++a) mx = s_logit[b * LP + a] > mx ? s_logit[b * LP + a] : mx;
     float s = 0.0f;
-    for (int a = 0; a < A; ++a) { pr[a] = az_expf(s_logit[b * 16 + a] - mx); s += pr[a]; }
+    for (int a = 0; a < A; ++a) { pr[a] = az_expf(s_logit[b * LP + a] - mx); s += pr[a]; }
     for (int a = 0; a < A; ++a) pr[a] = pr[a] / s;
     float av = 0.0f;
     for (int k = 0; k < F; ++k) av = az_fmaf(s_vh[b * SV + k], net.val2_w[k], av);
@@ -503,14 +506,14 @@ __device__ __forceinline__ void heads_mfma_tile(const NetDev& net, const GEnv* _
   }
 }
 template <class Gm, int F>
-__global__ void __launch_bounds__(64 * (F / 32 + 1))
+__global__ void __launch_bounds__(64 * (F / 32 + HEADS_NPT<Gm>))
 k_heads_mfma(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
              const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ Amask,
              const float* __restrict__ hfeat, float* __restrict__ Pout, float* __restrict__ Vout,
              float* __restrict__ Pinv, int pstride) {
   __builtin_amdgcn_s_setprio(3);   // few workgroups on the critical path of the group's next wave
   __shared__ float s_vh[32 * (F + 1)];
-  __shared__ float s_logit[32 * 16];
+  __shared__ float s_logit[32 * HEADS_LP<Gm>];
   const int n = n_eval_ptr ? *n_eval_ptr : n_fixed;
   const int board0 = blockIdx.x * 32;
   if (board0 >= n) return;

@@ -400,6 +400,8 @@ __device__ __forceinline__ void conv16p(const float* __restrict__ buf, const uin
 }
 
 template <int F> struct T16Threads { static constexpr int V = 64 * (F / 16); };
+// row tiles of the latency variant: 3 (one Connect-Four board, 5 Tic-tac-toe, 3 Mancala), or what one board needs (9x9: 6)
+template <class Gm> constexpr int NTS = Gm::P <= 48 ? 3 : (Gm::P + 15) / 16;
 
 // One wavefront's share of the tower: its NT row tiles start at row tile TILE0 of the workgroup's LDS buffer (rows in
 // Geo16's permuted order), it owns the 16 output channels of channel tile cw.  The caller has filled `planes` and the

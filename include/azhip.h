@@ -62,7 +62,13 @@ typedef enum {
   AZ_ERR_COMM = -5       /* an RCCL call failed / librccl.so could not be loaded */
 } az_status;
 
-typedef enum { AZ_GAME_CONNECT_FOUR = 0, AZ_GAME_TICTACTOE = 1, AZ_GAME_MANCALA = 2 } az_game_id;
+typedef enum {
+  AZ_GAME_CONNECT_FOUR = 0, AZ_GAME_TICTACTOE = 1, AZ_GAME_MANCALA = 2,
+  /* Network-only tensor geometry, no device twin: GI.state_dim = (9, 9, 4), 82 actions -- OpenSpiel 9x9 Go through
+   * src/openspiel.jl (BASELINE configs[4]).  Rules and tree stay on the host; the engine serves az_net_set_params /
+   * az_net_forward (Network.forward_normalized) for it and rejects every search, game and key-based entry point. */
+  AZ_GAME_GO9_PLANES = 3
+} az_game_id;
 
 /* Which oracle the search consults (src/mcts.jl:6-17). */
 typedef enum {

@@ -57,6 +57,13 @@ const DeviceGameSpec = Union{ConnectFour.GameSpec, Tictactoe.GameSpec, Mancala.G
 game_id(::ConnectFour.GameSpec) = Int32(0)
 game_id(::Tictactoe.GameSpec) = Int32(1)
 game_id(::Mancala.GameSpec) = Int32(2)
+"Games without a device twin (e.g. OpenSpiel games through src/openspiel.jl) can still use the HIP network when their
+tensor geometry is one the library instantiates: AZ_GAME_GO9_PLANES = 9 x 9 x 4 planes, 82 actions (OpenSpiel 9x9 Go).
+Only `HipResNet` / `Network.forward_normalized` work for them (seam 2); `simulate` falls back to the stock Julia loop."
+function game_id(gspec::AlphaZero.AbstractGameSpec)
+  GI.state_dim(gspec) == (9, 9, 4) && GI.num_actions(gspec) == 82 && return Int32(3)
+  error("no device twin and no matching plane geometry for $(typeof(gspec))")
+end
 const BLACK_BIT = UInt64(1) << 63
 
 function encode_state(::ConnectFour.GameSpec, s)

@@ -532,7 +532,8 @@ static void net_forward_one(const azr_net* n, const float* xin, float* p, float*
   conv_bn(n, a, F, n->npf, 1, w, w + (size_t)F * n->npf, w + (size_t)F * n->npf + n->npf, 0, 1, 1, hp);
   w += (size_t)F * n->npf + 5 * (size_t)n->npf;
   {
-    float logits[AZR_AMAX];
+    float logits[128];            /* the network restatement takes any geometry up to 128 actions (9x9 planes: 82) */
+    if (A > 128) { fprintf(stderr, "azref: too many actions\n"); abort(); }
     int K = P * n->npf;
     for (int o = 0; o < A; ++o) {
       float acc = 0.0f;

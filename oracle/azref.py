@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libazref.so")
 
 C4, TTT, MANCALA = 0, 1, 2
+GO9 = 3           # tensor geometry only (9 x 9 x 4 planes, 82 actions): the network restatement takes any dimensions
 ORACLE_UNIFORM, ORACLE_HASH, ORACLE_NET, ORACLE_ROLLOUT = 0, 1, 2, 3
 AMAX = 9
 CELLS = 42
@@ -110,8 +111,8 @@ def lib():
     return _lib
 
 
-NUM_ACTIONS = {C4: 7, TTT: 9, MANCALA: 6}
-DIMS = {C4: (7, 6, 3), TTT: (3, 3, 3), MANCALA: (14, 1, 5)}
+NUM_ACTIONS = {C4: 7, TTT: 9, MANCALA: 6, GO9: 82}
+DIMS = {C4: (7, 6, 3), TTT: (3, 3, 3), MANCALA: (14, 1, 5), GO9: (9, 9, 4)}
 
 
 class Game:

@@ -129,11 +129,11 @@ def test_tower_row_permutation_tables():
     f = lib.az_debug_tower_geometry
     f.restype = C.c_int
     f.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-    dims = {0: (7, 6), 1: (3, 3), 2: (14, 1)}
+    dims = {0: (7, 6), 1: (3, 3), 2: (14, 1), 3: (9, 9)}
     expect = {(0, 0): 85, (0, 1): 26, (0, 2): 159, (2, 0): 31}
     for game, (W, H) in dims.items():
         P = W * H
-        for which, ntiles in ((0, 11), (1, 3), (2, 21)):
+        for which, ntiles in ((0, 11), (1, 3 if P <= 48 else (P + 15) // 16), (2, 21)):
             out = np.zeros(10 * 21 * 16, dtype=np.uint16)
             rows, prod = C.c_int32(), C.c_int32()
             L.check(f(game, which, out.ctypes.data_as(C.c_void_p), out.size, C.byref(rows), C.byref(prod)))
