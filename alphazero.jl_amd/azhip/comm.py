@@ -49,7 +49,11 @@ class Comm:
 
 def torch_broadcast_id(rank):
     """unique id from rank 0 to every rank of the default torch.distributed group (any backend)"""
+    import torch
     import torch.distributed as dist
     box = [unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
+    if dist.get_backend() == "nccl":
+        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.broadcast_object_list(box, src=0)
     return box[0]

@@ -282,12 +282,22 @@ def main():
     # After the timed region (N > 1): the exchange step of the path -- every rank plays a short bounded phase device-only
     # and az_comm_gather_push all-gathers the records over RCCL straight into every rank's device replay memory
     # (simulate_distributed's fetch + push_trace!, src/simulations.jl:280-289, src/memory.jl:74-87).  Not part of `value`.
-    gather = None
-    if dist is not None:
-        try:
-            gather = gather_leg(azhip, blob, dev_index, rank, world)
-        except Exception as ex:                                     # the headline number must survive a failing extra leg
-            gather = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    gather, gather_hung = None, False
+    if dist is not None and not os.environ.get("AZ_BENCH_NO_GATHER"):
+        # the headline number must survive a failing or hanging extra leg: it runs on a helper thread with a deadline
+        box = {}
+
+        def run_gather():
+            try:
+                torch.cuda.set_device(dev_index)                    # the current device is per thread
+                box["r"] = gather_leg(azhip, blob, dev_index, rank, world)
+            except Exception as ex:
+                box["r"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        th = threading.Thread(target=run_gather, daemon=True)
+        th.start()
+        th.join(240.0)
+        gather_hung = th.is_alive()
+        gather = {"error": "the exchange leg did not finish within 240 s"} if gather_hung else box.get("r")
 
     if rank == 0:
         out = {
@@ -337,7 +347,9 @@ def main():
             out["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, hp, args.sims)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if gather_hung:
+        os._exit(0)                                                 # a helper thread is stuck in a collective: no orderly shutdown
     if dist is not None:
         dist.destroy_process_group()
 
