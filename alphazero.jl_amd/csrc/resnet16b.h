@@ -1,8 +1,10 @@
 // resnet16b.h -- k_tower16b: the residual tower in bfloat16 on v_mfma_f32_16x16x32_bf16 (BASELINE configs[4]: "ResNet-10x128 bf16").
 //
 // Same shape as k_tower16 (resnet16.h): a workgroup owns TB whole boards = NT row tiles of 16 in ONE LDS activation
-// buffer, rows in Geo16's border-class order (taps that fall off the board skipped per tile), wavefront w owns output
-// channels 16 w .. 16 w + 15 of every tile, stem + every residual block + both 1x1 head convolutions without leaving the CU.
+// buffer, rows in Geo16's border-class order (taps that fall off the board skipped per tile), stem + every residual block +
+// both 1x1 head convolutions without leaving the CU.  A wavefront owns half of the row tiles x 32 output channels (two
+// column tiles): with 16x the MFMA rate of fp32 the LDS reads of the activations are what binds, and every fragment read
+// now feeds two MFMAs (the first version, 16 channels x all tiles per wave, re-read each row 8 times per tap at F = 128).
 // What differs:
 //   * activations live in LDS as bf16 ([RPAD + 1][F + 8], 272-byte rows at F = 128: twice the boards-per-byte of fp32, so
 //     the 128-filter tower keeps two workgroups per CU), weights are bf16 fragments, accumulation is fp32 in the MFMA;
@@ -73,45 +75,52 @@ __device__ __forceinline__ void load_idx16b(const uint16_t* __restrict__ nbr, in
     if constexpr (t1 >= 0) idx[1] = (int)nbr[tap * T::RPAD + (TILE0 + t1) * 16 + lrow] * T::SH;
   }
 }
+// weights of one tap for this wave's two column tiles: b[ct][ks]
+template <class T>
+__device__ __forceinline__ void load_w16b(const bf16x8v* __restrict__ wl, int tap, bf16x8v (&b)[2][T::KS]) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < T::KS; ++ks) b[ct][ks] = wl[(size_t)((tap * T::CT + ct) * T::KS + ks) * 64];
+}
 template <class T, class SL, int NT, int TILE0, int NTAP, int K>
 __device__ __forceinline__ void conv16b_steps(const uint16_t* __restrict__ buf, const uint16_t* __restrict__ nbr, const bf16x8v* __restrict__ wl,
-                                              f32x4v (&acc)[NT], int lrow, int g, bf16x8v (&b0)[T::KS], bf16x8v (&b1)[T::KS],
+                                              f32x4v (&acc)[NT][2], int lrow, int g, bf16x8v (&b0)[2][T::KS], bf16x8v (&b1)[2][T::KS],
                                               bf16x8v (&aA)[2][T::KS], bf16x8v (&aB)[2][T::KS], int (&idx)[2]) {
   if constexpr (K < SL::list.n) {
     constexpr int t0 = SL::list.t0[K], t1 = SL::list.t1[K], ord = SL::list.ord[K];
     bf16x8v (&cur)[2][T::KS] = (K & 1) ? aB : aA;
     bf16x8v (&nxt)[2][T::KS] = (K & 1) ? aA : aB;
-    bf16x8v (&bc)[T::KS] = (ord & 1) ? b1 : b0;
-    bf16x8v (&bn)[T::KS] = (ord & 1) ? b0 : b1;
-    if constexpr (SL::list.first[K] && SL::list.next_tap[K] >= 0) {
-      constexpr int ntap = NTAP == 1 ? 0 : SL::list.next_tap[K];
-#pragma unroll
-      for (int ks = 0; ks < T::KS; ++ks) bn[ks] = wl[(size_t)(ntap * T::CT * T::KS + ks) * 64];
-    }
+    bf16x8v (&bc)[2][T::KS] = (ord & 1) ? b1 : b0;
+    bf16x8v (&bn)[2][T::KS] = (ord & 1) ? b0 : b1;
+    if constexpr (SL::list.first[K] && SL::list.next_tap[K] >= 0) load_w16b<T>(wl, NTAP == 1 ? 0 : SL::list.next_tap[K], bn);
     if constexpr (K + 1 < SL::list.n) {
       load_rows16b<T>(buf, idx[0], idx[1], SL::list.t1[K + 1] >= 0, g, nxt);
       load_idx16b<T, SL, K + 2, TILE0>(nbr, lrow, idx);
     }
+    // every activation fragment feeds both column tiles: half the LDS reads per MFMA of a 16-channel wave
 #pragma unroll
     for (int ks = 0; ks < T::KS; ++ks) {
-      acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[0][ks], bc[ks], acc[t0], 0, 0, 0);
-      if constexpr (t1 >= 0) acc[t1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[1][ks], bc[ks], acc[t1], 0, 0, 0);
+      acc[t0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[0][ks], bc[0][ks], acc[t0][0], 0, 0, 0);
+      acc[t0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[0][ks], bc[1][ks], acc[t0][1], 0, 0, 0);
+      if constexpr (t1 >= 0) {
+        acc[t1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[1][ks], bc[0][ks], acc[t1][0], 0, 0, 0);
+        acc[t1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[1][ks], bc[1][ks], acc[t1][1], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     conv16b_steps<T, SL, NT, TILE0, NTAP, K + 1>(buf, nbr, wl, acc, lrow, g, b0, b1, aA, aB, idx);
   }
 }
-// One F -> F convolution (NTAP = 9: 3x3, NTAP = 1: 1x1) into the NT accumulators of this wave: bf16 in, fp32 out.
+// One F -> F convolution (NTAP = 9: 3x3, NTAP = 1: 1x1) into this wave's NT x 2 accumulators: bf16 in, fp32 out.
 template <class T, class G, int NT, int TILE0, int NTAP>
 __device__ __forceinline__ void conv16b(const uint16_t* __restrict__ buf, const uint16_t* __restrict__ nbr, const bf16x8v* __restrict__ wl,
-                                        f32x4v (&acc)[NT], int lrow, int g) {
+                                        f32x4v (&acc)[NT][2], int lrow, int g) {
   using SL = Steps16<G, NT, TILE0, 1, NTAP>;                        // one step = (tap, tile pair), all F channels
   if constexpr (SL::list.n > 0) {
-    bf16x8v b0[T::KS], b1[T::KS], aA[2][T::KS], aB[2][T::KS];
+    bf16x8v b0[2][T::KS], b1[2][T::KS], aA[2][T::KS], aB[2][T::KS];
     int idx[2] = {0, 0};
-    constexpr int tap0 = NTAP == 1 ? 0 : SL::list.first_tap;
-#pragma unroll
-    for (int ks = 0; ks < T::KS; ++ks) b0[ks] = wl[(size_t)(tap0 * T::CT * T::KS + ks) * 64];
+    load_w16b<T>(wl, NTAP == 1 ? 0 : SL::list.first_tap, b0);
     load_idx16b<T, SL, 0, TILE0>(nbr, lrow, idx);
     load_rows16b<T>(buf, idx[0], idx[1], SL::list.t1[0] >= 0, g, aA);
     load_idx16b<T, SL, 1, TILE0>(nbr, lrow, idx);
@@ -120,13 +129,110 @@ __device__ __forceinline__ void conv16b(const uint16_t* __restrict__ buf, const 
   }
 }
 
+// One wavefront's share: row tiles TILE0 .. TILE0 + NT - 1 of the workgroup's buffer, output channels 32 cg .. 32 cg + 31
+// (two column tiles).  Every wavefront of the workgroup runs the same number of barriers.
+template <class T, int NT, int TILE0>
+__device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __restrict__ buf, const float* __restrict__ planes,
+                                              const uint16_t* __restrict__ nbr, const uint16_t* __restrict__ pos, int cg, int lane,
+                                              int n, int board0, float* __restrict__ hfeat) {
+  using Gm = typename T::Game;
+  using G = typename T::Geo;
+  constexpr int F = T::FILT, P = Gm::P, C = Gm::C, TB = T::TB, SH = T::SH, R0 = TILE0 * 16;
+  const int lrow = lane & 15, g = lane >> 4;
+  const int ch0 = cg * 32 + lrow;                                   // this lane's output channels: ch0 and ch0 + 16; rows tile*16 + 4 g + i
+  f32x4v acc[NT][2];
+  // ---- stem on the fp32 MFMA (K = 9 C), output rounded to bf16 -------------------------------------------------------------
+  {
+    constexpr int KK = 9 * C, K2 = (KK + 1) / 2, NS = (2 * K2 + 3) / 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float bw0 = net.stem_w[(size_t)((cg * 2) * NS + s) * 64 + lane], bw1 = net.stem_w[(size_t)((cg * 2 + 1) * NS + s) * 64 + lane];
+      const int p = 4 * s + g;
+      const int k = (p & 1) * K2 + (p >> 1);
+      const bool kin = k < KK && p < 2 * K2;
+      const int tap = kin ? k / C : 4, c = kin ? k % C : 0;
+#pragma unroll
+      for (int tile = 0; tile < NT; ++tile) {
+        const int row = kin ? (int)nbr[tap * T::RPAD + R0 + tile * 16 + lrow] : T::RPAD;
+        const float a = planes[row * C + c];
+        acc[tile][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw0, acc[tile][0], 0, 0, 0);
+        acc[tile][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw1, acc[tile][1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float sc = net.stem_ss[ch0 + 16 * ct], sh = net.stem_ss[F + ch0 + 16 * ct];
+#pragma unroll
+      for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = az_fmaf(acc[tile][ct][i], sc, sh);
+          buf[(R0 + tile * 16 + g * 4 + i) * SH + ch0 + 16 * ct] = f32_to_bf16_bits(v > 0.0f ? v : 0.0f);
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---- residual tower -------------------------------------------------------------------------------------------------------
+  uint32_t xres[NT][2][2];                                          // block input as the convolution saw it: bf16 pairs
+  const size_t LAYER_W = (size_t)9 * T::CT * T::KS * 64;            // fragments (16 B) per layer
+  for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    int lrow_l = lrow;
+    asm volatile("" : "+v"(lrow_l));                                // keeps the table look-ups inside the layer loop (registers)
+    conv16b<T, G, NT, TILE0, 9>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow_l, g);
+    __syncthreads();                                                // every wave has finished reading the buffer
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float sc = net.conv_ss[(size_t)layer * 2 * F + ch0 + 16 * ct], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch0 + 16 * ct];
+#pragma unroll
+      for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int a = (R0 + tile * 16 + g * 4 + i) * SH + ch0 + 16 * ct;
+          float v = az_fmaf(acc[tile][ct][i], sc, sh);
+          if (!(layer & 1)) {
+            const uint32_t old = buf[a];
+            if (i & 1) xres[tile][ct][i >> 1] |= old << 16; else xres[tile][ct][i >> 1] = old;
+          } else {
+            const uint32_t pr = xres[tile][ct][i >> 1];
+            v = v + bf16_bits_to_f32((uint16_t)((i & 1) ? (pr >> 16) : (pr & 0xffffu)));
+          }
+          buf[a] = f32_to_bf16_bits(v > 0.0f ? v : 0.0f);
+        }
+    }
+    __syncthreads();
+  }
+  // ---- both 1x1 head convolutions + BN + ReLU, features out in fp32 -------------------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+  conv16b<T, G, NT, TILE0, 1>(buf, nbr, net.head_w + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow, g);
+  {
+    const int nvalid = ((n - board0) < TB ? (n - board0) : TB) * P;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float sc = net.head_ss[ch0 + 16 * ct], sh = net.head_ss[F + ch0 + 16 * ct];
+#pragma unroll
+      for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ps = pos[R0 + tile * 16 + g * 4 + i];
+          const float v = az_fmaf(acc[tile][ct][i], sc, sh);
+          if (ps < nvalid) hfeat[((size_t)board0 * P + ps) * F + ch0 + 16 * ct] = v > 0.0f ? v : 0.0f;
+        }
+    }
+  }
+}
+
 template <class Gm, int F, bool FROM_PLANES, int NT = 11>
 __global__ void __launch_bounds__(64 * (F / 16), F == 64 ? 2 : 1)
 k_tower16b(Net16bDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
   using T = T16B<Gm, F, NT>;
-  using G = typename T::Geo;
-  constexpr int P = Gm::P, C = Gm::C, TB = T::TB, SH = T::SH;
+  constexpr int P = Gm::P, C = Gm::C, TB = T::TB, SH = T::SH, NCG = F / 32, NT0 = (NT + 1) / 2, NT1 = NT / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   uint16_t* buf = (uint16_t*)ldsb;
   float* planes = (float*)(ldsb + (size_t)T::BUFH * 2);
@@ -135,7 +241,7 @@ k_tower16b(Net16bDev net, const GEnv* __restrict__ leaf_env, const int* __restri
   const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
   const int board0 = blockIdx.x * TB;
   if (board0 >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63, cw = tid >> 6, lrow = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint16_t* geo = net.geo[NT == 11 ? 0 : 1];
   // ---- input planes (fp32, permuted row order), tables, the buffer's zero row -------------------------------------------
   for (int i = tid; i < T::PLANES; i += T::THREADS) {
@@ -155,86 +261,8 @@ k_tower16b(Net16bDev net, const GEnv* __restrict__ leaf_env, const int* __restri
   for (int i = tid; i < T::RPAD; i += T::THREADS) pos[i] = geo[i];
   for (int i = tid; i < 9 * T::RPAD; i += T::THREADS) nbr[i] = geo[T::RPAD + i];
   __syncthreads();
-
-  const int ch = cw * 16 + lrow;                                    // this lane's output channel; rows tile*16 + 4 g + i
-  f32x4v acc[NT];
-  // ---- stem on the fp32 MFMA (K = 9 C), output rounded to bf16 -------------------------------------------------------------
-  {
-    constexpr int KK = 9 * C, K2 = (KK + 1) / 2, NS = (2 * K2 + 3) / 4;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const float bw = net.stem_w[(size_t)(cw * NS + s) * 64 + lane];
-      const int p = 4 * s + g;
-      const int k = (p & 1) * K2 + (p >> 1);
-      const bool kin = k < KK && p < 2 * K2;
-      const int tap = kin ? k / C : 4, c = kin ? k % C : 0;
-#pragma unroll
-      for (int tile = 0; tile < NT; ++tile) {
-        const int row = kin ? (int)nbr[tap * T::RPAD + tile * 16 + lrow] : T::RPAD;
-        acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(planes[row * C + c], bw, acc[tile], 0, 0, 0);
-      }
-    }
-    const float sc = net.stem_ss[ch], sh = net.stem_ss[F + ch];
-#pragma unroll
-    for (int tile = 0; tile < NT; ++tile)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = az_fmaf(acc[tile][i], sc, sh);
-        buf[(tile * 16 + g * 4 + i) * SH + ch] = f32_to_bf16_bits(v > 0.0f ? v : 0.0f);
-      }
-  }
-  __syncthreads();
-
-  // ---- residual tower -------------------------------------------------------------------------------------------------------
-  float xres[NT][4];
-  const size_t LAYER_W = (size_t)9 * T::CT * T::KS * 64;            // fragments (16 B) per layer
-  for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    int lrow_l = lrow;
-    asm volatile("" : "+v"(lrow_l));                                // keeps the table look-ups inside the layer loop (registers)
-    conv16b<T, G, NT, 0, 9>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)cw * T::KS * 64 + lane, acc, lrow_l, g);
-    const float sc = net.conv_ss[(size_t)layer * 2 * F + ch], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch];
-    __syncthreads();                                                // every wave has finished reading the buffer
-    if (!(layer & 1)) {
-#pragma unroll
-      for (int tile = 0; tile < NT; ++tile)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int a = (tile * 16 + g * 4 + i) * SH + ch;
-          xres[tile][i] = bf16_bits_to_f32(buf[a]);                 // block input as the convolution saw it
-          const float v = az_fmaf(acc[tile][i], sc, sh);
-          buf[a] = f32_to_bf16_bits(v > 0.0f ? v : 0.0f);
-        }
-    } else {
-#pragma unroll
-      for (int tile = 0; tile < NT; ++tile)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int a = (tile * 16 + g * 4 + i) * SH + ch;
-          float v = az_fmaf(acc[tile][i], sc, sh);
-          v = v + xres[tile][i];
-          buf[a] = f32_to_bf16_bits(v > 0.0f ? v : 0.0f);
-        }
-    }
-    __syncthreads();
-  }
-  // ---- both 1x1 head convolutions + BN + ReLU, features out in fp32 -------------------------------------------------------------
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  conv16b<T, G, NT, 0, 1>(buf, nbr, net.head_w + (size_t)cw * T::KS * 64 + lane, acc, lrow, g);
-  {
-    const float sc = net.head_ss[ch], sh = net.head_ss[F + ch];
-    const int nvalid = ((n - board0) < TB ? (n - board0) : TB) * P;
-#pragma unroll
-    for (int tile = 0; tile < NT; ++tile)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ps = pos[tile * 16 + g * 4 + i];
-        const float v = az_fmaf(acc[tile][i], sc, sh);
-        if (ps < nvalid) hfeat[((size_t)board0 * P + ps) * F + ch] = v > 0.0f ? v : 0.0f;
-      }
-  }
+  // wavefront = (row group, column group): row group 0 owns tiles 0 .. NT0 - 1, row group 1 the rest; a column group is 32
+  // output channels, so an activation fragment read from LDS feeds two MFMAs
+  if (wave < NCG) tower16b_wave<T, NT0, 0>(net, buf, planes, nbr, pos, wave, lane, n, board0, hfeat);
+  else tower16b_wave<T, NT1, NT0>(net, buf, planes, nbr, pos, wave - NCG, lane, n, board0, hfeat);
 }
