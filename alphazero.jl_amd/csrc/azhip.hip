@@ -35,6 +35,7 @@ static int check_device_error(az_engine* e) {
     case DERR_DEPTH: return fail(AZ_ERR_CAPACITY, "simulation path deeper than %d plies", e->v.max_depth);
     case DERR_MOVES: return fail(AZ_ERR_CAPACITY, "game longer than max_moves_per_game = %d", e->v.max_moves);
     case DERR_NO_ROOT: return fail(AZ_ERR_STATE, "MCTS.explore! must be called before MCTS.policy");
+    case DERR_EXCHANGE: return fail(AZ_ERR_HIP, "k_tower16s: a workgroup waited for its partner's half of a layer for too long");
   }
   return fail(AZ_ERR_HIP, "unknown device error %d", code);
 }
@@ -190,6 +191,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     memset(&e->net, 0, sizeof e->net);
     memset(&e->net16, 0, sizeof e->net16);
     { const char* tw = getenv("AZHIP_TOWER"); e->tower_pick = tw ? atoi(tw) : 0; }
+    { const char* hd = getenv("AZHIP_HEADS"); e->heads_pick = hd ? atoi(hd) : 0; }
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); e->num_cu = pr.multiProcessorCount; }
     AZCHK(net_set_kernel_attrs(e));
     // slot groups
@@ -474,6 +476,19 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
       d[1] = o < A ? pol_w[(4 * i + 2 + hh) * L + o] : 0.0f;
     }
   }
+  // k_heads16 fragments (16-board tiles, 32 head filters): per 16-k block j and lane one float4, element s = W[16j + 4s + g][16 tile + (lane & 15)]
+  const bool hd16_ok = npf == 32 && nvf == 32;
+  std::vector<float> hd16_w(4);
+  if (hd16_ok) {
+    const int NV16 = F / 16, NP16 = (A + 15) / 16;
+    const size_t NB = (size_t)2 * P;
+    hd16_w.assign((size_t)(NV16 + NP16) * NB * 64 * 4, 0.0f);
+    for (int t = 0; t < NV16 + NP16; ++t) for (size_t j = 0; j < NB; ++j) for (int l = 0; l < 64; ++l) for (int s4 = 0; s4 < 4; ++s4) {
+      const size_t k = 16 * j + 4 * s4 + (l >> 4);
+      const int o = (t < NV16 ? t : t - NV16) * 16 + (l & 15);
+      hd16_w[((t * NB + j) * 64 + l) * 4 + s4] = t < NV16 ? val_w[k * F + o] : (o < A ? pol_w[k * L + o] : 0.0f);
+    }
+  }
   AZCHK(sync_all(e));
   drop_wave_graphs(e);                                             // they hold the old parameter pointers
   for (void* q : e->net_allocs) (void)hipFree(q);
@@ -501,6 +516,8 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   nd.val2_b = *v2b;
   AZCHK(up(hd_w, &tmp)); nd.hd_w = (const float2*)tmp;
   nd.hd_ok = hd_ok ? 1 : 0;
+  AZCHK(up(hd16_w, &tmp)); nd.hd16_w = (const float4*)tmp;
+  nd.hd16_ok = hd16_ok ? 1 : 0;
   Net16Dev n16;
   memset(&n16, 0, sizeof n16);
   {
@@ -565,6 +582,7 @@ extern "C" int az_net_forward(az_engine* e, const float* X, const float* A, int3
     HIPCHK(hipStreamSynchronize(e->stream));
   }
   HIPCHK(hipGetLastError());
+  if (e->xch_epoch) AZCHK(check_device_error(e));                  // k_tower16s: a bounded wait can give up (DERR_EXCHANGE)
   return AZ_OK;
 }
 
@@ -583,6 +601,7 @@ static int evaluate_envs(az_engine* e, const std::vector<GEnv>& envs, std::vecto
     HIPCHK(hipStreamSynchronize(e->stream));
   }
   HIPCHK(hipGetLastError());
+  if (e->xch_epoch) AZCHK(check_device_error(e));                  // k_tower16s: a bounded wait can give up (DERR_EXCHANGE)
   return AZ_OK;
 }
 
@@ -604,6 +623,7 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
     HIPCHK(hipStreamSynchronize(e->stream));
   }
   HIPCHK(hipGetLastError());
+  if (e->xch_epoch) AZCHK(check_device_error(e));                  // k_tower16s: a bounded wait can give up (DERR_EXCHANGE)
   return AZ_OK;
 }
 

@@ -75,6 +75,8 @@ struct az_engine {
   hipStream_t gt[AZ_MAX_GROUPS];      // network stream of the group
   hipEvent_t ev_tree[AZ_MAX_GROUPS], ev_net[AZ_MAX_GROUPS];
   float* g_hfeat[AZ_MAX_GROUPS];
+  // k_tower16s (split tower, 128 filters): publish areas per feature buffer (slot g = group g, AZ_MAX_GROUPS = d_hfeat), launch epoch
+  unsigned long long* xch[AZ_MAX_GROUPS + 1]; unsigned long long xch_epoch;
   std::vector<void*> allocs;
   std::vector<void*> net_allocs;   // device copies of the packed network (replaced by az_net_set_params)
   // network
@@ -86,6 +88,7 @@ struct az_engine {
   uint16_t* d_geo[3];            // Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h)
   int nts;                       // row tiles of the game's latency tower variant (NTS<Game>, resnet16.h)
   char last_tower[96];           // name of the tower kernel that served the most recent network launch (az_net_last_kernel)
+  int heads_pick;                // AZHIP_HEADS=16|32 forces k_heads16 / k_heads_mfma; 0 = by launch size
   int tower_pick;                // AZHIP_TOWER=16|32|3|21 forces a tower kernel (3 = k_tower16 with 3 row tiles, 21 = k_tower16x2); 0 = choose per launch
   int num_cu;
   int nn_cap;

@@ -16,6 +16,10 @@ template <class Gm, int F, bool PLANES_ONLY = false> static int set_kernel_attrs
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, NTS<Gm>>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, NTS<Gm>>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, NTS<Gm>>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, NTS<Gm>>::BYTES));
+  if constexpr (F == 128) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16s<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16S<Gm, F>::BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16s<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16S<Gm, F>::BYTES));
+  }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   return AZ_OK;
@@ -53,7 +57,8 @@ static void note_tower(az_engine* e, int tw, int F) {
   static const char* const gn[] = {"ConnectFour", "TicTacToe", "Mancala", "Go9Planes"};
   const char* g = gn[e->cfg.game];
   if (e->cfg.net_bf16) { snprintf(e->last_tower, sizeof e->last_tower, "k_tower16b<%s,%d,NT=%d>", g, F, tw == 3 ? e->nts : 11); return; }
-  if (tw == 21) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d>", g, F);
+  if (tw == 2) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16s<%s,%d>", g, F);
+  else if (tw == 21) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d>", g, F);
   else if (tw == 3) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=%d>", g, F, e->nts);
   else if (tw == 16) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=11>", g, F);
   else snprintf(e->last_tower, sizeof e->last_tower, "k_tower<%s,%d>", g, F);
@@ -67,6 +72,12 @@ static void note_tower(az_engine* e, int tw, int F) {
 // barriers per row).  Measured round 2 (tools/run_config.py): Mancala 8192 slots 13.5 M sims/s on k_tower, 21.5 M on
 // k_tower16 (31 of 99 products); 5x128 two groups 1.10 vs 1.20 M.  Returns 16, 21, 32 or 3.
 template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
+  // split tower (k_tower16s, 128 filters): both workgroups of every pair must be resident at once -> all slot groups'
+  // launches together at most num_cu workgroups (beyond that the towers queue for CUs and the split only costs: 256
+  // slots in two groups 0.62 vs 0.71 M sims/s); its kernel arguments change per launch (epoch): not under hipGraph replay
+  const bool can_split = F == 128 && !e->cfg.net_bf16 && !e->use_graphs && e->cfg.num_blocks <= 127 &&
+                         2 * std::max(1, e->ngroups) * ((n + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB) <= (e->num_cu > 0 ? e->num_cu : 256);
+  if (e->tower_pick == 2 && can_split) return 2;
   if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64))) return e->tower_pick;
   if (e->cfg.net_bf16) {                                           // k_tower16b: 11 or 3 row tiles
     if (e->tower_pick == 3 || e->tower_pick == 16) return e->tower_pick;
@@ -86,7 +97,7 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
   const double c16 = (double)((b16 + cu - 1) / cu) * T16<Gm, F>::RPAD * f16;
   const double c32 = (double)((b32 + cu - 1) / cu) * TOWER_ROWS;     // k_tower (32x32x2) computes every tap
   const double c3 = 1.1 * (double)((b3 + cu - 1) / cu) * T16<Gm, F, NTS<Gm>>::RPAD * f3;
-  if (c3 <= c16 && c3 <= c32) return 3;
+  if (c3 <= c16 && c3 <= c32) return can_split && e->tower_pick != 3 ? 2 : 3;
   // paired k_tower16x2: 336 rows = 8 Connect-Four boards per workgroup, no padding rows.  Its 92 KB of LDS allow one
   // workgroup per CU, so with several slot groups the groups' towers cannot interleave on a CU (Connect-Four, two groups:
   // 3.80 vs 4.11 M sims/s in round 1): +8 % on its cost there
@@ -97,11 +108,38 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
   }
   return c16 <= c32 ? 16 : 32;
 }
+// publish areas of k_tower16s for the launches that write `hfeat` (one feature buffer = one stream at a time)
+template <class Gm> static int xch_slot(az_engine* e, const float* hfeat, unsigned long long** xch) {
+  using T = T16S<Gm, 128>;
+  int slot = AZ_MAX_GROUPS;
+  for (int g = 0; g < e->ngroups; ++g) if (hfeat == e->g_hfeat[g]) slot = g;
+  if (!e->xch[slot]) AZCHK(dalloc(e, &e->xch[slot], (size_t)(e->num_cu > 0 ? e->num_cu : 256) * T::XCH_WORDS));   // zeroed: tag 0 is never expected
+  *xch = e->xch[slot];
+  return AZ_OK;
+}
+// Dense heads of n_max boards: 16-board tiles (k_heads16: a quarter of the chain latency, 23 instead of 43 us per launch
+// at 64 filters whatever the size) unless several slot groups run big launches side by side -- there the heads hide
+// under the other group's tower anyway and twice as many workgroups asking for a CU cost 1 % (0.867 vs 0.857 ms per
+// step, two groups of 2048): 32-board tiles (k_heads_mfma).  The vector-ALU kernel when the head filters do not fit
+// the MFMA fragments.
+static constexpr int HEADS16_MAX_BOARDS = 1024;
+template <class Gm, int F>
+static int launch_heads(az_engine* e, hipStream_t st, const float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max,
+                        const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
+  const bool small = e->heads_pick == 16 || (e->heads_pick != 32 && (n_max <= HEADS16_MAX_BOARDS || e->ngroups == 1));
+  if (e->net.hd16_ok && small)
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads16<Gm, F>), (n_max + 15) / 16, 64 * (F / 16 + HEADS16_NPT<Gm>), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
+  else if (e->net.hd_ok)
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, F>), (n_max + 31) / 32, 64 * (F / 32 + HEADS_NPT<Gm>), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
+  else
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads<Gm, F>), (n_max + 3) / 4, 4 * (F + HEADS_LP<Gm>), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
+  return AZ_OK;
+}
 template <class Gm, int F, bool FROM_PLANES>
 static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max, const float* X,
                         const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
   constexpr int TB = TOWER_ROWS / Gm::P;
-  const int gt = (n_max + TB - 1) / TB, gh = (n_max + 3) / 4;
+  const int gt = (n_max + TB - 1) / TB;
   if (gt == 0) return AZ_OK;
   constexpr int TB16 = T16<Gm, F>::TB, THR16 = T16<Gm, F>::THREADS, LDS16 = T16<Gm, F>::BYTES;
   constexpr int TB3 = T16<Gm, F, NTS<Gm>>::TB, LDS3 = T16<Gm, F, NTS<Gm>>::BYTES;
@@ -112,6 +150,13 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
     constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, NTS<Gm>>::TB, LDSb3 = T16B<Gm, F, NTS<Gm>>::BYTES;
     if (tw == 3) LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b<Gm, F, FROM_PLANES, NTS<Gm>>), (n_max + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
     else LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b<Gm, F, FROM_PLANES, 11>), (n_max + TBb - 1) / TBb, THRb, LDSb, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
+  } else if (tw == 2) {
+    if constexpr (F == 128) {
+      unsigned long long* xa;
+      AZCHK(xch_slot<Gm>(e, hfeat, &xa));
+      LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16s<Gm, F, FROM_PLANES>), 2 * ((n_max + TB3 - 1) / TB3), (T16S<Gm, F>::THREADS), LDS3, e->net16, envs, eslots, n_ptr, n_max, X, hfeat,
+                xa, ++e->xch_epoch, e->v.err);
+    }
   } else if (tw == 21) {
     if constexpr (F == 64)
       LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
@@ -121,11 +166,7 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES>), (n_max + TB16 - 1) / TB16, THR16, LDS16, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
   else
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower<Gm, F, FROM_PLANES>), gt, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, envs, eslots, n_ptr, n_max, X, hfeat);
-  if (e->net.hd_ok)
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, F>), (n_max + 31) / 32, 64 * (F / 32 + HEADS_NPT<Gm>), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
-  else
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads<Gm, F>), gh, 4 * (F + HEADS_LP<Gm>), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
-  return AZ_OK;
+  return launch_heads<Gm, F>(e, st, hfeat, envs, eslots, n_ptr, n_max, Amask, Pout, Vout, Pinv, pstride);
 }
 // launches tower + heads on `n` boards (device count in n_ptr when given)
 template <class Gm, bool FROM_PLANES>
@@ -155,6 +196,13 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
     constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, NTS<Gm>>::TB, LDSb3 = T16B<Gm, F, NTS<Gm>>::BYTES;
     if (tw == 3) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, NTS<Gm>>), (N + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
     else LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 11>), (N + TBb - 1) / TBb, THRb, LDSb, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+  } else if (tw == 2) {
+    if constexpr (F == 128) {
+      unsigned long long* xa;
+      AZCHK(xch_slot<Gm>(e, e->g_hfeat[g], &xa));
+      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16s<Gm, F, false>), 2 * ((N + TB3 - 1) / TB3), (T16S<Gm, F>::THREADS), LDS3, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g],
+                xa, ++e->xch_epoch, e->v.err);
+    }
   } else if (tw == 21) {
     if constexpr (F == 64)
       LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
@@ -165,10 +213,7 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   else
     LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower<Gm, F, false>), (N + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
-  if (e->net.hd_ok)
-    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads_mfma<Gm, F>), (N + 31) / 32, 64 * (F / 32 + HEADS_NPT<Gm>), 0, e->net, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
-  else
-    LAUNCH_ON(e, st, AZ_K_HEADS, N, (k_heads<Gm, F>), (N + 3) / 4, 4 * (F + HEADS_LP<Gm>), 0, e->net, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g], v.Pout, v.Vout, (float*)nullptr, L);
+  AZCHK((launch_heads<Gm, F>(e, st, e->g_hfeat[g], v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, v.Pout, v.Vout, (float*)nullptr, L)));
   return AZ_OK;
 }
 template <class Gm> static int wave_net(az_engine* e, int g, bool split, int nmax) {

@@ -26,6 +26,14 @@
 #include "games.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N - 1>): register arrays indexed by the constant are
+// split into registers by the front end (a `#pragma unroll` loop inside a run-time loop leaves them in scratch)
+template <int I, int N, class Fn> __device__ __forceinline__ void static_for_impl(Fn& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_impl<I + 1, N>(f); }
+}
+template <int N, class Fn> __device__ __forceinline__ void static_for(Fn f) { static_for_impl<0, N>(f); }
 
 struct NetDev {
   int nblocks, F, npf, nvf, HF;       // HF = padded npf + nvf (multiple of 32)
@@ -44,6 +52,8 @@ struct NetDev {
   unsigned long long* dbg;            // optional [blocks][16] s_memtime stamps (az_debug_tower_timeline)
   const float2* hd_w;                 // MFMA dense heads: [F/32 value tiles + 1 policy tile][K/4][64] float2
   int hd_ok;                          // 1 when npf % 4 == 0 && nvf % 4 == 0 (k_heads_mfma usable)
+  const float4* hd16_w;               // k_heads16: [F/16 value tiles + ceil(A/16) policy tiles][K/16][64] float4: W[16j + 4s + (lane>>4)][16 tile + (lane&15)], s = x..w
+  int hd16_ok;                        // 1 when npf == nvf == 32
 };
 
 static constexpr int TOWER_ROWS = 128;
@@ -327,6 +337,37 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
 #undef AZ_STAMP
 }
 
+// Last step of the heads for ONE board by one lane: softmax over the logits, Dense(F => 1, tanh) over the value-hidden
+// units, then forward_normalized (network.jl:264-271).  `logit`: the board's A logits (bias added), `vh`: its F hidden units.
+template <class Gm, int F>
+__device__ __forceinline__ void heads_finish(const NetDev& net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+                                             const float* __restrict__ Amask, float* __restrict__ Pout, float* __restrict__ Vout,
+                                             float* __restrict__ Pinv, int pstride, int e, const float* __restrict__ logit, const float* __restrict__ vh) {
+  constexpr int A = Gm::A;
+  float pr[A];
+  float mx = logit[0];
+  for (int a = 1; a < A; ++a) mx = logit[a] > mx ? logit[a] : mx;
+  float s = 0.0f;
+  for (int a = 0; a < A; ++a) { pr[a] = az_expf(logit[a] - mx); s += pr[a]; }
+  for (int a = 0; a < A; ++a) pr[a] = pr[a] / s;                   // softmax, resnet.jl:84
+  float av = 0.0f;
+  for (int k = 0; k < F; ++k) av = az_fmaf(vh[k], net.val2_w[k], av);
+  av = av + net.val2_b;
+  const float val = az_tanhf(av);                                  // Dense(F => 1, tanh), resnet.jl:90
+  float sp = 0.0f;
+  for (int a = 0; a < A; ++a) {
+    float mk;
+    if (Amask) mk = Amask[(size_t)e * A + a];
+    else mk = (float)((Gm::mask(leaf_env[eval_slots[e]]) >> a) & 1);
+    pr[a] = pr[a] * mk;
+    sp += pr[a];
+  }
+  for (int a = 0; a < A; ++a) Pout[(size_t)e * pstride + a] = pr[a] / (sp + 1.1920929e-7f);
+  for (int a = A; a < pstride; ++a) Pout[(size_t)e * pstride + a] = 0.0f;
+  Vout[e] = val;
+  if (Pinv) Pinv[e] = 1.0f - sp;
+}
+
 // Dense heads, softmax, tanh, forward_normalized.  HB boards per 4(F+16)-thread workgroup; thread
 // (b, o): o < F -> value hidden unit, F <= o < F + A -> policy logit.
 template <class Gm> constexpr int HEADS_LP = (Gm::A + 15) / 16 * 16;          // logit slots per board (16 for the device games, 96 for 82 actions)
@@ -370,31 +411,7 @@ k_heads(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
     }
   }
   __syncthreads();
-  if (o == 0 && e < n) {
-    float pr[A];
-    float mx = s_logit[b][0];
-    for (int a = 1; a < A; ++a) mx = s_logit[b][a] > mx ? s_logit[b][a] : mx;
-    float s = 0.0f;
-    for (int a = 0; a < A; ++a) { pr[a] = az_expf(s_logit[b][a] - mx); s += pr[a]; }
-    for (int a = 0; a < A; ++a) pr[a] = pr[a] / s;                 // softmax, resnet.jl:84
-    float acc = 0.0f;
-    for (int k = 0; k < F; ++k) acc = az_fmaf(s_vh[b][k], net.val2_w[k], acc);
-    acc = acc + net.val2_b;
-    const float val = az_tanhf(acc);                               // Dense(F => 1, tanh), resnet.jl:90
-    // forward_normalized, network.jl:264-271
-    float sp = 0.0f;
-    for (int a = 0; a < A; ++a) {
-      float mk;
-      if (Amask) mk = Amask[(size_t)e * A + a];
-      else mk = (float)((Gm::mask(leaf_env[eval_slots[e]]) >> a) & 1);
-      pr[a] = pr[a] * mk;
-      sp += pr[a];
-    }
-    for (int a = 0; a < A; ++a) Pout[(size_t)e * pstride + a] = pr[a] / (sp + 1.1920929e-7f);
-    for (int a = A; a < pstride; ++a) Pout[(size_t)e * pstride + a] = 0.0f;
-    Vout[e] = val;
-    if (Pinv) Pinv[e] = 1.0f - sp;
-  }
+  if (o == 0 && e < n) heads_finish<Gm, F>(net, leaf_env, eval_slots, Amask, Pout, Vout, Pinv, pstride, e, s_logit[b], s_vh[b]);
 }
 
 // Dense heads on MFMA.  One 32-board tile per call; wavefront w < F/32 computes value-hidden
@@ -479,31 +496,7 @@ __device__ __forceinline__ void heads_mfma_tile(const NetDev& net, const GEnv* _
   }
   __syncthreads();
   const int b = threadIdx.x;
-  if (b < 32 && board0 + b < n) {
-    const int e = board0 + b;
-    float pr[A];
-    float mx = s_logit[b * LP];
-    for (int a = 1; a < A; ++a) mx = s_logit[b * LP + a] > mx ? s_logit[b * LP + a] : mx;
-    float s = 0.0f;
-    for (int a = 0; a < A; ++a) { pr[a] = az_expf(s_logit[b * LP + a] - mx); s += pr[a]; }
-    for (int a = 0; a < A; ++a) pr[a] = pr[a] / s;
-    float av = 0.0f;
-    for (int k = 0; k < F; ++k) av = az_fmaf(s_vh[b * SV + k], net.val2_w[k], av);
-    av = av + net.val2_b;
-    const float val = az_tanhf(av);
-    float sp = 0.0f;
-    for (int a = 0; a < A; ++a) {
-      float mk;
-      if (Amask) mk = Amask[(size_t)e * A + a];
-      else mk = (float)((Gm::mask(leaf_env[eval_slots[e]]) >> a) & 1);
-      pr[a] = pr[a] * mk;
-      sp += pr[a];
-    }
-    for (int a = 0; a < A; ++a) Pout[(size_t)e * pstride + a] = pr[a] / (sp + 1.1920929e-7f);
-    for (int a = A; a < pstride; ++a) Pout[(size_t)e * pstride + a] = 0.0f;
-    Vout[e] = val;
-    if (Pinv) Pinv[e] = 1.0f - sp;
-  }
+  if (b < 32 && board0 + b < n) heads_finish<Gm, F>(net, leaf_env, eval_slots, Amask, Pout, Vout, Pinv, pstride, board0 + b, s_logit + b * LP, s_vh + b * SV);
 }
 template <class Gm, int F>
 __global__ void __launch_bounds__(64 * (F / 32 + HEADS_NPT<Gm>))
@@ -518,4 +511,103 @@ k_heads_mfma(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restric
   const int board0 = blockIdx.x * 32;
   if (board0 >= n) return;
   heads_mfma_tile<Gm, F>(net, leaf_env, eval_slots, n, Amask, hfeat, Pout, Vout, Pinv, pstride, board0, s_vh, s_logit);
+}
+
+// Dense heads for SMALL launches (a wave of a 128-worker engine, the arena): 16 boards per workgroup on
+// v_mfma_f32_16x16x4_f32, F/16 value wavefronts + ceil(A/16) policy wavefronts, so a board tile's K = 32 P chain costs
+// 8 P MFMAs of 32 cycles instead of 16 P of 64 (k_heads_mfma's 32-board tiles: 75 us for 128 boards at F = 128, one
+// workgroup's latency, against 14 us of chain here) and four times as many CUs take part.  32 head filters only
+// (NetDev::hd16_ok).  The MFMA's k slot is the lane group g = lane >> 4 and the contract wants ascending k, so the
+// lane (board m, g) needs features 4s + g (s = 0..3) of each 16-feature block while a coalesced float4 load gives it
+// 4g .. 4g + 3: the 4 x 4 transposition goes through a wavefront-private LDS patch (row stride 20 floats: the b128
+// writes and the b32 reads are both conflict-free), double-buffered, one block ahead of the MFMAs; global loads run
+// HEADS16_DEPTH blocks ahead.  Same fp32 chain as k_heads / k_heads_mfma: bit-identical outputs.
+#ifndef HEADS16_DEPTH
+#define HEADS16_DEPTH 8
+#endif
+template <class Gm> constexpr int HEADS16_NPT = (Gm::A + 15) / 16;
+template <class Gm, int F>
+__global__ void __launch_bounds__(64 * (F / 16 + HEADS16_NPT<Gm>))
+k_heads16(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+          const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ Amask,
+          const float* __restrict__ hfeat, float* __restrict__ Pout, float* __restrict__ Vout,
+          float* __restrict__ Pinv, int pstride) {
+  constexpr int P = Gm::P, A = Gm::A, NVT = F / 16, NPT = HEADS16_NPT<Gm>, LP = HEADS_LP<Gm>, SV = F + 1, NB = 2 * P, DEPTH = HEADS16_DEPTH, RS = 20;
+  static_assert(NB >= DEPTH, "pipeline deeper than the chain");
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ float s_vh[16 * SV];
+  __shared__ float s_logit[16 * LP];
+  __shared__ __attribute__((aligned(16))) float s_tr[NVT + NPT][2][16 * RS];
+  const int n = n_eval_ptr ? *n_eval_ptr : n_fixed;
+  const int board0 = blockIdx.x * 16;
+  if (board0 >= n) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
+  const bool is_pol = wave >= NVT;
+  const int pt = wave - NVT;
+  const int HF = net.HF;
+  int e = board0 + m;
+  if (e >= n) e = n - 1;                           // clamp: rows past the batch are computed and dropped
+  const float* hf = hfeat + (size_t)e * P * HF + (is_pol ? 0 : net.npf) + 4 * g;
+  const f32x4v* wp = (const f32x4v*)net.hd16_w + (size_t)wave * NB * 64 + lane;
+  float* trw = &s_tr[wave][0][0] + m * RS + 4 * g;         // this lane's float4 of a patch
+  const float* trr = &s_tr[wave][0][0] + m * RS + g;       // ... and its column (stride 4)
+  f32x4v ga[DEPTH], gb[DEPTH];
+  float ta[2][4];
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  // block j: features 16 (j & 1) .. + 15 of position j >> 1, fragment j of this wave's tile
+#define H16_LOAD(hfj, wpj, d, st) do { ga[st] = *(const f32x4v*)((hfj) + ((d) >> 1) * HF + ((d) & 1) * 16); gb[st] = (wpj)[(size_t)(d) * 64]; } while (0)
+  // ga[st] -> ta[par] through patch `par`
+#define H16_TRANSPOSE(st, par) do {                                              \
+    *(f32x4v*)(trw + (par) * 16 * RS) = ga[st];                                  \
+    __builtin_amdgcn_wave_barrier();                                             \
+    ta[par][0] = trr[(par) * 16 * RS]; ta[par][1] = trr[(par) * 16 * RS + 4];    \
+    ta[par][2] = trr[(par) * 16 * RS + 8]; ta[par][3] = trr[(par) * 16 * RS + 12]; } while (0)
+#define H16_MFMA(par, b) do {                                                    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[par][0], (b).x, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[par][1], (b).y, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[par][2], (b).z, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[par][3], (b).w, acc, 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+  static_for<DEPTH>([&](auto dc) { constexpr int d = decltype(dc)::value; H16_LOAD(hf, wp, d, d); });
+  H16_TRANSPOSE(0, 0);
+  // steady state in chunks of DEPTH blocks (every block of a chunk has its successor DEPTH ahead inside the chain),
+  // then a fully unrolled tail of DEPTH .. 2 DEPTH - 1 blocks
+  constexpr int MAIN = (NB - DEPTH) / DEPTH, TAIL = NB - MAIN * DEPTH;
+  static_assert(DEPTH % 2 == 0, "patch parity follows the register index");
+  const float* hfj = hf;
+  const f32x4v* wpj = wp;
+  for (int c = 0; c < MAIN; ++c) {
+    static_for<DEPTH>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      const f32x4v b = gb[d];
+      H16_LOAD(hfj, wpj, d + DEPTH, d);            // ga[d] went through the patch one block ago, gb[d] is in `b`
+      H16_TRANSPOSE((d + 1) % DEPTH, (d + 1) & 1);
+      H16_MFMA(d & 1, b);
+    });
+    hfj += (DEPTH / 2) * HF;
+    wpj += (size_t)DEPTH * 64;
+  }
+  static_for<TAIL>([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    const f32x4v b = gb[d % DEPTH];
+    if constexpr (d + DEPTH < TAIL) H16_LOAD(hfj, wpj, d + DEPTH, d % DEPTH);
+    if constexpr (d + 1 < TAIL) H16_TRANSPOSE((d + 1) % DEPTH, (d + 1) & 1);
+    H16_MFMA(d & 1, b);
+  });
+#undef H16_LOAD
+#undef H16_TRANSPOSE
+#undef H16_MFMA
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * g + i;                     // board of the tile; column m = output
+    if (is_pol) { if (pt * 16 + m < A) s_logit[row * LP + pt * 16 + m] = acc[i] + net.pol_b[pt * 16 + m]; }
+    else {
+      const int o = wave * 16 + m;
+      const float v = acc[i] + net.val_b[o];
+      s_vh[row * SV + o] = v > 0.0f ? v : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int b = threadIdx.x;
+  if (b < 16 && board0 + b < n) heads_finish<Gm, F>(net, leaf_env, eval_slots, Amask, Pout, Vout, Pinv, pstride, board0 + b, s_logit + b * LP, s_vh + b * SV);
 }

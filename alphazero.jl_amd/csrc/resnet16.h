@@ -22,7 +22,6 @@
 #include "games.h"
 #include "resnet.h"
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 struct Net16Dev {
   int nblocks;
@@ -33,7 +32,7 @@ struct Net16Dev {
   const float4* head_w;     // [4 col tiles][4][64] float4
   const float* head_ss;     // [2][64]
   const uint16_t* geo[3];   // row permutation tables (Geo16: pos [RPAD], nbr [9][RPAD]) of the 11-tile, 3-tile and 21-tile kernels
-  unsigned long long* dbg;  // optional [workgroups][8] s_memtime stamps (az_debug_tower_timeline): start, stem, tower, head conv + features, end
+  unsigned long long* dbg;  // optional [workgroups][8] s_memtime stamps (az_debug_tower_timeline): 0 start, 1 stem done, 2 tower done, 3 features written; layer 2: 6 start, 4 convolution done, 5 barrier passed, 7 epilogue done
 };
 // ---------------------------------------------------------------------------------------------------------------
 // Row permutation of the tower kernels: skipping the taps that fall off the board.
@@ -380,6 +379,8 @@ __device__ __forceinline__ void conv16p_steps(const float* __restrict__ buf, con
   }
 }
 // One F -> F convolution (NTAP = 9: 3x3, NTAP = 1: 1x1) into the NT accumulators of this wave, permuted rows.
+// (Requesting the first tap's weight fragments before the previous layer's epilogue and barriers was tried: the kernel
+// alone is unchanged, 0.844 ms per 4096 boards, and two slot groups lose 2 % -- 0.857 vs 0.838 ms per step.)
 template <class T, class G, int NT, int TILE0, int NTAP>
 __device__ __forceinline__ void conv16p(const float* __restrict__ buf, const uint16_t* __restrict__ nbr, const float4* __restrict__ wl,
                                         f32x4v (&acc)[NT], int lrow, int g) {
@@ -403,13 +404,79 @@ template <int F> struct T16Threads { static constexpr int V = 64 * (F / 16); };
 // row tiles of the latency variant: 3 (one Connect-Four board, 5 Tic-tac-toe, 3 Mancala), or what one board needs (9x9: 6)
 template <class Gm> constexpr int NTS = Gm::P <= 48 ? 3 : (Gm::P + 15) / 16;
 
+// What a workgroup does after it has written a layer's outputs (its own channels) into the activation buffer.
+// NoXch: the workgroup owns every channel -- a barrier.
+struct NoXch {
+  static constexpr int STEM_HALVES = 1;
+  static constexpr bool EARLY_PUBLISH = false;
+};
+// PairXch (k_tower16s): two workgroups share a board tile, each computes one half of the output channels of every
+// residual layer and needs the other half before the next convolution.  Every lane publishes its NT x 4 outputs, in
+// fragment order, as 64-bit words (value, tag) to the workgroup's area in HBM -- two areas, by layer parity; tag =
+// launch epoch x 256 + layer -- and then polls the partner lane's words until they carry the tag: no flag, no
+// store-completion wait, one store -> load latency per layer.  Agent-scope relaxed atomics (write-through stores,
+// cache-bypassing loads; 8-byte single-copy atomicity keeps value and tag together): no cache-wide write-back or
+// invalidate.  An area is rewritten two layers later, which the partner can only reach after it has read this layer.
+// (tools/probes/xcd_exchange.hip: a one-way hand-over with sc1 stores and sc1 loads takes ~1000 cycles inside an XCD and
+// ~1270 across XCDs; sc0 or plain loads, also RMW atomics at workgroup scope, keep returning the CU's cached copy and
+// never see the partner's word, even on the same XCD -- so pairs are simply (b, b ^ 1).)
+// The poll is bounded: a partner that never arrives (it cannot happen while all workgroups of the launch fit on the
+// chip, which pick_tower guarantees) raises DERR_EXCHANGE instead of hanging the GPU.
+enum { DERR_EXCHANGE = 6 };
+static constexpr int XCH_SPIN_LIMIT = 1 << 20;
+struct PairXch {
+  static constexpr int STEM_HALVES = 2;              // the stem is cheap: both halves computed locally, one exchange less
+  unsigned long long* mine;          // [2][NT * 4][THREADS]
+  const unsigned long long* theirs;
+  uint32_t tag0;                     // launch epoch << 8
+  int* err;
+  int pch;                           // the partner lane's output channel
+  static constexpr bool EARLY_PUBLISH = true;        // outputs leave for the partner before the workgroup's own barrier
+  template <class T, int NT>
+  __device__ __forceinline__ void publish(int step, const float (&ov)[NT][4], int tid) const {
+    const uint32_t tag = tag0 + (uint32_t)step;
+    unsigned long long* m = mine + (size_t)(step & 1) * NT * 4 * T::THREADS + tid;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __hip_atomic_store(m + (t * 4 + i) * T::THREADS, ((unsigned long long)tag << 32) | __float_as_uint(ov[t][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  template <class T, int NT, int R0>
+  __device__ __forceinline__ void collect(int step, float* __restrict__ buf, int g, int lrow, int tid) const {
+    constexpr int THREADS = T::THREADS, F = T::FILT;
+    const uint32_t tag = tag0 + (uint32_t)step;
+    const unsigned long long* th = theirs + (size_t)(step & 1) * NT * 4 * THREADS + tid;
+    unsigned long long pv[NT][4];
+    int spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pv[t][i] = __hip_atomic_load(th + (t * 4 + i) * THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (uint32_t)(pv[t][i] >> 32) == tag;
+        }
+      if (ok) break;
+      if (++spins > XCH_SPIN_LIMIT) { atomicCAS(err, 0, (int)DERR_EXCHANGE); break; }
+    }
+    const int ppos = posF<F>(pch);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) buf[(R0 + t * 16 + g * 4 + i) * T::STRIDE + ppos] = __uint_as_float((uint32_t)pv[t][i]);
+    __syncthreads();
+  }
+};
+
 // One wavefront's share of the tower: its NT row tiles start at row tile TILE0 of the workgroup's LDS buffer (rows in
 // Geo16's permuted order), it owns the 16 output channels of channel tile cw.  The caller has filled `planes` and the
 // tables, zeroed the buffer's zero row and synchronised; every wavefront of the workgroup runs the same number of barriers.
-template <class T, bool FROM_PLANES, int NT, int TILE0>
+template <class T, bool FROM_PLANES, int NT, int TILE0, class X = NoXch>
 __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restrict__ buf, const float* __restrict__ planes,
                                              const uint16_t* __restrict__ nbr, const uint16_t* __restrict__ pos, int cw,
-                                             int lane, int n, int board0, float* __restrict__ hfeat) {
+                                             int lane, int n, int board0, float* __restrict__ hfeat, const X& xch = X{}) {
   using Gm = typename T::Game;
   using G = typename T::Geo;
   constexpr int F = T::FILT, P = Gm::P, C = Gm::C, TB = T::TB, STRIDE = T::STRIDE, R0 = TILE0 * 16;
@@ -422,15 +489,20 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
   const int opos = posF<F>(ch);
 
   f32x4v acc[NT];
+  float ov[NT][4];                                   // this lane's outputs of the layer just finished (what a partner workgroup needs)
   // ---- stem: Conv(3x3, C => F) + BN + ReLU, K = 9C padded to a multiple of 4 (every tap: its k order mixes them) ----
-  {
+  // (a pair of workgroups, X::STEM_HALVES = 2: this wavefront also computes the partner's channel tile -- cheaper than an exchange)
+#pragma unroll
+  for (int hh = 0; hh < X::STEM_HALVES; ++hh) {
     constexpr int KK = 9 * C, K2 = (KK + 1) / 2, NS = (2 * K2 + 3) / 4;
+    const int cws = X::STEM_HALVES == 1 ? cw : hh * (F / 32) + cw % (F / 32);
+    const int chs = cws * 16 + lrow, oposs = posF<F>(chs);
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       // sequence position p = 4s + g -> k = (p & 1) * K2 + (p >> 1)   (the paired order of the contract)
-      const float bw = net.stem_w[(size_t)(cw * NS + s) * 64 + lane];
+      const float bw = net.stem_w[(size_t)(cws * NS + s) * 64 + lane];
       const int p = 4 * s + g;
       const int k = (p & 1) * K2 + (p >> 1);
       const bool kin = k < KK && p < 2 * K2;
@@ -442,13 +514,13 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
         acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[tile], 0, 0, 0);
       }
     }
-    const float sc = net.stem_ss[ch], sh = net.stem_ss[F + ch];
+    const float sc = net.stem_ss[chs], sh = net.stem_ss[F + chs];
 #pragma unroll
     for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float v = az_fmaf(acc[tile][i], sc, sh);
-        buf[(R0 + tile * 16 + g * 4 + i) * STRIDE + opos] = v > 0.0f ? v : 0.0f;
+        buf[(R0 + tile * 16 + g * 4 + i) * STRIDE + oposs] = v > 0.0f ? v : 0.0f;
       }
   }
   __syncthreads();
@@ -466,8 +538,32 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
     asm volatile("" : "+v"(lrow_l));
     conv16p<T, G, NT, TILE0, 9>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)cw * T::SQ * 64 + lane, acc, lrow_l, g);
     const float sc = net.conv_ss[(size_t)layer * 2 * F + ch], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch];
+    if (layer == 2) AZ_STAMP16(4);
+    if constexpr (X::EARLY_PUBLISH) {
+      // a pair of workgroups: the outputs (they need only this lane's own elements of the buffer) go to the partner
+      // first, then the barrier, the buffer update and the partner's half
+#pragma unroll
+      for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = az_fmaf(acc[tile][i], sc, sh);
+          if (!(layer & 1)) xres[tile][i] = buf[(R0 + tile * 16 + g * 4 + i) * STRIDE + opos];
+          else v = v + xres[tile][i];
+          ov[tile][i] = v > 0.0f ? v : 0.0f;
+        }
+      xch.template publish<T, NT>(layer, ov, threadIdx.x);
+      __builtin_amdgcn_s_setprio(2);
+      __syncthreads();                               // every wave has finished reading the buffer
+      if (layer == 2) AZ_STAMP16(5);
+#pragma unroll
+      for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) buf[(R0 + tile * 16 + g * 4 + i) * STRIDE + opos] = ov[tile][i];
+      xch.template collect<T, NT, R0>(layer, buf, g, lrow, threadIdx.x);
+    } else {
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();                                 // every wave has finished reading the buffer
+    if (layer == 2) AZ_STAMP16(5);
     if (!(layer & 1)) {
 #pragma unroll
       for (int tile = 0; tile < NT; ++tile)
@@ -490,7 +586,9 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
         }
     }
     __syncthreads();
+    }
     __builtin_amdgcn_s_setprio(0);
+    if (layer == 1 || layer == 2) AZ_STAMP16(5 + layer);           // 6: layer 2 starts, 7: layer 2 done
   }
   AZ_STAMP16(2);
   // ---- both 1x1 head convolutions + BN + ReLU as one F => F GEMM ------------------------------------
@@ -581,6 +679,56 @@ k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restri
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave < T::CT) tower16_wave<T, FROM_PLANES, T::NT0, 0>(net, buf, planes, nbr, pos, wave, lane, n, board0, hfeat);
   else tower16_wave<T, FROM_PLANES, T::NT1, T::NT0>(net, buf, planes, nbr, pos, wave - T::CT, lane, n, board0, hfeat);
+}
+
+// Split form for launches that leave most CUs idle (k_tower16s, 128 filters): TWO workgroups per board tile, each with
+// the whole activation buffer in LDS but only HALF of the output channels to compute, exchanging halves after every
+// layer (PairXch).  A workgroup's sequential layer chain carries half of the MFMA work of k_tower16<.., NT = 3> (one
+// Connect-Four board: 277 us on one CU, the floor of that variant).  Four wavefronts, one per SIMD, each with all row
+// tiles of one 16-channel tile (TG = 1) -- the arrangement of the 64-filter k_tower16<.., NT = 3>, which keeps its MFMA
+// pipe 95 % busy; TG = 3 (twelve wavefronts with one row tile each) triples the weight stream per MFMA and measured
+// 74 % busy in the convolutions with a 17 k-cycle barrier wait per layer (183 us per launch).
+#ifndef AZ_T16S_TG
+#define AZ_T16S_TG 1
+#endif
+template <class Gm, int F> struct T16S : T16<Gm, F, NTS<Gm>> {
+  static constexpr int SPLIT = 2, TG = AZ_T16S_TG, TPW = NTS<Gm> / TG, CWL = F / 16 / SPLIT;
+  static constexpr int WAVES = TG * CWL, THREADS = 64 * WAVES;
+  static constexpr int XCH_WORDS = 2 * TPW * 4 * THREADS;        // publish area of one workgroup (64-bit words)
+  static_assert(NTS<Gm> % TG == 0 && (TG == 1 || TG == 3), "row tiles in one or three groups");
+};
+template <class Gm, int F, bool FROM_PLANES>
+__global__ void __launch_bounds__((T16S<Gm, F>::THREADS), 1)
+k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+           const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat,
+           unsigned long long* __restrict__ xch, unsigned long long epoch, int* __restrict__ err) {
+  using T = T16S<Gm, F>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* buf = lds;
+  float* planes = lds + T::BUF;
+  uint16_t* nbr = (uint16_t*)(planes + T::PLANES);
+  uint16_t* pos = nbr + 9 * T::RPAD;
+  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
+  const int pair = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int board0 = pair * T::TB;
+  if (board0 >= n) return;                           // both workgroups of the pair
+  tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[1], leaf_env, eval_slots, X, n, board0, threadIdx.x);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tg = wave / T::CWL, cwl = wave % T::CWL;
+  PairXch x;
+  x.mine = xch + (size_t)blockIdx.x * T::XCH_WORDS;
+  x.theirs = xch + (size_t)(blockIdx.x ^ 1) * T::XCH_WORDS;
+  x.tag0 = (uint32_t)(epoch << 8);                   // + layer index < 256 (pick_tower)
+  x.err = err;
+  x.pch = ((half ^ 1) * T::CWL + cwl) * 16 + (lane & 15);
+  const int cw = half * T::CWL + cwl;
+  if constexpr (T::TG == 1) tower16_wave<T, FROM_PLANES, T::TPW, 0, PairXch>(net, buf, planes, nbr, pos, cw, lane, n, board0, hfeat, x);
+  else {
+    if (tg == 0) tower16_wave<T, FROM_PLANES, T::TPW, 0, PairXch>(net, buf, planes, nbr, pos, cw, lane, n, board0, hfeat, x);
+    else if (tg == 1) tower16_wave<T, FROM_PLANES, T::TPW, T::TPW, PairXch>(net, buf, planes, nbr, pos, cw, lane, n, board0, hfeat, x);
+    else tower16_wave<T, FROM_PLANES, T::TPW, 2 * T::TPW, PairXch>(net, buf, planes, nbr, pos, cw, lane, n, board0, hfeat, x);
+  }
 }
 
 // One 3x3 F -> F convolution as a stand-alone layer (HBM -> HBM), for the optimiser step (train.h): forward

@@ -26,12 +26,15 @@ def random_go_batch(n, seed):
     return X, A
 
 
-@pytest.mark.parametrize("nblocks,F,n,tower", [(2, 64, 23, "16"), (2, 64, 5, "3"), (2, 64, 40, "21"), (1, 64, 9, "32"),
-                                               (2, 128, 17, "16"), (10, 128, 6, "")])
-def test_go9_planes_fp32_bit_exact(nblocks, F, n, tower, monkeypatch):
+@pytest.mark.parametrize("nblocks,F,n,tower,heads", [(2, 64, 23, "16", ""), (2, 64, 5, "3", ""), (2, 64, 40, "21", "32"), (1, 64, 9, "32", ""),
+                                                     (2, 128, 17, "16", "32"), (10, 128, 6, "", ""), (1, 128, 21, "", "16"), (2, 128, 9, "2", "")])
+def test_go9_planes_fp32_bit_exact(nblocks, F, n, tower, heads, monkeypatch):
+    """`heads`: "" = the engine's choice (k_heads16 at these sizes: 6 policy tiles of 16 logits), "32" = k_heads_mfma"""
     import azhip
     if tower:
         monkeypatch.setenv("AZHIP_TOWER", tower)
+    if heads:
+        monkeypatch.setenv("AZHIP_HEADS", heads)
     hp = ResNetHP(num_blocks=nblocks, num_filters=F, num_policy_head_filters=32, num_value_head_filters=32)
     blob = random_params(azhip.GAME_GO9_PLANES, hp, seed=19)
     assert blob.size == R.net_num_params(R.GO9, nblocks, F, 32, 32)
@@ -47,6 +50,7 @@ def test_go9_planes_fp32_bit_exact(nblocks, F, n, tower, monkeypatch):
         with pytest.raises(azhip.AzError):
             e.net_evaluate_keys(np.zeros((1, 2), dtype=np.uint64))
     assert "Go9Planes" in kernel and (not tower or ("NT=6" in kernel) == (tower == "3"))   # one 9x9 board needs 6 row tiles
+    assert tower != "2" or kernel.startswith("k_tower16s<")
     Pr, Vr, Pir = R.net_forward_normalized(R.GO9, (nblocks, F, 32, 32), blob, X, A)
     assert np.array_equal(P, Pr), np.abs(P - Pr).max()
     assert np.array_equal(V, Vr) and np.array_equal(Pinv, Pir)

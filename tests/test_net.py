@@ -98,12 +98,13 @@ def test_param_count_matches_reference_doc():
 @pytest.mark.parametrize("game,nblocks,n,F,heads", [(R.C4, 5, 64, 64, (32, 32)), (R.C4, 1, 7, 64, (32, 32)), (R.TTT, 2, 33, 64, (32, 32)),
                                                       (R.MANCALA, 2, 20, 64, (32, 32)), (R.C4, 2, 40, 128, (32, 32)),
                                                       (R.C4, 1, 9, 64, (2, 1)), (R.TTT, 1, 5, 128, (16, 8))])
-@pytest.mark.parametrize("tower", ["16", "32", "3", "21"])
+@pytest.mark.parametrize("tower", ["16", "32", "3", "21", "2"])
 def test_hip_forward_bit_exact_vs_oracle(game, nblocks, n, F, heads, tower, monkeypatch):
     """F = 128 is the shipped connect-four network (games/connect-four/params.jl:7-13); heads (2, 1) are the
     ResNetHP defaults (resnet.jl:30-37) and take the VALU dense-head kernel.  All tower kernels (k_tower16 on
-    16x16x4 MFMA with 11 or 3 row tiles per workgroup, k_tower on 32x32x2) are forced in turn: the engine
-    otherwise picks one per launch size."""
+    16x16x4 MFMA with 11 or 3 row tiles per workgroup, k_tower on 32x32x2, "2" = k_tower16s: two workgroups per board
+    tile exchanging channel halves after every layer, 128 filters only -- the engine's own choice elsewhere) are forced
+    in turn: the engine otherwise picks one per launch size."""
     import azhip
     monkeypatch.setenv("AZHIP_TOWER", tower)
     npf, nvf = heads
@@ -188,3 +189,48 @@ def test_set_params_twice_replaces_the_network():
             e.net_set_params(b1[:-1])                # wrong blob size
     assert np.array_equal(P1, R.net_forward_normalized(R.C4, (1, 64, 32, 32), b1, X, A)[0])
     assert np.array_equal(P2, R.net_forward_normalized(R.C4, (1, 64, 32, 32), b2, X, A)[0]) and not np.array_equal(P1, P2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads_kernel", ["16", "32"])
+@pytest.mark.parametrize("game,F,n", [(R.C4, 64, 37), (R.C4, 128, 50), (R.TTT, 64, 19), (R.MANCALA, 128, 33), (R.C4, 64, 1)])
+def test_dense_head_kernels_bit_exact_vs_oracle(game, F, n, heads_kernel, monkeypatch):
+    """The dense heads have two MFMA kernels: k_heads16 (16-board tiles on 16x16x4, small launches) and k_heads_mfma
+    (32-board tiles on 32x32x2, full launches); the engine picks by launch size.  Both are forced here (AZHIP_HEADS) on
+    batches with a partial last tile: same ascending-k fp32 chain, so both equal the oracle bit for bit."""
+    import azhip
+    monkeypatch.setenv("AZHIP_HEADS", heads_kernel)
+    hp = ResNetHP(num_blocks=1, num_filters=F, num_policy_head_filters=32, num_value_head_filters=32)
+    blob = random_params(game, hp, seed=77)
+    X, A = batch_of(game, random_positions(game, n, 8))
+    with azhip.Engine(game=game, oracle=azhip.ORACLE_RESNET, num_workers=8, batch_size=8, num_iters_per_turn=8,
+                      num_blocks=1, num_filters=F, num_policy_head_filters=32, num_value_head_filters=32) as e:
+        e.net_set_params(blob)
+        P, V, Pinv = e.net_forward(X, A)
+    Pr, Vr, Pir = R.net_forward_normalized(game, (1, F, 32, 32), blob, X, A)
+    assert np.array_equal(P, Pr), np.abs(P - Pr).max()
+    assert np.array_equal(V, Vr) and np.array_equal(Pinv, Pir)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,nblocks,n", [(R.C4, 5, 128), (R.C4, 2, 1), (R.C4, 3, 77), (R.TTT, 2, 33), (R.MANCALA, 2, 100)])
+def test_split_tower_bit_exact_vs_oracle(game, nblocks, n):
+    """k_tower16s (128 filters, launches of at most num_cu workgroups): pairs of workgroups exchange halves of every
+    layer's channels through HBM with agent-scope atomics.  Bit-exact like every other tower kernel; the kernel is the
+    engine's own pick at these sizes; repeated launches reuse the exchange areas (epochs)."""
+    import azhip
+    hp = ResNetHP(num_blocks=nblocks, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32)
+    blob = random_params(game, hp, seed=41)
+    envs = random_positions(game, n, 11)
+    X, A = batch_of(game, envs)
+    with azhip.Engine(game=game, oracle=azhip.ORACLE_RESNET, num_workers=8, batch_size=8, num_iters_per_turn=8,
+                      num_blocks=nblocks, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32) as e:
+        e.net_set_params(blob)
+        outs = [e.net_forward(X, A) for _ in range(3)]
+        assert e.net_last_kernel().startswith("k_tower16s<")
+        Pk, Vk = e.net_evaluate_keys(np.array([g.key() for g in envs], dtype=np.uint64))
+    Pr, Vr, Pir = R.net_forward_normalized(game, (nblocks, 128, 32, 32), blob, X, A)
+    for P, V, Pinv in outs:
+        assert np.array_equal(P, Pr), np.abs(P - Pr).max()
+        assert np.array_equal(V, Vr) and np.array_equal(Pinv, Pir)
+    assert np.array_equal(Pk, Pr) and np.array_equal(Vk, Vr)

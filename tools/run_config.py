@@ -18,6 +18,7 @@ ap.add_argument("--blocks", type=int, default=5)
 ap.add_argument("--games", type=int, default=-1)
 ap.add_argument("--groups", type=int, default=1)
 ap.add_argument("--filters", type=int, default=64)
+ap.add_argument("--prof", action="store_true", help="time every kernel class with events (serialises the streams a little)")
 a = ap.parse_args()
 gid = {"connect-four": 0, "tictactoe": 1, "mancala": 2}[a.game]
 hp = ResNetHP(a.blocks, a.filters, (3, 3), 32, 32)
@@ -27,6 +28,10 @@ e = azhip.Engine(game=gid, oracle=azhip.ORACLE_RESNET, num_workers=a.slots, batc
                  max_moves_per_game=256 if gid == 2 else 0)
 e.net_set_params(random_params(gid, hp))
 e.selfplay_begin(a.games, 0)
+if a.prof:
+    e.selfplay_step(a.sims)
+    e.prof_enable(True)
+    e.prof_reset()
 t0 = time.perf_counter()
 done = 0
 while done < a.waves and e.selfplay_active() > 0:
@@ -38,3 +43,8 @@ dt = time.perf_counter() - t0
 print("%s slots=%d sims/move=%d waves=%d: %.0f sims/s, %.2f ms/wave, depth %.2f, evals/sim %.3f, games done %d, moves %d"
       % (a.game, a.slots, a.sims, s.waves, s.simulations / dt, 1e3 * dt / max(s.waves, 1), s.nodes_traversed / max(s.simulations, 1),
          s.leaf_evals / max(s.simulations, 1), s.games, s.moves))
+if a.prof:
+    print("  tower kernel:", e.net_last_kernel())
+    for k, v in e.prof_get().items():
+        if v["launches"]:
+            print("  %-12s %6d launches  %8.1f us each" % (k, v["launches"], 1e3 * v["ms"] / v["launches"]))
