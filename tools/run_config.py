@@ -32,6 +32,8 @@ if a.prof:
     e.selfplay_step(a.sims)
     e.prof_enable(True)
     e.prof_reset()
+s0 = e.selfplay_stats()
+base = (s0.simulations, s0.waves, s0.nodes_traversed, s0.leaf_evals)      # --prof: the warm-up move is not part of the timed region
 t0 = time.perf_counter()
 done = 0
 while done < a.waves and e.selfplay_active() > 0:
@@ -41,8 +43,8 @@ while done < a.waves and e.selfplay_active() > 0:
 s = e.selfplay_stats()
 dt = time.perf_counter() - t0
 print("%s slots=%d sims/move=%d waves=%d: %.0f sims/s, %.2f ms/wave, depth %.2f, evals/sim %.3f, games done %d, moves %d"
-      % (a.game, a.slots, a.sims, s.waves, s.simulations / dt, 1e3 * dt / max(s.waves, 1), s.nodes_traversed / max(s.simulations, 1),
-         s.leaf_evals / max(s.simulations, 1), s.games, s.moves))
+      % (a.game, a.slots, a.sims, s.waves - base[1], (s.simulations - base[0]) / dt, 1e3 * dt / max(s.waves - base[1], 1),
+         (s.nodes_traversed - base[2]) / max(s.simulations - base[0], 1), (s.leaf_evals - base[3]) / max(s.simulations - base[0], 1), s.games, s.moves))
 if a.prof:
     print("  tower kernel:", e.net_last_kernel())
     for k, v in e.prof_get().items():
