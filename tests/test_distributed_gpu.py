@@ -87,3 +87,56 @@ def test_native_comm_single_rank_gather_and_broadcast():
         c.broadcast_params(e, root=0)
         assert np.array_equal(e.net_get_params(), nn.params())
         a.close(); b.close()
+
+
+def _native_worker(rank, world, port, out_dir):
+    sys.path[:0] = [os.path.join(ROOT, "alphazero.jl_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # carries the 128-byte unique id only
+    import azhip
+    from azhip import comm
+    from azhip.training import self_play_step_device
+    gspec = azhip.TicTacToeSpec()
+    hp = azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    nn = azhip.ResNet(gspec, hp, seed=4 if rank == 0 else 99)             # rank 1 starts with other weights: the broadcast must replace them
+    with comm.Comm(rank, rank, world, comm.torch_broadcast_id(rank)) as c:
+        mem = azhip.MemoryBuffer(gspec, 10000, device=rank)
+        kw = dict(game=1, oracle=azhip.ORACLE_RESNET, num_workers=4, batch_size=4, num_iters_per_turn=16, num_blocks=1, num_filters=64,
+                  num_policy_head_filters=32, num_value_head_filters=32, device=rank)
+        with azhip.Engine(**kw) as e:
+            if rank == 0:
+                e.net_set_params(nn.params())
+            c.broadcast_params(e, root=0)                                    # ncclBroadcast of the blob
+            got = e.net_get_params()
+        nn0 = azhip.ResNet(gspec, hp, params=got)
+        rep = self_play_step_device(gspec, nn0, _params(), mem, seed=6, comm=c)
+        np.save(os.path.join(out_dir, "N%d.npy" % rank), _samples(mem))
+        np.save(os.path.join(out_dir, "W%d.npy" % rank), got)
+        assert rep.memory_size == len(mem)
+        mem.close()
+    dist.destroy_process_group()
+
+
+def test_native_comm_two_ranks_on_two_gpus(tmp_path):
+    """az_comm_* with a world of TWO ranks, one GPU each (RCCL over xGMI): weights broadcast from rank 0, shards played
+    device-only, ncclAllGather of the records straight into both ranks' device memories -- identical to the unsharded
+    single-GPU run.  Needs two visible GPUs (RCCL refuses two ranks on one device): skipped on the 1-GPU test box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the 1-GPU box runs test_native_comm_single_rank_gather_and_broadcast and the gloo test)")
+    port = 29900 + os.getpid() % 2000
+    mp.spawn(_native_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    import azhip
+    from azhip.training import self_play_step_device
+    gspec = azhip.TicTacToeSpec()
+    nn = azhip.ResNet(gspec, azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32), seed=4)
+    mem = azhip.MemoryBuffer(gspec, 10000)
+    self_play_step_device(gspec, nn, _params(), mem, seed=6)
+    want = _samples(mem)
+    mem.close()
+    N0, N1 = np.load(tmp_path / "N0.npy"), np.load(tmp_path / "N1.npy")
+    assert np.array_equal(N0, N1) and np.array_equal(N0, want)
+    assert np.array_equal(np.load(tmp_path / "W0.npy"), nn.params()) and np.array_equal(np.load(tmp_path / "W1.npy"), nn.params())
