@@ -185,93 +185,15 @@ template <class Gm, int F = 64> struct T16P {
   static constexpr int FILT = F;
 };
 
-// tap-validity bits of this lane's row in tile `tile`: 9 bits per tile, 3 tiles per word
-__device__ __forceinline__ uint32_t vmask(const uint32_t (&vm)[4], int tile) { return vm[tile / 3] >> (9 * (tile % 3)); }
 template <int F> __device__ __forceinline__ int posF(int c) { return ((c >= F / 2 ? 1 : 0) + 2 * (c & 1)) * (F / 4) + ((c % (F / 2)) >> 1); }
 
-// One 64 -> 64 convolution (NTAP = 9: 3x3, NTAP = 1: 1x1) into the 11 accumulators of this wave.
-// The work is a fully unrolled sequence of steps (tap, tile pair); the A rows of step k+1 are read from LDS and
-// (at the first pair of a tap) the B fragments of the next tap requested from L2 while the MFMAs of step k issue.
-// Tiles go in pairs so that consecutive MFMAs never hit the same accumulator (v_mfma_f32_16x16x4_f32: 32-cycle
-// issue, 40-cycle dependent latency); the 11th tile rides alone.  sched_barrier(0) after every step keeps hipcc
-// from hoisting further loads, which bounds the live A registers to two pairs (the kernel must stay near 200
-// VGPRs so that the tree kernels of the other slot group can co-reside on the SIMD).
+// One F -> F convolution (conv16p below) is a fully unrolled sequence of steps (tap, 64-channel half, tile pair); the A
+// rows of step k+1 are read from LDS and (at the first step of a tap) the B fragments of the next tap requested from L2
+// while the MFMAs of step k issue.  Tiles go in pairs so that consecutive MFMAs never hit the same accumulator
+// (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency); an odd tile rides alone.  sched_barrier(0)
+// after every step keeps hipcc from hoisting further loads, which bounds the live A registers to two pairs (the kernel
+// must stay near 200 VGPRs so that the tree kernels of the other slot group can co-reside on the SIMD).
 static constexpr int T16_GMAX = 2;
-template <int NT> __device__ __forceinline__ constexpr int t16_gsize(int pair) { return 2 * pair + 1 < NT ? 2 : 1; }
-template <class T, int NT>
-__device__ __forceinline__ void load_pair16(const float* __restrict__ buf, const uint32_t (&vm)[4], int tap, int pair, int kh,
-                                            int lrow, int g, float4 (&a)[T16_GMAX][4]) {
-  using Gm = typename T::Game;
-  constexpr int F = T::FILT;
-  const int delta = (tap / 3 - 1) * Gm::W + (tap % 3 - 1);
-#pragma unroll
-  for (int u = 0; u < T16_GMAX; ++u) {
-    const int tile = pair * 2 + u;
-    if (u < t16_gsize<NT>(pair)) {
-      const bool ok = (vmask(vm, tile) >> tap) & 1;
-      const int row = ok ? tile * 16 + lrow + delta : T::RPAD;
-      const float* p = buf + row * T::STRIDE + g * (F / 4) + kh * 16;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) a[u][q] = *(const float4*)(p + q * 4);
-    }
-  }
-}
-template <int PAIR, int KHI, int SQ, int NT>
-__device__ __forceinline__ void mfma_pair16(const float4 (&a)[T16_GMAX][4], const float4 (&bfull)[SQ], f32x4v (&acc)[NT]) {
-  constexpr int t0 = PAIR * 2, ng = t16_gsize<NT>(PAIR);
-  const float4* b = bfull + KHI * 4;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].x, b[q].x, acc[t0 + u], 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].y, b[q].y, acc[t0 + u], 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].z, b[q].z, acc[t0 + u], 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < ng; ++u) acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q].w, b[q].w, acc[t0 + u], 0, 0, 0);
-  }
-}
-template <class T, int NT, int NTAP, int K>
-__device__ __forceinline__ void conv16_steps(const float* __restrict__ buf, const float4* __restrict__ wl, f32x4v (&acc)[NT],
-                                             const uint32_t (&vm)[4], int lrow, int g, float4 (&b0)[T::FILT / 16], float4 (&b1)[T::FILT / 16],
-                                             float4 (&aA)[T16_GMAX][4], float4 (&aB)[T16_GMAX][4]) {
-  constexpr int F = T::FILT;
-  constexpr int STEPS = (NT + 1) / 2;               // tile pairs per (tap, 64-channel half); the last pair is a single tile when NT is odd
-  constexpr int SPT = STEPS * T::KH;                // pipeline steps per tap: (64-channel half, tile pair)
-  if constexpr (K < NTAP * SPT) {
-    constexpr int t = K / SPT, kh = (K % SPT) / STEPS, p = K % STEPS;
-    float4 (&cur)[T16_GMAX][4] = (K & 1) ? aB : aA;
-    float4 (&nxt)[T16_GMAX][4] = (K & 1) ? aA : aB;
-    float4 (&bc)[F / 16] = (t & 1) ? b1 : b0;
-    float4 (&bn)[F / 16] = (t & 1) ? b0 : b1;
-    if constexpr (K % SPT == 0 && t + 1 < NTAP) {
-#pragma unroll
-      for (int q = 0; q < T::SQ; ++q) bn[q] = wl[(size_t)((t + 1) * T::CT * T::SQ + q) * 64];
-    }
-    if constexpr (K + 1 < NTAP * SPT) {
-      constexpr int t1 = (K + 1) / SPT, kh1 = ((K + 1) % SPT) / STEPS, p1 = (K + 1) % STEPS;
-      load_pair16<T, NT>(buf, vm, NTAP == 1 ? 4 : t1, p1, kh1, lrow, g, nxt);
-    }
-    mfma_pair16<p, kh, F / 16, NT>(cur, bc, acc);
-#ifndef AZ_T16_FENCE
-#define AZ_T16_FENCE 1     // fence the scheduler every N steps
-#endif
-    if constexpr (K % AZ_T16_FENCE == AZ_T16_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
-    conv16_steps<T, NT, NTAP, K + 1>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
-  }
-}
-template <class T, int NT, int NTAP>
-__device__ __forceinline__ void conv16(const float* __restrict__ buf, const float4* __restrict__ wl,
-                                       f32x4v (&acc)[NT], const uint32_t (&vm)[4], int lrow, int g) {
-  constexpr int F = T::FILT;
-  float4 b0[F / 16], b1[F / 16], aA[T16_GMAX][4], aB[T16_GMAX][4];
-#pragma unroll
-  for (int q = 0; q < F / 16; ++q) b0[q] = wl[(size_t)q * 64];
-  load_pair16<T, NT>(buf, vm, NTAP == 1 ? 4 : 0, 0, 0, lrow, g, aA);
-  __builtin_amdgcn_sched_barrier(0);
-  conv16_steps<T, NT, NTAP, 0>(buf, wl, acc, vm, lrow, g, b0, b1, aA, aB);
-}
 
 // Compile-time list of the pipeline steps of one convolution for a wavefront that owns tiles TILE0 .. TILE0 + NT - 1:
 // (tap, 64-channel half, tile pair).  Tiles go in pairs so that consecutive MFMAs never hit the same accumulator.
@@ -731,18 +653,23 @@ k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restric
   }
 }
 
-// One 3x3 F -> F convolution as a stand-alone layer (HBM -> HBM), for the optimiser step (train.h): forward
+// One 3x3 F -> F convolution as a stand-alone layer (HBM -> HBM), for the optimiser step (train.hip): forward
 // g = conv(a) and data gradient da = conv_rot(dg) are the same kernel with different weight fragments.  A workgroup
-// takes 4 Connect-Four boards (T16<Game, F, 11>): rows [R][F] in natural channel order go into the LDS buffer in
-// the permuted order conv16 expects, the 11 accumulator tiles of each wavefront come back out in natural order.
-// No bias, no activation: batch norm follows with batch statistics (the bias cancels there).
+// takes 4 Connect-Four boards (T16<Game, F, 11>): rows [R][F] in natural channel order go into the LDS buffer in the
+// channel order conv16p expects and in Geo16's row order (`geo`: the engine's table of the 11-tile geometry), so the
+// (tile, tap) products that fall off the board are skipped as in the tower (85 of 99); the 11 accumulator tiles of each
+// wavefront come back out in natural order.  No bias, no activation: batch norm follows with batch statistics (the
+// bias cancels there).
 template <class Gm, int F>
 __global__ void __launch_bounds__(T16Threads<F>::V, 2)
-k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, float* __restrict__ out, int nboards) {
+k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, float* __restrict__ out, int nboards, const uint16_t* __restrict__ geo) {
   using T = T16<Gm, F, 11>;
-  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, STRIDE = T::STRIDE, NT = 11;
+  using G = typename T::Geo;
+  constexpr int P = Gm::P, STRIDE = T::STRIDE, NT = 11;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
+  uint16_t* nbr = (uint16_t*)(lds + T::BUF + T::PLANES);
+  uint16_t* pos = nbr + 9 * T::RPAD;
   const int board0 = blockIdx.x * T::TB;
   if (board0 >= nboards) return;
   const int nb = (nboards - board0) < T::TB ? (nboards - board0) : T::TB;
@@ -751,38 +678,27 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
   const float4* in4 = (const float4*)(in + (size_t)board0 * P * F);
   for (int idx = tid; idx < (T::RPAD + 1) * (F / 4); idx += T::THREADS) {
     const int row = idx / (F / 4), c4 = idx % (F / 4);
-    const float4 v = row < nvalid ? in4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ps = row < T::RPAD ? (int)geo[row] : 0xffff;          // board * P + position of this buffer row
+    const float4 v = ps < nvalid ? in4[(size_t)ps * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     float* dst = buf + row * STRIDE;
     dst[posF<F>(c4 * 4 + 0)] = v.x; dst[posF<F>(c4 * 4 + 1)] = v.y; dst[posF<F>(c4 * 4 + 2)] = v.z; dst[posF<F>(c4 * 4 + 3)] = v.w;
   }
+  for (int i = tid; i < T::RPAD; i += T::THREADS) pos[i] = geo[i];
+  for (int i = tid; i < 9 * T::RPAD; i += T::THREADS) nbr[i] = geo[T::RPAD + i];
   const int lrow = lane & 15, g = lane >> 4;
-  uint32_t vm[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int tile = 0; tile < NT; ++tile) {
-    const int row = tile * 16 + lrow;
-    const int q = row % P, x = q % W, y = q / W;
-    uint32_t m = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int dy = t / 3 - 1, dx = t % 3 - 1;
-      const bool ok = (row < T::ROWS) && (y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W);
-      m |= (uint32_t)ok << t;
-    }
-    vm[tile / 3] |= m << (9 * (tile % 3));
-  }
   __syncthreads();
   f32x4v acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  conv16<T, NT, 9>(buf, wfrag + (size_t)wave * T::SQ * 64 + lane, acc, vm, lrow, g);
+  conv16p<T, G, NT, 0, 9>(buf, nbr, wfrag + (size_t)wave * T::SQ * 64 + lane, acc, lrow, g);
   const int ch = wave * 16 + lrow;
   float* o = out + (size_t)board0 * P * F;
 #pragma unroll
   for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = tile * 16 + g * 4 + i;
-      if (row < nvalid) o[(size_t)row * F + ch] = acc[tile][i];
+      const int ps = pos[tile * 16 + g * 4 + i];
+      if (ps < nvalid) o[(size_t)ps * F + ch] = acc[tile][i];
     }
 }
 

@@ -468,7 +468,7 @@ template <class Gm, int F> static int tr_conv16_f(az_trainer* t, const float* in
   using T = T16<Gm, F, 11>;
   static bool attr_done = false;
   if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_layer<Gm, F>), hipFuncAttributeMaxDynamicSharedMemorySize, T::BYTES)); attr_done = true; }
-  hipLaunchKernelGGL((k_conv16_layer<Gm, F>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B);
+  hipLaunchKernelGGL((k_conv16_layer<Gm, F>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[0]);
   return AZ_OK;
 }
 // 3x3 F -> F convolution of [R][F] activations on the MFMA layer kernel
