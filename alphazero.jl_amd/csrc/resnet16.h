@@ -2,7 +2,7 @@
 //
 // Why a second tower kernel.  k_tower (resnet.h) quantises the batch in workgroups of 3 boards x 2 per CU:
 // 4096 boards are 2.67 "rounds" that cost 3 (-11 %).  Here a workgroup owns TB = 4 Connect-Four boards =
-// 168 rows = 10.5 -> 11 row tiles of 16, and keeps ONE activation buffer in LDS (48 KB, so two workgroups
+// 168 rows = 10.5 -> 11 row tiles of 16, and keeps ONE activation buffer in LDS (51 KB, so two workgroups
 // still share a CU): 4096 boards = 1024 workgroups = exactly two full rounds of 512.  Wave w owns the 16 output
 // channels w*16..w*16+15 of every row tile: 11 accumulators of 4 VGPRs, 176 MFMAs per tap against 4 weight
 // loads (k_tower: 64 MFMAs against 8 loads), so the VMEM issue cost of the weight stream disappears.
@@ -152,11 +152,11 @@ template <class Gm, int F = 64, int NT = 11> struct T16 {
   static constexpr int NTILE = NT, RPAD = NTILE * 16;
   static constexpr int TB = RPAD / Gm::P;            // NT = 11: 4 Connect-Four boards, 19 Tic-tac-toe, 12 Mancala; NT = 3: 1, 5, 3
   static constexpr int ROWS = TB * Gm::P;
-  static constexpr int STRIDE = F + 4;
+  static constexpr int STRIDE = F + 8;               // rows of 4 d dwords with d = 18 / 34: see posF
   static constexpr int BUF = (RPAD + 1) * STRIDE;    // row RPAD = zeros
   static constexpr int PLANES = (RPAD + 1) * Gm::C;
   static constexpr int TABLE = (10 * RPAD + 1) / 2;  // floats holding nbr [9][RPAD] + pos [RPAD] as u16 (Geo16)
-  static constexpr int BYTES = (BUF + PLANES + TABLE) * 4;   // 54 KB at F = 64 (2 workgroups per CU), 99 KB at F = 128 (1)
+  static constexpr int BYTES = (BUF + PLANES + TABLE) * 4;   // 57 KB at F = 64 (2 workgroups per CU), 102 KB at F = 128 (1)
   static constexpr int WAVES = F / 16, THREADS = 64 * WAVES;
   static constexpr int CT = F / 16;                  // channel tiles of 16 = wavefronts per row-tile set
   static constexpr int KH = F / 64;                  // 64-channel halves of a tap (one pipeline step each)
@@ -173,7 +173,7 @@ template <class Gm, int F = 64> struct T16P {
   static constexpr int NT0 = 11, NT1 = 10, NTW = NT0 + NT1, RPAD = NTW * 16;
   static constexpr int TB = RPAD / Gm::P;
   static constexpr int ROWS = TB * Gm::P;
-  static constexpr int STRIDE = F + 4;
+  static constexpr int STRIDE = F + 8;
   static constexpr int BUF = (RPAD + 1) * STRIDE;
   static constexpr int PLANES = (RPAD + 1) * Gm::C;
   static constexpr int TABLE = (10 * RPAD + 1) / 2;
@@ -185,7 +185,17 @@ template <class Gm, int F = 64> struct T16P {
   static constexpr int FILT = F;
 };
 
-template <int F> __device__ __forceinline__ int posF(int c) { return ((c >= F / 2 ? 1 : 0) + 2 * (c & 1)) * (F / 4) + ((c % (F / 2)) >> 1); }
+// Position of channel c inside a buffer row.  MFMA step (kh, q, j) of a tap feeds k group G = lane >> 4 the channel with
+// G(c) = (c >= F/2) + 2 (c & 1) and w(c) = (c mod F/2) >> 1 = 16 kh + 4 q + j (the contract's order j, F/2 + j); the lane
+// reads its four values of step (kh, q) as ONE float4 at position 64 kh + 16 q + 4 G.  The four k groups of a read are
+// thus 16 bytes apart and the rows 4 (F + 8) bytes: a ds_read_b128 pass covers the lanes (lrow 0..7, G and G + 1), and
+// with rows of 4 d dwords it reaches all 64 banks iff { d lrow + G } is distinct mod 16 -- d = 18 (F = 64) or 34 (F = 128).
+// (The first layout -- k groups F bytes apart, rows of F + 4 floats -- read at half the LDS rate, 8 cycles per wave
+// instruction instead of 4: tools/probes/lds_conflict.hip.)
+template <int F> __device__ __forceinline__ int posF(int c) {
+  const int G = (c >= F / 2 ? 1 : 0) + 2 * (c & 1), w = (c % (F / 2)) >> 1;
+  return (w >> 4) * 64 + ((w >> 2) & 3) * 16 + G * 4 + (w & 3);
+}
 
 // One F -> F convolution (conv16p below) is a fully unrolled sequence of steps (tap, 64-channel half, tile pair); the A
 // rows of step k+1 are read from LDS and (at the first step of a tap) the B fragments of the next tap requested from L2
@@ -240,14 +250,13 @@ template <class G, int NT, int TILE0, int KH, int NTAP> struct Steps16 {
 // tap-shifted rows in the buffer (from the nbr table)
 template <class T>
 __device__ __forceinline__ void load_rows16p(const float* __restrict__ buf, int off0, int off1, bool two, int kh, int g, float4 (&a)[T16_GMAX][4]) {
-  constexpr int F = T::FILT;
-  const float* p0 = buf + off0 + g * (F / 4) + kh * 16;
+  const float* p0 = buf + off0 + kh * 64 + g * 4;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) a[0][q] = *(const float4*)(p0 + q * 4);
+  for (int q = 0; q < 4; ++q) a[0][q] = *(const float4*)(p0 + q * 16);
   if (two) {
-    const float* p1 = buf + off1 + g * (F / 4) + kh * 16;
+    const float* p1 = buf + off1 + kh * 64 + g * 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a[1][q] = *(const float4*)(p1 + q * 4);
+    for (int q = 0; q < 4; ++q) a[1][q] = *(const float4*)(p1 + q * 16);
   }
 }
 template <int T0, int T1, int KHI, int SQ, int NT>

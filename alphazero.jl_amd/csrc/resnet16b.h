@@ -6,7 +6,7 @@
 // column tiles): with 16x the MFMA rate of fp32 the LDS reads of the activations are what binds, and every fragment read
 // now feeds two MFMAs (the first version, 16 channels x all tiles per wave, re-read each row 8 times per tap at F = 128).
 // What differs:
-//   * activations live in LDS as bf16 ([RPAD + 1][F + 8], 272-byte rows at F = 128: twice the boards-per-byte of fp32, so
+//   * activations live in LDS as bf16 ([RPAD + 1][SH], 288-byte rows at F = 128: twice the boards-per-byte of fp32, so
 //     the 128-filter tower keeps two workgroups per CU), weights are bf16 fragments, accumulation is fp32 in the MFMA;
 //     the folded batch norm, the residual add and the ReLU run in fp32 on the accumulators and the result is rounded to
 //     bf16 (round to nearest even, v_cvt_pk_bf16_f32) when it is written back -- the skip connection adds the ROUNDED
@@ -40,7 +40,11 @@ struct Net16bDev {
 template <class Gm, int F = 128, int NT = 11> struct T16B {
   static constexpr int NTILE = NT, RPAD = NTILE * 16;
   static constexpr int TB = RPAD / Gm::P, ROWS = TB * Gm::P;
-  static constexpr int SH = F + 8;                       // bf16 elements per buffer row (16 bytes of padding: the 4 k groups of a read hit different banks)
+  // bf16 elements per buffer row.  A ds_read_b128 of the A operand (lane = (row lrow, k group g), 16 bytes at
+  // row * SH + 8 g) runs at the full 256 B/clk only if the lanes (lrow 0..7, g and g + 1) of a pass cover all 64 banks:
+  // with rows of 4 d dwords that needs { d lrow + g } distinct mod 16 -- d = 9 (F = 64: 144-byte rows) or 18 (F = 128:
+  // 288-byte rows); 272-byte rows (d = 17) halve the rate (tools/probes/lds_conflict.hip)
+  static constexpr int SH = F == 128 ? F + 16 : F + 8;
   static constexpr int BUFH = (RPAD + 1) * SH;           // row RPAD = zeros
   static constexpr int PLANES = (RPAD + 1) * Gm::C;      // fp32 input planes for the stem
   static constexpr int TABLE = (10 * RPAD + 1) / 2;

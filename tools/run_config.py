@@ -18,6 +18,7 @@ ap.add_argument("--blocks", type=int, default=5)
 ap.add_argument("--games", type=int, default=-1)
 ap.add_argument("--groups", type=int, default=1)
 ap.add_argument("--filters", type=int, default=64)
+ap.add_argument("--bf16", action="store_true", help="bf16 tower (az_engine_cfg.net_bf16)")
 ap.add_argument("--prof", action="store_true", help="time every kernel class with events (serialises the streams a little)")
 a = ap.parse_args()
 gid = {"connect-four": 0, "tictactoe": 1, "mancala": 2}[a.game]
@@ -25,7 +26,7 @@ hp = ResNetHP(a.blocks, a.filters, (3, 3), 32, 32)
 e = azhip.Engine(game=gid, oracle=azhip.ORACLE_RESNET, num_workers=a.slots, batch_size=a.slots // a.groups, num_iters_per_turn=a.sims, cpuct=2.0,
                  dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1,
                  num_blocks=a.blocks, num_filters=a.filters, num_policy_head_filters=32, num_value_head_filters=32,
-                 max_moves_per_game=256 if gid == 2 else 0)
+                 max_moves_per_game=256 if gid == 2 else 0, net_bf16=1 if a.bf16 else 0)
 e.net_set_params(random_params(gid, hp))
 e.selfplay_begin(a.games, 0)
 if a.prof:
