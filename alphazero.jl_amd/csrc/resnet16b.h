@@ -6,8 +6,9 @@
 // column tiles): with 16x the MFMA rate of fp32 the LDS reads of the activations are what binds, and every fragment read
 // now feeds two MFMAs (the first version, 16 channels x all tiles per wave, re-read each row 8 times per tap at F = 128).
 // What differs:
-//   * activations live in LDS as bf16 ([RPAD + 1][SH], 288-byte rows at F = 128: twice the boards-per-byte of fp32, so
-//     the 128-filter tower keeps two workgroups per CU), weights are bf16 fragments, accumulation is fp32 in the MFMA;
+//   * activations live in LDS as bf16 ([RPAD + 1][SH], 288-byte rows at F = 128), weights are bf16 fragments, accumulation
+//     is fp32 in the MFMA (at F = 128 the kernel needs 192 VGPRs, so ONE 8-wave workgroup runs per CU and nothing covers its
+//     barriers and epilogue: 5.7 k of a layer's 18 k cycles; forcing 128 VGPRs spills 468 registers);
 //     the folded batch norm, the residual add and the ReLU run in fp32 on the accumulators and the result is rounded to
 //     bf16 (round to nearest even, v_cvt_pk_bf16_f32) when it is written back -- the skip connection adds the ROUNDED
 //     block input, i.e. exactly what the next convolution reads;
@@ -35,6 +36,7 @@ struct Net16bDev {
   const bf16x8v* head_w;    // [F/16][F/32][64] x 8 bf16
   const float* head_ss;     // [2][F]
   const uint16_t* geo[3];   // Geo16 tables (11-tile, 3-tile geometry; [2] unused)
+  unsigned long long* dbg;  // optional [workgroups][8] cycle stamps, as Net16Dev::dbg (az_debug_tower_timeline)
 };
 
 template <class Gm, int F = 128, int NT = 11> struct T16B {
@@ -58,6 +60,26 @@ template <class Gm, int F = 128, int NT = 11> struct T16B {
 
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+// Epilogue store of one accumulator tile column: this lane's four outputs v[i] (rows row0 + i, channel ch) are rounded
+// to bf16 (packed[0] = rows 0, 1; packed[1] = rows 2, 3 -- what the skip connection adds later) and written to the buffer.
+// The lanes of channels c and c + 1 (lrow even / odd) swap halves through DPP so that each writes TWO 32-bit words
+// (channels c, c + 1 of one row) instead of four 16-bit ones: half the LDS instructions and no two lanes on one dword
+// (the 16-bit version of this epilogue took 6.4 k of a layer's 19.9 k cycles at 10x128, tools/tower_timeline.py --bf16).
+template <class T>
+__device__ __forceinline__ void store_bf16x4(uint16_t* __restrict__ buf, int row0, int ch, int lrow, const float (&v)[4], uint32_t (&packed)[2]) {
+  packed[0] = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+  packed[1] = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+  const bool odd = lrow & 1;
+  const uint32_t send = odd ? packed[0] : packed[1];
+  const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, false);     // quad_perm [1, 0, 3, 2]: lane ^ 1
+  uint32_t w0, w1;
+  if (!odd) { w0 = (packed[0] & 0xffffu) | (recv << 16); w1 = (packed[0] >> 16) | (recv & 0xffff0000u); }
+  else { w0 = (recv & 0xffffu) | (packed[1] << 16); w1 = (recv >> 16) | (packed[1] & 0xffff0000u); }
+  uint16_t* dst = buf + (row0 + (odd ? 2 : 0)) * T::SH + (ch & ~1);
+  *(uint32_t*)dst = w0;
+  *(uint32_t*)(dst + T::SH) = w1;
+}
 
 // activation rows of one step: KS fragments of 8 channels per tile
 template <class T>
@@ -141,10 +163,14 @@ __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __
                                               int n, int board0, float* __restrict__ hfeat) {
   using Gm = typename T::Game;
   using G = typename T::Geo;
-  constexpr int F = T::FILT, P = Gm::P, C = Gm::C, TB = T::TB, SH = T::SH, R0 = TILE0 * 16;
+  constexpr int F = T::FILT, P = Gm::P, C = Gm::C, TB = T::TB, R0 = TILE0 * 16;
   const int lrow = lane & 15, g = lane >> 4;
   const int ch0 = cg * 32 + lrow;                                   // this lane's output channels: ch0 and ch0 + 16; rows tile*16 + 4 g + i
+  unsigned long long* dbg = (net.dbg && threadIdx.x == 0) ? net.dbg + (size_t)blockIdx.x * 8 : nullptr;
+#define AZ_STAMP16B(i) do { if (dbg) dbg[i] = __builtin_readcyclecounter(); } while (0)
+  AZ_STAMP16B(0);
   f32x4v acc[NT][2];
+  uint32_t xres[NT][2][2];                                          // the current block's input as the convolutions read it (bf16 pairs: rows 0, 1 | 2, 3): this lane wrote it
   // ---- stem on the fp32 MFMA (K = 9 C), output rounded to bf16 -------------------------------------------------------------
   {
     constexpr int KK = 9 * C, K2 = (KK + 1) / 2, NS = (2 * K2 + 3) / 4;
@@ -169,18 +195,18 @@ __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __
     for (int ct = 0; ct < 2; ++ct) {
       const float sc = net.stem_ss[ch0 + 16 * ct], sh = net.stem_ss[F + ch0 + 16 * ct];
 #pragma unroll
-      for (int tile = 0; tile < NT; ++tile)
+      for (int tile = 0; tile < NT; ++tile) {
+        float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = az_fmaf(acc[tile][ct][i], sc, sh);
-          buf[(R0 + tile * 16 + g * 4 + i) * SH + ch0 + 16 * ct] = f32_to_bf16_bits(v > 0.0f ? v : 0.0f);
-        }
+        for (int i = 0; i < 4; ++i) { const float y = az_fmaf(acc[tile][ct][i], sc, sh); v[i] = y > 0.0f ? y : 0.0f; }
+        store_bf16x4<T>(buf, R0 + tile * 16 + g * 4, ch0 + 16 * ct, lrow, v, xres[tile][ct]);
+      }
     }
   }
   __syncthreads();
+  AZ_STAMP16B(1);
 
   // ---- residual tower -------------------------------------------------------------------------------------------------------
-  uint32_t xres[NT][2][2];                                          // block input as the convolution saw it: bf16 pairs
   const size_t LAYER_W = (size_t)9 * T::CT * T::KS * 64;            // fragments (16 B) per layer
   for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
 #pragma unroll
@@ -188,28 +214,33 @@ __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __
     int lrow_l = lrow;
     asm volatile("" : "+v"(lrow_l));                                // keeps the table look-ups inside the layer loop (registers)
     conv16b<T, G, NT, TILE0, 9>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow_l, g);
+    if (layer == 2) AZ_STAMP16B(4);
     __syncthreads();                                                // every wave has finished reading the buffer
+    if (layer == 2) AZ_STAMP16B(5);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const float sc = net.conv_ss[(size_t)layer * 2 * F + ch0 + 16 * ct], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch0 + 16 * ct];
 #pragma unroll
-      for (int tile = 0; tile < NT; ++tile)
+      for (int tile = 0; tile < NT; ++tile) {
+        float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int a = (R0 + tile * 16 + g * 4 + i) * SH + ch0 + 16 * ct;
-          float v = az_fmaf(acc[tile][ct][i], sc, sh);
-          if (!(layer & 1)) {
-            const uint32_t old = buf[a];
-            if (i & 1) xres[tile][ct][i >> 1] |= old << 16; else xres[tile][ct][i >> 1] = old;
-          } else {
+          float y = az_fmaf(acc[tile][ct][i], sc, sh);
+          if (layer & 1) {                                          // second convolution of a block: + the block input (rounded, as read)
             const uint32_t pr = xres[tile][ct][i >> 1];
-            v = v + bf16_bits_to_f32((uint16_t)((i & 1) ? (pr >> 16) : (pr & 0xffffu)));
+            y = y + bf16_bits_to_f32((uint16_t)((i & 1) ? (pr >> 16) : (pr & 0xffffu)));
           }
-          buf[a] = f32_to_bf16_bits(v > 0.0f ? v : 0.0f);
+          v[i] = y > 0.0f ? y : 0.0f;
         }
+        uint32_t pk[2];
+        store_bf16x4<T>(buf, R0 + tile * 16 + g * 4, ch0 + 16 * ct, lrow, v, pk);
+        if (layer & 1) { xres[tile][ct][0] = pk[0]; xres[tile][ct][1] = pk[1]; }      // the next block's input
+      }
     }
     __syncthreads();
+    if (layer == 1 || layer == 2) AZ_STAMP16B(5 + layer);
   }
+  AZ_STAMP16B(2);
   // ---- both 1x1 head convolutions + BN + ReLU, features out in fp32 -------------------------------------------------------------
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
@@ -229,6 +260,8 @@ __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __
         }
     }
   }
+  AZ_STAMP16B(3);
+#undef AZ_STAMP16B
 }
 
 template <class Gm, int F, bool FROM_PLANES, int NT = 11>

@@ -19,11 +19,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--filters", type=int, default=64)
 ap.add_argument("--nt", type=int, default=11)
 ap.add_argument("--n", default="4096,2048,1024")
+ap.add_argument("--blocks", type=int, default=5)
+ap.add_argument("--bf16", action="store_true")
 a = ap.parse_args()
 ns = [int(x) for x in a.n.split(",")]
-hp = ResNetHP(5, a.filters, (3, 3), 32, 32)
-e = azhip.Engine(game=0, oracle=2, num_workers=max(ns), batch_size=max(ns), num_iters_per_turn=8, num_blocks=5,
-                 num_filters=a.filters, num_policy_head_filters=32, num_value_head_filters=32)
+hp = ResNetHP(a.blocks, a.filters, (3, 3), 32, 32)
+e = azhip.Engine(game=0, oracle=2, num_workers=max(ns), batch_size=max(ns), num_iters_per_turn=8, num_blocks=a.blocks,
+                 num_filters=a.filters, num_policy_head_filters=32, num_value_head_filters=32, net_bf16=1 if a.bf16 else 0)
 e.net_set_params(random_params(0, hp))
 f = lib().az_debug_tower_timeline
 f.restype = C.c_int
