@@ -69,6 +69,33 @@ template <int F> static int tower_timeline_bf16(az_engine* e, int32_t n, unsigne
   (void)hipFree(d);
   return AZ_OK;
 }
+// debug aid: cycle stamps of one split k_heads16 launch on n boards (after a tower launch that fills the head features):
+// workgroup 2 t = value tiles of board tile t, 2 t + 1 = its policy tiles; per wavefront 4 words: start, chain done,
+// workgroup barrier passed, end
+template <int F> static int heads_timeline(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
+  using H = H16<ConnectFour, F, true>;
+  const int nb = 2 * ((n + 15) / 16);
+  if (cap < (int64_t)nb * H::WAVES * 4) return fail(AZ_ERR_CAPACITY, "need %d words", nb * H::WAVES * 4);
+  unsigned long long* d = nullptr;
+  AZCHK(dalloc(e, &d, (size_t)nb * H::WAVES * 4));
+  std::vector<GEnv> envs(n, ConnectFour::init());
+  HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_ntmp, &n, sizeof(int), hipMemcpyHostToDevice, e->stream));
+  AZCHK(net_launch(e, e->stream, false, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, n, nullptr, nullptr, e->d_P, e->d_V, nullptr, ConnectFour::A));
+  NetDev nd = e->net;
+  nd.dbg = d;
+  hipLaunchKernelGGL((k_heads16<ConnectFour, F, true>), dim3(nb), dim3(H::THREADS), H::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat, e->d_P, e->d_V, (float*)nullptr, ConnectFour::A);
+  HIPCHK(hipMemcpyAsync(out, d, sizeof(unsigned long long) * nb * H::WAVES * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->allocs.pop_back();
+  (void)hipFree(d);
+  return AZ_OK;
+}
+extern "C" int az_debug_heads_timeline(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
+  ENGINE(e);
+  if (!e->net_loaded || n < 1 || n > e->nn_cap || e->cfg.game != AZ_GAME_CONNECT_FOUR || !e->net.hd16_ok) return fail(AZ_ERR_BAD_ARG, "connect-four with 32 head filters");
+  return e->cfg.num_filters == 128 ? heads_timeline<128>(e, n, out, cap) : heads_timeline<64>(e, n, out, cap);
+}
 extern "C" int az_debug_tower_timeline(az_engine* e, int32_t n, int32_t nt, unsigned long long* out, int64_t cap) {
   ENGINE(e);
   if (!e->net_loaded || n < 1 || n > e->nn_cap) return fail(AZ_ERR_BAD_ARG, "bad n / no net");

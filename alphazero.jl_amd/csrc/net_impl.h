@@ -20,6 +20,8 @@ template <class Gm, int F, bool PLANES_ONLY = false> static int set_kernel_attrs
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16s<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16S<Gm, F>::BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16s<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16S<Gm, F>::BYTES));
   }
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_heads16<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H16<Gm, F, true>::BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_heads16<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, H16<Gm, F, false>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TowerLds<F>::BYTES));
   return AZ_OK;
@@ -131,8 +133,11 @@ template <class Gm, int F>
 static int launch_heads(az_engine* e, hipStream_t st, const float* hfeat, const GEnv* envs, const int* eslots, const int* n_ptr, int n_max,
                         const float* Amask, float* Pout, float* Vout, float* Pinv, int pstride) {
   const bool small = e->heads_pick == 16 || (e->heads_pick != 32 && (n_max <= HEADS16_MAX_BOARDS || e->ngroups == 1));
-  if (e->net.hd16_ok && small)
-    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads16<Gm, F>), (n_max + 15) / 16, 64 * (F / 16 + HEADS16_NPT<Gm>), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
+  const int tiles = (n_max + 15) / 16;
+  if (e->net.hd16_ok && small && 2 * tiles <= (e->num_cu > 0 ? e->num_cu : 256))    // value and policy tiles in two workgroups, features staged in LDS
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads16<Gm, F, true>), 2 * tiles, (H16<Gm, F, true>::THREADS), (H16<Gm, F, true>::BYTES), e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
+  else if (e->net.hd16_ok && small)
+    LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads16<Gm, F, false>), tiles, (H16<Gm, F, false>::THREADS), (H16<Gm, F, false>::BYTES), e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
   else if (e->net.hd_ok)
     LAUNCH_ON(e, st, AZ_K_HEADS, n_max, (k_heads_mfma<Gm, F>), (n_max + 31) / 32, 64 * (F / 32 + HEADS_NPT<Gm>), 0, e->net, envs, eslots, n_ptr, n_max, Amask, hfeat, Pout, Vout, Pinv, pstride);
   else

@@ -337,12 +337,13 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
 #undef AZ_STAMP
 }
 
-// Last step of the heads for ONE board by one lane: softmax over the logits, Dense(F => 1, tanh) over the value-hidden
-// units, then forward_normalized (network.jl:264-271).  `logit`: the board's A logits (bias added), `vh`: its F hidden units.
-template <class Gm, int F>
-__device__ __forceinline__ void heads_finish(const NetDev& net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
-                                             const float* __restrict__ Amask, float* __restrict__ Pout, float* __restrict__ Vout,
-                                             float* __restrict__ Pinv, int pstride, int e, const float* __restrict__ logit, const float* __restrict__ vh) {
+// Last step of the heads for ONE board by one lane: softmax over the logits and forward_normalized (network.jl:264-271)
+// -- heads_finish_policy --, Dense(F => 1, tanh) over the value-hidden units -- heads_finish_value.
+// `logit`: the board's A logits (bias added), `vh`: its F hidden units.
+template <class Gm>
+__device__ __forceinline__ void heads_finish_policy(const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+                                                    const float* __restrict__ Amask, float* __restrict__ Pout, float* __restrict__ Pinv,
+                                                    int pstride, int e, const float* __restrict__ logit) {
   constexpr int A = Gm::A;
   float pr[A];
   float mx = logit[0];
@@ -350,10 +351,6 @@ __device__ __forceinline__ void heads_finish(const NetDev& net, const GEnv* __re
   float s = 0.0f;
   for (int a = 0; a < A; ++a) { pr[a] = az_expf(logit[a] - mx); s += pr[a]; }
   for (int a = 0; a < A; ++a) pr[a] = pr[a] / s;                   // softmax, resnet.jl:84
-  float av = 0.0f;
-  for (int k = 0; k < F; ++k) av = az_fmaf(vh[k], net.val2_w[k], av);
-  av = av + net.val2_b;
-  const float val = az_tanhf(av);                                  // Dense(F => 1, tanh), resnet.jl:90
   float sp = 0.0f;
   for (int a = 0; a < A; ++a) {
     float mk;
@@ -364,8 +361,21 @@ __device__ __forceinline__ void heads_finish(const NetDev& net, const GEnv* __re
   }
   for (int a = 0; a < A; ++a) Pout[(size_t)e * pstride + a] = pr[a] / (sp + 1.1920929e-7f);
   for (int a = A; a < pstride; ++a) Pout[(size_t)e * pstride + a] = 0.0f;
-  Vout[e] = val;
   if (Pinv) Pinv[e] = 1.0f - sp;
+}
+template <int F>
+__device__ __forceinline__ void heads_finish_value(const NetDev& net, float* __restrict__ Vout, int e, const float* __restrict__ vh) {
+  float av = 0.0f;
+  for (int k = 0; k < F; ++k) av = az_fmaf(vh[k], net.val2_w[k], av);
+  av = av + net.val2_b;
+  Vout[e] = az_tanhf(av);                                          // Dense(F => 1, tanh), resnet.jl:90
+}
+template <class Gm, int F>
+__device__ __forceinline__ void heads_finish(const NetDev& net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+                                             const float* __restrict__ Amask, float* __restrict__ Pout, float* __restrict__ Vout,
+                                             float* __restrict__ Pinv, int pstride, int e, const float* __restrict__ logit, const float* __restrict__ vh) {
+  heads_finish_policy<Gm>(leaf_env, eval_slots, Amask, Pout, Pinv, pstride, e, logit);
+  heads_finish_value<F>(net, Vout, e, vh);
 }
 
 // Dense heads, softmax, tanh, forward_normalized.  HB boards per 4(F+16)-thread workgroup; thread
@@ -513,101 +523,194 @@ k_heads_mfma(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restric
   heads_mfma_tile<Gm, F>(net, leaf_env, eval_slots, n, Amask, hfeat, Pout, Vout, Pinv, pstride, board0, s_vh, s_logit);
 }
 
-// Dense heads for SMALL launches (a wave of a 128-worker engine, the arena): 16 boards per workgroup on
-// v_mfma_f32_16x16x4_f32, F/16 value wavefronts + ceil(A/16) policy wavefronts, so a board tile's K = 32 P chain costs
-// 8 P MFMAs of 32 cycles instead of 16 P of 64 (k_heads_mfma's 32-board tiles: 75 us for 128 boards at F = 128, one
-// workgroup's latency, against 14 us of chain here) and four times as many CUs take part.  32 head filters only
-// (NetDev::hd16_ok).  The MFMA's k slot is the lane group g = lane >> 4 and the contract wants ascending k, so the
-// lane (board m, g) needs features 4s + g (s = 0..3) of each 16-feature block while a coalesced float4 load gives it
-// 4g .. 4g + 3: the 4 x 4 transposition goes through a wavefront-private LDS patch (row stride 20 floats: the b128
-// writes and the b32 reads are both conflict-free), double-buffered, one block ahead of the MFMAs; global loads run
-// HEADS16_DEPTH blocks ahead.  Same fp32 chain as k_heads / k_heads_mfma: bit-identical outputs.
+// Dense heads in 16-board tiles on v_mfma_f32_16x16x4_f32, one wavefront per 16 outputs (F/16 value tiles, ceil(A/16)
+// policy tiles): a board tile's K = 32 P chain is 8 P MFMAs of 32 cycles instead of 16 P of 64 (k_heads_mfma's 32-board
+// tiles: 75 us for 128 boards at F = 128, one workgroup's latency) and more CUs take part.  32 head filters only
+// (NetDev::hd16_ok).  Same fp32 chain as k_heads / k_heads_mfma: bit-identical outputs.
+//
+// The MFMA's k slot is the lane group g = lane >> 4 and the contract wants ascending k, so the lane (board m, g) needs
+// features 4 s + g (s = 0..3) of every 16-feature block, while a coalesced float4 load gives it 4 g .. 4 g + 3: a 4 x 4
+// transposition through LDS.  The kernel is a matrix-vector product at heart -- every weight is used for 16 boards --
+// and what binds is the CU's vector-memory path, not the MFMA chain (a dependent chain issues every 32.5 cycles,
+// tools/probes/mfma_latency.hip; tools/heads_timeline.py showed 400-700 cycles per 4-MFMA block when every wavefront
+// fetched and transposed the board features for itself).  Two forms:
+//   SPLIT (launches of up to num_cu workgroups): the value tiles and the policy tiles of a board tile are TWO workgroups
+//     (blockIdx & 1; softmax / mask and the value's Dense(F => 1) need nothing from each other), so a SIMD carries two
+//     chains instead of three; and, when they fit (P <= 48), phase 1 brings the workgroup's features into LDS ONCE,
+//     already transposed ([block][board][g][s], the g slot rotated by 2 for boards 4..7 and 12..15: the b128 reads of
+//     phase 2 are conflict-free), phase 2 = per block one ds_read_b128 + one float4 of weights (HEADS16_WDEPTH blocks
+//     ahead: a small launch has one workgroup per XCD, so every weight comes from HBM).
+//   unsplit (full launches, 9 x 9 boards): all tiles in one workgroup, policy wavefronts first (the oldest wavefronts of
+//     a SIMD win its issue slots), every wavefront transposes its own features through a private patch (row stride 20
+//     floats: the b128 writes and the b32 reads are both conflict-free), triple-buffered, two blocks ahead of the MFMAs.
+// (Four stride-4 dword loads straight from global memory instead of the LDS hop were tried: 94 us instead of 34.)
 #ifndef HEADS16_DEPTH
-#define HEADS16_DEPTH 4      // blocks of global loads in flight: 4 measured as fast as 8 (34.0 vs 35.3 us at 128 filters) with 78 instead of 132 VGPRs
+#define HEADS16_DEPTH 8      // blocks of global loads in flight, wavefronts that transpose for themselves
+#endif
+#ifndef HEADS16_WDEPTH
+#define HEADS16_WDEPTH 16    // weight fragments in flight, staged form
 #endif
 template <class Gm> constexpr int HEADS16_NPT = (Gm::A + 15) / 16;
-template <class Gm, int F>
-__global__ void __launch_bounds__(64 * (F / 16 + HEADS16_NPT<Gm>))
+template <class Gm, int F, bool SPLIT> struct H16 {
+  static constexpr int P = Gm::P, NVT = F / 16, NPT = HEADS16_NPT<Gm>;
+  static constexpr int WAVES = SPLIT ? (NVT > NPT ? NVT : NPT) : NVT + NPT, THREADS = 64 * WAVES;
+  static constexpr int NB = 2 * P, RS = 20, SV = F + 1, LP = HEADS_LP<Gm>;
+  static constexpr bool STAGE = SPLIT && 16 * P * 32 * 4 <= 96 * 1024;   // a workgroup's features fit in LDS
+  static constexpr int A_FLOATS = STAGE ? NB * 256 : 0, PATCH_FLOATS = STAGE ? 0 : WAVES * 3 * 16 * RS;
+  static constexpr int BYTES = (A_FLOATS + PATCH_FLOATS + 16 * SV + 16 * LP) * 4;
+};
+template <class Gm, int F, bool SPLIT> struct H16Threads { static constexpr int V = H16<Gm, F, SPLIT>::THREADS; };
+template <class Gm, int F, bool SPLIT>
+__global__ void __launch_bounds__((H16Threads<Gm, F, SPLIT>::V))
 k_heads16(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
           const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ Amask,
           const float* __restrict__ hfeat, float* __restrict__ Pout, float* __restrict__ Vout,
           float* __restrict__ Pinv, int pstride) {
-  constexpr int P = Gm::P, A = Gm::A, NVT = F / 16, NPT = HEADS16_NPT<Gm>, LP = HEADS_LP<Gm>, SV = F + 1, NB = 2 * P, DEPTH = HEADS16_DEPTH, RS = 20;
-  static_assert(NB >= DEPTH, "pipeline deeper than the chain");
+  using H = H16<Gm, F, SPLIT>;
+  constexpr int P = Gm::P, A = Gm::A, NVT = H::NVT, NPT = H::NPT, LP = H::LP, SV = H::SV, NB = H::NB, RS = H::RS;
   __builtin_amdgcn_s_setprio(3);
-  __shared__ float s_vh[16 * SV];
-  __shared__ float s_logit[16 * LP];
-  __shared__ __attribute__((aligned(16))) float s_tr[NVT + NPT][2][16 * RS];
+  extern __shared__ __attribute__((aligned(16))) float h16_lds[];
+  float* As = h16_lds;                                              // [NB][16 boards][4 g slots][4 s]
+  float* s_tr = h16_lds + H::A_FLOATS;                              // [WAVES][3][16 * RS]
+  float* s_vh = s_tr + H::PATCH_FLOATS;
+  float* s_logit = s_vh + 16 * SV;
   const int n = n_eval_ptr ? *n_eval_ptr : n_fixed;
-  const int board0 = blockIdx.x * 16;
+  const int board0 = (SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x) * 16;
   if (board0 >= n) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
-  const bool is_pol = wave >= NVT;
-  const int pt = wave - NVT;
-  const int HF = net.HF;
-  int e = board0 + m;
-  if (e >= n) e = n - 1;                           // clamp: rows past the batch are computed and dropped
-  const float* hf = hfeat + (size_t)e * P * HF + (is_pol ? 0 : net.npf) + 4 * g;
-  const f32x4v* wp = (const f32x4v*)net.hd16_w + (size_t)wave * NB * 64 + lane;
-  float* trw = &s_tr[wave][0][0] + m * RS + 4 * g;         // this lane's float4 of a patch
-  const float* trr = &s_tr[wave][0][0] + m * RS + g;       // ... and its column (stride 4)
-  f32x4v ga[DEPTH], gb[DEPTH];
-  float ta[2][4];
-  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-  // block j: features 16 (j & 1) .. + 15 of position j >> 1, fragment j of this wave's tile
-#define H16_LOAD(hfj, wpj, d, st) do { ga[st] = *(const f32x4v*)((hfj) + ((d) >> 1) * HF + ((d) & 1) * 16); gb[st] = (wpj)[(size_t)(d) * 64]; } while (0)
-  // ga[st] -> ta[par] through patch `par`
-#define H16_TRANSPOSE(st, par) do {                                              \
-    *(f32x4v*)(trw + (par) * 16 * RS) = ga[st];                                  \
-    __builtin_amdgcn_wave_barrier();                                             \
-    ta[par][0] = trr[(par) * 16 * RS]; ta[par][1] = trr[(par) * 16 * RS + 4];    \
-    ta[par][2] = trr[(par) * 16 * RS + 8]; ta[par][3] = trr[(par) * 16 * RS + 12]; } while (0)
-#define H16_MFMA(par, b) do {                                                    \
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[par][0], (b).x, acc, 0, 0, 0); \
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[par][1], (b).y, acc, 0, 0, 0); \
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[par][2], (b).z, acc, 0, 0, 0); \
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[par][3], (b).w, acc, 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0); } while (0)
-  static_for<DEPTH>([&](auto dc) { constexpr int d = decltype(dc)::value; H16_LOAD(hf, wp, d, d); });
-  H16_TRANSPOSE(0, 0);
-  // steady state in chunks of DEPTH blocks (every block of a chunk has its successor DEPTH ahead inside the chain),
-  // then a fully unrolled tail of DEPTH .. 2 DEPTH - 1 blocks
-  constexpr int MAIN = (NB - DEPTH) / DEPTH, TAIL = NB - MAIN * DEPTH;
-  static_assert(DEPTH % 2 == 0, "patch parity follows the register index");
-  const float* hfj = hf;
-  const f32x4v* wpj = wp;
-  for (int c = 0; c < MAIN; ++c) {
-    static_for<DEPTH>([&](auto dc) {
-      constexpr int d = decltype(dc)::value;
-      const f32x4v b = gb[d];
-      H16_LOAD(hfj, wpj, d + DEPTH, d);            // ga[d] went through the patch one block ago, gb[d] is in `b`
-      H16_TRANSPOSE((d + 1) % DEPTH, (d + 1) & 1);
-      H16_MFMA(d & 1, b);
-    });
-    hfj += (DEPTH / 2) * HF;
-    wpj += (size_t)DEPTH * 64;
+  unsigned long long* dbg = (net.dbg && lane == 0) ? net.dbg + ((size_t)blockIdx.x * H::WAVES + wave) * 4 : nullptr;   // az_debug_heads_timeline
+  if (dbg) dbg[0] = __builtin_readcyclecounter();
+  // this wavefront's chain: a policy tile pt or a value tile vt (split form: a workgroup has one kind, wavefronts beyond its
+  // tiles only help with phase 1)
+  const bool is_pol = SPLIT ? (blockIdx.x & 1) != 0 : wave < NPT;
+  const int pt = wave, vt = SPLIT ? wave : wave - NPT;
+  const bool active = !SPLIT || wave < (is_pol ? NPT : NVT);
+  const int HF = net.HF, foff = is_pol ? 0 : net.npf;
+  if constexpr (H::STAGE) {
+    // phase 1: feature f = 4 c + i of (board b, position p) -> block 2 p + (c >> 2), s = c & 3, g = i
+    for (int idx = threadIdx.x; idx < 16 * P * 8; idx += H::THREADS) {
+      const int c = idx & 7, p = (idx >> 3) % P, b = idx / (8 * P);
+      int eb = board0 + b;
+      if (eb >= n) eb = n - 1;                     // clamp: rows past the batch are computed and dropped
+      const f32x4v v = *(const f32x4v*)(hfeat + ((size_t)eb * P + p) * HF + foff + 4 * c);
+      float* dst = As + ((2 * p + (c >> 2)) * 16 + b) * 16 + (c & 3);
+      const int rot = 2 * ((b >> 2) & 1);
+      dst[4 * ((0 + rot) & 3)] = v.x; dst[4 * ((1 + rot) & 3)] = v.y; dst[4 * ((2 + rot) & 3)] = v.z; dst[4 * ((3 + rot) & 3)] = v.w;
+    }
+    __syncthreads();
   }
-  static_for<TAIL>([&](auto dc) {
-    constexpr int d = decltype(dc)::value;
-    const f32x4v b = gb[d % DEPTH];
-    if constexpr (d + DEPTH < TAIL) H16_LOAD(hfj, wpj, d + DEPTH, d % DEPTH);
-    if constexpr (d + 1 < TAIL) H16_TRANSPOSE((d + 1) % DEPTH, (d + 1) & 1);
-    H16_MFMA(d & 1, b);
-  });
+  if (active) {
+  const f32x4v* wp = (const f32x4v*)net.hd16_w + (size_t)(is_pol ? NVT + pt : vt) * NB * 64 + lane;   // fragments: value tiles, then policy tiles
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#define H16_MFMA(a0, a1, a2, a3, b) do {                                         \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, (b).x, acc, 0, 0, 0);         \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, (b).y, acc, 0, 0, 0);         \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, (b).z, acc, 0, 0, 0);         \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, (b).w, acc, 0, 0, 0);         \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+  if constexpr (H::STAGE) {
+    // phase 2: A from the staged features, two blocks ahead of the MFMAs; weights WD blocks ahead
+    constexpr int WD = HEADS16_WDEPTH;
+    static_assert(NB >= WD && WD % 2 == 0, "chain shorter than the pipeline");
+    const float* ap = As + m * 16 + 4 * ((g + 2 * ((m >> 2) & 1)) & 3);
+    f32x4v gb[WD], av[3];
+    static_for<WD>([&](auto dc) { constexpr int d = decltype(dc)::value; gb[d] = wp[(size_t)d * 64]; });
+    av[0] = *(const f32x4v*)ap;
+    av[1] = *(const f32x4v*)(ap + 256);
+    constexpr int CH = WD % 3 == 0 ? WD : 3 * WD, MAIN = NB >= WD + 2 ? (NB - WD - 2) / CH : 0, TAIL = NB - MAIN * CH;
+    const f32x4v* wpj = wp;
+    const float* apj = ap;
+    for (int c = 0; c < MAIN; ++c) {
+      static_for<CH>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        const f32x4v b = gb[d % WD];
+        av[(d + 2) % 3] = *(const f32x4v*)(apj + (d + 2) * 256);
+        gb[d % WD] = wpj[(size_t)(d + WD) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        H16_MFMA(av[d % 3].x, av[d % 3].y, av[d % 3].z, av[d % 3].w, b);
+      });
+      wpj += (size_t)CH * 64;
+      apj += CH * 256;
+    }
+    static_for<TAIL>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      const f32x4v b = gb[d % WD];
+      if constexpr (d + 2 < TAIL) av[(d + 2) % 3] = *(const f32x4v*)(apj + (d + 2) * 256);
+      if constexpr (d + WD < TAIL) gb[d % WD] = wpj[(size_t)(d + WD) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      H16_MFMA(av[d % 3].x, av[d % 3].y, av[d % 3].z, av[d % 3].w, b);
+    });
+  } else {
+    // a wavefront that fetches and transposes its own features
+    constexpr int DEPTH = HEADS16_DEPTH;
+    static_assert(NB >= DEPTH && DEPTH >= 3 && DEPTH % 2 == 0, "pipeline depth");
+    int e = board0 + m;
+    if (e >= n) e = n - 1;
+    const float* hf = hfeat + (size_t)e * P * HF + foff + 4 * g;
+    float* patch = s_tr + (size_t)wave * 3 * 16 * RS;
+    float* trw = patch + m * RS + 4 * g;           // this lane's float4 of a patch
+    const float* trr = patch + m * RS + g;         // ... and its column (stride 4)
+    f32x4v ga[DEPTH], gb[DEPTH];
+    float ta[3][4];
+    // block j: features 16 (j & 1) .. + 15 of position j >> 1, fragment j of this wave's tile
+#define H16_LOAD(hfj, wpj, d, st) do { ga[st] = *(const f32x4v*)((hfj) + ((d) >> 1) * HF + ((d) & 1) * 16); gb[st] = (wpj)[(size_t)(d) * 64]; } while (0)
+    // ga[st] -> ta[par] through patch `par`
+#define H16_TRANSPOSE(st, par) do {                                              \
+      *(f32x4v*)(trw + (par) * 16 * RS) = ga[st];                                \
+      __builtin_amdgcn_wave_barrier();                                           \
+      ta[par][0] = trr[(par) * 16 * RS]; ta[par][1] = trr[(par) * 16 * RS + 4];  \
+      ta[par][2] = trr[(par) * 16 * RS + 8]; ta[par][3] = trr[(par) * 16 * RS + 12]; } while (0)
+    static_for<DEPTH>([&](auto dc) { constexpr int d = decltype(dc)::value; H16_LOAD(hf, wp, d, d); });
+    H16_TRANSPOSE(0, 0);
+    H16_TRANSPOSE(1, 1);
+    // Block j's MFMAs run on ta[j % 3]; block j + 2 goes through the patch meanwhile; block j + DEPTH leaves global
+    // memory.  Steady state in chunks of lcm(3, DEPTH) blocks (static register indices), then a fully unrolled tail.
+    constexpr int CH = DEPTH % 3 == 0 ? DEPTH : 3 * DEPTH, MAIN = NB >= DEPTH + 2 ? (NB - DEPTH - 2) / CH : 0, TAIL = NB - MAIN * CH;
+    const float* hfj = hf;
+    const f32x4v* wpj = wp;
+    for (int c = 0; c < MAIN; ++c) {
+      static_for<CH>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        const f32x4v b = gb[d % DEPTH];
+        H16_TRANSPOSE((d + 2) % DEPTH, (d + 2) % 3);
+        H16_LOAD(hfj, wpj, d + DEPTH, d % DEPTH);  // ga[d % DEPTH] went through the patch two blocks ago, gb[d % DEPTH] is in `b`
+        __builtin_amdgcn_sched_barrier(0);
+        H16_MFMA(ta[d % 3][0], ta[d % 3][1], ta[d % 3][2], ta[d % 3][3], b);
+      });
+      hfj += (CH / 2) * HF;
+      wpj += (size_t)CH * 64;
+    }
+    static_for<TAIL>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      const f32x4v b = gb[d % DEPTH];
+      if constexpr (d + 2 < TAIL) H16_TRANSPOSE((d + 2) % DEPTH, (d + 2) % 3);
+      if constexpr (d + DEPTH < TAIL) H16_LOAD(hfj, wpj, d + DEPTH, d % DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+      H16_MFMA(ta[d % 3][0], ta[d % 3][1], ta[d % 3][2], ta[d % 3][3], b);
+    });
 #undef H16_LOAD
 #undef H16_TRANSPOSE
+  }
 #undef H16_MFMA
+  if (dbg) dbg[1] = __builtin_readcyclecounter();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 4 * g + i;                     // board of the tile; column m = output
     if (is_pol) { if (pt * 16 + m < A) s_logit[row * LP + pt * 16 + m] = acc[i] + net.pol_b[pt * 16 + m]; }
     else {
-      const int o = wave * 16 + m;
+      const int o = vt * 16 + m;
       const float v = acc[i] + net.val_b[o];
       s_vh[row * SV + o] = v > 0.0f ? v : 0.0f;
     }
   }
+  }
   __syncthreads();
+  if (dbg) dbg[2] = __builtin_readcyclecounter();
   const int b = threadIdx.x;
-  if (b < 16 && board0 + b < n) heads_finish<Gm, F>(net, leaf_env, eval_slots, Amask, Pout, Vout, Pinv, pstride, board0 + b, s_logit + b * LP, s_vh + b * SV);
+  if (b < 16 && board0 + b < n) {
+    if constexpr (!SPLIT) heads_finish<Gm, F>(net, leaf_env, eval_slots, Amask, Pout, Vout, Pinv, pstride, board0 + b, s_logit + b * LP, s_vh + b * SV);
+    else if (is_pol) heads_finish_policy<Gm>(leaf_env, eval_slots, Amask, Pout, Pinv, pstride, board0 + b, s_logit + b * LP);
+    else heads_finish_value<F>(net, Vout, board0 + b, s_vh + b * SV);
+  }
+  if (dbg) dbg[3] = __builtin_readcyclecounter();
 }
