@@ -192,6 +192,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     memset(&e->net16, 0, sizeof e->net16);
     { const char* tw = getenv("AZHIP_TOWER"); e->tower_pick = tw ? atoi(tw) : 0; }
     { const char* hd = getenv("AZHIP_HEADS"); e->heads_pick = hd ? atoi(hd) : 0; }
+    { const char* ep = getenv("AZHIP_XCH_EPOCH0"); e->xch_epoch = ep ? strtoull(ep, nullptr, 0) : 0; }   // tests: start k_tower16s' launch epoch near its 24-bit wrap
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); e->num_cu = pr.multiProcessorCount; }
     AZCHK(net_set_kernel_attrs(e));
     // slot groups

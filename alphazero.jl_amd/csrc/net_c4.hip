@@ -35,13 +35,13 @@ static int tower_timeline_split(az_engine* e, int32_t n, unsigned long long* out
   std::vector<GEnv> envs(n, ConnectFour::init());
   HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * n, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(e->d_ntmp, &n, sizeof(int), hipMemcpyHostToDevice, e->stream));
-  unsigned long long* xa;
-  AZCHK(xch_slot<ConnectFour>(e, e->d_hfeat, &xa));
+  unsigned long long* xa; unsigned long long ep;
   Net16Dev nd = e->net16;
   for (int rep = 0; rep < 2; ++rep) {
     nd.dbg = rep ? d : nullptr;
+    AZCHK(xch_slot<ConnectFour>(e, e->d_hfeat, &xa, &ep));
     hipLaunchKernelGGL((k_tower16s<ConnectFour, 128, false>), dim3(nb), dim3(T::THREADS), T::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat,
-                       xa, ++e->xch_epoch, e->v.err);
+                       xa, ep, e->v.err);
   }
   HIPCHK(hipMemcpyAsync(out, d, sizeof(unsigned long long) * nb * 8, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));

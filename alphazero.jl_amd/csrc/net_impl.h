@@ -115,12 +115,21 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
   return c16 <= c32 ? 16 : 32;
 }
 // publish areas of k_tower16s for the launches that write `hfeat` (one feature buffer = one stream at a time)
-template <class Gm> static int xch_slot(az_engine* e, const float* hfeat, unsigned long long** xch) {
+template <class Gm> static int xch_slot(az_engine* e, const float* hfeat, unsigned long long** xch, unsigned long long* epoch) {
   using T = T16S<Gm, 128>;
+  const size_t words = (size_t)(e->num_cu > 0 ? e->num_cu : 256) * T::XCH_WORDS;
   int slot = AZ_MAX_GROUPS;
   for (int g = 0; g < e->ngroups; ++g) if (hfeat == e->g_hfeat[g]) slot = g;
-  if (!e->xch[slot]) AZCHK(dalloc(e, &e->xch[slot], (size_t)(e->num_cu > 0 ? e->num_cu : 256) * T::XCH_WORDS));   // zeroed: tag 0 is never expected
+  if (!e->xch[slot]) AZCHK(dalloc(e, &e->xch[slot], words));        // zeroed: tag 0 is never expected
+  // a tag carries 24 bits of the launch epoch: before they repeat, every area is cleared (an area that a long run of
+  // smaller launches has not touched could otherwise still hold words with the tag of exactly 2^24 launches ago)
+  if (((e->xch_epoch + 1) & 0xFFFFFFull) == 0) {
+    AZCHK(sync_all(e));
+    for (int k = 0; k <= AZ_MAX_GROUPS; ++k) if (e->xch[k]) HIPCHK(hipMemset(e->xch[k], 0, words * sizeof(unsigned long long)));
+    ++e->xch_epoch;                                                  // skip the epoch whose tags would start at 0
+  }
   *xch = e->xch[slot];
+  *epoch = ++e->xch_epoch;
   return AZ_OK;
 }
 // Dense heads of n_max boards: 16-board tiles (k_heads16: a quarter of the chain latency, 23 instead of 43 us per launch
@@ -161,10 +170,10 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
     else LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b<Gm, F, FROM_PLANES, 11>), (n_max + TBb - 1) / TBb, THRb, LDSb, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
   } else if (tw == 2) {
     if constexpr (F == 128) {
-      unsigned long long* xa;
-      AZCHK(xch_slot<Gm>(e, hfeat, &xa));
+      unsigned long long* xa; unsigned long long ep;
+      AZCHK(xch_slot<Gm>(e, hfeat, &xa, &ep));
       LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16s<Gm, F, FROM_PLANES>), 2 * ((n_max + TB3 - 1) / TB3), (T16S<Gm, F>::THREADS), LDS3, e->net16, envs, eslots, n_ptr, n_max, X, hfeat,
-                xa, ++e->xch_epoch, e->v.err);
+                xa, ep, e->v.err);
     }
   } else if (tw == 21) {
     if constexpr (F == 64)
@@ -207,10 +216,10 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
     else LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 11>), (N + TBb - 1) / TBb, THRb, LDSb, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   } else if (tw == 2) {
     if constexpr (F == 128) {
-      unsigned long long* xa;
-      AZCHK(xch_slot<Gm>(e, e->g_hfeat[g], &xa));
+      unsigned long long* xa; unsigned long long ep;
+      AZCHK(xch_slot<Gm>(e, e->g_hfeat[g], &xa, &ep));
       LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16s<Gm, F, false>), 2 * ((N + TB3 - 1) / TB3), (T16S<Gm, F>::THREADS), LDS3, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g],
-                xa, ++e->xch_epoch, e->v.err);
+                xa, ep, e->v.err);
     }
   } else if (tw == 21) {
     if constexpr (F == 64)

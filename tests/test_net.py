@@ -234,3 +234,25 @@ def test_split_tower_bit_exact_vs_oracle(game, nblocks, n):
         assert np.array_equal(P, Pr), np.abs(P - Pr).max()
         assert np.array_equal(V, Vr) and np.array_equal(Pinv, Pir)
     assert np.array_equal(Pk, Pr) and np.array_equal(Vk, Vr)
+
+
+@pytest.mark.gpu
+def test_split_tower_epoch_wrap(monkeypatch):
+    """The exchange words of k_tower16s carry 24 bits of the launch epoch; before they repeat the library clears the
+    areas and skips the epoch whose tags would equal cleared memory.  Started three launches before the wrap, eight
+    forward passes (of different sizes, so that some areas go unused for a while) stay bit-exact."""
+    import azhip
+    monkeypatch.setenv("AZHIP_XCH_EPOCH0", str(0xFFFFFF - 3))
+    hp = ResNetHP(num_blocks=2, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32)
+    blob = random_params(R.C4, hp, seed=43)
+    envs = random_positions(R.C4, 60, 12)
+    X, A = batch_of(R.C4, envs)
+    Pr, Vr, _ = R.net_forward_normalized(R.C4, (2, 128, 32, 32), blob, X, A)
+    with azhip.Engine(game=R.C4, oracle=azhip.ORACLE_RESNET, num_workers=64, batch_size=64, num_iters_per_turn=8,
+                      num_blocks=2, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32) as e:
+        e.net_set_params(blob)
+        for k in range(8):
+            n = (60, 7, 33, 60, 2, 60, 19, 60)[k]
+            P, V, _ = e.net_forward(X[:n], A[:n])
+            assert e.net_last_kernel().startswith("k_tower16s<")
+            assert np.array_equal(P, Pr[:n]) and np.array_equal(V, Vr[:n]), k
