@@ -731,7 +731,7 @@ template <int F> struct WG16 {
 };
 template <class Gm, int F>
 __global__ void __launch_bounds__(64 * (F / 16), 1)
-k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __restrict__ part, int nboards, int boards_per_wg) {
+k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __restrict__ part, int nboards, int nsplits) {
   using G = WG16<F>;
   constexpr int P = Gm::P, W = Gm::W, H = Gm::H, STRIDE = G::STRIDE, RP = G::RP, CT = G::CT, TPW = G::TPW;
   constexpr int NBC = RP / P < 1 ? 1 : RP / P;                    // boards per chunk for this game
@@ -740,8 +740,11 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
   float* Ds = lds + (RP + 1) * STRIDE;                            // [RP][STRIDE]
   uint32_t* vtab = (uint32_t*)(Ds + RP * STRIDE);                 // [RP] tap validity of a chunk row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, g = lane >> 4;
-  const int b_begin = blockIdx.x * boards_per_wg;
-  const int b_end = (b_begin + boards_per_wg) < nboards ? (b_begin + boards_per_wg) : nboards;
+  // boards of this workgroup: nboards spread evenly over the nsplits workgroups of a tap group (the first nboards % nsplits
+  // take one more; a last partial LDS chunk costs only its rows)
+  const int bq = nboards / nsplits, br = nboards % nsplits;
+  const int b_begin = blockIdx.x * bq + ((int)blockIdx.x < br ? (int)blockIdx.x : br);
+  const int b_end = b_begin + bq + ((int)blockIdx.x < br ? 1 : 0);
   const int tap0 = blockIdx.y * TPW;
   for (int r = tid; r < RP; r += G::THREADS) {
     uint32_t m = 0;

@@ -454,11 +454,11 @@ static int trainer_build(az_trainer* t) {
   t->wg_part = nullptr; t->wg_splits = 0; t->wg_bpw = 0;
   if (t->wg_mfma) {
     const int tg = F == 128 ? 3 : 1, per_cu = 1;                    // 82 KB (64 filters) / 145 KB (128) of LDS: one workgroup per CU either way
-    const int nbc = std::max(1, 128 / P);
-    const int target = std::max(1, t->e->num_cu * per_cu / tg);
-    int bpw = (B + target - 1) / target;
-    bpw = (bpw + nbc - 1) / nbc * nbc;                             // whole LDS chunks
-    t->wg_bpw = bpw; t->wg_splits = (B + bpw - 1) / bpw;
+    // as many workgroups per tap group as the chip holds (one round), the boards spread evenly over them: 1024 boards at
+    // 128 filters = 85 workgroups x 3 tap groups with 12 or 13 boards each (whole 3-board LDS chunks per workgroup made it
+    // 69 x 3 workgroups with 15 boards: a fifth of the CUs idle and a fifth chunk for everyone)
+    t->wg_splits = std::max(1, std::min(B, t->e->num_cu * per_cu / tg));
+    t->wg_bpw = (B + t->wg_splits - 1) / t->wg_splits;
     AZCHK(tr_alloc(t, &t->wg_part, (size_t)t->wg_splits * 9 * F * F));
   }
   return AZ_OK;
@@ -481,7 +481,7 @@ template <class Gm, int F> static int tr_wgrad16_f(az_trainer* t, const float* a
   using G = WG16<F>;
   static bool attr_done = false;
   if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16<Gm, F>), hipFuncAttributeMaxDynamicSharedMemorySize, G::BYTES)); attr_done = true; }
-  hipLaunchKernelGGL((k_wgrad16<Gm, F>), dim3(t->wg_splits, G::TG), dim3(G::THREADS), G::BYTES, t->stream, a, dg, t->wg_part, t->B, t->wg_bpw);
+  hipLaunchKernelGGL((k_wgrad16<Gm, F>), dim3(t->wg_splits, G::TG), dim3(G::THREADS), G::BYTES, t->stream, a, dg, t->wg_part, t->B, t->wg_splits);
   const long long n = 9LL * F * F;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(tr_grid(n)), dim3(256), 0, t->stream, t->wg_part, t->wg_splits, n, out);
   return AZ_OK;
