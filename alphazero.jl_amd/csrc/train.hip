@@ -45,22 +45,6 @@ __global__ void k_tr_batch(const int* __restrict__ idx, int B, int xs, int A, co
   for (int i = threadIdx.x; i < A; i += blockDim.x) { bA[(size_t)b * A + i] = Am[s * A + i]; bP[(size_t)b * A + i] = P[s * A + i]; }
   if (threadIdx.x == 0) { bW[b] = W[s]; bV[b] = V[s]; }
 }
-// im2col of a 3x3 / pad 1 convolution over rows r = board*P + x + W*y: col[r][tap*C + c] = in(r + delta(tap))[c] or 0.
-// PLANES: `in` is the plane tensor [B][C][P]; else the activation matrix [R][C].
-// float4 form for activation matrices (C % 4 == 0): one thread moves 4 channels of one (row, tap)
-__global__ void __launch_bounds__(256) k_tr_im2col4(const float4* __restrict__ in, long long R, int C4, int Wd, int Hd, float4* __restrict__ col) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = R * 9 * C4;
-  if (t >= total) return;
-  const int c = (int)(t % C4);
-  const int tap = (int)((t / C4) % 9);
-  const long long r = t / (9LL * C4);
-  const int P = Wd * Hd, q = (int)(r % P), x = q % Wd, y = q / Wd;
-  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (y + dy >= 0 && y + dy < Hd && x + dx >= 0 && x + dx < Wd) v = in[(r + dy * Wd + dx) * C4 + c];
-  col[t] = v;
-}
 template <bool PLANES>
 __global__ void __launch_bounds__(256) k_tr_im2col(const float* __restrict__ in, long long R, int C, int Wd, int Hd, float* __restrict__ col) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,7 +276,7 @@ __global__ void k_tr_sumsq(const float* __restrict__ w, const unsigned char* __r
 struct TrConv {                 // one convolution + batch norm (3x3 of the tower, or a 1x1 head convolution)
   int cin, cout, taps;
   size_t off_w, off_b, off_bn;  // blob offsets: W, bias, (gamma, beta, mean, var)
-  size_t wk_wm, wk_wrot;        // offsets in the working-parameter array: GEMM matrix [taps*cin][cout], rotated [taps*cout][cin]
+  size_t wk_wm;                 // offset in the working-parameter array: GEMM matrix [taps*cin][cout]
   size_t wk_ffwd, wk_fdg;       // tower convolutions F -> F: MFMA fragments of k_conv16_layer for forward / data gradient
   bool mfma;                    // forward and data gradient on k_conv16_layer instead of im2col + GEMM
   float *col, *g, *a;           // im2col input [R][taps*cin] (taps == 1: alias of the input), GEMM output, activation
@@ -316,8 +300,8 @@ struct az_trainer {
   // batch + head buffers
   int* d_idx; float *bW, *bX, *bA, *bP, *bV;
   float *logits, *v1, *tpre, *dlogits, *dt, *dv1;
-  float *dact, *dact2, *dcol;                                                // [R][F] gradients, [R][9F] im2col of a gradient
-  float* wg_part; int wg_splits, wg_bpw; bool wg_mfma;                       // k_wgrad16: partial dW per row split, boards per workgroup
+  float *dact, *dact2, *dcol;                                                // [R][F] gradients (dact / dcol alternate as the running gradient, dact2 = the skip share)
+  float* wg_part; int wg_splits, wg_bpw;                       // k_wgrad16: partial dW per row split, boards per workgroup
   double *part, *sums, *terms, *bsums;
   std::vector<void*> allocs;
   std::vector<int> perm; int64_t perm_pos, epoch; int64_t step;
@@ -369,8 +353,7 @@ static int trainer_build(az_trainer* t) {
     c.off_b = off; off += cout;
     c.off_bn = off; off += 4 * (size_t)cout;
     c.wk_wm = wk; wk += (size_t)taps * cin * cout;
-    c.wk_wrot = wk; wk += (size_t)taps * cin * cout;
-    c.mfma = taps == 9 && cin == cout && (cin == 64 || cin == 128) && !getenv("AZHIP_TRAIN_GEMM");
+    c.mfma = taps == 9 && cin == cout;                               // the tower's F -> F convolutions (F = 64 or 128: az_engine_create): MFMA layer kernels
     c.wk_ffwd = c.wk_fdg = 0;
     if (c.mfma) { c.wk_ffwd = wk; wk += (size_t)taps * cin * cout; c.wk_fdg = wk; wk += (size_t)taps * cin * cout; }
     t->convs.push_back(c);
@@ -397,7 +380,6 @@ static int trainer_build(az_trainer* t) {
       for (int ci = 0; ci < c.cin; ++ci) for (int co = 0; co < c.cout; ++co) {
         const int b = (int)(c.off_w + (size_t)wi + (size_t)ks * (wj + (size_t)ks * (ci + (size_t)c.cin * co)));   // Flux W(kw, kh, ci, co), true convolution
         map[c.wk_wm + ((size_t)tap * c.cin + ci) * c.cout + co] = b;
-        map[c.wk_wrot + ((size_t)(c.taps - 1 - tap) * c.cout + co) * c.cin + ci] = b;                          // data gradient: taps mirrored, ci <-> co
       }
     }
     if (c.mfma) {
@@ -434,7 +416,7 @@ static int trainer_build(az_trainer* t) {
   const int ntower = 1 + 2 * t->nblocks;
   for (size_t l = 0; l < t->convs.size(); ++l) {
     TrConv& c = t->convs[l];
-    if (c.taps == 9) AZCHK(tr_alloc(t, &c.col, (size_t)R * 9 * c.cin)); else c.col = nullptr;
+    if (c.taps == 9 && !c.mfma) AZCHK(tr_alloc(t, &c.col, (size_t)R * 9 * c.cin)); else c.col = nullptr;   // the stem's im2col (K = 9 C)
     AZCHK(tr_alloc(t, &c.g, (size_t)R * c.cout)); AZCHK(tr_alloc(t, &c.a, (size_t)R * c.cout));
     AZCHK(tr_alloc(t, &c.mean, c.cout)); AZCHK(tr_alloc(t, &c.invstd, c.cout));
   }
@@ -445,14 +427,13 @@ static int trainer_build(az_trainer* t) {
   AZCHK(tr_alloc(t, &t->logits, (size_t)B * A)); AZCHK(tr_alloc(t, &t->dlogits, (size_t)B * A));
   AZCHK(tr_alloc(t, &t->v1, (size_t)B * F)); AZCHK(tr_alloc(t, &t->dv1, (size_t)B * F));
   AZCHK(tr_alloc(t, &t->tpre, B)); AZCHK(tr_alloc(t, &t->dt, B));
-  AZCHK(tr_alloc(t, &t->dact, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dact2, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dcol, (size_t)R * 9 * F));
+  AZCHK(tr_alloc(t, &t->dact, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dact2, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dcol, (size_t)R * F));
   const int nchunks = (int)((R + TR_CHUNK - 1) / TR_CHUNK);
   AZCHK(tr_alloc(t, &t->part, (size_t)nchunks * 2 * std::max(F, 64))); AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64)));
   AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 8 + 1024));
   // k_wgrad16: one round of workgroups over the chip
-  t->wg_mfma = (F == 64 || F == 128) && !getenv("AZHIP_TRAIN_GEMM") && !getenv("AZHIP_TRAIN_WGRAD_GEMM");
   t->wg_part = nullptr; t->wg_splits = 0; t->wg_bpw = 0;
-  if (t->wg_mfma) {
+  {
     const int tg = F == 128 ? 3 : 1, per_cu = 1;                    // 82 KB (64 filters) / 145 KB (128) of LDS: one workgroup per CU either way
     // as many workgroups per tap group as the chip holds (one round), the boards spread evenly over them: 1024 boards at
     // 128 filters = 85 workgroups x 3 tap groups with 12 or 13 boards each (whole 3-board LDS chunks per workgroup made it
@@ -523,11 +504,11 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
   for (int l = 0; l < ntower; ++l) {
     TrConv& c = t->convs[l];
     const float* in = l == 0 ? t->bX : t->convs[l - 1].a;
-    const bool need_col = !(c.mfma && t->wg_mfma);                  // the GEMM forms of forward / weight gradient read im2col(input)
-    if (l == 0) hipLaunchKernelGGL((k_tr_im2col<true>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
-    else if (need_col) hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cin / 4))), dim3(256), 0, st, (const float4*)in, R, c.cin / 4, gi.W, gi.H, (float4*)c.col);
-    if (c.mfma) AZCHK(tr_conv16(t, in, t->work + c.wk_ffwd, c.g));         // (the im2col above feeds the weight gradient)
-    else AZCHK(tr_gemm(t, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
+    if (c.mfma) AZCHK(tr_conv16(t, in, t->work + c.wk_ffwd, c.g));
+    else {                                                          // the stem: K = 9 C, im2col + GEMM
+      hipLaunchKernelGGL((k_tr_im2col<true>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
+      AZCHK(tr_gemm(t, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
+    }
     { TrFinal fin{}; fin.mode = 1; fin.R = R; fin.momentum = t->cfg.batch_norm_momentum; fin.bias = blob + c.off_b; fin.mean = c.mean; fin.invstd = c.invstd;
       fin.run_mean = blob + c.off_bn + 2 * c.cout; fin.run_var = blob + c.off_bn + 3 * c.cout;
       AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout, fin)); }
@@ -589,29 +570,27 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
     first = false;
   }
   // ---------------- backward: tower ----------------
-  // da = gradient w.r.t. the activation convs[l].a; kept in dact; dskip (block input share) in dact2
-  HIPCHK(hipMemcpyAsync(t->dact, dtrunk, sizeof(float) * (size_t)R * F, hipMemcpyDeviceToDevice, st));
+  // da = gradient w.r.t. the activation convs[l].a; dskip (block input share) in dact2.  da alternates between the front
+  // of the big scratch (where the head convolutions left the trunk gradient) and dact: the MFMA data-gradient convolution
+  // writes out of place, so the two buffers swap roles instead of being copied
+  float* da = dtrunk;
+  float* da_alt = t->dact;
   for (int l = ntower - 1; l >= 0; --l) {
     TrConv& c = t->convs[l];
     const bool second = l > 0 && (l % 2) == 0;
     { TrFinal fin{}; fin.mode = 2; fin.dgamma = gb + c.off_bn; fin.dbeta = gb + c.off_bn + c.cout;
-      AZCHK(tr_colsum<1>(t, t->dact, c.a, c.g, c.mean, c.invstd, R, c.cout, fin)); }
+      AZCHK(tr_colsum<1>(t, da, c.a, c.g, c.mean, c.invstd, R, c.cout, fin)); }
     // dg overwrites dact; for conv2 the masked gradient dy also flows to the block input (dact2)
-    hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, t->dact, c.a, c.g, c.mean, c.invstd, blob + c.off_bn, t->sums, R, R * c.cout, c.cout,
-                       t->dact, second ? t->dact2 : (float*)nullptr);
-    if (c.mfma && t->wg_mfma) AZCHK(tr_wgrad16(t, t->convs[l - 1].a, t->dact, gw + c.wk_wm));
-    else AZCHK(tr_gemm(t, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, t->dact, c.cout, 0.f, gw + c.wk_wm, c.cout));
+    hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, da, c.a, c.g, c.mean, c.invstd, blob + c.off_bn, t->sums, R, R * c.cout, c.cout,
+                       da, second ? t->dact2 : (float*)nullptr);
+    if (c.mfma) AZCHK(tr_wgrad16(t, t->convs[l - 1].a, da, gw + c.wk_wm));
+    else AZCHK(tr_gemm(t, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, da, c.cout, 0.f, gw + c.wk_wm, c.cout));
     if (l == 0) break;
-    // data gradient: da_prev = im2col(dg) * Wrot
-    if (c.mfma) {
-      AZCHK(tr_conv16(t, t->dact, t->work + c.wk_fdg, t->dcol));     // out of place: dcol's front [R][F] receives da
-      HIPCHK(hipMemcpyAsync(t->dact, t->dcol, sizeof(float) * (size_t)R * c.cin, hipMemcpyDeviceToDevice, st));
-    } else {
-      hipLaunchKernelGGL(k_tr_im2col4, dim3(tr_grid(R * 9 * (c.cout / 4))), dim3(256), 0, st, (const float4*)t->dact, R, c.cout / 4, gi.W, gi.H, (float4*)t->dcol);
-      AZCHK(tr_gemm(t, false, false, (int)R, c.cin, 9 * c.cout, 1.f, t->dcol, 9 * c.cout, t->work + c.wk_wrot, c.cin, 0.f, t->dact, c.cin));
-    }
+    // data gradient da_prev = conv(dg, mirrored taps, ci <-> co): the same MFMA layer kernel with the wk_fdg fragments, out of place
+    AZCHK(tr_conv16(t, da, t->work + c.wk_fdg, da_alt));
+    std::swap(da, da_alt);
     const bool first_of_block = (l % 2) == 1;                      // conv1: its input is the block input, which also gets the skip share
-    if (first_of_block) hipLaunchKernelGGL(k_tr_add, dim3(tr_grid(R * F)), dim3(256), 0, st, t->dact, t->dact2, R * F);
+    if (first_of_block) hipLaunchKernelGGL(k_tr_add, dim3(tr_grid(R * F)), dim3(256), 0, st, da, t->dact2, R * F);
   }
   // working-layout weight gradients -> blob layout (the rotated copies carry no gradient of their own: their slots in
   // gwork stay zero and map to the same blob entries, so scatter only the primary ranges)
