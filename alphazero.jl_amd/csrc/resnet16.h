@@ -422,6 +422,7 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
 
   f32x4v acc[NT];
   float ov[NT][4];                                   // this lane's outputs of the layer just finished (what a partner workgroup needs)
+  float xres[NT][4];                                 // the current block's input at this lane's elements (skip connection): the lane wrote them itself
   // ---- stem: Conv(3x3, C => F) + BN + ReLU, K = 9C padded to a multiple of 4 (every tap: its k order mixes them) ----
   // (a pair of workgroups, X::STEM_HALVES = 2: this wavefront also computes the partner's channel tile -- cheaper than an exchange)
 #pragma unroll
@@ -452,14 +453,15 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float v = az_fmaf(acc[tile][i], sc, sh);
-        buf[(R0 + tile * 16 + g * 4 + i) * STRIDE + oposs] = v > 0.0f ? v : 0.0f;
+        const float r = v > 0.0f ? v : 0.0f;
+        buf[(R0 + tile * 16 + g * 4 + i) * STRIDE + oposs] = r;
+        if (cws == cw) xres[tile][i] = r;            // this lane's own element: the first block's input
       }
   }
   __syncthreads();
   AZ_STAMP16(1);
 
   // ---- residual tower ---------------------------------------------------------------------------------
-  float xres[NT][4];
   const size_t LAYER_W = (size_t)9 * T::CT * T::SQ * 64;          // float4 per layer
   for (int layer = 0; layer < 2 * net.nblocks; ++layer) {
 #pragma unroll
@@ -479,9 +481,9 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v = az_fmaf(acc[tile][i], sc, sh);
-          if (!(layer & 1)) xres[tile][i] = buf[(R0 + tile * 16 + g * 4 + i) * STRIDE + opos];
-          else v = v + xres[tile][i];
+          if (layer & 1) v = v + xres[tile][i];
           ov[tile][i] = v > 0.0f ? v : 0.0f;
+          if (layer & 1) xres[tile][i] = ov[tile][i];                // the next block's input
         }
       xch.template publish<T, NT>(layer, ov, threadIdx.x);
       __builtin_amdgcn_s_setprio(2);
@@ -502,7 +504,6 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int a = (R0 + tile * 16 + g * 4 + i) * STRIDE + opos;
-          xres[tile][i] = buf[a];                    // block input, kept for the skip connection
           const float v = az_fmaf(acc[tile][i], sc, sh);
           buf[a] = v > 0.0f ? v : 0.0f;
         }
@@ -514,7 +515,8 @@ __device__ __forceinline__ void tower16_wave(const Net16Dev& net, float* __restr
           const int a = (R0 + tile * 16 + g * 4 + i) * STRIDE + opos;
           float v = az_fmaf(acc[tile][i], sc, sh);
           v = v + xres[tile][i];
-          buf[a] = v > 0.0f ? v : 0.0f;
+          xres[tile][i] = v > 0.0f ? v : 0.0f;       // block output = the next block's input
+          buf[a] = xres[tile][i];
         }
     }
     __syncthreads();
