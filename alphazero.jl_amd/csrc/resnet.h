@@ -18,7 +18,7 @@
 //            flatten + Dense layers + softmax / tanh + Network.forward_normalized
 //            (src/networks/network.jl:264-271): K = P*nf ascending chain per output, on MFMA (32-board tiles)
 //            or, for head widths that are not multiples of 4, one VALU thread per output.
-//  Debug/ablation switches (timing experiments only): AZ_STAGGER, AZ_ABLATE_B, NetDev::dbg stamps.
+//  Debug aid: NetDev::dbg cycle stamps (az_debug_tower_timeline / az_debug_heads_timeline).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -74,10 +74,6 @@ template <int F> struct TowerLds {
 // statically indexed.
 template <int F>
 __device__ __forceinline__ void load_b_tap(const float4* __restrict__ wt, float4 (&b)[F / 8]) {
-#ifdef AZ_ABLATE_B
-  asm volatile("" : "+v"(b[0].x));   // timing experiment: keep stale fragments, no load
-  return;
-#endif
 #pragma unroll
   for (int jq = 0; jq < F / 8; ++jq) b[jq] = wt[(size_t)jq * 64];
 }
@@ -210,11 +206,6 @@ k_tower(NetDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ e
   int dbgi = 0;
 #define AZ_STAMP() do { if (dbg && tid == 0) dbg[dbgi++] = __builtin_readcyclecounter(); } while (0)
   AZ_STAMP();
-#ifdef AZ_STAGGER
-  // co-resident workgroups start in phase (same code, same duration): offset every second resident set by
-  // about half a layer so one workgroup's epilogue/barrier overlaps the other's MFMA stream
-  if ((blockIdx.x >> 8) & 1) { for (int i = 0; i < AZ_STAGGER; ++i) __builtin_amdgcn_s_sleep(127); }
-#endif
 
   // ---- stage the input planes in the (still unused) T buffer: [128 rows + zero row][C] -------
   float* planes = bufT;

@@ -619,17 +619,13 @@ k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restri
 // the whole activation buffer in LDS but only HALF of the output channels to compute, exchanging halves after every
 // layer (PairXch).  A workgroup's sequential layer chain carries half of the MFMA work of k_tower16<.., NT = 3> (one
 // Connect-Four board: 277 us on one CU, the floor of that variant).  Four wavefronts, one per SIMD, each with all row
-// tiles of one 16-channel tile (TG = 1) -- the arrangement of the 64-filter k_tower16<.., NT = 3>, which keeps its MFMA
-// pipe 95 % busy; TG = 3 (twelve wavefronts with one row tile each) triples the weight stream per MFMA and measured
-// 74 % busy in the convolutions with a 17 k-cycle barrier wait per layer (183 us per launch).
-#ifndef AZ_T16S_TG
-#define AZ_T16S_TG 1
-#endif
+// tiles of one 16-channel tile -- the arrangement of the 64-filter k_tower16<.., NT = 3>, which keeps its MFMA pipe 95 %
+// busy.  (Twelve wavefronts with one row tile each tripled the weight stream per MFMA: 74 % busy in the convolutions,
+// a 17 k-cycle barrier wait per layer, 183 us per launch instead of 167.)
 template <class Gm, int F> struct T16S : T16<Gm, F, NTS<Gm>> {
-  static constexpr int SPLIT = 2, TG = AZ_T16S_TG, TPW = NTS<Gm> / TG, CWL = F / 16 / SPLIT;
-  static constexpr int WAVES = TG * CWL, THREADS = 64 * WAVES;
+  static constexpr int SPLIT = 2, TPW = NTS<Gm>, CWL = F / 16 / SPLIT;      // row tiles per wavefront, channel tiles per workgroup
+  static constexpr int WAVES = CWL, THREADS = 64 * WAVES;
   static constexpr int XCH_WORDS = 2 * TPW * 4 * THREADS;        // publish area of one workgroup (64-bit words)
-  static_assert(NTS<Gm> % TG == 0 && (TG == 1 || TG == 3), "row tiles in one or three groups");
 };
 template <class Gm, int F, bool FROM_PLANES>
 __global__ void __launch_bounds__((T16S<Gm, F>::THREADS), 1)
@@ -649,20 +645,14 @@ k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restric
   tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[1], leaf_env, eval_slots, X, n, board0, threadIdx.x);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tg = wave / T::CWL, cwl = wave % T::CWL;
+  const int cwl = wave;
   PairXch x;
   x.mine = xch + (size_t)blockIdx.x * T::XCH_WORDS;
   x.theirs = xch + (size_t)(blockIdx.x ^ 1) * T::XCH_WORDS;
   x.tag0 = (uint32_t)(epoch << 8);                   // + layer index < 256 (pick_tower)
   x.err = err;
   x.pch = ((half ^ 1) * T::CWL + cwl) * 16 + (lane & 15);
-  const int cw = half * T::CWL + cwl;
-  if constexpr (T::TG == 1) tower16_wave<T, FROM_PLANES, T::TPW, 0, PairXch>(net, buf, planes, nbr, pos, cw, lane, n, board0, hfeat, x);
-  else {
-    if (tg == 0) tower16_wave<T, FROM_PLANES, T::TPW, 0, PairXch>(net, buf, planes, nbr, pos, cw, lane, n, board0, hfeat, x);
-    else if (tg == 1) tower16_wave<T, FROM_PLANES, T::TPW, T::TPW, PairXch>(net, buf, planes, nbr, pos, cw, lane, n, board0, hfeat, x);
-    else tower16_wave<T, FROM_PLANES, T::TPW, 2 * T::TPW, PairXch>(net, buf, planes, nbr, pos, cw, lane, n, board0, hfeat, x);
-  }
+  tower16_wave<T, FROM_PLANES, T::TPW, 0, PairXch>(net, buf, planes, nbr, pos, half * T::CWL + cwl, lane, n, board0, hfeat, x);
 }
 
 // One 3x3 F -> F convolution as a stand-alone layer (HBM -> HBM), for the optimiser step (train.hip): forward
