@@ -18,7 +18,8 @@ def _hp(nblocks, F=64):
 @pytest.mark.parametrize("game,spec,ngames,workers,batch,nsims,F,tower", [
     (R.C4, "ConnectFourSpec", 12, 6, 6, 40, 64, "16"), (R.TTT, "TicTacToeSpec", 10, 4, 4, 24, 64, ""),
     (R.MANCALA, "MancalaSpec", 6, 3, 3, 24, 64, "32"), (R.C4, "ConnectFourSpec", 12, 6, 3, 40, 64, ""),
-    (R.C4, "ConnectFourSpec", 6, 4, 2, 24, 128, "16"), (R.C4, "ConnectFourSpec", 6, 4, 2, 24, 128, "")])
+    (R.C4, "ConnectFourSpec", 6, 4, 2, 24, 128, "16"), (R.C4, "ConnectFourSpec", 6, 4, 2, 24, 128, ""),
+    (R.C4, "ConnectFourSpec", 24, 24, 24, 12, 128, "")])     # 24 workers in one group: k_tower16s pairs + split k_heads16 tiles in the wave path
 def test_simulate_with_resnet_matches_oracle(game, spec, ngames, workers, batch, nsims, F, tower, monkeypatch):
     """Simulator / simulate (simulations.jl:179-244) with MctsPlayer + ResNet, vs the oracle's simulate.
     tower: AZHIP_TOWER override ("" = the engine's own choice, which is the 3-row-tile k_tower16 at these sizes)."""
