@@ -9,8 +9,11 @@
  * its own tests hold no numeric result for this path.  The
  * restatement is pinned only against (i) SURVEY.md Appendix D's RNG-free vectors,
  * (ii) the PLSchedule known-answer in src/schedule.jl:82-87, (iii) the 6000 legal
- * Connect-Four positions in games/connect-four/benchmark/Test_L*_R* (rules), and
- * (iv) an independent NumPy/PyTorch restatement (oracle/pyref.py).
+ * Connect-Four positions in games/connect-four/benchmark/Test_L*_R* AND the exact
+ * solver scores recorded beside them (azr_c4_solve: a negamax over this file's rules
+ * reproduces all 1000 end-game scores of Test_L3_R1), and (iv) an independent
+ * NumPy/PyTorch restatement (oracle/pyref.py).  The MCTS and network numerics remain
+ * unpinned to the reference itself.
  *
  * Every function cites the reference lines it restates (paths relative to
  * /root/reference).  Arithmetic follows the reference's types: priors Float32,
@@ -305,6 +308,55 @@ static void m_vectorize(const azr_state* st, float* out) {
 
 /* ========================= GameInterface dispatch ======================= */
 /* src/game.jl:34-336 -- the subset the path uses (SURVEY.md §8b seam 4). */
+/* Test infrastructure only: exact value of a Connect-Four position, in the convention of the second column of the
+ * reference's games/connect-four/benchmark/Test_L*_R* files (scripts/pons_benchmark.jl:49-98 replays them; the scores are
+ * John Tromp / Pascal Pons solver results): 0 = draw, +k = the player to move wins with his k-th stone counted from
+ * his last one (22 - stones he has played when he connects four), -k = the opponent does.  Plain negamax with
+ * alpha-beta over THIS file's rules -- c4_play, its win test, its actions mask, its termination -- so that agreeing with
+ * the recorded scores pins those rules (legal moves, four-in-a-row in all directions, draw on a full board) to data the
+ * reference ships.  `moves`: 0-based columns from the empty board.  Returns the score, or 99 if the position is illegal /
+ * already finished, or 98 if more than node_limit nodes were visited. */
+static int c4_negamax(const azr_env* g, int nstones, int alpha, int beta, long long* nodes, long long limit) {
+  if (++*nodes > limit) return 98;
+  static const int order[C4_COLS] = {3, 2, 4, 1, 5, 0, 6};
+  for (int k = 0; k < C4_COLS; ++k) {                 /* a winning move now: the mover connects with stone nstones/2 + 1 */
+    int col = order[k];
+    if (!g->amask[col]) continue;
+    azr_env c = *g;
+    c4_play(&c, col);
+    if (c.finished && c.winner != 0) return (C4_COLS * C4_ROWS + 1 - nstones) / 2;
+  }
+  if (nstones + 1 == C4_COLS * C4_ROWS) return 0;     /* the last cell, no win: draw */
+  int max = (C4_COLS * C4_ROWS - 1 - nstones) / 2;    /* cannot win before the move after next */
+  if (beta > max) { beta = max; if (alpha >= beta) return beta; }
+  for (int k = 0; k < C4_COLS; ++k) {
+    int col = order[k];
+    if (!g->amask[col]) continue;
+    azr_env c = *g;
+    c4_play(&c, col);
+    if (c.finished) { if (0 > alpha) alpha = 0; if (alpha >= beta) return alpha; continue; }   /* full board (a win was caught above) */
+    int sc = c4_negamax(&c, nstones + 1, -beta, -alpha, nodes, limit);
+    if (sc == 98) return 98;
+    sc = -sc;
+    if (sc >= beta) return sc;
+    if (sc > alpha) alpha = sc;
+  }
+  return alpha;
+}
+int azr_c4_solve(const int* moves, int nmoves, long long node_limit, long long* nodes_out) {
+  azr_env g;
+  c4_init(&g);
+  for (int i = 0; i < nmoves; ++i) {
+    if (g.finished || moves[i] < 0 || moves[i] >= C4_COLS || !g.amask[moves[i]]) return 99;
+    c4_play(&g, moves[i]);
+  }
+  if (g.finished) return 99;
+  long long nodes = 0;
+  int sc = c4_negamax(&g, nmoves, -(C4_COLS * C4_ROWS) / 2, (C4_COLS * C4_ROWS) / 2, &nodes, node_limit);
+  if (nodes_out) *nodes_out = nodes;
+  return sc;
+}
+
 void azr_init(azr_env* g, int game) {
   if (game == AZR_C4) c4_init(g); else if (game == AZR_TTT) ttt_init(g); else m_init(g);
 }

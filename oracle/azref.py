@@ -86,6 +86,8 @@ def lib():
         L.azr_simulate.restype = C.c_int64
         L.azr_simulate.argtypes = [C.POINTER(SimParams), C.c_void_p, C.c_void_p, C.c_int64]
         L.azr_expf.restype = C.c_float
+        L.azr_c4_solve.restype = C.c_int
+        L.azr_c4_solve.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]
         L.azr_expf.argtypes = [C.c_float]
         L.azr_tanhf.restype = C.c_float
         L.azr_tanhf.argtypes = [C.c_float]
@@ -379,3 +381,13 @@ def learning_status(game, hp, blob, data, l2=1e-4, nonvalidity_penalty=1.0, rewa
                               C.c_int64(len(W)), C.c_double(l2), C.c_double(nonvalidity_penalty), C.c_double(rewards_renormalization),
                               C.c_int64(batch), C.byref(out))
     return out
+
+
+def c4_solve(moves, node_limit=20_000_000):
+    """exact Connect-Four value (Pons' score convention) of the position after `moves` (0-based columns), by negamax over
+    the oracle's own rules; returns (score, nodes).  98 = node limit, 99 = illegal / finished position.  Test infrastructure."""
+    import numpy as _np
+    m = _np.asarray(moves, dtype=_np.int32)
+    nodes = C.c_longlong(0)
+    sc = lib().azr_c4_solve(m.ctypes.data_as(C.c_void_p), len(m), int(node_limit), C.byref(nodes))
+    return sc, nodes.value

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Regenerates the fixtures of tests/golden/ (run in the BUILD container, where /root/reference exists).
 
+  c4_scores.txt      move strings AND recorded solver scores of Test_L3_R1 (1000) and Test_L2_R1 (first 300)
   c4_positions.txt   the move strings of games/connect-four/benchmark/Test_L*_R* (first column; 6 x 1000
                      positions the reference's own Pons benchmark replays, scripts/pons_benchmark.jl:49-98)
   appendix_d.json    hand-transcribed from SURVEY.md Appendix D, src/schedule.jl:82-87 and Random123's KAT
@@ -26,6 +27,14 @@ def positions():
         for p in files:
             for line in open(p):
                 f.write(line.split()[0] + "\n")
+    # positions WITH the solver scores the reference ships beside them (second column): the 1000 end-game positions of
+    # Test_L3_R1 and the first 300 middle-game positions of Test_L2_R1 -- what tests/test_oracle_golden.py solves exactly
+    with open(os.path.join(HERE, "c4_scores.txt"), "w") as f:
+        for name, count in (("Test_L3_R1", 1000), ("Test_L2_R1", 300)):
+            for i, line in enumerate(open("/root/reference/games/connect-four/benchmark/" + name)):
+                if i < count:
+                    mv, sc = line.split()
+                    f.write("%s %s %d\n" % (name, mv, int(sc)))
 
 
 def net_golden():

@@ -160,6 +160,26 @@ def test_connect_four_symmetry_and_known_positions():
         assert np.array_equal(gm.vectorize().reshape(3, 6, 7), g.vectorize().reshape(3, 6, 7)[:, :, ::-1])
 
 
+def test_connect_four_rules_reproduce_the_reference_solver_scores():
+    """A pin to data the reference ships: games/connect-four/benchmark/Test_L*_R* hold positions WITH their exact
+    game-theoretic scores (Pons' convention; scripts/pons_benchmark.jl:49-98 measures the network against them).  A plain
+    negamax over the oracle's own Connect-Four rules -- legal moves, the four-in-a-row test of `play!`, termination on a
+    full board (games/connect-four/game.jl:50-146) -- reproduces every recorded score of the 1000 end-game positions
+    (Test_L3_R1) and of the middle-game positions (Test_L2_R1) it can solve within the node budget.  The device twin of
+    the game is tied to these rules move by move (tests/test_game_gpu.py)."""
+    lines = [l.split() for l in open(os.path.join(GOLD, "c4_scores.txt"))]
+    assert len(lines) == 1300
+    solved = {"Test_L3_R1": 0, "Test_L2_R1": 0}
+    for name, mv, sc in lines:
+        got, nodes = R.c4_solve([int(c) - 1 for c in mv], 10_000_000 if name == "Test_L3_R1" else 200_000)
+        if got == 98:
+            continue                                               # over the node budget (middle game only)
+        assert got == int(sc), (name, mv, sc, got)
+        solved[name] += 1
+    assert solved["Test_L3_R1"] == 1000 and solved["Test_L2_R1"] >= 200
+    assert R.c4_solve([3, 3, 3, 3, 3, 3, 3])[0] == 99             # a full column: illegal move string
+
+
 def test_mancala_flip_colors_bug_is_reproduced():
     """games/mancala/game.jl:224-229: with black to move the planes show the INITIAL board."""
     g = R.Game(R.MANCALA)
