@@ -20,7 +20,7 @@ int fail(int code, const char* fmt, ...) {
 extern "C" const char* az_last_error(void) { return g_err.c_str(); }
 extern "C" int az_abi_version(void) { return AZ_ABI_VERSION; }
 
-static int check_device_error(az_engine* e) {
+int check_device_error(az_engine* e) {
   int code = 0;
   AZCHK(sync_groups(e));
   HIPCHK(hipMemcpyAsync(&code, e->v.err, sizeof(int), hipMemcpyDeviceToHost, e->stream));

@@ -190,6 +190,9 @@ inline int prof_end(az_engine* e, hipStream_t st, int cls) {
   if (!(e)) return fail(AZ_ERR_BAD_ARG, "engine is NULL");      \
   HIPCHK(hipSetDevice((e)->device))
 
+// azhip.hip: waits for the engine's streams and turns a device-side error code (tree.h DERR_*, resnet16.h DERR_EXCHANGE) into a status
+int check_device_error(az_engine* e);
+
 // ---- net.hip: every instantiation of the tower / heads kernels lives there ----------------------------------
 int net_set_kernel_attrs(az_engine* e);   // + uploads the row permutation tables of the tower kernels (e->d_geo)
 // tower + heads on n_max boards (device count in n_ptr when given): from_planes ? X / Amask : envs[eslots[i]]

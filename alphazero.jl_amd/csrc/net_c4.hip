@@ -91,6 +91,22 @@ template <int F> static int heads_timeline(az_engine* e, int32_t n, unsigned lon
   (void)hipFree(d);
   return AZ_OK;
 }
+// debug aid: one k_tower16s launch in which workgroup 1 leaves at once, so that workgroup 0 never gets its partner's half:
+// the bounded poll must give up (DERR_EXCHANGE -> AZ_ERR_HIP from this call) instead of hanging the GPU
+extern "C" int az_debug_exchange_timeout(az_engine* e) {
+  ENGINE(e);
+  if (!e->net_loaded || e->cfg.game != AZ_GAME_CONNECT_FOUR || e->cfg.num_filters != 128 || e->cfg.net_bf16) return fail(AZ_ERR_BAD_ARG, "connect-four, 128 filters, fp32");
+  using T = T16S<ConnectFour, 128>;
+  const int n = 2;
+  std::vector<GEnv> envs(n, ConnectFour::init());
+  HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_ntmp, &n, sizeof(int), hipMemcpyHostToDevice, e->stream));
+  unsigned long long* xa; unsigned long long ep;
+  AZCHK(xch_slot<ConnectFour>(e, e->d_hfeat, &xa, &ep));
+  hipLaunchKernelGGL((k_tower16s<ConnectFour, 128, false>), dim3(2 * n), dim3(T::THREADS), T::BYTES, e->stream, e->net16, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat,
+                     xa, ep | (1ull << 63), e->v.err);
+  return check_device_error(e);
+}
 extern "C" int az_debug_heads_timeline(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
   ENGINE(e);
   if (!e->net_loaded || n < 1 || n > e->nn_cap || e->cfg.game != AZ_GAME_CONNECT_FOUR || !e->net.hd16_ok) return fail(AZ_ERR_BAD_ARG, "connect-four with 32 head filters");

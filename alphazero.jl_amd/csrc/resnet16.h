@@ -642,6 +642,7 @@ k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restric
   const int pair = blockIdx.x >> 1, half = blockIdx.x & 1;
   const int board0 = pair * T::TB;
   if (board0 >= n) return;                           // both workgroups of the pair
+  if ((epoch >> 63) && blockIdx.x == 1) return;      // fault injection (az_debug_exchange_timeout): workgroup 0 loses its partner
   tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[1], leaf_env, eval_slots, X, n, board0, threadIdx.x);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -256,3 +256,30 @@ def test_split_tower_epoch_wrap(monkeypatch):
             P, V, _ = e.net_forward(X[:n], A[:n])
             assert e.net_last_kernel().startswith("k_tower16s<")
             assert np.array_equal(P, Pr[:n]) and np.array_equal(V, Vr[:n]), k
+
+
+@pytest.mark.gpu
+def test_split_tower_gives_up_instead_of_hanging():
+    """The workgroups of k_tower16s wait for each other's halves with a BOUNDED poll.  az_debug_exchange_timeout launches
+    it with one workgroup missing: the call must come back with an error (about a second), not hang the GPU, and the
+    engine must work afterwards."""
+    import ctypes as C
+    import time
+    import azhip
+    from azhip._lib import lib
+    hp = ResNetHP(num_blocks=1, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32)
+    blob = random_params(R.C4, hp, seed=47)
+    X, A = batch_of(R.C4, random_positions(R.C4, 20, 13))
+    with azhip.Engine(game=R.C4, oracle=azhip.ORACLE_RESNET, num_workers=8, batch_size=8, num_iters_per_turn=8,
+                      num_blocks=1, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32) as e:
+        e.net_set_params(blob)
+        f = lib().az_debug_exchange_timeout
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p]
+        t0 = time.perf_counter()
+        st = f(e._h)
+        dt = time.perf_counter() - t0
+        assert st != 0 and b"partner" in lib().az_last_error() and dt < 30.0, (st, dt)
+        P, V, _ = e.net_forward(X, A)                               # the next launches are unaffected
+    Pr, Vr, _ = R.net_forward_normalized(R.C4, (1, 128, 32, 32), blob, X, A)
+    assert np.array_equal(P, Pr) and np.array_equal(V, Vr)
