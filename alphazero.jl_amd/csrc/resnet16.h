@@ -663,9 +663,13 @@ k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restric
 // (tile, tap) products that fall off the board are skipped as in the tower (85 of 99); the 11 accumulator tiles of each
 // wavefront come back out in natural order.  No bias, no activation: batch norm follows with batch statistics (the
 // bias cancels there).
-template <class Gm, int F>
+// STATS (the forward pass): the workgroup also leaves the column sums (sum v, sum v^2) of its rows of the output in
+// part[blockIdx.x][2][F] (double), the first stage of the batch-norm statistics -- the accumulators are at hand, a
+// separate pass over the output (k_tr_colsum<0>) is not needed.
+template <class Gm, int F, bool STATS>
 __global__ void __launch_bounds__(T16Threads<F>::V, 2)
-k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, float* __restrict__ out, int nboards, const uint16_t* __restrict__ geo) {
+k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, float* __restrict__ out, int nboards, const uint16_t* __restrict__ geo,
+               double* __restrict__ part) {
   using T = T16<Gm, F, 11>;
   using G = typename T::Geo;
   constexpr int P = Gm::P, STRIDE = T::STRIDE, NT = 11;
@@ -696,13 +700,23 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
   conv16p<T, G, NT, 0, 9>(buf, nbr, wfrag + (size_t)wave * T::SQ * 64 + lane, acc, lrow, g);
   const int ch = wave * 16 + lrow;
   float* o = out + (size_t)board0 * P * F;
+  double s0 = 0.0, s1 = 0.0;
 #pragma unroll
   for (int tile = 0; tile < NT; ++tile)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ps = pos[tile * 16 + g * 4 + i];
-      if (ps < nvalid) o[(size_t)ps * F + ch] = acc[tile][i];
+      if (ps < nvalid) {
+        o[(size_t)ps * F + ch] = acc[tile][i];
+        if constexpr (STATS) { const double v = (double)acc[tile][i]; s0 += v; s1 += v * v; }
+      }
     }
+  if constexpr (STATS) {
+    // the four row groups of a channel: (g0 + g1) + (g2 + g3), a fixed order
+    s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16);
+    s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
+    if (g == 0) { part[((size_t)blockIdx.x * 2) * F + ch] = s0; part[((size_t)blockIdx.x * 2 + 1) * F + ch] = s1; }
+  }
 }
 
 // Weight gradient of a 3x3 F -> F convolution for the optimiser step (train.h):

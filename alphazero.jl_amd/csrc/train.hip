@@ -429,7 +429,8 @@ static int trainer_build(az_trainer* t) {
   AZCHK(tr_alloc(t, &t->tpre, B)); AZCHK(tr_alloc(t, &t->dt, B));
   AZCHK(tr_alloc(t, &t->dact, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dact2, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dcol, (size_t)R * F));
   const int nchunks = (int)((R + TR_CHUNK - 1) / TR_CHUNK);
-  AZCHK(tr_alloc(t, &t->part, (size_t)nchunks * 2 * std::max(F, 64))); AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64)));
+  AZCHK(tr_alloc(t, &t->part, (size_t)std::max(nchunks, B + 1) * 2 * std::max(F, 64)));   // chunks of k_tr_colsum or workgroups of k_conv16_layer
+  AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64)));
   AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 8 + 1024));
   // k_wgrad16: one round of workgroups over the chip
   t->wg_part = nullptr; t->wg_splits = 0; t->wg_bpw = 0;
@@ -445,16 +446,22 @@ static int trainer_build(az_trainer* t) {
   return AZ_OK;
 }
 
-template <class Gm, int F> static int tr_conv16_f(az_trainer* t, const float* in, const float* frag, float* out) {
+template <class Gm, int F, bool STATS> static int tr_conv16_f(az_trainer* t, const float* in, const float* frag, float* out) {
   using T = T16<Gm, F, 11>;
   static bool attr_done = false;
-  if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_layer<Gm, F>), hipFuncAttributeMaxDynamicSharedMemorySize, T::BYTES)); attr_done = true; }
-  hipLaunchKernelGGL((k_conv16_layer<Gm, F>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[0]);
+  if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_layer<Gm, F, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, T::BYTES)); attr_done = true; }
+  hipLaunchKernelGGL((k_conv16_layer<Gm, F, STATS>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[0], t->part);
   return AZ_OK;
 }
-// 3x3 F -> F convolution of [R][F] activations on the MFMA layer kernel
-static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* out) {
-  DISPATCH_GAME(t->game, { if (t->F == 128) AZCHK((tr_conv16_f<Gm, 128>(t, in, frag, out))); else AZCHK((tr_conv16_f<Gm, 64>(t, in, frag, out))); });
+// 3x3 F -> F convolution of [R][F] activations on the MFMA layer kernel; stats: also the first stage of the column sums
+// (sum, sum of squares) of the output in t->part, *nparts workgroup partials
+static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* out, bool stats = false, int* nparts = nullptr) {
+  DISPATCH_GAME(t->game, {
+    using T = T16<Gm, 64, 11>;
+    if (nparts) *nparts = (t->B + T::TB - 1) / T::TB;
+    if (t->F == 128) { if (stats) AZCHK((tr_conv16_f<Gm, 128, true>(t, in, frag, out))); else AZCHK((tr_conv16_f<Gm, 128, false>(t, in, frag, out))); }
+    else { if (stats) AZCHK((tr_conv16_f<Gm, 64, true>(t, in, frag, out))); else AZCHK((tr_conv16_f<Gm, 64, false>(t, in, frag, out))); }
+  });
   return AZ_OK;
 }
 
@@ -504,14 +511,16 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
   for (int l = 0; l < ntower; ++l) {
     TrConv& c = t->convs[l];
     const float* in = l == 0 ? t->bX : t->convs[l - 1].a;
-    if (c.mfma) AZCHK(tr_conv16(t, in, t->work + c.wk_ffwd, c.g));
+    int nparts = 0;                                                 // > 0: the convolution kernel left the first stage of the statistics in t->part
+    if (c.mfma) AZCHK(tr_conv16(t, in, t->work + c.wk_ffwd, c.g, true, &nparts));
     else {                                                          // the stem: K = 9 C, im2col + GEMM
       hipLaunchKernelGGL((k_tr_im2col<true>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
       AZCHK(tr_gemm(t, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
     }
     { TrFinal fin{}; fin.mode = 1; fin.R = R; fin.momentum = t->cfg.batch_norm_momentum; fin.bias = blob + c.off_b; fin.mean = c.mean; fin.invstd = c.invstd;
       fin.run_mean = blob + c.off_bn + 2 * c.cout; fin.run_var = blob + c.off_bn + 3 * c.cout;
-      AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout, fin)); }
+      if (nparts > 0) hipLaunchKernelGGL(k_tr_colsum_final, dim3(c.cout), dim3(64), 0, st, t->part, nparts, c.cout, t->sums, fin);
+      else AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout, fin)); }
     const bool second = l > 0 && (l % 2) == 0;                     // conv2 of a block: skip connection from the block input
     const float* res = second ? t->convs[l - 2].a : nullptr;
     hipLaunchKernelGGL(k_tr_bn_apply, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, c.g, c.mean, c.invstd, blob + c.off_bn, blob + c.off_bn + c.cout, res, R * c.cout, c.cout, c.a);
