@@ -107,6 +107,22 @@ extern "C" int az_debug_exchange_timeout(az_engine* e) {
                      xa, ep | (1ull << 63), e->v.err);
   return check_device_error(e);
 }
+// debug aid: out == NULL -> from now on the first wavefront of every k_tree launch of group 0 leaves 8 cycle stamps
+// (DView::dbg); out != NULL -> copy the stamps of the most recent launch
+extern "C" int az_debug_tree_stamps(az_engine* e, unsigned long long* out) {
+  ENGINE(e);
+  if (!out) {
+    unsigned long long* d = nullptr;
+    AZCHK(dalloc(e, &d, 8));
+    AZCHK(sync_all(e));
+    e->v.dbg = d; e->gv[0].dbg = d;
+    return AZ_OK;
+  }
+  if (!e->gv[0].dbg) return fail(AZ_ERR_STATE, "stamps are not enabled");
+  AZCHK(sync_all(e));
+  HIPCHK(hipMemcpy(out, e->gv[0].dbg, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return AZ_OK;
+}
 extern "C" int az_debug_heads_timeline(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
   ENGINE(e);
   if (!e->net_loaded || n < 1 || n > e->nn_cap || e->cfg.game != AZ_GAME_CONNECT_FOUR || !e->net.hd16_ok) return fail(AZ_ERR_BAD_ARG, "connect-four with 32 head filters");

@@ -73,6 +73,8 @@ struct DView {
   int* finished;          // [G] set by k_move when the slot's game ended this round
   int* err;               // device error word (first error wins)
   long long* stat;        // [0] simulations [1] nodes traversed [2] leaf evals [3] moves
+  unsigned long long* dbg; // optional [8] cycle stamps of k_tree's first wavefront (az_debug_tree_stamps): start, phase A done,
+                          // root loaded, descent done, leaf stored, block atomics done, end
 };
 
 // Node record: N i32[A] | P f32[A] | W f64[A] | LO u16[A] | HI, padded to a multiple of 32 B.  With A = 7 that is
@@ -99,22 +101,45 @@ template <int L> __device__ inline unsigned group_ballot(bool pred) {
   int base = (threadIdx.x & 63) & ~(L - 1);
   return (unsigned)((b >> base) & ((1u << L) - 1));
 }
-template <int L> __device__ inline int group_sum(int x) {
-#pragma unroll
-  for (int o = 1; o < L; o <<= 1) x += __shfl_xor(x, o, L);
+// Reductions inside a slot's lane group (L = 8 or 16 lanes, aligned, inside one 16-lane DPP row) by DPP butterflies:
+// partner of step 0 = lane ^ 1 (quad_perm [1,0,3,2]), step 1 = lane ^ 2 ([2,3,0,1]), step 2 = 7 - lane within each half
+// row (row_half_mirror), step 3 (L = 16) = 15 - lane (row_mirror).  Every step pairs lanes that hold different partial
+// results, so after log2 L steps every lane holds the group's result.  (__shfl_xor compiles to ds_bpermute_b32: an LDS
+// round trip of ~120 cycles per step in the middle of the descent's dependent chain -- ten of them per ply.)
+template <int STEP> __device__ __forceinline__ int dpp_partner(int x) {
+  constexpr int ctrl = STEP == 0 ? 0xB1 : STEP == 1 ? 0x4E : STEP == 2 ? 0x141 : 0x140;
+  return __builtin_amdgcn_update_dpp(x, x, ctrl, 0xF, 0xF, false);
+}
+template <int STEP> __device__ __forceinline__ double dpp_partner(double x) {
+  const int lo = dpp_partner<STEP>(__double2loint(x)), hi = dpp_partner<STEP>(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+template <int L> __device__ __forceinline__ int group_sum(int x) {
+  static_assert(L == 8 || L == 16, "lane groups of 8 or 16");
+  x += dpp_partner<0>(x);
+  x += dpp_partner<1>(x);
+  x += dpp_partner<2>(x);
+  if constexpr (L == 16) x += dpp_partner<3>(x);
   return x;
 }
-// first maximum: highest score, ties to the lowest lane (argmax, src/mcts.jl:211)
-template <int L> __device__ inline int group_argmax(double s, int lane) {
+// first maximum: highest score, ties to the lowest lane (argmax, src/mcts.jl:211); `carry` travels with the winner
+// (every lane ends with the winner's index and carry: the order (score desc, lane asc) is total, so both lanes of a pair
+// pick the same one)
+template <int STEP> __device__ __forceinline__ void argmax_step(double& s, int& idx, int& carry) {
+  const double so = dpp_partner<STEP>(s);
+  const int io = dpp_partner<STEP>(idx), co = dpp_partner<STEP>(carry);
+  if (so > s || (so == s && io < idx)) { s = so; idx = io; carry = co; }
+}
+template <int L> __device__ __forceinline__ int group_argmax(double s, int lane, int* carry) {
+  static_assert(L == 8 || L == 16, "lane groups of 8 or 16");
   int idx = lane;
-#pragma unroll
-  for (int o = 1; o < L; o <<= 1) {
-    double so = __shfl_xor(s, o, L);
-    int io = __shfl_xor(idx, o, L);
-    if (so > s || (so == s && io < idx)) { s = so; idx = io; }
-  }
+  argmax_step<0>(s, idx, *carry);
+  argmax_step<1>(s, idx, *carry);
+  argmax_step<2>(s, idx, *carry);
+  if constexpr (L == 16) argmax_step<3>(s, idx, *carry);
   return idx;
 }
+template <int L> __device__ __forceinline__ int group_argmax(double s, int lane) { int c = 0; return group_argmax<L>(s, lane, &c); }
 
 // ---- Dict lookup: haskey(env.tree, state) (src/mcts.jl:165-174) ---------------------------
 // Returns the node index or -1; *ins receives the table position a new entry would take.
@@ -202,6 +227,8 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
   char* pool = v.nodes + (size_t)(live ? slot : 0) * v.cap_nodes * NL::BYTES;
   unsigned long long* path = v.path + (size_t)(live ? slot : 0) * v.max_depth;
   const bool links_ok = v.cap_nodes <= LINK_MAX;
+  unsigned long long* dbg = (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) ? v.dbg : nullptr;
+  if (dbg) dbg[0] = __builtin_readcyclecounter();
 
   // ------------------------------------------------------------------ phase A: expand + backup
   if (do_backup && live) {
@@ -290,6 +317,7 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
     if (!do_select && lane == 0) v.leaf_kind[slot] = LEAF_NONE;     // the pending simulation has been completed
   }
   if (!do_select) return;
+  if (dbg) dbg[1] = __builtin_readcyclecounter();
   __threadfence_block();            // phase A's stores (other lanes of the group) are ordered before phase B's loads
 
   // ------------------------------------------------------------------ phase B: select
@@ -321,6 +349,7 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
       const uint32_t lo = inrec ? ((const uint16_t*)(nd + NL::OFF_LO))[lane] : 0;
       const uint32_t hi = *(const typename NL::hi_t*)(nd + NL::OFF_HI);
       const int link = (int)(lo | (((hi >> (2 * lane)) & 3u) << 16));
+      if (dbg && depth == 0) dbg[2] = __builtin_readcyclecounter() + (unsigned long long)(N & 0);   // after the root record has arrived
       // uct_scores (mcts.jl:180-188): Float64, evaluated left to right
       const int Ntot = group_sum<L>(N);
       const double sqrtNtot = __builtin_sqrt((double)Ntot);
@@ -329,8 +358,8 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
       if (depth == 0 && p.eps != 0.0) Pd = (1.0 - p.eps) * Pd + p.eps * v.eta[(size_t)slot * L + lane];
       double sc = Q + p.cpuct * Pd * sqrtNtot / (double)(N + 1);
       if (!((amask >> lane) & 1)) sc = -__builtin_inf();
-      const int act = group_argmax<L>(sc, lane);
-      const int nxt = __shfl(link, gbase + act);
+      int nxt = link;                                               // the winner's child link travels with the argmax
+      const int act = group_argmax<L>(sc, lane, &nxt);
       const bool wp = Gm::white_playing(env);
       Gm::play(env, act);                                           // mcts.jl:213-217
       const float wr = Gm::white_reward(env);
@@ -344,6 +373,7 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
       probe = nxt == 0;
       idx = nxt - 1;
     }
+    if (dbg) dbg[3] = __builtin_readcyclecounter();
     if (lane == 0) {
       v.leaf_depth[slot] = depth;
       v.leaf_env[slot] = env;
@@ -351,6 +381,7 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
     }
   }
   if (live && lane == 0) v.leaf_kind[slot] = kind;
+  if (dbg) dbg[4] = __builtin_readcyclecounter();
 
   // ------------------------------------------------------------------ evaluation batch + statistics of the wave
   const bool head = live && lane == 0;
@@ -374,6 +405,7 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
     if (blockIdx.x == 0) v.n_eval[par ^ 1] = 0;                     // the next wave's counter
   }
   __syncthreads();
+  if (dbg) dbg[5] = __builtin_readcyclecounter();
   if (isnew) {
     int base = s_base;
     for (int i = 0; i < w; ++i) base += s_new[i];
@@ -381,6 +413,7 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
     v.eidx[slot] = e;
     v.eval_slots[e] = slot;
   }
+  if (dbg) dbg[6] = __builtin_readcyclecounter();
 }
 
 // rollout! (src/mcts.jl:41-50) from a leaf, value from the leaf's player (mcts.jl:52-60): uniform random
