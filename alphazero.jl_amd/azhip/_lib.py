@@ -96,7 +96,9 @@ PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p)
 # every symbol include/azhip.h declares: name -> argtypes (restype is int unless noted)
 _VP, _I32, _I64, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
 class GatherStats(C.Structure):
-    _fields_ = [("games", C.c_int64), ("moves", C.c_int64), ("bytes", C.c_int64), ("gather_ms", C.c_double), ("total_ms", C.c_double)]
+    _fields_ = [("games", C.c_int64), ("moves", C.c_int64), ("bytes", C.c_int64), ("gather_ms", C.c_double), ("total_ms", C.c_double),
+                ("ranks", C.c_int64), ("total_simulations", C.c_int64), ("total_nodes_traversed", C.c_int64), ("max_nodes", C.c_int64),
+                ("mean_game_depth", C.c_double)]
 
 
 AZ_ERR_COMM = -5
@@ -158,6 +160,8 @@ SYMBOLS = {
     "az_comm_unique_id": [_VP],
     "az_comm_init": [_I32, _I32, _I32, _VP, C.POINTER(_VP)],
     "az_comm_destroy": [_VP],
+    "az_engine_device_bytes": [_VP, C.POINTER(C.c_int64)],
+    "az_engine_release_phase": [_VP],
     "az_comm_gather_push": [_VP, _VP, _VP, C.c_double, C.POINTER(GatherStats)],
     "az_comm_broadcast_params": [_VP, _VP, _I32],
 }

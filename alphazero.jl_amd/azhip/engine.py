@@ -1,5 +1,6 @@
 """Engine: one MI355X self-play engine (a thin object wrapper over the C ABI, numpy in / numpy out)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -233,6 +234,16 @@ class Engine:
         check(lib().az_selfplay_active(self._h, C.byref(n)))
         return n.value
 
+    def device_bytes(self):
+        """device memory this engine holds (az_engine_device_bytes)"""
+        n = C.c_int64()
+        check(lib().az_engine_device_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def release_phase(self):
+        """drop the device-resident records of the last phase once they have been pushed / gathered"""
+        check(lib().az_engine_release_phase(self._h))
+
     def selfplay_end(self):
         check(lib().az_selfplay_end(self._h))
 
@@ -252,22 +263,35 @@ class Engine:
 # ---- engine cache --------------------------------------------------------------------------------------------------
 # An engine owns its slots' node pools (10 GB at 4096 Connect-Four slots x 400 simulations): building one per
 # self_play_step / pit_networks / Trainer call pays hipMalloc + table clears every time and can hold several at once.
-# Engines are therefore kept by configuration (the az_engine_cfg bytes + a role, so that the two players of an arena
-# get two engines) and only their parameters are replaced between phases (az_net_set_params = Network.copy per phase,
-# training.jl:278-279).  At most CACHE_MAX stay alive, least recently used first out.
+# Engines are therefore kept by configuration and only their parameters are replaced between phases (az_net_set_params =
+# Network.copy per phase, training.jl:278-279).  The key is everything az_engine_create looks at: a role (the two players
+# of an arena get two engines), the az_engine_cfg bytes AND the environment overrides the library reads at creation
+# (AZHIP_TOWER / AZHIP_HEADS / AZHIP_GRAPH / AZHIP_XCH_EPOCH0 -- an engine built under one override must not serve a call
+# made under another).  Bounded by count and by device bytes (az_engine_device_bytes), least recently used first out; a
+# cached engine does not keep its last phase's records (az_engine_release_phase at eviction time is too late: callers
+# release them once pushed, see training.py).
 CACHE_MAX = 4
+CACHE_MAX_BYTES = int(float(os.environ.get("AZHIP_CACHE_GB", "96")) * (1 << 30))
+CREATE_ENV = ("AZHIP_TOWER", "AZHIP_HEADS", "AZHIP_GRAPH", "AZHIP_XCH_EPOCH0")
 _cache = {}
+
+
+def _cache_bytes():
+    return sum(e.device_bytes() for e in _cache.values() if e._h is not None)
 
 
 def cached_engine(role="", **kw):
     import ctypes
     cfg = default_cfg(**kw)
-    key = (role, bytes(ctypes.string_at(ctypes.addressof(cfg), ctypes.sizeof(cfg))))
+    key = (role, bytes(ctypes.string_at(ctypes.addressof(cfg), ctypes.sizeof(cfg))), tuple(os.environ.get(k, "") for k in CREATE_ENV))
     e = _cache.pop(key, None)
     if e is None or e._h is None:
         while len(_cache) >= CACHE_MAX:
             _cache.pop(next(iter(_cache))).close()
         e = Engine(cfg=cfg)
+        need = e.device_bytes()
+        while _cache and _cache_bytes() + need > CACHE_MAX_BYTES:
+            _cache.pop(next(iter(_cache))).close()
     _cache[key] = e                                                 # most recently used last
     return e
 

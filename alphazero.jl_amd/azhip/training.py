@@ -113,25 +113,37 @@ def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_pl
         sim = SimParams(**{**sim.__dict__, "num_games": count})
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     games, moves, ng, nm, stats, eng = run_local(simulator, gspec, sim, first, game_played, device, seed, device_only=not torch_group)
+    # `elapsed` is the time of simulate_distributed alone (training.jl:284-287: its fetch of the workers' results is inside,
+    # push_trace! is not): the clock stops here, plus the gather where there is one
+    elapsed = time.perf_counter() - t0
     memory.new_batch()
+    depth = footprint = None
     if comm is not None:
         gs = comm.gather_push(eng, memory, params.mcts.gamma)
         nm = gs.moves
+        elapsed += gs.gather_ms * 1e-3
+        # mean / maximum over ALL ranks' games (training.jl:293-294), from the gathered game records
+        depth, footprint = float(gs.mean_game_depth), int(gs.max_nodes)
+        eng.release_phase()                                         # the cached engine keeps its trees' pools, not the records
     elif torch_group:
+        tg = time.perf_counter()
         g, mm = repack_by_game_id(*gather_records(*records_to_numpy(games, moves, ng, nm), group))
         ng, nm = len(g), len(mm)
+        elapsed += time.perf_counter() - tg
         games = (L.GameRec * max(ng, 1)).from_buffer_copy(g.tobytes() or bytes(C.sizeof(L.GameRec)))
         moves = (L.MoveRec * max(nm, 1)).from_buffer_copy(mm.tobytes() or bytes(C.sizeof(L.MoveRec)))
         memory.push_records(games, moves, ng, nm, params.mcts.gamma)
     else:
         memory.push_engine(eng, params.mcts.gamma)
         nm = stats.moves
-    elapsed = time.perf_counter() - t0
-    depth = float(np.mean([games[i].total_nodes_traversed / max(games[i].total_simulations, 1) for i in range(ng)])) if ng else 0.0
+        eng.release_phase()
+    if depth is None:
+        depth = float(np.mean([games[i].total_nodes_traversed / max(games[i].total_simulations, 1) for i in range(ng)])) if ng else 0.0
+        footprint = int(max((games[i].nodes for i in range(ng)), default=0))
     with memory.dataset(use_position_averaging=True) as d:
         distinct = len(d)
     return SelfPlayReport(samples_gen_speed=nm / elapsed, average_exploration_depth=depth,
-                          mcts_memory_footprint=int(max((games[i].nodes for i in range(ng)), default=0)),
+                          mcts_memory_footprint=footprint,
                           memory_size=len(memory), memory_num_distinct_boards=distinct)
 
 

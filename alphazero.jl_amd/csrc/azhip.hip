@@ -127,7 +127,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   HIPCHK(hipSetDevice(c->device));
   az_engine* e = new (std::nothrow) az_engine();
   if (!e) return fail(AZ_ERR_HIP, "out of host memory");
-  e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0;
+  e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0; e->alloc_bytes = 0;
   e->net_loaded = false; e->running = false; e->prof_on = false; { const char* ug = getenv("AZHIP_GRAPH"); e->use_graphs = ug ? atoi(ug) : 0; }
   e->d_phase = nullptr; e->phase_cap = 0; e->phase_n = 0; e->host_moves = true; e->last_tower[0] = 0; e->prof_mask = 0; e->prof_used = 0;
   memset(&e->prof, 0, sizeof e->prof);
@@ -244,6 +244,20 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   return AZ_OK;
 }
 
+
+extern "C" int az_engine_device_bytes(az_engine* e, int64_t* bytes) {
+  if (!e || !bytes) return fail(AZ_ERR_BAD_ARG, "NULL");
+  *bytes = (int64_t)e->alloc_bytes + (int64_t)sizeof(az_move_rec) * e->phase_cap;
+  return AZ_OK;
+}
+extern "C" int az_engine_release_phase(az_engine* e) {
+  ENGINE(e);
+  if (e->running) return fail(AZ_ERR_STATE, "self-play in progress");
+  AZCHK(sync_all(e));
+  if (e->d_phase) HIPCHK(hipFree(e->d_phase));
+  e->d_phase = nullptr; e->phase_cap = 0; e->phase_n = 0; e->ph_games.clear(); e->ph_off.clear();
+  return AZ_OK;
+}
 
 extern "C" int az_device_info(az_engine* e, char* name, int32_t name_cap, int32_t* num_cu, int64_t* hbm_bytes) {
   ENGINE(e);

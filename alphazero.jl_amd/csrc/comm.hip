@@ -12,11 +12,28 @@
 // RCCL is dlopen'ed by path next to the HIP runtime this library uses (a process that also imports PyTorch holds a second,
 // bundled RCCL: binding by soname could hand our communicator to that copy's HIP runtime), on first use only: single-GPU
 // users never load it.  The unique id travels between the processes by whatever the host has (Julia's Distributed, MPI,
-// a file; bench.py uses torch.distributed's store).
+// a file; bench.py uses torch.distributed's gloo store).
+//
+// Transport seam: AZHIP_RCCL_LIB=<path> makes rc::load() open that library instead of RCCL.  It exists so that the W > 1
+// branches below (padding, per-rank offsets, the re-ordering by global game id) can be EXECUTED on a box with one GPU, where
+// RCCL itself refuses two ranks per device: tests/rccl_stub/ builds a test-only library with the same six entry points that
+// moves the bytes through host shared memory.  The product never sets the variable.
+//
+// Failure agreement: every local reason to refuse (no phase, wrong device, allocation failure, the root without parameters)
+// is turned into a status word that travels with the first all-gather of a call, so all ranks leave together instead of one
+// rank returning while the others wait inside ncclAllGather for ever; a failing collective aborts the communicator.
 #include "engine.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+
+// The part of RCCL's C ABI this file binds (rccl.h, NCCL 2.x ABI: stable enum values), declared here so that building
+// libazhip.so does not need the RCCL development headers -- the library is dlopen'ed on first use only.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclInt64 = 4, ncclFloat32 = 7 } ncclDataType_t;
+}
 
 namespace rc {
 struct Lib {
@@ -24,6 +41,7 @@ struct Lib {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -33,7 +51,12 @@ static int load() {
   if (g.so) return AZ_OK;
   void* so = nullptr;
   Dl_info info;
-  if (dladdr(reinterpret_cast<void*>(&hipGetLastError), &info) && info.dli_fname) {
+  const char* forced = getenv("AZHIP_RCCL_LIB");
+  if (forced && *forced) {
+    so = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (!so) return fail(AZ_ERR_COMM, "cannot load AZHIP_RCCL_LIB=%s (%s)", forced, dlerror());
+  }
+  if (!so && dladdr(reinterpret_cast<void*>(&hipGetLastError), &info) && info.dli_fname) {
     std::string p(info.dli_fname);
     const size_t k = p.rfind('/');
     if (k != std::string::npos) so = dlopen((p.substr(0, k) + "/librccl.so").c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -45,6 +68,7 @@ static int load() {
   g.GetUniqueId = (decltype(g.GetUniqueId))dlsym(so, "ncclGetUniqueId");
   g.CommInitRank = (decltype(g.CommInitRank))dlsym(so, "ncclCommInitRank");
   g.CommDestroy = (decltype(g.CommDestroy))dlsym(so, "ncclCommDestroy");
+  g.CommAbort = (decltype(g.CommAbort))dlsym(so, "ncclCommAbort");
   g.AllGather = (decltype(g.AllGather))dlsym(so, "ncclAllGather");
   g.Broadcast = (decltype(g.Broadcast))dlsym(so, "ncclBroadcast");
   g.GetErrorString = (decltype(g.GetErrorString))dlsym(so, "ncclGetErrorString");
@@ -121,17 +145,42 @@ static __global__ void k_pack_moves(const az_move_rec* __restrict__ phase, const
   for (int k = threadIdx.x; k < cnt[g] * 4; k += blockDim.x) d[k] = s[k];
 }
 
+// One int64 per rank: AZ_OK or the first local failure.  Every rank learns whether ALL ranks can go on (max |status|).
+static int agree(az_comm* c, int local_status, long long* d_send, long long* d_all, int* worst_rank) {
+  const int W = c->world;
+  long long v = local_status;
+  HIPCHK(hipMemcpyAsync(d_send, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+  RCCLCHK(rc::g.AllGather(d_send, d_all, 1, ncclInt64, c->comm, c->stream));
+  std::vector<long long> all((size_t)W);
+  HIPCHK(hipMemcpyAsync(all.data(), d_all, sizeof(long long) * W, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *worst_rank = -1;
+  for (int r = 0; r < W; ++r) if (all[r] != AZ_OK && *worst_rank < 0) *worst_rank = r;
+  return AZ_OK;
+}
+// a collective failed half way: the other ranks may be inside it -- tear the communicator down so that they fail too
+static void abort_comm(az_comm* c) {
+  if (c->comm && rc::g.CommAbort) { (void)rc::g.CommAbort(c->comm); c->comm = nullptr; }
+}
+#define COMM_ALIVE(c) if (!(c)->comm) return fail(AZ_ERR_COMM, "the communicator was aborted by an earlier failed collective")
+
 extern "C" int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, double gamma, az_gather_stats* stats) {
-  if (!c || !e) return fail(AZ_ERR_BAD_ARG, "NULL argument");
-  if (e->device != c->device || (m && m->device != c->device)) return fail(AZ_ERR_BAD_ARG, "engine / memory / communicator are on different devices");
-  if (m && m->game != e->cfg.game) return fail(AZ_ERR_BAD_ARG, "memory and engine differ in game");
-  if (e->running) return fail(AZ_ERR_STATE, "self-play in progress");
-  if (!e->d_phase) return fail(AZ_ERR_STATE, "the engine holds no device-resident phase (az_selfplay_run first)");
+  if (!c) return fail(AZ_ERR_BAD_ARG, "NULL communicator");
+  COMM_ALIVE(c);
   HIPCHK(hipSetDevice(c->device));
-  AZCHK(sync_all(e));
+  // local validation first; its verdict travels with the counts, so that every rank returns together (never one rank
+  // leaving while the others sit in ncclAllGather)
+  int local = AZ_OK;
+  if (!e) local = fail(AZ_ERR_BAD_ARG, "NULL engine");
+  else if (e->device != c->device || (m && m->device != c->device)) local = fail(AZ_ERR_BAD_ARG, "engine / memory / communicator are on different devices");
+  else if (m && m->game != e->cfg.game) local = fail(AZ_ERR_BAD_ARG, "memory and engine differ in game");
+  else if (e->running) local = fail(AZ_ERR_STATE, "self-play in progress");
+  else if (!e->d_phase) local = fail(AZ_ERR_STATE, "the engine holds no device-resident phase (az_selfplay_run first)");
+  else local = sync_all(e);
+  std::string local_msg = local != AZ_OK ? az_last_error() : "";
   const auto t0 = std::chrono::steady_clock::now();
   const int W = c->world;
-  const size_t ng = e->ph_games.size();
+  const size_t ng = local == AZ_OK ? e->ph_games.size() : 0;
   std::vector<int> ord(ng);
   for (size_t i = 0; i < ng; ++i) ord[i] = (int)i;
   std::sort(ord.begin(), ord.end(), [&](int a, int b) { return e->ph_games[a].game_id < e->ph_games[b].game_id; });
@@ -147,23 +196,45 @@ extern "C" int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, doubl
   }
   std::vector<void*> tmp;
   auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); };
+  bool in_collective = false;
   int st = [&]() -> int {
-    // 1. counts of every rank
-    long long hc[2] = {(long long)ng, nm};
+    // 1. counts and status of every rank
+    long long hc[3] = {(long long)ng, nm, (long long)local};
     long long *d_cnt_send, *d_cnt_all;
-    AZCHK(mem_alloc(&tmp, &d_cnt_send, 2)); AZCHK(mem_alloc(&tmp, &d_cnt_all, (size_t)2 * W));
+    AZCHK(mem_alloc(&tmp, &d_cnt_send, 3)); AZCHK(mem_alloc(&tmp, &d_cnt_all, (size_t)3 * W));
+    in_collective = true;
     HIPCHK(hipMemcpyAsync(d_cnt_send, hc, sizeof hc, hipMemcpyHostToDevice, c->stream));
-    RCCLCHK(rc::g.AllGather(d_cnt_send, d_cnt_all, 2, ncclInt64, c->comm, c->stream));
-    std::vector<long long> all((size_t)2 * W);
-    HIPCHK(hipMemcpyAsync(all.data(), d_cnt_all, sizeof(long long) * 2 * W, hipMemcpyDeviceToHost, c->stream));
+    RCCLCHK(rc::g.AllGather(d_cnt_send, d_cnt_all, 3, ncclInt64, c->comm, c->stream));
+    std::vector<long long> all((size_t)3 * W);
+    HIPCHK(hipMemcpyAsync(all.data(), d_cnt_all, sizeof(long long) * 3 * W, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    in_collective = false;
     long long maxg = 1, maxm = 1, totg = 0, totm = 0;
-    for (int r = 0; r < W; ++r) { maxg = std::max(maxg, all[2 * r]); maxm = std::max(maxm, all[2 * r + 1]); totg += all[2 * r]; totm += all[2 * r + 1]; }
+    for (int r = 0; r < W; ++r) {
+      if (all[3 * r + 2] != AZ_OK) {
+        if (r == c->rank) return fail(local, "%s", local_msg.c_str());
+        return fail(AZ_ERR_COMM, "rank %d cannot take part in the gather (status %lld); nothing was exchanged", r, all[3 * r + 2]);
+      }
+      maxg = std::max(maxg, all[3 * r]); maxm = std::max(maxm, all[3 * r + 1]); totg += all[3 * r]; totm += all[3 * r + 1];
+    }
     // 2. this rank's records packed in game-id order, then the two all-gathers (equal, padded segments per rank)
-    az_move_rec *d_msend, *d_mall; az_game_rec *d_gsend, *d_gall; long long *d_src, *d_dst; int* d_n;
-    AZCHK(mem_alloc(&tmp, &d_msend, (size_t)maxm)); AZCHK(mem_alloc(&tmp, &d_mall, (size_t)maxm * W));
-    AZCHK(mem_alloc(&tmp, &d_gsend, (size_t)maxg)); AZCHK(mem_alloc(&tmp, &d_gall, (size_t)maxg * W));
-    AZCHK(mem_alloc(&tmp, &d_src, std::max<size_t>(ng, 1))); AZCHK(mem_alloc(&tmp, &d_dst, std::max<size_t>(ng, 1))); AZCHK(mem_alloc(&tmp, &d_n, std::max<size_t>(ng, 1)));
+    az_move_rec *d_msend = nullptr, *d_mall = nullptr; az_game_rec *d_gsend = nullptr, *d_gall = nullptr; long long *d_src = nullptr, *d_dst = nullptr; int* d_n = nullptr;
+    int ast = [&]() -> int {
+      AZCHK(mem_alloc(&tmp, &d_msend, (size_t)maxm)); AZCHK(mem_alloc(&tmp, &d_mall, (size_t)maxm * W));
+      AZCHK(mem_alloc(&tmp, &d_gsend, (size_t)maxg)); AZCHK(mem_alloc(&tmp, &d_gall, (size_t)maxg * W));
+      AZCHK(mem_alloc(&tmp, &d_src, std::max<size_t>(ng, 1))); AZCHK(mem_alloc(&tmp, &d_dst, std::max<size_t>(ng, 1))); AZCHK(mem_alloc(&tmp, &d_n, std::max<size_t>(ng, 1)));
+      return AZ_OK;
+    }();
+    if (W > 1) {                       // the buffers are sized by the largest rank: a rank that cannot allocate them says so first
+      std::string amsg = ast != AZ_OK ? az_last_error() : "";
+      int bad = -1;
+      in_collective = true;
+      AZCHK(agree(c, ast, d_cnt_send, d_cnt_all, &bad));
+      in_collective = false;
+      if (bad >= 0) return bad == c->rank || ast != AZ_OK ? fail(ast != AZ_OK ? ast : AZ_ERR_COMM, "%s", ast != AZ_OK ? amsg.c_str() : "another rank failed")
+                                                            : fail(AZ_ERR_COMM, "rank %d could not allocate the gather buffers; nothing was exchanged", bad);
+    } else AZCHK(ast);
+    in_collective = true;
     if (ng) {
       HIPCHK(hipMemcpyAsync(d_src, src.data(), sizeof(long long) * ng, hipMemcpyHostToDevice, c->stream));
       HIPCHK(hipMemcpyAsync(d_dst, dst.data(), sizeof(long long) * ng, hipMemcpyHostToDevice, c->stream));
@@ -178,14 +249,15 @@ extern "C" int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, doubl
     HIPCHK(hipMemcpyAsync(gall.data(), d_gall, sizeof(az_game_rec) * gall.size(), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
+    in_collective = false;
     const auto t1 = std::chrono::steady_clock::now();
     struct Ref { int32_t id; long long first; int n; };
     std::vector<Ref> refs;
     refs.reserve((size_t)totg);
     for (int r = 0; r < W; ++r)
-      for (long long i = 0; i < all[2 * r]; ++i) {
+      for (long long i = 0; i < all[3 * r]; ++i) {
         const az_game_rec& gr = gall[(size_t)r * maxg + i];
-        refs.push_back({gr.game_id, (long long)r * maxm + gr.first_move, gr.num_moves});
+        refs.push_back({gr.game_id, (long long)r * maxm + gr.first_move, gr.num_moves});   // rank r's segment starts at r * maxm
       }
     std::sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.id < b.id; });
     if (m) {
@@ -196,35 +268,77 @@ extern "C" int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, doubl
     }
     if (stats) {
       stats->games = totg; stats->moves = totm;
-      stats->bytes = (int64_t)W * (maxm * (long long)sizeof(az_move_rec) + maxg * (long long)sizeof(az_game_rec) + 16);
+      stats->bytes = (int64_t)W * (maxm * (long long)sizeof(az_move_rec) + maxg * (long long)sizeof(az_game_rec) + 24);
       stats->gather_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
       stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      // Report.SelfPlay wants mean depth and the largest tree over ALL games (training.jl:293-296), not the rank's own
+      long long sims = 0, trav = 0, nodes = 0;
+      for (int r = 0; r < W; ++r)
+        for (long long i = 0; i < all[3 * r]; ++i) {
+          const az_game_rec& gr = gall[(size_t)r * maxg + i];
+          sims += gr.total_simulations; trav += gr.total_nodes_traversed; nodes = std::max<long long>(nodes, gr.nodes);
+        }
+      double dsum = 0.0;                 // mean over games of each game's average depth, in global game-id order
+      {
+        std::vector<std::pair<int32_t, double>> dep;
+        dep.reserve((size_t)totg);
+        for (int r = 0; r < W; ++r)
+          for (long long i = 0; i < all[3 * r]; ++i) {
+            const az_game_rec& gr = gall[(size_t)r * maxg + i];
+            dep.push_back({gr.game_id, gr.total_simulations ? (double)gr.total_nodes_traversed / (double)gr.total_simulations : 0.0});
+          }
+        std::sort(dep.begin(), dep.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) { return a.first < b.first; });
+        for (const auto& d : dep) dsum += d.second;
+      }
+      stats->ranks = W;
+      stats->total_simulations = sims; stats->total_nodes_traversed = trav; stats->max_nodes = nodes;
+      stats->mean_game_depth = totg ? dsum / (double)totg : 0.0;
     }
     return AZ_OK;
   }();
+  if (st != AZ_OK && in_collective) abort_comm(c);
   cleanup();
   return st;
 }
 
 extern "C" int az_comm_broadcast_params(az_comm* c, az_engine* e, int32_t root) {
-  if (!c || !e) return fail(AZ_ERR_BAD_ARG, "NULL argument");
-  if (root < 0 || root >= c->world) return fail(AZ_ERR_BAD_ARG, "root %d of %d", root, c->world);
-  if (e->cfg.oracle != AZ_ORACLE_RESNET) return fail(AZ_ERR_STATE, "engine was created without the ResNet oracle");
-  if (c->rank == root && !e->net_loaded) return fail(AZ_ERR_STATE, "the root has no parameters loaded");
+  if (!c) return fail(AZ_ERR_BAD_ARG, "NULL communicator");
+  COMM_ALIVE(c);
+  if (root < 0 || root >= c->world) return fail(AZ_ERR_BAD_ARG, "root %d of %d", root, c->world);   // the same argument on every rank
   HIPCHK(hipSetDevice(c->device));
+  int local = AZ_OK;
   int64_t n = 0;
-  AZCHK(az_net_num_params(e, &n));
-  float* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, sizeof(float) * (size_t)n));
-  std::vector<float> h((size_t)n);
+  if (!e) local = fail(AZ_ERR_BAD_ARG, "NULL engine");
+  else if (e->device != c->device) local = fail(AZ_ERR_BAD_ARG, "engine and communicator are on different devices");
+  else if (e->cfg.oracle != AZ_ORACLE_RESNET) local = fail(AZ_ERR_STATE, "engine was created without the ResNet oracle");
+  else if (c->rank == root && !e->net_loaded) local = fail(AZ_ERR_STATE, "the root has no parameters loaded");
+  else local = az_net_num_params(e, &n);
+  std::string local_msg = local != AZ_OK ? az_last_error() : "";
+  std::vector<void*> tmp;
+  std::vector<float> h;
+  bool in_collective = false;
   int st = [&]() -> int {
+    long long *d_s, *d_all;
+    AZCHK(mem_alloc(&tmp, &d_s, 1)); AZCHK(mem_alloc(&tmp, &d_all, (size_t)c->world));
+    float* d = nullptr;
+    if (local == AZ_OK) { local = mem_alloc(&tmp, &d, (size_t)n); if (local != AZ_OK) local_msg = az_last_error(); }
+    int bad = -1;
+    in_collective = true;
+    AZCHK(agree(c, local, d_s, d_all, &bad));
+    in_collective = false;
+    if (local != AZ_OK) return fail(local, "%s", local_msg.c_str());
+    if (bad >= 0) return fail(AZ_ERR_COMM, "rank %d cannot take part in the broadcast%s; nothing was sent", bad, bad == root ? " (the root has no parameters?)" : "");
+    h.resize((size_t)n);
+    in_collective = true;
     if (c->rank == root) HIPCHK(hipMemcpyAsync(d, e->blob.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     RCCLCHK(rc::g.Broadcast(d, d, (size_t)n, ncclFloat32, root, c->comm, c->stream));
     HIPCHK(hipMemcpyAsync(h.data(), d, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    in_collective = false;
     return AZ_OK;
   }();
-  (void)hipFree(d);
+  if (st != AZ_OK && in_collective) abort_comm(c);
+  for (void* p : tmp) (void)hipFree(p);
   AZCHK(st);
   // Network.copy(nn; on_gpu = true, test_mode = true) on every rank: the kernels want their packed fragments
   return az_net_set_params(e, h.data(), n);

@@ -78,6 +78,7 @@ struct az_engine {
   // k_tower16s (split tower, 128 filters): publish areas per feature buffer (slot g = group g, AZ_MAX_GROUPS = d_hfeat), launch epoch
   unsigned long long* xch[AZ_MAX_GROUPS + 1]; unsigned long long xch_epoch;
   std::vector<void*> allocs;
+  size_t alloc_bytes;              // device bytes behind `allocs` (az_engine_device_bytes)
   std::vector<void*> net_allocs;   // device copies of the packed network (replaced by az_net_set_params)
   // network
   bool net_loaded;
@@ -134,6 +135,7 @@ template <class T> inline int dalloc(az_engine* e, T** p, size_t n, bool zero = 
   hipError_t r = hipMalloc(&q, bytes);
   if (r != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r));
   e->allocs.push_back(q);
+  e->alloc_bytes += bytes;
   if (zero) HIPCHK(hipMemsetAsync(q, 0, bytes, e->stream));
   *p = (T*)q;
   return AZ_OK;

@@ -260,6 +260,7 @@ extern "C" int az_memory_create(int32_t game, int32_t device, int64_t capacity, 
   *out = nullptr;
   GameInfo gi;
   if (!game_info(game, &gi)) return fail(AZ_ERR_BAD_ARG, "unknown game id %d", game);
+  if (game == AZ_GAME_GO9_PLANES) return fail(AZ_ERR_BAD_ARG, "game id %d is a network-only tensor geometry (no device twin): the device replay memory needs the game's state keys", game);
   if (capacity < 1 || capacity > (1LL << 31) - 1) return fail(AZ_ERR_BAD_ARG, "capacity must be in 1..2^31-1");
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
@@ -481,7 +482,8 @@ extern "C" int az_dataset_create(az_memory* m, int32_t which, int32_t use_symmet
   switch (m->game) {
     case AZ_GAME_CONNECT_FOUR: st = dataset_build<ConnectFour>(m, d, which, use_symmetries != 0, use_position_averaging != 0, weighing_policy); break;
     case AZ_GAME_TICTACTOE: st = dataset_build<TicTacToe>(m, d, which, use_symmetries != 0, use_position_averaging != 0, weighing_policy); break;
-    default: st = dataset_build<Mancala>(m, d, which, use_symmetries != 0, use_position_averaging != 0, weighing_policy); break;
+    case AZ_GAME_MANCALA: st = dataset_build<Mancala>(m, d, which, use_symmetries != 0, use_position_averaging != 0, weighing_policy); break;
+    default: st = fail(AZ_ERR_BAD_ARG, "game id %d has no device twin", m->game); break;
   }
   if (st != AZ_OK) { az_dataset_destroy(d); return st; }
   *out = d;

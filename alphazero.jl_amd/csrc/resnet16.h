@@ -352,10 +352,14 @@ struct NoXch {
 // ~1270 across XCDs; sc0 or plain loads, also RMW atomics at workgroup scope, keep returning the CU's cached copy and
 // never see the partner's word, even on the same XCD -- so pairs are simply (b, b ^ 1).)
 // (Waiting on one word per wavefront before reading all twelve cost a round trip more than it saved: 172 vs 167 us.)
-// The poll is bounded: a partner that never arrives (it cannot happen while all workgroups of the launch fit on the
-// chip, which pick_tower guarantees) raises DERR_EXCHANGE instead of hanging the GPU.
+// The poll is bounded IN TIME (2 s of the 100 MHz constant clock, looked at every 256 polls): a partner that never
+// arrives raises DERR_EXCHANGE instead of hanging the GPU.  Workgroups of a launch are dispatched in order and a pair is
+// (b, b ^ 1), so at any moment at most ONE pair of a launch is half resident and every other resident workgroup of it
+// belongs to a complete pair, which finishes and frees its CU: a pair cannot deadlock, it can only wait for CUs that
+// other work holds (another engine's tower in an arena, a trainer, another process) -- for as long as that work runs,
+// which is why the bound is wall time (round 2 counted 2^20 polls, ~0.7 s alone but arbitrarily little under contention).
 enum { DERR_EXCHANGE = 6 };
-static constexpr int XCH_SPIN_LIMIT = 1 << 20;
+static constexpr unsigned long long XCH_WAIT_TICKS = 200000000ull;
 struct PairXch {
   static constexpr int STEM_HALVES = 2;              // the stem is cheap: both halves computed locally, one exchange less
   unsigned long long* mine;          // [2][NT * 4][THREADS]
@@ -381,6 +385,7 @@ struct PairXch {
     const unsigned long long* th = theirs + (size_t)(step & 1) * NT * 4 * THREADS + tid;
     unsigned long long pv[NT][4];
     int spins = 0;
+    unsigned long long t_start = 0;
     for (;;) {
       bool ok = true;
 #pragma unroll
@@ -391,7 +396,11 @@ struct PairXch {
           ok = ok && (uint32_t)(pv[t][i] >> 32) == tag;
         }
       if (ok) break;
-      if (++spins > XCH_SPIN_LIMIT) { atomicCAS(err, 0, (int)DERR_EXCHANGE); break; }
+      if ((++spins & 255) == 0) {
+        const unsigned long long now = wall_clock64();
+        if (!t_start) t_start = now;
+        else if (now - t_start > XCH_WAIT_TICKS) { atomicCAS(err, 0, (int)DERR_EXCHANGE); break; }
+      }
     }
     const int ppos = posF<F>(pch);
 #pragma unroll

@@ -648,6 +648,7 @@ extern "C" int az_trainer_create(az_engine* e, az_dataset* d, const az_train_cfg
   if (cfg->struct_size != (int32_t)sizeof(az_train_cfg)) return fail(AZ_ERR_BAD_ARG, "az_train_cfg size mismatch: call az_train_cfg_init");
   if (e->cfg.oracle != AZ_ORACLE_RESNET || !e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
   if (d->game != e->cfg.game || d->device != e->device) return fail(AZ_ERR_BAD_ARG, "data set and engine differ in game or device");
+  if (e->cfg.game == AZ_GAME_GO9_PLANES) return fail(AZ_ERR_BAD_ARG, "game id %d is a network-only tensor geometry: no device trainer", e->cfg.game);
   if (cfg->optimiser != AZ_OPT_ADAM && cfg->optimiser != AZ_OPT_CYCLIC_NESTEROV) return fail(AZ_ERR_BAD_ARG, "unknown optimiser %d", cfg->optimiser);
   const int64_t B = std::min<int64_t>(cfg->batch_size, d->n);     // batchsize = min(params.batch_size, length(W)), learning.jl:113
   if (cfg->batch_size < 2 || B < 2) return fail(AZ_ERR_BAD_ARG, "batch_size and the data set must have at least 2 samples (batch statistics)");

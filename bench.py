@@ -177,7 +177,7 @@ def gather_leg(azhip, blob, dev_index, rank, world, games_per_rank=512, nsims=48
     gs = c.gather_push(eng, mem, 1.0)
     dt = time.perf_counter() - t0
     out = {"collective": "ncclAllGather (RCCL) of device-resident az_move_rec / az_game_rec + push_trace! on the device",
-           "ranks": world, "games": gs.games, "samples": gs.moves, "bytes_received_per_rank": gs.bytes,
+           "ranks": int(gs.ranks), "world": world, "rendezvous": "torch.distributed/%s" % __import__("torch").distributed.get_backend(), "games": gs.games, "samples": gs.moves, "bytes_received_per_rank": gs.bytes,
            "gather_ms": gs.gather_ms, "gather_and_push_ms": gs.total_ms, "wall_ms": 1e3 * dt, "memory_length": len(mem),
            "GB_per_s_per_rank": gs.bytes / max(gs.gather_ms, 1e-9) / 1e6}
     mem.close()
@@ -195,7 +195,7 @@ def main():
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--groups", type=int, default=2, help="interleaved slot groups = num_workers / batch_size: 2 (default) overlaps the tree kernels of one half-batch with the network of the other, the reference's num_workers = 2 x batch_size; 1 = one 4096-leaf batch per wave")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 code path on a single GPU)")
+    ap.add_argument("--backend", default="gloo", help="torch.distributed backend of the RENDEZVOUS for N > 1: a barrier, two scalar reductions and the 128-byte RCCL id are all that goes through it, so gloo (CPU) is the default and the process holds exactly ONE RCCL instance, the one libazhip.so loads for az_comm_*; nccl = torch's bundled RCCL as well")
     ap.add_argument("--no-prof", action="store_true", help="do not wrap launches in HIP events")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel class (default: only the dominant kernel, k_tower)")
     args = ap.parse_args()

@@ -130,6 +130,12 @@ int az_abi_version(void);
 int az_engine_cfg_init(az_engine_cfg* cfg);
 int az_engine_create(const az_engine_cfg* cfg, az_engine** out);
 int az_engine_destroy(az_engine* e);
+/* Device memory the engine holds (node pools, tables, network buffers, the phase buffer): a host that keeps engines alive
+ * between phases (the reference rebuilds its MCTS.Env per phase, src/simulations.jl:216-218) budgets with it. */
+int az_engine_device_bytes(az_engine* e, int64_t* bytes);
+/* Frees the device-resident records of the last phase (up to 64 B x num_games x max_moves) once they have been pushed /
+ * gathered; the next az_selfplay_run / az_selfplay_begin allocates again. */
+int az_engine_release_phase(az_engine* e);
 
 /* ---- game plugin, device twins (GameInterface, src/game.jl:34-336) -------------------- */
 int az_game_num_actions(int game, int32_t* num_actions);
@@ -340,17 +346,24 @@ typedef struct {
   int64_t games, moves;             /* over all ranks */
   int64_t bytes;                    /* received per rank by the all-gathers */
   double gather_ms, total_ms;       /* pack + all-gathers + game-record read-back; plus the push into the memory */
+  /* Report.SelfPlay's inputs over ALL ranks' games (src/training.jl:293-296): mean over games of average_exploration_depth,
+   * the largest tree (nodes; x memory_footprint_per_node = mcts_memory_footprint), and the raw totals */
+  int64_t ranks, total_simulations, total_nodes_traversed, max_nodes;
+  double mean_game_depth;
 } az_gather_stats;
 /* ncclGetUniqueId on ONE rank; the 128 bytes go to the other ranks by the host's own means (Distributed, MPI, a file). */
 int az_comm_unique_id(uint8_t id[AZ_COMM_ID_BYTES]);
 /* ncclCommInitRank: collective over all `world` ranks, each on its own device. */
 int az_comm_init(int32_t device, int32_t rank, int32_t world, const uint8_t id[AZ_COMM_ID_BYTES], az_comm** out);
 int az_comm_destroy(az_comm* c);
-/* Collective.  All-gathers the ranks' device-resident phase records (the `fetch` + `vcat` of simulations.jl:280-289) and,
+/* Collective.  A rank that cannot take part (no phase held, wrong device, allocation failure) still enters the first
+ * all-gather with its status, and EVERY rank then returns an error together (the failing rank its own, the others
+ * AZ_ERR_COMM) -- no rank is left waiting; a collective that fails half way aborts the communicator (later calls
+ * return AZ_ERR_COMM).  All-gathers the ranks' device-resident phase records (the `fetch` + `vcat` of simulations.jl:280-289) and,
  * where `m` is not NULL, runs push_trace! (src/memory.jl:74-87) for ALL games in global game-id order into m: every rank
  * that passes a memory ends up with the same samples a single-GPU run of all the games would have pushed. */
 int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, double gamma, az_gather_stats* stats);
-/* Collective.  ncclBroadcast of `root`'s parameter blob, then az_net_set_params on every rank (the network shipped to the
+/* Collective (same failure agreement as az_comm_gather_push).  ncclBroadcast of `root`'s parameter blob, then az_net_set_params on every rank (the network shipped to the
  * workers before a phase, src/training.jl:278-282). */
 int az_comm_broadcast_params(az_comm* c, az_engine* e, int32_t root);
 

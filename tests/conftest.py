@@ -34,3 +34,13 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _drop_cached_engines():
+    """azhip keeps engines alive by configuration between phases (azhip/engine.py); tests of one module may share them,
+    the next module starts with an empty cache (node pools of up to 10 GB each must not pile up over the suite)."""
+    yield
+    eng = sys.modules.get("azhip.engine")
+    if eng is not None:
+        eng.clear_engine_cache()

@@ -89,8 +89,17 @@ def test_native_comm_single_rank_gather_and_broadcast():
         a.close(); b.close()
 
 
-def _native_worker(rank, world, port, out_dir):
+STUB = os.path.join(ROOT, "tests", "rccl_stub", "librccl_stub.so")
+
+
+def _native_worker(rank, world, port, out_dir, stub=False):
+    """stub: all ranks on cuda:0 with the test-only transport (tests/rccl_stub) in place of RCCL -- the code under test,
+    csrc/comm.hip, is the shipped one"""
     sys.path[:0] = [os.path.join(ROOT, "alphazero.jl_amd")]
+    if stub:
+        os.environ["AZHIP_RCCL_LIB"] = STUB
+        os.environ["AZSTUB_SLOT_MB"] = "1"                                # az_comm_broadcast_params' 1 MB+ blob goes in pieces
+    dev = 0 if stub else rank
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -102,11 +111,24 @@ def _native_worker(rank, world, port, out_dir):
     gspec = azhip.TicTacToeSpec()
     hp = azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
     nn = azhip.ResNet(gspec, hp, seed=4 if rank == 0 else 99)             # rank 1 starts with other weights: the broadcast must replace them
-    with comm.Comm(rank, rank, world, comm.torch_broadcast_id(rank)) as c:
-        mem = azhip.MemoryBuffer(gspec, 10000, device=rank)
+    with comm.Comm(dev, rank, world, comm.torch_broadcast_id(rank)) as c:
+        mem = azhip.MemoryBuffer(gspec, 10000, device=dev)
         kw = dict(game=1, oracle=azhip.ORACLE_RESNET, num_workers=4, batch_size=4, num_iters_per_turn=16, num_blocks=1, num_filters=64,
-                  num_policy_head_filters=32, num_value_head_filters=32, device=rank)
+                  num_policy_head_filters=32, num_value_head_filters=32, device=dev)
         with azhip.Engine(**kw) as e:
+            # failure agreement: the root holds no parameters yet -- EVERY rank gets an error (the root its own, the others
+            # AZ_ERR_COMM) instead of the non-roots waiting in ncclBroadcast for ever; the communicator stays usable
+            try:
+                c.broadcast_params(e, root=0)
+                raise AssertionError("broadcast from a root without parameters succeeded")
+            except azhip.AzError as ex:
+                assert ("no parameters" in str(ex)) if rank == 0 else ("rank 0 cannot take part" in str(ex)), str(ex)
+            # ... and a rank without a device-resident phase stops the gather on all ranks, nothing exchanged
+            try:
+                c.gather_push(e, None, 1.0)
+                raise AssertionError("gather without a phase succeeded")
+            except azhip.AzError as ex:
+                assert "no device-resident phase" in str(ex), str(ex)
             if rank == 0:
                 e.net_set_params(nn.params())
             c.broadcast_params(e, root=0)                                    # ncclBroadcast of the blob
@@ -114,6 +136,7 @@ def _native_worker(rank, world, port, out_dir):
         nn0 = azhip.ResNet(gspec, hp, params=got)
         rep = self_play_step_device(gspec, nn0, _params(), mem, seed=6, comm=c)
         np.save(os.path.join(out_dir, "N%d.npy" % rank), _samples(mem))
+        np.save(os.path.join(out_dir, "R%d.npy" % rank), np.array([rep.average_exploration_depth, rep.mcts_memory_footprint], dtype=np.float64))
         np.save(os.path.join(out_dir, "W%d.npy" % rank), got)
         assert rep.memory_size == len(mem)
         mem.close()
@@ -140,3 +163,31 @@ def test_native_comm_two_ranks_on_two_gpus(tmp_path):
     N0, N1 = np.load(tmp_path / "N0.npy"), np.load(tmp_path / "N1.npy")
     assert np.array_equal(N0, N1) and np.array_equal(N0, want)
     assert np.array_equal(np.load(tmp_path / "W0.npy"), nn.params()) and np.array_equal(np.load(tmp_path / "W1.npy"), nn.params())
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_native_comm_several_ranks_share_one_gpu_through_the_transport_seam(tmp_path, world):
+    """The shipped exchange (csrc/comm.hip: az_comm_gather_push / az_comm_broadcast_params) with a world of 2 and 4 ranks on
+    the ONE GPU of the test box: AZHIP_RCCL_LIB points the library's loader at tests/rccl_stub (host shared memory behind the
+    six nccl entry points; RCCL itself refuses two ranks per device).  10 games split 6 + 4 / 4 + 2 + 2 + 2 (divrem, remainder
+    to rank 0: the padded segments differ in fill), every rank's device memory must hold exactly the samples of the unsharded
+    run in the same order, the broadcast weights must arrive, Report.SelfPlay's depth / footprint must cover all games, and
+    the failure-agreement paths must return on all ranks."""
+    import subprocess
+    if not os.path.exists(STUB):
+        subprocess.check_call(["make", "-C", os.path.dirname(STUB)])
+    port = 30100 + os.getpid() % 2000 + world
+    mp.spawn(_native_worker, args=(world, port, str(tmp_path), True), nprocs=world, join=True)
+    import azhip
+    from azhip.training import self_play_step_device
+    gspec = azhip.TicTacToeSpec()
+    nn = azhip.ResNet(gspec, azhip.ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32), seed=4)
+    mem = azhip.MemoryBuffer(gspec, 10000)
+    rep = self_play_step_device(gspec, nn, _params(), mem, seed=6)
+    want = _samples(mem)
+    mem.close()
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("N%d.npy" % r)), want), r
+        assert np.array_equal(np.load(tmp_path / ("W%d.npy" % r)), nn.params()), r
+        got = np.load(tmp_path / ("R%d.npy" % r))
+        assert abs(got[0] - rep.average_exploration_depth) < 1e-12 and got[1] == rep.mcts_memory_footprint, (r, got, rep)
