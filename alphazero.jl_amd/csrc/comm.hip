@@ -210,9 +210,9 @@ extern "C" int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, doubl
     HIPCHK(hipStreamSynchronize(c->stream));
     in_collective = false;
     long long maxg = 1, maxm = 1, totg = 0, totm = 0;
+    if (local != AZ_OK) return fail(local, "%s", local_msg.c_str());   // a failing rank reports its own reason
     for (int r = 0; r < W; ++r) {
       if (all[3 * r + 2] != AZ_OK) {
-        if (r == c->rank) return fail(local, "%s", local_msg.c_str());
         return fail(AZ_ERR_COMM, "rank %d cannot take part in the gather (status %lld); nothing was exchanged", r, all[3 * r + 2]);
       }
       maxg = std::max(maxg, all[3 * r]); maxm = std::max(maxm, all[3 * r + 1]); totg += all[3 * r]; totm += all[3 * r + 1];

@@ -120,7 +120,14 @@ template <class Gm> static int xch_slot(az_engine* e, const float* hfeat, unsign
   const size_t words = (size_t)(e->num_cu > 0 ? e->num_cu : 256) * T::XCH_WORDS;
   int slot = AZ_MAX_GROUPS;
   for (int g = 0; g < e->ngroups; ++g) if (hfeat == e->g_hfeat[g]) slot = g;
-  if (!e->xch[slot]) AZCHK(dalloc(e, &e->xch[slot], words));        // zeroed: tag 0 is never expected
+  if (!e->xch[slot]) {
+    // zeroed: tag 0 is never expected.  The clear runs on e->stream while the launch that follows is on the group's own
+    // (non-blocking) stream: it must have finished before that kernel polls the area -- recycled device memory can hold an
+    // earlier engine's words, and every engine's epochs start at 1, so stale tags WOULD match (seen once in a full test
+    // run: a two-group engine created after other engines had been freed evaluated garbage)
+    AZCHK(dalloc(e, &e->xch[slot], words));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
   // a tag carries 24 bits of the launch epoch: before they repeat, every area is cleared (an area that a long run of
   // smaller launches has not touched could otherwise still hold words with the tag of exactly 2^24 launches ago)
   if (((e->xch_epoch + 1) & 0xFFFFFFull) == 0) {
