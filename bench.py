@@ -42,6 +42,140 @@ def executed_flop(kernel):
 
 
 PEAK_HBM_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PEAK_BF16_MFMA_TFLOPS = 2500.0                       # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (no sparsity)
+# Little's law for the search-tree kernel: a slot's simulation is a CHAIN of dependent 128-byte node-line loads (one line in
+# flight per slot); a dependent load that misses L2 takes ~840 shader cycles (tools/probes/chase_latency.hip)
+# ~ 400 ns at the sustained clock.  G slots therefore cannot move more than G x 128 B per 400 ns, whatever the kernel does.
+TREE_LINE_BYTES, TREE_LOAD_LATENCY_S = 128.0, 400e-9
+GAME_DIMS = {0: ("Connect-Four", 42, 3), 1: ("Tic-tac-toe", 9, 3), 2: ("Mancala", 14, 5)}   # name, board positions, planes
+
+
+def tower_flop(game, hp):
+    """dense (algorithmic) FLOP of stem + residual tower + both 1x1 head convolutions per board"""
+    _, P, Cin = GAME_DIMS[game]
+    F = hp.num_filters
+    return 2 * P * F * (9 * Cin + 2 * hp.num_blocks * 9 * F + hp.num_policy_head_filters + hp.num_value_head_filters)
+
+
+def executed_fraction(game, kernel):
+    """fraction of a 3x3 convolution's (row tile, tap) products the named tower kernel really executes (Geo16 skips the ones
+    that fall off the board for a whole tile; az_debug_tower_geometry reports the geometry's product count)"""
+    import ctypes as C
+    from azhip._lib import lib
+    if kernel.startswith("k_tower<"):
+        return 1.0
+    which = 2 if "k_tower16x2" in kernel else (0 if "NT=11" in kernel else 1)
+    f = lib().az_debug_tower_geometry
+    f.restype = C.c_int
+    f.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    buf = (C.c_uint16 * 8192)()
+    rows, prods = C.c_int32(), C.c_int32()
+    if f(game, which, buf, 8192, C.byref(rows), C.byref(prods)) != 0:
+        return 1.0
+    return prods.value / (9.0 * (rows.value // 16))
+
+
+def pmc_lookup(kernel):
+    """HBM bytes per launch of `kernel` from this round's separate rocprofv3 --pmc passes (profiles/r3/pmc_summary.json,
+    tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE in KB, FETCH doubled on gfx950 as MI355X_MICROARCH.md prescribes);
+    returns (bytes, units per launch) or None: counters cannot be read from inside this process."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r3", "pmc_summary.json")))
+        for k in d.get("kernels", []):
+            if kernel.startswith(k["match"]):
+                return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0, k["units_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def steady_block(azhip, dev_index, label, game, slots, groups, sims, hp, waves, bf16=False, note=None, max_moves=0):
+    """One extra configuration, measured like the headline: steady state (every slot has made its first move), `waves`
+    timed search waves, tower launches timed with HIP events, roofline on the tower kernel."""
+    from azhip.network import random_params
+    eng = azhip.Engine(game=game, oracle=azhip.ORACLE_RESNET, device=dev_index, num_workers=slots, batch_size=slots // groups,
+                       num_iters_per_turn=sims, gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
+                       prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
+                       num_blocks=hp.num_blocks, num_filters=hp.num_filters, num_policy_head_filters=hp.num_policy_head_filters,
+                       num_value_head_filters=hp.num_value_head_filters, net_bf16=1 if bf16 else 0, max_moves_per_game=max_moves)
+    try:
+        eng.net_set_params(random_params(game, hp, seed=2026))
+        dev_bytes = eng.device_bytes()
+        eng.selfplay_begin(-1, first_game_id=1 << 27)
+        eng.selfplay_step(sims + sims // 2)
+        s0 = eng.selfplay_stats()
+        eng.prof_reset()
+        eng.prof_enable(True, classes=("tower",))
+        t0 = time.perf_counter()
+        eng.selfplay_step(waves)
+        s1 = eng.selfplay_stats()
+        dt = time.perf_counter() - t0
+        prof = eng.prof_get()
+        kernel = eng.net_last_kernel()
+        eng.prof_enable(False)
+        eng.selfplay_end()
+    finally:
+        eng.close()
+    return block_report(label, game, hp, bf16, kernel, prof, s0, s1, dt, waves, slots, groups, sims, note, dev_bytes)
+
+
+def block_report(label, game, hp, bf16, kernel, prof, s0, s1, dt, waves, slots, groups, sims, note, dev_bytes):
+    sims_n, evals, trav, moves = (s1.simulations - s0.simulations, s1.leaf_evals - s0.leaf_evals,
+                                  s1.nodes_traversed - s0.nodes_traversed, s1.moves - s0.moves)
+    tw = prof["tower"]
+    flop = tower_flop(game, hp)
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    excl_ms = min(tw["ms"], 1e3 * dt)                    # towers of several slot groups overlap: clipped to the wall time
+    achieved = evals * flop / (excl_ms * 1e-3) / 1e12 if excl_ms > 0 else 0.0
+    ex = executed_fraction(game, kernel)
+    conv = 2 * hp.num_blocks * 9 * hp.num_filters
+    ex_flop = flop * (conv * ex + 9 * GAME_DIMS[game][2] + hp.num_policy_head_filters + hp.num_value_head_filters) / \
+        (conv + 9 * GAME_DIMS[game][2] + hp.num_policy_head_filters + hp.num_value_head_filters)
+    out = {"workload": "%s self-play, %d sims/move, %d parallel games, ResNet %dx%d %s, %d slot group(s)%s"
+                       % (GAME_DIMS[game][0], sims, slots, hp.num_blocks, hp.num_filters, "bf16 tower (opt-in, NOT the reference's fp32 precision)" if bf16 else "fp32", groups, "; " + note if note else ""),
+           "value": sims_n / dt, "unit": "sims/s", "steps": waves, "ms_per_step": 1e3 * dt / max(waves, 1), "dtype": "bf16" if bf16 else "f32",
+           "samples_per_sec": moves / dt, "avg_exploration_depth": trav / max(sims_n, 1), "leaf_evals_per_sim": evals / max(sims_n, 1),
+           "engine_device_GB": dev_bytes / 2.0**30,
+           "roofline": {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                        "mfma_executed_frac": achieved / peak * ex_flop / flop, "executed_product_frac": ex, "flop_per_board": flop,
+                        "launches": tw["launches"], "avg_boards_per_launch": evals / max(tw["launches"], 1),
+                        "avg_launch_ms": tw["ms"] / max(tw["launches"], 1), "exclusive_ms": excl_ms, "traffic": None}}
+    t = pmc_lookup(kernel)
+    if t is not None:
+        out["roofline"]["traffic"] = t[0] * out["roofline"]["avg_boards_per_launch"] / t[1]
+    return out
+
+
+def whole_phase(azhip, dev_index, blob, hp, slots, sims, groups):
+    """SURVEY.md §8(d)'s metric over a WHOLE self-play phase: `slots` Connect-Four games from the empty board to completion
+    (az_selfplay_run, device-only) -- first moves from empty trees, every move step, refills, trace write-out into the phase
+    buffer and the drain at the end while the batch empties -- against the steady-state headline."""
+    eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=dev_index, num_workers=slots, batch_size=slots // groups,
+                       num_iters_per_turn=sims, gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
+                       prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
+                       num_blocks=hp.num_blocks, num_filters=hp.num_filters, num_policy_head_filters=32, num_value_head_filters=32)
+    try:
+        eng.net_set_params(blob)
+        dev_bytes = eng.device_bytes()
+        from azhip._lib import SelfplayStats
+        s0 = SelfplayStats()                                 # az_selfplay_run counts from zero
+        eng.prof_reset()
+        eng.prof_enable(True, classes=("tower",))
+        t0 = time.perf_counter()
+        games, _, ng, _, st = eng.selfplay_run(slots, first_game_id=1 << 26, device_only=True)
+        dt = time.perf_counter() - t0
+        prof = eng.prof_get()
+        kernel = eng.net_last_kernel()
+        eng.prof_enable(False)
+    finally:
+        eng.close()
+    out = block_report("whole_phase", azhip.GAME_CONNECT_FOUR, hp, False, kernel, prof, s0, st, dt, int(st.waves - s0.waves), slots, groups, sims,
+                       "%d games played from the empty board to the end, drain included" % ng, dev_bytes)
+    out["games"] = int(ng)
+    out["positions"] = int(st.moves - s0.moves)
+    out["seconds"] = dt
+    return out
+
 
 
 def pmc_traffic(kernel, boards_per_launch):
@@ -154,6 +288,15 @@ def alone_and_tree(args, blob, dev_index, kernel, waves=200):
             "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
             "bytes_per_sim": tree_bytes / max(sims, 1), "avg_exploration_depth": trav / max(sims, 1), "slots": args.slots,
             "us_per_wave": 1e3 * tree_ms / waves, "traffic": None}
+    # what 4096 dependent chains can move at all (see TREE_LOAD_LATENCY_S): the ceiling this kernel is judged against
+    ceiling = args.slots * TREE_LINE_BYTES / TREE_LOAD_LATENCY_S / 1e9
+    tree["littles_law_ceiling_GBs"] = ceiling
+    tree["littles_law_ceiling_frac"] = ceiling / PEAK_HBM_GBS
+    tree["frac_of_littles_law_ceiling"] = gbs / ceiling if ceiling > 0 else None
+    t = pmc_lookup("k_tree")
+    if t is not None:
+        tree["traffic"] = t[0] * args.slots / t[1]
+        tree["traffic_over_algorithmic"] = tree["traffic"] / (tree_bytes / waves)
     return alone, tree
 
 
@@ -195,6 +338,7 @@ def main():
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--groups", type=int, default=2, help="interleaved slot groups = num_workers / batch_size: 2 (default) overlaps the tree kernels of one half-batch with the network of the other, the reference's num_workers = 2 x batch_size; 1 = one 4096-leaf batch per wave")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra configurations (whole phase, C3, C4 Mancala, bf16 10x128, 128 workers) reported under `extra`")
     ap.add_argument("--backend", default="gloo", help="torch.distributed backend of the RENDEZVOUS for N > 1: a barrier, two scalar reductions and the 128-byte RCCL id are all that goes through it, so gloo (CPU) is the default and the process holds exactly ONE RCCL instance, the one libazhip.so loads for az_comm_*; nccl = torch's bundled RCCL as well")
     ap.add_argument("--no-prof", action="store_true", help="do not wrap launches in HIP events")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel class (default: only the dominant kernel, k_tower)")
@@ -329,7 +473,7 @@ def main():
             out["roofline"] = {
                 "kernel": kernel, "bound": "mfma", "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": pmc_traffic(kernel, boards),
+                "traffic": (lambda t: t[0] * boards / t[1] if t is not None else pmc_traffic(kernel, boards))(pmc_lookup(kernel)),
                 "flop_per_board": flop, "launches": tw["launches"], "avg_boards_per_launch": boards,
                 "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),          # raw HIP-event average (includes co-scheduled time)
                 "launch_ms_sum": tw["ms"], "wall_ms": wall_ms, "exclusive_ms": excl_ms,
@@ -345,6 +489,29 @@ def main():
             out["roofline_tree"] = tree
         if gather is not None:
             out["gather"] = gather
+        if world == 1 and not args.no_extras:
+            # The rest of DESIGN.md §0's table, measured here so that the driver's line carries it (bounded: ~40 s in all).
+            # None of it is part of `value`.  A failing block reports its error instead of taking the headline with it.
+            mk = ResNetHP
+            blocks = [
+                ("whole_phase", lambda: whole_phase(azhip, dev_index, blob, hp, args.slots, args.sims, args.groups)),
+                ("c3", lambda: steady_block(azhip, dev_index, "c3", azhip.GAME_CONNECT_FOUR, 4096, 2, 600, hp, 200,
+                                            note="BASELINE configs[2] per GPU (games/connect-four/params.jl:25)")),
+                ("c4_mancala", lambda: steady_block(azhip, dev_index, "c4_mancala", azhip.GAME_MANCALA, 8192, 1, 800, hp, 200, max_moves=256,
+                                                    note="BASELINE configs[3] (games/mancala/params.jl:23-29), bug-compatible flip_colors")),
+                ("bf16_10x128", lambda: steady_block(azhip, dev_index, "bf16_10x128", azhip.GAME_CONNECT_FOUR, 4096, 1, 400,
+                                                     mk(num_blocks=10, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32), 200, bf16=True,
+                                                     note="BASELINE configs[4]'s network on Connect-Four boards")),
+                ("workers_128_5x128", lambda: steady_block(azhip, dev_index, "workers_128_5x128", azhip.GAME_CONNECT_FOUR, 128, 1, 600,
+                                                           mk(num_blocks=5, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32), 400,
+                                                           note="the reference's shipped self-play parameters (games/connect-four/params.jl:7-30: 128 workers, 5x128)")),
+            ]
+            out["extra"] = {}
+            for name, fn in blocks:
+                try:
+                    out["extra"][name] = fn()
+                except Exception as ex:
+                    out["extra"][name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, hp, args.sims)
         print(json.dumps(out), flush=True)
