@@ -8,6 +8,10 @@
 #   seam 3  HipResNet <: AbstractNetwork      the Network plugin backed by the HIP tower/heads kernels
 #   seam 2  Network.forward_normalized / evaluate_batch on a HipResNet (stock Julia MCTS on top of it)
 #   seam 1  AlphaZero.simulate(simulator, gspec::DeviceGameSpec, p) -> whole self-play phase on the GPU
+#           AlphaZero.simulate_distributed(simulator, gspec::DeviceGameSpec, p) -> one worker process per GPU, global game ids
+#           device_self_play_step!(gspec, nn, params, mem, comm) -> self_play_step! with records and samples resident in HBM,
+#           az_comm_gather_push (RCCL) between the ranks
+#   seam 5  DeviceMctsEnv: explore! / state_info / counters / reset! on a device tree (Explorer's MCTS statistics)
 # `Scripts.train` is unchanged: pick `HipResNet` as the experiment's network type.
 module AlphaZeroHIP
 
@@ -282,7 +286,7 @@ function AlphaZero.simulate(simulator::Simulator, gspec::DeviceGameSpec, p::SimP
   m = player.mcts
   mp = MctsParams(gamma=m.gamma, cpuct=m.cpuct, num_iters_per_turn=player.niters, temperature=player.τ,
                   dirichlet_noise_ϵ=m.noise_ϵ, dirichlet_noise_α=m.noise_α, prior_temperature=m.prior_temperature)
-  e = Engine(make_cfg(gspec, mp, p, oracle.hyper; seed=seed))
+  e = Engine(make_cfg(gspec, mp, p, oracle.hyper; seed=seed, device=parse(Int, get(ENV, "AZHIP_DEVICE", "0"))))
   check(ccall((:az_net_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, oracle.blob, length(oracle.blob)))
   maxlen = gspec isa ConnectFour.GameSpec ? 42 : gspec isa Tictactoe.GameSpec ? 9 : 256
   games = Vector{GameRec}(undef, p.num_games); moves = Vector{MoveRec}(undef, p.num_games * maxlen)
@@ -426,5 +430,222 @@ function device_batch_updates!(nn::HipResNet, m::DeviceMemory, lp, n; use_symmet
   end
   return losses
 end
+
+# ---- multi-GPU: simulate_distributed (src/simulations.jl:252-290) and the device-resident self-play step -------------
+import Distributed
+
+struct GatherStats
+  games::Int64; moves::Int64; bytes::Int64; gather_ms::Float64; total_ms::Float64
+  ranks::Int64; total_simulations::Int64; total_nodes_traversed::Int64; max_nodes::Int64; mean_game_depth::Float64
+end
+const COMM_ID_BYTES = 128
+
+"ncclGetUniqueId on the calling process (rank 0); ship the bytes to the other ranks with Distributed"
+function comm_unique_id()
+  id = Vector{UInt8}(undef, COMM_ID_BYTES)
+  check(ccall((:az_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+  return id
+end
+
+"One rank's RCCL communicator (az_comm_init is collective over all `world` ranks, one GPU each)"
+mutable struct Comm
+  h::Ptr{Cvoid}; rank::Int; world::Int; device::Int
+  function Comm(device, rank, world, id::Vector{UInt8})
+    @assert length(id) == COMM_ID_BYTES
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:az_comm_init, LIB), Cint, (Int32, Int32, Int32, Ptr{UInt8}, Ref{Ptr{Cvoid}}), device, rank, world, id, out))
+    c = new(out[], rank, world, device)
+    finalizer(x -> (x.h != C_NULL && ccall((:az_comm_destroy, LIB), Cint, (Ptr{Cvoid},), x.h); x.h = C_NULL), c)
+    return c
+  end
+end
+
+"Collective: every rank's device-resident phase records -> (optionally) this rank's DeviceMemory, global game-id order"
+function gather_push!(c::Comm, e::Engine, m::Union{Nothing, DeviceMemory}, gamma)
+  st = Ref(GatherStats(0, 0, 0, 0.0, 0.0, 0, 0, 0, 0, 0.0))
+  check(ccall((:az_comm_gather_push, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ref{GatherStats}),
+    c.h, e.h, isnothing(m) ? C_NULL : m.h, gamma, st))
+  return st[]
+end
+"Collective: the root's parameters to every rank's engine (the network shipped to the workers, training.jl:278-282)"
+broadcast_params!(c::Comm, e::Engine, root=0) =
+  check(ccall((:az_comm_broadcast_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32), c.h, e.h, root))
+
+"push_trace! for every game of the engine's last device-only phase, on the device (az_memory_push_engine)"
+push_engine!(m::DeviceMemory, e::Engine, gamma) =
+  check(ccall((:az_memory_push_engine, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64), m.h, e.h, gamma))
+release_phase!(e::Engine) = check(ccall((:az_engine_release_phase, LIB), Cint, (Ptr{Cvoid},), e.h))
+function device_bytes(e::Engine)
+  n = Ref{Int64}(0)
+  check(ccall((:az_engine_device_bytes, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), e.h, n))
+  return n[]
+end
+
+"az_selfplay_run with the move records kept in HBM: returns the game records (first_move = -1) and the phase statistics"
+function selfplay_device_only!(e::Engine, num_games, first_game_id; game_simulated=nothing)
+  games = Vector{GameRec}(undef, num_games)
+  stats = SelfplayStats()
+  progress_cb[] = game_simulated
+  GC.@preserve games begin
+    tb = TraceBuf(pointer(games), length(games), 0, Ptr{MoveRec}(C_NULL), 0, 0)
+    check(ccall((:az_selfplay_run, LIB), Cint,
+      (Ptr{Cvoid}, Int32, Int32, Ref{TraceBuf}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{SelfplayStats}),
+      e.h, num_games, first_game_id, tb, @cfunction(c_progress, Cvoid, (Ptr{Cvoid},)), C_NULL, stats))
+    resize!(games, tb.num_games)
+  end
+  return games, stats
+end
+
+"simulate_distributed's split (simulations.jl:268-278): divrem, the remainder to the first worker; global ids contiguous in rank order"
+function shard_games(num_games, world, rank)
+  num_each, rem = divrem(num_games, world)
+  @assert num_each >= 1
+  counts = [r == 0 ? num_each + rem : num_each for r in 0:world-1]
+  return sum(counts[1:rank]), counts[rank + 1]
+end
+
+"""
+    simulate_distributed(simulator, gspec::DeviceGameSpec, p; game_simulated)
+
+More specific method of the reference's function (src/simulations.jl:252-290) for games with a device twin: one Julia worker
+process per GPU (worker i drives device i-1), the games split by `divrem` exactly as the reference does, every worker runs
+`simulate` on its GPU with GLOBAL game ids (so the traces do not depend on the number of workers), results fetched and
+concatenated in worker order = game-id order.  This form returns host traces like the reference; `device_self_play_step!`
+below is the form in which no record leaves the GPUs.
+"""
+function AlphaZero.simulate_distributed(simulator::Simulator, gspec::DeviceGameSpec, p::SimParams; game_simulated, seed=1)
+  workers = Distributed.workers()
+  length(workers) == 1 && return AlphaZero.simulate(simulator, gspec, p; game_simulated=game_simulated, seed=seed)
+  chan = Distributed.RemoteChannel(() -> Channel{Nothing}(1))
+  @async for i in 1:p.num_games
+    take!(chan); game_simulated()
+  end
+  remote_game_simulated() = put!(chan, nothing)
+  tasks = map(enumerate(workers)) do (i, w)
+    first, count = shard_games(p.num_games, length(workers), i - 1)
+    Distributed.@spawnat w begin
+      ENV["AZHIP_DEVICE"] = string(i - 1)
+      AlphaZero.simulate(simulator, gspec, SimParams(p; num_games=count);
+                         game_simulated=remote_game_simulated, first_game_id=first, seed=seed)
+    end
+  end
+  return reduce(vcat, fetch.(tasks))
+end
+
+"""
+    device_self_play_step!(gspec, bestnn::HipResNet, params::SelfPlayParams, mem::DeviceMemory, comm; seed) -> Report.SelfPlay
+
+`self_play_step!` (src/training.jl:275-300) on one rank of a multi-GPU job, nothing leaving HBM: the rank's shard of the games
+is simulated device-only (global game ids), `az_comm_gather_push` all-gathers the records of all ranks over RCCL and runs
+`push_trace!` for ALL games in game-id order into this rank's device memory -- every rank ends with the samples a single-GPU
+run would have pushed.  `comm === nothing`: single GPU (az_memory_push_engine).  Call it on every rank (e.g. with
+`Distributed.@spawnat` on one worker per GPU after `Comm(device, rank, world, id)` there).
+"""
+function device_self_play_step!(gspec::DeviceGameSpec, bestnn::HipResNet, params, mem::DeviceMemory, comm::Union{Nothing, Comm};
+                                seed=1, game_simulated=nothing)
+  world, rank, device = isnothing(comm) ? (1, 0, 0) : (comm.world, comm.rank, comm.device)
+  first, count = shard_games(params.sim.num_games, world, rank)
+  e = Engine(make_cfg(gspec, params.mcts, SimParams(params.sim; num_games=count), bestnn.hyper; seed=seed, device=device))
+  check(ccall((:az_net_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, bestnn.blob, length(bestnn.blob)))
+  t0 = time()
+  games, stats = selfplay_device_only!(e, count, first; game_simulated=game_simulated)
+  elapsed = time() - t0
+  check(ccall((:az_memory_new_batch, LIB), Cint, (Ptr{Cvoid},), mem.h))
+  nA = GI.num_actions(gspec)
+  hb = nA <= 8 ? 2 : 4
+  node_bytes = cld(cld(cld(8nA, 8) * 8 + 8nA + 2nA, hb) * hb + hb, 32) * 32 + 16 + 4 + 12
+  if isnothing(comm)
+    push_engine!(mem, e, params.mcts.gamma)
+    nsamples = stats.moves
+    edepth = isempty(games) ? 0.0 : sum(g.total_nodes_traversed / max(g.total_simulations, 1) for g in games) / length(games)
+    footprint = node_bytes * maximum(g.nodes for g in games; init=0)
+  else
+    gs = gather_push!(comm, e, mem, params.mcts.gamma)
+    elapsed += gs.gather_ms / 1000            # simulate_distributed's `fetch` is inside the reference's @timed region
+    nsamples, edepth, footprint = gs.moves, gs.mean_game_depth, node_bytes * gs.max_nodes
+  end
+  release_phase!(e)
+  len = Ref{Int64}(0); cur = Ref{Int64}(0)
+  check(ccall((:az_memory_length, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), mem.h, len, cur))
+  ds = Ref{Ptr{Cvoid}}(C_NULL)                 # memory_num_distinct_boards = length(merge_by_state(get_experience(mem)))
+  check(ccall((:az_dataset_create, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ref{Ptr{Cvoid}}), mem.h, 0, 0, 1, 0, ds))
+  info = Ref(DatasetInfo(0, 0, 0.0, 0f0, 0f0))
+  check(ccall((:az_dataset_get_info, LIB), Cint, (Ptr{Cvoid}, Ref{DatasetInfo}), ds[], info))
+  ccall((:az_dataset_destroy, LIB), Cint, (Ptr{Cvoid},), ds[])
+  return AlphaZero.Report.SelfPlay(nsamples / elapsed, edepth, footprint, len[], info[].num_samples)
+end
+
+# ---- seam 5: the explorer's view of a device tree (src/ui/explorer.jl:70-86; MCTS.explore! / reset!, mcts.jl:239-281) --------
+"""
+    DeviceMctsEnv(gspec, nn::HipResNet, params::MctsParams)
+
+`MCTS.Env` whose tree lives in slot 0 of a one-worker engine: `explore!`, `policy`-style statistics of a state, counters and
+`reset!` -- what `Explorer.state_statistics` reads of `player.mcts` (N, W, P per action, Ntot, Vest).
+"""
+mutable struct DeviceMctsEnv
+  gspec
+  engine::Engine
+  params::MctsParams
+end
+function DeviceMctsEnv(gspec::DeviceGameSpec, nn::HipResNet, params::MctsParams; seed=1)
+  e = Engine(make_cfg(gspec, params, SimParams(num_games=1, num_workers=1, batch_size=1), nn.hyper; seed=seed))
+  check(ccall((:az_net_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, nn.blob, length(nn.blob)))
+  return DeviceMctsEnv(gspec, e, params)
+end
+"MCTS.explore!(env, game, nsims) (mcts.jl:239-245); the Dirichlet noise is drawn from the library's RNG contract for (game_id, move)"
+function explore!(env::DeviceMctsEnv, game, nsims=env.params.num_iters_per_turn; game_id=0, move=0)
+  key = [encode_state(env.gspec, GI.current_state(game))]
+  check(ccall((:az_mcts_explore, LIB), Cint,
+    (Ptr{Cvoid}, Ptr{NTuple{2,UInt64}}, Int32, Int32, Ptr{Float64}, Ptr{UInt32}, Ptr{UInt32}),
+    env.engine.h, key, 1, nsims, C_NULL, UInt32[game_id], UInt32[move]))
+end
+"tree[state]: (N, W, P) over the available actions in GI.actions order, Vest -- or nothing when the state is not in the tree"
+function state_info(env::DeviceMctsEnv, state)
+  key = [encode_state(env.gspec, state)]
+  N = Vector{Int32}(undef, MAX_ACTIONS); W = Vector{Float64}(undef, MAX_ACTIONS); P = Vector{Float32}(undef, MAX_ACTIONS)
+  vest = Ref{Float32}(0); mask = Ref{UInt32}(0)
+  st = ccall((:az_mcts_node_stats, LIB), Cint,
+    (Ptr{Cvoid}, Int32, Ptr{NTuple{2,UInt64}}, Ptr{Int32}, Ptr{Float64}, Ptr{Float32}, Ref{Float32}, Ref{UInt32}),
+    env.engine.h, 0, key, N, W, P, vest, mask)
+  st == 0 || return nothing
+  avail = [a for a in 1:GI.num_actions(env.gspec) if (mask[] >> (a - 1)) & 1 == 1]
+  return (N=N[avail], W=W[avail], P=P[avail], Vest=vest[])
+end
+"(total_simulations, total_nodes_traversed, length(tree)): MCTS.average_exploration_depth / memory footprint inputs (mcts.jl:286-321)"
+function counters(env::DeviceMctsEnv)
+  a = Ref{Int64}(0); b = Ref{Int64}(0); c = Ref{Int64}(0)
+  check(ccall((:az_mcts_counters, LIB), Cint, (Ptr{Cvoid}, Int32, Ref{Int64}, Ref{Int64}, Ref{Int64}), env.engine.h, 0, a, b, c))
+  return (total_simulations=a[], total_nodes_traversed=b[], num_nodes=c[])
+end
+"MCTS.reset!(env) (mcts.jl:278-281)"
+reset!(env::DeviceMctsEnv) = check(ccall((:az_mcts_reset, LIB), Cint, (Ptr{Cvoid},), env.engine.h))
+
+# ---- what this file deliberately does not bind, and why (tests/test_julia_glue_static.py checks the list against the header:
+# an entry point of include/azhip.h that is neither `ccall`ed above nor named here fails the test) ---------------------------
+const UNBOUND = Dict(
+  :az_abi_version => "version probe; the glue is built against one header",
+  :az_engine_cfg_init => "EngineCfg is filled field by field from MctsParams / SimParams (make_cfg)",
+  :az_game_num_actions => "GI.num_actions(gspec) answers it on the Julia side",
+  :az_game_state_dim => "GI.state_dim(gspec) answers it on the Julia side",
+  :az_game_init_key => "encode_state(gspec, GI.current_state(GI.init(gspec))) answers it",
+  :az_game_encode => "GI.vectorize_state is the reference's own; the device encode is fused into az_net_evaluate_keys",
+  :az_game_play => "GI.play! is the reference's own; the twins are checked against it by tests/, not used from Julia",
+  :az_net_num_params => "length(nn.blob) is known from the Flux network",
+  :az_net_get_params => "nn.blob is the master copy; az_trainer_get_params returns trained parameters",
+  :az_selfplay_begin => "stepping form (bench / polling): az_selfplay_run is what simulate needs",
+  :az_selfplay_step => "stepping form, see az_selfplay_begin",
+  :az_selfplay_collect => "stepping form, see az_selfplay_begin",
+  :az_selfplay_get_stats => "az_selfplay_run returns the statistics",
+  :az_selfplay_active => "stepping form, see az_selfplay_begin",
+  :az_selfplay_end => "stepping form, see az_selfplay_begin",
+  :az_push_trace => "host-side helper for foreign hosts; Julia has the reference's push_trace!",
+  :az_memory_push_samples => "host TrainingSamples -> device memory: only needed when mixing host and device memories",
+  :az_memory_empty => "empty!(mem): not used by the training loop (src/training.jl)",
+  :az_dataset_read => "debug / test read-back of the converted samples",
+  :az_train_cfg_init => "TrainCfg is filled from LearningParams (train_cfg)",
+  :az_trainer_gradients => "test hook (gradients of one batch against autograd)",
+  :az_prof_enable => "bench.py's HIP-event profiling", :az_prof_get => "bench.py's HIP-event profiling",
+  :az_prof_reset => "bench.py's HIP-event profiling", :az_device_info => "bench.py's report", :az_net_last_kernel => "bench.py's report",
+)
 
 end # module
