@@ -146,6 +146,22 @@ def block_report(label, game, hp, bf16, kernel, prof, s0, s1, dt, waves, slots, 
     return out
 
 
+def host_stepped_c5(seconds=6.0):
+    """BASELINE configs[4] end to end as far as it can go without OpenSpiel: examples/host_stepped_go9 (plain C++ over
+    include/azhip.h: host rules + host trees on all host threads, ResNet 10x128 bf16 on the GPU through az_net_forward at
+    1600 sims/move).  The rules are a labelled stand-in (OpenSpiel is not in the reference tree): no parity claim, the
+    number says what the network seam sustains and how much of the wall time the host needs."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "host_stepped_go9")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    r = subprocess.run([exe, "--workers", "1024", "--sims", "1600", "--seconds", str(seconds)], capture_output=True, text=True, timeout=120)
+    line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
+    if r.returncode != 0 or line is None:
+        raise RuntimeError("host_stepped_go9 exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+    return json.loads(line)
+
+
 def whole_phase(azhip, dev_index, blob, hp, slots, sims, groups):
     """SURVEY.md §8(d)'s metric over a WHOLE self-play phase: `slots` Connect-Four games from the empty board to completion
     (az_selfplay_run, device-only) -- first moves from empty trees, every move step, refills, trace write-out into the phase
@@ -506,6 +522,7 @@ def main():
                                                            mk(num_blocks=5, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32), 400,
                                                            note="the reference's shipped self-play parameters (games/connect-four/params.jl:7-30: 128 workers, 5x128)")),
             ]
+            blocks.append(("c5_host_stepped", lambda: host_stepped_c5()))
             out["extra"] = {}
             for name, fn in blocks:
                 try:
