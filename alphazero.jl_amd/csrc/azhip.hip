@@ -548,6 +548,7 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
     memset(&nbd, 0, sizeof nbd);
     nbd.nblocks = nb; nbd.stem_w = n16.stem_w; nbd.stem_ss = n16.stem_ss; nbd.conv_ss = n16.conv_ss; nbd.head_ss = n16.head_ss;
     for (int k = 0; k < 3; ++k) nbd.geo[k] = e->d_geo[k];
+    nbd.geo[2] = e->d_geo[3];                                        // bf16 tower: [2] = the 22-tile geometry (8 Connect-Four boards per workgroup)
     if (c.net_bf16) {
       auto up16 = [&](const std::vector<uint16_t>& h, const bf16x8v** d) -> int {
         uint16_t* q = nullptr;

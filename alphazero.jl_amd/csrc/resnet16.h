@@ -50,15 +50,31 @@ struct Net16Dev {
 // (nbr[tap][row], buffer offset of the neighbour or of the zero row; built on the host from the same constexpr
 // function, staged in LDS), read one pipeline step ahead of the activation rows it addresses; the list of
 // (tap, tile pair) steps is a compile-time list, so the unrolled MFMA stream simply has fewer steps.
+//
+// Bank-conflict-free gathers (round 3).  The A operand of a tap is a GATHER of tap-shifted rows, and a ds_read_b128 pass
+// (8 rows x 2 adjacent k groups, resnet16b.h / posF) runs at the full LDS rate only if its 8 rows are distinct mod 8 (rows
+// of 72 or 136 dwords: the bank offset of a row is 8 (row mod 8)).  With the cells of a class in plain (board, position)
+// order the shifted rows of a pass collide -- 119 extra LDS cycles over the 170 passes of a Connect-Four convolution, 59 %
+// of the LDS rate, which is what bounds the bf16 tower once two workgroups keep the MFMA pipe fed.  So inside every class
+// segment the cells are placed such that row = L(cell) (mod 8) for ONE linear function L = a x + b y + g board of the whole
+// layout (a, b, g searched at compile time; Connect-Four, 4 boards: x + 4 y + 5 board with 2 of 168 cells off; 8 boards:
+// L = board).  The 8 rows of a pass have 8 distinct residues, their tap-shifted neighbours have L + (a dx + b dy): distinct
+// again.  Off-board neighbours read one of GEO_NZ = 8 zero rows, the one whose residue the neighbour would have had.
+static constexpr int GEO_NZ = 8;
 template <class Gm, int NTILES, int TBOARDS> struct Geo16 {
   static constexpr int P = Gm::P, W = Gm::W, H = Gm::H, RPAD = NTILES * 16, ROWS = TBOARDS * P, NPADR = RPAD - ROWS;
   static_assert(NPADR >= 0, "boards do not fit the tiles");
   struct Tab {
     uint16_t pos[RPAD];            // buffer row -> board * P + position, 0xffff = padding row
-    uint16_t nbr[9 * RPAD];        // [tap][row] -> buffer row of the neighbour, RPAD = the zero row
+    uint16_t nbr[9 * RPAD];        // [tap][row] -> buffer row of the neighbour, RPAD + k = zero row k
     uint16_t tapmask[NTILES];      // bit t: tap t is inside the board for at least one row of the tile
     int cost;                      // sum of popcount(tapmask)
+    int la, lb, lg, off;           // the residue function and the number of cells whose row is not = L (mod 8)
   };
+  static constexpr int lres(int a, int b, int g, int cell) {
+    const int bd = cell / P, q = cell % P;
+    return (a * (q % W) + b * (q / W) + g * bd) & 7;
+  }
   static constexpr int cls(int q) {
     const int x = q % W, y = q / W;
     if (W >= 2 && x == 0) return 1;
@@ -107,23 +123,85 @@ template <class Gm, int NTILES, int TBOARDS> struct Geo16 {
     }
     return cost;
   }
+  // class-ordered rows (as cost_of walks them), then inside every class segment cells and rows matched by residue
+  static constexpr int arrange(int order_code, int padpos, int a, int b, int g, bool same_taps, uint16_t (&out)[RPAD]) {
+    const Order o = order_of(order_code);
+    int v9[P] = {};
+    for (int q = 0; q < P; ++q) v9[q] = valid9(q);
+    uint16_t cells[RPAD] = {};
+    uint8_t res[RPAD] = {};
+    int r = 0, off = 0;
+    for (int ci = 0; ci < 5; ++ci) {
+      int n = 0;
+      for (int bd = 0; bd < TBOARDS; ++bd)
+        for (int q = 0; q < P; ++q) if (cls(q) == o.ord[ci]) { cells[n] = (uint16_t)(bd * P + q); res[n] = (uint8_t)lres(a, b, g, bd * P + q); ++n; }
+      // row r + i wants a cell with residue (r + i) & 7 -- any cell of the class, or (same_taps) only one with the tap set of
+      // the plain layout's cell i, which keeps every tile's tap mask exactly what cost_of priced
+      bool used[RPAD] = {};
+      for (int i = 0; i < n; ++i) {
+        const int want = (r + i) & 7, v = v9[cells[i] % P];
+        out[r + i] = 0xfffe;
+        for (int j = 0; j < n; ++j)
+          if (!used[j] && res[j] == want && (!same_taps || v9[cells[j] % P] == v)) { out[r + i] = cells[j]; used[j] = true; break; }
+      }
+      for (int i = 0; i < n; ++i) if (out[r + i] == 0xfffe) {        // left-overs: any cell of the same tap set
+        const int v = v9[cells[i] % P];
+        for (int j = 0; j < n; ++j) if (!used[j] && (!same_taps || v9[cells[j] % P] == v)) { out[r + i] = cells[j]; used[j] = true; ++off; break; }
+      }
+      r += n;
+      if (ci == padpos) for (int k = 0; k < NPADR; ++k) out[r++] = 0xffff;
+    }
+    return off;
+  }
+  static constexpr int products(const uint16_t (&pos)[RPAD]) {
+    int cost = 0;
+    for (int t = 0; t < NTILES; ++t) {
+      int m = 0;
+      for (int i = 0; i < 16; ++i) if (pos[t * 16 + i] != 0xffff) m |= valid9(pos[t * 16 + i] % P);
+      for (int tap = 0; tap < 9; ++tap) cost += (m >> tap) & 1;
+    }
+    return cost;
+  }
+  // cells that cannot sit on a row of their residue, by histograms only (cheap enough to try all 512 functions)
+  static constexpr int mismatch(int order_code, int padpos, int a, int b, int g) {
+    const Order o = order_of(order_code);
+    int r = 0, off = 0;
+    for (int ci = 0; ci < 5; ++ci) {
+      int have[8] = {}, n = 0;
+      for (int q = 0; q < P; ++q) if (cls(q) == o.ord[ci])
+        for (int bd = 0; bd < TBOARDS; ++bd) { have[(a * (q % W) + b * (q / W) + g * bd) & 7]++; ++n; }
+      for (int k = 0; k < 8; ++k) {
+        const int need = n / 8 + (((k - r) & 7) < n % 8 ? 1 : 0);    // rows r .. r + n - 1 with residue k
+        off += have[k] > need ? have[k] - need : 0;
+      }
+      r += n;
+      if (ci == padpos) r += NPADR;
+    }
+    return off;
+  }
   static constexpr Tab build(int order_code, int padpos) {
     Tab t{};
-    const Order o = order_of(order_code);
-    int r = 0;
-    for (int ci = 0; ci < 5; ++ci) {
-      for (int b = 0; b < TBOARDS; ++b)
-        for (int q = 0; q < P; ++q) if (cls(q) == o.ord[ci]) t.pos[r++] = (uint16_t)(b * P + q);
-      if (ci == padpos) for (int k = 0; k < NPADR; ++k) t.pos[r++] = 0xffff;
-    }
+    int ba = 0, bb = 0, bg = 0, boff = RPAD + 1;
+    for (int a = 0; a < 8; ++a)
+      for (int b = 0; b < 8; ++b)
+        for (int g = 0; g < 8; ++g) {
+          const int off = mismatch(order_code, padpos, a, b, g);
+          if (off < boff) { boff = off; ba = a; bb = b; bg = g; }
+        }
+    t.la = ba; t.lb = bb; t.lg = bg;
+    // free matching inside a class first; if that moved a corner cell into a tile whose mask it widens (one more product
+    // than the plain layout has), the matching restricted to equal tap sets
+    t.off = arrange(order_code, padpos, ba, bb, bg, false, t.pos);
+    if (products(t.pos) > cost_of(order_code, padpos)) t.off = arrange(order_code, padpos, ba, bb, bg, true, t.pos);
     uint16_t row_of[ROWS > 0 ? ROWS : 1] = {};
     for (int i = 0; i < RPAD; ++i) if (t.pos[i] != 0xffff) row_of[t.pos[i]] = (uint16_t)i;
     for (int i = 0; i < NTILES; ++i) t.tapmask[i] = 0;
     for (int i = 0; i < RPAD; ++i) {
       for (int tap = 0; tap < 9; ++tap) {
-        int nb = RPAD;
+        const int dx = tap % 3 - 1, dy = tap / 3 - 1;
+        int nb = RPAD + ((i + ba * dx + bb * dy + 16) & 7);            // the zero row with the residue the neighbour would have
         if (t.pos[i] != 0xffff) {
-          const int b = t.pos[i] / P, q = t.pos[i] % P, x = q % W + (tap % 3 - 1), y = q / W + (tap / 3 - 1);
+          const int b = t.pos[i] / P, q = t.pos[i] % P, x = q % W + dx, y = q / W + dy;
           if (x >= 0 && x < W && y >= 0 && y < H) { nb = row_of[b * P + y * W + x]; t.tapmask[i / 16] |= (uint16_t)(1u << tap); }
         }
         t.nbr[tap * RPAD + i] = (uint16_t)nb;
@@ -153,8 +231,8 @@ template <class Gm, int F = 64, int NT = 11> struct T16 {
   static constexpr int TB = RPAD / Gm::P;            // NT = 11: 4 Connect-Four boards, 19 Tic-tac-toe, 12 Mancala; NT = 3: 1, 5, 3
   static constexpr int ROWS = TB * Gm::P;
   static constexpr int STRIDE = F + 8;               // rows of 4 d dwords with d = 18 / 34: see posF
-  static constexpr int BUF = (RPAD + 1) * STRIDE;    // row RPAD = zeros
-  static constexpr int PLANES = (RPAD + 1) * Gm::C;
+  static constexpr int BUF = (RPAD + GEO_NZ) * STRIDE;   // rows RPAD .. RPAD + 7 = zeros
+  static constexpr int PLANES = (RPAD + GEO_NZ) * Gm::C;
   static constexpr int TABLE = (10 * RPAD + 1) / 2;  // floats holding nbr [9][RPAD] + pos [RPAD] as u16 (Geo16)
   static constexpr int BYTES = (BUF + PLANES + TABLE) * 4;   // 57 KB at F = 64 (2 workgroups per CU), 102 KB at F = 128 (1)
   static constexpr int WAVES = F / 16, THREADS = 64 * WAVES;
@@ -174,8 +252,8 @@ template <class Gm, int F = 64> struct T16P {
   static constexpr int TB = RPAD / Gm::P;
   static constexpr int ROWS = TB * Gm::P;
   static constexpr int STRIDE = F + 8;
-  static constexpr int BUF = (RPAD + 1) * STRIDE;
-  static constexpr int PLANES = (RPAD + 1) * Gm::C;
+  static constexpr int BUF = (RPAD + GEO_NZ) * STRIDE;
+  static constexpr int PLANES = (RPAD + GEO_NZ) * Gm::C;
   static constexpr int TABLE = (10 * RPAD + 1) / 2;
   static constexpr int BYTES = (BUF + PLANES + TABLE) * 4;
   static constexpr int CT = F / 16, WAVES = 2 * CT, THREADS = 64 * WAVES;
@@ -216,6 +294,10 @@ template <class G, int NT, int TILE0, int KH, int NTAP> struct Steps16 {
     int8_t next_tap[MAXS];                              // tap whose weights to request (-1: none)
     int8_t ord[MAXS];                                   // ordinal of the tap among the taps that have steps (weight stage = ord & 1)
     int8_t first_tap;
+    // the same list seen as units (tap, kh) -- for pipelines that stage the weights per 64-channel (fp32) / half-K (bf16) unit
+    int8_t ufirst[MAXS];                                // first step of its unit
+    int8_t unext_tap[MAXS], unext_kh[MAXS];             // the unit after this step's (-1: none)
+    int8_t uord[MAXS];                                  // ordinal of the unit
   };
   static constexpr L make() {
     L l{};
@@ -239,6 +321,10 @@ template <class G, int NT, int TILE0, int KH, int NTAP> struct Steps16 {
           l.first[k] = (kh == 0 && i == 0);
           l.next_tap[k] = (int8_t)(ti + 1 < ntaps ? taps[ti + 1] : -1);
           l.ord[k] = (int8_t)ti;
+          l.ufirst[k] = (i == 0);
+          l.unext_tap[k] = (int8_t)(kh + 1 < KH ? tap : (ti + 1 < ntaps ? taps[ti + 1] : -1));
+          l.unext_kh[k] = (int8_t)(kh + 1 < KH ? kh + 1 : 0);
+          l.uord[k] = (int8_t)(ti * KH + kh);
         }
     }
     return l;
@@ -580,7 +666,7 @@ __device__ __forceinline__ void tower16_fill(float* __restrict__ buf, float* __r
     }
     planes[i] = val;
   }
-  for (int i = tid; i < T::STRIDE; i += T::THREADS) buf[T::RPAD * T::STRIDE + i] = 0.0f;
+  for (int i = tid; i < GEO_NZ * T::STRIDE; i += T::THREADS) buf[T::RPAD * T::STRIDE + i] = 0.0f;
   for (int i = tid; i < T::RPAD; i += T::THREADS) pos[i] = geo[i];
   for (int i = tid; i < 9 * T::RPAD; i += T::THREADS) nbr[i] = geo[T::RPAD + i];
 }
@@ -692,7 +778,7 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
   const int nvalid = nb * P;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float4* in4 = (const float4*)(in + (size_t)board0 * P * F);
-  for (int idx = tid; idx < (T::RPAD + 1) * (F / 4); idx += T::THREADS) {
+  for (int idx = tid; idx < (T::RPAD + GEO_NZ) * (F / 4); idx += T::THREADS) {
     const int row = idx / (F / 4), c4 = idx % (F / 4);
     const int ps = row < T::RPAD ? (int)geo[row] : 0xffff;          // board * P + position of this buffer row
     const float4 v = ps < nvalid ? in4[(size_t)ps * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);

@@ -35,7 +35,7 @@ struct Net16bDev {
   const float* conv_ss;     // [2*nblocks][2][F]
   const bf16x8v* head_w;    // [F/16][F/32][64] x 8 bf16
   const float* head_ss;     // [2][F]
-  const uint16_t* geo[3];   // Geo16 tables (11-tile, 3-tile geometry; [2] unused)
+  const uint16_t* geo[3];   // Geo16 tables: [0] 11 tiles, [1] the latency variant's (NTS), [2] 22 tiles
   unsigned long long* dbg;  // optional [workgroups][8] cycle stamps, as Net16Dev::dbg (az_debug_tower_timeline)
 };
 
@@ -47,8 +47,8 @@ template <class Gm, int F = 128, int NT = 11> struct T16B {
   // with rows of 4 d dwords that needs { d lrow + g } distinct mod 16 -- d = 9 (F = 64: 144-byte rows) or 18 (F = 128:
   // 288-byte rows); 272-byte rows (d = 17) halve the rate (tools/probes/lds_conflict.hip)
   static constexpr int SH = F == 128 ? F + 16 : F + 8;
-  static constexpr int BUFH = (RPAD + 1) * SH;           // row RPAD = zeros
-  static constexpr int PLANES = (RPAD + 1) * Gm::C;      // fp32 input planes for the stem
+  static constexpr int BUFH = (RPAD + GEO_NZ) * SH;      // rows RPAD .. RPAD + 7 = zeros
+  static constexpr int PLANES = (RPAD + GEO_NZ) * Gm::C; // fp32 input planes for the stem
   static constexpr int TABLE = (10 * RPAD + 1) / 2;
   static constexpr int BYTES = BUFH * 2 + (PLANES + TABLE) * 4;
   static constexpr int WAVES = F / 16, THREADS = 64 * WAVES, CT = F / 16, KS = F / 32;
@@ -155,9 +155,97 @@ __device__ __forceinline__ void conv16b(const uint16_t* __restrict__ buf, const 
   }
 }
 
+// ---- the half-K pipeline (k_tower16b1) ----------------------------------------------------------------------------------
+// A wavefront that owns 11 row tiles x 2 column tiles holds 88 accumulator registers and 44 of skip input; with whole-tap
+// steps (32 registers of weights and 32 of activation rows, each double-buffered: 260 in all) the register allocator cannot
+// keep the two activation buffers apart, the reads of step k + 1 slide to the end of step k and every step starts by waiting
+// for LDS (ISA of the first k_tower16b1: ~120 of a step's 356 cycles; a lone wavefront drove the MFMA pipe at 66 %).  Here
+// a step is (tap, half of the input channels, tile pair): 8 MFMAs, 16 registers of weights and 16 of rows per stage, the
+// rows in a ring of NBUF stages (loads issued NBUF - 1 steps = 128 (NBUF - 1) MFMA cycles ahead), ~215 registers in all.
+template <class T>
+__device__ __forceinline__ void load_rows16c(const uint16_t* __restrict__ buf, int off0, int off1, bool two, int kh, int g, bf16x8v (&a)[2][T::KS / 2]) {
+  constexpr int KSH = T::KS / 2;
+  const uint16_t* p0 = buf + off0 + g * 8 + kh * KSH * 32;
+#pragma unroll
+  for (int j = 0; j < KSH; ++j) a[0][j] = *(const bf16x8v*)(p0 + j * 32);
+  if (two) {
+    const uint16_t* p1 = buf + off1 + g * 8 + kh * KSH * 32;
+#pragma unroll
+    for (int j = 0; j < KSH; ++j) a[1][j] = *(const bf16x8v*)(p1 + j * 32);
+  }
+}
+template <class T>
+__device__ __forceinline__ void load_w16c(const bf16x8v* __restrict__ wl, int tap, int kh, bf16x8v (&b)[2][T::KS / 2]) {
+  constexpr int KSH = T::KS / 2;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int j = 0; j < KSH; ++j) b[ct][j] = wl[(size_t)((tap * T::CT + ct) * T::KS + kh * KSH + j) * 64];
+}
+template <class T, class SL, int K, int TILE0>
+__device__ __forceinline__ void issue_rows16c(const uint16_t* __restrict__ buf, int g, const int (&idx)[2], bf16x8v (&a)[2][T::KS / 2]) {
+  if constexpr (K < SL::list.n) load_rows16c<T>(buf, idx[0], idx[1], SL::list.t1[K] >= 0, SL::list.kh[K], g, a);
+}
+// offsets are looked up LA = 2 steps before the reads that use them: under two workgroups' traffic an LDS round trip is
+// longer than one 8-MFMA step (with LA = 1 every step began with s_waitcnt on a look-up issued 3 MFMAs earlier)
+template <class T, class SL, int NT, int TILE0, int NTAP, int NBUF, int K>
+__device__ __forceinline__ void conv16c_steps(const uint16_t* __restrict__ buf, const uint16_t* __restrict__ nbr, const bf16x8v* __restrict__ wl,
+                                              f32x4v (&acc)[NT][2], int lrow, int g, bf16x8v (&b)[2][2][T::KS / 2],
+                                              bf16x8v (&a)[NBUF][2][T::KS / 2], int (&idx)[4][2]) {
+  if constexpr (K < SL::list.n) {
+    constexpr int t0 = SL::list.t0[K], t1 = SL::list.t1[K], uo = SL::list.uord[K], KSH = T::KS / 2, R = K + NBUF - 1;
+    if constexpr (SL::list.ufirst[K] && SL::list.unext_tap[K] >= 0)
+      load_w16c<T>(wl, NTAP == 1 ? 0 : SL::list.unext_tap[K], SL::list.unext_kh[K], b[(uo + 1) & 1]);
+    // rows of step R = K + NBUF - 1 into the stage step K - 1 has just left (offsets looked up two steps ago), then the
+    // offsets of step R + 2
+    issue_rows16c<T, SL, R, TILE0>(buf, g, idx[R % 4], a[R % NBUF]);
+    load_idx16b<T, SL, R + 2, TILE0>(nbr, lrow, idx[(R + 2) % 4]);
+    bf16x8v (&cur)[2][KSH] = a[K % NBUF];
+    bf16x8v (&bc)[2][KSH] = b[uo & 1];
+#pragma unroll
+    for (int j = 0; j < KSH; ++j) {
+      acc[t0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[0][j], bc[0][j], acc[t0][0], 0, 0, 0);
+      acc[t0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[0][j], bc[1][j], acc[t0][1], 0, 0, 0);
+      if constexpr (t1 >= 0) {
+        acc[t1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[1][j], bc[0][j], acc[t1][0], 0, 0, 0);
+        acc[t1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[1][j], bc[1][j], acc[t1][1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    conv16c_steps<T, SL, NT, TILE0, NTAP, NBUF, K + 1>(buf, nbr, wl, acc, lrow, g, b, a, idx);
+  }
+}
+template <class T, class SL, int TILE0, int NBUF, int J>
+__device__ __forceinline__ void conv16c_prologue(const uint16_t* __restrict__ buf, const uint16_t* __restrict__ nbr, int lrow, int g,
+                                                 bf16x8v (&a)[NBUF][2][T::KS / 2], int (&idx)[4][2]) {
+  // stages 0 .. NBUF - 2 filled, offsets of steps NBUF - 1 and NBUF looked up
+  if constexpr (J < NBUF - 1) {
+    load_idx16b<T, SL, J, TILE0>(nbr, lrow, idx[J % 4]);
+    issue_rows16c<T, SL, J, TILE0>(buf, g, idx[J % 4], a[J]);
+    conv16c_prologue<T, SL, TILE0, NBUF, J + 1>(buf, nbr, lrow, g, a, idx);
+  } else {
+    load_idx16b<T, SL, NBUF - 1, TILE0>(nbr, lrow, idx[(NBUF - 1) % 4]);
+    load_idx16b<T, SL, NBUF, TILE0>(nbr, lrow, idx[NBUF % 4]);
+  }
+}
+template <class T, class G, int NT, int TILE0, int NTAP, int NBUF = 3>
+__device__ __forceinline__ void conv16c(const uint16_t* __restrict__ buf, const uint16_t* __restrict__ nbr, const bf16x8v* __restrict__ wl,
+                                        f32x4v (&acc)[NT][2], int lrow, int g) {
+  using SL = Steps16<G, NT, TILE0, 2, NTAP>;                        // one step = (tap, half of K, tile pair)
+  static_assert(NBUF >= 2 && NBUF <= 4, "ring of 2..4 stages (the offset ring has 4 entries)");
+  if constexpr (SL::list.n > 0) {
+    bf16x8v b[2][2][T::KS / 2], a[NBUF][2][T::KS / 2];
+    int idx[4][2] = {};
+    load_w16c<T>(wl, NTAP == 1 ? 0 : SL::list.first_tap, 0, b[0]);
+    conv16c_prologue<T, SL, TILE0, NBUF, 0>(buf, nbr, lrow, g, a, idx);
+    __builtin_amdgcn_sched_barrier(0);
+    conv16c_steps<T, SL, NT, TILE0, NTAP, NBUF, 0>(buf, nbr, wl, acc, lrow, g, b, a, idx);
+  }
+}
+
 // One wavefront's share: row tiles TILE0 .. TILE0 + NT - 1 of the workgroup's buffer, output channels 32 cg .. 32 cg + 31
 // (two column tiles).  Every wavefront of the workgroup runs the same number of barriers.
-template <class T, int NT, int TILE0>
+template <class T, int NT, int TILE0, int PIPE = 0>
 __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __restrict__ buf, const float* __restrict__ planes,
                                               const uint16_t* __restrict__ nbr, const uint16_t* __restrict__ pos, int cg, int lane,
                                               int n, int board0, float* __restrict__ hfeat) {
@@ -213,7 +301,8 @@ __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __
     for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
     int lrow_l = lrow;
     asm volatile("" : "+v"(lrow_l));                                // keeps the table look-ups inside the layer loop (registers)
-    conv16b<T, G, NT, TILE0, 9>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow_l, g);
+    if constexpr (PIPE > 0) conv16c<T, G, NT, TILE0, 9, PIPE>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow_l, g);
+    else conv16b<T, G, NT, TILE0, 9>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow_l, g);
     if (layer == 2) AZ_STAMP16B(4);
     __syncthreads();                                                // every wave has finished reading the buffer
     if (layer == 2) AZ_STAMP16B(5);
@@ -244,7 +333,8 @@ __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __
   // ---- both 1x1 head convolutions + BN + ReLU, features out in fp32 -------------------------------------------------------------
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
-  conv16b<T, G, NT, TILE0, 1>(buf, nbr, net.head_w + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow, g);
+  if constexpr (PIPE > 0) conv16c<T, G, NT, TILE0, 1, PIPE>(buf, nbr, net.head_w + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow, g);
+  else conv16b<T, G, NT, TILE0, 1>(buf, nbr, net.head_w + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow, g);
   {
     const int nvalid = ((n - board0) < TB ? (n - board0) : TB) * P;
 #pragma unroll
@@ -279,7 +369,7 @@ k_tower16b(Net16bDev net, const GEnv* __restrict__ leaf_env, const int* __restri
   const int board0 = blockIdx.x * TB;
   if (board0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint16_t* geo = net.geo[NT == 11 ? 0 : 1];
+  const uint16_t* geo = net.geo[NT == 11 ? 0 : NT == 22 ? 2 : 1];
   // ---- input planes (fp32, permuted row order), tables, the buffer's zero row -------------------------------------------
   for (int i = tid; i < T::PLANES; i += T::THREADS) {
     const int row = i / C, c = i % C;
@@ -294,7 +384,7 @@ k_tower16b(Net16bDev net, const GEnv* __restrict__ leaf_env, const int* __restri
     }
     planes[i] = val;
   }
-  for (int i = tid; i < SH; i += T::THREADS) buf[T::RPAD * SH + i] = 0;
+  for (int i = tid; i < GEO_NZ * SH; i += T::THREADS) buf[T::RPAD * SH + i] = 0;
   for (int i = tid; i < T::RPAD; i += T::THREADS) pos[i] = geo[i];
   for (int i = tid; i < 9 * T::RPAD; i += T::THREADS) nbr[i] = geo[T::RPAD + i];
   __syncthreads();
@@ -302,4 +392,46 @@ k_tower16b(Net16bDev net, const GEnv* __restrict__ leaf_env, const int* __restri
   // output channels, so an activation fragment read from LDS feeds two MFMAs
   if (wave < NCG) tower16b_wave<T, NT0, 0>(net, buf, planes, nbr, pos, wave, lane, n, board0, hfeat);
   else tower16b_wave<T, NT1, NT0>(net, buf, planes, nbr, pos, wave - NCG, lane, n, board0, hfeat);
+}
+
+// One row group (k_tower16b1, 128 filters): F / 32 = 4 wavefronts, each owns ALL row tiles x 32 output channels -- the
+// per-wavefront shape of the 22-tile kernel above (11 tiles x 2 column tiles: a weight fragment serves 11 row tiles, half
+// the weight stream per board of the two-row-group form), but 4 boards and 57 KB of LDS per workgroup: TWO workgroups share
+// a CU, one wavefront of each per SIMD (2 x 253 VGPRs).  They drift out of phase, so the barriers and the epilogue of one
+// run under the MFMAs of the other -- the fp32 tower's arrangement (k_tower16, resnet16.h), which the 8-wave forms cannot
+// have -- and two slot groups' towers interleave on a CU as well.
+template <class Gm, int F, bool FROM_PLANES, int NT = 11, int PIPE = 3>
+__global__ void __launch_bounds__(64 * (F / 32), 2)
+k_tower16b1(Net16bDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
+  using T = T16B<Gm, F, NT>;
+  constexpr int P = Gm::P, C = Gm::C, TB = T::TB, SH = T::SH, THREADS = 64 * (F / 32);
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  uint16_t* buf = (uint16_t*)ldsb;
+  float* planes = (float*)(ldsb + (size_t)T::BUFH * 2);
+  uint16_t* nbr = (uint16_t*)(planes + T::PLANES);
+  uint16_t* pos = nbr + 9 * T::RPAD;
+  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
+  const int board0 = blockIdx.x * TB;
+  if (board0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint16_t* geo = net.geo[NT == 11 ? 0 : NT == 22 ? 2 : 1];
+  for (int i = tid; i < T::PLANES; i += THREADS) {
+    const int row = i / C, c = i % C;
+    float val = 0.0f;
+    if (row < T::RPAD) {
+      const int ps = geo[row];
+      if (ps != 0xffff && board0 + ps / P < n) {
+        const int b = ps / P, q = ps % P;
+        if (FROM_PLANES) val = X[((size_t)(board0 + b) * C + c) * P + q];
+        else val = Gm::plane(leaf_env[eval_slots[board0 + b]], q, c);
+      }
+    }
+    planes[i] = val;
+  }
+  for (int i = tid; i < GEO_NZ * SH; i += THREADS) buf[T::RPAD * SH + i] = 0;
+  for (int i = tid; i < T::RPAD; i += THREADS) pos[i] = geo[i];
+  for (int i = tid; i < 9 * T::RPAD; i += THREADS) nbr[i] = geo[T::RPAD + i];
+  __syncthreads();
+  tower16b_wave<T, NT, 0, PIPE>(net, buf, planes, nbr, pos, wave, lane, n, board0, hfeat);
 }
