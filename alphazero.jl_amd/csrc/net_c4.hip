@@ -49,7 +49,7 @@ static int tower_timeline_split(az_engine* e, int32_t n, unsigned long long* out
   (void)hipFree(d);
   return AZ_OK;
 }
-template <int F, bool ONE = false> static int tower_timeline_bf16(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
+template <int F> static int tower_timeline_bf16(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {
   using T = T16B<ConnectFour, F, 11>;
   const int nb = (n + T::TB - 1) / T::TB;
   if (cap < (int64_t)nb * 8) return fail(AZ_ERR_CAPACITY, "need %d words", nb * 8);
@@ -61,8 +61,7 @@ template <int F, bool ONE = false> static int tower_timeline_bf16(az_engine* e, 
   Net16bDev nd = e->net16b;
   for (int rep = 0; rep < 2; ++rep) {
     nd.dbg = rep ? d : nullptr;
-    if constexpr (ONE) hipLaunchKernelGGL((k_tower16b1<ConnectFour, F, false, 11>), dim3(nb), dim3(64 * (F / 32)), T::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat);
-    else hipLaunchKernelGGL((k_tower16b<ConnectFour, F, false, 11>), dim3(nb), dim3(T::THREADS), T::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat);
+    hipLaunchKernelGGL((k_tower16b<ConnectFour, F, false, 11>), dim3(nb), dim3(T::THREADS), T::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat);
   }
   HIPCHK(hipMemcpyAsync(out, d, sizeof(unsigned long long) * nb * 8, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -132,7 +131,6 @@ extern "C" int az_debug_heads_timeline(az_engine* e, int32_t n, unsigned long lo
 extern "C" int az_debug_tower_timeline(az_engine* e, int32_t n, int32_t nt, unsigned long long* out, int64_t cap) {
   ENGINE(e);
   if (!e->net_loaded || n < 1 || n > e->nn_cap) return fail(AZ_ERR_BAD_ARG, "bad n / no net");
-  if (e->cfg.game == AZ_GAME_CONNECT_FOUR && e->cfg.net_bf16 && nt == 41 && e->cfg.num_filters == 128) return tower_timeline_bf16<128, true>(e, n, out, cap);
   if (e->cfg.game == AZ_GAME_CONNECT_FOUR && e->cfg.net_bf16 && nt == 11) return e->cfg.num_filters == 128 ? tower_timeline_bf16<128>(e, n, out, cap) : tower_timeline_bf16<64>(e, n, out, cap);
   if (e->cfg.game != AZ_GAME_CONNECT_FOUR || e->cfg.net_bf16 || (nt != 11 && nt != 3 && nt != 2)) return fail(AZ_ERR_BAD_ARG, "connect-four; fp32: nt = 11, 3 or 2 (= split tower), bf16: nt = 11");
   if (nt == 2) return e->cfg.num_filters == 128 ? tower_timeline_split(e, n, out, cap) : fail(AZ_ERR_BAD_ARG, "split tower: 128 filters");

@@ -17,13 +17,6 @@ template <class Gm, int F, bool PLANES_ONLY = false> static int set_kernel_attrs
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, NTS<Gm>>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, NTS<Gm>>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, NTS<Gm>>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, NTS<Gm>>::BYTES));
   if constexpr (F == 128) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b1<Gm, F, false, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b1<Gm, F, true, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
-    if constexpr (std::is_same<Gm, ConnectFour>::value) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b1<Gm, F, false, 11, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b1<Gm, F, false, 11, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b1<Gm, F, false, 11, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
-    }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, 22>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 22>::BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, 22>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 22>::BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16s<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16S<Gm, F>::BYTES));
@@ -72,7 +65,6 @@ template <class Gm> static int set_kernel_attrs(az_engine* e) {
 static void note_tower(az_engine* e, int tw, int F) {
   static const char* const gn[] = {"ConnectFour", "TicTacToe", "Mancala", "Go9Planes"};
   const char* g = gn[e->cfg.game];
-  if (e->cfg.net_bf16 && tw >= 40 && tw <= 43) { snprintf(e->last_tower, sizeof e->last_tower, "k_tower16b1<%s,%d,NT=11,PIPE=%d>", g, F, tw == 40 ? 0 : tw == 41 ? 3 : tw == 42 ? 4 : 2); return; }
   if (e->cfg.net_bf16) { snprintf(e->last_tower, sizeof e->last_tower, "k_tower16b<%s,%d,NT=%d>", g, F, tw == 3 ? e->nts : tw == 22 ? 22 : 11); return; }
   if (tw == 2) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16s<%s,%d>", g, F);
   else if (tw == 21) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d>", g, F);
@@ -98,12 +90,22 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
   if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64))) return e->tower_pick;
   if (e->cfg.net_bf16) {                                           // k_tower16b: 22 (128 filters), 11 or 3 row tiles
     if (e->tower_pick == 3 || e->tower_pick == 16) return e->tower_pick;
-    if ((e->tower_pick == 22 || (e->tower_pick >= 40 && e->tower_pick <= 43)) && F == 128) return e->tower_pick;
+    if (e->tower_pick == 22 && F == 128) return 22;
     const long cu2 = e->num_cu > 0 ? e->num_cu : 256;
     const long a16 = (n + T16B<Gm, F>::TB - 1) / T16B<Gm, F>::TB, a3 = (n + T16B<Gm, F, NTS<Gm>>::TB - 1) / T16B<Gm, F, NTS<Gm>>::TB;
     const long per = F == 64 ? 2 : 1;                               // workgroups per CU
-    const double d16 = (double)((a16 + per * cu2 - 1) / (per * cu2)) * T16B<Gm, F>::RPAD;
-    const double d3 = 1.1 * (double)((a3 + per * cu2 - 1) / (per * cu2)) * T16B<Gm, F, NTS<Gm>>::RPAD;
+    // rounds x rows per workgroup x fraction of the tile-tap products executed (Geo16)
+    constexpr double g16 = T16B<Gm, F>::Geo::tab.cost / (9.0 * 11), g3 = T16B<Gm, F, NTS<Gm>>::Geo::tab.cost / (9.0 * NTS<Gm>);
+    const double d16 = (double)((a16 + per * cu2 - 1) / (per * cu2)) * T16B<Gm, F>::RPAD * g16;
+    const double d3 = 1.1 * (double)((a3 + per * cu2 - 1) / (per * cu2)) * T16B<Gm, F, NTS<Gm>>::RPAD * g3;
+    if constexpr (F == 128) {
+      // 22 row tiles = twice the boards per workgroup: each weight fragment serves twice the rows (10x128, 4096 boards: 578
+      // vs 684 us); only where it does not leave CUs idle that the 11-tile form would use
+      constexpr double g22 = T16B<Gm, F, 22>::Geo::tab.cost / (9.0 * 22);
+      const long a22 = (n + T16B<Gm, F, 22>::TB - 1) / T16B<Gm, F, 22>::TB;
+      const double d22 = 0.9 * (double)((a22 + cu2 - 1) / cu2) * T16B<Gm, F, 22>::RPAD * g22;
+      if (d22 <= d16 && d22 <= d3) return 22;
+    }
     return d3 <= d16 ? 3 : 16;
   }
   const long cu = e->num_cu > 0 ? e->num_cu : 256;
@@ -185,9 +187,7 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
   note_tower(e, tw, F);
   if (e->cfg.net_bf16) {
     constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, NTS<Gm>>::TB, LDSb3 = T16B<Gm, F, NTS<Gm>>::BYTES;
-    if (tw >= 40 && tw <= 43) {
-      if constexpr (F == 128) LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b1<Gm, F, FROM_PLANES, 11>), (n_max + TBb - 1) / TBb, 64 * (F / 32), LDSb, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
-    } else if (tw == 22) {
+    if (tw == 22) {
       constexpr int TB22 = T16B<Gm, F, 22>::TB, LDS22 = T16B<Gm, F, 22>::BYTES;
       if constexpr (F == 128) LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b<Gm, F, FROM_PLANES, 22>), (n_max + TB22 - 1) / TB22, THRb, LDS22, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
     } else if (tw == 3) LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16b<Gm, F, FROM_PLANES, NTS<Gm>>), (n_max + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, envs, eslots, n_ptr, n_max, X, hfeat);
@@ -236,17 +236,7 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   note_tower(e, tw, F);
   if (e->cfg.net_bf16) {
     constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, NTS<Gm>>::TB, LDSb3 = T16B<Gm, F, NTS<Gm>>::BYTES;
-    if (tw >= 40 && tw <= 43) {
-      if constexpr (F == 128) {
-        // A/B variants of the pipeline (Connect-Four wave path only): 40 = whole-tap steps, 43 / 41 / 42 = half-K ring of 2 / 3 / 4 stages
-        if constexpr (std::is_same<Gm, ConnectFour>::value) {
-          if (tw == 40) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b1<Gm, F, false, 11, 0>), (N + TBb - 1) / TBb, 64 * (F / 32), LDSb, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
-          else if (tw == 42) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b1<Gm, F, false, 11, 4>), (N + TBb - 1) / TBb, 64 * (F / 32), LDSb, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
-          else if (tw == 43) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b1<Gm, F, false, 11, 2>), (N + TBb - 1) / TBb, 64 * (F / 32), LDSb, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
-          else LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b1<Gm, F, false, 11>), (N + TBb - 1) / TBb, 64 * (F / 32), LDSb, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
-        } else LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b1<Gm, F, false, 11>), (N + TBb - 1) / TBb, 64 * (F / 32), LDSb, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
-      }
-    } else if (tw == 22) {
+    if (tw == 22) {
       constexpr int TB22 = T16B<Gm, F, 22>::TB, LDS22 = T16B<Gm, F, 22>::BYTES;
       if constexpr (F == 128) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 22>), (N + TB22 - 1) / TB22, THRb, LDS22, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
     } else if (tw == 3) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, NTS<Gm>>), (N + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);

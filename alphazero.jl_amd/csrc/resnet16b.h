@@ -6,9 +6,9 @@
 // column tiles): with 16x the MFMA rate of fp32 the LDS reads of the activations are what binds, and every fragment read
 // now feeds two MFMAs (the first version, 16 channels x all tiles per wave, re-read each row 8 times per tap at F = 128).
 // What differs:
-//   * activations live in LDS as bf16 ([RPAD + 1][SH], 288-byte rows at F = 128), weights are bf16 fragments, accumulation
+//   * activations live in LDS as bf16 ([RPAD + 8][SH], 288-byte rows at F = 128), weights are bf16 fragments, accumulation
 //     is fp32 in the MFMA (at F = 128 the kernel needs 192 VGPRs, so ONE 8-wave workgroup runs per CU and nothing covers its
-//     barriers and epilogue: 5.7 k of a layer's 18 k cycles; forcing 128 VGPRs spills 468 registers);
+//     barriers and epilogue; forcing 128 VGPRs spills 468 registers);
 //     the folded batch norm, the residual add and the ReLU run in fp32 on the accumulators and the result is rounded to
 //     bf16 (round to nearest even, v_cvt_pk_bf16_f32) when it is written back -- the skip connection adds the ROUNDED
 //     block input, i.e. exactly what the next convolution reads;
@@ -17,6 +17,19 @@
 //     hardware's pairing of k within a group is irrelevant because A and B use the same one;
 //   * the stem (K = 27) stays on the fp32 MFMA with the fp32 planes (it is 0.1 % of the work), the head features leave
 //     in fp32 for k_heads_mfma, so everything outside the tower is unchanged.
+// Round 3 (10x128, 4096 boards: 753 -> 578 us per launch = 1.76 PFLOP/s = 70 % of the nominal bf16 peak, 86 % of the
+// 2.05 PFLOP/s the chip sustains at the ~2.0 GHz it holds under matrix load, tools/probes/mfma_sustained.hip):
+//   * NT = 22: 8 Connect-Four boards per workgroup, a wavefront = 11 row tiles x 2 column tiles: the weight fragments of a
+//     tap serve twice as many rows (the vector-memory path delivers ~71 B/clk per CU, tools/probes/l1_bw.hip, and the
+//     4-board form asked it for 45), 253-256 VGPRs, no spill;
+//   * Geo16 places the rows so that tap-shifted gathers are bank-conflict free (resnet16.h): the LDS reads of the A operand,
+//     at 98 % of the LDS cycle budget when the MFMA pipe is full, ran at 59 % of the LDS rate before;
+//   * branch-free epilogue (store_bf16x4): 4.9 k -> 2.5 k cycles per layer and wavefront pair.
+//   Measured and not kept: one row group per workgroup with two workgroups per CU (4 waves x 253 VGPRs each, the fp32
+//   tower's arrangement: 609 us -- with both workgroups in their convolutions the LDS reads bind, not the MFMA pipe);
+//   steps of half a tap's input channels with the rows in a ring of 2-4 register stages and look-ups two steps ahead
+//   (no measurable change: 670 vs 669 us); 64 output channels per wavefront (halves the LDS reads, doubles the weight
+//   stream to 91 B/clk per CU: more than the path delivers).
 // Numerics: NOT the fp32 contract.  tests/test_net_bf16_gpu.py holds it to (a) a torch emulation of exactly this scheme
 // (bf16-rounded weights and activations, wide accumulation) within 2e-3 and (b) the fp32 oracle within the stated bf16
 // tolerance; searches run with it are deterministic but not comparable move for move with the fp32 oracle.
@@ -66,19 +79,30 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __builtin
 // The lanes of channels c and c + 1 (lrow even / odd) swap halves through DPP so that each writes TWO 32-bit words
 // (channels c, c + 1 of one row) instead of four 16-bit ones: half the LDS instructions and no two lanes on one dword
 // (the 16-bit version of this epilogue took 6.4 k of a layer's 19.9 k cycles at 10x128, tools/tower_timeline.py --bf16).
-template <class T>
-__device__ __forceinline__ void store_bf16x4(uint16_t* __restrict__ buf, int row0, int ch, int lrow, const float (&v)[4], uint32_t (&packed)[2]) {
-  packed[0] = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-  packed[1] = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+// Round 3: branch free.  The even / odd cases were two exec-masked blocks and ~25 VALU instructions per call; now the lane
+// keeps `mine` (even: rows 0, 1; odd: rows 2, 3), sends the other pair, and two v_perm_b32 with per-lane selectors
+// (EpiSel, computed once per wavefront) interleave the halves: 2 cvt + 2 select + 1 DPP + 2 perm + 1 ds_write2.
+struct EpiSel { uint32_t s0, s1; bool odd; };
+__device__ __forceinline__ EpiSel epi_sel(int lrow) {
+  // v_perm_b32(a, b, sel): result byte i = byte sel[i] of {a (bytes 4..7), b (bytes 0..3)}; here a = received, b = mine
   const bool odd = lrow & 1;
-  const uint32_t send = odd ? packed[0] : packed[1];
+  // even lane: w0 = lo(mine) | lo(recv) << 16, w1 = hi(mine) | hi(recv) << 16;  odd lane: w0 = lo(recv) | lo(mine) << 16, w1 = hi(recv) | hi(mine) << 16
+  return EpiSel{odd ? 0x01000504u : 0x05040100u, odd ? 0x03020706u : 0x07060302u, odd};
+}
+template <class T>
+__device__ __forceinline__ void store_bf16x4(uint16_t* __restrict__ dst, const EpiSel& es, const float (&v)[4], uint32_t (&packed)[2]) {
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  packed[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2v{v[0], v[1]}, bf16x2v));
+  packed[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2v{v[2], v[3]}, bf16x2v));
+  const uint32_t mine = es.odd ? packed[1] : packed[0], send = es.odd ? packed[0] : packed[1];
   const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, false);     // quad_perm [1, 0, 3, 2]: lane ^ 1
-  uint32_t w0, w1;
-  if (!odd) { w0 = (packed[0] & 0xffffu) | (recv << 16); w1 = (packed[0] >> 16) | (recv & 0xffff0000u); }
-  else { w0 = (recv & 0xffffu) | (packed[1] << 16); w1 = (recv >> 16) | (packed[1] & 0xffff0000u); }
-  uint16_t* dst = buf + (row0 + (odd ? 2 : 0)) * T::SH + (ch & ~1);
-  *(uint32_t*)dst = w0;
-  *(uint32_t*)(dst + T::SH) = w1;
+  *(uint32_t*)dst = __builtin_amdgcn_perm(recv, mine, es.s0);
+  *(uint32_t*)(dst + T::SH) = __builtin_amdgcn_perm(recv, mine, es.s1);
+}
+// buffer address of the words a lane writes for (row0, ch): rows row0 (+ 2 for odd lanes), channels ch & ~1
+template <class T> __device__ __forceinline__ uint16_t* epi_dst(uint16_t* __restrict__ buf, int row0, int ch, bool odd) {
+  return buf + (row0 + (odd ? 2 : 0)) * T::SH + (ch & ~1);
 }
 
 // activation rows of one step: KS fragments of 8 channels per tile
@@ -155,97 +179,9 @@ __device__ __forceinline__ void conv16b(const uint16_t* __restrict__ buf, const 
   }
 }
 
-// ---- the half-K pipeline (k_tower16b1) ----------------------------------------------------------------------------------
-// A wavefront that owns 11 row tiles x 2 column tiles holds 88 accumulator registers and 44 of skip input; with whole-tap
-// steps (32 registers of weights and 32 of activation rows, each double-buffered: 260 in all) the register allocator cannot
-// keep the two activation buffers apart, the reads of step k + 1 slide to the end of step k and every step starts by waiting
-// for LDS (ISA of the first k_tower16b1: ~120 of a step's 356 cycles; a lone wavefront drove the MFMA pipe at 66 %).  Here
-// a step is (tap, half of the input channels, tile pair): 8 MFMAs, 16 registers of weights and 16 of rows per stage, the
-// rows in a ring of NBUF stages (loads issued NBUF - 1 steps = 128 (NBUF - 1) MFMA cycles ahead), ~215 registers in all.
-template <class T>
-__device__ __forceinline__ void load_rows16c(const uint16_t* __restrict__ buf, int off0, int off1, bool two, int kh, int g, bf16x8v (&a)[2][T::KS / 2]) {
-  constexpr int KSH = T::KS / 2;
-  const uint16_t* p0 = buf + off0 + g * 8 + kh * KSH * 32;
-#pragma unroll
-  for (int j = 0; j < KSH; ++j) a[0][j] = *(const bf16x8v*)(p0 + j * 32);
-  if (two) {
-    const uint16_t* p1 = buf + off1 + g * 8 + kh * KSH * 32;
-#pragma unroll
-    for (int j = 0; j < KSH; ++j) a[1][j] = *(const bf16x8v*)(p1 + j * 32);
-  }
-}
-template <class T>
-__device__ __forceinline__ void load_w16c(const bf16x8v* __restrict__ wl, int tap, int kh, bf16x8v (&b)[2][T::KS / 2]) {
-  constexpr int KSH = T::KS / 2;
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int j = 0; j < KSH; ++j) b[ct][j] = wl[(size_t)((tap * T::CT + ct) * T::KS + kh * KSH + j) * 64];
-}
-template <class T, class SL, int K, int TILE0>
-__device__ __forceinline__ void issue_rows16c(const uint16_t* __restrict__ buf, int g, const int (&idx)[2], bf16x8v (&a)[2][T::KS / 2]) {
-  if constexpr (K < SL::list.n) load_rows16c<T>(buf, idx[0], idx[1], SL::list.t1[K] >= 0, SL::list.kh[K], g, a);
-}
-// offsets are looked up LA = 2 steps before the reads that use them: under two workgroups' traffic an LDS round trip is
-// longer than one 8-MFMA step (with LA = 1 every step began with s_waitcnt on a look-up issued 3 MFMAs earlier)
-template <class T, class SL, int NT, int TILE0, int NTAP, int NBUF, int K>
-__device__ __forceinline__ void conv16c_steps(const uint16_t* __restrict__ buf, const uint16_t* __restrict__ nbr, const bf16x8v* __restrict__ wl,
-                                              f32x4v (&acc)[NT][2], int lrow, int g, bf16x8v (&b)[2][2][T::KS / 2],
-                                              bf16x8v (&a)[NBUF][2][T::KS / 2], int (&idx)[4][2]) {
-  if constexpr (K < SL::list.n) {
-    constexpr int t0 = SL::list.t0[K], t1 = SL::list.t1[K], uo = SL::list.uord[K], KSH = T::KS / 2, R = K + NBUF - 1;
-    if constexpr (SL::list.ufirst[K] && SL::list.unext_tap[K] >= 0)
-      load_w16c<T>(wl, NTAP == 1 ? 0 : SL::list.unext_tap[K], SL::list.unext_kh[K], b[(uo + 1) & 1]);
-    // rows of step R = K + NBUF - 1 into the stage step K - 1 has just left (offsets looked up two steps ago), then the
-    // offsets of step R + 2
-    issue_rows16c<T, SL, R, TILE0>(buf, g, idx[R % 4], a[R % NBUF]);
-    load_idx16b<T, SL, R + 2, TILE0>(nbr, lrow, idx[(R + 2) % 4]);
-    bf16x8v (&cur)[2][KSH] = a[K % NBUF];
-    bf16x8v (&bc)[2][KSH] = b[uo & 1];
-#pragma unroll
-    for (int j = 0; j < KSH; ++j) {
-      acc[t0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[0][j], bc[0][j], acc[t0][0], 0, 0, 0);
-      acc[t0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[0][j], bc[1][j], acc[t0][1], 0, 0, 0);
-      if constexpr (t1 >= 0) {
-        acc[t1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[1][j], bc[0][j], acc[t1][0], 0, 0, 0);
-        acc[t1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[1][j], bc[1][j], acc[t1][1], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    conv16c_steps<T, SL, NT, TILE0, NTAP, NBUF, K + 1>(buf, nbr, wl, acc, lrow, g, b, a, idx);
-  }
-}
-template <class T, class SL, int TILE0, int NBUF, int J>
-__device__ __forceinline__ void conv16c_prologue(const uint16_t* __restrict__ buf, const uint16_t* __restrict__ nbr, int lrow, int g,
-                                                 bf16x8v (&a)[NBUF][2][T::KS / 2], int (&idx)[4][2]) {
-  // stages 0 .. NBUF - 2 filled, offsets of steps NBUF - 1 and NBUF looked up
-  if constexpr (J < NBUF - 1) {
-    load_idx16b<T, SL, J, TILE0>(nbr, lrow, idx[J % 4]);
-    issue_rows16c<T, SL, J, TILE0>(buf, g, idx[J % 4], a[J]);
-    conv16c_prologue<T, SL, TILE0, NBUF, J + 1>(buf, nbr, lrow, g, a, idx);
-  } else {
-    load_idx16b<T, SL, NBUF - 1, TILE0>(nbr, lrow, idx[(NBUF - 1) % 4]);
-    load_idx16b<T, SL, NBUF, TILE0>(nbr, lrow, idx[NBUF % 4]);
-  }
-}
-template <class T, class G, int NT, int TILE0, int NTAP, int NBUF = 3>
-__device__ __forceinline__ void conv16c(const uint16_t* __restrict__ buf, const uint16_t* __restrict__ nbr, const bf16x8v* __restrict__ wl,
-                                        f32x4v (&acc)[NT][2], int lrow, int g) {
-  using SL = Steps16<G, NT, TILE0, 2, NTAP>;                        // one step = (tap, half of K, tile pair)
-  static_assert(NBUF >= 2 && NBUF <= 4, "ring of 2..4 stages (the offset ring has 4 entries)");
-  if constexpr (SL::list.n > 0) {
-    bf16x8v b[2][2][T::KS / 2], a[NBUF][2][T::KS / 2];
-    int idx[4][2] = {};
-    load_w16c<T>(wl, NTAP == 1 ? 0 : SL::list.first_tap, 0, b[0]);
-    conv16c_prologue<T, SL, TILE0, NBUF, 0>(buf, nbr, lrow, g, a, idx);
-    __builtin_amdgcn_sched_barrier(0);
-    conv16c_steps<T, SL, NT, TILE0, NTAP, NBUF, 0>(buf, nbr, wl, acc, lrow, g, b, a, idx);
-  }
-}
-
 // One wavefront's share: row tiles TILE0 .. TILE0 + NT - 1 of the workgroup's buffer, output channels 32 cg .. 32 cg + 31
 // (two column tiles).  Every wavefront of the workgroup runs the same number of barriers.
-template <class T, int NT, int TILE0, int PIPE = 0>
+template <class T, int NT, int TILE0>
 __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __restrict__ buf, const float* __restrict__ planes,
                                               const uint16_t* __restrict__ nbr, const uint16_t* __restrict__ pos, int cg, int lane,
                                               int n, int board0, float* __restrict__ hfeat) {
@@ -258,6 +194,7 @@ __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __
 #define AZ_STAMP16B(i) do { if (dbg) dbg[i] = __builtin_readcyclecounter(); } while (0)
   AZ_STAMP16B(0);
   f32x4v acc[NT][2];
+  const EpiSel es = epi_sel(lrow);
   uint32_t xres[NT][2][2];                                          // the current block's input as the convolutions read it (bf16 pairs: rows 0, 1 | 2, 3): this lane wrote it
   // ---- stem on the fp32 MFMA (K = 9 C), output rounded to bf16 -------------------------------------------------------------
   {
@@ -287,7 +224,7 @@ __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const float y = az_fmaf(acc[tile][ct][i], sc, sh); v[i] = y > 0.0f ? y : 0.0f; }
-        store_bf16x4<T>(buf, R0 + tile * 16 + g * 4, ch0 + 16 * ct, lrow, v, xres[tile][ct]);
+        store_bf16x4<T>(epi_dst<T>(buf, R0 + tile * 16 + g * 4, ch0 + 16 * ct, es.odd), es, v, xres[tile][ct]);
       }
     }
   }
@@ -301,29 +238,40 @@ __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __
     for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
     int lrow_l = lrow;
     asm volatile("" : "+v"(lrow_l));                                // keeps the table look-ups inside the layer loop (registers)
-    if constexpr (PIPE > 0) conv16c<T, G, NT, TILE0, 9, PIPE>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow_l, g);
-    else conv16b<T, G, NT, TILE0, 9>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow_l, g);
+    conv16b<T, G, NT, TILE0, 9>(buf, nbr, net.conv_w + (size_t)layer * LAYER_W + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow_l, g);
     if (layer == 2) AZ_STAMP16B(4);
     __syncthreads();                                                // every wave has finished reading the buffer
     if (layer == 2) AZ_STAMP16B(5);
+    // the two kinds of layer are two uniform branches (as one body the residual add was computed and then selected away
+    // in every first convolution of a block)
+    if (layer & 1) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const float sc = net.conv_ss[(size_t)layer * 2 * F + ch0 + 16 * ct], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch0 + 16 * ct];
+      for (int ct = 0; ct < 2; ++ct) {
+        const float sc = net.conv_ss[(size_t)layer * 2 * F + ch0 + 16 * ct], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch0 + 16 * ct];
 #pragma unroll
-      for (int tile = 0; tile < NT; ++tile) {
-        float v[4];
+        for (int tile = 0; tile < NT; ++tile) {
+          float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float y = az_fmaf(acc[tile][ct][i], sc, sh);
-          if (layer & 1) {                                          // second convolution of a block: + the block input (rounded, as read)
+          for (int i = 0; i < 4; ++i) {                             // second convolution of a block: + the block input (rounded, as read)
             const uint32_t pr = xres[tile][ct][i >> 1];
-            y = y + bf16_bits_to_f32((uint16_t)((i & 1) ? (pr >> 16) : (pr & 0xffffu)));
+            const float y = az_fmaf(acc[tile][ct][i], sc, sh) + __builtin_bit_cast(float, (i & 1) ? (pr & 0xffff0000u) : (pr << 16));
+            v[i] = y > 0.0f ? y : 0.0f;
           }
-          v[i] = y > 0.0f ? y : 0.0f;
+          store_bf16x4<T>(epi_dst<T>(buf, R0 + tile * 16 + g * 4, ch0 + 16 * ct, es.odd), es, v, xres[tile][ct]);   // also the next block's input
         }
-        uint32_t pk[2];
-        store_bf16x4<T>(buf, R0 + tile * 16 + g * 4, ch0 + 16 * ct, lrow, v, pk);
-        if (layer & 1) { xres[tile][ct][0] = pk[0]; xres[tile][ct][1] = pk[1]; }      // the next block's input
+      }
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const float sc = net.conv_ss[(size_t)layer * 2 * F + ch0 + 16 * ct], sh = net.conv_ss[(size_t)layer * 2 * F + F + ch0 + 16 * ct];
+#pragma unroll
+        for (int tile = 0; tile < NT; ++tile) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const float y = az_fmaf(acc[tile][ct][i], sc, sh); v[i] = y > 0.0f ? y : 0.0f; }
+          uint32_t pk[2];
+          store_bf16x4<T>(epi_dst<T>(buf, R0 + tile * 16 + g * 4, ch0 + 16 * ct, es.odd), es, v, pk);
+        }
       }
     }
     __syncthreads();
@@ -333,8 +281,7 @@ __device__ __forceinline__ void tower16b_wave(const Net16bDev& net, uint16_t* __
   // ---- both 1x1 head convolutions + BN + ReLU, features out in fp32 -------------------------------------------------------------
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
-  if constexpr (PIPE > 0) conv16c<T, G, NT, TILE0, 1, PIPE>(buf, nbr, net.head_w + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow, g);
-  else conv16b<T, G, NT, TILE0, 1>(buf, nbr, net.head_w + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow, g);
+  conv16b<T, G, NT, TILE0, 1>(buf, nbr, net.head_w + (size_t)(cg * 2) * T::KS * 64 + lane, acc, lrow, g);
   {
     const int nvalid = ((n - board0) < TB ? (n - board0) : TB) * P;
 #pragma unroll
@@ -394,44 +341,3 @@ k_tower16b(Net16bDev net, const GEnv* __restrict__ leaf_env, const int* __restri
   else tower16b_wave<T, NT1, NT0>(net, buf, planes, nbr, pos, wave - NCG, lane, n, board0, hfeat);
 }
 
-// One row group (k_tower16b1, 128 filters): F / 32 = 4 wavefronts, each owns ALL row tiles x 32 output channels -- the
-// per-wavefront shape of the 22-tile kernel above (11 tiles x 2 column tiles: a weight fragment serves 11 row tiles, half
-// the weight stream per board of the two-row-group form), but 4 boards and 57 KB of LDS per workgroup: TWO workgroups share
-// a CU, one wavefront of each per SIMD (2 x 253 VGPRs).  They drift out of phase, so the barriers and the epilogue of one
-// run under the MFMAs of the other -- the fp32 tower's arrangement (k_tower16, resnet16.h), which the 8-wave forms cannot
-// have -- and two slot groups' towers interleave on a CU as well.
-template <class Gm, int F, bool FROM_PLANES, int NT = 11, int PIPE = 3>
-__global__ void __launch_bounds__(64 * (F / 32), 2)
-k_tower16b1(Net16bDev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
-            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
-  using T = T16B<Gm, F, NT>;
-  constexpr int P = Gm::P, C = Gm::C, TB = T::TB, SH = T::SH, THREADS = 64 * (F / 32);
-  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-  uint16_t* buf = (uint16_t*)ldsb;
-  float* planes = (float*)(ldsb + (size_t)T::BUFH * 2);
-  uint16_t* nbr = (uint16_t*)(planes + T::PLANES);
-  uint16_t* pos = nbr + 9 * T::RPAD;
-  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
-  const int board0 = blockIdx.x * TB;
-  if (board0 >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint16_t* geo = net.geo[NT == 11 ? 0 : NT == 22 ? 2 : 1];
-  for (int i = tid; i < T::PLANES; i += THREADS) {
-    const int row = i / C, c = i % C;
-    float val = 0.0f;
-    if (row < T::RPAD) {
-      const int ps = geo[row];
-      if (ps != 0xffff && board0 + ps / P < n) {
-        const int b = ps / P, q = ps % P;
-        if (FROM_PLANES) val = X[((size_t)(board0 + b) * C + c) * P + q];
-        else val = Gm::plane(leaf_env[eval_slots[board0 + b]], q, c);
-      }
-    }
-    planes[i] = val;
-  }
-  for (int i = tid; i < GEO_NZ * SH; i += THREADS) buf[T::RPAD * SH + i] = 0;
-  for (int i = tid; i < T::RPAD; i += THREADS) pos[i] = geo[i];
-  for (int i = tid; i < 9 * T::RPAD; i += THREADS) nbr[i] = geo[T::RPAD + i];
-  __syncthreads();
-  tower16b_wave<T, NT, 0, PIPE>(net, buf, planes, nbr, pos, wave, lane, n, board0, hfeat);
-}

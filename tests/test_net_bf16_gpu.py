@@ -59,8 +59,7 @@ def torch_forward_bf16(game, hp, blob, X, A):
 
 @pytest.mark.parametrize("game,nblocks,F,n,tower", [(R.C4, 10, 128, 40, "16"), (R.C4, 10, 128, 9, "3"), (R.C4, 5, 64, 37, ""),
                                                      (R.TTT, 2, 64, 50, "16"), (R.MANCALA, 3, 128, 30, ""),
-                                                     (R.C4, 10, 128, 43, "22"), (R.MANCALA, 3, 128, 57, "22"), (R.TTT, 2, 128, 80, "22"),
-                                                     (R.C4, 10, 128, 43, "41"), (R.MANCALA, 3, 128, 57, "41"), (R.TTT, 2, 128, 80, "41")])   # 41: one row group, 4 waves, two workgroups per CU   # 22 row tiles: 8 Connect-Four boards per workgroup
+                                                     (R.C4, 10, 128, 43, "22"), (R.MANCALA, 3, 128, 57, "22"), (R.TTT, 2, 128, 80, "22")])   # 22 row tiles: 8 Connect-Four boards per workgroup
 def test_bf16_tower_matches_its_own_scheme_and_tracks_fp32(game, nblocks, F, n, tower, monkeypatch):
     import azhip
     if tower:
@@ -100,3 +99,24 @@ def test_bf16_self_play_is_deterministic_and_well_formed():
                                                          for k in range(g[i].num_moves)]) for i in range(ng)])
             assert st.simulations == 32 * nm and all(sum(m[g[i].first_move].N) == 31 for i in range(ng))
     assert runs[0] == runs[1]
+
+
+def test_full_launch_picks_the_22_tile_form_and_equals_the_11_tile_form(monkeypatch):
+    """4096 boards at 128 filters: the engine's own choice is k_tower16b<..., NT=22> (8 boards per workgroup).  Tiling does not
+    enter the arithmetic -- every output element is the same sequence of MFMAs over (tap, k step) -- so its outputs must equal
+    the 11-tile form's bit for bit (which the cases above hold to the emulation and to the fp32 oracle)."""
+    import azhip
+    hp = ResNetHP(num_blocks=3, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32)
+    blob = random_params(R.C4, hp, seed=78)
+    envs = random_positions(R.C4, 4096, 6)
+    X, A = batch_of(R.C4, envs)
+    out = {}
+    for tower in ("", "16"):
+        if tower:
+            monkeypatch.setenv("AZHIP_TOWER", tower)
+        with azhip.Engine(game=R.C4, oracle=azhip.ORACLE_RESNET, num_workers=4096, batch_size=4096, num_iters_per_turn=8, num_blocks=3,
+                          num_filters=128, num_policy_head_filters=32, num_value_head_filters=32, net_bf16=1) as e:
+            e.net_set_params(blob)
+            out[tower] = e.net_forward(X, A)[:2] + (e.net_last_kernel(),)
+    assert "NT=22" in out[""][2] and "NT=11" in out["16"][2], (out[""][2], out["16"][2])
+    assert np.array_equal(out[""][0], out["16"][0]) and np.array_equal(out[""][1], out["16"][1])

@@ -30,7 +30,7 @@ e.net_set_params(random_params(0, hp))
 f = lib().az_debug_tower_timeline
 f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
-tb = 4 if a.nt in (11, 41) else 1                              # 41: k_tower16b1 (bf16, one row group, two workgroups per CU)
+tb = 4 if a.nt == 11 else 1
 wg_per_tile = 2 if a.nt == 2 else 1                                # nt = 2: the split tower, two workgroups per board
 for n in ns:
     nb = wg_per_tile * ((n + tb - 1) // tb)
