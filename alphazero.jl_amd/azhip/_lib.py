@@ -59,7 +59,8 @@ class TraceBuf(C.Structure):
 
 class SelfplayStats(C.Structure):
     _fields_ = [("simulations", C.c_int64), ("nodes_traversed", C.c_int64), ("leaf_evals", C.c_int64),
-                ("moves", C.c_int64), ("games", C.c_int64), ("waves", C.c_int64), ("seconds", C.c_double)]
+                ("moves", C.c_int64), ("games", C.c_int64), ("waves", C.c_int64), ("seconds", C.c_double),
+                ("aborted_games", C.c_int64)]
 
 
 class Prof(C.Structure):
@@ -131,6 +132,7 @@ SYMBOLS = {
     "az_selfplay_get_stats": [_VP, C.POINTER(SelfplayStats)],
     "az_selfplay_active": [_VP, C.POINTER(_I32)],
     "az_selfplay_end": [_VP],
+    "az_selfplay_aborted": [_VP, _VP, _I32, C.POINTER(_I32)],
     "az_arena_run": [_VP, _VP, _I32, _I32, _I32, C.POINTER(TraceBuf), _VP, C.POINTER(C.c_double), PROGRESS_CB, _VP],
     "az_push_trace": [_VP, _I32, C.c_double, _VP, _VP],
     "az_memory_create": [_I32, _I32, _I64, C.POINTER(_VP)],

@@ -247,6 +247,14 @@ class Engine:
     def selfplay_end(self):
         check(lib().az_selfplay_end(self._h))
 
+    def selfplay_aborted(self):
+        """ids of the games the current / last phase aborted (slot out of tree nodes or move records)"""
+        n = C.c_int32()
+        check(lib().az_selfplay_aborted(self._h, None, 0, C.byref(n)))
+        ids = (C.c_int32 * max(n.value, 1))()
+        check(lib().az_selfplay_aborted(self._h, ids, n.value, C.byref(n)))
+        return [ids[i] for i in range(n.value)]
+
     # ---- arena ----------------------------------------------------------------------------------
     def arena_run(self, baseline, num_games, first_game_id=0, alternate_colors=False, progress=None, traces=True):
         """pit_networks: self = contender's engine, baseline = the other player's engine.

@@ -108,11 +108,12 @@ class Env:
         return 0 if ts == 0 else tt / ts
 
     def approximate_memory_footprint(self):
-        """mcts.jl:319-321 with the per-node size of the DEVICE record (32 + 16 APAD bytes)"""
+        """mcts.jl:319-321 with the per-node size of the DEVICE record (memory_footprint_per_node)"""
         return memory_footprint_per_node(self.gspec) * self.num_nodes()
 
 
 def memory_footprint_per_node(gspec):
     nA = gspec.num_actions()
-    rec = ((16 + 8 * nA + 7) // 8 * 8 + 8 * nA + 31) // 32 * 32
-    return rec + 4 + 12             # node record + Vest + its share of the 1.5x hash table (8 B entries)
+    hb = 2 if nA <= 8 else 4
+    rec = ((18 * nA + hb - 1) // hb * hb + hb + 31) // 32 * 32      # NodeL (csrc/tree.h): 16 B per action + child links
+    return rec + 32 + 12            # node record + side record (key, Vest) + its share of the 1.5x hash table (8 B entries)

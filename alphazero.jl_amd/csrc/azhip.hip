@@ -83,6 +83,8 @@ extern "C" int az_engine_destroy(az_engine* e) {
   for (void* q : e->net_allocs) (void)hipFree(q);
   for (void* q : e->allocs) (void)hipFree(q);
   if (e->d_phase) (void)hipFree(e->d_phase);
+  for (size_t i = 0; i < e->vm_handles.size(); ++i) { (void)hipMemUnmap(e->vm_at[i], e->vm_chunk); (void)hipMemRelease(e->vm_handles[i]); }
+  if (e->vm_base) (void)hipMemAddressFree(e->vm_base, e->vm_bytes);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return AZ_OK;
@@ -95,6 +97,62 @@ __global__ void k_fill_u32(uint32_t* p, uint32_t val, int n) {
 __global__ void k_iota(int* p, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
+}
+
+// ------------------------------------------------------------------------------- node pool
+// The reference's tree is a Dict that grows as it is used (src/mcts.jl:124-151).  Here a slot's nodes are an array indexed by
+// creation order; its worst case (one new node per simulation, every ply of the longest game) is what `cap` says, and for
+// Mancala at BASELINE configs[3] (8192 slots x 800 simulations x 128 plies) that is 107 GB of which a phase touches a
+// fraction.  Pools above VM_THRESHOLD therefore live in a VIRTUAL address range (hipMemAddressReserve) laid out
+// [chunk row][slot][2 MB]: the kernels' address arithmetic is a shift and a mask (node_at, tree.h), and the host backs chunk
+// (row, slot) with physical memory (hipMemCreate + hipMemMap, ~30 us each) at the move step before slot s can reach it --
+// a slot adds at most one node per wave, so one look at the node counts every num_iters_per_turn waves is enough.
+// tools/probes/vmm_probe.hip: the runtime hands out physical memory in 2 MB units whatever size is asked for; handles above a
+// few MB crashed it, so every mapping is one 2 MB handle.  If the device runs out of memory (or AZHIP_POOL_GB is reached)
+// a slot simply stops growing and is retired when it fills up (DParams::retire).
+static constexpr size_t VM_CHUNK = (size_t)2 << 20;
+static constexpr size_t VM_THRESHOLD = (size_t)24 << 30;
+static int vm_map(az_engine* e, int row, int slot) {
+  if (e->vm_mapped + VM_CHUNK > e->vm_budget) return 1;             // budget reached: not an error, the slot stops growing
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = e->device;
+  hipMemGenericAllocationHandle_t h;
+  if (hipMemCreate(&h, VM_CHUNK, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  char* at = e->vm_base + ((size_t)row * e->v.G + slot) * VM_CHUNK;
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+  if (hipMemMap(at, VM_CHUNK, 0, h, 0) != hipSuccess || hipMemSetAccess(at, VM_CHUNK, &acc, 1) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipMemRelease(h);
+    return fail(AZ_ERR_HIP, "hipMemMap of a node-pool chunk failed");
+  }
+  e->vm_handles.push_back(h); e->vm_at.push_back(at);
+  e->vm_mapped += VM_CHUNK;
+  return AZ_OK;
+}
+// backs the chunks the slots will need before the host looks again (`ahead` nodes from now); uploads the new capacities
+static int vm_grow(az_engine* e, int ahead) {
+  if (!e->vm_rows) return AZ_OK;
+  const int G = e->v.G;
+  HIPCHK(hipMemcpyAsync(e->h_node_count.data(), e->v.node_count, sizeof(int) * G, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  bool changed = false;
+  for (int s = 0; s < G; ++s) {
+    const long long want = std::min<long long>((long long)e->h_node_count[s] + ahead, e->v.cap_nodes);
+    while (e->h_slot_cap[s] < want) {
+      const int row = e->h_slot_cap[s] / e->vm_chunk_nodes;
+      if (row >= e->vm_rows) break;
+      const int st = vm_map(e, row, s);
+      if (st == 1) break;                                             // out of memory / budget: the slot keeps what it has
+      AZCHK(st);
+      e->h_slot_cap[s] = std::min<long long>((long long)(row + 1) * e->vm_chunk_nodes, e->v.cap_nodes);
+      changed = true;
+    }
+  }
+  if (changed) {
+    HIPCHK(hipMemcpyAsync(e->d_slot_cap, e->h_slot_cap.data(), sizeof(int) * G, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  return AZ_OK;
 }
 
 extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
@@ -128,6 +186,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   az_engine* e = new (std::nothrow) az_engine();
   if (!e) return fail(AZ_ERR_HIP, "out of host memory");
   e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0; e->alloc_bytes = 0;
+  e->vm_base = nullptr; e->vm_bytes = 0; e->vm_chunk = 0; e->vm_rows = 0; e->vm_chunk_nodes = 0; e->d_slot_cap = nullptr; e->vm_budget = 0; e->vm_mapped = 0;
   e->net_loaded = false; e->running = false; e->prof_on = false; { const char* ug = getenv("AZHIP_GRAPH"); e->use_graphs = ug ? atoi(ug) : 0; }
   e->d_phase = nullptr; e->phase_cap = 0; e->phase_n = 0; e->host_moves = true; e->last_tower[0] = 0; e->prof_mask = 0; e->prof_used = 0;
   memset(&e->prof, 0, sizeof e->prof);
@@ -160,13 +219,39 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &v.worker_sim_id, G)); AZCHK(dalloc(e, &v.tot_sims, G)); AZCHK(dalloc(e, &v.tot_trav, G));
     AZCHK(dalloc(e, &v.eta, (size_t)G * gi.APAD));
     AZCHK(dalloc(e, &v.ht, (size_t)G * hs));
-    AZCHK(dalloc(e, &v.nodes, (size_t)G * cap * gi.node_bytes, false));
-    AZCHK(dalloc(e, &v.vest, (size_t)G * cap, false));
+    {
+      const size_t pool_bytes = (size_t)G * cap * gi.node_bytes;
+      const char* fv = getenv("AZHIP_VMM");                          // 1 / 0 force the mapped-on-demand pool on / off (tests)
+      const size_t chunk_nodes = VM_CHUNK / gi.node_bytes;
+      const bool pow2 = (chunk_nodes & (chunk_nodes - 1)) == 0 && chunk_nodes * gi.node_bytes == VM_CHUNK;
+      const bool want = fv ? atoi(fv) != 0 : pool_bytes > VM_THRESHOLD;
+      if (want && pow2 && (size_t)cap > chunk_nodes && gi.node_bytes > 0) {
+        e->vm_chunk = VM_CHUNK; e->vm_chunk_nodes = (int)chunk_nodes;
+        e->vm_rows = (int)((cap + chunk_nodes - 1) / chunk_nodes);
+        e->vm_bytes = (size_t)e->vm_rows * G * VM_CHUNK;
+        void* base = nullptr;
+        HIPCHK(hipMemAddressReserve(&base, e->vm_bytes, VM_CHUNK, nullptr, 0));
+        e->vm_base = (char*)base;
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        const char* gb = getenv("AZHIP_POOL_GB");
+        e->vm_budget = gb ? (size_t)(atof(gb) * (double)((size_t)1 << 30)) : fr;     // default: whatever the device still has
+        v.nodes = e->vm_base;
+        int sh = 0; while (((size_t)1 << sh) < chunk_nodes) ++sh;
+        v.node_sh = sh; v.node_mask = (uint32_t)chunk_nodes - 1; v.node_row = (size_t)G * VM_CHUNK; v.node_stride = VM_CHUNK;
+        e->h_slot_cap.assign(G, 0); e->h_node_count.assign(G, 0);
+        AZCHK(dalloc(e, &e->d_slot_cap, G));
+        v.slot_cap = e->d_slot_cap;
+      } else {
+        AZCHK(dalloc(e, &v.nodes, pool_bytes, false));
+        v.node_sh = 31; v.node_mask = 0x7fffffffu; v.node_row = 0; v.node_stride = (size_t)cap * gi.node_bytes; v.slot_cap = nullptr;
+      }
+    }
     AZCHK(dalloc(e, &v.path, (size_t)G * v.max_depth));
     AZCHK(dalloc(e, &v.leaf_kind, G)); AZCHK(dalloc(e, &v.leaf_depth, G)); AZCHK(dalloc(e, &v.leaf_env, G));
     AZCHK(dalloc(e, &v.leaf_ins, G)); AZCHK(dalloc(e, &v.eidx, G)); AZCHK(dalloc(e, &v.eval_slots, G));
     AZCHK(dalloc(e, &v.n_eval, 2 * AZ_MAX_GROUPS));
-    AZCHK(dalloc(e, &v.keys, (size_t)G * cap * 2, false)); AZCHK(dalloc(e, &v.root_idx, G));
+    AZCHK(dalloc(e, &v.keys, (size_t)G * cap * 4, false)); AZCHK(dalloc(e, &v.root_idx, G));
     hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, (uint32_t*)v.root_idx, 0xffffffffu, G);
     AZCHK(dalloc(e, &v.Pout, (size_t)std::max(G, 1) * gi.APAD)); AZCHK(dalloc(e, &v.Vout, G));
     AZCHK(dalloc(e, &v.trace, (size_t)G * v.max_moves)); AZCHK(dalloc(e, &v.grec, G));
@@ -207,9 +292,10 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       gv.G = Gh;
       gv.root += o; gv.active += o; gv.game_id += o; gv.move_idx += o; gv.epoch += o; gv.node_count += o;
       gv.worker_sim_id += o; gv.tot_sims += o; gv.tot_trav += o; gv.eta += o * gi.APAD;
-      gv.ht += o * hs; gv.nodes += o * (size_t)cap * gi.node_bytes; gv.vest += o * (size_t)cap; gv.path += o * v.max_depth;
+      gv.ht += o * hs; gv.nodes += o * v.node_stride; gv.path += o * v.max_depth;
+      if (gv.slot_cap) gv.slot_cap += o;
       gv.leaf_kind += o; gv.leaf_depth += o; gv.leaf_env += o; gv.leaf_ins += o; gv.eidx += o; gv.eval_slots += o;
-      gv.n_eval += 2 * g; gv.keys += o * (size_t)cap * 2; gv.root_idx += o; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
+      gv.n_eval += 2 * g; gv.keys += o * (size_t)cap * 4; gv.root_idx += o; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;
       if (ng == 1) { e->gs[g] = e->gt[g] = e->stream; }
       else {
@@ -231,7 +317,8 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     p.gamma = c->gamma; p.cpuct = c->cpuct; p.eps = c->dirichlet_noise_eps; p.alpha = c->dirichlet_noise_alpha;
     p.prior_temp = c->prior_temperature; p.nsims = c->num_iters_per_turn; p.temp_len = c->temperature_len;
     for (int i = 0; i < AZ_SCHED_MAX; ++i) { p.temp_xs[i] = c->temperature_xs[i]; p.temp_ys[i] = c->temperature_ys[i]; }
-    p.seed = c->seed; p.oracle = c->oracle; p.reset_every = c->reset_every;
+    p.seed = c->seed; p.oracle = c->oracle; p.reset_every = c->reset_every; p.retire = 0;
+    if (e->vm_rows) AZCHK(vm_grow(e, 1));                            // the first chunk of every slot
     e->h_finished.resize(G); e->h_grec.resize(G);
     e->prof_pool.resize(2048);
     for (auto& r : e->prof_pool) { HIPCHK(hipEventCreate(&r.a)); HIPCHK(hipEventCreate(&r.b)); }
@@ -247,7 +334,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
 
 extern "C" int az_engine_device_bytes(az_engine* e, int64_t* bytes) {
   if (!e || !bytes) return fail(AZ_ERR_BAD_ARG, "NULL");
-  *bytes = (int64_t)e->alloc_bytes + (int64_t)sizeof(az_move_rec) * e->phase_cap;
+  *bytes = (int64_t)e->alloc_bytes + (int64_t)sizeof(az_move_rec) * e->phase_cap + (int64_t)e->vm_mapped;
   return AZ_OK;
 }
 extern "C" int az_engine_release_phase(az_engine* e) {
@@ -836,8 +923,6 @@ __global__ void k_node_stats(DView v, int slot, unsigned long long ka, unsigned 
   const unsigned long long hk = az_hash_key(ka, kb);
   const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
-  const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
-  const unsigned long long* keys = v.keys + (size_t)slot * v.cap_nodes * 2;
   int* found = (int*)out;
   *found = 0;
   for (uint32_t i = 0; i <= H1; ++i) {
@@ -845,11 +930,11 @@ __global__ void k_node_stats(DView v, int slot, unsigned long long ka, unsigned 
     uint32_t idx1 = (uint32_t)e;
     if (!((uint32_t)(e >> 48) == epoch && idx1 != 0)) return;
     if (((uint32_t)(e >> 32) & 0xffff) == tag) {
-      const char* nd = pool + (size_t)(idx1 - 1) * NL::BYTES;
-      const unsigned long long* k = keys + (size_t)(idx1 - 1) * 2;
+      const char* nd = node_at<Gm>(v, slot, (int)(idx1 - 1));
+      const unsigned long long* k = side_at(v, slot, (int)(idx1 - 1));
       if (k[0] == ka && k[1] == kb) {
         *found = 1;
-        *(float*)(out + 4) = v.vest[(size_t)slot * v.cap_nodes + (idx1 - 1)];
+        *(float*)(out + 4) = __uint_as_float((uint32_t)k[2]);
         for (int b = 0; b < NL::BYTES; ++b) out[16 + b] = nd[b];
         return;
       }
@@ -869,11 +954,11 @@ extern "C" int az_mcts_node_stats(az_engine* e, int32_t slot, const uint64_t key
   int found; memcpy(&found, buf, 4);
   if (!found) return fail(AZ_ERR_BAD_ARG, "state not in the tree of slot %d", slot);
   const char* nd = buf + 16;
-  const int A = e->gi.A, offP = 4 * A, offW = (8 * A + 7) / 8 * 8;   // NodeL (tree.h)
+  const int A = e->gi.A;                                            // NodeL::Stat (tree.h): per action { W f64 | N i32 | P f32 }
   for (int a = 0; a < A; ++a) {
-    if (N) memcpy(&N[a], nd + 4 * a, 4);
-    if (P) memcpy(&P[a], nd + offP + 4 * a, 4);
-    if (W) memcpy(&W[a], nd + offW + 8 * a, 8);
+    if (W) memcpy(&W[a], nd + 16 * a, 8);
+    if (N) memcpy(&N[a], nd + 16 * a + 8, 4);
+    if (P) memcpy(&P[a], nd + 16 * a + 12, 4);
   }
   if (Vest) memcpy(Vest, buf + 4, 4);
   if (mask) DISPATCH_GAME(e->cfg.game, *mask = Gm::mask(Gm::from_key(key[0], key[1])));
@@ -926,11 +1011,14 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
     }
   }
   memset(&e->stats, 0, sizeof e->stats);
+  e->aborted_ids.clear();
+  e->p.retire = 1;                                                  // an overflowing slot is retired, the phase goes on
   const int n0 = num_games < 0 ? G : std::min(G, (int)num_games);
   std::vector<int> slots(n0);
   std::vector<uint32_t> gids(n0);
   for (int i = 0; i < n0; ++i) { slots[i] = i; gids[i] = (uint32_t)(first_game_id + e->next_game++); }
   DISPATCH_GAME(e->cfg.game, AZCHK(start_games<Gm>(e, slots, gids, nullptr, 1, 1)));
+  AZCHK(vm_grow(e, e->p.nsims + 2));                                 // every slot can take its first explore!
   e->active_slots = n0;
   for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->group_active[g] = 0;
   for (int i = 0; i < n0; ++i) e->group_active[i / e->gv[0].G]++;
@@ -948,28 +1036,49 @@ template <class Gm> static int move_round(az_engine* e) {
   HIPCHK(hipMemcpyAsync(e->h_finished.data(), e->v.finished, sizeof(int) * G, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->h_grec.data(), e->v.grec, sizeof(az_game_rec) * G, hipMemcpyDeviceToHost, e->stream));
   AZCHK(check_device_error(e));   // synchronises
-  e->stats.moves += e->active_slots;
-  std::vector<int> fslots, offs;
+  std::vector<int> fslots, offs, aslots;
   int total = 0;
-  for (int s = 0; s < G; ++s) if (e->h_finished[s]) { fslots.push_back(s); offs.push_back(total); total += e->h_grec[s].num_moves; }
-  if (fslots.empty()) return AZ_OK;
+  for (int s = 0; s < G; ++s) {
+    if (e->h_finished[s] == 1) { fslots.push_back(s); offs.push_back(total); total += e->h_grec[s].num_moves; }
+    else if (e->h_finished[s] == 2) aslots.push_back(s);             // retired: node pool or move record full
+  }
+  e->stats.moves += e->active_slots - (int)aslots.size();
+  std::vector<int> rslots, aslots_refill;
+  std::vector<uint32_t> rgids, agids;
+  if (!aslots.empty()) {
+    // the retired slots' games are reported as aborted (their ids via az_selfplay_aborted), count as done, and the slots
+    // take the next games with an empty tree
+    std::vector<uint32_t> gid(G);
+    HIPCHK(hipMemcpyAsync(gid.data(), e->v.game_id, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int sl : aslots) {
+      e->aborted_ids.push_back((int32_t)gid[sl]);
+      e->games_done++; e->stats.aborted_games++;
+      e->active_slots--; e->group_active[sl / e->gv[0].G]--;
+      if (e->total_games < 0 || e->next_game < e->total_games) {
+        aslots_refill.push_back(sl); agids.push_back((uint32_t)(e->first_game_id + e->next_game++));
+        e->active_slots++; e->group_active[sl / e->gv[0].G]++;
+      }
+    }
+  }
+  if (fslots.empty() && aslots.empty()) return vm_grow(e, e->p.nsims + 2);
   const int nf = (int)fslots.size();
-  HIPCHK(hipMemcpyAsync(e->d_slots, fslots.data(), sizeof(int) * nf, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->d_offsets, offs.data(), sizeof(int) * nf, hipMemcpyHostToDevice, e->stream));
+  if (nf) {
+    HIPCHK(hipMemcpyAsync(e->d_slots, fslots.data(), sizeof(int) * nf, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_offsets, offs.data(), sizeof(int) * nf, hipMemcpyHostToDevice, e->stream));
+  }
   // the finished games' records: packed behind the phase's earlier games in HBM (or into the staging area when the
   // phase is unbounded), and from there to the host only if the caller wants host traces
   if (e->d_phase && e->phase_n + total > e->phase_cap) return fail(AZ_ERR_CAPACITY, "phase buffer overflow");
   az_move_rec* dst = e->d_phase ? e->d_phase + e->phase_n : e->d_stage;
-  hipLaunchKernelGGL(k_gather_traces, dim3(nf), dim3(64), 0, e->stream, e->v, e->d_slots, e->d_offsets, nf, dst);
+  if (nf) hipLaunchKernelGGL(k_gather_traces, dim3(nf), dim3(64), 0, e->stream, e->v, e->d_slots, e->d_offsets, nf, dst);
   const size_t m0 = e->q_moves.size();
-  if (e->host_moves || !e->d_phase) {
+  if ((e->host_moves || !e->d_phase) && total) {
     e->q_moves.resize(m0 + total);
     HIPCHK(hipMemcpyAsync(e->q_moves.data() + m0, dst, sizeof(az_move_rec) * total, hipMemcpyDeviceToHost, e->stream));
   }
   HIPCHK(hipMemsetAsync(e->v.finished, 0, sizeof(int) * G, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  std::vector<int> rslots;
-  std::vector<uint32_t> rgids;
   for (int i = 0; i < nf; ++i) {
     az_game_rec g = e->h_grec[fslots[i]];
     g.first_move = (int32_t)(m0 + offs[i]);
@@ -988,7 +1097,8 @@ template <class Gm> static int move_round(az_engine* e) {
   }
   if (e->d_phase) e->phase_n += total;
   AZCHK(start_games<Gm>(e, rslots, rgids, nullptr, 0, 1));
-  return AZ_OK;
+  AZCHK(start_games<Gm>(e, aslots_refill, agids, nullptr, 1, 1));    // a retired slot starts over with an empty tree
+  return vm_grow(e, e->p.nsims + 2);                                 // chunks for the next explore! of every slot
 }
 
 extern "C" int az_selfplay_step(az_engine* e, int32_t nwaves) {
@@ -1060,8 +1170,18 @@ extern "C" int az_selfplay_collect(az_engine* e, az_trace_buf* out) {
   return AZ_OK;
 }
 
+extern "C" int az_selfplay_aborted(az_engine* e, int32_t* game_ids, int32_t cap, int32_t* n) {
+  ENGINE(e);
+  if (!n || (cap > 0 && !game_ids)) return fail(AZ_ERR_BAD_ARG, "NULL");
+  *n = (int32_t)e->aborted_ids.size();
+  if (*n > cap) return cap == 0 ? AZ_OK : fail(AZ_ERR_CAPACITY, "%d aborted games, room for %d", *n, cap);
+  for (int i = 0; i < *n; ++i) game_ids[i] = e->aborted_ids[i];
+  return AZ_OK;
+}
+
 extern "C" int az_selfplay_end(az_engine* e) {
   ENGINE(e);
+  e->p.retire = 0;
   if (!e->running) return AZ_OK;
   AZCHK(reset_wave_state(e));                                      // an unfinished simulation (stepping form stopped mid-move) is dropped
   HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));

@@ -79,6 +79,12 @@ struct az_engine {
   unsigned long long* xch[AZ_MAX_GROUPS + 1]; unsigned long long xch_epoch;
   std::vector<void*> allocs;
   size_t alloc_bytes;              // device bytes behind `allocs` (az_engine_device_bytes)
+  // node pool mapped on demand (azhip.hip "node pool"): a virtual range of rows x G chunks of 2 MB; chunk (row r, slot s) is
+  // backed when slot s is about to need it.  vm_rows = 0: plain hipMalloc pool.
+  char* vm_base; size_t vm_bytes, vm_chunk; int vm_rows, vm_chunk_nodes;
+  std::vector<hipMemGenericAllocationHandle_t> vm_handles; std::vector<char*> vm_at;
+  std::vector<int> h_slot_cap, h_node_count; int* d_slot_cap; size_t vm_budget, vm_mapped;
+  std::vector<int32_t> aborted_ids;   // games retired because their slot ran out of nodes / move records (az_selfplay_aborted)
   std::vector<void*> net_allocs;   // device copies of the packed network (replaced by az_net_set_params)
   // network
   bool net_loaded;

@@ -4,9 +4,11 @@
 // Layout in HBM (one engine = G game slots, every array is slot-major):
 //   nodes  [G][cap][NODE_BYTES]   one record per stored state (the reference's StateInfo +
 //                                 Vector{ActionStats}, src/mcts.jl:78-87), full action width:
-//                                   N i32[A] | P f32[A] | W f64[A] | child links (18 bit per action)
-//                                 (128 B for 7 actions: one cache line per visit);  vest [G][cap] f32
-//   keys   [G][cap][2] u64        the state of every node (only hash probes read it)
+//                                   per action 16 B { W f64 | N i32 | P f32 } | child links (18 bit per action)
+//                                 (128 B for 7 actions: one cache line per visit, ONE 16-byte load per lane, and the
+//                                 read-modify-write of a backup touches one 32-byte sector instead of two)
+//                                 Big pools live in a VIRTUAL range whose 2 MB chunks are mapped on demand (node_at)
+//   keys   [G][cap][4] u64        side record of every node: state key (only hash probes read it) | Vest f32 | unused
 //   ht     [G][H] u64             the Dict{State,StateInfo} of src/mcts.jl:126 as an open-addressed
 //                                 table: epoch(16) | tag(16) | node index+1 (32); an entry is live
 //                                 only if its epoch equals the slot's epoch, so MCTS.reset! is O(1)
@@ -39,6 +41,8 @@ struct DParams {
   double temp_ys[AZ_SCHED_MAX];
   uint64_t seed;
   int oracle, reset_every;
+  int retire;             // 1 (self-play): a slot whose node pool or move record overflows is RETIRED (finished = 2, the game is
+                          // reported as aborted, the phase goes on); 0 (explore! / arena hooks): a device error
 };
 
 struct DView {
@@ -55,9 +59,14 @@ struct DView {
   double* eta;            // [G][APAD] by full action index
   unsigned long long* ht;
   char* nodes;
-  unsigned long long* keys; // [G][cap][2] state of every node
+  // node idx of slot s lives at nodes + ((idx >> node_sh) * node_row + s * node_stride) + (idx & node_mask) * NODE_BYTES.
+  // Plain pool: node_sh = 31 (one "chunk" = the slot's whole region, node_stride = cap * NODE_BYTES).  Mapped-on-demand pool:
+  // chunks of 2^node_sh nodes = 2 MB, chunk row r of all slots contiguous (node_row = G * 2 MB), so that the host can back
+  // row r of a run of slots with one mapping; slot_cap[s] = nodes of slot s that are backed by memory right now.
+  int node_sh; uint32_t node_mask; size_t node_row, node_stride;
+  const int* slot_cap;    // [G] or NULL (plain pool: cap_nodes for every slot)
+  unsigned long long* keys; // [G][cap][4]: state key (2 words), Vest (f32, StateInfo.Vest, src/mcts.jl:86) in word 2
   int* root_idx;          // [G] node index of the slot's current root, -1 = not looked up yet this move
-  float* vest;            // [G][cap] StateInfo.Vest (src/mcts.jl:86), off the hot path
   unsigned long long* path;
   int* leaf_kind;
   int* leaf_depth;
@@ -85,12 +94,21 @@ struct DView {
 // from the state in registers.
 template <class Gm> struct NodeL {
   static constexpr int A = Gm::A;
-  static constexpr int OFF_N = 0, OFF_P = 4 * A, OFF_W = (8 * A + 7) / 8 * 8, OFF_LO = OFF_W + 8 * A;
+  struct Stat { double W; int N; float P; };        // ActionStats (src/mcts.jl:78-82), 16 bytes: lane a loads nd + 16 a as one dwordx4
+  static constexpr int OFF_LO = 16 * A;
   static constexpr int HI_BYTES = A <= 8 ? 2 : 4;
   static constexpr int OFF_HI = (OFF_LO + 2 * A + HI_BYTES - 1) / HI_BYTES * HI_BYTES;
   static constexpr int BYTES = (OFF_HI + HI_BYTES + 31) / 32 * 32;
   using hi_t = typename std::conditional<A <= 8, uint16_t, uint32_t>::type;
+  static __host__ __device__ inline Stat* stat(char* nd, int a) { return (Stat*)(nd + 16 * a); }
+  static __host__ __device__ inline const Stat* stat(const char* nd, int a) { return (const Stat*)(nd + 16 * a); }
 };
+static_assert(sizeof(NodeL<ConnectFour>::Stat) == 16, "ActionStats record");
+// address of node idx of slot `slot` (DView::node_*); v.nodes of a slot-group view is already offset to the group's first slot
+template <class Gm> __device__ __forceinline__ char* node_at(const DView& v, int slot, int idx) {
+  return v.nodes + (size_t)((uint32_t)idx >> v.node_sh) * v.node_row + (size_t)slot * v.node_stride + (size_t)((uint32_t)idx & v.node_mask) * NodeL<Gm>::BYTES;
+}
+__device__ __forceinline__ unsigned long long* side_at(const DView& v, int slot, int idx) { return v.keys + ((size_t)slot * v.cap_nodes + idx) * 4; }
 static constexpr int LINK_MAX = (1 << 18) - 2;
 
 __device__ inline void dev_fail(const DView& v, int code) { atomicCAS(v.err, 0, code); }
@@ -152,7 +170,7 @@ __device__ inline int ht_lookup(const DView& v, int slot, int lane, unsigned lon
   const uint32_t h0 = (uint32_t)hk & H1;
   const uint32_t tag = (uint32_t)(hk >> 40) & 0xffff;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
-  const unsigned long long* keys = v.keys + (size_t)slot * v.cap_nodes * 2;
+  const unsigned long long* keys = v.keys + (size_t)slot * v.cap_nodes * 4;
   const int iters = v.ht_size / L;
   for (int i = 0; i < iters; ++i) {
     uint32_t pos = (h0 + (uint32_t)(i * L + lane)) & H1;
@@ -161,7 +179,7 @@ __device__ inline int ht_lookup(const DView& v, int slot, int lane, unsigned lon
     bool live = ((uint32_t)(e >> 48) == epoch) && idx1 != 0;
     bool match = false;
     if (live && ((uint32_t)(e >> 32) & 0xffff) == tag) {
-      const unsigned long long* k = keys + (size_t)(idx1 - 1) * 2;
+      const unsigned long long* k = keys + (size_t)(idx1 - 1) * 4;
       match = (k[0] == ka) && (k[1] == kb);
     }
     unsigned mb = group_ballot<L>(match), db = group_ballot<L>(!live);
@@ -224,8 +242,8 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
   const int slot = tid / L, lane = tid % L;
   const int wl = threadIdx.x & 63, w = threadIdx.x >> 6, gbase = wl & ~(L - 1);
   const bool live = slot < v.G;
-  char* pool = v.nodes + (size_t)(live ? slot : 0) * v.cap_nodes * NL::BYTES;
-  unsigned long long* path = v.path + (size_t)(live ? slot : 0) * v.max_depth;
+  const int pslot = live ? slot : 0;
+  unsigned long long* path = v.path + (size_t)pslot * v.max_depth;
   const bool links_ok = v.cap_nodes <= LINK_MAX;
   unsigned long long* dbg = (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) ? v.dbg : nullptr;
   if (dbg) dbg[0] = __builtin_readcyclecounter();
@@ -240,8 +258,13 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
       if (kind == LEAF_NEW) {
         const int e = v.eidx[slot];
         const int idx = v.node_count[slot];
-        if (idx >= v.cap_nodes) { dev_fail(v, DERR_NODE_POOL); ok = false; }
-        else {
+        if (idx >= (v.slot_cap ? v.slot_cap[slot] : v.cap_nodes)) {
+          // the slot's pool is exhausted (the reference has no such limit, src/mcts.jl:124-151): self-play retires the slot --
+          // its game is reported as aborted and the phase goes on; the hooks report a capacity error
+          ok = false;
+          if (!p.retire) dev_fail(v, DERR_NODE_POOL);
+          else if (lane == 0) { v.finished[slot] = 2; v.active[slot] = 0; v.leaf_kind[slot] = LEAF_NONE; }
+        } else {
           const GEnv env = v.leaf_env[slot];
           const uint32_t m = Gm::mask(env);
           float Pf = v.Pout[(size_t)e * L + lane];
@@ -260,18 +283,15 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
             }
             Pf = av ? (float)res : 0.f;
           }
-          char* nd = pool + (size_t)idx * NL::BYTES;
+          char* nd = node_at<Gm>(v, slot, idx);
           if (lane < Gm::A) {
-            ((int*)(nd + NL::OFF_N))[lane] = 0;
-            ((float*)(nd + NL::OFF_P))[lane] = Pf;
-            ((double*)(nd + NL::OFF_W))[lane] = 0.0;
+            *NL::stat(nd, lane) = typename NL::Stat{0.0, 0, Pf};
             ((uint16_t*)(nd + NL::OFF_LO))[lane] = 0;
           }
           if (lane == 0) {
             *(typename NL::hi_t*)(nd + NL::OFF_HI) = 0;
-            unsigned long long* kk = v.keys + ((size_t)slot * v.cap_nodes + idx) * 2;
-            kk[0] = env.a; kk[1] = env.b;
-            v.vest[(size_t)slot * v.cap_nodes + idx] = V;
+            unsigned long long* kk = side_at(v, slot, idx);
+            kk[0] = env.a; kk[1] = env.b; kk[2] = (unsigned long long)__float_as_uint(V);
             const unsigned long long hk = az_hash_key(env.a, env.b);
             const unsigned long long tag = (hk >> 40) & 0xffff;
             v.ht[(size_t)slot * v.ht_size + v.leaf_ins[slot]] =
@@ -280,7 +300,7 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
             if (depth == 0) v.root_idx[slot] = idx;
             else if (links_ok) {                                    // memoise tree[state] on the edge that reached it
               const unsigned long long st = path[depth - 1];
-              set_link<Gm>(pool + (size_t)(uint32_t)st * NL::BYTES, (int)((st >> 32) & 0xff), (uint32_t)(idx + 1));
+              set_link<Gm>(node_at<Gm>(v, slot, (int)(uint32_t)st), (int)((st >> 32) & 0xff), (uint32_t)(idx + 1));
             }
           }
           q = (double)V;                                            // return info.Vest
@@ -302,10 +322,9 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
             if (lane == k) qmine = q;
           }
           if (lane < kn) {
-            char* nd = pool + (size_t)(uint32_t)st * NL::BYTES;
-            const int act = (int)((st >> 32) & 0xff);
-            ((double*)(nd + NL::OFF_W))[act] += qmine;              // update_state_info!, mcts.jl:190-194
-            ((int*)(nd + NL::OFF_N))[act] += 1;
+            typename NL::Stat* sa = NL::stat(node_at<Gm>(v, slot, (int)(uint32_t)st), (int)((st >> 32) & 0xff));
+            sa->W += qmine;                                         // update_state_info!, mcts.jl:190-194
+            sa->N += 1;
           }
         }
         if (lane == 0) {
@@ -336,16 +355,17 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
         if (idx < 0) { kind = LEAF_NEW; break; }                    // mcts.jl:205-207
         if (lane == 0) {
           if (depth == 0) v.root_idx[slot] = idx;
-          else if (links_ok) set_link<Gm>(pool + (size_t)pidx * NL::BYTES, pact, (uint32_t)(idx + 1));
+          else if (links_ok) set_link<Gm>(node_at<Gm>(v, slot, pidx), pact, (uint32_t)(idx + 1));
         }
       }
       if (depth >= v.max_depth) { dev_fail(v, DERR_DEPTH); kind = LEAF_NONE; break; }
-      const char* nd = pool + (size_t)idx * NL::BYTES;
+      const char* nd = node_at<Gm>(v, slot, idx);
       const uint32_t amask = Gm::mask(env);
       const bool inrec = lane < Gm::A;
-      const int N = inrec ? ((const int*)(nd + NL::OFF_N))[lane] : 0;
-      const float Pf = inrec ? ((const float*)(nd + NL::OFF_P))[lane] : 0.0f;
-      const double W = inrec ? ((const double*)(nd + NL::OFF_W))[lane] : 0.0;
+      const typename NL::Stat sa = inrec ? *NL::stat(nd, lane) : typename NL::Stat{0.0, 0, 0.0f};
+      const int N = sa.N;
+      const float Pf = sa.P;
+      const double W = sa.W;
       const uint32_t lo = inrec ? ((const uint16_t*)(nd + NL::OFF_LO))[lane] : 0;
       const uint32_t hi = *(const typename NL::hi_t*)(nd + NL::OFF_HI);
       const int link = (int)(lo | (((hi >> (2 * lane)) & 3u) << 16));
@@ -493,15 +513,13 @@ __device__ inline const char* find_node(const DView& v, int slot, unsigned long 
   const unsigned long long hk = az_hash_key(ka, kb);
   const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
-  const char* pool = v.nodes + (size_t)slot * v.cap_nodes * NL::BYTES;
-  const unsigned long long* keys = v.keys + (size_t)slot * v.cap_nodes * 2;
   for (uint32_t i = 0; i <= H1; ++i) {
     unsigned long long e = tab[((uint32_t)hk + i) & H1];
     uint32_t idx1 = (uint32_t)e;
     if (!((uint32_t)(e >> 48) == epoch && idx1 != 0)) break;
     if (((uint32_t)(e >> 32) & 0xffff) == tag) {
-      const unsigned long long* k = keys + (size_t)(idx1 - 1) * 2;
-      if (k[0] == ka && k[1] == kb) { if (idx_out) *idx_out = idx1 - 1; return pool + (size_t)(idx1 - 1) * NL::BYTES; }
+      const unsigned long long* k = side_at(v, slot, (int)(idx1 - 1));
+      if (k[0] == ka && k[1] == kb) { if (idx_out) *idx_out = idx1 - 1; return node_at<Gm>(v, slot, (int)(idx1 - 1)); }
     }
   }
   return nullptr;
@@ -572,9 +590,14 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
   const char* nd = find_node<Gm>(v, slot, env.a, env.b);          // tree[state] must exist after explore!
   if (!nd) { dev_fail(v, DERR_NO_ROOT); return; }
   const uint32_t m = Gm::mask(env);
-  const int* Nn = (const int*)(nd + NL::OFF_N);
+  int Nn[AZ_MAX_ACTIONS];
+  for (int a = 0; a < Gm::A; ++a) Nn[a] = NL::stat(nd, a)->N;
   const uint32_t mv = v.move_idx[slot];
-  if ((int)mv >= v.max_moves) { dev_fail(v, DERR_MOVES); return; }
+  if ((int)mv >= v.max_moves) {                                   // a game longer than the trace can hold: retired like a full node pool
+    if (!p.retire) dev_fail(v, DERR_MOVES);
+    else { v.finished[slot] = 2; v.active[slot] = 0; }
+    return;
+  }
   az_move_rec* rec = v.trace + (size_t)slot * v.max_moves + mv;
   rec->key[0] = env.a; rec->key[1] = env.b;
   for (int a = 0; a < AZ_MAX_ACTIONS + 1; ++a) rec->N[a] = (a < Gm::A && ((m >> a) & 1)) ? Nn[a] : 0;
@@ -656,7 +679,7 @@ __global__ void __launch_bounds__(256) k_root_visits(DView v, const int* slots, 
   const char* nd = find_node<Gm>(v, slots[i], roots[i].a, roots[i].b);
   o[0] = nd != nullptr;
   const uint32_t m = Gm::mask(roots[i]);
-  for (int a = 0; a < AZ_MAX_ACTIONS; ++a) o[1 + a] = (nd && a < Gm::A && ((m >> a) & 1)) ? ((const int*)(nd + NL::OFF_N))[a] : 0;
+  for (int a = 0; a < AZ_MAX_ACTIONS; ++a) o[1 + a] = (nd && a < Gm::A && ((m >> a) & 1)) ? NL::stat(nd, a)->N : 0;
 }
 // MCTS.reset! (mcts.jl:278-281) on a list of slots: a new epoch empties the slot's table in O(1)
 static __global__ void __launch_bounds__(256) k_reset_slots(DView v, const int* slots, int n) {

@@ -212,6 +212,10 @@ typedef struct {
   int64_t games;
   int64_t waves;
   double seconds;
+  int64_t aborted_games;            /* games whose slot ran out of tree nodes (max_nodes_per_slot / device memory) or of move
+                                     * records (max_moves_per_game): the slot is retired, the game dropped and counted here
+                                     * (ids: az_selfplay_aborted), the phase goes on.  The reference's Dict has no such limit
+                                     * (src/mcts.jl:124-151); with the default pool sizes this stays 0. */
 } az_selfplay_stats;
 typedef void (*az_progress_cb)(void* user);   /* game_simulated(), once per finished game */
 
@@ -228,6 +232,8 @@ int az_selfplay_step(az_engine* e, int32_t nwaves);
 int az_selfplay_collect(az_engine* e, az_trace_buf* out);   /* finished, not yet collected */
 int az_selfplay_get_stats(az_engine* e, az_selfplay_stats* stats);
 int az_selfplay_active(az_engine* e, int32_t* active_slots);
+/* ids of the games the current / last phase aborted (see az_selfplay_stats.aborted_games); cap = 0 only counts. */
+int az_selfplay_aborted(az_engine* e, int32_t* game_ids, int32_t cap, int32_t* n);
 int az_selfplay_end(az_engine* e);
 
 /* ---- arena (pit_networks, src/training.jl:130-144; TwoPlayers, src/play.jl:248-282) ------ */

@@ -49,7 +49,8 @@ end
 mutable struct SelfplayStats
   simulations::Int64; nodes_traversed::Int64; leaf_evals::Int64; moves::Int64; games::Int64; waves::Int64
   seconds::Float64
-  SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0)
+  aborted_games::Int64
+  SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0, 0)
 end
 @assert sizeof(EngineCfg) == 224 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56
 
@@ -297,10 +298,12 @@ function AlphaZero.simulate(simulator::Simulator, gspec::DeviceGameSpec, p::SimP
     check(ccall((:az_selfplay_run, LIB), Cint,
       (Ptr{Cvoid}, Int32, Int32, Ref{TraceBuf}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{SelfplayStats}),
       e.h, p.num_games, first_game_id, tb, @cfunction(c_progress, Cvoid, (Ptr{Cvoid},)), C_NULL, stats))
+    resize!(games, tb.num_games)
   end
+  stats.aborted_games == 0 || @warn "azhip: $(stats.aborted_games) games were aborted (tree node pool / move record full): raise max_nodes_per_slot"
   nA = GI.num_actions(gspec)
   hb = nA <= 8 ? 2 : 4                                            # width of the child-link high bits (NodeL, csrc/tree.h)
-  nbytes = cld(cld(cld(8nA, 8) * 8 + 8nA + 2nA, hb) * hb + hb, 32) * 32 + 16 + 4 + 12   # node record + key + Vest + hash-table share
+  nbytes = cld(cld(cld(8nA, 8) * 8 + 8nA + 2nA, hb) * hb + hb, 32) * 32 + 32 + 12   # node record + side record (key, Vest) + hash-table share
   return map(games) do g
     recs = moves[g.first_move + 1 : g.first_move + g.num_moves]
     trace = Trace(decode_state(gspec, recs[1].key))
@@ -553,7 +556,7 @@ function device_self_play_step!(gspec::DeviceGameSpec, bestnn::HipResNet, params
   check(ccall((:az_memory_new_batch, LIB), Cint, (Ptr{Cvoid},), mem.h))
   nA = GI.num_actions(gspec)
   hb = nA <= 8 ? 2 : 4
-  node_bytes = cld(cld(cld(8nA, 8) * 8 + 8nA + 2nA, hb) * hb + hb, 32) * 32 + 16 + 4 + 12
+  node_bytes = cld(cld(cld(8nA, 8) * 8 + 8nA + 2nA, hb) * hb + hb, 32) * 32 + 32 + 12
   if isnothing(comm)
     push_engine!(mem, e, params.mcts.gamma)
     nsamples = stats.moves
@@ -638,6 +641,7 @@ const UNBOUND = Dict(
   :az_selfplay_get_stats => "az_selfplay_run returns the statistics",
   :az_selfplay_active => "stepping form, see az_selfplay_begin",
   :az_selfplay_end => "stepping form, see az_selfplay_begin",
+  :az_selfplay_aborted => "ids of aborted games: simulate checks SelfplayStats.aborted_games and raises instead",
   :az_push_trace => "host-side helper for foreign hosts; Julia has the reference's push_trace!",
   :az_memory_push_samples => "host TrainingSamples -> device memory: only needed when mixing host and device memories",
   :az_memory_empty => "empty!(mem): not used by the training loop (src/training.jl)",
