@@ -40,7 +40,7 @@ def test_a_full_node_pool_retires_the_slot_and_the_phase_finishes():
         assert rec == want[gid], gid
     need = {g0[i].game_id: g0[i].nodes for i in range(n0)}
     assert all(need[gid] > cap - 32 for gid in aborted) and all(need[gid] <= cap for gid in got)
-    assert st.moves == nm == sum(len(r) for r in got.values())
+    assert nm == sum(len(r) for r in got.values()) and st.moves >= nm   # st.moves also counts the moves the aborted games made
 
 
 def test_a_game_longer_than_the_move_record_is_retired_too():
@@ -56,7 +56,7 @@ def test_a_game_longer_than_the_move_record_is_retired_too():
 def test_mapped_on_demand_pool_gives_the_plain_pool_s_games_and_holds_less_memory(monkeypatch):
     import azhip
     kw = dict(game=R.MANCALA, oracle=azhip.ORACLE_HASH, num_workers=6, batch_size=3, num_iters_per_turn=600, cpuct=2.0, dirichlet_noise_eps=0.25,
-              reset_every=1, seed=5, max_moves_per_game=256)
+              reset_every=1, seed=5, max_moves_per_game=256, temperature=((0, 10), (1.0, 0.5)))
     out = {}
     for vmm in ("0", "1"):
         monkeypatch.setenv("AZHIP_VMM", vmm)
@@ -69,7 +69,7 @@ def test_mapped_on_demand_pool_gives_the_plain_pool_s_games_and_holds_less_memor
     assert out["0"][2] - out["1"][2] > pool // 3, (out["0"][2], out["1"][2])
 
     # the oracle plays the same games: the mapped pool is not only self-consistent
-    games, moves, _ = R.simulate(R.MANCALA, R.ORACLE_HASH, 8, 6, 600, cpuct=2.0, noise_eps=0.25, reset_every=1, seed=5)
+    games, moves, _ = R.simulate(R.MANCALA, R.ORACLE_HASH, 8, 6, 600, cpuct=2.0, noise_eps=0.25, reset_every=1, seed=5, temp_xs=(0, 10), temp_ys=(1.0, 0.5))
     ref = {games[i].game_id: [(tuple(moves[games[i].first_move + k].key), list(moves[games[i].first_move + k].N), moves[games[i].first_move + k].action)
                               for k in range(games[i].num_moves)] for i in range(8)}
     assert out["1"][0] == ref

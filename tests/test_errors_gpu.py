@@ -53,10 +53,9 @@ def test_capacity_and_state_errors():
 
 
 def test_game_too_long_is_reported():
+    """round 3: a game that outgrows its move record no longer fails the phase -- it is retired and reported as aborted"""
     import azhip
-    from azhip import _lib as L
     with azhip.Engine(game=2, oracle=azhip.ORACLE_UNIFORM, num_workers=4, batch_size=4, num_iters_per_turn=8,
                       max_moves_per_game=5) as e:
-        with pytest.raises(azhip.AzError) as ei:
-            e.selfplay_run(4)
-        assert ei.value.status == L.AZ_ERR_CAPACITY and "max_moves_per_game" in str(ei.value)
+        g, m, ng, nm, st = e.selfplay_run(4)
+        assert ng == 0 and st.aborted_games == 4 and sorted(e.selfplay_aborted()) == [0, 1, 2, 3]
