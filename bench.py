@@ -43,6 +43,12 @@ def executed_flop(kernel):
 
 PEAK_HBM_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_BF16_MFMA_TFLOPS = 2500.0                       # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (no sparsity)
+# What the matrix pipes SUSTAIN for the length of a tower launch (tools/probes/mfma_sustained.hip, profiles/r3/mfma_sustained.txt:
+# 256 CUs x 4 SIMDs x 2 waves of independent MFMAs for ~1.5 ms): the chip holds 2.19 GHz under fp32 MFMA load and ~2.0 GHz under
+# bf16 MFMA load, not the 2.4 GHz the nominal peaks assume.  `frac` stays against the nominal peak (the guide's number); the
+# *_of_sustained fields say how much of what the silicon can actually do the kernel gets.
+SUSTAINED_FP32_MFMA_TFLOPS = 142.6
+SUSTAINED_BF16_MFMA_TFLOPS = 2046.4
 # Little's law for the search-tree kernel: a slot's simulation is a CHAIN of dependent 128-byte node-line loads (one line in
 # flight per slot); a dependent load that misses L2 takes ~840 shader cycles (tools/probes/chase_latency.hip)
 # ~ 400 ns at the sustained clock.  G slots therefore cannot move more than G x 128 B per 400 ns, whatever the kernel does.
@@ -138,6 +144,8 @@ def block_report(label, game, hp, bf16, kernel, prof, s0, s1, dt, waves, slots, 
            "engine_device_GB": dev_bytes / 2.0**30,
            "roofline": {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                         "mfma_executed_frac": achieved / peak * ex_flop / flop, "executed_product_frac": ex, "flop_per_board": flop,
+                        "sustained_peak": SUSTAINED_BF16_MFMA_TFLOPS if bf16 else SUSTAINED_FP32_MFMA_TFLOPS,
+                        "mfma_executed_frac_of_sustained": achieved * ex_flop / flop / (SUSTAINED_BF16_MFMA_TFLOPS if bf16 else SUSTAINED_FP32_MFMA_TFLOPS),
                         "launches": tw["launches"], "avg_boards_per_launch": evals / max(tw["launches"], 1),
                         "avg_launch_ms": tw["ms"] / max(tw["launches"], 1), "exclusive_ms": excl_ms, "traffic": None}}
     t = pmc_lookup(kernel)
@@ -295,7 +303,9 @@ def alone_and_tree(args, blob, dev_index, kernel, waves=200):
     alone = {"kernel": name, "slot_groups": 1, "waves": waves, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
              "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
              "avg_boards_per_launch": evals / max(tw["launches"], 1),
-             "mfma_executed_frac": achieved / PEAK_FP32_MFMA_TFLOPS * executed_flop(name) / flop}
+             "mfma_executed_frac": achieved / PEAK_FP32_MFMA_TFLOPS * executed_flop(name) / flop,
+             "sustained_peak": SUSTAINED_FP32_MFMA_TFLOPS,
+             "mfma_executed_frac_of_sustained": achieved / SUSTAINED_FP32_MFMA_TFLOPS * executed_flop(name) / flop}
     tree_cls = [c for c in ("select", "compact", "expand") if prof[c]["launches"]]
     tree_ms = sum(prof[c]["ms"] for c in tree_cls)
     tree_bytes = 148.0 * trav + (16 + 136 + 64) * evals + 16.0 * (sims - evals)
@@ -497,6 +507,9 @@ def main():
                 # products with the zero padding are skipped: fraction of the fp32 MFMA peak the executed products amount to
                 "mfma_executed_frac": achieved / PEAK_FP32_MFMA_TFLOPS * executed_flop(kernel) / flop,
                 "executed_flop_per_board": executed_flop(kernel),
+                "sustained_peak": SUSTAINED_FP32_MFMA_TFLOPS,
+                "frac_of_sustained_peak": achieved / SUSTAINED_FP32_MFMA_TFLOPS,
+                "mfma_executed_frac_of_sustained": achieved / SUSTAINED_FP32_MFMA_TFLOPS * executed_flop(kernel) / flop,
             }
             out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
         if prof is not None and world == 1:

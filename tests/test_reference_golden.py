@@ -281,3 +281,14 @@ def test_unpinned_is_reported_not_hidden():
         pytest.skip("reference golden files present: parity is pinned")
     with pytest.raises(pytest.skip.Exception, match="parity unpinned"):
         load(GOLDEN, "ref_mcts.json")
+
+
+def test_check_golden_front_end(tmp_path):
+    """tools/check_golden.py: exit 0 on a directory the loader accepts (here: the pyref-written miniature), 1 while files are missing"""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "check_golden.py")
+    r = subprocess.run([sys.executable, tool, "--selftest"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count("ok ") == 3 and "NOT the reference's" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, tool, "--dir", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and r.stdout.count("MISSING") == 3 and "parity unpinned" in r.stdout
