@@ -113,14 +113,14 @@ extern "C" int az_debug_tree_stamps(az_engine* e, unsigned long long* out) {
   ENGINE(e);
   if (!out) {
     unsigned long long* d = nullptr;
-    AZCHK(dalloc(e, &d, 8));
+    AZCHK(dalloc(e, &d, 16));
     AZCHK(sync_all(e));
     e->v.dbg = d; e->gv[0].dbg = d;
     return AZ_OK;
   }
   if (!e->gv[0].dbg) return fail(AZ_ERR_STATE, "stamps are not enabled");
   AZCHK(sync_all(e));
-  HIPCHK(hipMemcpy(out, e->gv[0].dbg, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, e->gv[0].dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return AZ_OK;
 }
 extern "C" int az_debug_heads_timeline(az_engine* e, int32_t n, unsigned long long* out, int64_t cap) {

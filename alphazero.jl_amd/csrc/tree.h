@@ -82,7 +82,7 @@ struct DView {
   int* finished;          // [G] set by k_move when the slot's game ended this round
   int* err;               // device error word (first error wins)
   long long* stat;        // [0] simulations [1] nodes traversed [2] leaf evals [3] moves
-  unsigned long long* dbg; // optional [8] cycle stamps of k_tree's first wavefront (az_debug_tree_stamps): start, phase A done,
+  unsigned long long* dbg; // optional [16] cycle stamps of k_tree's first wavefront (az_debug_tree_stamps): start, phase A done,
                           // root loaded, descent done, leaf stored, block atomics done, end
 };
 
@@ -148,8 +148,34 @@ template <int STEP> __device__ __forceinline__ void argmax_step(double& s, int& 
   const int io = dpp_partner<STEP>(idx), co = dpp_partner<STEP>(carry);
   if (so > s || (so == s && io < idx)) { s = so; idx = io; carry = co; }
 }
+// L = 8: maximum first, position second.  The butterfly above exchanges (score, index, carry) and decides with two Float64
+// compares per round: ~45 instructions, most of them waiting on the previous one -- 876 cycles per ply with one or two
+// wavefronts on a SIMD (tools/tree_stamps.py; an all-pairs form with 14 Float64 compares was slower still: 1094).  Here the
+// three rounds only carry v_max_f64, ONE compare marks the lanes that hold the maximum, a ballot picks the lowest of them in
+// every group (ties, +0 = -0 included, go to the lowest lane as before), and the winner's link is OR-reduced over the group.
+template <int CTRL> __device__ __forceinline__ double dpp_ctrl(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int group_argmax8(double s, int lane, int* carry) {
+  constexpr int Q1 = 0xB1, Q2 = 0x4E, HM = 0x141;                  // quad_perm [1,0,3,2], [2,3,0,1]; row_half_mirror
+  double m = __builtin_fmax(s, dpp_ctrl<Q1>(s));
+  m = __builtin_fmax(m, dpp_ctrl<Q2>(m));
+  m = __builtin_fmax(m, dpp_ctrl<HM>(m));
+  const unsigned long long eq = __ballot(s == m);
+  const int base = (threadIdx.x & 63) & ~7;
+  const int idx = __ffs((unsigned)((eq >> base) & 0xffu)) - 1;
+  int c = (lane == idx) ? *carry : 0;                               // exactly one lane of the group contributes
+  c |= __builtin_amdgcn_update_dpp(0, c, Q1, 0xF, 0xF, false);
+  c |= __builtin_amdgcn_update_dpp(0, c, Q2, 0xF, 0xF, false);
+  c |= __builtin_amdgcn_update_dpp(0, c, HM, 0xF, 0xF, false);
+  *carry = c;
+  return idx;
+}
 template <int L> __device__ __forceinline__ int group_argmax(double s, int lane, int* carry) {
   static_assert(L == 8 || L == 16, "lane groups of 8 or 16");
+  if constexpr (L == 8) return group_argmax8(s, lane, carry);
   int idx = lane;
   argmax_step<0>(s, idx, *carry);
   argmax_step<1>(s, idx, *carry);
@@ -233,7 +259,7 @@ template <class Gm> __device__ inline void set_link(char* nd, int act, uint32_t 
 // one lane per ply); phase B one node record per ply (child links), a table probe only on edges never taken before.
 // =========================================================================================
 template <class Gm>
-__global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_backup, int do_select, int par) {   // 8 waves per SIMD = 64 VGPRs: fits beside two tower waves (2 x 224)
+__global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_backup, int do_select, int par) {   // 6 waves per SIMD = 80 VGPRs: fits beside two tower waves (2 x 176 + 80 of 512)
   __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   constexpr int L = Gm::APAD;
   using NL = NodeL<Gm>;
@@ -248,16 +274,27 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
   unsigned long long* dbg = (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) ? v.dbg : nullptr;
   if (dbg) dbg[0] = __builtin_readcyclecounter();
 
+  // Everything whose address does not depend on another load is requested up front, in one round trip: the pending leaf's
+  // kind / depth / batch index, the node count, the first L path entries (one per lane) and, for phase B, the root state and
+  // the epoch.  (Inside the branches below they were three dependent rounds: kind -> depth, eidx -> path, Pout.)
+  const int kind0 = (do_backup && live) ? v.leaf_kind[pslot] : LEAF_NONE;
+  const int depth0 = v.leaf_depth[pslot], e0 = v.eidx[pslot], nc0 = v.node_count[pslot];
+  const unsigned long long st0 = path[lane < v.max_depth ? lane : 0];
+  const GEnv root0 = v.root[pslot];
+  const uint32_t epoch0 = v.epoch[pslot], ins0 = v.leaf_ins[pslot];
+  const GEnv lenv0 = v.leaf_env[pslot];
+  const long long trav0 = v.tot_trav[pslot], sims0 = v.tot_sims[pslot];
+
   // ------------------------------------------------------------------ phase A: expand + backup
   if (do_backup && live) {
-    const int kind = v.leaf_kind[slot];
+    const int kind = kind0;
     if (kind != LEAF_NONE) {
-      const int depth = v.leaf_depth[slot];
+      const int depth = depth0;
       double q = 0.0;                                               // terminal: return 0.
       bool ok = true;
       if (kind == LEAF_NEW) {
-        const int e = v.eidx[slot];
-        const int idx = v.node_count[slot];
+        const int e = e0;
+        const int idx = nc0;
         if (idx >= (v.slot_cap ? v.slot_cap[slot] : v.cap_nodes)) {
           // the slot's pool is exhausted (the reference has no such limit, src/mcts.jl:124-151): self-play retires the slot --
           // its game is reported as aborted and the phase goes on; the hooks report a capacity error
@@ -265,7 +302,7 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
           if (!p.retire) dev_fail(v, DERR_NODE_POOL);
           else if (lane == 0) { v.finished[slot] = 2; v.active[slot] = 0; v.leaf_kind[slot] = LEAF_NONE; }
         } else {
-          const GEnv env = v.leaf_env[slot];
+          const GEnv env = lenv0;
           const uint32_t m = Gm::mask(env);
           float Pf = v.Pout[(size_t)e * L + lane];
           const float V = v.Vout[e];
@@ -284,6 +321,8 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
             Pf = av ? (float)res : 0.f;
           }
           char* nd = node_at<Gm>(v, slot, idx);
+          // the edge that reached the new node: entry depth - 1 of the path, already in lane depth - 1's register when depth <= L
+          const unsigned long long st_par = (depth >= 1 && depth <= L) ? __shfl(st0, gbase + depth - 1) : (depth > L ? path[depth - 1] : 0ULL);
           if (lane < Gm::A) {
             *NL::stat(nd, lane) = typename NL::Stat{0.0, 0, Pf};
             ((uint16_t*)(nd + NL::OFF_LO))[lane] = 0;
@@ -294,13 +333,12 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
             kk[0] = env.a; kk[1] = env.b; kk[2] = (unsigned long long)__float_as_uint(V);
             const unsigned long long hk = az_hash_key(env.a, env.b);
             const unsigned long long tag = (hk >> 40) & 0xffff;
-            v.ht[(size_t)slot * v.ht_size + v.leaf_ins[slot]] =
-                ((unsigned long long)v.epoch[slot] << 48) | (tag << 32) | (unsigned long long)(idx + 1);
+            v.ht[(size_t)slot * v.ht_size + ins0] =
+                ((unsigned long long)epoch0 << 48) | (tag << 32) | (unsigned long long)(idx + 1);
             v.node_count[slot] = idx + 1;
             if (depth == 0) v.root_idx[slot] = idx;
             else if (links_ok) {                                    // memoise tree[state] on the edge that reached it
-              const unsigned long long st = path[depth - 1];
-              set_link<Gm>(node_at<Gm>(v, slot, (int)(uint32_t)st), (int)((st >> 32) & 0xff), (uint32_t)(idx + 1));
+              set_link<Gm>(node_at<Gm>(v, slot, (int)(uint32_t)st_par), (int)((st_par >> 32) & 0xff), (uint32_t)(idx + 1));
             }
           }
           q = (double)V;                                            // return info.Vest
@@ -311,7 +349,7 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
         // arithmetic on shuffled path entries, the read-modify-writes of a chunk of L plies go out together
         for (int c = (depth - 1) / L; c >= 0 && depth > 0; --c) {
           const int k0 = c * L, kn = (depth - k0) < L ? (depth - k0) : L;
-          const unsigned long long st = lane < kn ? path[k0 + lane] : 0ULL;
+          const unsigned long long st = lane < kn ? (c == 0 ? st0 : path[k0 + lane]) : 0ULL;
           double qmine = 0.0;
           for (int k = kn - 1; k >= 0; --k) {
             const unsigned long long sk = __shfl(st, gbase + k);
@@ -328,8 +366,8 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
           }
         }
         if (lane == 0) {
-          v.tot_trav[slot] += depth;                                // mcts.jl:222
-          v.tot_sims[slot] += 1;                                    // mcts.jl:242
+          v.tot_trav[slot] = trav0 + depth;                         // mcts.jl:222
+          v.tot_sims[slot] = sims0 + 1;                             // mcts.jl:242
         }
       }
     }
@@ -342,12 +380,17 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
   // ------------------------------------------------------------------ phase B: select
   int depth = 0, kind = LEAF_NONE;
   if (live && v.active[slot]) {
-    GEnv env = v.root[slot];
-    const uint32_t epoch = v.epoch[slot];
+    GEnv env = root0;
+    const uint32_t epoch = epoch0;
     int idx = v.root_idx[slot];
     bool probe = idx < 0;
     uint32_t ins = 0;
     int pidx = 0, pact = 0;
+    const bool inrec = lane < Gm::A;
+    // what a lane holds of a node: its action's statistics (one 16-byte load), its link's low half, the shared high bits
+    typename NL::Stat sa = {0.0, 0, 0.0f};
+    uint32_t lo = 0, hi = 0;
+    bool have = false;                                              // sa / lo / hi already hold node idx (requested a ply ago)
     for (;;) {
       if (env.fin & 1) { kind = LEAF_TERMINAL; break; }             // mcts.jl:200-201
       if (probe) {                                                  // haskey(env.tree, state), mcts.jl:165-174
@@ -357,17 +400,18 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
           if (depth == 0) v.root_idx[slot] = idx;
           else if (links_ok) set_link<Gm>(node_at<Gm>(v, slot, pidx), pact, (uint32_t)(idx + 1));
         }
+        have = false;
       }
       if (depth >= v.max_depth) { dev_fail(v, DERR_DEPTH); kind = LEAF_NONE; break; }
-      const char* nd = node_at<Gm>(v, slot, idx);
+      if (!have) {
+        const char* nd = node_at<Gm>(v, slot, idx);
+        if (inrec) { sa = *NL::stat(nd, lane); lo = ((const uint16_t*)(nd + NL::OFF_LO))[lane]; }
+        hi = *(const typename NL::hi_t*)(nd + NL::OFF_HI);
+      }
       const uint32_t amask = Gm::mask(env);
-      const bool inrec = lane < Gm::A;
-      const typename NL::Stat sa = inrec ? *NL::stat(nd, lane) : typename NL::Stat{0.0, 0, 0.0f};
       const int N = sa.N;
       const float Pf = sa.P;
       const double W = sa.W;
-      const uint32_t lo = inrec ? ((const uint16_t*)(nd + NL::OFF_LO))[lane] : 0;
-      const uint32_t hi = *(const typename NL::hi_t*)(nd + NL::OFF_HI);
       const int link = (int)(lo | (((hi >> (2 * lane)) & 3u) << 16));
       if (dbg && depth == 0) dbg[2] = __builtin_readcyclecounter() + (unsigned long long)(N & 0);   // after the root record has arrived
       // uct_scores (mcts.jl:180-188): Float64, evaluated left to right
@@ -379,7 +423,19 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
       double sc = Q + p.cpuct * Pd * sqrtNtot / (double)(N + 1);
       if (!((amask >> lane) & 1)) sc = -__builtin_inf();
       int nxt = link;                                               // the winner's child link travels with the argmax
+      if (dbg && depth == 0) dbg[7] = __builtin_readcyclecounter() + (unsigned long long)(__double2loint(sc) & 0);   // scores of the root ready
       const int act = group_argmax<L>(sc, lane, &nxt);
+      if (dbg && depth == 0) dbg[8] = __builtin_readcyclecounter() + (unsigned long long)(act & 0);   // argmax done
+      // The child's record is requested NOW, before play! / the terminal test / the path entry: its address needs only the link,
+      // and the ~840 cycles of a dependent load cover that work (round 2 issued it a ply later, after all of it).  A link is
+      // only ever written for a stored state, so the address is valid even if the child turns out to be unreachable because
+      // the game ended (then the data is dropped).
+      have = nxt != 0;
+      if (have) {
+        const char* nd = node_at<Gm>(v, slot, nxt - 1);
+        if (inrec) { sa = *NL::stat(nd, lane); lo = ((const uint16_t*)(nd + NL::OFF_LO))[lane]; }
+        hi = *(const typename NL::hi_t*)(nd + NL::OFF_HI);
+      }
       const bool wp = Gm::white_playing(env);
       Gm::play(env, act);                                           // mcts.jl:213-217
       const float wr = Gm::white_reward(env);
@@ -389,6 +445,7 @@ __global__ void __launch_bounds__(256, 8) k_tree(DView v, DParams p, int do_back
         path[depth] = (unsigned long long)(uint32_t)idx | ((unsigned long long)act << 32) |
                       ((unsigned long long)(psw ? 1 : 0) << 40) | ((unsigned long long)(r + 1) << 41);
       pidx = idx; pact = act;
+      if (dbg && depth == 0) dbg[9] = __builtin_readcyclecounter() + (env.a & 0);   // play! / reward / path entry of the first ply done
       depth++;
       probe = nxt == 0;
       idx = nxt - 1;

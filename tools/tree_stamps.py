@@ -26,7 +26,7 @@ check(f(e._h, None))
 rows = []
 for _ in range(a.waves):
     e.selfplay_step(1)
-    out = np.zeros(8, dtype=np.uint64)
+    out = np.zeros(16, dtype=np.uint64)
     check(f(e._h, out.ctypes.data_as(C.c_void_p)))
     rows.append(out.astype(np.int64))
 t = np.array(rows)
@@ -35,3 +35,5 @@ print("k_tree, %d slots, hash oracle: cycles between stamps of block 0 / wavefro
 for name, col in zip(("phase A (expand + backup)", "fence + slot state + root record", "descent", "leaf stores", "block atomics + barrier", "eval slot stores"), range(6)):
     print("  %-34s %8.0f" % (name, np.median(d[:, col])))
 print("  %-34s %8.0f" % ("total", np.median(t[:, 6] - t[:, 0])))
+print("  first ply: record arrived -> scores %.0f, argmax %.0f, play! + reward + path entry %.0f; rest of the descent %.0f"
+      % (np.median(t[:, 7] - t[:, 2]), np.median(t[:, 8] - t[:, 7]), np.median(t[:, 9] - t[:, 8]), np.median(t[:, 3] - t[:, 9])))
