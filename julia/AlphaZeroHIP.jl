@@ -513,10 +513,30 @@ end
 More specific method of the reference's function (src/simulations.jl:252-290) for games with a device twin: one Julia worker
 process per GPU (worker i drives device i-1), the games split by `divrem` exactly as the reference does, every worker runs
 `simulate` on its GPU with GLOBAL game ids (so the traces do not depend on the number of workers), results fetched and
-concatenated in worker order = game-id order.  This form returns host traces like the reference; `device_self_play_step!`
-below is the form in which no record leaves the GPUs.
+concatenated in worker order = game-id order: host traces like the reference's.  With `comm` (and `memory`) the call is ONE
+RANK of a job with one process per GPU: device-only phase + `az_comm_gather_push`, no record leaves the GPUs;
+`device_self_play_step!` below wraps that form into `self_play_step!`'s report.
 """
-function AlphaZero.simulate_distributed(simulator::Simulator, gspec::DeviceGameSpec, p::SimParams; game_simulated, seed=1)
+function AlphaZero.simulate_distributed(simulator::Simulator, gspec::DeviceGameSpec, p::SimParams; game_simulated, seed=1,
+                                        comm::Union{Nothing, Comm}=nothing, memory::Union{Nothing, DeviceMemory}=nothing, gamma=1.0)
+  if !isnothing(comm)
+    # One rank of a multi-GPU job (one process per GPU, `comm` over RCCL): the shard of this rank is simulated DEVICE-ONLY
+    # with global game ids, then ONE collective all-gathers the records of all ranks and pushes every game, in game-id order,
+    # into this rank's device memory (`az_comm_gather_push`).  Returns the GatherStats (games, samples, depth, footprint).
+    oracle = simulator.make_oracles()
+    player = simulator.make_player(oracle)
+    @assert oracle isa HipResNet && player isa MctsPlayer "the device-only form needs MctsPlayer + HipResNet"
+    first, count = shard_games(p.num_games, comm.world, comm.rank)
+    m = player.mcts
+    mp = MctsParams(gamma=m.gamma, cpuct=m.cpuct, num_iters_per_turn=player.niters, temperature=player.τ,
+                    dirichlet_noise_ϵ=m.noise_ϵ, dirichlet_noise_α=m.noise_α, prior_temperature=m.prior_temperature)
+    e = Engine(make_cfg(gspec, mp, SimParams(p; num_games=count), oracle.hyper; seed=seed, device=comm.device))
+    check(ccall((:az_net_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, oracle.blob, length(oracle.blob)))
+    selfplay_device_only!(e, count, first; game_simulated=game_simulated)
+    gs = gather_push!(comm, e, memory, gamma)
+    release_phase!(e)
+    return gs
+  end
   workers = Distributed.workers()
   length(workers) == 1 && return AlphaZero.simulate(simulator, gspec, p; game_simulated=game_simulated, seed=seed)
   chan = Distributed.RemoteChannel(() -> Channel{Nothing}(1))
