@@ -183,7 +183,8 @@ def test_every_entry_point_of_the_header_is_bound_or_listed_as_unbound():
               "az_memory_push_engine", "az_engine_release_phase", "az_mcts_explore", "az_mcts_node_stats", "az_mcts_counters", "az_mcts_reset"):
         assert f in bound, f
     assert "function AlphaZero.simulate_distributed(simulator::Simulator, gspec::DeviceGameSpec" in JL
-    body = JL[JL.index("function AlphaZero.simulate_distributed("):JL.index("    device_self_play_step!")]
+    start = JL.index("function AlphaZero.simulate_distributed(")
+    body = JL[start:JL.index("function device_self_play_step!", start)]
     # the rank form: divrem shard, device-only phase, ONE collective into the rank's device memory
     assert "shard_games(p.num_games, comm.world, comm.rank)" in body and "selfplay_device_only!(e, count, first" in body and "gather_push!(comm, e, memory, gamma)" in body
 
