@@ -225,12 +225,17 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       const size_t chunk_nodes = VM_CHUNK / gi.node_bytes;
       const bool pow2 = (chunk_nodes & (chunk_nodes - 1)) == 0 && chunk_nodes * gi.node_bytes == VM_CHUNK;
       const bool want = fv ? atoi(fv) != 0 : pool_bytes > VM_THRESHOLD;
-      if (want && pow2 && (size_t)cap > chunk_nodes && gi.node_bytes > 0) {
+      void* base = nullptr;
+      const int rows = (int)((cap + chunk_nodes - 1) / chunk_nodes);
+      const size_t vbytes = (size_t)rows * G * VM_CHUNK;
+      // a runtime without virtual memory management (or without room in the address space) gets the plain pool
+      const bool vm_ok = want && pow2 && (size_t)cap > chunk_nodes && gi.node_bytes > 0 &&
+                         hipMemAddressReserve(&base, vbytes, VM_CHUNK, nullptr, 0) == hipSuccess;
+      if (want && !vm_ok) (void)hipGetLastError();
+      if (vm_ok) {
         e->vm_chunk = VM_CHUNK; e->vm_chunk_nodes = (int)chunk_nodes;
-        e->vm_rows = (int)((cap + chunk_nodes - 1) / chunk_nodes);
-        e->vm_bytes = (size_t)e->vm_rows * G * VM_CHUNK;
-        void* base = nullptr;
-        HIPCHK(hipMemAddressReserve(&base, e->vm_bytes, VM_CHUNK, nullptr, 0));
+        e->vm_rows = rows;
+        e->vm_bytes = vbytes;
         e->vm_base = (char*)base;
         size_t fr = 0, tot = 0;
         HIPCHK(hipMemGetInfo(&fr, &tot));
@@ -891,6 +896,7 @@ static int explore_slots(az_engine* e, const std::vector<int>& slots, const std:
                          const std::vector<uint32_t>& gids, const std::vector<uint32_t>& mv, const double* eta, int nsims) {
   int nga = 0;
   AZCHK(explore_begin<Gm>(e, slots, roots, gids, mv, eta, &nga));
+  AZCHK(vm_grow(e, nsims + 2));                                    // mapped-on-demand pool: room for this explore! (a no-op for plain pools)
   if (nga) AZCHK(run_waves<Gm>(e, nga, nsims, 0));
   return explore_end<Gm>(e, nga);
 }

@@ -73,3 +73,19 @@ def test_mapped_on_demand_pool_gives_the_plain_pool_s_games_and_holds_less_memor
     ref = {games[i].game_id: [(tuple(moves[games[i].first_move + k].key), list(moves[games[i].first_move + k].N), moves[games[i].first_move + k].action)
                               for k in range(games[i].num_moves)] for i in range(8)}
     assert out["1"][0] == ref
+
+
+def test_explore_on_a_mapped_pool_grows_past_its_first_chunk(monkeypatch):
+    """MCTS.explore! through the hook (az_mcts_explore) on a mapped-on-demand pool: 30 000 simulations from one root need more
+    nodes than the 16 384 of the first 2 MB chunk -- the chunks are mapped before the waves run, the tree equals the plain pool's"""
+    import azhip
+    out = {}
+    for vmm in ("0", "1"):
+        monkeypatch.setenv("AZHIP_VMM", vmm)
+        with azhip.Engine(game=R.C4, oracle=azhip.ORACLE_HASH, num_workers=2, batch_size=2, num_iters_per_turn=8, cpuct=2.0,
+                          dirichlet_noise_eps=0.0, max_nodes_per_slot=40000) as e:
+            key = e.init_key()
+            e.mcts_explore([key, key], 30000)
+            N, W, P, V, mask = e.mcts_node_stats(1, key)
+            out[vmm] = (list(N), list(W), e.mcts_counters(1))
+    assert out["0"] == out["1"] and out["1"][2][2] > 16384 and sum(out["1"][0]) == 29999
