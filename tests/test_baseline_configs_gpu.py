@@ -71,3 +71,11 @@ def test_config4_mancala_8192_slots_800_sims():
     an 8192-slot engine (games/mancala/params.jl:23-29: cpuct 2, eps 0.25, alpha 1, PLSchedule([0, 20, 30], [1, 1, 0.3]))."""
     import azhip
     _run_case(azhip.GAME_MANCALA, R.MANCALA, 8192, 2, 800, 6, 0, C4_SCHED, False)
+
+
+def test_config1_tictactoe_32_games_64_sims():
+    """BASELINE configs[0] (the reference's own CPU-runnable case: Tic-tac-toe, 64 sims/move, 32 parallel games) on the device:
+    ALL 32 games of a 32-slot engine against the oracle, record by record (search constants as in the other cases)."""
+    import azhip
+    st = _run_case(azhip.GAME_TICTACTOE, R.TTT, 32, 1, 64, 32, 0, ((0,), (1.0,)), True, full_games=32)
+    assert st.games == 32 and st.simulations == 64 * st.moves
