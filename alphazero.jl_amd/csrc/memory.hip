@@ -11,7 +11,7 @@
 // arrays.  The network forward of the loss is the same fused tower + heads as self-play (test mode).
 // The loss's network forward goes through net_launch (engine.h).
 #include "engine.h"
-#include <hipcub/hipcub.hpp>
+#include "prims.h"
 
 // push_trace! (memory.jl:74-87): one thread per game walks its records from the last position to the first
 template <class Gm>
@@ -235,22 +235,20 @@ __global__ void __launch_bounds__(256) k_batch_sums(const double* __restrict__ t
   if (threadIdx.x < 5) out[(size_t)blockIdx.x * 5 + threadIdx.x] = sh[threadIdx.x][0];
 }
 
-struct DevReducer {                     // hipcub::DeviceReduce::Sum over double ranges (deterministic for a given size)
-  void* tmp = nullptr; size_t tmp_bytes = 0; double* d_out = nullptr;
-  int init(long long nmax, hipStream_t st) {
-    HIPCHK(hipcub::DeviceReduce::Sum(nullptr, tmp_bytes, (const double*)nullptr, (double*)nullptr, (int)nmax, st));
-    HIPCHK(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-    HIPCHK(hipMalloc((void**)&d_out, sizeof(double)));
+struct DevReducer {                     // deterministic sum of doubles (prims.h: fixed tiles, fixed tree)
+  double* tmp = nullptr;
+  int init(long long nmax, hipStream_t) {
+    HIPCHK(hipMalloc((void**)&tmp, sizeof(double) * prims::sum_tmp_doubles(nmax)));
     return AZ_OK;
   }
   int sum(const double* d_in, long long n, hipStream_t st, double* out) {
-    size_t tb = tmp_bytes;
-    HIPCHK(hipcub::DeviceReduce::Sum(tmp, tb, d_in, d_out, (int)n, st));
-    HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double), hipMemcpyDeviceToHost, st));
+    double* d_res = nullptr;
+    HIPCHK(prims::sum_doubles(d_in, n, tmp, &d_res, st));
+    HIPCHK(hipMemcpyAsync(out, d_res, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return AZ_OK;
   }
-  ~DevReducer() { if (tmp) (void)hipFree(tmp); if (d_out) (void)hipFree(d_out); }
+  ~DevReducer() { if (tmp) (void)hipFree(tmp); }
 };
 
 #define MEMORY(m) if (!(m)) return fail(AZ_ERR_BAD_ARG, "memory is NULL"); HIPCHK(hipSetDevice((m)->device))
@@ -407,17 +405,13 @@ static int dataset_build(az_memory* m, az_dataset* d, int which, bool use_sym, b
       const unsigned gb = (unsigned)((n1 + 255) / 256);
       hipLaunchKernelGGL(k_mem_keys, dim3(gb), dim3(256), 0, st, s1, (long long)n1, k0, k1, i0);
       // LSD: stable sort by key[1], then by key[0] -> ascending (key[0], key[1], buffer index)
-      size_t tb = 0;
-      HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k1, ks, i0, i1, (int)n1, 0, 64, st));
-      void* tbuf; AZCHK(mem_alloc<char>(&tmp, (char**)&tbuf, tb));
-      HIPCHK(hipcub::DeviceRadixSort::SortPairs(tbuf, tb, k1, ks, i0, i1, (int)n1, 0, 64, st));
+      int* stmp;
+      AZCHK(mem_alloc(&tmp, &stmp, std::max(prims::sort_tmp_ints(n1), prims::scan_tmp_ints(n1))));
+      HIPCHK(prims::sort_pairs(k1, ks, i0, i1, n1, stmp, st));        // (k1, i0) are the sort's ping-pong partner: not used again
       hipLaunchKernelGGL(k_mem_gather_u64, dim3(gb), dim3(256), 0, st, k0, i1, (long long)n1, ks2);
-      HIPCHK(hipcub::DeviceRadixSort::SortPairs(tbuf, tb, ks2, ks, i1, i2, (int)n1, 0, 64, st));
+      HIPCHK(prims::sort_pairs(ks2, ks, i1, i2, n1, stmp, st));
       hipLaunchKernelGGL(k_mem_heads, dim3(gb), dim3(256), 0, st, s1, i2, (long long)n1, head);
-      size_t sb = 0;
-      HIPCHK(hipcub::DeviceScan::InclusiveSum(nullptr, sb, head, seg, (int)n1, st));
-      void* sbuf; AZCHK(mem_alloc<char>(&tmp, (char**)&sbuf, sb));
-      HIPCHK(hipcub::DeviceScan::InclusiveSum(sbuf, sb, head, seg, (int)n1, st));
+      HIPCHK(prims::scan_ints(head, seg, n1, true, stmp, st));
       int nseg = 0;
       HIPCHK(hipMemcpyAsync(&nseg, seg + (n1 - 1), sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));

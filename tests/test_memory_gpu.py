@@ -92,6 +92,25 @@ def test_long_segments_merge_in_buffer_order():
     mem.close()
 
 
+def test_large_data_set_sorts_scans_and_sums_across_many_tiles():
+    """merge_by_state on ~100 k augmented samples: the hand-written radix sort (csrc/prims.h: 8 passes over ~50 tiles, two stable
+    sorts for the 128-bit key), the multi-level scan and the tiled double sum, against the oracle's sequential merge"""
+    import azhip
+    gspec = azhip.ConnectFourSpec()
+    games, moves, ng, nm, _ = _selfplay(0, 2500, 512, 8, 9)
+    ref = R.merge_by_state(0, R.augment_with_symmetries(0, _oracle_samples(0, games, moves, ng, 1.0)))
+    assert 2 * nm > 80000
+    mem = azhip.MemoryBuffer(gspec, 200000)
+    mem.push_records(games, moves, ng, nm, 1.0)
+    with mem.dataset(use_symmetries=True, use_position_averaging=True, weighing_policy=azhip.LOG_WEIGHT) as d:
+        _same_samples(d.raw_samples(), ref, 7)
+        W, X, A, P, V = d.tensors()
+        Wr = R.convert_samples(0, 1, ref)[0]
+        assert np.array_equal(W, Wr) and d.sum_n == 2 * nm
+        assert abs(d.Wtot - float(Wr.astype(np.float64).sum())) < 1e-9 * d.Wtot
+    mem.close()
+
+
 def test_circular_buffer_semantics():
     """CircularBuffer(size) + cur_batch_size / last_batch / new_batch! / empty! (memory.jl:34-60)"""
     import azhip
