@@ -1,0 +1,35 @@
+"""bench.py's N > 1 path as the driver launches it (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`),
+rehearsed on the ONE GPU of the test box: two ranks share cuda:0 and the library's exchange runs over the test-only transport
+(AZHIP_RCCL_LIB -> tests/rccl_stub; RCCL itself refuses two ranks per device).  What it proves: the rendezvous over gloo, the
+barrier + max-over-ranks timing, the summed counters, and the exchange leg after the timed region (weights broadcast, device-only
+phases with global game ids, az_comm_gather_push into every rank's device memory) run end to end with W = 2."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_on_one_gpu_print_one_line_with_the_gather_leg():
+    stub = os.path.join(ROOT, "tests", "rccl_stub", "librccl_stub.so")
+    if not os.path.exists(stub):
+        subprocess.check_call(["make", "-C", os.path.dirname(stub)])
+    env = dict(os.environ, AZHIP_RCCL_LIB=stub, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29000 + os.getpid() % 900
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--slots", "512"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]          # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["sims_per_sec_per_gpu"] * 2 - d["value"]) < 1e-6 * d["value"]
+    g = d["gather"]
+    assert "error" not in g, g
+    assert g["ranks"] == 2 and g["world"] == 2 and g["rendezvous"].endswith("gloo")
+    assert g["games"] == 1024 and g["memory_length"] == g["samples"] > 1024 * 7                  # every rank holds all ranks' samples
+    assert "extra" not in d and "cpu_baseline" not in d                                         # those legs belong to N = 1
