@@ -39,6 +39,11 @@
  * az_numerics.h.  The reference (Flux/NNlib/cuDNN) defines no summation order; any order
  * is within the 1e-5 tolerance BASELINE.json states, this one is also reproducible.
  *
+ * Environment (diagnostics and tests; the product path sets none of them): AZHIP_TOWER / AZHIP_HEADS force a tower / heads kernel
+ * (read at az_engine_create), AZHIP_GRAPH=1 replays wave pairs as hipGraphs, AZHIP_VMM=0|1 forces the plain / mapped-on-demand
+ * node pool and AZHIP_POOL_GB bounds the physical memory of the latter, AZHIP_RCCL_LIB=<path> substitutes the library az_comm_*
+ * loads (tests/rccl_stub: several ranks on one GPU).
+ *
  * RNG contract: include/az_numerics.h (philox4x32-10 keyed by seed, counter = game id,
  * move index, purpose, draw index).
  */
