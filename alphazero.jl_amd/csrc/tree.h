@@ -140,15 +140,8 @@ template <int L> __device__ __forceinline__ int group_sum(int x) {
   if constexpr (L == 16) x += dpp_partner<3>(x);
   return x;
 }
-// first maximum: highest score, ties to the lowest lane (argmax, src/mcts.jl:211); `carry` travels with the winner
-// (every lane ends with the winner's index and carry: the order (score desc, lane asc) is total, so both lanes of a pair
-// pick the same one)
-template <int STEP> __device__ __forceinline__ void argmax_step(double& s, int& idx, int& carry) {
-  const double so = dpp_partner<STEP>(s);
-  const int io = dpp_partner<STEP>(idx), co = dpp_partner<STEP>(carry);
-  if (so > s || (so == s && io < idx)) { s = so; idx = io; carry = co; }
-}
-// L = 8: maximum first, position second.  The butterfly above exchanges (score, index, carry) and decides with two Float64
+// first maximum: highest score, ties to the lowest lane (argmax, src/mcts.jl:211); `carry` travels with the winner.
+// Maximum first, position second.  The round-2 butterfly exchanged (score, index, carry) and decided with two Float64
 // compares per round: ~45 instructions, most of them waiting on the previous one -- 876 cycles per ply with one or two
 // wavefronts on a SIMD (tools/tree_stamps.py; an all-pairs form with 14 Float64 compares was slower still: 1094).  Here the
 // three rounds only carry v_max_f64, ONE compare marks the lanes that hold the maximum, a ballot picks the lowest of them in
@@ -158,29 +151,22 @@ template <int CTRL> __device__ __forceinline__ double dpp_ctrl(double x) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ int group_argmax8(double s, int lane, int* carry) {
-  constexpr int Q1 = 0xB1, Q2 = 0x4E, HM = 0x141;                  // quad_perm [1,0,3,2], [2,3,0,1]; row_half_mirror
+template <int L> __device__ __forceinline__ int group_argmax(double s, int lane, int* carry) {
+  static_assert(L == 8 || L == 16, "lane groups of 8 or 16");
+  constexpr int Q1 = 0xB1, Q2 = 0x4E, HM = 0x141, RM = 0x140;      // quad_perm [1,0,3,2], [2,3,0,1]; row_half_mirror; row_mirror
   double m = __builtin_fmax(s, dpp_ctrl<Q1>(s));
   m = __builtin_fmax(m, dpp_ctrl<Q2>(m));
   m = __builtin_fmax(m, dpp_ctrl<HM>(m));
+  if constexpr (L == 16) m = __builtin_fmax(m, dpp_ctrl<RM>(m));
   const unsigned long long eq = __ballot(s == m);
-  const int base = (threadIdx.x & 63) & ~7;
-  const int idx = __ffs((unsigned)((eq >> base) & 0xffu)) - 1;
+  const int base = (threadIdx.x & 63) & ~(L - 1);
+  const int idx = __ffs((unsigned)((eq >> base) & ((1u << L) - 1u))) - 1;
   int c = (lane == idx) ? *carry : 0;                               // exactly one lane of the group contributes
   c |= __builtin_amdgcn_update_dpp(0, c, Q1, 0xF, 0xF, false);
   c |= __builtin_amdgcn_update_dpp(0, c, Q2, 0xF, 0xF, false);
   c |= __builtin_amdgcn_update_dpp(0, c, HM, 0xF, 0xF, false);
+  if constexpr (L == 16) c |= __builtin_amdgcn_update_dpp(0, c, RM, 0xF, 0xF, false);
   *carry = c;
-  return idx;
-}
-template <int L> __device__ __forceinline__ int group_argmax(double s, int lane, int* carry) {
-  static_assert(L == 8 || L == 16, "lane groups of 8 or 16");
-  if constexpr (L == 8) return group_argmax8(s, lane, carry);
-  int idx = lane;
-  argmax_step<0>(s, idx, *carry);
-  argmax_step<1>(s, idx, *carry);
-  argmax_step<2>(s, idx, *carry);
-  if constexpr (L == 16) argmax_step<3>(s, idx, *carry);
   return idx;
 }
 template <int L> __device__ __forceinline__ int group_argmax(double s, int lane) { int c = 0; return group_argmax<L>(s, lane, &c); }
