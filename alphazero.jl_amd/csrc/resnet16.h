@@ -764,7 +764,7 @@ k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restric
 template <class Gm, int F, bool STATS>
 __global__ void __launch_bounds__(T16Threads<F>::V, 2)
 k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, float* __restrict__ out, int nboards, const uint16_t* __restrict__ geo,
-               double* __restrict__ part) {
+               double* __restrict__ part, const float* __restrict__ addend) {
   using T = T16<Gm, F, 11>;
   using G = typename T::Geo;
   constexpr int P = Gm::P, STRIDE = T::STRIDE, NT = 11;
@@ -802,7 +802,9 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
     for (int i = 0; i < 4; ++i) {
       const int ps = pos[tile * 16 + g * 4 + i];
       if (ps < nvalid) {
-        o[(size_t)ps * F + ch] = acc[tile][i];
+        // addend (the data-gradient pass of a block's first convolution): the skip connection's share of the gradient joins here
+        // instead of in a pass of its own over the 22 MB tensor (same single fp32 add)
+        o[(size_t)ps * F + ch] = addend ? acc[tile][i] + (addend + (size_t)board0 * P * F)[(size_t)ps * F + ch] : acc[tile][i];
         if constexpr (STATS) { const double v = (double)acc[tile][i]; s0 += v; s1 += v * v; }
       }
     }

@@ -160,10 +160,6 @@ __global__ void k_tr_bn_bwd(const float* __restrict__ da, const float* __restric
   dg[i] = gamma[c] * invstd[c] * (dy - m0 - xh * m1);
   if (dy_out) dy_out[i] = dy;
 }
-__global__ void k_tr_add(float* __restrict__ x, const float* __restrict__ y, long long n) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] += y[i];
-}
 // dense epilogues: y = [relu](x + bias[c]);  backward mask: dx = dy * (y > 0)
 __global__ void k_tr_bias_act(float* __restrict__ x, const float* __restrict__ bias, long long n, int C, int relu) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -446,21 +442,21 @@ static int trainer_build(az_trainer* t) {
   return AZ_OK;
 }
 
-template <class Gm, int F, bool STATS> static int tr_conv16_f(az_trainer* t, const float* in, const float* frag, float* out) {
+template <class Gm, int F, bool STATS> static int tr_conv16_f(az_trainer* t, const float* in, const float* frag, float* out, const float* addend) {
   using T = T16<Gm, F, 11>;
   static bool attr_done = false;
   if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_layer<Gm, F, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, T::BYTES)); attr_done = true; }
-  hipLaunchKernelGGL((k_conv16_layer<Gm, F, STATS>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[0], t->part);
+  hipLaunchKernelGGL((k_conv16_layer<Gm, F, STATS>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[0], t->part, addend);
   return AZ_OK;
 }
 // 3x3 F -> F convolution of [R][F] activations on the MFMA layer kernel; stats: also the first stage of the column sums
 // (sum, sum of squares) of the output in t->part, *nparts workgroup partials
-static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* out, bool stats = false, int* nparts = nullptr) {
+static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* out, bool stats = false, int* nparts = nullptr, const float* addend = nullptr) {
   DISPATCH_GAME(t->game, {
     using T = T16<Gm, 64, 11>;
     if (nparts) *nparts = (t->B + T::TB - 1) / T::TB;
-    if (t->F == 128) { if (stats) AZCHK((tr_conv16_f<Gm, 128, true>(t, in, frag, out))); else AZCHK((tr_conv16_f<Gm, 128, false>(t, in, frag, out))); }
-    else { if (stats) AZCHK((tr_conv16_f<Gm, 64, true>(t, in, frag, out))); else AZCHK((tr_conv16_f<Gm, 64, false>(t, in, frag, out))); }
+    if (t->F == 128) { if (stats) AZCHK((tr_conv16_f<Gm, 128, true>(t, in, frag, out, addend))); else AZCHK((tr_conv16_f<Gm, 128, false>(t, in, frag, out, addend))); }
+    else { if (stats) AZCHK((tr_conv16_f<Gm, 64, true>(t, in, frag, out, addend))); else AZCHK((tr_conv16_f<Gm, 64, false>(t, in, frag, out, addend))); }
   });
   return AZ_OK;
 }
@@ -596,10 +592,9 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
     else AZCHK(tr_gemm(t, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, da, c.cout, 0.f, gw + c.wk_wm, c.cout));
     if (l == 0) break;
     // data gradient da_prev = conv(dg, mirrored taps, ci <-> co): the same MFMA layer kernel with the wk_fdg fragments, out of place
-    AZCHK(tr_conv16(t, da, t->work + c.wk_fdg, da_alt));
-    std::swap(da, da_alt);
     const bool first_of_block = (l % 2) == 1;                      // conv1: its input is the block input, which also gets the skip share
-    if (first_of_block) hipLaunchKernelGGL(k_tr_add, dim3(tr_grid(R * F)), dim3(256), 0, st, da, t->dact2, R * F);
+    AZCHK(tr_conv16(t, da, t->work + c.wk_fdg, da_alt, false, nullptr, first_of_block ? t->dact2 : nullptr));   // (r3) the add rides in the epilogue
+    std::swap(da, da_alt);
   }
   // working-layout weight gradients -> blob layout (the rotated copies carry no gradient of their own: their slots in
   // gwork stay zero and map to the same blob entries, so scatter only the primary ranges)
