@@ -106,3 +106,21 @@ def test_new_record_layouts():
     assert abs(cfg.lr - 2e-3) < 1e-9 and cfg.l2_regularization == 1e-4       # games/connect-four/params.jl:46-58
     assert C.sizeof(L.DatasetInfo) == 32 and C.sizeof(L.LearningStatusRec) == 28
     assert L.lib().az_train_cfg_init(None) == L.AZ_ERR_BAD_ARG
+
+
+def test_transport_stub_exports_the_entry_points_comm_hip_binds():
+    """tests/rccl_stub (TEST infrastructure: several ranks on one GPU) must offer exactly the symbols csrc/comm.hip looks up"""
+    import ctypes
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "tests", "rccl_stub")], stdout=subprocess.DEVNULL)
+    src = open(os.path.join(root, "alphazero.jl_amd", "csrc", "comm.hip")).read()
+    wanted = set(re.findall(r'dlsym\(so, "(nccl[A-Za-z]+)"\)', src))
+    assert wanted == {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclAllGather", "ncclBroadcast", "ncclGetErrorString"}
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(root, "tests", "rccl_stub", "librccl_stub.so")], text=True)
+    have = set(re.findall(r"\bT (nccl[A-Za-z]+)", out))
+    assert wanted <= have, wanted - have
+    # the product never names the stub: only the environment variable does
+    for f in ("comm.hip", "azhip.hip"):
+        assert "rccl_stub" not in open(os.path.join(root, "alphazero.jl_amd", "csrc", f)).read().replace("tests/rccl_stub", "")
