@@ -260,7 +260,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, (uint32_t*)v.root_idx, 0xffffffffu, G);
     AZCHK(dalloc(e, &v.Pout, (size_t)std::max(G, 1) * gi.APAD)); AZCHK(dalloc(e, &v.Vout, G));
     AZCHK(dalloc(e, &v.trace, (size_t)G * v.max_moves)); AZCHK(dalloc(e, &v.grec, G));
-    AZCHK(dalloc(e, &v.finished, G)); AZCHK(dalloc(e, &v.err, 1)); AZCHK(dalloc(e, &v.stat, 8));
+    AZCHK(dalloc(e, &v.finished, G)); AZCHK(dalloc(e, &v.err, 1));
     hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, v.epoch, 1u, G);
     // staging
     e->io_cap = std::max(G, 4096);
@@ -291,8 +291,15 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     if (ng > AZ_MAX_GROUPS) ng = AZ_MAX_GROUPS;
     while (ng > 1 && G % ng != 0) --ng;
     const int Gh = G / ng;
+    // statistics accumulators: one record per k_tree workgroup of every slot group (and of the whole-engine view, used by the hooks)
+    const int blk_group = (Gh * gi.APAD + 255) / 256, blk_all = (G * gi.APAD + 255) / 256;
+    e->stat_words = (size_t)4 * ((size_t)blk_group * ng + blk_all);
+    AZCHK(dalloc(e, &v.stat, e->stat_words));
+    long long* stat_base = v.stat;
+    v.stat = stat_base + (size_t)4 * blk_group * ng;                 // the whole-engine view's records come after the groups'
     for (int g = 0; g < ng; ++g) {
       DView gv = v;
+      gv.stat = stat_base + (size_t)4 * blk_group * g;
       const size_t o = (size_t)g * Gh;
       gv.G = Gh;
       gv.root += o; gv.active += o; gv.game_id += o; gv.move_idx += o; gv.epoch += o; gv.node_count += o;
@@ -1002,7 +1009,7 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   HIPCHK(hipMemsetAsync(e->v.worker_sim_id, 0, sizeof(int) * G, e->stream));
   HIPCHK(hipMemsetAsync(e->v.tot_sims, 0, sizeof(long long) * G, e->stream));
   HIPCHK(hipMemsetAsync(e->v.tot_trav, 0, sizeof(long long) * G, e->stream));
-  HIPCHK(hipMemsetAsync(e->v.stat, 0, sizeof(long long) * 8, e->stream));
+  HIPCHK(hipMemsetAsync(e->gv[0].stat, 0, sizeof(long long) * e->stat_words, e->stream));   // gv[0].stat = the base of the accumulator array
   e->total_games = num_games; e->first_game_id = first_game_id; e->next_game = 0; e->games_done = 0; e->wave_in_move = 0;
   e->q_games.clear(); e->q_moves.clear();
   e->ph_games.clear(); e->ph_off.clear(); e->phase_n = 0;
@@ -1133,10 +1140,12 @@ extern "C" int az_selfplay_active(az_engine* e, int32_t* n) {
 extern "C" int az_selfplay_get_stats(az_engine* e, az_selfplay_stats* s) {
   ENGINE(e);
   if (!s) return fail(AZ_ERR_BAD_ARG, "NULL");
-  long long st[8];
+  long long st[4] = {0, 0, 0, 0};
   AZCHK(sync_groups(e));
-  HIPCHK(hipMemcpyAsync(st, e->v.stat, sizeof st, hipMemcpyDeviceToHost, e->stream));
+  e->h_stat.resize(e->stat_words);
+  HIPCHK(hipMemcpyAsync(e->h_stat.data(), e->gv[0].stat, sizeof(long long) * e->stat_words, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  for (size_t i = 0; i < e->stat_words; ++i) st[i & 3] += e->h_stat[i];
   e->stats.simulations = st[0]; e->stats.nodes_traversed = st[1]; e->stats.leaf_evals = st[2];
   e->stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - e->t_begin).count();
   *s = e->stats;

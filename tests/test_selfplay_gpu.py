@@ -163,3 +163,23 @@ def test_shards_by_first_game_id_equal_the_unsharded_run():
         parts += run(first, count, 4)
     assert [g for g, _ in whole] == list(range(11)) == [g for g, _ in parts]
     assert whole == parts
+
+
+def test_very_large_engine_plays_the_same_games_and_conserves_its_counters():
+    """65 536 Connect-Four slots (16 x the BASELINE batch, 2048 tree-kernel workgroups): the statistics are accumulated per workgroup
+    (three same-address atomics per workgroup and wave were what bounded k_tree at this scale) and summed by the host.  A game's
+    trace depends on its id alone, so games 0..11 must be the oracle's games; the counters must be conserved over the whole phase."""
+    import azhip
+    kw = dict(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_HASH, num_iters_per_turn=12, cpuct=2.0, dirichlet_noise_eps=0.25,
+              dirichlet_noise_alpha=1.0, temperature=((0, 6), (1.0, 0.5)), reset_every=1, seed=21)
+    with azhip.Engine(num_workers=65536, batch_size=65536, **kw) as e:
+        g, m, ng, nm, st = e.selfplay_run(65536)
+    assert ng == 65536 and st.simulations == 12 * st.moves == 12 * nm and st.aborted_games == 0
+    assert st.nodes_traversed == sum(g[i].total_nodes_traversed for i in range(ng))
+    rg, rm, _ = R.simulate(R.C4, R.ORACLE_HASH, 12, 12, 12, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0, temp_xs=(0, 6), temp_ys=(1.0, 0.5),
+                           reset_every=1, seed=21)
+    for i in range(12):
+        assert (g[i].game_id, g[i].num_moves, g[i].nodes) == (rg[i].game_id, rg[i].num_moves, rg[i].nodes), i
+        for k in range(g[i].num_moves):
+            a, b = m[g[i].first_move + k], rm[rg[i].first_move + k]
+            assert tuple(a.key) == tuple(b.key) and list(a.N) == list(b.N) and a.action == b.action, (i, k)
