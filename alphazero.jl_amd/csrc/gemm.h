@@ -81,15 +81,30 @@ __global__ void __launch_bounds__(256) k_gemm_f32(int M, int N, int K, const flo
     }
   }
 }
-static __global__ void k_gemm_reduce(const float* __restrict__ partial, int nsplit, int M, int N, float* __restrict__ Cout, int ldc, float alpha, float beta) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)M * N) return;
-  float s = 0.0f;
-  for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * M * N + i];
-  const int row = (int)(i / N), col = (int)(i % N);
-  float v = alpha * s;
-  if (beta != 0.0f) v += beta * Cout[(size_t)row * ldc + col];
-  Cout[(size_t)row * ldc + col] = v;
+// a block = 64 outputs x 4 lanes over the splits (lane l adds splits l, l+4, ... with four running sums: sixteen loads in
+// flight per output instead of a chain of nsplit dependent ones), combined in a fixed order
+static __global__ void __launch_bounds__(256) k_gemm_reduce(const float* __restrict__ partial, int nsplit, int M, int N, float* __restrict__ Cout, int ldc, float alpha, float beta) {
+  __shared__ float sh[4][64];
+  const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + ol;
+  const long long mn = (long long)M * N;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < mn) {
+    int k = sl;
+    for (; k + 12 < nsplit; k += 16)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += partial[(size_t)(k + 4 * u) * mn + i];
+    for (; k < nsplit; k += 4) s[0] += partial[(size_t)k * mn + i];
+  }
+  sh[sl][ol] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (sl == 0 && i < mn) {
+    const float t = (sh[0][ol] + sh[1][ol]) + (sh[2][ol] + sh[3][ol]);
+    const int row = (int)(i / N), col = (int)(i % N);
+    float v = alpha * t;
+    if (beta != 0.0f) v += beta * Cout[(size_t)row * ldc + col];
+    Cout[(size_t)row * ldc + col] = v;
+  }
 }
 
 // ws: workspace of ws_floats floats for the split reductions (may be nullptr: no splitting)
@@ -113,6 +128,6 @@ static inline int gemm_f32(hipStream_t st, float* ws, size_t ws_floats, bool ta,
   else if (ta && !tb) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, ksplit, ws);
   else if (!ta && tb) hipLaunchKernelGGL((k_gemm_f32<false, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, ksplit, ws);
   else hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, ksplit, ws);
-  if (splits > 1) hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, st, ws, splits, M, N, C, ldc, alpha, beta);
+  if (splits > 1) hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)(((long long)M * N + 63) / 64)), dim3(256), 0, st, ws, splits, M, N, C, ldc, alpha, beta);
   return 0;
 }

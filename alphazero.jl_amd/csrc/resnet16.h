@@ -821,9 +821,13 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
 // as MFMA 16x16x4 products with the ROWS as the reduction dimension: A operand = 16 input channels x 4 rows of the layer
 // input (shifted by the tap), B operand = 4 rows x 16 output channels of the output gradient.  A workgroup walks its
 // boards three at a time (126 rows + 2 zero rows in LDS, natural channel order); wavefront w owns input-channel tile w
-// and keeps accumulators for TPW taps x all F/16 output-channel tiles in registers (F = 128: 3 taps = one kernel row
-// per workgroup, blockIdx.y selects it; F = 64: all 9 taps).  Every workgroup writes its partial dW, a second kernel
-// adds the partials in a fixed order (deterministic, no atomics).
+// and keeps accumulators for TPW taps x all F/16 output-channel tiles in registers (F = 128: 3 taps per workgroup,
+// blockIdx.y selects the group; F = 64: all 9 taps).  Every workgroup writes its partial dW, a second kernel adds the
+// partials in a fixed order (deterministic, no atomics).
+// (r3) The reduction runs over the rows in ANY order, so each tap walks only the rows whose shifted neighbour is on the
+// board: a table per tap lists them (a corner tap of a 7x6 board keeps 30 of 42 rows, an edge tap 35 or 36), and the three
+// taps of a workgroup are chosen so that every group has the same work -- {two corners, centre}, {corner, two edges},
+// {corner, two edges}: 78 / 77 / 77 four-row steps per 3-board chunk instead of 96.
 template <int F> struct WG16 {
   static constexpr int TPW = F == 128 ? 3 : 9;                    // taps per workgroup
   static constexpr int TG = 9 / TPW;                              // tap groups (grid.y)
@@ -831,58 +835,58 @@ template <int F> struct WG16 {
   static constexpr int NB = 3;                                    // boards per LDS chunk
   static constexpr int RP = 128;                                  // padded rows of a chunk (3 x 42 = 126 used; other games: RP / P boards)
   static constexpr int STRIDE = F + 16;                           // 16-bank shift per row: the 4 row groups of a fragment read use disjoint bank halves in pairs
-  static constexpr int BYTES = ((RP + 1) * STRIDE + RP * STRIDE + RP) * 4;
+  static constexpr int RLS = RP + 8;                              // row-list entries per tap (the pipeline reads two steps ahead)
+  static constexpr int BYTES = ((RP + 1) * STRIDE + RP * STRIDE + TPW * RLS) * 4;
+  // tap k of group y: balanced groups for TPW == 3, natural order otherwise
+  __host__ __device__ static constexpr int tap(int y, int k) {
+    constexpr int sel[3][3] = {{0, 8, 4}, {2, 1, 3}, {6, 7, 5}};
+    return TPW == 3 ? sel[y][k] : k;
+  }
 };
 template <class Gm, int F>
 __global__ void __launch_bounds__(64 * (F / 16), 1)
 k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __restrict__ part, int nboards, int nsplits) {
   using G = WG16<F>;
-  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, STRIDE = G::STRIDE, RP = G::RP, CT = G::CT, TPW = G::TPW;
+  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, STRIDE = G::STRIDE, RP = G::RP, CT = G::CT, TPW = G::TPW, RLS = G::RLS;
   constexpr int NBC = RP / P < 1 ? 1 : RP / P;                    // boards per chunk for this game
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                                                // [(RP + 1)][STRIDE], row RP = zeros
   float* Ds = lds + (RP + 1) * STRIDE;                            // [RP][STRIDE]
-  uint32_t* vtab = (uint32_t*)(Ds + RP * STRIDE);                 // [RP] tap validity of a chunk row
+  uint32_t* rl = (uint32_t*)(Ds + RP * STRIDE);                   // [TPW][RLS] row lists: (row of a) << 16 | row of dg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, g = lane >> 4;
   // boards of this workgroup: nboards spread evenly over the nsplits workgroups of a tap group (the first nboards % nsplits
   // take one more; a last partial LDS chunk costs only its rows)
   const int bq = nboards / nsplits, br = nboards % nsplits;
   const int b_begin = blockIdx.x * bq + ((int)blockIdx.x < br ? (int)blockIdx.x : br);
   const int b_end = b_begin + bq + ((int)blockIdx.x < br ? 1 : 0);
-  const int tap0 = blockIdx.y * TPW;
-  for (int r = tid; r < RP; r += G::THREADS) {
-    uint32_t m = 0;
-    if (r < NBC * P) {
-      const int q = r % P, x = q % W, y = q / W;
-      for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3 - 1, dx = t % 3 - 1;
-        m |= (uint32_t)((y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W)) << t;
+  // row lists: for tap k the rows of a chunk whose neighbour at the tap's offset is on the board, board after board; the
+  // rest of a list pairs the zero row of `a` with any row of dg
+  for (int i = tid; i < TPW * RLS; i += G::THREADS) rl[i] = ((uint32_t)RP << 16) | (uint32_t)(RP - 1);
+  for (int i = tid; i < STRIDE; i += G::THREADS) As[RP * STRIDE + i] = 0.0f;
+  __syncthreads();
+  int cnt[TPW];                                                   // valid rows per board of tap k
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) {
+    const int tap = G::tap(blockIdx.y, k), dy = tap / 3 - 1, dx = tap % 3 - 1;
+    cnt[k] = (W - (dx != 0)) * (H - (dy != 0));
+  }
+  if (tid < TPW * NBC) {
+    const int k = tid / NBC, b = tid % NBC;
+    const int tap = G::tap(blockIdx.y, k), dy = tap / 3 - 1, dx = tap % 3 - 1;
+    int n = b * (W - (dx != 0)) * (H - (dy != 0));
+    for (int q = 0; q < P; ++q) {
+      const int x = q % W, y = q / W;
+      if ((y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W)) {
+        const int r = b * P + q;
+        rl[k * RLS + n++] = ((uint32_t)(r + dy * W + dx) << 16) | (uint32_t)r;
       }
     }
-    vtab[r] = m;
   }
-  for (int i = tid; i < STRIDE; i += G::THREADS) As[RP * STRIDE + i] = 0.0f;
   f32x4v acc[TPW][CT];
 #pragma unroll
   for (int k = 0; k < TPW; ++k)
 #pragma unroll
     for (int j = 0; j < CT; ++j) acc[k][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  // tap validity of this lane's row in every step of a chunk (rows 4 s + g, s = 0..31), one bit per step and tap:
-  // chunk-invariant, so the operand addresses of a step need no table look-up
-  uint32_t vbits[TPW];
-#pragma unroll
-  for (int k = 0; k < TPW; ++k) vbits[k] = 0;
-  for (int st = 0; st < RP / 4; ++st) {
-    const int r = 4 * st + g;
-    if (r < NBC * P) {
-      const int q = r % P, x = q % W, y = q / W;
-#pragma unroll
-      for (int k = 0; k < TPW; ++k) {
-        const int tap = tap0 + k, dy = tap / 3 - 1, dx = tap % 3 - 1;
-        vbits[k] |= (uint32_t)((y + dy >= 0) && (y + dy < H) && (x + dx >= 0) && (x + dx < W)) << st;
-      }
-    }
-  }
   // The chunk after the current one travels from HBM into registers while the MFMAs of the current one run (every
   // workgroup reaches its chunk boundaries at the same time: without the overlap the chip alternates between a burst of
   // loads and a burst of MFMAs); it is stored to LDS once the current chunk has been consumed.
@@ -905,8 +909,7 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
   prefetch(b_begin);
   for (int b0 = b_begin; b0 < b_end; b0 += NBC) {
     const int nb = (b_end - b0) < NBC ? (b_end - b0) : NBC;
-    const int nvalid = nb * P;
-    __syncthreads();                                              // the previous chunk has been consumed
+    __syncthreads();                                              // the previous chunk has been consumed (first pass: the row lists are complete)
 #pragma unroll
     for (int q = 0; q < NPF; ++q) {
       const int idx = tid + q * G::THREADS, row = idx / (F / 4), c4 = idx % (F / 4);
@@ -915,48 +918,51 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
     }
     __syncthreads();
     if (b0 + NBC < b_end) prefetch(b0 + NBC);
-    const int nsteps = (nvalid + 15) / 16 * 4;                    // rows past the chunk's boards are zero: skip them (whole groups of 4 steps)
-    // two register stages: the LDS operands of step s+1 are requested before the 24 (36) MFMAs of step s issue
-    float bv0[CT], av0[TPW], bv1[CT], av1[TPW];
-    auto load_step = [&](int st, float (&bv)[CT], float (&av)[TPW]) {
-      const int row = 4 * st + g;
 #pragma unroll
-      for (int j = 0; j < CT; ++j) bv[j] = Ds[row * STRIDE + j * 16 + lrow];
+    for (int k = 0; k < TPW; ++k) {
+      // the rows of tap k in this chunk, four per step; an even number of steps (a list's tail is zero rows).  Two
+      // register stages: the LDS operands of step s+1 are requested before the CT MFMAs of step s issue, the list
+      // entry of step s+2 before that.
+      const int nsteps = ((nb * cnt[k] + 7) >> 3) << 1;
+      const uint32_t* list = rl + k * RLS + g;
+      float bv0[CT], bv1[CT], av0, av1;
+      auto load_step = [&](uint32_t e, float (&bv)[CT], float& av) {
+        const float* dp = Ds + (e & 0xffffu) * STRIDE + lrow;
 #pragma unroll
-      for (int k = 0; k < TPW; ++k) {
-        const int tap = tap0 + k;
-        const int delta = (tap / 3 - 1) * W + (tap % 3 - 1);
-        const int ar = ((vbits[k] >> st) & 1) ? row + delta : RP;
-        av[k] = As[ar * STRIDE + wave * 16 + lrow];
+        for (int j = 0; j < CT; ++j) bv[j] = dp[j * 16];
+        av = As[(e >> 16) * STRIDE + wave * 16 + lrow];
+      };
+      auto mfma_step = [&](const float (&bv)[CT], float av) {
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[k][j], 0, 0, 0);
+      };
+      uint32_t e0 = list[0], e1 = list[4];
+      load_step(e0, bv0, av0);
+      for (int s0 = 0; s0 < nsteps; s0 += 2) {
+        e0 = list[4 * (s0 + 2)];
+        load_step(e1, bv1, av1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(bv0, av0);
+        __builtin_amdgcn_sched_barrier(0);
+        e1 = list[4 * (s0 + 3)];
+        load_step(e0, bv0, av0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(bv1, av1);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    };
-    auto mfma_step = [&](const float (&bv)[CT], const float (&av)[TPW]) {
-#pragma unroll
-      for (int k = 0; k < TPW; ++k)
-#pragma unroll
-        for (int j = 0; j < CT; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[j], acc[k][j], 0, 0, 0);
-    };
-    load_step(0, bv0, av0);
-    for (int s0 = 0; s0 < nsteps; s0 += 2) {
-      load_step(s0 + 1, bv1, av1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(bv0, av0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s0 + 2 < nsteps) load_step(s0 + 2, bv0, av0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(bv1, av1);
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // partial dW of this workgroup: [split][tap][ci][co], ci = 16 wave + 4 g + i, co = 16 j + lrow
   float* o = part + (size_t)blockIdx.x * 9 * F * F;
 #pragma unroll
-  for (int k = 0; k < TPW; ++k)
+  for (int k = 0; k < TPW; ++k) {
+    const int tap = G::tap(blockIdx.y, k);
 #pragma unroll
     for (int j = 0; j < CT; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        o[((size_t)(tap0 + k) * F + (wave * 16 + g * 4 + i)) * F + j * 16 + lrow] = acc[k][j][i];
+        o[((size_t)tap * F + (wave * 16 + g * 4 + i)) * F + j * 16 + lrow] = acc[k][j][i];
+  }
 }
 static __global__ void k_wgrad_reduce(const float* __restrict__ part, int nsplit, long long n, float* __restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

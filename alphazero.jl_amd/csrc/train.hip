@@ -30,9 +30,10 @@ __global__ void k_tr_gather(const float* __restrict__ blob, const int* __restric
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) work[j] = blob[map[j]];
 }
-__global__ void k_tr_scatter(const float* __restrict__ gwork, const int* __restrict__ map, long long n, float* __restrict__ gblob) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) gblob[map[j]] = gwork[j];
+// gblob[map[j]] = gwork[j] for the working entries j = list[i] that carry a gradient (one launch for every layer)
+__global__ void k_tr_scatter(const float* __restrict__ gwork, const int* __restrict__ map, const int* __restrict__ list, long long n, float* __restrict__ gblob) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const int j = list[i]; gblob[map[j]] = gwork[j]; }
 }
 // the batch of a step: rows idx[0..B) of the data set's tensors
 __global__ void k_tr_batch(const int* __restrict__ idx, int B, int xs, int A, const float* __restrict__ W, const float* __restrict__ X,
@@ -98,12 +99,61 @@ __global__ void __launch_bounds__(256) k_tr_colsum(const float* __restrict__ x, 
     part[((size_t)blockIdx.x * 2 + 1) * C + c] = ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl];
   }
 }
+// MODE 1 with four channels per thread (C % 4 == 0, 256 % (C/4) == 0): a block = C/4 channel quads x 256/(C/4) row lanes
+// over the same 64-row chunk, 16-byte loads; the row lanes are added in lane order through 8 KB of LDS (it has to fit
+// beside k_wgrad16's 150 KB).  Same partial layout as k_tr_colsum.
+__global__ void __launch_bounds__(256) k_tr_colsum1v(const float* __restrict__ x, const float* __restrict__ out_act, const float* __restrict__ g,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd, long long R, int C,
+                                                     double* __restrict__ part /* [nchunks][2][C] */) {
+  __shared__ double sh[256][4];
+  const int CQ = C >> 2, RL = 256 / CQ;
+  const int q = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+  const long long r0 = (long long)blockIdx.x * TR_CHUNK, r1 = r0 + TR_CHUNK < R ? r0 + TR_CHUNK : R;
+  const float4 mu = *(const float4*)(mean + 4 * q), is = *(const float4*)(invstd + 4 * q);
+  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  auto add = [&](const float4& vx, const float4& va, const float4& vg) {
+    const float dx[4] = {vx.x, vx.y, vx.z, vx.w}, av[4] = {va.x, va.y, va.z, va.w}, gv[4] = {vg.x, vg.y, vg.z, vg.w};
+    const float m[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dy = av[k] > 0.0f ? dx[k] : 0.0f;
+      const float xh = (gv[k] - m[k]) * iv[k];
+      s0[k] += (double)dy; s1[k] += (double)dy * (double)xh;
+    }
+  };
+  long long r = r0 + rl;
+  for (; r + RL < r1; r += 2 * RL) {                                // two rows in flight
+    const size_t i = (size_t)r * C + 4 * q, j = i + (size_t)RL * C;
+    const float4 x0 = *(const float4*)(x + i), a0 = *(const float4*)(out_act + i), g0 = *(const float4*)(g + i);
+    const float4 x1 = *(const float4*)(x + j), a1 = *(const float4*)(out_act + j), g1 = *(const float4*)(g + j);
+    add(x0, a0, g0); add(x1, a1, g1);
+  }
+  for (; r < r1; r += RL) {
+    const size_t i = (size_t)r * C + 4 * q;
+    add(*(const float4*)(x + i), *(const float4*)(out_act + i), *(const float4*)(g + i));
+  }
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sh[threadIdx.x][k] = w == 0 ? s0[k] : s1[k];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double v = sh[q][k];
+        for (int l = 1; l < RL; ++l) v += sh[q + l * CQ][k];
+        part[((size_t)blockIdx.x * 2 + w) * C + 4 * q + k] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
 // what the one thread that holds a channel's two sums does with them (fused into the final reduction: no extra launch)
 struct TrFinal {
   int mode;                     // 0: sums only; 1: batch-norm statistics (forward); 2: dgamma / dbeta (backward); 3: out0 = sum0 (bias gradient)
   long long R; float momentum;
   const float* bias; float *mean, *invstd, *run_mean, *run_var;      // mode 1
-  float *dgamma, *dbeta;                                              // mode 2
+  float *dgamma, *dbeta, *mf;                                         // mode 2 (mf[2][C]: the two sums / R as floats, what k_tr_bn_bwd subtracts)
   float* out0;                                                        // mode 3
 };
 __global__ void __launch_bounds__(64) k_tr_colsum_final(const double* __restrict__ part, int nchunks, int C, double* __restrict__ sums /* [2][C] */, TrFinal f) {
@@ -131,7 +181,7 @@ __global__ void __launch_bounds__(64) k_tr_colsum_final(const double* __restrict
       const float b = f.bias ? f.bias[c] : 0.0f;
       f.run_mean[c] = (1.0f - f.momentum) * f.run_mean[c] + f.momentum * ((float)m + b);
       f.run_var[c] = (1.0f - f.momentum) * f.run_var[c] + f.momentum * (float)(var * ((double)f.R / (double)(f.R - 1)));
-    } else if (f.mode == 2) { f.dbeta[c] = (float)s0; f.dgamma[c] = (float)s1; }
+    } else if (f.mode == 2) { f.dbeta[c] = (float)s0; f.dgamma[c] = (float)s1; f.mf[c] = (float)(s0 / (double)f.R); f.mf[C + c] = (float)(s1 / (double)f.R); }
     else if (f.mode == 3) f.out0[c] = (float)s0;
   }
 }
@@ -147,18 +197,32 @@ __global__ void k_tr_bn_apply(const float* __restrict__ g, const float* __restri
   a[i] = v > 0.0f ? v : 0.0f;
 }
 // batch-norm backward: dy = da * (a > 0); dg = gamma * invstd * (dy - sum(dy)/R - xhat * sum(dy*xhat)/R); dgamma = sum(dy*xhat),
-// dbeta = sum(dy).  `dy_out` (optional) receives dy: the gradient that also flows into the skip connection.
-__global__ void k_tr_bn_bwd(const float* __restrict__ da, const float* __restrict__ a, const float* __restrict__ g,
+// dbeta = sum(dy).  `dy_out` (optional) receives dy: the gradient that also flows into the skip connection.  mf = the two
+// means as floats (k_tr_colsum_final, mode 2).  V = 4: four channels per thread (C % 4 == 0), the form that still moves
+// bytes when it shares the chip with k_wgrad16 and gets one wavefront per SIMD.
+template <int V>
+__global__ void __launch_bounds__(256) k_tr_bn_bwd(const float* __restrict__ da, const float* __restrict__ a, const float* __restrict__ g,
                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                            const double* __restrict__ sums, long long R, long long n, int C, float* __restrict__ dg, float* __restrict__ dy_out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                            const float* __restrict__ mf, long long n, int C, float* __restrict__ dg, float* __restrict__ dy_out) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
   if (i >= n) return;
   const int c = (int)(i % C);
-  const float dy = a[i] > 0.0f ? da[i] : 0.0f;
-  const float xh = (g[i] - mean[c]) * invstd[c];
-  const float m0 = (float)(sums[c] / (double)R), m1 = (float)(sums[C + c] / (double)R);
-  dg[i] = gamma[c] * invstd[c] * (dy - m0 - xh * m1);
-  if (dy_out) dy_out[i] = dy;
+  float vda[V], va[V], vg[V], o[V], dyv[V];
+  if constexpr (V == 4) {
+    const float4 x = *(const float4*)(da + i), y = *(const float4*)(a + i), z = *(const float4*)(g + i);
+    vda[0] = x.x; vda[1] = x.y; vda[2] = x.z; vda[3] = x.w; va[0] = y.x; va[1] = y.y; va[2] = y.z; va[3] = y.w; vg[0] = z.x; vg[1] = z.y; vg[2] = z.z; vg[3] = z.w;
+  } else { vda[0] = da[i]; va[0] = a[i]; vg[0] = g[i]; }
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const float dy = va[k] > 0.0f ? vda[k] : 0.0f;
+    const float xh = (vg[k] - mean[c + k]) * invstd[c + k];
+    o[k] = gamma[c + k] * invstd[c + k] * (dy - mf[c + k] - xh * mf[C + c + k]);
+    dyv[k] = dy;
+  }
+  if constexpr (V == 4) {
+    *(float4*)(dg + i) = make_float4(o[0], o[1], o[2], o[3]);
+    if (dy_out) *(float4*)(dy_out + i) = make_float4(dyv[0], dyv[1], dyv[2], dyv[3]);
+  } else { dg[i] = o[0]; if (dy_out) dy_out[i] = dyv[0]; }
 }
 // dense epilogues: y = [relu](x + bias[c]);  backward mask: dx = dy * (y > 0)
 __global__ void k_tr_bias_act(float* __restrict__ x, const float* __restrict__ bias, long long n, int C, int relu) {
@@ -284,6 +348,8 @@ struct az_trainer {
   az_train_cfg cfg;
   int game, device; GameInfo gi;
   hipStream_t stream;
+  hipStream_t side;                                                          // the weight gradients of the tower run here, beside the batch-norm backward passes of the next layer
+  std::vector<hipEvent_t> ev_dg, ev_wg;                                     // per tower layer: output gradient ready / weight gradient done
   float* gemm_ws; size_t gemm_ws_floats;                                     // split-reduction workspace of gemm_f32
   int B, nblocks, F, npf, nvf, nA;
   long long R;
@@ -292,13 +358,15 @@ struct az_trainer {
   size_t off_pd_w, off_pd_b, off_v1_w, off_v1_b, off_v2_w, off_v2_b;      // dense layers in the blob
   size_t wk_pd, wk_v1, wk_v2, nwork;
   float *blob, *gblob, *opt_m, *opt_v; unsigned char* trainable;           // [nparams]
+  int* scat; long long nscat;                                                // working entries that carry a gradient (the primary ranges)
   float *work, *gwork; int* map;                                             // working parameters and their blob map
   // batch + head buffers
   int* d_idx; float *bW, *bX, *bA, *bP, *bV;
   float *logits, *v1, *tpre, *dlogits, *dt, *dv1;
-  float *dact, *dact2, *dcol;                                                // [R][F] gradients (dact / dcol alternate as the running gradient, dact2 = the skip share)
+  float *dact, *dact2, *dact3, *dcol;                                        // [R][F] gradients (dcol / dact / dact3 take turns as the running gradient, dact2 = the skip share)
   float* wg_part; int wg_splits, wg_bpw;                       // k_wgrad16: partial dW per row split, boards per workgroup
   double *part, *sums, *terms, *bsums;
+  float* bn_mf;                                                              // [2][C] the batch-norm backward means of the layer in flight
   std::vector<void*> allocs;
   std::vector<int> perm; int64_t perm_pos, epoch; int64_t step;
   float b1t, b2t;
@@ -331,6 +399,10 @@ extern "C" int az_trainer_destroy(az_trainer* t) {
   if (!t) return AZ_OK;
   (void)hipSetDevice(t->device);
   for (void* p : t->allocs) (void)hipFree(p);
+  if (t->stream) (void)hipStreamSynchronize(t->stream);
+  if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
+  for (hipEvent_t ev : t->ev_dg) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : t->ev_wg) (void)hipEventDestroy(ev);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;
   return AZ_OK;
@@ -400,6 +472,12 @@ static int trainer_build(az_trainer* t) {
   for (int p = 0; p < P; ++p) for (int f = 0; f < nvf; ++f) for (int o = 0; o < F; ++o)
     map[t->wk_v1 + ((size_t)p * nvf + f) * F + o] = (int)(t->off_v1_w + o + (size_t)F * (p + (size_t)P * f));
   for (int o = 0; o < F; ++o) map[t->wk_v2 + o] = (int)(t->off_v2_w + o);
+  std::vector<int> scat;
+  for (const TrConv& c : t->convs) for (size_t j = 0; j < (size_t)c.taps * c.cin * c.cout; ++j) scat.push_back((int)(c.wk_wm + j));
+  for (size_t j = t->wk_pd; j < wk; ++j) scat.push_back((int)j);
+  t->nscat = (long long)scat.size();
+  AZCHK(tr_alloc(t, &t->scat, scat.size()));
+  HIPCHK(hipMemcpyAsync(t->scat, scat.data(), sizeof(int) * scat.size(), hipMemcpyHostToDevice, t->stream));
   AZCHK(tr_alloc(t, &t->map, wk)); AZCHK(tr_alloc(t, &t->work, wk)); AZCHK(tr_alloc(t, &t->gwork, wk, true));
   AZCHK(tr_alloc(t, &t->blob, t->nparams)); AZCHK(tr_alloc(t, &t->gblob, t->nparams, true));
   AZCHK(tr_alloc(t, &t->opt_m, t->nparams, true)); AZCHK(tr_alloc(t, &t->opt_v, t->nparams, true));
@@ -416,17 +494,21 @@ static int trainer_build(az_trainer* t) {
     AZCHK(tr_alloc(t, &c.g, (size_t)R * c.cout)); AZCHK(tr_alloc(t, &c.a, (size_t)R * c.cout));
     AZCHK(tr_alloc(t, &c.mean, c.cout)); AZCHK(tr_alloc(t, &c.invstd, c.cout));
   }
-  (void)ntower;
+  for (int l = 0; l < ntower; ++l) {
+    hipEvent_t a = nullptr, b = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming)); t->ev_dg.push_back(a);
+    HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming)); t->ev_wg.push_back(b);
+  }
   const int B = t->B;
   AZCHK(tr_alloc(t, &t->d_idx, B)); AZCHK(tr_alloc(t, &t->bW, B)); AZCHK(tr_alloc(t, &t->bV, B));
   AZCHK(tr_alloc(t, &t->bX, (size_t)B * C * P)); AZCHK(tr_alloc(t, &t->bA, (size_t)B * A)); AZCHK(tr_alloc(t, &t->bP, (size_t)B * A));
   AZCHK(tr_alloc(t, &t->logits, (size_t)B * A)); AZCHK(tr_alloc(t, &t->dlogits, (size_t)B * A));
   AZCHK(tr_alloc(t, &t->v1, (size_t)B * F)); AZCHK(tr_alloc(t, &t->dv1, (size_t)B * F));
   AZCHK(tr_alloc(t, &t->tpre, B)); AZCHK(tr_alloc(t, &t->dt, B));
-  AZCHK(tr_alloc(t, &t->dact, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dact2, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dcol, (size_t)R * F));
+  AZCHK(tr_alloc(t, &t->dact, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dact2, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dact3, (size_t)R * F)); AZCHK(tr_alloc(t, &t->dcol, (size_t)R * F));
   const int nchunks = (int)((R + TR_CHUNK - 1) / TR_CHUNK);
   AZCHK(tr_alloc(t, &t->part, (size_t)std::max(nchunks, B + 1) * 2 * std::max(F, 64)));   // chunks of k_tr_colsum or workgroups of k_conv16_layer
-  AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64)));
+  AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64))); AZCHK(tr_alloc(t, &t->bn_mf, (size_t)2 * std::max(F, 64)));
   AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 8 + 1024));
   // k_wgrad16: one round of workgroups over the chip
   t->wg_part = nullptr; t->wg_splits = 0; t->wg_bpw = 0;
@@ -461,27 +543,34 @@ static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* o
   return AZ_OK;
 }
 
-template <class Gm, int F> static int tr_wgrad16_f(az_trainer* t, const float* a, const float* dg, float* out) {
+template <class Gm, int F> static int tr_wgrad16_f(az_trainer* t, const float* a, const float* dg, float* out, hipStream_t st) {
   using G = WG16<F>;
   static bool attr_done = false;
   if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16<Gm, F>), hipFuncAttributeMaxDynamicSharedMemorySize, G::BYTES)); attr_done = true; }
-  hipLaunchKernelGGL((k_wgrad16<Gm, F>), dim3(t->wg_splits, G::TG), dim3(G::THREADS), G::BYTES, t->stream, a, dg, t->wg_part, t->B, t->wg_splits);
+  hipLaunchKernelGGL((k_wgrad16<Gm, F>), dim3(t->wg_splits, G::TG), dim3(G::THREADS), G::BYTES, st, a, dg, t->wg_part, t->B, t->wg_splits);
   const long long n = 9LL * F * F;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(tr_grid(n)), dim3(256), 0, t->stream, t->wg_part, t->wg_splits, n, out);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(tr_grid(n)), dim3(256), 0, st, t->wg_part, t->wg_splits, n, out);
   return AZ_OK;
 }
 // weight gradient of a 3x3 F -> F convolution on the MFMA kernel: out = [9][F][F] in the Wm layout
-static int tr_wgrad16(az_trainer* t, const float* a, const float* dg, float* out) {
-  DISPATCH_GAME(t->game, { if (t->F == 128) AZCHK((tr_wgrad16_f<Gm, 128>(t, a, dg, out))); else AZCHK((tr_wgrad16_f<Gm, 64>(t, a, dg, out))); });
+static int tr_wgrad16(az_trainer* t, const float* a, const float* dg, float* out, hipStream_t st) {
+  DISPATCH_GAME(t->game, { if (t->F == 128) AZCHK((tr_wgrad16_f<Gm, 128>(t, a, dg, out, st))); else AZCHK((tr_wgrad16_f<Gm, 64>(t, a, dg, out, st))); });
   return AZ_OK;
 }
 
+static void tr_bn_bwd(az_trainer* t, const float* da, const float* a, const float* g, const float* mean, const float* invstd, const float* gamma,
+                      long long n, int C, float* dg, float* dy_out) {
+  if (C % 4 == 0) hipLaunchKernelGGL((k_tr_bn_bwd<4>), dim3(tr_grid(n / 4)), dim3(256), 0, t->stream, da, a, g, mean, invstd, gamma, t->bn_mf, n, C, dg, dy_out);
+  else hipLaunchKernelGGL((k_tr_bn_bwd<1>), dim3(tr_grid(n)), dim3(256), 0, t->stream, da, a, g, mean, invstd, gamma, t->bn_mf, n, C, dg, dy_out);
+}
 // column sums of mode MODE over R rows, result in t->sums
 template <int MODE>
 static int tr_colsum(az_trainer* t, const float* x, const float* out_act, const float* g, const float* mean, const float* invstd, long long R, int C,
                      TrFinal fin = TrFinal{}) {
   const int nchunks = (int)((R + TR_CHUNK - 1) / TR_CHUNK);
-  hipLaunchKernelGGL((k_tr_colsum<MODE>), dim3(nchunks, (C + 63) / 64), dim3(256), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part);
+  if (MODE == 1 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0)
+    hipLaunchKernelGGL(k_tr_colsum1v, dim3(nchunks), dim3(256), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part);
+  else hipLaunchKernelGGL((k_tr_colsum<MODE>), dim3(nchunks, (C + 63) / 64), dim3(256), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part);
   hipLaunchKernelGGL(k_tr_colsum_final, dim3(C), dim3(64), 0, t->stream, t->part, nchunks, C, t->sums, fin);
   return AZ_OK;
 }
@@ -565,9 +654,9 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
   bool first = true;
   for (TrConv* c : {&hp, &hv}) {
     float* dh = c == &hp ? dhp : dhv;
-    { TrFinal fin{}; fin.mode = 2; fin.dgamma = gb + c->off_bn; fin.dbeta = gb + c->off_bn + c->cout;
+    { TrFinal fin{}; fin.mode = 2; fin.R = R; fin.mf = t->bn_mf; fin.dgamma = gb + c->off_bn; fin.dbeta = gb + c->off_bn + c->cout;
       AZCHK(tr_colsum<1>(t, dh, c->a, c->g, c->mean, c->invstd, R, c->cout, fin)); }
-    hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c->cout)), dim3(256), 0, st, dh, c->a, c->g, c->mean, c->invstd, blob + c->off_bn, t->sums, R, R * c->cout, c->cout, dh, (float*)nullptr);
+    tr_bn_bwd(t, dh, c->a, c->g, c->mean, c->invstd, blob + c->off_bn, R * c->cout, c->cout, dh, nullptr);
     AZCHK(tr_gemm(t, true, false, F, c->cout, (int)R, 1.f, trunk, F, dh, c->cout, 0.f, gw + c->wk_wm, c->cout));
     // the bias of a convolution that feeds a train-mode BatchNorm has gradient sum(dg) = gamma invstd (sum dy - R m0 - m1 sum xhat)
     // = 0 exactly (the batch mean absorbs it): its slot in gblob stays 0 and only the L2 term moves it
@@ -575,33 +664,45 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
     first = false;
   }
   // ---------------- backward: tower ----------------
-  // da = gradient w.r.t. the activation convs[l].a; dskip (block input share) in dact2.  da alternates between the front
-  // of the big scratch (where the head convolutions left the trunk gradient) and dact: the MFMA data-gradient convolution
-  // writes out of place, so the two buffers swap roles instead of being copied
-  float* da = dtrunk;
-  float* da_alt = t->dact;
+  // da = gradient w.r.t. the activation convs[l].a; dskip (block input share) in dact2.  The MFMA data-gradient convolution
+  // writes out of place, so the running gradient moves through three buffers (the front of the big scratch, where the head
+  // convolutions left the trunk gradient, dact and dact3) instead of being copied.
+  // (r3) The weight gradient of a layer is off the chain dg(l) -> da(l-1) -> dg(l-1): it runs on a second stream, so the
+  // HBM-bound batch-norm backward passes of layer l-1 share the chip with the MFMA-bound k_wgrad16 of layer l.  Three
+  // buffers because the data-gradient convolution of layer l-1 must not overwrite the dg that k_wgrad16 of layer l still
+  // reads: it writes the buffer last read by the weight gradient of layer l+1 and waits for that one only.
+  float* ring[3] = {dtrunk, t->dact, t->dact3};
+  int cur = 0;
   for (int l = ntower - 1; l >= 0; --l) {
     TrConv& c = t->convs[l];
+    float* da = ring[cur];
     const bool second = l > 0 && (l % 2) == 0;
-    { TrFinal fin{}; fin.mode = 2; fin.dgamma = gb + c.off_bn; fin.dbeta = gb + c.off_bn + c.cout;
+    { TrFinal fin{}; fin.mode = 2; fin.R = R; fin.mf = t->bn_mf; fin.dgamma = gb + c.off_bn; fin.dbeta = gb + c.off_bn + c.cout;
       AZCHK(tr_colsum<1>(t, da, c.a, c.g, c.mean, c.invstd, R, c.cout, fin)); }
-    // dg overwrites dact; for conv2 the masked gradient dy also flows to the block input (dact2)
-    hipLaunchKernelGGL(k_tr_bn_bwd, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, da, c.a, c.g, c.mean, c.invstd, blob + c.off_bn, t->sums, R, R * c.cout, c.cout,
-                       da, second ? t->dact2 : (float*)nullptr);
-    if (c.mfma) AZCHK(tr_wgrad16(t, t->convs[l - 1].a, da, gw + c.wk_wm));
-    else AZCHK(tr_gemm(t, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, da, c.cout, 0.f, gw + c.wk_wm, c.cout));
-    if (l == 0) break;
-    // data gradient da_prev = conv(dg, mirrored taps, ci <-> co): the same MFMA layer kernel with the wk_fdg fragments, out of place
-    const bool first_of_block = (l % 2) == 1;                      // conv1: its input is the block input, which also gets the skip share
-    AZCHK(tr_conv16(t, da, t->work + c.wk_fdg, da_alt, false, nullptr, first_of_block ? t->dact2 : nullptr));   // (r3) the add rides in the epilogue
-    std::swap(da, da_alt);
+    // dg overwrites da; for conv2 the masked gradient dy also flows to the block input (dact2)
+    tr_bn_bwd(t, da, c.a, c.g, c.mean, c.invstd, blob + c.off_bn, R * c.cout, c.cout, da, second ? t->dact2 : nullptr);
+    if (!c.mfma) AZCHK(tr_gemm(t, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, da, c.cout, 0.f, gw + c.wk_wm, c.cout));
+    if (l > 0) {
+      // data gradient da_prev = conv(dg, mirrored taps, ci <-> co): the same MFMA layer kernel with the wk_fdg fragments, out of place
+      const bool first_of_block = (l % 2) == 1;                    // conv1: its input is the block input, which also gets the skip share
+      const int nxt = (cur + 1) % 3;                               // last read by the weight gradient of layer l + 2
+      if (l + 2 < ntower && t->convs[l + 2].mfma) HIPCHK(hipStreamWaitEvent(st, t->ev_wg[l + 2], 0));
+      AZCHK(tr_conv16(t, da, t->work + c.wk_fdg, ring[nxt], false, nullptr, first_of_block ? t->dact2 : nullptr));   // (r3) the add rides in the epilogue
+      cur = nxt;
+    }
+    if (c.mfma) {
+      // the weight gradient starts when the data gradient of its layer is done: two MFMA kernels side by side only halve each
+      // other's share of the chip (measured), while the HBM-bound passes of layer l-1 do fit beside k_wgrad16
+      HIPCHK(hipEventRecord(t->ev_dg[l], st));
+      HIPCHK(hipStreamWaitEvent(t->side, t->ev_dg[l], 0));
+      AZCHK(tr_wgrad16(t, t->convs[l - 1].a, da, gw + c.wk_wm, t->side));
+      HIPCHK(hipEventRecord(t->ev_wg[l], t->side));
+    }
   }
+  for (int l = 1; l < ntower && l <= 2; ++l) if (t->convs[l].mfma) HIPCHK(hipStreamWaitEvent(st, t->ev_wg[l], 0));   // the side stream is in order: its last two launches
   // working-layout weight gradients -> blob layout (the rotated copies carry no gradient of their own: their slots in
   // gwork stay zero and map to the same blob entries, so scatter only the primary ranges)
-  for (const TrConv& c : t->convs)
-    hipLaunchKernelGGL(k_tr_scatter, dim3(tr_grid((long long)c.taps * c.cin * c.cout)), dim3(256), 0, st, gw + c.wk_wm, t->map + c.wk_wm, (long long)c.taps * c.cin * c.cout, gb);
-  const long long ndense = (long long)(t->nwork - t->wk_pd);
-  hipLaunchKernelGGL(k_tr_scatter, dim3(tr_grid(ndense)), dim3(256), 0, st, gw + t->wk_pd, t->map + t->wk_pd, ndense, gb);
+  hipLaunchKernelGGL(k_tr_scatter, dim3(tr_grid(t->nscat)), dim3(256), 0, st, gw, t->map, t->scat, t->nscat, gb);
   return AZ_OK;
 }
 // `losses` from the five sums of a step (learning.jl:67-90): L and (Lp, Lv, Lreg, Linv, mean(W)/Wmean)
@@ -650,12 +751,16 @@ extern "C" int az_trainer_create(az_engine* e, az_dataset* d, const az_train_cfg
   if (!(cfg->rewards_renormalization > 0.0)) return fail(AZ_ERR_BAD_ARG, "rewards_renormalization must be > 0");
   az_trainer* t = new (std::nothrow) az_trainer();
   if (!t) return fail(AZ_ERR_HIP, "out of host memory");
-  t->e = e; t->d = d; t->cfg = *cfg; t->game = e->cfg.game; t->device = e->device; t->gi = e->gi; t->stream = nullptr; t->gemm_ws = nullptr; t->gemm_ws_floats = 0;
+  t->e = e; t->d = d; t->cfg = *cfg; t->game = e->cfg.game; t->device = e->device; t->gi = e->gi; t->stream = nullptr; t->side = nullptr; t->gemm_ws = nullptr; t->gemm_ws_floats = 0;
   t->B = (int)B; t->nblocks = e->cfg.num_blocks; t->F = e->cfg.num_filters; t->npf = e->cfg.num_policy_head_filters; t->nvf = e->cfg.num_value_head_filters;
   t->nA = e->gi.A; t->R = (long long)B * e->gi.P; t->nparams = e->blob.size();
   t->perm_pos = 0; t->epoch = 0; t->step = 0; t->b1t = 1.0f; t->b2t = 1.0f;
   int st = [&]() -> int {
-    HIPCHK(hipStreamCreate(&t->stream));
+    // the chain of the step on a high-priority stream, the weight gradients beside it on a low-priority one
+    int pr_least = 0, pr_greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+    HIPCHK(hipStreamCreateWithPriority(&t->stream, hipStreamDefault, pr_greatest));
+    HIPCHK(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, pr_least));
     t->gemm_ws_floats = (size_t)4 << 20;                            // 16 MB: partial tiles of the split weight-gradient reductions
     AZCHK(tr_alloc(t, &t->gemm_ws, t->gemm_ws_floats));
     AZCHK(trainer_build(t));
