@@ -843,9 +843,13 @@ template <int F> struct WG16 {
     return TPW == 3 ? sel[y][k] : k;
   }
 };
-template <class Gm, int F>
+// STAMP (tools/probes/wgrad_stamps.hip): every workgroup leaves clock readings in stamps[workgroup][8]; 2: the steps read no
+// LDS operands, 3: they issue no MFMAs (what bounds the loop)
+template <class Gm, int F, int STAMP = 0>
 __global__ void __launch_bounds__(64 * (F / 16), 1)
-k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __restrict__ part, int nboards, int nsplits) {
+k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __restrict__ part, int nboards, int nsplits, long long* __restrict__ stamps) {
+  long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (STAMP) ts[0] = wall_clock64();
   using G = WG16<F>;
   constexpr int P = Gm::P, W = Gm::W, H = Gm::H, STRIDE = G::STRIDE, RP = G::RP, CT = G::CT, TPW = G::TPW, RLS = G::RLS;
   constexpr int NBC = RP / P < 1 ? 1 : RP / P;                    // boards per chunk for this game
@@ -859,6 +863,28 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
   const int bq = nboards / nsplits, br = nboards % nsplits;
   const int b_begin = blockIdx.x * bq + ((int)blockIdx.x < br ? (int)blockIdx.x : br);
   const int b_end = b_begin + bq + ((int)blockIdx.x < br ? 1 : 0);
+  // The chunk after the current one travels from HBM into registers while the MFMAs of the current one run (every
+  // workgroup reaches its chunk boundaries at the same time: without the overlap the chip alternates between a burst of
+  // loads and a burst of MFMAs); it is stored to LDS once the current chunk has been consumed.
+  constexpr int NPF = RP * (F / 4) / G::THREADS;                  // float4 per thread and array
+  static_assert(RP * (F / 4) % G::THREADS == 0, "chunk must divide over the threads");
+  float4 pa[NPF], pd[NPF];
+  // (issued in one burst after the chunk's barrier: spread over the taps' loops they cost 11 more registers, and 232 is the most
+  // that leaves room beside this kernel for a wavefront of the batch-norm backward passes, see train.hip)
+  auto prefetch = [&](int b0, int q0, int q1) {
+    const int nbp = (b_end - b0) < NBC ? (b_end - b0) : NBC;
+    const int nv = nbp > 0 ? nbp * P : 0;
+    const float4* a4 = (const float4*)(a + (size_t)b0 * P * F);
+    const float4* d4 = (const float4*)(dg + (size_t)b0 * P * F);
+#pragma unroll
+    for (int q = q0; q < q1; ++q) {
+      const int idx = tid + q * G::THREADS, row = idx / (F / 4), c4 = idx % (F / 4);
+      const bool ok = row < nv;
+      pa[q] = ok ? a4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      pd[q] = ok ? d4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  prefetch(b_begin, 0, NPF);                                      // first: its latency covers the table build
   // row lists: for tap k the rows of a chunk whose neighbour at the tap's offset is on the board, board after board; the
   // rest of a list pairs the zero row of `a` with any row of dg
   for (int i = tid; i < TPW * RLS; i += G::THREADS) rl[i] = ((uint32_t)RP << 16) | (uint32_t)(RP - 1);
@@ -887,29 +913,14 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
   for (int k = 0; k < TPW; ++k)
 #pragma unroll
     for (int j = 0; j < CT; ++j) acc[k][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  // The chunk after the current one travels from HBM into registers while the MFMAs of the current one run (every
-  // workgroup reaches its chunk boundaries at the same time: without the overlap the chip alternates between a burst of
-  // loads and a burst of MFMAs); it is stored to LDS once the current chunk has been consumed.
-  constexpr int NPF = RP * (F / 4) / G::THREADS;                  // float4 per thread and array
-  static_assert(RP * (F / 4) % G::THREADS == 0, "chunk must divide over the threads");
-  float4 pa[NPF], pd[NPF];
-  auto prefetch = [&](int b0) {
-    const int nbp = (b_end - b0) < NBC ? (b_end - b0) : NBC;
-    const int nv = nbp > 0 ? nbp * P : 0;
-    const float4* a4 = (const float4*)(a + (size_t)b0 * P * F);
-    const float4* d4 = (const float4*)(dg + (size_t)b0 * P * F);
-#pragma unroll
-    for (int q = 0; q < NPF; ++q) {
-      const int idx = tid + q * G::THREADS, row = idx / (F / 4), c4 = idx % (F / 4);
-      const bool ok = row < nv;
-      pa[q] = ok ? a4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-      pd[q] = ok ? d4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  prefetch(b_begin);
+  if constexpr (STAMP) ts[1] = wall_clock64();
   for (int b0 = b_begin; b0 < b_end; b0 += NBC) {
     const int nb = (b_end - b0) < NBC ? (b_end - b0) : NBC;
+    long long tb = 0;
+    if constexpr (STAMP) tb = wall_clock64();
     __syncthreads();                                              // the previous chunk has been consumed (first pass: the row lists are complete)
+    long long tb1 = 0;
+    if constexpr (STAMP) tb1 = wall_clock64();
 #pragma unroll
     for (int q = 0; q < NPF; ++q) {
       const int idx = tid + q * G::THREADS, row = idx / (F / 4), c4 = idx % (F / 4);
@@ -917,7 +928,10 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
       *(float4*)(Ds + row * STRIDE + c4 * 4) = pd[q];
     }
     __syncthreads();
-    if (b0 + NBC < b_end) prefetch(b0 + NBC);
+    long long tb2 = 0;
+    if constexpr (STAMP) tb2 = wall_clock64();
+    if (b0 + NBC < b_end) prefetch(b0 + NBC, 0, NPF);
+    if constexpr (STAMP) { const long long tn = wall_clock64(); if (b0 == b_begin) ts[2] = tn; else { ts[3] += tn - tb; ts[6] += tb1 - tb; ts[7] += tb2 - tb1; } }
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
       // the rows of tap k in this chunk, four per step; an even number of steps (a list's tail is zero rows).  Two
@@ -927,6 +941,12 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
       const uint32_t* list = rl + k * RLS + g;
       float bv0[CT], bv1[CT], av0, av1;
       auto load_step = [&](uint32_t e, float (&bv)[CT], float& av) {
+        if constexpr (STAMP == 2) {
+#pragma unroll
+          for (int j = 0; j < CT; ++j) bv[j] = __uint_as_float(e + j);
+          av = __uint_as_float(e);
+          return;
+        }
         const float* dp = Ds + (e & 0xffffu) * STRIDE + lrow;
 #pragma unroll
         for (int j = 0; j < CT; ++j) bv[j] = dp[j * 16];
@@ -934,24 +954,39 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
       };
       auto mfma_step = [&](const float (&bv)[CT], float av) {
 #pragma unroll
-        for (int j = 0; j < CT; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[k][j], 0, 0, 0);
+        for (int j = 0; j < CT; ++j) {
+          if constexpr (STAMP == 3) acc[k][j][0] += av * bv[j];
+          else acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[k][j], 0, 0, 0);
+        }
+      };
+      // one MFMA, then a share of the next step's address arithmetic and LDS reads: a wavefront that runs alone on its SIMD
+      // (its partner waits at the chunk barrier, or is in its own load phase) keeps the matrix pipe busy by itself
+      auto interleave = [&]() {
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
       };
       uint32_t e0 = list[0], e1 = list[4];
       load_step(e0, bv0, av0);
       for (int s0 = 0; s0 < nsteps; s0 += 2) {
+        __builtin_amdgcn_sched_barrier(0);
         e0 = list[4 * (s0 + 2)];
         load_step(e1, bv1, av1);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_step(bv0, av0);
+        interleave();
         __builtin_amdgcn_sched_barrier(0);
         e1 = list[4 * (s0 + 3)];
         load_step(e0, bv0, av0);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_step(bv1, av1);
-        __builtin_amdgcn_sched_barrier(0);
+        interleave();
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if constexpr (STAMP) ts[4] = wall_clock64();
   // partial dW of this workgroup: [split][tap][ci][co], ci = 16 wave + 4 g + i, co = 16 j + lrow
   float* o = part + (size_t)blockIdx.x * 9 * F * F;
 #pragma unroll
@@ -962,6 +997,11 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         o[((size_t)tap * F + (wave * 16 + g * 4 + i)) * F + j * 16 + lrow] = acc[k][j][i];
+  }
+  if constexpr (STAMP) {
+    __builtin_amdgcn_s_waitcnt(0);
+    ts[5] = wall_clock64();
+    if (tid == 0) for (int i = 0; i < 8; ++i) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = ts[i];
   }
 }
 static __global__ void k_wgrad_reduce(const float* __restrict__ part, int nsplit, long long n, float* __restrict__ out) {

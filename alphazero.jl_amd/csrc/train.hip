@@ -547,7 +547,7 @@ template <class Gm, int F> static int tr_wgrad16_f(az_trainer* t, const float* a
   using G = WG16<F>;
   static bool attr_done = false;
   if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16<Gm, F>), hipFuncAttributeMaxDynamicSharedMemorySize, G::BYTES)); attr_done = true; }
-  hipLaunchKernelGGL((k_wgrad16<Gm, F>), dim3(t->wg_splits, G::TG), dim3(G::THREADS), G::BYTES, st, a, dg, t->wg_part, t->B, t->wg_splits);
+  hipLaunchKernelGGL((k_wgrad16<Gm, F>), dim3(t->wg_splits, G::TG), dim3(G::THREADS), G::BYTES, st, a, dg, t->wg_part, t->B, t->wg_splits, (long long*)nullptr);
   const long long n = 9LL * F * F;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(tr_grid(n)), dim3(256), 0, st, t->wg_part, t->wg_splits, n, out);
   return AZ_OK;
