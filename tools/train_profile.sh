@@ -26,3 +26,23 @@ for r in rows:
                                             (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 PY
 fi
+# PMC=1: one counter pass (its own run, --kernel-trace only): MFMA pipe time of the trainer's kernels (the profiler serialises
+# the two streams, so these are the kernels alone)
+if [ -n "$PMC" ]; then
+  p=/tmp/pmc_$TAG; rm -rf $p
+  (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $p -- python $ROOT/tools/train_bench.py --steps 10 ${BENCH_ARGS} > $OUT/pmc_stdout.txt 2>&1 < /dev/null)
+  c=$(find $p -name '*counter_collection.csv' 2>/dev/null | head -1)
+  if [ -n "$c" ]; then python - "$c" > $OUT/pmc_mfma_busy.txt <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"].replace("void ", "").split("(")[0]
+    acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
+    if v.get("GRBM_GUI_ACTIVE", 0) > 0:
+        # SQ_VALU_MFMA_BUSY_CYCLES sums 1024 SIMDs, GRBM_GUI_ACTIVE 8 XCDs
+        print("%-50s launches %5d  %8.1f us  MFMA pipes busy %.3f of the kernel's cycles" % (k[:50], n[(k, "GRBM_GUI_ACTIVE")],
+              v["GRBM_GUI_ACTIVE"] / 8 / n[(k, "GRBM_GUI_ACTIVE")] / 2100.0, v["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * v["GRBM_GUI_ACTIVE"])))
+PY
+  head -8 $OUT/pmc_mfma_busy.txt; fi
+fi
