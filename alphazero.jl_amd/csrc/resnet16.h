@@ -761,10 +761,13 @@ k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restric
 // STATS (the forward pass): the workgroup also leaves the column sums (sum v, sum v^2) of its rows of the output in
 // part[blockIdx.x][2][F] (double), the first stage of the batch-norm statistics -- the accumulators are at hand, a
 // separate pass over the output (k_tr_colsum<0>) is not needed.
-template <class Gm, int F, bool STATS>
+// STAMP (tools/probes/conv_stamps.hip): clock readings of the first wavefront of every workgroup in stamps[workgroup][4]
+template <class Gm, int F, bool STATS, bool STAMP = false>
 __global__ void __launch_bounds__(T16Threads<F>::V, 2)
 k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, float* __restrict__ out, int nboards, const uint16_t* __restrict__ geo,
-               double* __restrict__ part, const float* __restrict__ addend) {
+               double* __restrict__ part, const float* __restrict__ addend, long long* __restrict__ stamps) {
+  long long ts[4] = {0, 0, 0, 0};
+  if constexpr (STAMP) ts[0] = wall_clock64();
   using T = T16<Gm, F, 11>;
   using G = typename T::Geo;
   constexpr int P = Gm::P, STRIDE = T::STRIDE, NT = 11;
@@ -789,10 +792,12 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
   for (int i = tid; i < 9 * T::RPAD; i += T::THREADS) nbr[i] = geo[T::RPAD + i];
   const int lrow = lane & 15, g = lane >> 4;
   __syncthreads();
+  if constexpr (STAMP) ts[1] = wall_clock64();
   f32x4v acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
   conv16p<T, G, NT, 0, 9>(buf, nbr, wfrag + (size_t)wave * T::SQ * 64 + lane, acc, lrow, g);
+  if constexpr (STAMP) { ts[2] = wall_clock64(); __syncthreads(); }    // the barrier: the epilogue reading then starts when the LAST wavefront has its products
   const int ch = wave * 16 + lrow;
   float* o = out + (size_t)board0 * P * F;
   double s0 = 0.0, s1 = 0.0;
@@ -813,6 +818,11 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
     s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16);
     s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
     if (g == 0) { part[((size_t)blockIdx.x * 2) * F + ch] = s0; part[((size_t)blockIdx.x * 2 + 1) * F + ch] = s1; }
+  }
+  if constexpr (STAMP) {
+    __builtin_amdgcn_s_waitcnt(0);
+    ts[3] = wall_clock64();
+    if (tid == 0) for (int i = 0; i < 4; ++i) stamps[(size_t)blockIdx.x * 4 + i] = ts[i];
   }
 }
 

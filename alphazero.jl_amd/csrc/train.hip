@@ -528,7 +528,7 @@ template <class Gm, int F, bool STATS> static int tr_conv16_f(az_trainer* t, con
   using T = T16<Gm, F, 11>;
   static bool attr_done = false;
   if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_layer<Gm, F, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, T::BYTES)); attr_done = true; }
-  hipLaunchKernelGGL((k_conv16_layer<Gm, F, STATS>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[0], t->part, addend);
+  hipLaunchKernelGGL((k_conv16_layer<Gm, F, STATS>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[0], t->part, addend, (long long*)nullptr);
   return AZ_OK;
 }
 // 3x3 F -> F convolution of [R][F] activations on the MFMA layer kernel; stats: also the first stage of the column sums
