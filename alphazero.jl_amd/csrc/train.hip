@@ -348,6 +348,7 @@ struct az_trainer {
   az_train_cfg cfg;
   int game, device; GameInfo gi;
   hipStream_t stream;
+  bool one_stream;
   hipStream_t side;                                                          // the weight gradients of the tower run here, beside the batch-norm backward passes of the next layer
   std::vector<hipEvent_t> ev_dg, ev_wg;                                     // per tower layer: output gradient ready / weight gradient done
   float* gemm_ws; size_t gemm_ws_floats;                                     // split-reduction workspace of gemm_f32
@@ -694,9 +695,9 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
       // the weight gradient starts when the data gradient of its layer is done: two MFMA kernels side by side only halve each
       // other's share of the chip (measured), while the HBM-bound passes of layer l-1 do fit beside k_wgrad16
       HIPCHK(hipEventRecord(t->ev_dg[l], st));
-      HIPCHK(hipStreamWaitEvent(t->side, t->ev_dg[l], 0));
-      AZCHK(tr_wgrad16(t, t->convs[l - 1].a, da, gw + c.wk_wm, t->side));
-      HIPCHK(hipEventRecord(t->ev_wg[l], t->side));
+      if (!t->one_stream) HIPCHK(hipStreamWaitEvent(t->side, t->ev_dg[l], 0));
+      AZCHK(tr_wgrad16(t, t->convs[l - 1].a, da, gw + c.wk_wm, t->one_stream ? st : t->side));
+      HIPCHK(hipEventRecord(t->ev_wg[l], t->one_stream ? st : t->side));
     }
   }
   for (int l = 1; l < ntower && l <= 2; ++l) if (t->convs[l].mfma) HIPCHK(hipStreamWaitEvent(st, t->ev_wg[l], 0));   // the side stream is in order: its last two launches
@@ -761,6 +762,7 @@ extern "C" int az_trainer_create(az_engine* e, az_dataset* d, const az_train_cfg
     HIPCHK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
     HIPCHK(hipStreamCreateWithPriority(&t->stream, hipStreamDefault, pr_greatest));
     HIPCHK(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, pr_least));
+    { const char* one = getenv("AZHIP_TRAIN_ONE_STREAM"); t->one_stream = one && atoi(one) != 0; }   // diagnosis: the weight gradients in line with everything else
     t->gemm_ws_floats = (size_t)4 << 20;                            // 16 MB: partial tiles of the split weight-gradient reductions
     AZCHK(tr_alloc(t, &t->gemm_ws, t->gemm_ws_floats));
     AZCHK(trainer_build(t));

@@ -86,7 +86,12 @@ class TorchNet:
         return scale * (Lp + Lv + Lreg + Linv), (Lp, Lv, Lreg, Linv, scale)
 
 
-def _rel_err_by_array(game, hp, got, want):
+def _rel_err_by_array(game, hp, got, want, tol=1e-3, l2_tol=None):
+    """every array: max |got - want| <= tol * max |want| (+ 2e-6); l2_tol: also ||got - want||_2 <= l2_tol * ||want||_2.
+    The deep cases use the pair (1e-2, 1e-3): with ~0.5 M activations per layer a handful of them sit within rounding of zero,
+    an fp32 chain and an fp64 chain then disagree on their ReLU masks, and ONE flipped row moves single weight-gradient entries
+    by a few 1e-3 of the array's largest while the array as a whole stays within 1e-3 (seen: 4.4e-3 on block4.conv1.W of a
+    5x128 tower with 96 samples, the same with the round-2 kernels)."""
     worst, off = 0.0, 0
     for name, shape in param_layout(game, hp):
         n = int(np.prod(shape))
@@ -97,7 +102,9 @@ def _rel_err_by_array(game, hp, got, want):
             continue
         denom = max(np.abs(w).max(), 1e-7)
         worst = max(worst, np.abs(g - w).max() / denom) if np.abs(w).max() > 1e-6 else worst
-        assert np.abs(g - w).max() <= 1e-3 * denom + 2e-6, (name, np.abs(g - w).max(), denom)
+        assert np.abs(g - w).max() <= tol * denom + 2e-6, (name, np.abs(g - w).max(), denom)
+        if l2_tol is not None:
+            assert np.linalg.norm(g - w) <= l2_tol * np.linalg.norm(w) + 1e-7, (name, np.linalg.norm(g - w), np.linalg.norm(w))
     return worst
 
 
@@ -123,7 +130,8 @@ def test_gradients_with_default_heads_and_no_blocks():
 
 
 @pytest.mark.parametrize("game,nblocks,F,B,policy", [(1, 1, 64, 24, 1), (0, 2, 64, 16, 0), (2, 1, 64, 20, 2), (0, 1, 128, 12, 1),
-                                                     (0, 1, 128, 203, 1), (0, 2, 64, 333, 0), (1, 1, 64, 500, 2)])   # many workgroups, ragged tails
+                                                     (0, 1, 128, 203, 1), (0, 2, 64, 333, 0), (1, 1, 64, 500, 2),    # many workgroups, ragged tails
+                                                     (0, 5, 128, 96, 1), (2, 3, 64, 130, 0)])   # deep towers: the three-buffer gradient ring of the backward pass wraps
 def test_gradients_match_torch_autograd(game, nblocks, F, B, policy):
     import azhip
     gspec, mem = _memory(game, 12 if B < 100 else 60, 3)
@@ -144,7 +152,8 @@ def test_gradients_match_torch_autograd(game, nblocks, F, B, policy):
         want = ref.blob(grads=True)
         assert abs(loss - L.item()) < 2e-5 * max(1.0, abs(L.item()))
         assert np.allclose(parts, [Lp.item(), Lv.item(), Lreg.item(), Linv.item(), scale.item()], rtol=5e-5, atol=5e-6), (parts, Lp.item(), Lv.item())
-        _rel_err_by_array(game, hp, grad.astype(np.float64), want)
+        deep = nblocks >= 3
+        _rel_err_by_array(game, hp, grad.astype(np.float64), want, tol=1e-2 if deep else 1e-3, l2_tol=1e-3 if deep else None)
         # the probe does not move the parameters or the running statistics
         assert np.array_equal(tr.trained_params(), nn.params())
     mem.close()
@@ -295,4 +304,24 @@ def test_trainer_errors_and_lifecycle():
             L.check(L.lib().az_train_cfg_init(C.byref(cfg)))
             assert L.lib().az_trainer_create(e2._h, tr.data._h, C.byref(cfg), C.byref(h)) == L.AZ_ERR_STATE
     assert L.lib().az_trainer_destroy(None) == 0
+    mem.close()
+
+
+def test_weight_gradient_stream_does_not_change_the_values(monkeypatch):
+    """round 3: k_wgrad16 runs on a second stream beside the batch-norm backward passes of the next layer; with
+    AZHIP_TRAIN_ONE_STREAM=1 it stays in line.  Same kernels, same partial sums: the gradients are bit-identical."""
+    import azhip
+    gspec, mem = _memory(0, 40, 3)
+    hp = azhip.ResNetHP(num_blocks=4, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    nn = azhip.ResNet(gspec, hp, seed=3)
+    lp = azhip.LearningParams(samples_weighing_policy=1, l2_regularization=1e-4, loss_computation_batch_size=64, batch_size=150)
+    grads = []
+    for one in ("0", "1"):
+        monkeypatch.setenv("AZHIP_TRAIN_ONE_STREAM", one)
+        with azhip.Trainer(gspec, nn, mem, lp, use_symmetries=True) as tr:
+            idx = np.arange(150) * 3 % len(tr.data.tensors()[0])
+            g = [tr.gradients(idx)[2].copy() for _ in range(3)]     # repeated: a race would not repeat itself
+            assert all(np.array_equal(g[0], x) for x in g[1:])
+            grads.append(g[0])
+    assert np.array_equal(grads[0], grads[1])
     mem.close()
