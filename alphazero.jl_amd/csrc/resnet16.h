@@ -838,15 +838,21 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
 // board: a table per tap lists them (a corner tap of a 7x6 board keeps 30 of 42 rows, an edge tap 35 or 36), and the three
 // taps of a workgroup are chosen so that every group has the same work -- {two corners, centre}, {corner, two edges},
 // {corner, two edges}: 78 / 77 / 77 four-row steps per 3-board chunk instead of 96.
-template <int F> struct WG16 {
+// CS / RPC (r3): CS = 2 gives every workgroup one HALF of the input channels (4 wavefronts at F = 128) and RPC = 48 makes
+// a chunk one board: 44 KB of LDS instead of 150 and one wavefront per SIMD, so that a workgroup fits on a CU BESIDE a
+// workgroup of k_conv16_layer (104 KB, two wavefronts per SIMD at <= 128 registers) -- the weight gradient of layer l then
+// shares the matrix pipes with the data-gradient convolution of layer l - 1 instead of waiting for it (train.hip).
+template <int F, int CS_ = 1, int RPC_ = 128> struct WG16 {
   static constexpr int TPW = F == 128 ? 3 : 9;                    // taps per workgroup
-  static constexpr int TG = 9 / TPW;                              // tap groups (grid.y)
-  static constexpr int CT = F / 16, WAVES = CT, THREADS = 64 * WAVES;
-  static constexpr int NB = 3;                                    // boards per LDS chunk
-  static constexpr int RP = 128;                                  // padded rows of a chunk (3 x 42 = 126 used; other games: RP / P boards)
-  static constexpr int STRIDE = F + 16;                           // 16-bank shift per row: the 4 row groups of a fragment read use disjoint bank halves in pairs
+  static constexpr int TG = 9 / TPW;                              // tap groups
+  static constexpr int CS = CS_;                                  // splits of the input channels (grid.y = TG * CS)
+  static constexpr int FA = F / CS;                               // input channels of a workgroup
+  static constexpr int CT = F / 16, WAVES = FA / 16, THREADS = 64 * WAVES;
+  static constexpr int RP = RPC_;                                 // padded rows of a chunk (128: 3 x 42 = 126 used; other games: RP / P boards)
+  static constexpr int STRIDE_A = FA + 16, STRIDE = F + 16;       // 16-bank shift per row: the 4 row groups of a fragment read use disjoint bank halves in pairs
   static constexpr int RLS = RP + 8;                              // row-list entries per tap (the pipeline reads two steps ahead)
-  static constexpr int BYTES = ((RP + 1) * STRIDE + RP * STRIDE + TPW * RLS) * 4;
+  static constexpr int BYTES = ((RP + 1) * STRIDE_A + RP * STRIDE + TPW * RLS) * 4;
+  static constexpr int WGS_PER_CU = (RP <= 64 && CS > 1) ? 2 : 1;
   // tap k of group y: balanced groups for TPW == 3, natural order otherwise
   __host__ __device__ static constexpr int tap(int y, int k) {
     constexpr int sel[3][3] = {{0, 8, 4}, {2, 1, 3}, {6, 7, 5}};
@@ -855,19 +861,21 @@ template <int F> struct WG16 {
 };
 // STAMP (tools/probes/wgrad_stamps.hip): every workgroup leaves clock readings in stamps[workgroup][8]; 2: the steps read no
 // LDS operands, 3: they issue no MFMAs (what bounds the loop)
-template <class Gm, int F, int STAMP = 0>
-__global__ void __launch_bounds__(64 * (F / 16), 1)
+template <class Gm, int F, int STAMP = 0, int CS = 1, int RPC = 128>
+__global__ void __launch_bounds__((WG16<F, CS, RPC>::THREADS), (WG16<F, CS, RPC>::WGS_PER_CU))
 k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __restrict__ part, int nboards, int nsplits, long long* __restrict__ stamps) {
   long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if constexpr (STAMP) ts[0] = wall_clock64();
-  using G = WG16<F>;
-  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, STRIDE = G::STRIDE, RP = G::RP, CT = G::CT, TPW = G::TPW, RLS = G::RLS;
+  using G = WG16<F, CS, RPC>;
+  constexpr int P = Gm::P, W = Gm::W, H = Gm::H, STRIDE = G::STRIDE, STRIDE_A = G::STRIDE_A, FA = G::FA, RP = G::RP, CT = G::CT, TPW = G::TPW, RLS = G::RLS;
   constexpr int NBC = RP / P < 1 ? 1 : RP / P;                    // boards per chunk for this game
+  static_assert(RP >= P, "a chunk holds at least one board");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;                                                // [(RP + 1)][STRIDE], row RP = zeros
-  float* Ds = lds + (RP + 1) * STRIDE;                            // [RP][STRIDE]
+  float* As = lds;                                                // [(RP + 1)][STRIDE_A], row RP = zeros
+  float* Ds = lds + (RP + 1) * STRIDE_A;                          // [RP][STRIDE]
   uint32_t* rl = (uint32_t*)(Ds + RP * STRIDE);                   // [TPW][RLS] row lists: (row of a) << 16 | row of dg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, g = lane >> 4;
+  const int tgroup = blockIdx.y % G::TG, half = blockIdx.y / G::TG;  // tap group, input-channel split
   // boards of this workgroup: nboards spread evenly over the nsplits workgroups of a tap group (the first nboards % nsplits
   // take one more; a last partial LDS chunk costs only its rows)
   const int bq = nboards / nsplits, br = nboards % nsplits;
@@ -876,39 +884,42 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
   // The chunk after the current one travels from HBM into registers while the MFMAs of the current one run (every
   // workgroup reaches its chunk boundaries at the same time: without the overlap the chip alternates between a burst of
   // loads and a burst of MFMAs); it is stored to LDS once the current chunk has been consumed.
-  constexpr int NPF = RP * (F / 4) / G::THREADS;                  // float4 per thread and array
-  static_assert(RP * (F / 4) % G::THREADS == 0, "chunk must divide over the threads");
-  float4 pa[NPF], pd[NPF];
+  constexpr int NPA = RP * (FA / 4) / G::THREADS, NPD = RP * (F / 4) / G::THREADS;   // float4 per thread: a, dg
+  static_assert(RP * (FA / 4) % G::THREADS == 0 && RP * (F / 4) % G::THREADS == 0, "chunk must divide over the threads");
+  float4 pa[NPA], pd[NPD];
   // (issued in one burst after the chunk's barrier: spread over the taps' loops they cost 11 more registers, and 232 is the most
   // that leaves room beside this kernel for a wavefront of the batch-norm backward passes, see train.hip)
-  auto prefetch = [&](int b0, int q0, int q1) {
+  auto prefetch = [&](int b0) {
     const int nbp = (b_end - b0) < NBC ? (b_end - b0) : NBC;
     const int nv = nbp > 0 ? nbp * P : 0;
-    const float4* a4 = (const float4*)(a + (size_t)b0 * P * F);
+    const float4* a4 = (const float4*)(a + (size_t)b0 * P * F + half * FA);
     const float4* d4 = (const float4*)(dg + (size_t)b0 * P * F);
 #pragma unroll
-    for (int q = q0; q < q1; ++q) {
+    for (int q = 0; q < NPA; ++q) {
+      const int idx = tid + q * G::THREADS, row = idx / (FA / 4), c4 = idx % (FA / 4);
+      pa[q] = row < nv ? a4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < NPD; ++q) {
       const int idx = tid + q * G::THREADS, row = idx / (F / 4), c4 = idx % (F / 4);
-      const bool ok = row < nv;
-      pa[q] = ok ? a4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-      pd[q] = ok ? d4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      pd[q] = row < nv ? d4[(size_t)row * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  prefetch(b_begin, 0, NPF);                                      // first: its latency covers the table build
+  prefetch(b_begin);                                              // first: its latency covers the table build
   // row lists: for tap k the rows of a chunk whose neighbour at the tap's offset is on the board, board after board; the
   // rest of a list pairs the zero row of `a` with any row of dg
   for (int i = tid; i < TPW * RLS; i += G::THREADS) rl[i] = ((uint32_t)RP << 16) | (uint32_t)(RP - 1);
-  for (int i = tid; i < STRIDE; i += G::THREADS) As[RP * STRIDE + i] = 0.0f;
+  for (int i = tid; i < STRIDE_A; i += G::THREADS) As[RP * STRIDE_A + i] = 0.0f;
   __syncthreads();
   int cnt[TPW];                                                   // valid rows per board of tap k
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
-    const int tap = G::tap(blockIdx.y, k), dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int tap = G::tap(tgroup, k), dy = tap / 3 - 1, dx = tap % 3 - 1;
     cnt[k] = (W - (dx != 0)) * (H - (dy != 0));
   }
   if (tid < TPW * NBC) {
     const int k = tid / NBC, b = tid % NBC;
-    const int tap = G::tap(blockIdx.y, k), dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int tap = G::tap(tgroup, k), dy = tap / 3 - 1, dx = tap % 3 - 1;
     int n = b * (W - (dx != 0)) * (H - (dy != 0));
     for (int q = 0; q < P; ++q) {
       const int x = q % W, y = q / W;
@@ -932,22 +943,26 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
     long long tb1 = 0;
     if constexpr (STAMP) tb1 = wall_clock64();
 #pragma unroll
-    for (int q = 0; q < NPF; ++q) {
+    for (int q = 0; q < NPA; ++q) {
+      const int idx = tid + q * G::THREADS, row = idx / (FA / 4), c4 = idx % (FA / 4);
+      *(float4*)(As + row * STRIDE_A + c4 * 4) = pa[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NPD; ++q) {
       const int idx = tid + q * G::THREADS, row = idx / (F / 4), c4 = idx % (F / 4);
-      *(float4*)(As + row * STRIDE + c4 * 4) = pa[q];
       *(float4*)(Ds + row * STRIDE + c4 * 4) = pd[q];
     }
     __syncthreads();
     long long tb2 = 0;
     if constexpr (STAMP) tb2 = wall_clock64();
-    if (b0 + NBC < b_end) prefetch(b0 + NBC, 0, NPF);
+    if (b0 + NBC < b_end) prefetch(b0 + NBC);
     if constexpr (STAMP) { const long long tn = wall_clock64(); if (b0 == b_begin) ts[2] = tn; else { ts[3] += tn - tb; ts[6] += tb1 - tb; ts[7] += tb2 - tb1; } }
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
-      // the rows of tap k in this chunk, four per step; an even number of steps (a list's tail is zero rows).  Two
-      // register stages: the LDS operands of step s+1 are requested before the CT MFMAs of step s issue, the list
-      // entry of step s+2 before that.
-      const int nsteps = ((nb * cnt[k] + 7) >> 3) << 1;
+      // the rows of tap k in this chunk, four per step (a list's tail is zero rows).  Two register stages: the LDS
+      // operands of step s+1 are requested before the CT MFMAs of step s issue, the list entry of step s+2 before that;
+      // an odd step at the end runs on the operands the last pair already requested.
+      const int nsteps = (nb * cnt[k] + 3) >> 2;
       const uint32_t* list = rl + k * RLS + g;
       float bv0[CT], bv1[CT], av0, av1;
       auto load_step = [&](uint32_t e, float (&bv)[CT], float& av) {
@@ -960,7 +975,7 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
         const float* dp = Ds + (e & 0xffffu) * STRIDE + lrow;
 #pragma unroll
         for (int j = 0; j < CT; ++j) bv[j] = dp[j * 16];
-        av = As[(e >> 16) * STRIDE + wave * 16 + lrow];
+        av = As[(e >> 16) * STRIDE_A + wave * 16 + lrow];
       };
       auto mfma_step = [&](const float (&bv)[CT], float av) {
 #pragma unroll
@@ -981,7 +996,7 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
       };
       uint32_t e0 = list[0], e1 = list[4];
       load_step(e0, bv0, av0);
-      for (int s0 = 0; s0 < nsteps; s0 += 2) {
+      for (int s0 = 0; s0 + 2 <= nsteps; s0 += 2) {
         __builtin_amdgcn_sched_barrier(0);
         e0 = list[4 * (s0 + 2)];
         load_step(e1, bv1, av1);
@@ -994,19 +1009,21 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
         interleave();
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (nsteps & 1) mfma_step(bv0, av0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if constexpr (STAMP) ts[4] = wall_clock64();
-  // partial dW of this workgroup: [split][tap][ci][co], ci = 16 wave + 4 g + i, co = 16 j + lrow
+  // partial dW of this workgroup: [split][tap][ci][co], ci = FA half + 16 wave + 4 g + i, co = 16 j + lrow
   float* o = part + (size_t)blockIdx.x * 9 * F * F;
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
-    const int tap = G::tap(blockIdx.y, k);
+    const int tap = G::tap(tgroup, k);
 #pragma unroll
     for (int j = 0; j < CT; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        o[((size_t)tap * F + (wave * 16 + g * 4 + i)) * F + j * 16 + lrow] = acc[k][j][i];
+        o[((size_t)tap * F + (half * FA + wave * 16 + g * 4 + i)) * F + j * 16 + lrow] = acc[k][j][i];
   }
   if constexpr (STAMP) {
     __builtin_amdgcn_s_waitcnt(0);
@@ -1015,6 +1032,7 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
   }
 }
 static __global__ void k_wgrad_reduce(const float* __restrict__ part, int nsplit, long long n, float* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);   // short and HBM-bound, and the next k_wgrad16 of its stream waits for it
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // eight independent partial sums keep eight loads in flight; combined in a fixed order

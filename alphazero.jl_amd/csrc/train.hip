@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(256) k_tr_colsum(const float* __restrict__ x, 
 __global__ void __launch_bounds__(256) k_tr_colsum1v(const float* __restrict__ x, const float* __restrict__ out_act, const float* __restrict__ g,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd, long long R, int C,
                                                      double* __restrict__ part /* [nchunks][2][C] */) {
+  __builtin_amdgcn_s_setprio(3);   // HBM-bound and short: its few instructions go first when it shares a SIMD with k_wgrad16's wavefronts
   __shared__ double sh[256][4];
   const int CQ = C >> 2, RL = 256 / CQ;
   const int q = threadIdx.x % CQ, rl = threadIdx.x / CQ;
@@ -122,6 +123,14 @@ __global__ void __launch_bounds__(256) k_tr_colsum1v(const float* __restrict__ x
     }
   };
   long long r = r0 + rl;
+  for (; r + 3 * RL < r1; r += 4 * RL) {                            // four rows in flight: beside k_wgrad16 this kernel gets one wavefront per SIMD
+    const size_t i0 = (size_t)r * C + 4 * q, i1 = i0 + (size_t)RL * C, i2 = i1 + (size_t)RL * C, i3 = i2 + (size_t)RL * C;
+    const float4 x0 = *(const float4*)(x + i0), a0 = *(const float4*)(out_act + i0), g0 = *(const float4*)(g + i0);
+    const float4 x1 = *(const float4*)(x + i1), a1 = *(const float4*)(out_act + i1), g1 = *(const float4*)(g + i1);
+    const float4 x2 = *(const float4*)(x + i2), a2 = *(const float4*)(out_act + i2), g2 = *(const float4*)(g + i2);
+    const float4 x3 = *(const float4*)(x + i3), a3 = *(const float4*)(out_act + i3), g3 = *(const float4*)(g + i3);
+    add(x0, a0, g0); add(x1, a1, g1); add(x2, a2, g2); add(x3, a3, g3);
+  }
   for (; r + RL < r1; r += 2 * RL) {                                // two rows in flight
     const size_t i = (size_t)r * C + 4 * q, j = i + (size_t)RL * C;
     const float4 x0 = *(const float4*)(x + i), a0 = *(const float4*)(out_act + i), g0 = *(const float4*)(g + i);
@@ -157,6 +166,7 @@ struct TrFinal {
   float* out0;                                                        // mode 3
 };
 __global__ void __launch_bounds__(64) k_tr_colsum_final(const double* __restrict__ part, int nchunks, int C, double* __restrict__ sums /* [2][C] */, TrFinal f) {
+  __builtin_amdgcn_s_setprio(3);
   __shared__ double sh[2][64];
   const int c = blockIdx.x, t = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
@@ -204,6 +214,7 @@ template <int V>
 __global__ void __launch_bounds__(256) k_tr_bn_bwd(const float* __restrict__ da, const float* __restrict__ a, const float* __restrict__ g,
                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                             const float* __restrict__ mf, long long n, int C, float* __restrict__ dg, float* __restrict__ dy_out) {
+  __builtin_amdgcn_s_setprio(3);
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
   if (i >= n) return;
   const int c = (int)(i % C);
@@ -348,7 +359,7 @@ struct az_trainer {
   az_train_cfg cfg;
   int game, device; GameInfo gi;
   hipStream_t stream;
-  bool one_stream;
+  bool one_stream, wg_late;
   hipStream_t side;                                                          // the weight gradients of the tower run here, beside the batch-norm backward passes of the next layer
   std::vector<hipEvent_t> ev_dg, ev_wg;                                     // per tower layer: output gradient ready / weight gradient done
   float* gemm_ws; size_t gemm_ws_floats;                                     // split-reduction workspace of gemm_f32
@@ -545,10 +556,13 @@ static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* o
 }
 
 template <class Gm, int F> static int tr_wgrad16_f(az_trainer* t, const float* a, const float* dg, float* out, hipStream_t st) {
-  using G = WG16<F>;
+  // 128 filters: the 4-wavefront form (half the input channels per workgroup, one board per LDS chunk, 44 KB): the same sums in
+  // the same order as the 8-wavefront form, and a workgroup of it fits on a CU beside one of k_conv16_layer
+  constexpr int CS = (F == 128 && Gm::P <= 48) ? 2 : 1, RPC = CS == 2 ? 48 : 128;
+  using G = WG16<F, CS, RPC>;
   static bool attr_done = false;
-  if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16<Gm, F>), hipFuncAttributeMaxDynamicSharedMemorySize, G::BYTES)); attr_done = true; }
-  hipLaunchKernelGGL((k_wgrad16<Gm, F>), dim3(t->wg_splits, G::TG), dim3(G::THREADS), G::BYTES, st, a, dg, t->wg_part, t->B, t->wg_splits, (long long*)nullptr);
+  if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16<Gm, F, 0, CS, RPC>), hipFuncAttributeMaxDynamicSharedMemorySize, G::BYTES)); attr_done = true; }
+  hipLaunchKernelGGL((k_wgrad16<Gm, F, 0, CS, RPC>), dim3(t->wg_splits, G::TG * CS), dim3(G::THREADS), G::BYTES, st, a, dg, t->wg_part, t->B, t->wg_splits, (long long*)nullptr);
   const long long n = 9LL * F * F;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(tr_grid(n)), dim3(256), 0, st, t->wg_part, t->wg_splits, n, out);
   return AZ_OK;
@@ -683,6 +697,7 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
     // dg overwrites da; for conv2 the masked gradient dy also flows to the block input (dact2)
     tr_bn_bwd(t, da, c.a, c.g, c.mean, c.invstd, blob + c.off_bn, R * c.cout, c.cout, da, second ? t->dact2 : nullptr);
     if (!c.mfma) AZCHK(tr_gemm(t, true, false, 9 * c.cin, c.cout, (int)R, 1.f, c.col, 9 * c.cin, da, c.cout, 0.f, gw + c.wk_wm, c.cout));
+    if (c.mfma && !t->wg_late) HIPCHK(hipEventRecord(t->ev_dg[l], st));    // dg(l) is ready: the weight gradient may start beside the data gradient
     if (l > 0) {
       // data gradient da_prev = conv(dg, mirrored taps, ci <-> co): the same MFMA layer kernel with the wk_fdg fragments, out of place
       const bool first_of_block = (l % 2) == 1;                    // conv1: its input is the block input, which also gets the skip share
@@ -694,7 +709,7 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
     if (c.mfma) {
       // the weight gradient starts when the data gradient of its layer is done: two MFMA kernels side by side only halve each
       // other's share of the chip (measured), while the HBM-bound passes of layer l-1 do fit beside k_wgrad16
-      HIPCHK(hipEventRecord(t->ev_dg[l], st));
+      if (t->wg_late) HIPCHK(hipEventRecord(t->ev_dg[l], st));
       if (!t->one_stream) HIPCHK(hipStreamWaitEvent(t->side, t->ev_dg[l], 0));
       AZCHK(tr_wgrad16(t, t->convs[l - 1].a, da, gw + c.wk_wm, t->one_stream ? st : t->side));
       HIPCHK(hipEventRecord(t->ev_wg[l], t->one_stream ? st : t->side));
@@ -762,7 +777,8 @@ extern "C" int az_trainer_create(az_engine* e, az_dataset* d, const az_train_cfg
     HIPCHK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
     HIPCHK(hipStreamCreateWithPriority(&t->stream, hipStreamDefault, pr_greatest));
     HIPCHK(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, pr_least));
-    { const char* one = getenv("AZHIP_TRAIN_ONE_STREAM"); t->one_stream = one && atoi(one) != 0; }   // diagnosis: the weight gradients in line with everything else
+    { const char* one = getenv("AZHIP_TRAIN_ONE_STREAM"); t->one_stream = one && atoi(one) != 0; }
+    { const char* la = getenv("AZHIP_TRAIN_WG_LATE"); t->wg_late = la && atoi(la) != 0; }   // diagnosis: k_wgrad16(l) only after the data gradient of layer l   // diagnosis: the weight gradients in line with everything else
     t->gemm_ws_floats = (size_t)4 << 20;                            // 16 MB: partial tiles of the split weight-gradient reductions
     AZCHK(tr_alloc(t, &t->gemm_ws, t->gemm_ws_floats));
     AZCHK(trainer_build(t));
