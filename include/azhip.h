@@ -43,7 +43,8 @@
  * (read at az_engine_create), AZHIP_GRAPH=1 replays wave pairs as hipGraphs, AZHIP_VMM=0|1 forces the plain / mapped-on-demand
  * node pool and AZHIP_POOL_GB bounds the physical memory of the latter, AZHIP_RCCL_LIB=<path> substitutes the library az_comm_*
  * loads (tests/rccl_stub: several ranks on one GPU), AZHIP_TRAIN_ONE_STREAM=1 keeps the trainer's weight gradients on the
- * step's own stream (same values, read at az_trainer_create).
+ * step's own stream and AZHIP_TRAIN_WG_LATE=1 starts them after the data gradient of their layer instead of beside it (same values
+ * either way, read at az_trainer_create).
  *
  * RNG contract: include/az_numerics.h (philox4x32-10 keyed by seed, counter = game id,
  * move index, purpose, draw index).
