@@ -294,10 +294,6 @@ template <class G, int NT, int TILE0, int KH, int NTAP> struct Steps16 {
     int8_t next_tap[MAXS];                              // tap whose weights to request (-1: none)
     int8_t ord[MAXS];                                   // ordinal of the tap among the taps that have steps (weight stage = ord & 1)
     int8_t first_tap;
-    // the same list seen as units (tap, kh) -- for pipelines that stage the weights per 64-channel (fp32) / half-K (bf16) unit
-    int8_t ufirst[MAXS];                                // first step of its unit
-    int8_t unext_tap[MAXS], unext_kh[MAXS];             // the unit after this step's (-1: none)
-    int8_t uord[MAXS];                                  // ordinal of the unit
   };
   static constexpr L make() {
     L l{};
@@ -321,10 +317,6 @@ template <class G, int NT, int TILE0, int KH, int NTAP> struct Steps16 {
           l.first[k] = (kh == 0 && i == 0);
           l.next_tap[k] = (int8_t)(ti + 1 < ntaps ? taps[ti + 1] : -1);
           l.ord[k] = (int8_t)ti;
-          l.ufirst[k] = (i == 0);
-          l.unext_tap[k] = (int8_t)(kh + 1 < KH ? tap : (ti + 1 < ntaps ? taps[ti + 1] : -1));
-          l.unext_kh[k] = (int8_t)(kh + 1 < KH ? kh + 1 : 0);
-          l.uord[k] = (int8_t)(ti * KH + kh);
         }
     }
     return l;

@@ -157,14 +157,14 @@ def block_report(label, game, hp, bf16, kernel, prof, s0, s1, dt, waves, slots, 
 
 def host_stepped_c5(seconds=6.0):
     """BASELINE configs[4] end to end as far as it can go without OpenSpiel: examples/host_stepped_go9 (plain C++ over
-    include/azhip.h: host rules + host trees on all host threads, ResNet 10x128 bf16 on the GPU through az_net_forward at
-    1600 sims/move).  The rules are a labelled stand-in (OpenSpiel is not in the reference tree): no parity claim, the
+    include/azhip.h: host rules + host trees on up to 16 host threads, 4096 workers in two halves that take turns between the
+    host and the network, ResNet 10x128 bf16 on the GPU through az_net_forward at 1600 sims/move).  The rules are a labelled stand-in (OpenSpiel is not in the reference tree): no parity claim, the
     number says what the network seam sustains and how much of the wall time the host needs."""
     import subprocess
     exe = os.path.join(ROOT, "examples", "host_stepped_go9")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
-    r = subprocess.run([exe, "--workers", "1024", "--sims", "1600", "--seconds", str(seconds)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([exe, "--workers", "4096", "--sims", "1600", "--seconds", str(seconds)], capture_output=True, text=True, timeout=120)
     line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
     if r.returncode != 0 or line is None:
         raise RuntimeError("host_stepped_go9 exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))

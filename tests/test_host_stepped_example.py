@@ -27,8 +27,8 @@ def test_dry_mode_plays_go_shaped_games_on_the_host():
     r, d = _run("--dry", "--workers", "32", "--sims", "24", "--seconds", "1.5", "--threads", "2")
     assert r.returncode == 0, r.stderr
     assert d["value"] > 1000 and d["games_finished"] >= 1 and d["moves"] > 100      # whole games reach two passes / the move limit
-    assert 0.9 < d["boards_per_launch"] <= 32 and d["avg_exploration_depth"] > 0.5
-    assert abs(d["host_tree_share"] + d["network_share"] + d["move_share"] - 1.0) < 0.05
+    assert 0.9 < d["boards_per_launch"] <= 16 and d["avg_exploration_depth"] > 0.5      # two halves of 16 workers take turns
+    assert 0.2 < d["host_tree_share"] <= 1.0 and 0.0 <= d["network_wait_share"] < 0.8
     assert "NOT OpenSpiel" in d["rules"]
 
 
@@ -44,5 +44,5 @@ def test_real_mode_refuses_to_run_without_a_gpu():
 def test_host_tree_over_the_network_seam_reports_a_throughput():
     r, d = _run("--workers", "256", "--sims", "64", "--seconds", "2")
     assert r.returncode == 0, r.stderr
-    assert d["value"] > 1000 and d["kernel"].startswith("k_tower16b<Go9Planes,128") and d["network_share"] > 0.01
-    assert d["boards_per_launch"] > 100
+    assert d["value"] > 1000 and d["kernel"].startswith("k_tower16b<Go9Planes,128") and d["network_busy_share"] > 0.01
+    assert 50 < d["boards_per_launch"] <= 128
