@@ -16,7 +16,7 @@
 //
 //   g++ -O2 -std=c++17 -Iinclude examples/host_stepped_go9.cpp -Lalphazero.jl_amd/csrc -lazhip -lpthread ...
 //       -Wl,-rpath,$PWD/alphazero.jl_amd/csrc -o examples/host_stepped_go9      (or: make -C examples)
-//   examples/host_stepped_go9 [--workers 512] [--sims 1600] [--seconds 8] [--threads 0=all usable] [--arena-gb 8] [--fp32] [--blocks 10] [--filters 128]
+//   examples/host_stepped_go9 [--workers 512] [--sims 1600] [--seconds 8] [--threads 0=all usable] [--arena-gb 0=auto] [--fp32] [--blocks 10] [--filters 128]
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -244,7 +244,7 @@ struct Worker {
   }
 };
 
-struct Opt { bool dry = false; int workers = 512, sims = 1600, threads = 0, blocks = 10, filters = 128, bf16 = 1; double seconds = 8.0, cpuct = 2.0, eps = 0.25, alpha = 0.03, arena_gb = 8.0; };
+struct Opt { bool dry = false; int workers = 512, sims = 1600, threads = 0, blocks = 10, filters = 128, bf16 = 1; double seconds = 8.0, cpuct = 2.0, eps = 0.25, alpha = 0.03, arena_gb = 0.0; };
 
 // select (mcts.jl:199-217) until an unseen or a terminal state
 void descend(Worker& w, const Opt& o) {
@@ -447,6 +447,18 @@ int main(int argc, char** argv) {
   }
   const int W = o.workers;
   Pool pool(o.threads);
+  if (o.arena_gb <= 0.0) {
+    // 2 M simulations/s x 1.4 KB per node = 2.8 GB/s of tree: enough for the run (trees are only reset when a game ends), at most a
+    // quarter of what the host has available
+    o.arena_gb = 4.0 + 3.5 * (o.seconds + std::min(2.0, 0.25 * o.seconds));
+    double avail_gb = 16.0;
+    if (FILE* f = fopen("/proc/meminfo", "r")) {
+      char line[256];
+      while (fgets(line, sizeof line, f)) { long long kb; if (sscanf(line, "MemAvailable: %lld kB", &kb) == 1) avail_gb = (double)kb / 1048576.0; }
+      fclose(f);
+    }
+    o.arena_gb = std::min(o.arena_gb, 0.25 * avail_gb);
+  }
   SLABS.init((size_t)(o.arena_gb * 1073741824.0));
   pool.run((int)SLABS.nslabs, [&](int i) { char* q = SLABS.base + (size_t)i * SlabPool::SLAB; for (size_t k = 0; k < SlabPool::SLAB; k += 4096) q[k] = 0; });
   std::vector<Worker> ws((size_t)W);
