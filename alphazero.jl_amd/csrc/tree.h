@@ -270,6 +270,9 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
   const uint32_t epoch0 = v.epoch[pslot], ins0 = v.leaf_ins[pslot];
   const GEnv lenv0 = v.leaf_env[pslot];
   const long long trav0 = v.tot_trav[pslot], sims0 = v.tot_sims[pslot];
+  const int ridx0 = v.root_idx[pslot], active0 = v.active[pslot];   // phase B's first two loads; phase A knows when it changes them
+  bool retired = false;
+  int new_root = -1;
 
   // ------------------------------------------------------------------ phase A: expand + backup
   if (do_backup && live) {
@@ -286,7 +289,7 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
           // its game is reported as aborted and the phase goes on; the hooks report a capacity error
           ok = false;
           if (!p.retire) dev_fail(v, DERR_NODE_POOL);
-          else if (lane == 0) { v.finished[slot] = 2; v.active[slot] = 0; v.leaf_kind[slot] = LEAF_NONE; }
+          else { retired = true; if (lane == 0) { v.finished[slot] = 2; v.active[slot] = 0; v.leaf_kind[slot] = LEAF_NONE; } }
         } else {
           const GEnv env = lenv0;
           const uint32_t m = Gm::mask(env);
@@ -306,6 +309,7 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
             }
             Pf = av ? (float)res : 0.f;
           }
+          if (depth == 0) new_root = idx;
           char* nd = node_at<Gm>(v, slot, idx);
           // the edge that reached the new node: entry depth - 1 of the path, already in lane depth - 1's register when depth <= L
           const unsigned long long st_par = (depth >= 1 && depth <= L) ? __shfl(st0, gbase + depth - 1) : (depth > L ? path[depth - 1] : 0ULL);
@@ -365,10 +369,10 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
 
   // ------------------------------------------------------------------ phase B: select
   int depth = 0, kind = LEAF_NONE;
-  if (live && v.active[slot]) {
+  if (live && active0 && !retired) {
     GEnv env = root0;
     const uint32_t epoch = epoch0;
-    int idx = v.root_idx[slot];
+    int idx = new_root >= 0 ? new_root : ridx0;
     bool probe = idx < 0;
     uint32_t ins = 0;
     int pidx = 0, pact = 0;
