@@ -131,7 +131,8 @@ def test_gradients_with_default_heads_and_no_blocks():
 
 @pytest.mark.parametrize("game,nblocks,F,B,policy", [(1, 1, 64, 24, 1), (0, 2, 64, 16, 0), (2, 1, 64, 20, 2), (0, 1, 128, 12, 1),
                                                      (0, 1, 128, 203, 1), (0, 2, 64, 333, 0), (1, 1, 64, 500, 2),    # many workgroups, ragged tails
-                                                     (0, 5, 128, 96, 1), (2, 3, 64, 130, 0)])   # deep towers: the three-buffer gradient ring of the backward pass wraps
+                                                     (0, 5, 128, 96, 1), (2, 3, 64, 130, 0),    # deep towers: the three-buffer gradient ring of the backward pass wraps
+                                                     (1, 1, 128, 70, 1), (2, 2, 128, 45, 0)])   # 128 filters on the small boards: k_wgrad16's 4-wavefront form with 5 / 3 boards per LDS chunk
 def test_gradients_match_torch_autograd(game, nblocks, F, B, policy):
     import azhip
     gspec, mem = _memory(game, 12 if B < 100 else 60, 3)
