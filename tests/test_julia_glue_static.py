@@ -199,3 +199,23 @@ def test_shard_games_formula_is_the_python_mirror_s():
         counts = [each + rem if r == 0 else each for r in range(w)]
         for r in range(w):
             assert shard_games(n, w, r) == (sum(counts[:r]), counts[r])
+
+
+def test_julia_sources_are_structurally_balanced():
+    """the glue and the golden-vector script have never been executed (no Julia in the image): at least every block is closed
+    and every bracket paired (tools/julia_balance.py), and the checker does notice a missing `end` / bracket"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "julia_balance.py")
+    for f in ("julia/AlphaZeroHIP.jl", "tools/gen_golden.jl"):
+        r = subprocess.run([sys.executable, tool, os.path.join(root, f)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.startswith("balanced"), (f, r.stdout)
+    src = open(os.path.join(root, "julia", "AlphaZeroHIP.jl")).read()
+    import tempfile
+    for broken in (src.replace("\nend\n", "\n\n", 1), src.replace("ccall((", "ccall(", 1)):
+        with tempfile.NamedTemporaryFile("w", suffix=".jl", delete=False) as tf:
+            tf.write(broken)
+        r = subprocess.run([sys.executable, tool, tf.name], capture_output=True, text=True)
+        os.unlink(tf.name)
+        assert r.returncode == 1, r.stdout
