@@ -1023,16 +1023,30 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
     if (tid == 0) for (int i = 0; i < 8; ++i) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = ts[i];
   }
 }
-static __global__ void k_wgrad_reduce(const float* __restrict__ part, int nsplit, long long n, float* __restrict__ out) {
+// two outputs per thread (n is even: n = 9 F F), 8-byte loads, eight in flight: beside a convolution and a k_wgrad16
+// workgroup 56 registers per SIMD lane are free -- with 4-byte loads this kernel moved 1 TB/s there (50 us for the 50 MB of a
+// layer), with 16-byte loads it needs 70 registers and waits for a CU
+static __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, int nsplit, long long n, float* __restrict__ out) {
   __builtin_amdgcn_s_setprio(3);   // short and HBM-bound, and the next k_wgrad16 of its stream waits for it
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
   if (i >= n) return;
-  // eight independent partial sums keep eight loads in flight; combined in a fixed order
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // eight independent partial sums keep eight loads in flight; combined in a fixed order (per output the same sums as ever)
+  float2 s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = make_float2(0.f, 0.f);
   int k = 0;
   for (; k + 8 <= nsplit; k += 8)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(k + u) * n + i];
-  for (; k < nsplit; ++k) s[0] += part[(size_t)k * n + i];
-  out[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    for (int u = 0; u < 8; ++u) {
+      const float2 v = *(const float2*)(part + (size_t)(k + u) * n + i);
+      s[u].x += v.x; s[u].y += v.y;
+    }
+  for (; k < nsplit; ++k) {
+    const float2 v = *(const float2*)(part + (size_t)k * n + i);
+    s[0].x += v.x; s[0].y += v.y;
+  }
+  float2 r;
+  r.x = ((s[0].x + s[1].x) + (s[2].x + s[3].x)) + ((s[4].x + s[5].x) + (s[6].x + s[7].x));
+  r.y = ((s[0].y + s[1].y) + (s[2].y + s[3].y)) + ((s[4].y + s[5].y) + (s[6].y + s[7].y));
+  *(float2*)(out + i) = r;
 }

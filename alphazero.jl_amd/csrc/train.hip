@@ -564,7 +564,7 @@ template <class Gm, int F> static int tr_wgrad16_f(az_trainer* t, const float* a
   if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16<Gm, F, 0, CS, RPC>), hipFuncAttributeMaxDynamicSharedMemorySize, G::BYTES)); attr_done = true; }
   hipLaunchKernelGGL((k_wgrad16<Gm, F, 0, CS, RPC>), dim3(t->wg_splits, G::TG * CS), dim3(G::THREADS), G::BYTES, st, a, dg, t->wg_part, t->B, t->wg_splits, (long long*)nullptr);
   const long long n = 9LL * F * F;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(tr_grid(n)), dim3(256), 0, st, t->wg_part, t->wg_splits, n, out);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(tr_grid(n / 2)), dim3(256), 0, st, t->wg_part, t->wg_splits, n, out);
   return AZ_OK;
 }
 // weight gradient of a 3x3 F -> F convolution on the MFMA kernel: out = [9][F][F] in the Wm layout
@@ -575,7 +575,7 @@ static int tr_wgrad16(az_trainer* t, const float* a, const float* dg, float* out
 
 static void tr_bn_bwd(az_trainer* t, const float* da, const float* a, const float* g, const float* mean, const float* invstd, const float* gamma,
                       long long n, int C, float* dg, float* dy_out) {
-  if (C % 4 == 0) hipLaunchKernelGGL((k_tr_bn_bwd<4>), dim3(tr_grid(n / 4)), dim3(256), 0, t->stream, da, a, g, mean, invstd, gamma, t->bn_mf, n, C, dg, dy_out);
+  if (C % 4 == 0) hipLaunchKernelGGL((k_tr_bn_bwd<4>), dim3(tr_grid(n / 2)), dim3(256), 0, t->stream, da, a, g, mean, invstd, gamma, t->bn_mf, n, C, dg, dy_out);
   else hipLaunchKernelGGL((k_tr_bn_bwd<1>), dim3(tr_grid(n)), dim3(256), 0, t->stream, da, a, g, mean, invstd, gamma, t->bn_mf, n, C, dg, dy_out);
 }
 // column sums of mode MODE over R rows, result in t->sums
