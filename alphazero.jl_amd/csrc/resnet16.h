@@ -879,8 +879,8 @@ k_wgrad16(const float* __restrict__ a, const float* __restrict__ dg, float* __re
   constexpr int NPA = RP * (FA / 4) / G::THREADS, NPD = RP * (F / 4) / G::THREADS;   // float4 per thread: a, dg
   static_assert(RP * (FA / 4) % G::THREADS == 0 && RP * (F / 4) % G::THREADS == 0, "chunk must divide over the threads");
   float4 pa[NPA], pd[NPD];
-  // (issued in one burst after the chunk's barrier: spread over the taps' loops they cost 11 more registers, and 232 is the most
-  // that leaves room beside this kernel for a wavefront of the batch-norm backward passes, see train.hip)
+  // (issued in one burst after the chunk's barrier: spread over the taps' loops they cost 11 more registers, and the registers
+  // this kernel leaves free decide what can share the CU with it: 2 x 160 of k_conv16_layer + 192 of the 4-wavefront form = 512)
   auto prefetch = [&](int b0) {
     const int nbp = (b_end - b0) < NBC ? (b_end - b0) : NBC;
     const int nv = nbp > 0 ? nbp * P : 0;

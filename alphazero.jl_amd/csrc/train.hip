@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_tr_colsum(const float* __restrict__ x, 
 }
 // MODE 1 with four channels per thread (C % 4 == 0, 256 % (C/4) == 0): a block = C/4 channel quads x 256/(C/4) row lanes
 // over the same 64-row chunk, 16-byte loads; the row lanes are added in lane order through 8 KB of LDS (it has to fit
-// beside k_wgrad16's 150 KB).  Same partial layout as k_tr_colsum.
+// beside two workgroups of k_wgrad16, and the first form of that kernel left 10 KB).  Same partial layout as k_tr_colsum.
 __global__ void __launch_bounds__(256) k_tr_colsum1v(const float* __restrict__ x, const float* __restrict__ out_act, const float* __restrict__ g,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd, long long R, int C,
                                                      double* __restrict__ part /* [nchunks][2][C] */) {
