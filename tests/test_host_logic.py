@@ -1,3 +1,4 @@
+import os
 """Host-side mirror logic that needs no GPU: parameter mapping, sharding, trace / sample reconstruction
 from packed records (exercised on records produced by the oracle, which share the ABI layout)."""
 import ctypes as C
@@ -176,3 +177,34 @@ def test_tower_row_permutation_tables():
                 assert prod.value == expect[(game, which)]
             if game == 2:
                 assert prod.value <= 3 * ntiles                              # 14x1 board: the six taps with dy != 0 never apply
+
+
+def test_register_budget_of_the_kernels_that_share_a_cu():
+    """Two design points rest on kernels fitting on a CU TOGETHER (512 VGPRs per SIMD lane, allocated in blocks of 8): the
+    headline step (two k_tower16 workgroups + k_tree: 2 x 176 + 80) and the optimiser step's backward pass (k_conv16_layer at two
+    wavefronts per SIMD + one 4-wavefront k_wgrad16 workgroup: 2 x 160 + 192 = 512 to the register; two k_wgrad16 workgroups + a
+    wavefront of the batch-norm passes).  A compiler that spends eight registers more breaks neither parity nor a test on the GPU,
+    only the overlap: check the built code objects (skipped when csrc/*.o have not been built)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "alphazero.jl_amd", "csrc", "train.o")):
+        pytest.skip("csrc/*.o not built")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py")], capture_output=True, text=True).stdout
+    regs = {}
+    for line in out.splitlines():
+        m = re.match(r"(\S.*?)\s+vgpr\s+(\d+)\s+agpr\s+(\d+).*spill (\d+)", line)
+        if m:
+            regs[m.group(1)] = (-(-(int(m.group(2)) + int(m.group(3))) // 8) * 8, int(m.group(4)))
+    def alloc(prefix):
+        hit = [v for k, v in regs.items() if k.startswith(prefix)]
+        assert hit, prefix
+        assert all(sp == 0 for _, sp in hit), (prefix, hit)
+        return max(a for a, _ in hit)
+    assert 2 * alloc("k_tower16<ConnectFour, 64, false, 11>") + alloc("k_tree<ConnectFour>") <= 512
+    conv = max(alloc("k_conv16_layer<ConnectFour, 128, true"), alloc("k_conv16_layer<ConnectFour, 128, false"))
+    wg = alloc("k_wgrad16<ConnectFour, 128, 0, 2, 48>")
+    assert 2 * conv + wg <= 512, (conv, wg)
+    assert 2 * wg + alloc("k_tr_colsum1v") <= 512 and 2 * wg + 2 * alloc("k_tr_bn_bwd<4>") <= 512
+    assert conv + wg + alloc("k_wgrad_reduce") <= 512 + conv      # the reduction beside one convolution wavefront pair and the weight gradient
