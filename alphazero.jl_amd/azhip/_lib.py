@@ -10,6 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("AZHIP_LIB", os.path.join(CSRC, "libazhip.so"))   # override: A/B builds
 
+ABI_VERSION = 2              # include/azhip.h AZ_ABI_VERSION: struct layouts below are version 2's
+REPLACEMENT_GAME_BIT = 0x40000000
 AZ_OK, AZ_ERR_BAD_ARG, AZ_ERR_CAPACITY, AZ_ERR_HIP, AZ_ERR_STATE = 0, -1, -2, -3, -4
 GAME_CONNECT_FOUR, GAME_TICTACTOE, GAME_MANCALA = 0, 1, 2
 GAME_GO9_PLANES = 3          # network-only geometry (9, 9, 4), 82 actions: az_net_forward for host-stepped 9x9 Go
@@ -64,7 +66,8 @@ class SelfplayStats(C.Structure):
 
 
 class Prof(C.Structure):
-    _fields_ = [("launches", C.c_int64 * PROF_NUM), ("ms", C.c_double * PROF_NUM), ("units", C.c_int64 * PROF_NUM)]
+    _fields_ = [("launches", C.c_int64 * PROF_NUM), ("ms", C.c_double * PROF_NUM), ("units", C.c_int64 * PROF_NUM),
+                ("exec_units", C.c_double * PROF_NUM)]
 
 
 class Sample(C.Structure):
@@ -108,6 +111,7 @@ COMM_ID_BYTES = 128
 SYMBOLS = {
     "az_last_error": None,
     "az_abi_version": [],
+    "az_abi_struct_size": [_I32],
     "az_engine_cfg_init": [C.POINTER(EngineCfg)],
     "az_engine_create": [C.POINTER(EngineCfg), C.POINTER(_VP)],
     "az_engine_destroy": [_VP],
@@ -162,12 +166,17 @@ SYMBOLS = {
     "az_comm_unique_id": [_VP],
     "az_comm_init": [_I32, _I32, _I32, _VP, C.POINTER(_VP)],
     "az_comm_destroy": [_VP],
+    "az_comm_version": [C.POINTER(_I32), C.c_char_p, _I32],
     "az_engine_device_bytes": [_VP, C.POINTER(C.c_int64)],
     "az_engine_release_phase": [_VP],
     "az_comm_gather_push": [_VP, _VP, _VP, C.c_double, C.POINTER(GatherStats)],
     "az_comm_broadcast_params": [_VP, _VP, _I32],
 }
 
+# az_struct_id order of include/azhip.h
+STRUCTS = [("az_engine_cfg", EngineCfg), ("az_move_rec", MoveRec), ("az_game_rec", GameRec), ("az_trace_buf", TraceBuf),
+           ("az_selfplay_stats", SelfplayStats), ("az_sample", Sample), ("az_dataset_info", DatasetInfo),
+           ("az_learning_status_t", LearningStatusRec), ("az_train_cfg", TrainCfg), ("az_gather_stats", GatherStats), ("az_prof", Prof)]
 _lib = None
 
 
@@ -188,8 +197,12 @@ def lib():
             else:
                 f.restype = C.c_int
                 f.argtypes = args
-        if L.az_abi_version() != 1:
-            raise ImportError("libazhip.so ABI version mismatch")
+        if L.az_abi_version() != ABI_VERSION:
+            raise ImportError("libazhip.so ABI version %d, this mirror is written against %d (include/azhip.h AZ_ABI_VERSION)" % (L.az_abi_version(), ABI_VERSION))
+        # a stale mirror must fail here, not be written out of bounds by the library
+        for which, (name, st) in enumerate(STRUCTS):
+            if L.az_abi_struct_size(which) != C.sizeof(st):
+                raise ImportError("%s: the library's struct is %d bytes, this mirror's %d" % (name, L.az_abi_struct_size(which), C.sizeof(st)))
         _lib = L
     return _lib
 

@@ -16,6 +16,14 @@ def unique_id():
     return bytes(buf)
 
 
+def version():
+    """(ncclGetVersion code, path of the collective library az_comm_* bound)"""
+    v = C.c_int32()
+    buf = C.create_string_buffer(512)
+    L.check(L.lib().az_comm_version(C.byref(v), buf, 512))
+    return int(v.value), buf.value.decode("utf-8", "replace")
+
+
 class Comm:
     def __init__(self, device, rank, world, uid):
         assert len(uid) == L.COMM_ID_BYTES

@@ -90,7 +90,7 @@ class Engine:
     def prof_get(self):
         p = Prof()
         check(lib().az_prof_get(self._h, C.byref(p)))
-        return {name: {"launches": p.launches[i], "ms": p.ms[i], "units": p.units[i]}
+        return {name: {"launches": p.launches[i], "ms": p.ms[i], "units": p.units[i], "exec_units": p.exec_units[i]}
                 for i, name in enumerate(L.KERNEL_CLASSES)}
 
     # ---- game plugin ------------------------------------------------------------------------

@@ -116,6 +116,16 @@ def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_pl
     # `elapsed` is the time of simulate_distributed alone (training.jl:284-287: its fetch of the workers' results is inside,
     # push_trace! is not): the clock stops here, plus the gather where there is one
     elapsed = time.perf_counter() - t0
+    if stats.aborted_games:
+        # a slot ran out of tree nodes / move records (the reference's Dict has no bound, src/mcts.jl:124-151): the engine played
+        # replacement games, so the count is right unless a replacement overflowed too; long games are the ones that go, which
+        # biases the data -- tell the user, and refuse when it is more than a few
+        import warnings
+        msg = ("azhip: %d of %d self-play games were aborted (tree node pool / move record full) and replayed with replacement ids; "
+               "%d games came back.  Raise max_nodes_per_slot / max_moves_per_game." % (stats.aborted_games, sim.num_games, ng))
+        if stats.aborted_games * 20 > max(sim.num_games, 1) or ng < sim.num_games:
+            raise L.AzError(L.AZ_ERR_CAPACITY, msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
     memory.new_batch()
     depth = footprint = None
     if comm is not None:

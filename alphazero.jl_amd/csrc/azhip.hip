@@ -19,6 +19,22 @@ int fail(int code, const char* fmt, ...) {
 }
 extern "C" const char* az_last_error(void) { return g_err.c_str(); }
 extern "C" int az_abi_version(void) { return AZ_ABI_VERSION; }
+extern "C" int az_abi_struct_size(int32_t which) {
+  switch (which) {
+    case AZ_STRUCT_ENGINE_CFG: return (int)sizeof(az_engine_cfg);
+    case AZ_STRUCT_MOVE_REC: return (int)sizeof(az_move_rec);
+    case AZ_STRUCT_GAME_REC: return (int)sizeof(az_game_rec);
+    case AZ_STRUCT_TRACE_BUF: return (int)sizeof(az_trace_buf);
+    case AZ_STRUCT_SELFPLAY_STATS: return (int)sizeof(az_selfplay_stats);
+    case AZ_STRUCT_SAMPLE: return (int)sizeof(az_sample);
+    case AZ_STRUCT_DATASET_INFO: return (int)sizeof(az_dataset_info);
+    case AZ_STRUCT_LEARNING_STATUS: return (int)sizeof(az_learning_status_t);
+    case AZ_STRUCT_TRAIN_CFG: return (int)sizeof(az_train_cfg);
+    case AZ_STRUCT_GATHER_STATS: return (int)sizeof(az_gather_stats);
+    case AZ_STRUCT_PROF: return (int)sizeof(az_prof);
+  }
+  return -1;
+}
 
 int check_device_error(az_engine* e) {
   int code = 0;
@@ -187,6 +203,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   if (!e) return fail(AZ_ERR_HIP, "out of host memory");
   e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0; e->alloc_bytes = 0;
   e->vm_base = nullptr; e->vm_bytes = 0; e->vm_chunk = 0; e->vm_rows = 0; e->vm_chunk_nodes = 0; e->d_slot_cap = nullptr; e->vm_budget = 0; e->vm_mapped = 0;
+  e->next_exec = 1.0;
   e->net_loaded = false; e->running = false; e->prof_on = false; { const char* ug = getenv("AZHIP_GRAPH"); e->use_graphs = ug ? atoi(ug) : 0; }
   e->d_phase = nullptr; e->phase_cap = 0; e->phase_n = 0; e->host_moves = true; e->last_tower[0] = 0; e->prof_mask = 0; e->prof_used = 0;
   memset(&e->prof, 0, sizeof e->prof);
@@ -1025,7 +1042,6 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   }
   memset(&e->stats, 0, sizeof e->stats);
   e->aborted_ids.clear();
-  e->p.retire = 1;                                                  // an overflowing slot is retired, the phase goes on
   const int n0 = num_games < 0 ? G : std::min(G, (int)num_games);
   std::vector<int> slots(n0);
   std::vector<uint32_t> gids(n0);
@@ -1035,6 +1051,8 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   e->active_slots = n0;
   for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->group_active[g] = 0;
   for (int i = 0; i < n0; ++i) e->group_active[i / e->gv[0].G]++;
+  e->p.retire = 1;                                                  // an overflowing slot is retired, the phase goes on; set only once
+                                                                    // nothing can fail any more (the hooks must never see it: ADVICE r3)
   e->running = true;
   e->t_begin = std::chrono::steady_clock::now();
   return AZ_OK;
@@ -1065,9 +1083,18 @@ template <class Gm> static int move_round(az_engine* e) {
     HIPCHK(hipMemcpyAsync(gid.data(), e->v.game_id, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int sl : aslots) {
-      e->aborted_ids.push_back((int32_t)gid[sl]);
-      e->games_done++; e->stats.aborted_games++;
+      const int32_t id = (int32_t)gid[sl];
+      e->aborted_ids.push_back(id);
+      e->stats.aborted_games++;
       e->active_slots--; e->group_active[sl / e->gv[0].G]--;
+      if (!(id & AZ_REPLACEMENT_GAME_BIT)) {
+        // the phase still owes the caller this game: ONE replacement with its own RNG streams (id | bit 30) takes the slot, so
+        // that num_games games come back and every game_simulated() callback a host waits for arrives
+        aslots_refill.push_back(sl); agids.push_back((uint32_t)(id | AZ_REPLACEMENT_GAME_BIT));
+        e->active_slots++; e->group_active[sl / e->gv[0].G]++;
+        continue;
+      }
+      e->games_done++;                                               // the replacement overflowed too: given up, counted, reported
       if (e->total_games < 0 || e->next_game < e->total_games) {
         aslots_refill.push_back(sl); agids.push_back((uint32_t)(e->first_game_id + e->next_game++));
         e->active_slots++; e->group_active[sl / e->gv[0].G]++;

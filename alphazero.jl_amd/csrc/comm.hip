@@ -45,6 +45,8 @@ struct Lib {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;      // optional
+  std::string path;                                // what was loaded (az_comm_version)
 };
 static Lib g;
 static int load() {
@@ -72,6 +74,8 @@ static int load() {
   g.AllGather = (decltype(g.AllGather))dlsym(so, "ncclAllGather");
   g.Broadcast = (decltype(g.Broadcast))dlsym(so, "ncclBroadcast");
   g.GetErrorString = (decltype(g.GetErrorString))dlsym(so, "ncclGetErrorString");
+  g.GetVersion = (decltype(g.GetVersion))dlsym(so, "ncclGetVersion");
+  if (Dl_info li; g.GetUniqueId && dladdr(reinterpret_cast<void*>(g.GetUniqueId), &li) && li.dli_fname) g.path = li.dli_fname;
   if (!g.GetUniqueId || !g.CommInitRank || !g.CommDestroy || !g.AllGather || !g.Broadcast || !g.GetErrorString)
     return fail(AZ_ERR_COMM, "librccl.so lacks the expected symbols");
   g.so = so;
@@ -89,6 +93,9 @@ struct az_comm {
   ncclComm_t comm;
   int rank, world, device;
   hipStream_t stream;
+  // status / count words of the failure agreement, allocated ONCE at az_comm_init: a collective call must not be able to fail
+  // locally (an allocation) before it has entered the first all-gather, or the other ranks would wait in it for ever
+  long long *d_word_send, *d_word_all;             // [3], [3 * world]
 };
 static_assert(sizeof(ncclUniqueId) == AZ_COMM_ID_BYTES, "ncclUniqueId size");
 
@@ -101,12 +108,23 @@ extern "C" int az_comm_unique_id(uint8_t* id) {
   return AZ_OK;
 }
 
+extern "C" int az_comm_version(int32_t* version, char* path, int32_t cap) {
+  AZCHK(rc::load());
+  int v = 0;
+  if (rc::g.GetVersion && rc::g.GetVersion(&v) != ncclSuccess) v = 0;
+  if (version) *version = v;
+  if (path && cap > 0) { strncpy(path, rc::g.path.c_str(), (size_t)cap - 1); path[cap - 1] = 0; }
+  return AZ_OK;
+}
+
 extern "C" int az_comm_destroy(az_comm* c) {
   if (!c) return AZ_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)rc::g.CommDestroy(c->comm);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->d_word_send) (void)hipFree(c->d_word_send);
+  if (c->d_word_all) (void)hipFree(c->d_word_all);
   delete c;
   return AZ_OK;
 }
@@ -123,8 +141,11 @@ extern "C" int az_comm_init(int32_t device, int32_t rank, int32_t world, const u
   az_comm* c = new (std::nothrow) az_comm();
   if (!c) return fail(AZ_ERR_HIP, "out of host memory");
   c->comm = nullptr; c->rank = rank; c->world = world; c->device = device; c->stream = nullptr;
+  c->d_word_send = c->d_word_all = nullptr;
   int st = [&]() -> int {
     HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipMalloc((void**)&c->d_word_send, 3 * sizeof(long long)));
+    HIPCHK(hipMalloc((void**)&c->d_word_all, (size_t)3 * world * sizeof(long long)));
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     RCCLCHK(rc::g.CommInitRank(&c->comm, world, u, rank));
@@ -167,7 +188,7 @@ static void abort_comm(az_comm* c) {
 extern "C" int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, double gamma, az_gather_stats* stats) {
   if (!c) return fail(AZ_ERR_BAD_ARG, "NULL communicator");
   COMM_ALIVE(c);
-  HIPCHK(hipSetDevice(c->device));
+  if (hipSetDevice(c->device) != hipSuccess) { abort_comm(c); return fail(AZ_ERR_HIP, "hipSetDevice(%d) failed; communicator aborted", c->device); }
   // local validation first; its verdict travels with the counts, so that every rank returns together (never one rank
   // leaving while the others sit in ncclAllGather)
   int local = AZ_OK;
@@ -200,8 +221,7 @@ extern "C" int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, doubl
   int st = [&]() -> int {
     // 1. counts and status of every rank
     long long hc[3] = {(long long)ng, nm, (long long)local};
-    long long *d_cnt_send, *d_cnt_all;
-    AZCHK(mem_alloc(&tmp, &d_cnt_send, 3)); AZCHK(mem_alloc(&tmp, &d_cnt_all, (size_t)3 * W));
+    long long *d_cnt_send = c->d_word_send, *d_cnt_all = c->d_word_all;   // allocated at az_comm_init: nothing can fail before the all-gather
     in_collective = true;
     HIPCHK(hipMemcpyAsync(d_cnt_send, hc, sizeof hc, hipMemcpyHostToDevice, c->stream));
     RCCLCHK(rc::g.AllGather(d_cnt_send, d_cnt_all, 3, ncclInt64, c->comm, c->stream));
@@ -305,7 +325,7 @@ extern "C" int az_comm_broadcast_params(az_comm* c, az_engine* e, int32_t root) 
   if (!c) return fail(AZ_ERR_BAD_ARG, "NULL communicator");
   COMM_ALIVE(c);
   if (root < 0 || root >= c->world) return fail(AZ_ERR_BAD_ARG, "root %d of %d", root, c->world);   // the same argument on every rank
-  HIPCHK(hipSetDevice(c->device));
+  if (hipSetDevice(c->device) != hipSuccess) { abort_comm(c); return fail(AZ_ERR_HIP, "hipSetDevice(%d) failed; communicator aborted", c->device); }
   int local = AZ_OK;
   int64_t n = 0;
   if (!e) local = fail(AZ_ERR_BAD_ARG, "NULL engine");
@@ -318,8 +338,7 @@ extern "C" int az_comm_broadcast_params(az_comm* c, az_engine* e, int32_t root) 
   std::vector<float> h;
   bool in_collective = false;
   int st = [&]() -> int {
-    long long *d_s, *d_all;
-    AZCHK(mem_alloc(&tmp, &d_s, 1)); AZCHK(mem_alloc(&tmp, &d_all, (size_t)c->world));
+    long long *d_s = c->d_word_send, *d_all = c->d_word_all;
     float* d = nullptr;
     if (local == AZ_OK) { local = mem_alloc(&tmp, &d, (size_t)n); if (local != AZ_OK) local_msg = az_last_error(); }
     int bad = -1;

@@ -132,6 +132,7 @@ struct az_engine {
   std::vector<ProfRec> prof_pool;
   size_t prof_used;
   az_prof prof;
+  double next_exec;              // executed-product fraction of the NEXT profiled launch (set by the tower launches, consumed by prof_begin)
   std::vector<int> h_finished;
   std::vector<az_game_rec> h_grec;
 };
@@ -178,6 +179,8 @@ inline int prof_begin(az_engine* e, hipStream_t st, int cls, int64_t units) {
   r.cls = cls;
   e->prof.launches[cls] += 1;
   e->prof.units[cls] += units;
+  e->prof.exec_units[cls] += (double)units * e->next_exec;          // the tower launches set next_exec (tower_exec_frac); everything else counts in full
+  e->next_exec = 1.0;
   HIPCHK(hipEventRecord(r.a, st));
   return AZ_OK;
 }

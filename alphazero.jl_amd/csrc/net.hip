@@ -44,9 +44,9 @@ int net_wave(az_engine* e, int g, bool split, int nmax) {
 }
 
 // debug aid (not part of the ABI in azhip.h): the row permutation of a tower kernel (which = 0: 11 tiles, 1: 3 tiles,
-// 2: 21 tiles): out = pos [rows] then nbr [9][rows] (Geo16, resnet16.h), *products = (tile, tap) products per convolution
+// 2: 21 tiles, 3: the 22 tiles of the bf16 8-board form): out = pos [rows] then nbr [9][rows] (Geo16, resnet16.h), *products = (tile, tap) products per convolution
 extern "C" int az_debug_tower_geometry(int32_t game, int32_t which, uint16_t* out, int64_t cap, int32_t* rows, int32_t* products) {
-  if (!out || !rows || !products || which < 0 || which > 2) return fail(AZ_ERR_BAD_ARG, "bad argument");
+  if (!out || !rows || !products || which < 0 || which > 3) return fail(AZ_ERR_BAD_ARG, "bad argument");
   switch (game) {
     case AZ_GAME_CONNECT_FOUR: return net_geometry_c4(which, out, cap, rows, products);
     case AZ_GAME_TICTACTOE: return net_geometry_ttt(which, out, cap, rows, products);

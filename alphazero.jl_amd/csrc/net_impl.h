@@ -128,6 +128,20 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
   }
   return c16 <= c32 ? 16 : 32;
 }
+// Fraction of a 3x3 convolution's (row tile, tap) products the tower kernel `tw` executes (Geo16 skips the products whose tap
+// falls off the board for a whole tile); k_tower (32x32x2) computes every tap.  az_prof.exec_units weighs a launch's boards
+// with it, so that a roofline can count the work DONE instead of the dense convolution's.
+template <class Gm, int F> static double tower_exec_frac(const az_engine* e, int tw) {
+  if (e->cfg.net_bf16) {
+    if constexpr (F == 128) { if (tw == 22) return T16B<Gm, F, 22>::Geo::tab.cost / (9.0 * 22); }
+    if (tw == 3) return T16B<Gm, F, NTS<Gm>>::Geo::tab.cost / (9.0 * NTS<Gm>);
+    return T16B<Gm, F>::Geo::tab.cost / (9.0 * 11);
+  }
+  if (tw == 2 || tw == 3) return T16<Gm, F, NTS<Gm>>::Geo::tab.cost / (9.0 * NTS<Gm>);
+  if (tw == 16) return T16<Gm, F>::Geo::tab.cost / (9.0 * T16<Gm, F>::NTILE);
+  if (tw == 21) return T16P<Gm, 64>::Geo::tab.cost / (9.0 * T16P<Gm, 64>::NTW);
+  return 1.0;
+}
 // publish areas of k_tower16s for the launches that write `hfeat` (one feature buffer = one stream at a time)
 template <class Gm> static int xch_slot(az_engine* e, const float* hfeat, unsigned long long** xch, unsigned long long* epoch) {
   using T = T16S<Gm, 128>;
@@ -185,6 +199,7 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
   constexpr int TB21 = T16P<Gm, 64>::TB, THR21 = T16P<Gm, 64>::THREADS, LDS21 = T16P<Gm, 64>::BYTES;
   const int tw = pick_tower<Gm, F>(e, n_max);
   note_tower(e, tw, F);
+  e->next_exec = tower_exec_frac<Gm, F>(e, tw);
   if (e->cfg.net_bf16) {
     constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, NTS<Gm>>::TB, LDSb3 = T16B<Gm, F, NTS<Gm>>::BYTES;
     if (tw == 22) {
@@ -234,6 +249,7 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   const int* nev = v.n_eval + e->wave_par[g];                      // the leaf counter of this wave (k_tree)
   const int tw = pick_tower<Gm, F>(e, N);
   note_tower(e, tw, F);
+  e->next_exec = tower_exec_frac<Gm, F>(e, tw);
   if (e->cfg.net_bf16) {
     constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, NTS<Gm>>::TB, LDSb3 = T16B<Gm, F, NTS<Gm>>::BYTES;
     if (tw == 22) {
@@ -278,5 +294,6 @@ template <class Gm> static int wave_net(az_engine* e, int g, bool split, int nma
   int net_geometry_##sfx(int which, uint16_t* out, int64_t cap, int* rows, int* products) {                                  \
     return which == 0 ? geometry_out<typename T16<Gm, 64, 11>::Geo>(out, cap, rows, products)                                \
          : which == 1 ? geometry_out<typename T16<Gm, 64, NTS<Gm>>::Geo>(out, cap, rows, products)                                 \
-                      : geometry_out<typename T16P<Gm, 64>::Geo>(out, cap, rows, products);                                  \
+         : which == 2 ? geometry_out<typename T16P<Gm, 64>::Geo>(out, cap, rows, products)                                   \
+                      : geometry_out<typename T16B<Gm, 128, 22>::Geo>(out, cap, rows, products);                             \
   }

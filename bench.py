@@ -7,9 +7,11 @@ run_simulation! each, src/mcts.jl:199-226), plus the move step of play_game (src
 every 400th wave and slot refill when games end.  Workload = BASELINE.json configs[1]:
 Connect-Four, 400 sims/move, 4096 parallel games, ResNet 5x64 fp32, synthetic weights.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): games shard embarrassingly -- every rank
-runs its own 4096 slots with global game ids offset by rank, no collective in the timed region
-(weak scaling); value = simulations of all ranks / max-over-ranks time.
+N > 1 (one rank per GPU): games shard embarrassingly -- every rank runs its own 4096 slots with global
+game ids offset by rank, no collective in the timed region (weak scaling); value = simulations of all
+ranks / max-over-ranks time.  Launched either by torch.distributed.run (RANK / WORLD_SIZE in the
+environment) or as plain `python bench.py --gpus N`: with WORLD_SIZE unset the script re-executes
+itself under torch.distributed.run with N ranks (self_launch), so `--gpus N` always means N ranks.
 """
 import argparse
 import json
@@ -29,26 +31,14 @@ HEADS_FLOP = 2 * (1344 * 7 + 1344 * 64 + 64)
 assert TOWER_FLOP + HEADS_FLOP == 31645952
 PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 # The tower kernels skip the (16-row tile, tap) products whose tap falls off the board for the whole tile (Geo16,
-# csrc/resnet16.h): of the 9 x tiles products of a 3x3 convolution they execute 85 of 99 (k_tower16, 4 boards per workgroup),
-# 159 of 189 (k_tower16x2, 8 boards), 26 of 27 (one board per workgroup); k_tower (32x32x2) executes all of them.  The
-# ALGORITHMIC work (every tap of every position, what a dense convolution does) stays the numerator of
-# roofline.achieved; mfma_executed_frac says how busy the matrix pipes really were.
-EXECUTED_TAPS = {"k_tower16x2": 159.0 / 189.0, "NT=11": 85.0 / 99.0, "NT=3": 26.0 / 27.0}
-
-
-def executed_flop(kernel):
-    r = next((v for k, v in EXECUTED_TAPS.items() if k in kernel), 1.0)
-    return 2 * 42 * 64 * (27 + 10 * 576 * r + 64)
+# csrc/resnet16.h).  roofline.achieved / frac count the work DONE: the dense FLOPs of the real board rows x the fraction of the
+# convolutions' products the kernels that ran executed (az_prof.exec_units / units, reported by the library per launch), so no
+# fraction can exceed 1.  The dense convolution's count (every tap of every position) is kept beside it as
+# dense_achieved / dense_frac -- a speed-up over a dense kernel, not a fraction of the machine.
 
 
 PEAK_HBM_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_BF16_MFMA_TFLOPS = 2500.0                       # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (no sparsity)
-# What the matrix pipes SUSTAIN for the length of a tower launch (tools/probes/mfma_sustained.hip, profiles/r3/mfma_sustained.txt:
-# 256 CUs x 4 SIMDs x 2 waves of independent MFMAs for ~1.5 ms): the chip holds 2.19 GHz under fp32 MFMA load and ~2.0 GHz under
-# bf16 MFMA load, not the 2.4 GHz the nominal peaks assume.  `frac` stays against the nominal peak (the guide's number); the
-# *_of_sustained fields say how much of what the silicon can actually do the kernel gets.
-SUSTAINED_FP32_MFMA_TFLOPS = 142.6
-SUSTAINED_BF16_MFMA_TFLOPS = 2046.4
 # Little's law for the search-tree kernel: a slot's simulation is a CHAIN of dependent 128-byte node-line loads (one line in
 # flight per slot); a dependent load that misses L2 takes ~840 shader cycles (tools/probes/chase_latency.hip)
 # ~ 400 ns at the sustained clock.  G slots therefore cannot move more than G x 128 B per 400 ns, whatever the kernel does.
@@ -63,22 +53,32 @@ def tower_flop(game, hp):
     return 2 * P * F * (9 * Cin + 2 * hp.num_blocks * 9 * F + hp.num_policy_head_filters + hp.num_value_head_filters)
 
 
-def executed_fraction(game, kernel):
-    """fraction of a 3x3 convolution's (row tile, tap) products the named tower kernel really executes (Geo16 skips the ones
-    that fall off the board for a whole tile; az_debug_tower_geometry reports the geometry's product count)"""
-    import ctypes as C
-    from azhip._lib import lib
-    if kernel.startswith("k_tower<"):
-        return 1.0
-    which = 2 if "k_tower16x2" in kernel else (0 if "NT=11" in kernel else 1)
-    f = lib().az_debug_tower_geometry
-    f.restype = C.c_int
-    f.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-    buf = (C.c_uint16 * 8192)()
-    rows, prods = C.c_int32(), C.c_int32()
-    if f(game, which, buf, 8192, C.byref(rows), C.byref(prods)) != 0:
-        return 1.0
-    return prods.value / (9.0 * (rows.value // 16))
+def tower_roofline(game, hp, bf16, kernel, tw, evals, wall_s):
+    """roofline object of the tower launches `tw` (az_prof class "tower") that evaluated `evals` boards within wall_s seconds.
+    achieved = EXECUTED FLOPs / exclusive kernel time: per board the dense FLOPs of stem + head 1x1 convolutions and of the 3x3
+    tower convolutions x the executed-product fraction of the kernels that ran; time = sum of the HIP-event durations of the
+    launches, clipped to the wall time (towers of several slot groups overlap)."""
+    _, P, Cin = GAME_DIMS[game]
+    F = hp.num_filters
+    conv, other = 2 * hp.num_blocks * 9 * F, 9 * Cin + hp.num_policy_head_filters + hp.num_value_head_filters
+    dense = 2 * P * F * (conv + other)
+    ex = tw["exec_units"] / tw["units"] if tw["units"] else 1.0
+    executed = 2 * P * F * (conv * ex + other)
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    wall_ms = 1e3 * wall_s
+    excl_ms = min(tw["ms"], wall_ms)
+    achieved = evals * executed / (excl_ms * 1e-3) / 1e12 if excl_ms > 0 else 0.0
+    boards = evals / max(tw["launches"], 1)
+    out = {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+           "flop_per_board": executed, "executed_product_frac": ex,
+           "dense_flop_per_board": dense, "dense_achieved": achieved * dense / executed, "dense_frac": achieved * dense / executed / peak,
+           "dense_note": "dense_* = the same time priced with the dense convolution's FLOPs (zero padding included): a speed-up over a dense kernel, can exceed 1, NOT a machine fraction",
+           "launches": tw["launches"], "avg_boards_per_launch": boards, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
+           "launch_ms_sum": tw["ms"], "wall_ms": wall_ms, "exclusive_ms": excl_ms, "traffic": None}
+    t = pmc_lookup(kernel, "bf16" if bf16 else "f32")
+    if t is not None:
+        out["traffic"] = t[0] * boards / t[1]
+    return out
 
 
 def pmc_lookup(kernel, config="f32"):
@@ -129,29 +129,12 @@ def steady_block(azhip, dev_index, label, game, slots, groups, sims, hp, waves, 
 def block_report(label, game, hp, bf16, kernel, prof, s0, s1, dt, waves, slots, groups, sims, note, dev_bytes):
     sims_n, evals, trav, moves = (s1.simulations - s0.simulations, s1.leaf_evals - s0.leaf_evals,
                                   s1.nodes_traversed - s0.nodes_traversed, s1.moves - s0.moves)
-    tw = prof["tower"]
-    flop = tower_flop(game, hp)
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    excl_ms = min(tw["ms"], 1e3 * dt)                    # towers of several slot groups overlap: clipped to the wall time
-    achieved = evals * flop / (excl_ms * 1e-3) / 1e12 if excl_ms > 0 else 0.0
-    ex = executed_fraction(game, kernel)
-    conv = 2 * hp.num_blocks * 9 * hp.num_filters
-    ex_flop = flop * (conv * ex + 9 * GAME_DIMS[game][2] + hp.num_policy_head_filters + hp.num_value_head_filters) / \
-        (conv + 9 * GAME_DIMS[game][2] + hp.num_policy_head_filters + hp.num_value_head_filters)
     out = {"workload": "%s self-play, %d sims/move, %d parallel games, ResNet %dx%d %s, %d slot group(s)%s"
                        % (GAME_DIMS[game][0], sims, slots, hp.num_blocks, hp.num_filters, "bf16 tower (opt-in, NOT the reference's fp32 precision)" if bf16 else "fp32", groups, "; " + note if note else ""),
            "value": sims_n / dt, "unit": "sims/s", "steps": waves, "ms_per_step": 1e3 * dt / max(waves, 1), "dtype": "bf16" if bf16 else "f32",
            "samples_per_sec": moves / dt, "avg_exploration_depth": trav / max(sims_n, 1), "leaf_evals_per_sim": evals / max(sims_n, 1),
            "engine_device_GB": dev_bytes / 2.0**30,
-           "roofline": {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                        "mfma_executed_frac": achieved / peak * ex_flop / flop, "executed_product_frac": ex, "flop_per_board": flop,
-                        "sustained_peak": SUSTAINED_BF16_MFMA_TFLOPS if bf16 else SUSTAINED_FP32_MFMA_TFLOPS,
-                        "mfma_executed_frac_of_sustained": achieved * ex_flop / flop / (SUSTAINED_BF16_MFMA_TFLOPS if bf16 else SUSTAINED_FP32_MFMA_TFLOPS),
-                        "launches": tw["launches"], "avg_boards_per_launch": evals / max(tw["launches"], 1),
-                        "avg_launch_ms": tw["ms"] / max(tw["launches"], 1), "exclusive_ms": excl_ms, "traffic": None}}
-    t = pmc_lookup(kernel, "bf16" if bf16 else "f32")
-    if t is not None:
-        out["roofline"]["traffic"] = t[0] * out["roofline"]["avg_boards_per_launch"] / t[1]
+           "roofline": tower_roofline(game, hp, bf16, kernel, prof["tower"], evals, dt)}
     return out
 
 
@@ -171,9 +154,10 @@ def host_stepped_c5(seconds=6.0):
     return json.loads(line)
 
 
-def whole_phase(azhip, dev_index, blob, hp, slots, sims, groups):
-    """SURVEY.md §8(d)'s metric over a WHOLE self-play phase: `slots` Connect-Four games from the empty board to completion
-    (az_selfplay_run, device-only) -- first moves from empty trees, every move step, refills, trace write-out into the phase
+def whole_phase(azhip, dev_index, blob, hp, slots, sims, groups, games_per_slot=4):
+    """SURVEY.md §8(d)'s metric over a WHOLE self-play phase: 4 x `slots` Connect-Four games from the empty board to completion
+    (az_selfplay_run, device-only; the reference plays 5000 games on 128 workers, games/connect-four/params.jl:15-25, so a slot
+    sees many games per phase) -- first moves from empty trees, every move step, refills, trace write-out into the phase
     buffer and the drain at the end while the batch empties -- against the steady-state headline."""
     eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=dev_index, num_workers=slots, batch_size=slots // groups,
                        num_iters_per_turn=sims, gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
@@ -187,7 +171,7 @@ def whole_phase(azhip, dev_index, blob, hp, slots, sims, groups):
         eng.prof_reset()
         eng.prof_enable(True, classes=("tower",))
         t0 = time.perf_counter()
-        games, _, ng, _, st = eng.selfplay_run(slots, first_game_id=1 << 26, device_only=True)
+        games, _, ng, _, st = eng.selfplay_run(games_per_slot * slots, first_game_id=1 << 26, device_only=True)
         dt = time.perf_counter() - t0
         prof = eng.prof_get()
         kernel = eng.net_last_kernel()
@@ -195,7 +179,7 @@ def whole_phase(azhip, dev_index, blob, hp, slots, sims, groups):
     finally:
         eng.close()
     out = block_report("whole_phase", azhip.GAME_CONNECT_FOUR, hp, False, kernel, prof, s0, st, dt, int(st.waves - s0.waves), slots, groups, sims,
-                       "%d games played from the empty board to the end, drain included" % ng, dev_bytes)
+                       "%d games (%d per slot) played from the empty board to the end, drain included" % (ng, games_per_slot), dev_bytes)
     out["games"] = int(ng)
     out["positions"] = int(st.moves - s0.moves)
     out["seconds"] = dt
@@ -262,7 +246,7 @@ def cpu_baseline(blob, hp, nsims, seconds=8.0):
 TOWER_CODE = {"k_tower16x2": "21", "k_tower16<": "16", "k_tower<": "32"}
 
 
-def alone_and_tree(args, blob, dev_index, kernel, waves=200):
+def alone_and_tree(args, blob, hp, dev_index, kernel, waves=200):
     """Extra evidence, measured live after the timed region (not part of `value`): the same workload with ONE slot group, so
     nothing is co-scheduled with a launch and HIP-event durations are exclusive.  (i) the kernel of the timed region, alone
     (forced with AZHIP_TOWER so that it is the SAME kernel, not the one a single group would pick); (ii) the search-tree
@@ -298,15 +282,8 @@ def alone_and_tree(args, blob, dev_index, kernel, waves=200):
     eng.selfplay_end()
     eng.close()
     evals, sims, trav = s1.leaf_evals - s0.leaf_evals, s1.simulations - s0.simulations, s1.nodes_traversed - s0.nodes_traversed
-    tw = prof["tower"]
-    flop = TOWER_FLOP
-    achieved = evals * flop / (tw["ms"] * 1e-3) / 1e12 if tw["ms"] > 0 else 0.0
-    alone = {"kernel": name, "slot_groups": 1, "waves": waves, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-             "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),
-             "avg_boards_per_launch": evals / max(tw["launches"], 1),
-             "mfma_executed_frac": achieved / PEAK_FP32_MFMA_TFLOPS * executed_flop(name) / flop,
-             "sustained_peak": SUSTAINED_FP32_MFMA_TFLOPS,
-             "mfma_executed_frac_of_sustained": achieved / SUSTAINED_FP32_MFMA_TFLOPS * executed_flop(name) / flop}
+    alone = tower_roofline(azhip.GAME_CONNECT_FOUR, hp, False, name, prof["tower"], evals, 1e9)
+    alone.update(slot_groups=1, waves=waves)
     tree_cls = [c for c in ("select", "compact", "expand") if prof[c]["launches"]]
     tree_ms = sum(prof[c]["ms"] for c in tree_cls)
     tree_bytes = 148.0 * trav + (16 + 136 + 64) * evals + 16.0 * (sims - evals)
@@ -346,7 +323,9 @@ def gather_leg(azhip, blob, dev_index, rank, world, games_per_rank=512, nsims=48
     t0 = time.perf_counter()
     gs = c.gather_push(eng, mem, 1.0)
     dt = time.perf_counter() - t0
+    ver, path = comm.version()
     out = {"collective": "ncclAllGather (RCCL) of device-resident az_move_rec / az_game_rec + push_trace! on the device",
+           "library": path, "nccl_version_code": ver,
            "ranks": int(gs.ranks), "world": world, "rendezvous": "torch.distributed/%s" % __import__("torch").distributed.get_backend(), "games": gs.games, "samples": gs.moves, "bytes_received_per_rank": gs.bytes,
            "gather_ms": gs.gather_ms, "gather_and_push_ms": gs.total_ms, "wall_ms": 1e3 * dt, "memory_length": len(mem),
            "GB_per_s_per_rank": gs.bytes / max(gs.gather_ms, 1e-9) / 1e6}
@@ -354,6 +333,29 @@ def gather_leg(azhip, blob, dev_index, rank, world, games_per_rank=512, nsims=48
     eng.close()
     c.close()
     return out
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same flags>` (one rank per GPU; simulate_distributed's one process per
+    worker, src/simulations.jl:252-290).  Refuses loudly when the node has fewer than N devices -- unless the test-only
+    transport is selected (AZHIP_RCCL_LIB, tests/rccl_stub: RCCL itself refuses two ranks on one device), in which case the
+    ranks share the devices there are.  Rank 0's JSON line is the child's stdout, passed through unchanged."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (libazhip.so has no CPU fallback)")
+    if n > ndev and not os.environ.get("AZHIP_RCCL_LIB"):
+        raise SystemExit("bench.py --gpus %d: only %d device(s) visible; one rank per GPU (RCCL refuses several ranks on a device)" % (n, ndev))
+    with socket.socket() as so:                                      # a free rendezvous port on the loopback
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), AZ_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -370,6 +372,12 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="do not wrap launches in HIP events")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel class (default: only the dominant kernel, k_tower)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)                                       # does not return
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%s: the two must agree" % (args.gpus, os.environ["WORLD_SIZE"]))
 
     import torch
     import azhip
@@ -381,6 +389,8 @@ def main():
     dist = None
     ndev = max(torch.cuda.device_count(), 1)
     dev_index = local_rank % ndev
+    if world > ndev and not os.environ.get("AZHIP_RCCL_LIB"):
+        raise SystemExit("bench.py: %d ranks but %d device(s) visible; one rank per GPU (RCCL refuses several ranks on a device)" % (world, ndev))
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
@@ -440,7 +450,11 @@ def main():
     moves = s1.moves - s0.moves
     local_evals = evals
     local_elapsed = elapsed
+    per_rank = [sims / elapsed]
     if dist is not None:
+        pr = [torch.zeros(2, dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(pr, torch.tensor([sims, elapsed], dtype=torch.float64, device=red_dev))
+        per_rank = [float(x[0] / x[1]) for x in pr]
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -482,42 +496,25 @@ def main():
                        "slots_per_gpu": args.slots, "sims_per_move": args.sims, "slot_groups": args.groups, "leaves_per_network_launch": args.slots // args.groups, "parallelism": "dp%d (games sharded, no collective in the timed region)" % world,
                        "device": dev_name, "compute_units": ncu},
             "sims_per_sec_per_gpu": sims / elapsed / world,
+            "sims_per_sec_by_rank": per_rank,                         # each rank's own simulations / its own time
+            "launcher": "self (python bench.py --gpus N -> torch.distributed.run)" if os.environ.get("AZ_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if dist is not None and world > 1 else "single process"),
             "samples_per_sec": moves / elapsed,
             "avg_exploration_depth": trav / max(sims, 1),
             "leaf_evals_per_sim": evals / max(sims, 1),
         }
         if prof is not None:
-            tw = prof["tower"]
-            kernel = eng_kernel
-            flop = TOWER_FLOP
-            flops = local_evals * flop
-            # exclusive kernel time: with several slot groups the towers of different groups overlap, so the sum of their
-            # HIP-event durations can exceed the wall time of the region; it is clipped to it (kernel time per step <= ms_per_step)
-            wall_ms = 1e3 * local_elapsed
-            excl_ms = min(tw["ms"], wall_ms)
-            achieved = flops / (excl_ms * 1e-3) / 1e12 if excl_ms > 0 else 0.0
-            boards = local_evals / max(tw["launches"], 1)
-            out["roofline"] = {
-                "kernel": kernel, "bound": "mfma", "achieved": achieved,
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": (lambda t: t[0] * boards / t[1] if t is not None else pmc_traffic(kernel, boards))(pmc_lookup(kernel)),
-                "flop_per_board": flop, "launches": tw["launches"], "avg_boards_per_launch": boards,
-                "avg_launch_ms": tw["ms"] / max(tw["launches"], 1),          # raw HIP-event average (includes co-scheduled time)
-                "launch_ms_sum": tw["ms"], "wall_ms": wall_ms, "exclusive_ms": excl_ms,
-                "kernel_ms_per_step": excl_ms / args.steps,
-                # products with the zero padding are skipped: fraction of the fp32 MFMA peak the executed products amount to
-                "mfma_executed_frac": achieved / PEAK_FP32_MFMA_TFLOPS * executed_flop(kernel) / flop,
-                "executed_flop_per_board": executed_flop(kernel),
-                "sustained_peak": SUSTAINED_FP32_MFMA_TFLOPS,
-                "frac_of_sustained_peak": achieved / SUSTAINED_FP32_MFMA_TFLOPS,
-                "mfma_executed_frac_of_sustained": achieved / SUSTAINED_FP32_MFMA_TFLOPS * executed_flop(kernel) / flop,
-            }
+            out["roofline"] = tower_roofline(azhip.GAME_CONNECT_FOUR, hp, False, eng_kernel, prof["tower"], local_evals, local_elapsed)
+            out["roofline"]["kernel_ms_per_step"] = out["roofline"]["exclusive_ms"] / args.steps
+            if out["roofline"]["traffic"] is None:
+                out["roofline"]["traffic"] = pmc_traffic(eng_kernel, out["roofline"]["avg_boards_per_launch"])
             out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
         if prof is not None and world == 1:
-            alone, tree = alone_and_tree(args, blob, dev_index, eng_kernel)
+            alone, tree = alone_and_tree(args, blob, hp, dev_index, eng_kernel)
             out["roofline_kernel_alone"] = alone
             out["roofline_tree"] = tree
         if gather is not None:
+            if world > 1 and "error" not in gather and gather.get("ranks") != world:
+                gather["error"] = "the exchange saw %s ranks, the job has %d" % (gather.get("ranks"), world)
             out["gather"] = gather
         if world == 1 and not args.no_extras:
             # The rest of DESIGN.md §0's table, measured here so that the driver's line carries it (bounded: ~40 s in all).

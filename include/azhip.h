@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define AZ_ABI_VERSION 1
+#define AZ_ABI_VERSION 2   /* 2 (round 4): az_selfplay_stats.aborted_games, az_gather_stats' report fields, az_prof.exec_units, az_comm_version */
 
 typedef enum {
   AZ_OK = 0,
@@ -132,6 +132,15 @@ typedef struct az_engine az_engine;
 
 const char* az_last_error(void);
 int az_abi_version(void);
+/* sizeof() of a struct of this header as the LIBRARY was compiled (which = az_struct_id), -1 for an unknown id: a host mirror
+ * (ctypes, Julia isbits structs) asserts its own sizes against these, so that a stale mirror fails at load time instead of
+ * being written out of bounds. */
+typedef enum {
+  AZ_STRUCT_ENGINE_CFG = 0, AZ_STRUCT_MOVE_REC = 1, AZ_STRUCT_GAME_REC = 2, AZ_STRUCT_TRACE_BUF = 3, AZ_STRUCT_SELFPLAY_STATS = 4,
+  AZ_STRUCT_SAMPLE = 5, AZ_STRUCT_DATASET_INFO = 6, AZ_STRUCT_LEARNING_STATUS = 7, AZ_STRUCT_TRAIN_CFG = 8, AZ_STRUCT_GATHER_STATS = 9,
+  AZ_STRUCT_PROF = 10
+} az_struct_id;
+int az_abi_struct_size(int32_t which);
 
 /* Defaults = games/connect-four/params.jl:5-30 with the 64-filter trunk. */
 int az_engine_cfg_init(az_engine_cfg* cfg);
@@ -221,9 +230,14 @@ typedef struct {
   double seconds;
   int64_t aborted_games;            /* games whose slot ran out of tree nodes (max_nodes_per_slot / device memory) or of move
                                      * records (max_moves_per_game): the slot is retired, the game dropped and counted here
-                                     * (ids: az_selfplay_aborted), the phase goes on.  The reference's Dict has no such limit
-                                     * (src/mcts.jl:124-151); with the default pool sizes this stays 0. */
+                                     * (ids: az_selfplay_aborted), the phase goes on.  A bounded phase still returns num_games
+                                     * games: the slot plays ONE replacement game with id = aborted id | AZ_REPLACEMENT_GAME_BIT
+                                     * (its own RNG streams); if that overflows as well the game is given up (both ids reported,
+                                     * the phase returns one game fewer).  The reference's Dict has no such limit
+                                     * (src/mcts.jl:124-151); with the default pool sizes this stays 0.  Hosts should warn when
+                                     * it is not (azhip/training.py, julia/AlphaZeroHIP.jl do). */
 } az_selfplay_stats;
+#define AZ_REPLACEMENT_GAME_BIT 0x40000000   /* game ids handed to az_selfplay_* must stay below it */
 typedef void (*az_progress_cb)(void* user);   /* game_simulated(), once per finished game */
 
 /* simulate(simulator, gspec, SimParams(num_games=…)): plays num_games games with global ids
@@ -366,6 +380,10 @@ typedef struct {
 } az_gather_stats;
 /* ncclGetUniqueId on ONE rank; the 128 bytes go to the other ranks by the host's own means (Distributed, MPI, a file). */
 int az_comm_unique_id(uint8_t id[AZ_COMM_ID_BYTES]);
+/* Which collective library az_comm_* bound: ncclGetVersion's code (e.g. 22105 = 2.21.5; 0 if the library does not say)
+ * and the path of the shared object (librccl.so next to the HIP runtime, or AZHIP_RCCL_LIB).  No reference counterpart:
+ * evidence for bench.py's `gather` object. */
+int az_comm_version(int32_t* version, char* path, int32_t cap);
 /* ncclCommInitRank: collective over all `world` ranks, each on its own device. */
 int az_comm_init(int32_t device, int32_t rank, int32_t world, const uint8_t id[AZ_COMM_ID_BYTES], az_comm** out);
 int az_comm_destroy(az_comm* c);
@@ -389,7 +407,11 @@ typedef enum {
 typedef struct {
   int64_t launches[AZ_PROF_NUM];
   double ms[AZ_PROF_NUM];
-  int64_t units[AZ_PROF_NUM];       /* boards (tower/heads) or slots processed */
+  int64_t units[AZ_PROF_NUM];       /* boards (tower/heads) or slots processed (upper bound known to the host at launch) */
+  double exec_units[AZ_PROF_NUM];   /* tower: sum over launches of units x the fraction of the 3x3 convolutions' (row tile, tap)
+                                       products the kernel that ran really executes (the others fall off the board for a whole
+                                       tile and are skipped); other classes: = units.  exec_units / units = the average executed
+                                       fraction of the timed launches */
 } az_prof;
 int az_prof_enable(az_engine* e, int32_t on);   /* 1: wrap every launch in a HIP event pair; 1 | (mask << 1):
                                                    only the kernel classes whose bit is set in mask; 0: off */

@@ -52,7 +52,17 @@ mutable struct SelfplayStats
   aborted_games::Int64
   SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0, 0)
 end
-@assert sizeof(EngineCfg) == 224 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56
+@assert sizeof(EngineCfg) == 224 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56 && sizeof(SelfplayStats) == 64
+const ABI_VERSION = 2   # include/azhip.h AZ_ABI_VERSION the structs above are written against
+"Called once before the first engine is created: a library built from another header must not be written into these structs."
+function check_abi()
+  v = ccall((:az_abi_version, LIB), Cint, ())
+  v == ABI_VERSION || error("libazhip.so has ABI version $v, this glue is written against $ABI_VERSION")
+  for (which, T) in ((0, EngineCfg), (1, MoveRec), (2, GameRec), (3, TraceBuf), (4, SelfplayStats))
+    n = ccall((:az_abi_struct_size, LIB), Cint, (Int32,), Int32(which))
+    n == sizeof(T) || error("$T: the library's struct is $n bytes, the glue's $(sizeof(T))")
+  end
+end
 
 last_error() = unsafe_string(ccall((:az_last_error, LIB), Cstring, ()))
 check(status::Integer) = status == 0 ? nothing : error("azhip status $status: $(last_error())")
@@ -127,6 +137,7 @@ end
 mutable struct Engine
   h::Ptr{Cvoid}
   function Engine(cfg::EngineCfg)
+    check_abi()
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:az_engine_create, LIB), Cint, (Ref{EngineCfg}, Ref{Ptr{Cvoid}}), cfg, out))
     e = new(out[])
@@ -646,7 +657,7 @@ reset!(env::DeviceMctsEnv) = check(ccall((:az_mcts_reset, LIB), Cint, (Ptr{Cvoid
 # ---- what this file deliberately does not bind, and why (tests/test_julia_glue_static.py checks the list against the header:
 # an entry point of include/azhip.h that is neither `ccall`ed above nor named here fails the test) ---------------------------
 const UNBOUND = Dict(
-  :az_abi_version => "version probe; the glue is built against one header",
+  :az_comm_version => "evidence for bench.py's gather object (which collective library was bound); nothing in the training loop needs it",
   :az_engine_cfg_init => "EngineCfg is filled field by field from MctsParams / SimParams (make_cfg)",
   :az_game_num_actions => "GI.num_actions(gspec) answers it on the Julia side",
   :az_game_state_dim => "GI.state_dim(gspec) answers it on the Julia side",

@@ -23,7 +23,17 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.az_abi_version() == 1
+    assert lib.az_abi_version() == 2 == L.ABI_VERSION
+
+
+def test_struct_sizes_of_the_mirror_are_the_library_s():
+    """az_selfplay_stats / az_gather_stats / az_prof grew; a mirror built against an older header must not load"""
+    lib = L.lib()
+    sizes = {name: lib.az_abi_struct_size(i) for i, (name, _) in enumerate(L.STRUCTS)}
+    assert sizes == {name: C.sizeof(st) for name, st in L.STRUCTS}
+    assert (sizes["az_engine_cfg"], sizes["az_move_rec"], sizes["az_game_rec"], sizes["az_selfplay_stats"], sizes["az_gather_stats"],
+            sizes["az_prof"], sizes["az_sample"]) == (224, 64, 56, 64, 80, 256, 112)
+    assert lib.az_abi_struct_size(len(L.STRUCTS)) == -1
 
 
 def test_record_layouts_match_the_oracle_records():
@@ -117,7 +127,8 @@ def test_transport_stub_exports_the_entry_points_comm_hip_binds():
     subprocess.check_call(["make", "-C", os.path.join(root, "tests", "rccl_stub")], stdout=subprocess.DEVNULL)
     src = open(os.path.join(root, "alphazero.jl_amd", "csrc", "comm.hip")).read()
     wanted = set(re.findall(r'dlsym\(so, "(nccl[A-Za-z]+)"\)', src))
-    assert wanted == {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclAllGather", "ncclBroadcast", "ncclGetErrorString"}
+    assert wanted == {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclAllGather", "ncclBroadcast", "ncclGetErrorString", "ncclGetVersion"}
+    wanted.discard("ncclGetVersion")                                 # optional: only az_comm_version asks for it
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(root, "tests", "rccl_stub", "librccl_stub.so")], text=True)
     have = set(re.findall(r"\bT (nccl[A-Za-z]+)", out))
     assert wanted <= have, wanted - have

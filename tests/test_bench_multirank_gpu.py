@@ -33,3 +33,33 @@ def test_two_ranks_on_one_gpu_print_one_line_with_the_gather_leg():
     assert g["ranks"] == 2 and g["world"] == 2 and g["rendezvous"].endswith("gloo")
     assert g["games"] == 1024 and g["memory_length"] == g["samples"] > 1024 * 7                  # every rank holds all ranks' samples
     assert "extra" not in d and "cpu_baseline" not in d                                         # those legs belong to N = 1
+
+
+def test_plain_bench_with_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` exactly as a driver without a launcher calls it: the script re-executes itself under
+    torch.distributed.run with two ranks (stub transport on the one GPU) and rank 0 prints ONE line with n_gpus = 2."""
+    stub = os.path.join(ROOT, "tests", "rccl_stub", "librccl_stub.so")
+    if not os.path.exists(stub):
+        subprocess.check_call(["make", "-C", os.path.dirname(stub)])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AZHIP_RCCL_LIB=stub, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--slots", "512"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["launcher"].startswith("self") and len(d["sims_per_sec_by_rank"]) == 2
+    assert all(v > 0 for v in d["sims_per_sec_by_rank"]) and d["value"] <= sum(d["sims_per_sec_by_rank"]) * (1 + 1e-9)
+    g = d["gather"]
+    assert "error" not in g and g["ranks"] == 2 and g["library"].endswith("librccl_stub.so"), g
+
+
+def test_plain_bench_refuses_more_ranks_than_devices_without_the_stub():
+    """no silent 1-GPU number under an n_gpus = 8 label: more ranks than devices is an error (RCCL: one rank per device)"""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "AZHIP_RCCL_LIB")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "device(s) visible" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

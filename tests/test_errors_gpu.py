@@ -58,4 +58,5 @@ def test_game_too_long_is_reported():
     with azhip.Engine(game=2, oracle=azhip.ORACLE_UNIFORM, num_workers=4, batch_size=4, num_iters_per_turn=8,
                       max_moves_per_game=5) as e:
         g, m, ng, nm, st = e.selfplay_run(4)
-        assert ng == 0 and st.aborted_games == 4 and sorted(e.selfplay_aborted()) == [0, 1, 2, 3]
+        # every game and its one replacement (id | bit 30) outgrow the record: all given up, all eight reported, the call returns
+        assert ng == 0 and st.aborted_games == 8 and sorted(e.selfplay_aborted()) == [0, 1, 2, 3] + [0x40000000 + i for i in range(4)]
