@@ -149,7 +149,8 @@ static int vm_map(az_engine* e, int row, int slot) {
 static int vm_grow(az_engine* e, int ahead) {
   if (!e->vm_rows) return AZ_OK;
   const int G = e->v.G;
-  HIPCHK(hipMemcpyAsync(e->h_node_count.data(), e->v.node_count, sizeof(int) * G, hipMemcpyDeviceToHost, e->stream));
+  hipLaunchKernelGGL(k_node_counts, dim3((G + 255) / 256), dim3(256), 0, e->stream, e->v, e->d_node_count);
+  HIPCHK(hipMemcpyAsync(e->h_node_count.data(), e->d_node_count, sizeof(int) * G, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   bool changed = false;
   for (int s = 0; s < G; ++s) {
@@ -231,9 +232,9 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     int hs = 1024;
     while ((long long)hs * 2 < cap * 3) hs <<= 1;
     v.ht_size = hs;
-    AZCHK(dalloc(e, &v.root, G)); AZCHK(dalloc(e, &v.active, G)); AZCHK(dalloc(e, &v.game_id, G));
-    AZCHK(dalloc(e, &v.move_idx, G)); AZCHK(dalloc(e, &v.epoch, G)); AZCHK(dalloc(e, &v.node_count, G));
-    AZCHK(dalloc(e, &v.worker_sim_id, G)); AZCHK(dalloc(e, &v.tot_sims, G)); AZCHK(dalloc(e, &v.tot_trav, G));
+    AZCHK(dalloc(e, &v.sr, G)); AZCHK(dalloc(e, &v.game_id, G));
+    AZCHK(dalloc(e, &v.move_idx, G)); AZCHK(dalloc(e, &e->d_node_count, G));
+    AZCHK(dalloc(e, &v.worker_sim_id, G));
     AZCHK(dalloc(e, &v.eta, (size_t)G * gi.APAD));
     AZCHK(dalloc(e, &v.ht, (size_t)G * hs));
     {
@@ -254,10 +255,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
         e->vm_rows = rows;
         e->vm_bytes = vbytes;
         e->vm_base = (char*)base;
-        size_t fr = 0, tot = 0;
-        HIPCHK(hipMemGetInfo(&fr, &tot));
-        const char* gb = getenv("AZHIP_POOL_GB");
-        e->vm_budget = gb ? (size_t)(atof(gb) * (double)((size_t)1 << 30)) : fr;     // default: whatever the device still has
+        e->vm_budget = ~(size_t)0;                                   // set once every fixed allocation of the engine is made (below)
         v.nodes = e->vm_base;
         int sh = 0; while (((size_t)1 << sh) < chunk_nodes) ++sh;
         v.node_sh = sh; v.node_mask = (uint32_t)chunk_nodes - 1; v.node_row = (size_t)G * VM_CHUNK; v.node_stride = VM_CHUNK;
@@ -270,15 +268,15 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       }
     }
     AZCHK(dalloc(e, &v.path, (size_t)G * v.max_depth));
-    AZCHK(dalloc(e, &v.leaf_kind, G)); AZCHK(dalloc(e, &v.leaf_depth, G)); AZCHK(dalloc(e, &v.leaf_env, G));
-    AZCHK(dalloc(e, &v.leaf_ins, G)); AZCHK(dalloc(e, &v.eidx, G)); AZCHK(dalloc(e, &v.eval_slots, G));
+    AZCHK(dalloc(e, &v.leaf_env, G));
+    AZCHK(dalloc(e, &v.eval_slots, G));
     AZCHK(dalloc(e, &v.n_eval, 2 * AZ_MAX_GROUPS));
-    AZCHK(dalloc(e, &v.keys, (size_t)G * cap * 4, false)); AZCHK(dalloc(e, &v.root_idx, G));
-    hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, (uint32_t*)v.root_idx, 0xffffffffu, G);
+    AZCHK(dalloc(e, &v.keys, (size_t)G * cap * 4, false)); 
+    hipLaunchKernelGGL(k_slot_records, dim3((G + 255) / 256), dim3(256), 0, e->stream, v, (int)SR_ZERO);   // epoch 1, no root, nothing else
     AZCHK(dalloc(e, &v.Pout, (size_t)std::max(G, 1) * gi.APAD)); AZCHK(dalloc(e, &v.Vout, G));
     AZCHK(dalloc(e, &v.trace, (size_t)G * v.max_moves)); AZCHK(dalloc(e, &v.grec, G));
     AZCHK(dalloc(e, &v.finished, G)); AZCHK(dalloc(e, &v.err, 1));
-    hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, v.epoch, 1u, G);
+
     // staging
     e->io_cap = std::max(G, 4096);
     AZCHK(dalloc(e, &e->d_slots, e->io_cap)); AZCHK(dalloc(e, &e->d_gids, e->io_cap)); AZCHK(dalloc(e, &e->d_roots, e->io_cap));
@@ -319,12 +317,12 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       gv.stat = stat_base + (size_t)4 * blk_group * g;
       const size_t o = (size_t)g * Gh;
       gv.G = Gh;
-      gv.root += o; gv.active += o; gv.game_id += o; gv.move_idx += o; gv.epoch += o; gv.node_count += o;
-      gv.worker_sim_id += o; gv.tot_sims += o; gv.tot_trav += o; gv.eta += o * gi.APAD;
+      gv.sr += o; gv.game_id += o; gv.move_idx += o;
+      gv.worker_sim_id += o; gv.eta += o * gi.APAD;
       gv.ht += o * hs; gv.nodes += o * v.node_stride; gv.path += o * v.max_depth;
       if (gv.slot_cap) gv.slot_cap += o;
-      gv.leaf_kind += o; gv.leaf_depth += o; gv.leaf_env += o; gv.leaf_ins += o; gv.eidx += o; gv.eval_slots += o;
-      gv.n_eval += 2 * g; gv.keys += o * (size_t)cap * 4; gv.root_idx += o; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
+      gv.leaf_env += o; gv.eval_slots += o;
+      gv.n_eval += 2 * g; gv.keys += o * (size_t)cap * 4; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;
       if (ng == 1) { e->gs[g] = e->gt[g] = e->stream; }
       else {
@@ -347,7 +345,17 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     p.prior_temp = c->prior_temperature; p.nsims = c->num_iters_per_turn; p.temp_len = c->temperature_len;
     for (int i = 0; i < AZ_SCHED_MAX; ++i) { p.temp_xs[i] = c->temperature_xs[i]; p.temp_ys[i] = c->temperature_ys[i]; }
     p.seed = c->seed; p.oracle = c->oracle; p.reset_every = c->reset_every; p.retire = 0;
-    if (e->vm_rows) AZCHK(vm_grow(e, 1));                            // the first chunk of every slot
+    if (e->vm_rows) {
+      // Budget of the growing pool: what the device has left AFTER this engine's fixed allocations, minus what is
+      // still to come -- the phase buffer of a bounded phase (num_workers x 4 games of move records is the usual order), the
+      // replay memory / trainer of the same process -- as a margin of 1/8 of the device, at least 4 GB.  AZHIP_POOL_GB overrides.
+      size_t fr = 0, tot = 0;
+      HIPCHK(hipMemGetInfo(&fr, &tot));
+      const size_t margin = std::max<size_t>(tot / 8, (size_t)4 << 30);
+      const char* gb = getenv("AZHIP_POOL_GB");
+      e->vm_budget = gb ? (size_t)(atof(gb) * (double)((size_t)1 << 30)) : (fr > margin ? fr - margin : fr / 2);
+      AZCHK(vm_grow(e, 1));                                          // the first chunk of every slot
+    }
     e->h_finished.resize(G); e->h_grec.resize(G);
     e->prof_pool.resize(2048);
     for (auto& r : e->prof_pool) { HIPCHK(hipEventCreate(&r.a)); HIPCHK(hipEventCreate(&r.b)); }
@@ -852,7 +860,7 @@ template <class Gm> static int run_waves(az_engine* e, int nga, int n, uint32_t 
 // no simulation in flight: pending leaves dropped, both leaf counters of every group zero
 static int reset_wave_state(az_engine* e) {
   AZCHK(sync_groups(e));
-  HIPCHK(hipMemsetAsync(e->v.leaf_kind, 0, sizeof(int) * e->v.G, e->stream));
+  hipLaunchKernelGGL(k_slot_records, dim3((e->v.G + 255) / 256), dim3(256), 0, e->stream, e->v, (int)SR_CLEAR_LEAF);
   HIPCHK(hipMemsetAsync(e->v.n_eval, 0, sizeof(int) * 2 * AZ_MAX_GROUPS, e->stream));
   for (int g = 0; g < AZ_MAX_GROUPS; ++g) { e->pending[g] = false; e->wave_par[g] = 0; }
   return AZ_OK;
@@ -877,9 +885,7 @@ extern "C" int az_mcts_reset(az_engine* e) {
   if (e->running) return fail(AZ_ERR_STATE, "self-play in progress");
   const int G = e->v.G;
   HIPCHK(hipMemsetAsync(e->v.ht, 0, sizeof(unsigned long long) * (size_t)G * e->v.ht_size, e->stream));
-  HIPCHK(hipMemsetAsync(e->v.node_count, 0, sizeof(int) * G, e->stream));
-  hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, e->v.epoch, 1u, G);
-  hipLaunchKernelGGL(k_fill_u32, dim3((G + 255) / 256), dim3(256), 0, e->stream, (uint32_t*)e->v.root_idx, 0xffffffffu, G);
+  hipLaunchKernelGGL(k_slot_records, dim3((G + 255) / 256), dim3(256), 0, e->stream, e->v, (int)SR_RESET_TREE);
   AZCHK(reset_wave_state(e));
   HIPCHK(hipStreamSynchronize(e->stream));
   return AZ_OK;
@@ -897,7 +903,7 @@ static int explore_begin(az_engine* e, const std::vector<int>& slots, const std:
   int maxslot = 0;
   for (int s : slots) maxslot = std::max(maxslot, s);
   AZCHK(reset_wave_state(e));
-  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
+  hipLaunchKernelGGL(k_slot_records, dim3((e->v.G + 255) / 256), dim3(256), 0, e->stream, e->v, (int)SR_CLEAR_ACTIVE);
   AZCHK(start_games<Gm>(e, slots, gids, &roots, 0, 0));
   HIPCHK(hipMemcpyAsync(e->d_moves, mv.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, e->stream));
   if (eta) HIPCHK(hipMemcpyAsync(e->d_eta, eta, sizeof(double) * (size_t)n * AZ_MAX_ACTIONS, hipMemcpyHostToDevice, e->stream));
@@ -912,7 +918,7 @@ template <class Gm> static int explore_end(az_engine* e, int nga) {
   if (!nga) return AZ_OK;
   AZCHK(flush_pending<Gm>(e));                                     // the last simulation's expand + backup
   AZCHK(sync_groups(e));
-  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
+  hipLaunchKernelGGL(k_slot_records, dim3((e->v.G + 255) / 256), dim3(256), 0, e->stream, e->v, (int)SR_CLEAR_ACTIVE);
   return check_device_error(e);
 }
 template <class Gm>
@@ -949,7 +955,7 @@ extern "C" int az_mcts_explore(az_engine* e, const uint64_t* root_keys, int32_t 
 template <class Gm>
 __global__ void k_node_stats(DView v, int slot, unsigned long long ka, unsigned long long kb, char* out) {
   using NL = NodeL<Gm>;
-  const uint32_t epoch = v.epoch[slot];
+  const uint32_t epoch = v.sr[slot].epoch;
   const unsigned long long hk = az_hash_key(ka, kb);
   const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
@@ -999,11 +1005,10 @@ extern "C" int az_mcts_counters(az_engine* e, int32_t slot, int64_t* ts, int64_t
   ENGINE(e);
   if (slot < 0 || slot >= e->v.G) return fail(AZ_ERR_BAD_ARG, "bad slot");
   AZCHK(sync_groups(e));
-  long long a = 0, b = 0; int c = 0;
-  HIPCHK(hipMemcpyAsync(&a, e->v.tot_sims + slot, 8, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(&b, e->v.tot_trav + slot, 8, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(&c, e->v.node_count + slot, 4, hipMemcpyDeviceToHost, e->stream));
+  SlotRec r;
+  HIPCHK(hipMemcpyAsync(&r, e->v.sr + slot, sizeof r, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  const long long a = r.tot_sims, b = r.tot_trav; const int c = r.node_count;
   if (ts) *ts = a;
   if (tt) *tt = b;
   if (nn) *nn = c;
@@ -1021,11 +1026,10 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   const int G = e->v.G;
   // a fresh player per worker (simulations.jl:217-218): empty trees, zero counters
   AZCHK(reset_wave_state(e));
-  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * G, e->stream));
+  hipLaunchKernelGGL(k_slot_records, dim3((G + 255) / 256), dim3(256), 0, e->stream, e->v, (int)(SR_CLEAR_ACTIVE | SR_CLEAR_TOTALS));
   HIPCHK(hipMemsetAsync(e->v.finished, 0, sizeof(int) * G, e->stream));
   HIPCHK(hipMemsetAsync(e->v.worker_sim_id, 0, sizeof(int) * G, e->stream));
-  HIPCHK(hipMemsetAsync(e->v.tot_sims, 0, sizeof(long long) * G, e->stream));
-  HIPCHK(hipMemsetAsync(e->v.tot_trav, 0, sizeof(long long) * G, e->stream));
+
   HIPCHK(hipMemsetAsync(e->gv[0].stat, 0, sizeof(long long) * e->stat_words, e->stream));   // gv[0].stat = the base of the accumulator array
   e->total_games = num_games; e->first_game_id = first_game_id; e->next_game = 0; e->games_done = 0; e->wave_in_move = 0;
   e->q_games.clear(); e->q_moves.clear();
@@ -1226,7 +1230,7 @@ extern "C" int az_selfplay_end(az_engine* e) {
   e->p.retire = 0;
   if (!e->running) return AZ_OK;
   AZCHK(reset_wave_state(e));                                      // an unfinished simulation (stepping form stopped mid-move) is dropped
-  HIPCHK(hipMemsetAsync(e->v.active, 0, sizeof(int) * e->v.G, e->stream));
+  hipLaunchKernelGGL(k_slot_records, dim3((e->v.G + 255) / 256), dim3(256), 0, e->stream, e->v, (int)SR_CLEAR_ACTIVE);
   HIPCHK(hipStreamSynchronize(e->stream));
   e->running = false;
   e->active_slots = 0;

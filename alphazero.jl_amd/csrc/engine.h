@@ -83,7 +83,7 @@ struct az_engine {
   // backed when slot s is about to need it.  vm_rows = 0: plain hipMalloc pool.
   char* vm_base; size_t vm_bytes, vm_chunk; int vm_rows, vm_chunk_nodes;
   std::vector<hipMemGenericAllocationHandle_t> vm_handles; std::vector<char*> vm_at;
-  std::vector<int> h_slot_cap, h_node_count; int* d_slot_cap; size_t vm_budget, vm_mapped;
+  std::vector<int> h_slot_cap, h_node_count; int* d_slot_cap; int* d_node_count; size_t vm_budget, vm_mapped;
   size_t stat_words; std::vector<long long> h_stat;   // per-workgroup statistics accumulators of k_tree (DView::stat), summed on request
   std::vector<int32_t> aborted_ids;   // games retired because their slot ran out of nodes / move records (az_selfplay_aborted)
   std::vector<void*> net_allocs;   // device copies of the packed network (replaced by az_net_set_params)

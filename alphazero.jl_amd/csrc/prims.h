@@ -151,7 +151,7 @@ inline hipError_t sort_pairs(unsigned long long* keys_in, unsigned long long* ke
   int* scan_tmp = first + (size_t)RS_BINS * tiles;
   unsigned long long *ka = keys_in, *kb = keys_out;
   unsigned int *va = vals_in, *vb = vals_out;
-  for (int pass = 0; pass < 8; ++pass) {                            // an even number of passes: the result ends in (kb, vb) of pass 7 = the caller's out
+  for (int pass = 0; pass < 8; ++pass) {                            // an even number of passes over two buffers: pass 7 writes (keys_in, vals_in), copied to the caller's out below
     const int shift = 8 * pass;
     hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, ka, n, shift, (int)tiles, hist);
     hipError_t e = scan_ints(hist, first, (long long)RS_BINS * tiles, false, scan_tmp, st);

@@ -45,17 +45,36 @@ struct DParams {
                           // reported as aborted, the phase goes on); 0 (explore! / arena hooks): a device error
 };
 
+// Per-slot search state (round 4): what used to be thirteen slot-major arrays -- thirteen 32-byte sectors read and up to eight
+// written per slot and wave, of which 4 to 24 bytes each were used -- is one 64-byte record: two sectors.
+//   root_a / root_b / root_fin   the live game (GI state of the root, play.jl:299-313)
+//   tot_sims / tot_trav          MCTS.Env.total_simulations / total_nodes_traversed (mcts.jl:128-130)
+//   leaf_kd                      pending leaf: kind (LEAF_*) | depth << 2
+//   eidx                         slot -> index in the evaluation batch
+//   node_count                   length(env.tree)
+//   epoch                        live epoch of the slot's hash table (MCTS.reset! is a new epoch)
+//   leaf_ins                     table position the pending leaf will take
+//   root_idx                     node index of the current root, -1 = not looked up yet this move
+//   active                       the slot searches
+struct alignas(64) SlotRec {
+  unsigned long long root_a, root_b;
+  long long tot_sims, tot_trav;
+  uint32_t root_fin;
+  int leaf_kd;
+  int eidx, node_count;
+  uint32_t epoch, leaf_ins;
+  int root_idx, active;
+  __host__ __device__ inline GEnv root() const { GEnv g; g.a = root_a; g.b = root_b; g.fin = root_fin; return g; }
+  __host__ __device__ inline void set_root(const GEnv& g) { root_a = g.a; root_b = g.b; root_fin = g.fin; }
+};
+static_assert(sizeof(SlotRec) == 64, "slot record");
+
 struct DView {
   int G, cap_nodes, ht_size, max_depth, max_moves;
-  GEnv* root;
-  int* active;
+  SlotRec* sr;            // [G] the search state of a slot that k_tree reads and writes every wave, ONE 64-byte record (round 4)
   uint32_t* game_id;
   uint32_t* move_idx;
-  uint32_t* epoch;
-  int* node_count;
   int* worker_sim_id;
-  long long* tot_sims;
-  long long* tot_trav;
   double* eta;            // [G][APAD] by full action index
   unsigned long long* ht;
   char* nodes;
@@ -66,13 +85,8 @@ struct DView {
   int node_sh; uint32_t node_mask; size_t node_row, node_stride;
   const int* slot_cap;    // [G] or NULL (plain pool: cap_nodes for every slot)
   unsigned long long* keys; // [G][cap][4]: state key (2 words), Vest (f32, StateInfo.Vest, src/mcts.jl:86) in word 2
-  int* root_idx;          // [G] node index of the slot's current root, -1 = not looked up yet this move
   unsigned long long* path;
-  int* leaf_kind;
-  int* leaf_depth;
-  GEnv* leaf_env;
-  uint32_t* leaf_ins;
-  int* eidx;              // slot -> index in the evaluation batch
+  GEnv* leaf_env;         // [G] state of the slot's pending leaf (read by the network kernels through eval_slots)
   int* eval_slots;        // evaluation batch -> slot
   int* n_eval;            // [2] leaves of the wave, double-buffered by wave parity (k_tree zeroes the other one)
   float* Pout;            // [n_eval][APAD] masked-normalised priors, full width
@@ -263,14 +277,21 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
   // Everything whose address does not depend on another load is requested up front, in one round trip: the pending leaf's
   // kind / depth / batch index, the node count, the first L path entries (one per lane) and, for phase B, the root state and
   // the epoch.  (Inside the branches below they were three dependent rounds: kind -> depth, eidx -> path, Pout.)
-  const int kind0 = (do_backup && live) ? v.leaf_kind[pslot] : LEAF_NONE;
-  const int depth0 = v.leaf_depth[pslot], e0 = v.eidx[pslot], nc0 = v.node_count[pslot];
-  const unsigned long long st0 = path[lane < v.max_depth ? lane : 0];
-  const GEnv root0 = v.root[pslot];
-  const uint32_t epoch0 = v.epoch[pslot], ins0 = v.leaf_ins[pslot];
-  const GEnv lenv0 = v.leaf_env[pslot];
-  const long long trav0 = v.tot_trav[pslot], sims0 = v.tot_sims[pslot];
-  const int ridx0 = v.root_idx[pslot], active0 = v.active[pslot];   // phase B's first two loads; phase A knows when it changes them
+  SlotRec* const sr = v.sr + pslot;
+  const SlotRec s0 = *sr;                                           // 64 bytes, the same for all lanes of the slot
+  unsigned long long st0 = path[lane < v.max_depth ? lane : 0];
+  GEnv lenv0 = v.leaf_env[pslot];
+  int kind0 = s0.leaf_kd & 3, depth0 = s0.leaf_kd >> 2, e0 = s0.eidx, nc0 = s0.node_count;
+  GEnv root0 = s0.root();
+  uint32_t epoch0 = s0.epoch, ins0 = s0.leaf_ins;
+  long long trav0 = s0.tot_trav, sims0 = s0.tot_sims;
+  int ridx0 = s0.root_idx, active0 = s0.active;
+  // (The compiler sinks a load into the branch that uses it, which turned this one round trip into several dependent ones; the
+  // values are therefore pinned into registers right here -- one wait for all of them.)
+#define AZ_PIN(x) asm volatile("" : "+v"(x))
+  AZ_PIN(kind0); AZ_PIN(depth0); AZ_PIN(e0); AZ_PIN(nc0); AZ_PIN(st0); AZ_PIN(root0.a); AZ_PIN(root0.b); AZ_PIN(root0.fin);
+  AZ_PIN(epoch0); AZ_PIN(ins0); AZ_PIN(lenv0.a); AZ_PIN(lenv0.b); AZ_PIN(lenv0.fin); AZ_PIN(trav0); AZ_PIN(sims0); AZ_PIN(ridx0); AZ_PIN(active0);
+  if (!(do_backup && live)) kind0 = LEAF_NONE;
   bool retired = false;
   int new_root = -1;
 
@@ -289,7 +310,7 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
           // its game is reported as aborted and the phase goes on; the hooks report a capacity error
           ok = false;
           if (!p.retire) dev_fail(v, DERR_NODE_POOL);
-          else { retired = true; if (lane == 0) { v.finished[slot] = 2; v.active[slot] = 0; v.leaf_kind[slot] = LEAF_NONE; } }
+          else { retired = true; if (lane == 0) { v.finished[slot] = 2; sr->active = 0; sr->leaf_kd = LEAF_NONE; } }
         } else {
           const GEnv env = lenv0;
           const uint32_t m = Gm::mask(env);
@@ -325,8 +346,8 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
             const unsigned long long tag = (hk >> 40) & 0xffff;
             v.ht[(size_t)slot * v.ht_size + ins0] =
                 ((unsigned long long)epoch0 << 48) | (tag << 32) | (unsigned long long)(idx + 1);
-            v.node_count[slot] = idx + 1;
-            if (depth == 0) v.root_idx[slot] = idx;
+            sr->node_count = idx + 1;
+            if (depth == 0) sr->root_idx = idx;
             else if (links_ok) {                                    // memoise tree[state] on the edge that reached it
               set_link<Gm>(node_at<Gm>(v, slot, (int)(uint32_t)st_par), (int)((st_par >> 32) & 0xff), (uint32_t)(idx + 1));
             }
@@ -356,12 +377,12 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
           }
         }
         if (lane == 0) {
-          v.tot_trav[slot] = trav0 + depth;                         // mcts.jl:222
-          v.tot_sims[slot] = sims0 + 1;                             // mcts.jl:242
+          sr->tot_trav = trav0 + depth;                             // mcts.jl:222
+          sr->tot_sims = sims0 + 1;                                 // mcts.jl:242
         }
       }
     }
-    if (!do_select && lane == 0) v.leaf_kind[slot] = LEAF_NONE;     // the pending simulation has been completed
+    if (!do_select && lane == 0) sr->leaf_kd = LEAF_NONE;           // the pending simulation has been completed
   }
   if (!do_select) return;
   if (dbg) dbg[1] = __builtin_readcyclecounter();
@@ -387,7 +408,7 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
         idx = ht_lookup<Gm>(v, slot, lane, env.a, env.b, epoch, &ins);
         if (idx < 0) { kind = LEAF_NEW; break; }                    // mcts.jl:205-207
         if (lane == 0) {
-          if (depth == 0) v.root_idx[slot] = idx;
+          if (depth == 0) sr->root_idx = idx;
           else if (links_ok) set_link<Gm>(node_at<Gm>(v, slot, pidx), pact, (uint32_t)(idx + 1));
         }
         have = false;
@@ -442,12 +463,11 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
     }
     if (dbg) dbg[3] = __builtin_readcyclecounter();
     if (lane == 0) {
-      v.leaf_depth[slot] = depth;
       v.leaf_env[slot] = env;
-      v.leaf_ins[slot] = ins;
+      sr->leaf_ins = ins;
     }
   }
-  if (live && lane == 0) v.leaf_kind[slot] = kind;
+  if (live && lane == 0) sr->leaf_kd = kind | (depth << 2);
   if (dbg) dbg[4] = __builtin_readcyclecounter();
 
   // ------------------------------------------------------------------ evaluation batch + statistics of the wave
@@ -478,7 +498,7 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
     int base = s_base;
     for (int i = 0; i < w; ++i) base += s_new[i];
     const int e = base + __popcll(bal & ((1ULL << wl) - 1ULL));
-    v.eidx[slot] = e;
+    sr->eidx = e;
     v.eval_slots[e] = slot;
   }
   if (dbg) dbg[6] = __builtin_readcyclecounter();
@@ -557,7 +577,7 @@ template <class Gm>
 __device__ inline const char* find_node(const DView& v, int slot, unsigned long long ka, unsigned long long kb,
                                         uint32_t* idx_out = nullptr) {
   using NL = NodeL<Gm>;
-  const uint32_t epoch = v.epoch[slot];
+  const uint32_t epoch = v.sr[slot].epoch;
   const unsigned long long hk = az_hash_key(ka, kb);
   const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
@@ -632,9 +652,11 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
   using NL = NodeL<Gm>;
   constexpr int L = Gm::APAD;
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;       // one lane per slot: n <= 9, serial
-  if (slot >= v.G || !v.active[slot]) return;
-  GEnv env = v.root[slot];
-  const uint32_t epoch = v.epoch[slot];
+  if (slot >= v.G) return;
+  SlotRec* const sr = v.sr + slot;
+  if (!sr->active) return;
+  GEnv env = sr->root();
+  const uint32_t epoch = sr->epoch;
   const char* nd = find_node<Gm>(v, slot, env.a, env.b);          // tree[state] must exist after explore!
   if (!nd) { dev_fail(v, DERR_NO_ROOT); return; }
   const uint32_t m = Gm::mask(env);
@@ -643,7 +665,7 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
   const uint32_t mv = v.move_idx[slot];
   if ((int)mv >= v.max_moves) {                                   // a game longer than the trace can hold: retired like a full node pool
     if (!p.retire) dev_fail(v, DERR_MOVES);
-    else { v.finished[slot] = 2; v.active[slot] = 0; }
+    else { v.finished[slot] = 2; sr->active = 0; }
     return;
   }
   az_move_rec* rec = v.trace + (size_t)slot * v.max_moves + mv;
@@ -653,8 +675,8 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
   Gm::play(env, act);
   rec->action = act;
   rec->reward = Gm::white_reward(env);
-  v.root[slot] = env;
-  v.root_idx[slot] = -1;
+  sr->set_root(env);
+  sr->root_idx = -1;
   v.move_idx[slot] = mv + 1;
   if (env.fin & 1) {
     az_game_rec* g = v.grec + slot;
@@ -662,17 +684,17 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
     g->slot = slot;
     g->num_moves = (int32_t)(mv + 1);
     g->first_move = 0;
-    g->nodes = v.node_count[slot];                               // measured BEFORE the periodic reset
-    g->total_simulations = v.tot_sims[slot];
-    g->total_nodes_traversed = v.tot_trav[slot];
+    g->nodes = sr->node_count;                                   // measured BEFORE the periodic reset
+    g->total_simulations = sr->tot_sims;
+    g->total_nodes_traversed = sr->tot_trav;
     g->final_key[0] = env.a; g->final_key[1] = env.b;
     v.finished[slot] = 1;
-    v.active[slot] = 0;
+    sr->active = 0;
     const int ws = v.worker_sim_id[slot] + 1;
     v.worker_sim_id[slot] = ws;
     if (p.reset_every > 0 && ws % p.reset_every == 0) {          // reset_player!, simulations.jl:235-237
-      v.epoch[slot] = epoch + 1;                                  // wrap handled by k_start_games
-      v.node_count[slot] = 0;
+      sr->epoch = epoch + 1;                                      // wrap handled by k_start_games
+      sr->node_count = 0;
     }
   } else {
     arm_noise<Gm>(v, p, slot, env);                               // next explore! draws its eta
@@ -688,21 +710,22 @@ __global__ void __launch_bounds__(256) k_start_games(DView v, DParams p, const i
   if (i >= n) return;
   const int slot = slots[i];
   GEnv env = roots ? roots[i] : Gm::init();
-  v.root[slot] = env;
-  v.root_idx[slot] = -1;
-  v.leaf_kind[slot] = LEAF_NONE;
+  SlotRec* const sr = v.sr + slot;
+  sr->set_root(env);
+  sr->root_idx = -1;
+  sr->leaf_kd = LEAF_NONE;
   v.game_id[slot] = game_ids ? game_ids[i] : 0;
   v.move_idx[slot] = 0;
-  v.active[slot] = 1;
+  sr->active = 1;
   v.finished[slot] = 0;
-  uint32_t ep = v.epoch[slot];
-  if (reset_tree) { ep += 1; v.node_count[slot] = 0; }
+  uint32_t ep = sr->epoch;
+  if (reset_tree) { ep += 1; sr->node_count = 0; }
   if (ep == 0 || ep >= 0xffff) {                                  // epoch space exhausted: really clear
     unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
     for (int k = 0; k < v.ht_size; ++k) tab[k] = 0;
-    ep = 1; v.node_count[slot] = 0;
+    ep = 1; sr->node_count = 0;
   }
-  v.epoch[slot] = ep;
+  sr->epoch = ep;
 }
 // eta for explore!: given by the caller (full action index) or drawn from the RNG contract
 template <class Gm>
@@ -714,7 +737,7 @@ __global__ void __launch_bounds__(256) k_arm_noise(DView v, DParams p, const int
   const int slot = slots[i];
   if (moves) v.move_idx[slot] = moves[i];
   if (eta_in) { for (int a = 0; a < L; ++a) v.eta[(size_t)slot * L + a] = a < AZ_MAX_ACTIONS ? eta_in[(size_t)i * AZ_MAX_ACTIONS + a] : 0.0; }
-  else arm_noise<Gm>(v, p, slot, v.root[slot]);
+  else arm_noise<Gm>(v, p, slot, v.sr[slot].root());
 }
 
 // root visit counts of a list of slots (MCTS.policy's input, mcts.jl:255-271): out[i] = {found, N[0..AZ_MAX_ACTIONS)}
@@ -734,15 +757,33 @@ static __global__ void __launch_bounds__(256) k_reset_slots(DView v, const int* 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int slot = slots[i];
-  uint32_t ep = v.epoch[slot] + 1;
+  uint32_t ep = v.sr[slot].epoch + 1;
   if (ep >= 0xffff) {
     unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
     for (int k = 0; k < v.ht_size; ++k) tab[k] = 0;
     ep = 1;
   }
-  v.epoch[slot] = ep;
-  v.node_count[slot] = 0;
-  v.root_idx[slot] = -1;
+  v.sr[slot].epoch = ep;
+  v.sr[slot].node_count = 0;
+  v.sr[slot].root_idx = -1;
+}
+
+// host-side maintenance of the slot records (what were hipMemsets of single arrays): any combination of
+enum { SR_CLEAR_ACTIVE = 1, SR_CLEAR_LEAF = 2, SR_CLEAR_TOTALS = 4, SR_RESET_TREE = 8, SR_ZERO = 16 };
+static __global__ void __launch_bounds__(256) k_slot_records(DView v, int what) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= v.G) return;
+  SlotRec* const sr = v.sr + slot;
+  if (what & SR_ZERO) { SlotRec z = {}; z.epoch = 1; z.root_idx = -1; *sr = z; return; }
+  if (what & SR_CLEAR_ACTIVE) sr->active = 0;
+  if (what & SR_CLEAR_LEAF) sr->leaf_kd = LEAF_NONE;
+  if (what & SR_CLEAR_TOTALS) { sr->tot_sims = 0; sr->tot_trav = 0; }
+  if (what & SR_RESET_TREE) { sr->node_count = 0; sr->epoch = 1; sr->root_idx = -1; }   // the caller has zeroed the hash tables
+}
+// node counts of all slots, dense (the host maps pool chunks ahead of the slots, azhip.hip vm_grow)
+static __global__ void __launch_bounds__(256) k_node_counts(DView v, int* out) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot < v.G) out[slot] = v.sr[slot].node_count;
 }
 
 // gather the move records of finished games into one contiguous staging area
