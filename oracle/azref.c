@@ -18,8 +18,9 @@
  * Every function cites the reference lines it restates (paths relative to
  * /root/reference).  Arithmetic follows the reference's types: priors Float32,
  * W Float64, N Int64, UCT in Float64 evaluated left to right without contraction.
- * Randomness and transcendental functions follow include/az_numerics.h (the RNG
- * contract of SURVEY.md §8c) because Julia's streams cannot be reproduced.
+ * Randomness and transcendental functions follow the RNG / numerics contract of SURVEY.md §8c
+ * (Julia's streams cannot be reproduced), implemented HERE in oracle/ref_numerics.h, separately
+ * from the product's include/az_numerics.h (round 4: the two no longer share code).
  *
  * Build: see oracle/Makefile  (gcc -O3 -ffp-contract=off -mavx2 -mfma).
  */
@@ -29,7 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../include/az_numerics.h"
+#include "ref_numerics.h"   /* the oracle's OWN implementation of the numerics + RNG contract (not the product's header) */
 
 #define AZR_C4 0
 #define AZR_TTT 1
@@ -476,7 +477,7 @@ static void bn_fold(const float* bias, const float* bn, int n, float* scale, flo
   const float *g = bn, *be = bn + n, *mu = bn + 2 * n, *var = bn + 3 * n;
   for (int i = 0; i < n; ++i) {
     scale[i] = g[i] / sqrtf(var[i] + 1e-5f);
-    shift[i] = az_fmaf(bias[i] - mu[i], scale[i], be[i]);
+    shift[i] = __builtin_fmaf(bias[i] - mu[i], scale[i], be[i]);
   }
 }
 
@@ -514,7 +515,7 @@ static void conv_bn(const azr_net* n, const float* in, int Cin, int Cout, int ks
         int inside = (yy >= 0 && yy < H && xx >= 0 && xx < W);
         float v = inside ? in[(size_t)(xx + W * yy) * Cin + ci] : 0.0f;
         const float* wrow = Wp + ((size_t)t * Cin + ci) * Cout;
-        for (int co = 0; co < Cout; ++co) o[co] = az_fmaf(v, wrow[co], o[co]);
+        for (int co = 0; co < Cout; ++co) o[co] = __builtin_fmaf(v, wrow[co], o[co]);
       }
       ntap = 0;
     }
@@ -526,11 +527,11 @@ static void conv_bn(const azr_net* n, const float* in, int Cin, int Cout, int ks
         int ci = paired ? ((kk & 1) ? half + (kk >> 1) : (kk >> 1)) : kk;
         float v = inside ? in[(size_t)(xx + W * yy) * Cin + ci] : 0.0f;
         const float* wrow = Wp + ((size_t)t * Cin + ci) * Cout;
-        for (int co = 0; co < Cout; ++co) o[co] = az_fmaf(v, wrow[co], o[co]);
+        for (int co = 0; co < Cout; ++co) o[co] = __builtin_fmaf(v, wrow[co], o[co]);
       }
     }
     for (int co = 0; co < Cout; ++co) {
-      float v = az_fmaf(o[co], scale[co], shift[co]);
+      float v = __builtin_fmaf(o[co], scale[co], shift[co]);
       if (res) v = v + res[(size_t)(x + W * y) * Cout + co];
       if (relu) v = v > 0.0f ? v : 0.0f;
       o[co] = v;
@@ -590,7 +591,7 @@ static void net_forward_one(const azr_net* n, const float* xin, float* p, float*
     for (int o = 0; o < A; ++o) {
       float acc = 0.0f;
       for (int pz = 0; pz < P; ++pz) for (int f = 0; f < n->npf; ++f)
-        acc = az_fmaf(hp[(size_t)pz * n->npf + f], w[o + (size_t)A * (pz + (size_t)P * f)], acc);
+        acc = __builtin_fmaf(hp[(size_t)pz * n->npf + f], w[o + (size_t)A * (pz + (size_t)P * f)], acc);
       logits[o] = acc + w[(size_t)A * K + o];
     }
     w += (size_t)A * K + A;
@@ -598,7 +599,7 @@ static void net_forward_one(const azr_net* n, const float* xin, float* p, float*
     float m = logits[0];
     for (int o = 1; o < A; ++o) m = logits[o] > m ? logits[o] : m;
     float s = 0.0f;
-    for (int o = 0; o < A; ++o) { p[o] = az_expf(logits[o] - m); s += p[o]; }
+    for (int o = 0; o < A; ++o) { p[o] = rn_expf(logits[o] - m); s += p[o]; }
     for (int o = 0; o < A; ++o) p[o] = p[o] / s;
   }
   /* value head, resnet.jl:85-90 */
@@ -610,7 +611,7 @@ static void net_forward_one(const azr_net* n, const float* xin, float* p, float*
     for (int pz = 0; pz < P; ++pz) for (int f = 0; f < n->nvf; ++f) {
       float hvv = hv[(size_t)pz * n->nvf + f];
       const float* wr = w + (size_t)F * (pz + (size_t)P * f);
-      for (int o = 0; o < F; ++o) vh[o] = az_fmaf(hvv, wr[o], vh[o]);
+      for (int o = 0; o < F; ++o) vh[o] = __builtin_fmaf(hvv, wr[o], vh[o]);
     }
     for (int o = 0; o < F; ++o) {
       float acc = vh[o] + w[(size_t)F * K + o];
@@ -618,9 +619,9 @@ static void net_forward_one(const azr_net* n, const float* xin, float* p, float*
     }
     w += (size_t)F * K + F;
     float acc = 0.0f;
-    for (int k = 0; k < F; ++k) acc = az_fmaf(vh[k], w[k], acc);
+    for (int k = 0; k < F; ++k) acc = __builtin_fmaf(vh[k], w[k], acc);
     acc = acc + w[F];
-    *v = az_tanhf(acc);
+    *v = rn_tanhf(acc);
   }
   free(x0);
 }
@@ -681,7 +682,7 @@ static uint64_t state_hash(const azr_state* s) {
   uint64_t h = 0xcbf29ce484222325ULL;
   const uint8_t* p = (const uint8_t*)s;
   for (size_t i = 0; i < sizeof(azr_state); ++i) { h ^= p[i]; h *= 0x100000001b3ULL; }
-  return az_mix64(h);
+  return rn_mix64(h);
 }
 static azr_node* tree_find(azr_mcts* e, const azr_state* s, int insert) {
   if (insert && (e->count + 1) * 2 > e->cap) {
@@ -733,21 +734,21 @@ int64_t azr_mcts_oracle_calls(const azr_mcts* e) { return e->oracle_calls; }
  * (fp32, sum in action order); V = (h16 - 32768) / 65536. */
 void azr_hash_oracle(int game, const azr_state* st, const uint8_t* mask, float* Pfull, float* V) {
   uint64_t key[2]; azr_pack_key(game, st, key);
-  uint64_t h = az_hash_key(key[0], key[1]);
+  uint64_t h = rn_hash_key(key[0], key[1]);
   int A = azr_num_actions_(game);
   float s = 0.0f;
   for (int a = 0; a < A; ++a) {
-    float raw = mask[a] ? (float)(1 + (int)(az_mix64(h + (uint64_t)(a + 1)) & 0xffff)) : 0.0f;
+    float raw = mask[a] ? (float)(1 + (int)(rn_mix64(h + (uint64_t)(a + 1)) & 0xffff)) : 0.0f;
     Pfull[a] = raw; s += raw;
   }
   for (int a = 0; a < A; ++a) Pfull[a] = Pfull[a] / s;
-  *V = (float)((int)(az_mix64(h + 99) & 0xffff) - 32768) / 65536.0f;
+  *V = (float)((int)(rn_mix64(h + 99) & 0xffff) - 32768) / 65536.0f;
 }
 
 /* rollout! (src/mcts.jl:41-50); rand(available_actions) = action floor(u * n) of the RNG contract */
-static double rollout(azr_env* g, double gamma, az_rng* r) {
+static double rollout(azr_env* g, double gamma, rn_stream* r) {
   int acts[AZR_AMAX]; int n = available(g, acts);
-  int k = (int)(az_rng_f64(r) * (double)n);
+  int k = (int)(rn_u64(r) * (double)n);
   if (k >= n) k = n - 1;
   azr_play(g, acts[k]);
   double wr = azr_white_reward(g);
@@ -767,8 +768,8 @@ static void call_oracle(azr_mcts* e, const azr_state* st, float* P, float* V) {
     /* (r::RolloutOracle)(state), src/mcts.jl:52-60 */
     int wp = azr_white_playing(&g);
     for (int i = 0; i < n; ++i) P[i] = (float)(1.0 / (double)n);
-    az_rng r = az_rng_make(e->rng_seed, e->rng_game, e->rng_move, AZ_RNG_ROLLOUT);
-    r.ctr[3] = e->rng_sim * 1024u;
+    rn_stream r = rn_open(e->rng_seed, e->rng_game, e->rng_move, RN_ROLLOUT);
+    r.draw = e->rng_sim * 1024u;
     double wr = rollout(&g, 1.0, &r);
     *V = (float)(wp ? wr : -wr);
   } else if (e->oracle_kind == AZR_ORACLE_HASH) {
@@ -797,7 +798,7 @@ static void apply_temperature(const double* pi, int n, double tau, double* res) 
     return;
   }
   double inv = 1.0 / tau, s = 0.0;
-  for (int i = 0; i < n; ++i) { res[i] = az_pow(pi[i], inv); s += res[i]; }
+  for (int i = 0; i < n; ++i) { res[i] = rn_pow(pi[i], inv); s += res[i]; }
   for (int i = 0; i < n; ++i) res[i] = res[i] / s;
 }
 
@@ -870,7 +871,7 @@ void azr_mcts_explore(azr_mcts* e, const azr_env* game, int nsims, const double*
   double eta[AZR_AMAX];
   int acts[AZR_AMAX]; int n = available(game, acts);
   if (eta_in) memcpy(eta, eta_in, sizeof(double) * (size_t)n);
-  else { az_rng r = az_rng_make(seed, game_id, move, AZ_RNG_NOISE); az_dirichlet(&r, n, e->noise_alpha, eta); }
+  else { rn_stream r = rn_open(seed, game_id, move, RN_NOISE); rn_dirichlet(&r, n, e->noise_alpha, eta); }
   e->rng_seed = seed; e->rng_game = game_id; e->rng_move = move;
   for (int i = 0; i < nsims; ++i) {
     e->rng_sim = (uint32_t)i;
@@ -931,7 +932,7 @@ int azr_rand_categorical(const double* pi, int n, float u) {
     if (s == 0.0f) for (int i = 0; i < n; ++i) p[i] = 1.0f / (float)n;
     else for (int i = 0; i < n; ++i) p[i] = p[i] / s;
   }
-  return az_categorical_f32(p, n, u);
+  return rn_categorical(p, n, u);
 }
 void azr_apply_temperature(const double* pi, int n, double tau, double* res) { apply_temperature(pi, n, tau, res); }
 
@@ -1012,8 +1013,8 @@ int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
       /* temperature index = #moves already played (play.jl:309) */
       double tau = azr_plschedule(p->temp_xs, p->temp_ys, p->temp_len, sl->nmoves);
       apply_temperature(pi, n, tau, pis);
-      az_rng r = az_rng_make(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, AZ_RNG_MOVE);
-      int a = acts[azr_rand_categorical(pis, n, az_rng_f32(&r))];
+      rn_stream r = rn_open(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, RN_MOVE);
+      int a = acts[azr_rand_categorical(pis, n, rn_u32(&r))];
       azr_play(&sl->game, a);
       mr->action = a; mr->reward = (float)azr_white_reward(&sl->game);
       sl->nmoves++;
@@ -1115,9 +1116,9 @@ int64_t azr_arena(const azr_sim_params* pc, const azr_sim_params* pb, int altern
       memset(mr, 0, sizeof *mr);
       azr_pack_key(pc->game, &sl->game.s, mr->key);
       if (flip_probability != 0.) {                                   /* play.jl:305-307 */
-        az_rng r = az_rng_make(pc->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, AZ_RNG_FLIP);
-        if (az_rng_f64(&r) < flip_probability) {
-          int k = (int)(az_rng_f64(&r) * (double)nsym);
+        rn_stream r = rn_open(pc->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, RN_FLIP);
+        if (rn_u64(&r) < flip_probability) {
+          int k = (int)(rn_u64(&r) * (double)nsym);
           if (k >= nsym) k = nsym - 1;
           apply_symmetry(&sl->game, k);
           mr->N[AZR_AMAX] = k + 1;
@@ -1143,8 +1144,8 @@ int64_t azr_arena(const azr_sim_params* pc, const azr_sim_params* pb, int altern
       }
       double tau = azr_plschedule(p->temp_xs, p->temp_ys, p->temp_len, sl->nmoves);   /* player_temperature, play.jl:276-282; PlayerWithTemperature */
       apply_temperature(pi, n, tau, pis);
-      az_rng r = az_rng_make(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, AZ_RNG_MOVE);
-      int a = acts[azr_rand_categorical(pis, n, az_rng_f32(&r))];
+      rn_stream r = rn_open(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, RN_MOVE);
+      int a = acts[azr_rand_categorical(pis, n, rn_u32(&r))];
       azr_play(&sl->game, a);
       mr->action = a; mr->reward = (float)azr_white_reward(&sl->game);
       sl->nmoves++;
@@ -1305,7 +1306,7 @@ void azr_convert_samples(int game, int policy, const azr_sample* es, int64_t n, 
   size_t xs = (size_t)w * h * c;
   for (int64_t i = 0; i < n; ++i) {
     const azr_sample* e = &es[i];
-    W[i] = policy == 0 ? 1.0f : policy == 1 ? (float)(az_log2((double)e->n) + 1.0) : (float)e->n;
+    W[i] = policy == 0 ? 1.0f : policy == 1 ? (float)(rn_log2((double)e->n) + 1.0) : (float)e->n;
     azr_state st; azr_unpack_key(game, e->key, &st);
     azr_env g; azr_init_state(&g, game, &st);
     azr_vectorize_state(game, &st, X + xs * (size_t)i);
@@ -1345,7 +1346,7 @@ void azr_learning_status(int W_, int H_, int C_, int A, int nblocks, int F, int 
   double sw = 0., shp = 0.;
   for (int64_t i = 0; i < n; ++i) {
     sw += (double)W[i];
-    for (int a = 0; a < A; ++a) { float p = P[i * A + a]; shp += (double)(p * az_logf(p + epsf) * W[i]); }
+    for (int a = 0; a < A; ++a) { float p = P[i * A + a]; shp += (double)(p * rn_logf(p + epsf) * W[i]); }
   }
   float Wmean = (float)(sw / (double)n);                    /* mean(W), learning.jl:110 */
   float Hp = (float)(-shp / sw);                            /* entropy_wmean(P, W), :111 */
@@ -1361,8 +1362,8 @@ void azr_learning_status(int W_, int H_, int C_, int A, int nblocks, int F, int 
       float w = W[i];
       bw += (double)w;
       for (int a = 0; a < A; ++a) {
-        kl += (double)(P[i * A + a] * az_logf(ph[a] + epsf) * w);
-        hn += (double)(ph[a] * az_logf(ph[a] + epsf) * w);
+        kl += (double)(P[i * A + a] * rn_logf(ph[a] + epsf) * w);
+        hn += (double)(ph[a] * rn_logf(ph[a] + epsf) * w);
       }
       float d = vh / (float)renorm - V[i] / (float)renorm;
       mse += (double)(d * d * w);
@@ -1383,18 +1384,28 @@ void azr_learning_status(int W_, int H_, int C_, int A, int nblocks, int F, int 
 size_t azr_sizeof_sample(void) { return sizeof(azr_sample); }
 
 /* ================================ misc =================================== */
-int azr_numerics_selftest(void) { return az_numerics_selftest(); }
-float azr_expf(float x) { return az_expf(x); }
-float azr_tanhf(float x) { return az_tanhf(x); }
-double azr_log(double x) { return az_log(x); }
-double azr_exp(double x) { return az_exp(x); }
-double azr_pow(double x, double y) { return az_pow(x, y); }
-void azr_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { az_philox4x32_10(ctr, key, out); }
+int azr_numerics_selftest(void) { return rn_selftest(); }
+float azr_expf(float x) { return rn_expf(x); }
+float azr_tanhf(float x) { return rn_tanhf(x); }
+double azr_log(double x) { return rn_log(x); }
+double azr_exp(double x) { return rn_exp(x); }
+double azr_pow(double x, double y) { return rn_pow(x, y); }
+void azr_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { rn_philox(ctr, key, out); }
 void azr_dirichlet(uint64_t seed, uint32_t game, uint32_t move, int n, double alpha, double* eta) {
-  az_rng r = az_rng_make(seed, game, move, AZ_RNG_NOISE); az_dirichlet(&r, n, alpha, eta);
+  rn_stream r = rn_open(seed, game, move, RN_NOISE); rn_dirichlet(&r, n, alpha, eta);
 }
 float azr_move_uniform(uint64_t seed, uint32_t game, uint32_t move) {
-  az_rng r = az_rng_make(seed, game, move, AZ_RNG_MOVE); return az_rng_f32(&r);
+  rn_stream r = rn_open(seed, game, move, RN_MOVE); return rn_u32(&r);
+}
+double azr_log2(double x) { return rn_log2(x); }
+float azr_logf(float x) { return rn_logf(x); }
+uint64_t azr_hash_key(uint64_t a, uint64_t b) { return rn_hash_key(a, b); }
+int azr_categorical(const float* p, int n, float u) { return rn_categorical(p, n, u); }
+/* n f64 uniforms followed by n f32 uniforms of one stream (draws 0 .. 2n-1) */
+void azr_stream_uniforms(uint64_t seed, uint32_t game, uint32_t move, uint32_t purpose, int n, double* u64, float* u32) {
+  rn_stream s = rn_open(seed, game, move, purpose);
+  for (int i = 0; i < n; ++i) u64[i] = rn_u64(&s);
+  for (int i = 0; i < n; ++i) u32[i] = rn_u32(&s);
 }
 size_t azr_sizeof_state(void) { return sizeof(azr_state); }
 size_t azr_sizeof_env(void) { return sizeof(azr_env); }

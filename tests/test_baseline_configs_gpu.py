@@ -2,11 +2,14 @@
 
 The engines are created at the configurations' full slot counts and network sizes (C2: 4096 slots, 400 sims/move,
 ResNet 5x64; C3: a rank's 4096-slot shard with 600 sims/move and global game ids; C4: Mancala, 8192 slots, 800
-sims/move); a sample of whole games is compared move record by move record with the oracle's simulate (visit counts,
-sampled action, reward, node counts, simulation / traversal counters -- all integers or exact floats).  RNG streams are
+sims/move); a sample of 64 whole games per configuration (seeded draw + the longest game + the game with the most free turns) is
+compared move record by move record with the oracle's simulate (visit counts, sampled action, reward, node counts, simulation /
+traversal counters -- all integers or exact floats), and the replay-memory contents built from them (src/memory.jl:74-114).  RNG streams are
 keyed by GLOBAL game id and trees reset after every game (reset_every = 1), so a game's trace does not depend on
 how many slots run beside it (tests/test_selfplay_gpu.py::test_full_size_slot_count_independence): the sampled games
 stand for every game of the full phase.  The oracle runs its workers on host threads (OpenMP), ~30 s per case."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -17,7 +20,37 @@ pytestmark = pytest.mark.gpu
 C4_SCHED = ((0, 20, 30), (1.0, 1.0, 0.3))          # games/connect-four/params.jl:24-30, games/mancala/params.jl:23-29
 
 
-def _run_case(game_hip, game_ref, slots, groups, nsims, ngames, first_id, sched, whole_phase, full_games=None):
+NSAMPLE = 64                                        # games compared per configuration (was 8 / 6)
+
+
+def _rec(g, moves):
+    return (g.game_id, g.num_moves, g.nodes, g.total_simulations, g.total_nodes_traversed, tuple(g.final_key),
+            [(tuple(moves[g.first_move + k].key), list(moves[g.first_move + k].N), moves[g.first_move + k].action,
+              moves[g.first_move + k].reward) for k in range(g.num_moves)])
+
+
+def _free_turns(rec):
+    """moves after which the same player is to move again (Mancala's free turns, games/mancala/game.jl): bit 63 of key word 0"""
+    keys = [m[0] for m in rec[6]]
+    return sum(1 for a, b in zip(keys, keys[1:]) if (a[0] >> 63) == (b[0] >> 63))
+
+
+def _sample_ids(hip, n, seed):
+    """n game ids of the phase: the longest game, the game with the most free turns, the rest by a seeded draw"""
+    ids = sorted(hip)
+    must = {max(ids, key=lambda i: (hip[i][1], -i)), max(ids, key=lambda i: (_free_turns(hip[i]), -i))}
+    rng = np.random.default_rng(seed)
+    rest = [i for i in rng.permutation(ids).tolist() if i not in must]
+    return sorted(must | set(rest[:max(0, n - len(must))]))
+
+
+def _run_case(game_hip, game_ref, slots, groups, nsims, nsample, first_id, sched, phase_games, check_memory=False):
+    """The device plays `phase_games` games (ids first_id ...); `nsample` of them are replayed by the oracle ONE BY ONE from
+    their ids (a game's trace depends on its id alone: fresh tree per game, RNG streams keyed by game id) on host threads and
+    compared record by record.  check_memory: the sampled games' push_trace! samples, their symmetric images and the merged
+    data set (src/memory.jl:74-114) on the device against the oracle's, built from the ORACLE's records."""
+    import concurrent.futures as cf
+    import os
     import azhip
     from azhip.network import ResNetHP, random_params
     hp = ResNetHP(num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
@@ -27,55 +60,97 @@ def _run_case(game_hip, game_ref, slots, groups, nsims, ngames, first_id, sched,
                       prior_temperature=1.0, temperature=sched, reset_every=1, seed=1, num_blocks=5, num_filters=64,
                       num_policy_head_filters=32, num_value_head_filters=32) as e:
         e.net_set_params(blob)
-        n_run = full_games if whole_phase else ngames
-        games, moves, ng, nm, stats = e.selfplay_run(n_run, first_game_id=first_id)
-        assert ng == n_run
-        hip = []
-        for i in range(ngames):
-            g = games[i]
-            hip.append((g.game_id, g.num_moves, g.nodes, g.total_simulations, g.total_nodes_traversed, tuple(g.final_key),
-                        [(tuple(moves[g.first_move + k].key), list(moves[g.first_move + k].N), moves[g.first_move + k].action,
-                          moves[g.first_move + k].reward) for k in range(g.num_moves)]))
-    rg, rm, rnm = R.simulate(game_ref, R.ORACLE_NET, ngames, ngames, nsims, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0,
-                             temp_xs=sched[0], temp_ys=sched[1], reset_every=1, seed=1, net=(5, 64, 32, 32, blob),
-                             first_game_id=first_id)
-    for i in range(ngames):
-        g = rg[i]
-        ref = (g.game_id, g.num_moves, g.nodes, g.total_simulations, g.total_nodes_traversed, tuple(g.final_key),
-               [(tuple(rm[g.first_move + k].key), list(rm[g.first_move + k].N), rm[g.first_move + k].action,
-                 rm[g.first_move + k].reward) for k in range(g.num_moves)])
-        assert hip[i][:2] == ref[:2], (i, hip[i][:2], ref[:2])
-        for k, (a, b) in enumerate(zip(hip[i][6], ref[6])):
-            assert a == b, "game %d move %d: HIP %r != oracle %r" % (ref[0], k, a, b)
-        assert hip[i][:6] == ref[:6], (i, hip[i][:6], ref[:6])
+        games, moves, ng, nm, stats = e.selfplay_run(phase_games, first_game_id=first_id)
+        assert ng == phase_games and stats.aborted_games == 0
+        hip = {games[i].game_id: _rec(games[i], moves) for i in range(ng)}
+        assert sorted(hip) == list(range(first_id, first_id + phase_games))
+        ids = _sample_ids(hip, min(nsample, phase_games), seed=20260924 + nsims)
+        if check_memory:
+            sel = [i for i in range(ng) if games[i].game_id in set(ids)]     # in game-id order (az_selfplay_run sorts by id)
+            g2 = (type(games[0]) * len(sel))()
+            m2 = (type(moves[0]) * sum(games[i].num_moves for i in sel))()
+            off = 0
+            for j, i in enumerate(sel):
+                g = games[i]
+                C.memmove(C.byref(g2[j]), C.byref(g), C.sizeof(g))
+                g2[j].first_move = off
+                for k in range(g.num_moves):
+                    C.memmove(C.byref(m2[off + k]), C.byref(moves[g.first_move + k]), C.sizeof(moves[0]))
+                off += g.num_moves
+            gspec = {0: azhip.ConnectFourSpec, 1: azhip.TicTacToeSpec, 2: azhip.MancalaSpec}[game_hip]()
+            mem = azhip.MemoryBuffer(gspec, 1 << 16)
+            mem.push_records(g2, m2, len(sel), off, 1.0)
+            with mem.dataset() as d:
+                dev_raw = list(d.raw_samples())
+            with mem.dataset(use_symmetries=game_hip != 2, use_position_averaging=True, weighing_policy=1) as d:
+                dev_merged = list(d.raw_samples())
+                dev_tensors = d.tensors()
+            mem.close()
+
+    def replay(gid):
+        rg, rm, _ = R.simulate(game_ref, R.ORACLE_NET, 1, 1, nsims, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0,
+                               temp_xs=sched[0], temp_ys=sched[1], reset_every=1, seed=1, net=(5, 64, 32, 32, blob), first_game_id=gid)
+        return _rec(rg[0], rm), [rm[rg[0].first_move + k] for k in range(rg[0].num_moves)]
+    with cf.ThreadPoolExecutor(max_workers=min(len(ids), max(4, (os.cpu_count() or 8) - 2))) as ex:   # ctypes releases the GIL
+        refs = dict(zip(ids, ex.map(replay, ids)))
+    for gid in ids:
+        ref, h = refs[gid][0], hip[gid]
+        assert h[:2] == ref[:2], (gid, h[:2], ref[:2])
+        for k, (a, b) in enumerate(zip(h[6], ref[6])):
+            assert a == b, "game %d move %d: HIP %r != oracle %r" % (gid, k, a, b)
+        assert h[:6] == ref[:6], (gid, h[:6], ref[:6])
         assert sum(ref[6][0][1]) == nsims - 1                      # first move of a fresh tree: sum N = nsims - 1 (Appendix A.2)
-    return stats
+    if check_memory:
+        nA = R.NUM_ACTIONS[game_ref]
+        ref_samples = []
+        for gid in ids:                                              # push order = game-id order
+            mv = refs[gid][1]
+            arr = (R.MoveRec * len(mv))(*mv)
+            ss = R.samples_from_trace(game_ref, arr, 0, len(mv), 1.0)
+            ref_samples += [ss[k] for k in range(len(mv))]
+
+        def same(dev, ref):
+            assert len(dev) == len(ref)
+            for a, b in zip(dev, ref):
+                assert (a.key[0], a.key[1]) == (b.key[0], b.key[1]) and list(a.pi[:nA]) == list(b.pi[:nA]) and (a.z, a.t, a.n) == (b.z, b.t, b.n)
+        same(dev_raw, ref_samples)
+        merged = R.merge_by_state(game_ref, R.augment_with_symmetries(game_ref, ref_samples) if game_hip != 2 else ref_samples)
+        same(dev_merged, merged)
+        for x, y in zip(dev_tensors, R.convert_samples(game_ref, 1, merged)):
+            assert np.array_equal(x, y)
+    return stats, hip, ids
 
 
 def test_config2_connect_four_4096_slots_400_sims():
     """BASELINE configs[1]: the WHOLE 4096-game phase runs on the device (4096 slots, two slot groups as bench.py
-    does); games 0..7 are compared with the oracle."""
+    does); 64 of its games -- the longest, the one with the most consecutive moves by one side, 62 by a seeded draw -- are
+    replayed by the oracle and compared record by record, and so are their replay-memory samples (push_trace!, symmetric
+    images, merge_by_state, the Float32 tensors)."""
     import azhip
-    st = _run_case(azhip.GAME_CONNECT_FOUR, R.C4, 4096, 2, 400, 8, 0, C4_SCHED, True, full_games=4096)
-    assert st.games == 4096 and st.simulations == 400 * st.moves
+    st, hip, ids = _run_case(azhip.GAME_CONNECT_FOUR, R.C4, 4096, 2, 400, NSAMPLE, 0, C4_SCHED, 4096, check_memory=True)
+    assert st.games == 4096 and st.simulations == 400 * st.moves and len(ids) == NSAMPLE
+    assert max(h[1] for h in hip.values()) == max(hip[i][1] for i in ids)          # the longest game is in the sample
 
 
 def test_config3_rank_shard_600_sims():
     """BASELINE configs[2] as rank 3 of 8 sees it: 4096 slots, 600 sims/move, global game ids from 3 * 4096."""
     import azhip
-    _run_case(azhip.GAME_CONNECT_FOUR, R.C4, 4096, 2, 600, 6, 3 * 4096, C4_SCHED, False)
+    st, hip, ids = _run_case(azhip.GAME_CONNECT_FOUR, R.C4, 4096, 2, 600, NSAMPLE, 3 * 4096, C4_SCHED, 512)
+    assert len(ids) == NSAMPLE and min(ids) >= 3 * 4096
 
 
 def test_config4_mancala_8192_slots_800_sims():
     """BASELINE configs[3]: Mancala (variable action mask, free turns, bug-compatible flip_colors), 800 sims/move,
     an 8192-slot engine (games/mancala/params.jl:23-29: cpuct 2, eps 0.25, alpha 1, PLSchedule([0, 20, 30], [1, 1, 0.3]))."""
     import azhip
-    _run_case(azhip.GAME_MANCALA, R.MANCALA, 8192, 2, 800, 6, 0, C4_SCHED, False)
+    st, hip, ids = _run_case(azhip.GAME_MANCALA, R.MANCALA, 8192, 2, 800, NSAMPLE, 0, C4_SCHED, 512, check_memory=True)
+    most = max(hip, key=lambda i: (_free_turns(hip[i]), -i))
+    assert len(ids) == NSAMPLE and most in ids and _free_turns(hip[most]) >= 3      # free turns are exercised, and compared
 
 
 def test_config1_tictactoe_32_games_64_sims():
     """BASELINE configs[0] (the reference's own CPU-runnable case: Tic-tac-toe, 64 sims/move, 32 parallel games) on the device:
     ALL 32 games of a 32-slot engine against the oracle, record by record (search constants as in the other cases)."""
     import azhip
-    st = _run_case(azhip.GAME_TICTACTOE, R.TTT, 32, 1, 64, 32, 0, ((0,), (1.0,)), True, full_games=32)
-    assert st.games == 32 and st.simulations == 64 * st.moves
+    st, hip, ids = _run_case(azhip.GAME_TICTACTOE, R.TTT, 32, 1, 64, 32, 0, ((0,), (1.0,)), 32, check_memory=True)
+    assert st.games == 32 and st.simulations == 64 * st.moves and len(ids) == 32
