@@ -187,6 +187,142 @@ def whole_phase(azhip, dev_index, blob, hp, slots, sims, groups, games_per_slot=
 
 
 
+def _hash_phase(azhip, dev_index, games):
+    """synthetic Connect-Four positions for the replay-memory / trainer blocks: `games` short games on the hash oracle (8 sims/move)"""
+    with azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_HASH, device=dev_index, num_workers=4096, batch_size=4096,
+                      num_iters_per_turn=8, reset_every=1, dirichlet_noise_eps=0.25, cpuct=1.0, temperature=([0], [1.0])) as e:
+        return e.selfplay_run(games)
+
+
+def trainer_block(azhip, dev_index, filters, steps=60, batch=1024):
+    """the optimiser step batch_updates! (src/learning.jl:123-141) at the reference's learning parameters
+    (games/connect-four/params.jl:46-58: Adam 2e-3, L2 1e-4, batch 1024, LOG_WEIGHT), train-mode forward + backward + update on
+    the device.  FLOPs = forward + data gradient + weight gradient of every convolution, dense count (the padded taps are
+    skipped by the kernels, so the machine fraction is a lower bound on the dense-equivalent one)."""
+    gspec = azhip.ConnectFourSpec()
+    games, moves, ng, nm, _ = _hash_phase(azhip, dev_index, 8192)
+    mem = azhip.MemoryBuffer(gspec, 4 * nm, device=dev_index)
+    try:
+        mem.push_records(games, moves, ng, nm, 1.0)
+        hp = azhip.ResNetHP(num_blocks=5, num_filters=filters, num_policy_head_filters=32, num_value_head_filters=32)
+        nn = azhip.ResNet(gspec, hp, seed=1)
+        lp = azhip.LearningParams(samples_weighing_policy=azhip.LOG_WEIGHT, l2_regularization=1e-4, loss_computation_batch_size=1024,
+                                  batch_size=batch, optimiser=azhip.Adam(lr=2e-3))
+        with azhip.Trainer(gspec, nn, mem, lp, use_symmetries=True, device=dev_index) as tr:
+            tr.batch_updates(3)
+            t0 = time.perf_counter()
+            ls = tr.batch_updates(steps)
+            dt = time.perf_counter() - t0
+            n = tr.num_samples()
+    finally:
+        mem.close()
+    flop = 3 * 2 * batch * 42 * filters * (9 * 3 + 2 * 5 * 9 * filters + 64)
+    tf = flop / (dt / steps) / 1e12
+    return {"workload": "batch_updates! (train-mode forward, backward, Adam): Connect-Four, ResNet 5x%d fp32, batch %d, %d merged boards" % (filters, batch, n),
+            "ms_per_step": 1e3 * dt / steps, "steps": steps, "samples_per_sec": batch * steps / dt, "dtype": "f32",
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+                         "flop_per_step": flop, "note": "dense FLOPs of forward + data gradient + weight gradient of all convolutions; heads' dense layers not counted"},
+            "loss_first_last": [float(ls[0]), float(ls[-1])]}
+
+
+def memory_block(azhip, dev_index, games=16384):
+    """replay memory on the device -- push_trace! (src/memory.jl:74-87) of a phase's records, then the
+    Trainer's data set: augment_with_symmetries, merge_by_state, convert_samples (src/memory.jl:89-114, src/learning.jl:98-121).
+    HBM-bound integer/byte work: GB/s = bytes the algorithm touches (64 B record in, 112 B sample out; data set: every augmented
+    sample read and written by two 128-bit sort passes of 16-byte pairs + the gather, tensors written once) / time."""
+    gspec = azhip.ConnectFourSpec()
+    g, m, ng, nm, _ = _hash_phase(azhip, dev_index, games)
+    mem = azhip.MemoryBuffer(gspec, 4 * nm, device=dev_index)
+    try:
+        mem.push_records(g, m, ng, nm, 1.0)
+        mem.empty()
+        t0 = time.perf_counter()
+        mem.push_records(g, m, ng, nm, 1.0)
+        t_push = time.perf_counter() - t0
+        d = mem.dataset(use_symmetries=True, use_position_averaging=True, weighing_policy=azhip.LOG_WEIGHT)
+        d.close()
+        t0 = time.perf_counter()
+        d = mem.dataset(use_symmetries=True, use_position_averaging=True, weighing_policy=azhip.LOG_WEIGHT)
+        t_ds = time.perf_counter() - t0
+        merged = len(d)
+        d.close()
+    finally:
+        mem.close()
+    aug = 2 * nm
+    # bytes touched: augment nm x 112 read + aug x 112 written; 16 radix passes over aug x 12 B (key half + index) read + written;
+    # merge: aug x 112 read, merged x 112 written; tensors: merged x (112 read + (1 + 126 + 7 + 7 + 1) x 4 written)
+    ds_bytes = nm * 112 + aug * 112 + 16 * 2 * aug * 12 + aug * 112 + merged * 112 + merged * (112 + 142 * 4)
+    return {"workload": "replay memory on the device: %d games, %d positions (hash oracle, 8 sims/move)" % (ng, nm),
+            "push_trace": {"samples": nm, "ms": 1e3 * t_push, "samples_per_sec": nm / t_push, "note": "includes the 64 B / position H2D copy of host records; az_memory_push_engine (device-only phases) skips it"},
+            "data_set": {"samples_in": nm, "augmented": aug, "merged_boards": merged, "ms": 1e3 * t_ds, "samples_per_sec": nm / t_ds,
+                         "roofline": {"bound": "hbm", "achieved": ds_bytes / t_ds / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ds_bytes / t_ds / 1e9 / PEAK_HBM_GBS,
+                                      "algorithmic_bytes": ds_bytes, "note": "wall time of the call (host loop, launches and synchronisations included)"}}}
+
+
+def arena_block(azhip, dev_index, filters=128, games=128, sims=600):
+    """one checkpoint evaluation compare_networks (src/training.jl:159-172) at the reference's arena
+    parameters (games/connect-four/params.jl:31-44): 128 games on 128 workers, 600 sims/move, two ResNet 5x128, flip 0.5,
+    colours alternated, ConstSchedule(0.2), eps 0.05."""
+    gspec = azhip.ConnectFourSpec()
+    hp = azhip.ResNetHP(num_blocks=5, num_filters=filters, num_policy_head_filters=32, num_value_head_filters=32)
+    c, b = azhip.ResNet(gspec, hp, seed=1), azhip.ResNet(gspec, hp, seed=2)
+    mp = azhip.MctsParams(num_iters_per_turn=sims, cpuct=2.0, dirichlet_noise_ϵ=0.05, dirichlet_noise_α=1.0, temperature=azhip.ConstSchedule(0.2))
+    params = azhip.ArenaParams(mcts=mp, sim=azhip.SimParams(num_games=games, num_workers=games, batch_size=games, use_gpu=True, reset_every=2,
+                                                            flip_probability=0.5, alternate_colors=True), update_threshold=0.05)
+    t0 = time.perf_counter()
+    ev = azhip.compare_networks(gspec, c, b, params, device=dev_index)
+    dt = time.perf_counter() - t0
+    return {"workload": "compare_networks: %d games, %d workers, %d sims/move, two ResNet 5x%d fp32 (random weights)" % (games, games, sims, filters),
+            "seconds": dt, "seconds_inside_simulate": ev.time, "avgr": ev.avgr, "redundancy": ev.redundancy}
+
+
+def iteration_block(azhip, dev_index, num_games=5000, workers=4096):
+    """ONE training iteration (train!'s loop body, src/training.jl:321-333) at the reference's shipped Connect-Four parameters
+    (games/connect-four/params.jl:5-75): self_play_step! 5000 games x 600 sims with ResNet 5x128 (reset_every 2, PLSchedule
+    temperature, eps 0.25) -> push_trace! -> learning_step!: Trainer data set (symmetries, merge, tensors), learning_status,
+    batch_updates! (Adam 2e-3, batch 1024, min_checkpoints_per_epoch 1, max_batches_per_checkpoint 2000, 1 checkpoint),
+    learning_status, compare_networks (128 games).  Random initial weights, everything on the device.  Deviation from the shipped
+    file: num_workers %d / batch_size %d instead of 128 / 64 -- the worker count is a throughput knob of the engine (it enters the
+    results only through which games share a tree under reset_every 2); extra.workers_128_5x128 has the 128-worker rate."""
+    from azhip.training import SelfPlayParams, learning_step, self_play_step_device
+    gspec = azhip.ConnectFourSpec()
+    hp = azhip.ResNetHP(num_blocks=5, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32)
+    best = azhip.ResNet(gspec, hp, seed=1)
+    cur = best.copy_()
+    mcts = azhip.MctsParams(num_iters_per_turn=600, cpuct=2.0, prior_temperature=1.0, temperature=azhip.PLSchedule([0, 20, 30], [1.0, 1.0, 0.3]),
+                            dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0)
+    sp = SelfPlayParams(mcts=mcts, sim=azhip.SimParams(num_games=num_games, num_workers=workers, batch_size=workers // 2, use_gpu=True, reset_every=2,
+                                                      flip_probability=0.0, alternate_colors=False))
+    amcts = azhip.MctsParams(num_iters_per_turn=600, cpuct=2.0, prior_temperature=1.0, temperature=azhip.ConstSchedule(0.2), dirichlet_noise_ϵ=0.05, dirichlet_noise_α=1.0)
+    arena = azhip.ArenaParams(mcts=amcts, sim=azhip.SimParams(num_games=128, num_workers=128, batch_size=128, use_gpu=True, reset_every=2,
+                                                               flip_probability=0.5, alternate_colors=True), update_threshold=0.05)
+    lp = azhip.LearningParams(use_position_averaging=True, samples_weighing_policy=azhip.LOG_WEIGHT, batch_size=1024, loss_computation_batch_size=1024,
+                              optimiser=azhip.Adam(lr=2e-3), l2_regularization=1e-4, nonvalidity_penalty=1.0, min_checkpoints_per_epoch=1,
+                              max_batches_per_checkpoint=2000, num_checkpoints=1)
+    mem = azhip.MemoryBuffer(gspec, 400000, device=dev_index)        # mem_buffer_size at iteration 0
+    try:
+        t0 = time.perf_counter()
+        rep = self_play_step_device(gspec, best, sp, mem, seed=1)
+        t_sp = time.perf_counter() - t0
+        samples = len(mem)
+        t_sim = samples / rep.samples_gen_speed if rep.samples_gen_speed > 0 else t_sp   # simulate_distributed alone (training.jl:284-287)
+        t0 = time.perf_counter()
+        cur, best, lr = learning_step(gspec, cur, best, mem, lp, arena, use_symmetries=True, seed=1)
+        t_learn = time.perf_counter() - t0
+    finally:
+        mem.close()
+    total = t_sp + t_learn
+    phases = {"self_play (simulate)": t_sim, "push_trace! + memory report": t_sp - t_sim, "data set (symmetries, merge, tensors)": lr.time_convert,
+              "learning_status (x2)": lr.time_loss + max(0.0, t_learn - lr.time_convert - lr.time_loss - lr.time_train - lr.time_eval),
+              "batch_updates!": lr.time_train, "arena (compare_networks)": lr.time_eval}
+    return {"workload": iteration_block.__doc__.split("\n")[0].strip() + " -- games/connect-four/params.jl:5-75, %d workers" % workers,
+            "seconds": total, "games": num_games, "samples": samples, "sims_per_sec_self_play": samples * 600 / t_sim,
+            "optimiser_steps": int(len(lr.losses)), "loss_first_last": [float(lr.losses[0]), float(lr.losses[-1])] if len(lr.losses) else None,
+            "arena_avgr": lr.checkpoints[0].evaluation.avgr if lr.checkpoints else None, "nn_replaced": bool(lr.nn_replaced),
+            "phases_seconds": phases, "phases_share": {k: v / total for k, v in phases.items()},
+            "reference": "README.md:76-78: 'about one hour' per iteration on the authors' desktop GPU -- quoted, NOT reproduced here (no Julia in the image)"}
+
+
 def pmc_traffic(kernel, boards_per_launch):
     """HBM bytes per tower launch from THIS round's PMC passes of this workload (profiles/r2/pmc_tower_summary.json,
     written by tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs; KB units, FETCH doubled
@@ -368,6 +504,8 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="interleaved slot groups = num_workers / batch_size: 2 (default) overlaps the tree kernels of one half-batch with the network of the other, the reference's num_workers = 2 x batch_size; 1 = one 4096-leaf batch per wave")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra configurations (whole phase, C3, C4 Mancala, bf16 10x128, 128 workers) reported under `extra`")
+    ap.add_argument("--no-iteration", action="store_true", help="skip extra.iteration (one whole training iteration at the reference's shipped Connect-Four parameters, ~1-2 min)")
+    ap.add_argument("--iteration", action="store_true", help="run ONLY the headline and extra.iteration (skips the other extras and the CPU baseline)")
     ap.add_argument("--backend", default="gloo", help="torch.distributed backend of the RENDEZVOUS for N > 1: a barrier, two scalar reductions and the 128-byte RCCL id are all that goes through it, so gloo (CPU) is the default and the process holds exactly ONE RCCL instance, the one libazhip.so loads for az_comm_*; nccl = torch's bundled RCCL as well")
     ap.add_argument("--no-prof", action="store_true", help="do not wrap launches in HIP events")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel class (default: only the dominant kernel, k_tower)")
@@ -534,13 +672,20 @@ def main():
                                                            note="the reference's shipped self-play parameters (games/connect-four/params.jl:7-30: 128 workers, 5x128)")),
             ]
             blocks.append(("c5_host_stepped", lambda: host_stepped_c5()))
+            # SURVEY §8(f) rows, driver-observed
+            blocks += [("trainer_5x64", lambda: trainer_block(azhip, dev_index, 64)), ("trainer_5x128", lambda: trainer_block(azhip, dev_index, 128)),
+                       ("memory_pipeline", lambda: memory_block(azhip, dev_index)), ("arena_128", lambda: arena_block(azhip, dev_index))]
+            if not args.no_iteration:
+                blocks.append(("iteration", lambda: iteration_block(azhip, dev_index)))
+            if args.iteration:
+                blocks = [b for b in blocks if b[0] == "iteration"]
             out["extra"] = {}
             for name, fn in blocks:
                 try:
                     out["extra"][name] = fn()
                 except Exception as ex:
                     out["extra"][name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.iteration:
             out["cpu_baseline"] = cpu_baseline(blob, hp, args.sims)
         print(json.dumps(out), flush=True)
     if gather_hung:
