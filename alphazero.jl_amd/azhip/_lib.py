@@ -62,7 +62,7 @@ class TraceBuf(C.Structure):
 class SelfplayStats(C.Structure):
     _fields_ = [("simulations", C.c_int64), ("nodes_traversed", C.c_int64), ("leaf_evals", C.c_int64),
                 ("moves", C.c_int64), ("games", C.c_int64), ("waves", C.c_int64), ("seconds", C.c_double),
-                ("aborted_games", C.c_int64)]
+                ("aborted_games", C.c_int64), ("tower_fallbacks", C.c_int64)]
 
 
 class Prof(C.Structure):

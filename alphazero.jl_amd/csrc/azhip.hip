@@ -36,6 +36,22 @@ extern "C" int az_abi_struct_size(int32_t which) {
   return -1;
 }
 
+// Streams of this process that may launch split towers (k_tower16s) on a device at the same time: the sum of the slot groups of
+// all live engines with 128-filter fp32 networks (an arena drives two engines side by side).  pick_tower keeps the split only
+// while all of them together fit the chip, so that every pair of workgroups is co-resident.
+static std::mutex g_split_mu;
+static std::map<int, int> g_split_streams;
+int split_streams_on_device(int device) {
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  auto it = g_split_streams.find(device);
+  return it == g_split_streams.end() ? 0 : it->second;
+}
+static void split_register(az_engine* e, int n) {
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  g_split_streams[e->device] += n - e->split_registered;
+  e->split_registered = n;
+}
+
 int check_device_error(az_engine* e) {
   int code = 0;
   AZCHK(sync_groups(e));
@@ -94,6 +110,8 @@ extern "C" int az_engine_destroy(az_engine* e) {
     (void)hipEventDestroy(e->ev_tree[g]); (void)hipEventDestroy(e->ev_net[g]);
   }
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  split_register(e, 0);
+  if (e->h_xflag) (void)hipHostFree(e->h_xflag);
   drop_wave_graphs(e);
   for (auto& r : e->prof_pool) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
   for (void* q : e->net_allocs) (void)hipFree(q);
@@ -205,6 +223,8 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0; e->alloc_bytes = 0;
   e->vm_base = nullptr; e->vm_bytes = 0; e->vm_chunk = 0; e->vm_rows = 0; e->vm_chunk_nodes = 0; e->d_slot_cap = nullptr; e->vm_budget = 0; e->vm_mapped = 0;
   e->next_exec = 1.0;
+  e->h_xflag = nullptr; e->d_xflag = nullptr; e->split_off = false; e->split_registered = 0; e->xch_launches = 0;
+  { const char* fa = getenv("AZHIP_XCH_FAIL_AT"); e->xch_fail_at = fa ? atoll(fa) : 0; }
   e->net_loaded = false; e->running = false; e->prof_on = false; { const char* ug = getenv("AZHIP_GRAPH"); e->use_graphs = ug ? atoi(ug) : 0; }
   e->d_phase = nullptr; e->phase_cap = 0; e->phase_n = 0; e->host_moves = true; e->last_tower[0] = 0; e->prof_mask = 0; e->prof_used = 0;
   memset(&e->prof, 0, sizeof e->prof);
@@ -276,6 +296,13 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &v.Pout, (size_t)std::max(G, 1) * gi.APAD)); AZCHK(dalloc(e, &v.Vout, G));
     AZCHK(dalloc(e, &v.trace, (size_t)G * v.max_moves)); AZCHK(dalloc(e, &v.grec, G));
     AZCHK(dalloc(e, &v.finished, G)); AZCHK(dalloc(e, &v.err, 1));
+    // split tower fallback: one exchange word per slot group (+ one nobody sets for the whole-engine view), the counters of the
+    // k_tree launches that stood still meanwhile, and a host-mapped word the kernel raises so that the host notices without a sync
+    AZCHK(dalloc(e, &e->d_xerr, AZ_MAX_GROUPS + 1)); AZCHK(dalloc(e, &e->d_skipped, 2 * (AZ_MAX_GROUPS + 1)));
+    v.xerr = e->d_xerr + AZ_MAX_GROUPS; v.skipped = e->d_skipped + 2 * AZ_MAX_GROUPS;
+    HIPCHK(hipHostMalloc((void**)&e->h_xflag, sizeof(int), hipHostMallocMapped));
+    *e->h_xflag = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&e->d_xflag, e->h_xflag, 0));
 
     // staging
     e->io_cap = std::max(G, 4096);
@@ -322,6 +349,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       gv.ht += o * hs; gv.nodes += o * v.node_stride; gv.path += o * v.max_depth;
       if (gv.slot_cap) gv.slot_cap += o;
       gv.leaf_env += o; gv.eval_slots += o;
+      gv.xerr = e->d_xerr + g; gv.skipped = e->d_skipped + 2 * g;
       gv.n_eval += 2 * g; gv.keys += o * (size_t)cap * 4; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;
       if (ng == 1) { e->gs[g] = e->gt[g] = e->stream; }
@@ -345,6 +373,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     p.prior_temp = c->prior_temperature; p.nsims = c->num_iters_per_turn; p.temp_len = c->temperature_len;
     for (int i = 0; i < AZ_SCHED_MAX; ++i) { p.temp_xs[i] = c->temperature_xs[i]; p.temp_ys[i] = c->temperature_ys[i]; }
     p.seed = c->seed; p.oracle = c->oracle; p.reset_every = c->reset_every; p.retire = 0;
+    if (c->oracle == AZ_ORACLE_RESNET && c->num_filters == 128 && !c->net_bf16) split_register(e, e->ngroups);
     if (e->vm_rows) {
       // Budget of the growing pool: what the device has left AFTER this engine's fixed allocations, minus what is
       // still to come -- the phase buffer of a bounded phase (num_workers x 4 games of move records is the usual order), the
@@ -705,6 +734,23 @@ extern "C" int az_net_get_params(const az_engine* e, float* blob, int64_t n) {
   return AZ_OK;
 }
 
+// The network seam (one launch at a time on the engine's stream): did the split tower of the launch just enqueued give up?  If
+// so the split is switched off for this engine, the error is cleared and the caller launches again (k_tower16<NT = 3>: the same
+// bits).  Costs a stream synchronisation, only while this engine has ever used the split tower.
+static bool split_gave_up(az_engine* e) {
+  if (!e->xch_epoch || e->split_off) return false;
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+  if (!*(volatile int*)e->h_xflag) return false;
+  int code = 0;
+  if (hipMemcpy(&code, e->v.err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || code != DERR_EXCHANGE) return false;
+  code = 0;
+  (void)hipMemcpy(e->v.err, &code, sizeof(int), hipMemcpyHostToDevice);
+  *e->h_xflag = 0;
+  e->split_off = true;
+  e->stats.tower_fallbacks++;
+  return true;
+}
+
 extern "C" int az_net_forward(az_engine* e, const float* X, const float* A, int32_t N, float* P, float* V, float* Pinv) {
   ENGINE(e);
   if (!e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
@@ -716,6 +762,7 @@ extern "C" int az_net_forward(az_engine* e, const float* X, const float* A, int3
     HIPCHK(hipMemcpyAsync(e->d_X, X + xs * off, sizeof(float) * xs * m, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_A, A + (size_t)gi.A * off, sizeof(float) * gi.A * m, hipMemcpyHostToDevice, e->stream));
     AZCHK(net_launch(e, e->stream, true, e->d_hfeat, nullptr, nullptr, nullptr, m, e->d_X, e->d_A, e->d_P, e->d_V, e->d_Pinv, gi.A));
+    if (split_gave_up(e)) AZCHK(net_launch(e, e->stream, true, e->d_hfeat, nullptr, nullptr, nullptr, m, e->d_X, e->d_A, e->d_P, e->d_V, e->d_Pinv, gi.A));
     HIPCHK(hipMemcpyAsync(P + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(V + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
     if (Pinv) HIPCHK(hipMemcpyAsync(Pinv + off, e->d_Pinv, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
@@ -736,6 +783,7 @@ static int evaluate_envs(az_engine* e, const std::vector<GEnv>& envs, std::vecto
     HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data() + off, sizeof(GEnv) * m, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_ntmp, &m, sizeof(int), hipMemcpyHostToDevice, e->stream));
     AZCHK(net_launch(e, e->stream, false, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A));
+    if (split_gave_up(e)) AZCHK(net_launch(e, e->stream, false, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A));
     HIPCHK(hipMemcpyAsync(P.data() + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(V.data() + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -758,6 +806,7 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
     HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * m, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_ntmp, &m, sizeof(int), hipMemcpyHostToDevice, e->stream));
     AZCHK(net_launch(e, e->stream, false, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A));
+    if (split_gave_up(e)) AZCHK(net_launch(e, e->stream, false, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A));
     HIPCHK(hipMemcpyAsync(P + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(V + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -772,23 +821,59 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
 // this wave's select + leaf gathering) -> oracle.  Nothing is read back by the host.  The simulation a wave starts is
 // completed by the group's next k_tree launch: the next wave's, or flush_pending's.
 // sim_idx: index of this simulation within the current explore! (keys the rollout oracle's RNG stream)
-template <class Gm> static int wave(az_engine* e, int ngroups_active, uint32_t sim_idx) {
+template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx) {
   constexpr int L = Gm::APAD;
+  const DView& v = e->gv[g];
+  hipStream_t st = e->gs[g], sn = e->gt[g];
+  const bool split = st != sn;
+  const int G = v.G;
+  const int gb = (G * L + 255) / 256;
+  const int par = (e->wave_par[g] ^= 1);
+  LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_tree<Gm>), gb, 256, 0, v, e->p, e->pending[g] ? 1 : 0, 1, par);
+  e->pending[g] = true;
+  if (e->cfg.oracle == AZ_ORACLE_RESNET) {
+    AZCHK(net_wave(e, g, split, e->group_active[g]));
+  } else {
+    LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p, sim_idx, par);
+  }
+  return AZ_OK;
+}
+// A split tower (k_tower16s) whose exchange gave up -- the partner workgroup was not co-resident: another engine, a trainer or
+// another process holds the CUs -- must not cost the phase.  The kernel raises a host-mapped word; every k_tree of
+// that slot group launched since has stood still and been counted (tree.h), every split tower has returned at once.  Here: wait
+// for the device, switch the split off for this engine, evaluate the pending leaves of every group again without it (all tower
+// forms give the same bits, so this is idempotent) and launch the waves that stood still once more.  Returns with the engine in
+// the state the caller believes it is in.
+template <class Gm> static int recover_split(az_engine* e) {
+  AZCHK(sync_all(e));
+  *e->h_xflag = 0;
+  int xerr[AZ_MAX_GROUPS + 1], skipped[2 * (AZ_MAX_GROUPS + 1)];
+  HIPCHK(hipMemcpy(xerr, e->d_xerr, sizeof xerr, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(skipped, e->d_skipped, sizeof skipped, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemsetAsync(e->d_xerr, 0, sizeof xerr, e->stream));
+  HIPCHK(hipMemsetAsync(e->d_skipped, 0, sizeof skipped, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));                           // before anything is launched on the groups' own streams
+  bool any = false;
+  for (int g = 0; g < e->ngroups; ++g) any = any || xerr[g] == DERR_EXCHANGE;
+  if (!any) return AZ_OK;                                            // raised by the network seam's launch: split_gave_up handles that one
+  e->split_off = true;
+  e->stats.tower_fallbacks++;
+  for (int g = 0; g < e->ngroups; ++g) {
+    e->wave_par[g] ^= (skipped[2 * g] & 1);                          // back to the leaf counter of the last wave that really ran
+    if (skipped[2 * g + 1]) e->pending[g] = true;                    // its expand + backup did not happen
+  }
+  if (e->cfg.oracle == AZ_ORACLE_RESNET)
+    for (int g = 0; g < e->ngroups; ++g)
+      if (e->pending[g] && e->group_active[g] > 0) AZCHK(net_wave(e, g, e->gs[g] != e->gt[g], e->group_active[g]));
+  for (int g = 0; g < e->ngroups; ++g)
+    for (int i = 0; i < skipped[2 * g]; ++i) AZCHK(wave_group<Gm>(e, g, 0));
+  return AZ_OK;
+}
+template <class Gm> static int wave(az_engine* e, int ngroups_active, uint32_t sim_idx) {
+  if (*(volatile int*)e->h_xflag) AZCHK(recover_split<Gm>(e));
   for (int g = 0; g < ngroups_active; ++g) {
     if (e->group_active[g] == 0) continue;                         // nothing left to search in this group
-    const DView& v = e->gv[g];
-    hipStream_t st = e->gs[g], sn = e->gt[g];
-    const bool split = st != sn;
-    const int G = v.G;
-    const int gb = (G * L + 255) / 256;
-    const int par = (e->wave_par[g] ^= 1);
-    LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_tree<Gm>), gb, 256, 0, v, e->p, e->pending[g] ? 1 : 0, 1, par);
-    e->pending[g] = true;
-    if (e->cfg.oracle == AZ_ORACLE_RESNET) {
-      AZCHK(net_wave(e, g, split, e->group_active[g]));
-    } else {
-      LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p, sim_idx, par);
-    }
+    AZCHK(wave_group<Gm>(e, g, sim_idx));
   }
   e->stats.waves++;
   return AZ_OK;
@@ -918,6 +1003,10 @@ template <class Gm> static int explore_end(az_engine* e, int nga) {
   if (!nga) return AZ_OK;
   AZCHK(flush_pending<Gm>(e));                                     // the last simulation's expand + backup
   AZCHK(sync_groups(e));
+  if (e->xch_epoch && !e->split_off) {                              // split towers have run: did one give up? (the word is only valid once the device is idle)
+    AZCHK(sync_all(e));
+    if (*(volatile int*)e->h_xflag) { AZCHK(recover_split<Gm>(e)); AZCHK(flush_pending<Gm>(e)); AZCHK(sync_all(e)); }
+  }
   hipLaunchKernelGGL(k_slot_records, dim3((e->v.G + 255) / 256), dim3(256), 0, e->stream, e->v, (int)SR_CLEAR_ACTIVE);
   return check_device_error(e);
 }
@@ -1067,6 +1156,10 @@ template <class Gm> static int move_round(az_engine* e) {
   const int G = e->v.G;
   AZCHK(flush_pending<Gm>(e));                                     // explore! is over: the last simulation's expand + backup
   AZCHK(sync_groups(e));
+  if (e->xch_epoch && !e->split_off) {                              // split towers have run: did one give up? (the word is only valid once the device is idle)
+    AZCHK(sync_all(e));
+    if (*(volatile int*)e->h_xflag) { AZCHK(recover_split<Gm>(e)); AZCHK(flush_pending<Gm>(e)); AZCHK(sync_all(e)); }
+  }
   LAUNCH(e, AZ_K_MOVE, G, (k_move<Gm>), (G + 255) / 256, 256, 0, e->v, e->p);
   HIPCHK(hipMemcpyAsync(e->h_finished.data(), e->v.finished, sizeof(int) * G, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->h_grec.data(), e->v.grec, sizeof(az_game_rec) * G, hipMemcpyDeviceToHost, e->stream));

@@ -12,6 +12,7 @@
 #include <new>
 #include <string>
 #include <map>
+#include <mutex>
 #include <vector>
 #include <unordered_set>
 
@@ -77,6 +78,12 @@ struct az_engine {
   float* g_hfeat[AZ_MAX_GROUPS];
   // k_tower16s (split tower, 128 filters): publish areas per feature buffer (slot g = group g, AZ_MAX_GROUPS = d_hfeat), launch epoch
   unsigned long long* xch[AZ_MAX_GROUPS + 1]; unsigned long long xch_epoch;
+  // (r4) a split tower whose exchange gives up degrades instead of failing the phase (azhip.hip recover_split)
+  int* d_xerr; int* d_skipped;   // [AZ_MAX_GROUPS + 1] exchange words, [..][2] counters of idle k_tree launches (DView::xerr / skipped)
+  int* h_xflag; int* d_xflag;    // host-mapped word the kernel sets when an exchange gives up; looked at before every launch
+  bool split_off;                // the split is disabled for this engine after the first time
+  long long xch_fail_at, xch_launches;   // AZHIP_XCH_FAIL_AT = n: the n-th split launch loses a partner (fault injection for the tests)
+  int split_registered;          // streams this engine contributes to the device's count of split-tower users
   std::vector<void*> allocs;
   size_t alloc_bytes;              // device bytes behind `allocs` (az_engine_device_bytes)
   // node pool mapped on demand (azhip.hip "node pool"): a virtual range of rows x G chunks of 2 MB; chunk (row r, slot s) is
@@ -204,6 +211,9 @@ inline int prof_end(az_engine* e, hipStream_t st, int cls) {
 
 // azhip.hip: waits for the engine's streams and turns a device-side error code (tree.h DERR_*, resnet16.h DERR_EXCHANGE) into a status
 int check_device_error(az_engine* e);
+
+// azhip.hip: how many streams of this process may launch split towers on `device` at the same time (all engines with 128 filters)
+int split_streams_on_device(int device);
 
 // ---- net.hip: every instantiation of the tower / heads kernels lives there ----------------------------------
 int net_set_kernel_attrs(az_engine* e);   // + uploads the row permutation tables of the tower kernels (e->d_geo)

@@ -41,7 +41,7 @@ static int tower_timeline_split(az_engine* e, int32_t n, unsigned long long* out
     nd.dbg = rep ? d : nullptr;
     AZCHK(xch_slot<ConnectFour>(e, e->d_hfeat, &xa, &ep));
     hipLaunchKernelGGL((k_tower16s<ConnectFour, 128, false>), dim3(nb), dim3(T::THREADS), T::BYTES, e->stream, nd, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat,
-                       xa, ep, e->v.err);
+                       xa, ep, e->v.err, e->d_xflag);
   }
   HIPCHK(hipMemcpyAsync(out, d, sizeof(unsigned long long) * nb * 8, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -104,7 +104,7 @@ extern "C" int az_debug_exchange_timeout(az_engine* e) {
   unsigned long long* xa; unsigned long long ep;
   AZCHK(xch_slot<ConnectFour>(e, e->d_hfeat, &xa, &ep));
   hipLaunchKernelGGL((k_tower16s<ConnectFour, 128, false>), dim3(2 * n), dim3(T::THREADS), T::BYTES, e->stream, e->net16, e->d_tmp_env, e->d_iota, e->d_ntmp, n, (const float*)nullptr, e->d_hfeat,
-                     xa, ep | (1ull << 63), e->v.err);
+                     xa, ep | (1ull << 63), e->v.err, e->d_xflag);
   return check_device_error(e);
 }
 // debug aid: out == NULL -> from now on the first wavefront of every k_tree launch of group 0 leaves 8 cycle stamps

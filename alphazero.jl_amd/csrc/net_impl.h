@@ -84,8 +84,10 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
   // split tower (k_tower16s, 128 filters): both workgroups of every pair must be resident at once -> all slot groups'
   // launches together at most num_cu workgroups (beyond that the towers queue for CUs and the split only costs: 256
   // slots in two groups 0.62 vs 0.71 M sims/s); its kernel arguments change per launch (epoch): not under hipGraph replay
-  const bool can_split = F == 128 && !e->cfg.net_bf16 && !e->use_graphs && e->cfg.num_blocks <= 127 &&
-                         2 * std::max(1, e->ngroups) * ((n + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB) <= (e->num_cu > 0 ? e->num_cu : 256);
+  // (r4) the count runs over ALL engines of the process on this device that may launch split towers side by side (an arena has
+  // two); an engine whose exchange has given up once (another process, a trainer: work this count cannot see) stays unsplit
+  const bool can_split = F == 128 && !e->cfg.net_bf16 && !e->use_graphs && e->cfg.num_blocks <= 127 && !e->split_off &&
+                         2 * std::max(std::max(1, e->ngroups), split_streams_on_device(e->device)) * ((n + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB) <= (e->num_cu > 0 ? e->num_cu : 256);
   if (e->tower_pick == 2 && can_split) return 2;
   if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64))) return e->tower_pick;
   if (e->cfg.net_bf16) {                                           // k_tower16b: 22 (128 filters), 11 or 3 row tiles
@@ -165,6 +167,7 @@ template <class Gm> static int xch_slot(az_engine* e, const float* hfeat, unsign
   }
   *xch = e->xch[slot];
   *epoch = ++e->xch_epoch;
+  if (e->xch_fail_at > 0 && ++e->xch_launches == e->xch_fail_at) *epoch |= 1ull << 63;   // tests: this launch loses a partner (AZHIP_XCH_FAIL_AT)
   return AZ_OK;
 }
 // Dense heads of n_max boards: 16-board tiles (k_heads16: a quarter of the chain latency, 23 instead of 43 us per launch
@@ -212,7 +215,7 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
       unsigned long long* xa; unsigned long long ep;
       AZCHK(xch_slot<Gm>(e, hfeat, &xa, &ep));
       LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16s<Gm, F, FROM_PLANES>), 2 * ((n_max + TB3 - 1) / TB3), (T16S<Gm, F>::THREADS), LDS3, e->net16, envs, eslots, n_ptr, n_max, X, hfeat,
-                xa, ep, e->v.err);
+                xa, ep, e->v.err, e->d_xflag);
     }
   } else if (tw == 21) {
     if constexpr (F == 64)
@@ -262,7 +265,7 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
       unsigned long long* xa; unsigned long long ep;
       AZCHK(xch_slot<Gm>(e, e->g_hfeat[g], &xa, &ep));
       LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16s<Gm, F, false>), 2 * ((N + TB3 - 1) / TB3), (T16S<Gm, F>::THREADS), LDS3, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g],
-                xa, ep, e->v.err);
+                xa, ep, v.xerr, e->d_xflag);
     }
   } else if (tw == 21) {
     if constexpr (F == 64)

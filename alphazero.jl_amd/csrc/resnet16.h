@@ -444,6 +444,7 @@ struct PairXch {
   const unsigned long long* theirs;
   uint32_t tag0;                     // launch epoch << 8
   int* err;
+  int* hflag;                        // host-visible copy of "an exchange gave up" (the host looks at it before every launch, no sync)
   int pch;                           // the partner lane's output channel
   static constexpr bool EARLY_PUBLISH = true;        // outputs leave for the partner before the workgroup's own barrier
   template <class T, int NT>
@@ -477,7 +478,11 @@ struct PairXch {
       if ((++spins & 255) == 0) {
         const unsigned long long now = wall_clock64();
         if (!t_start) t_start = now;
-        else if (now - t_start > XCH_WAIT_TICKS) { atomicCAS(err, 0, (int)DERR_EXCHANGE); break; }
+        else if (now - t_start > XCH_WAIT_TICKS) {
+          atomicCAS(err, 0, (int)DERR_EXCHANGE);
+          if (hflag) __hip_atomic_store(hflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
       }
     }
     const int ppos = posF<F>(pch);
@@ -718,7 +723,7 @@ template <class Gm, int F, bool FROM_PLANES>
 __global__ void __launch_bounds__((T16S<Gm, F>::THREADS), 1)
 k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat,
-           unsigned long long* __restrict__ xch, unsigned long long epoch, int* __restrict__ err) {
+           unsigned long long* __restrict__ xch, unsigned long long epoch, int* __restrict__ err, int* __restrict__ hflag) {
   using T = T16S<Gm, F>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
@@ -729,6 +734,9 @@ k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restric
   const int pair = blockIdx.x >> 1, half = blockIdx.x & 1;
   const int board0 = pair * T::TB;
   if (board0 >= n) return;                           // both workgroups of the pair
+  // an exchange of an EARLIER launch gave up: the host has not noticed yet and the results of every launch queued behind it
+  // will be recomputed (azhip.hip recover_split) -- do not wait for partners again
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)DERR_EXCHANGE) return;
   if ((epoch >> 63) && blockIdx.x == 1) return;      // fault injection (az_debug_exchange_timeout): workgroup 0 loses its partner
   tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[1], leaf_env, eval_slots, X, n, board0, threadIdx.x);
   __syncthreads();
@@ -739,6 +747,7 @@ k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restric
   x.theirs = xch + (size_t)(blockIdx.x ^ 1) * T::XCH_WORDS;
   x.tag0 = (uint32_t)(epoch << 8);                   // + layer index < 256 (pick_tower)
   x.err = err;
+  x.hflag = hflag;
   x.pch = ((half ^ 1) * T::CWL + cwl) * 16 + (lane & 15);
   tower16_wave<T, FROM_PLANES, T::TPW, 0, PairXch>(net, buf, planes, nbr, pos, half * T::CWL + cwl, lane, n, board0, hfeat, x);
 }

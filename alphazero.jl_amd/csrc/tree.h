@@ -95,6 +95,9 @@ struct DView {
   az_game_rec* grec;      // [G]
   int* finished;          // [G] set by k_move when the slot's game ended this round
   int* err;               // device error word (first error wins)
+  int* xerr;              // the slot group's own word for "an exchange of this group's split tower gave up" (DERR_EXCHANGE): set by the
+                          // group's tower, read by the group's NEXT k_tree -- same stream order, so a launch sees one value throughout
+  int* skipped;           // [2] launches of k_tree that did nothing because a split tower's exchange had given up: with / without select
   long long* stat;        // [workgroups of k_tree][4]: simulations, nodes traversed, leaf evals, spare -- accumulated per workgroup
   unsigned long long* dbg; // optional [16] cycle stamps of k_tree's first wavefront (az_debug_tree_stamps): start, phase A done,
                           // root loaded, descent done, leaf stored, block atomics done, end
@@ -273,6 +276,14 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
   const bool links_ok = v.cap_nodes <= LINK_MAX;
   unsigned long long* dbg = (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) ? v.dbg : nullptr;
   if (dbg) dbg[0] = __builtin_readcyclecounter();
+  // The oracle's answers of this group's pending wave are not to be trusted once an exchange of k_tower16s has given up (the host
+  // has not noticed yet: launches are queued ahead): do nothing, be counted; the host re-evaluates the pending leaves without
+  // the split and launches the skipped waves again (azhip.hip recover_split).  Uniform over the grid: the word belongs to this
+  // slot group, only the group's own tower (earlier on the same stream order) sets it and only the host clears it, between launches.
+  if (__hip_atomic_load(v.xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)DERR_EXCHANGE) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(v.skipped + (do_select ? 0 : 1), 1);
+    return;
+  }
 
   // Everything whose address does not depend on another load is requested up front, in one round trip: the pending leaf's
   // kind / depth / batch index, the node count, the first L path entries (one per lane) and, for phase B, the root state and

@@ -236,6 +236,10 @@ typedef struct {
                                      * the phase returns one game fewer).  The reference's Dict has no such limit
                                      * (src/mcts.jl:124-151); with the default pool sizes this stays 0.  Hosts should warn when
                                      * it is not (azhip/training.py, julia/AlphaZeroHIP.jl do). */
+  int64_t tower_fallbacks;          /* times the split tower of small launches (k_tower16s: two workgroups per board exchanging halves
+                                     * of every layer) gave up waiting for a partner that was not co-resident and the engine fell back
+                                     * to the unsplit kernel for good: results are unaffected, small launches get slower.  0 unless
+                                     * something else (a trainer, another process) holds the device's CUs. */
 } az_selfplay_stats;
 #define AZ_REPLACEMENT_GAME_BIT 0x40000000   /* game ids handed to az_selfplay_* must stay below it */
 typedef void (*az_progress_cb)(void* user);   /* game_simulated(), once per finished game */

@@ -50,9 +50,10 @@ mutable struct SelfplayStats
   simulations::Int64; nodes_traversed::Int64; leaf_evals::Int64; moves::Int64; games::Int64; waves::Int64
   seconds::Float64
   aborted_games::Int64
-  SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0, 0)
+  tower_fallbacks::Int64
+  SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0, 0, 0)
 end
-@assert sizeof(EngineCfg) == 224 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56 && sizeof(SelfplayStats) == 64
+@assert sizeof(EngineCfg) == 224 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56 && sizeof(SelfplayStats) == 72
 const ABI_VERSION = 2   # include/azhip.h AZ_ABI_VERSION the structs above are written against
 "Called once before the first engine is created: a library built from another header must not be written into these structs."
 function check_abi()
