@@ -82,17 +82,19 @@ def tower_roofline(game, hp, bf16, kernel, tw, evals, wall_s):
 
 
 def pmc_lookup(kernel, config="f32"):
-    """HBM bytes per launch of `kernel` from this round's separate rocprofv3 --pmc passes (profiles/r3/pmc_summary.json,
-    tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE in KB, FETCH doubled on gfx950 as MI355X_MICROARCH.md prescribes);
+    """HBM bytes per launch of `kernel` from this round's separate rocprofv3 --pmc passes (profiles/r4/pmc_summary.json, r3's as a
+    fall-back; tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE in KB, FETCH doubled on gfx950 as MI355X_MICROARCH.md prescribes --
+    tools/fetch_calib.sh, profiles/r4/fetch_calibration.txt: 2 x FETCH_SIZE = 128-byte LINES requested, WRITE_SIZE exact);
     returns (bytes, units per launch) or None: counters cannot be read from inside this process."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r3", "pmc_summary.json")))
-        ks = d.get("kernels", [])
-        for k in [k for k in ks if k.get("config") == config] + ks:      # the pass of this configuration first
-            if kernel.startswith(k["match"]):
-                return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0, k["units_per_launch"]
-    except Exception:
-        pass
+    for rnd in ("r4", "r3"):                                         # this round's passes first
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")))
+            ks = d.get("kernels", [])
+            for k in [k for k in ks if k.get("config") == config] + ks:  # the pass of this configuration first
+                if kernel.startswith(k["match"]):
+                    return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0, k["units_per_launch"]
+        except Exception:
+            pass
     return None
 
 

@@ -11,7 +11,7 @@ import re
 from azhip import _lib as L
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-JL = open(os.path.join(ROOT, "julia", "AlphaZeroHIP.jl")).read()
+JL = open(os.path.join(ROOT, "julia", "AlphaZeroHIP.jl")).read() + "\n" + open(os.path.join(ROOT, "julia", "AlphaZeroHIPExtras.jl")).read()   # core (the three seams of the hot path) + optional extras
 HDR = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "azhip.h")).read(), flags=re.S)
 
 
@@ -208,7 +208,7 @@ def test_julia_sources_are_structurally_balanced():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tool = os.path.join(root, "tools", "julia_balance.py")
-    for f in ("julia/AlphaZeroHIP.jl", "tools/gen_golden.jl"):
+    for f in ("julia/AlphaZeroHIP.jl", "julia/AlphaZeroHIPExtras.jl", "tools/gen_golden.jl"):
         r = subprocess.run([sys.executable, tool, os.path.join(root, f)], capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout.startswith("balanced"), (f, r.stdout)
     src = open(os.path.join(root, "julia", "AlphaZeroHIP.jl")).read()
