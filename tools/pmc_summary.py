@@ -1,4 +1,4 @@
-"""Summarises the rocprofv3 --pmc passes of tools/profile_r3.sh (fp32 headline configuration and bf16 10x128): per kernel the
+"""Summarises the rocprofv3 --pmc passes of tools/profile_r4.sh / profile_r3.sh (fp32 headline configuration and bf16 10x128): per kernel the
 average counter values per dispatch -> pmc_summary.json, with a `kernels` list in the form bench.py's pmc_lookup reads
 (HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB: FETCH is counted in 64-byte... units that the guide says to double
 on gfx950)."""
@@ -35,7 +35,7 @@ for cfg, ks in summ.items():
                 short = "%s<%s,%s,NT=%s>" % (short[:short.index("<")], parts[0], parts[1], parts[2] if len(parts) > 2 else "11")
             kernels.append({"match": short.split("<")[0] if short.startswith("k_tree") else short, "config": cfg, "FETCH_SIZE_KB": d["FETCH_SIZE"],
                             "WRITE_SIZE_KB": d["WRITE_SIZE"], "units_per_launch": 4096,
-                            "source": "tools/profile_r3.sh: separate rocprofv3 --pmc passes, 4096 slots / leaves per launch"})
+                            "source": "tools/profile_r4.sh (r3: profile_r3.sh): separate rocprofv3 --pmc passes, 4096 slots / leaves per launch"})
 summ["kernels"] = kernels
 json.dump(summ, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1)
 for cfg, ks in summ.items():
