@@ -752,6 +752,77 @@ k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restric
   tower16_wave<T, FROM_PLANES, T::TPW, 0, PairXch>(net, buf, planes, nbr, pos, half * T::CWL + cwl, lane, n, board0, hfeat, x);
 }
 
+// ---- pieces of the optimiser step that ride inside its kernels instead of in launches of their own (round 4) --------------------
+// A step at 5x64 is ~170 dependent launches of 5 to 50 us: the ~5 us between two dependent kernels were a third of it.
+// (a) TrFinal / tr_finish: the second stage of a column sum.  Every workgroup leaves its partial sums in part[workgroup][2][C];
+//     the workgroup that finishes LAST (a counter) adds them in index order -- deterministic -- and does with a channel's two sums
+//     what the mode says.  Was k_tr_colsum_final, one launch after every producer (29 per step).
+struct TrFinal {
+  int mode;                     // 0: sums only; 1: batch-norm statistics (forward); 2: dgamma / dbeta (backward); 3: out0 = sum0 (bias gradient)
+  long long R; float momentum;
+  const float* bias; float *mean, *invstd, *run_mean, *run_var;      // mode 1
+  float *dgamma, *dbeta, *mf;                                         // mode 2 (mf[2][C]: the two sums / R as floats, what k_tr_bn_bwd subtracts)
+  float* out0;                                                        // mode 3
+  int* counter;                 // workgroups of the launch that have left their partials (back to 0 when the last one is done)
+};
+// The partials cross workgroups (and XCDs, whose L2s are not coherent with each other) inside one launch: they are written and
+// read with agent-scope relaxed atomics (write-through stores, cache-bypassing loads -- the exchange idiom of k_tower16s), the
+// counter likewise; no fence, no cache-wide write-back (a __threadfence() per workgroup flushes the XCD's dirty L2 -- the layer's
+// whole output -- and doubled the step time when it was tried).
+__device__ __forceinline__ void part_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double part_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// scratch: (blockDim.x + 2 C) doubles of LDS nobody else uses any more.  All threads of the workgroup call it, after part_store.
+__device__ __forceinline__ void tr_finish(const double* __restrict__ part, int C, const TrFinal& f, double* __restrict__ scratch) {
+  if (!f.counter) return;
+  __shared__ int s_last;
+  __builtin_amdgcn_s_waitcnt(0);                                     // this thread's partials have been performed at the device's coherence point
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(f.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y) - 1;
+  __syncthreads();
+  if (!s_last) return;
+  const int nparts = (int)gridDim.x, T = (int)blockDim.x, t = (int)threadIdx.x, npair = 2 * C;
+  double* fin = scratch + T;                                         // [2][C] the finished sums
+  if (npair <= T) {
+    // pair (w, c) = t % npair; T / npair threads share it: partials k = sub, sub + nsub, ... then the subs in order
+    const int nsub = T / npair, pair = t % npair, sub = t / npair, w = pair / C, c = pair % C;
+    double acc = 0.0;
+    if (sub < nsub) for (int k = sub; k < nparts; k += nsub) acc += part_load(part + ((size_t)k * 2 + w) * C + c);
+    scratch[t] = acc;
+    __syncthreads();
+    if (sub == 0) { double v = scratch[pair]; for (int q = 1; q < nsub; ++q) v += scratch[pair + q * npair]; fin[pair] = v; }
+  } else {
+    for (int pair = t; pair < npair; pair += T) {
+      const int w = pair / C, c = pair % C;
+      double acc = 0.0;
+      for (int k = 0; k < nparts; ++k) acc += part_load(part + ((size_t)k * 2 + w) * C + c);
+      fin[pair] = acc;
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += T) {
+    const double s0 = fin[c], s1 = fin[C + c];
+    if (f.mode == 1) {
+      // batch statistics -> mean, 1/sqrt(var + eps) (Flux BatchNorm: biased variance, eps 1e-5) and the running statistics
+      // mu <- (1-m) mu + m (mean + bias), var <- (1-m) var + m * var * R/(R-1)
+      const double m = s0 / (double)f.R;
+      double var = s1 / (double)f.R - m * m;
+      if (var < 0.0) var = 0.0;
+      f.mean[c] = (float)m;
+      f.invstd[c] = (float)(1.0 / __builtin_sqrt(var + 1e-5));
+      const float b = f.bias ? f.bias[c] : 0.0f;
+      f.run_mean[c] = (1.0f - f.momentum) * f.run_mean[c] + f.momentum * ((float)m + b);
+      f.run_var[c] = (1.0f - f.momentum) * f.run_var[c] + f.momentum * (float)(var * ((double)f.R / (double)(f.R - 1)));
+    } else if (f.mode == 2) { f.dbeta[c] = (float)s0; f.dgamma[c] = (float)s1; f.mf[c] = (float)(s0 / (double)f.R); f.mf[C + c] = (float)(s1 / (double)f.R); }
+    else if (f.mode == 3) f.out0[c] = (float)s0;
+  }
+  if (t == 0) __hip_atomic_store(f.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch on this counter starts from zero (stream order)
+}
+// (b) BnIn: the INPUT of a forward convolution computed on the fly from the previous layer's pre-activation,
+//     a = relu(gamma * ((g - mean) * invstd) + beta (+ res)) -- exactly k_tr_bn_apply's operations -- while the rows go into LDS;
+//     the workgroup also writes a (the backward pass needs it): boards do not share rows, so every element has one writer.
+//     Was a pass of its own over the tensor between every two convolutions.
+struct BnIn { const float *g, *mean, *invstd, *gamma, *beta, *res; float* a_out; };
+
 // One 3x3 F -> F convolution as a stand-alone layer (HBM -> HBM), for the optimiser step (train.hip): forward
 // g = conv(a) and data gradient da = conv_rot(dg) are the same kernel with different weight fragments.  A workgroup
 // takes 4 Connect-Four boards (T16<Game, F, 11>): rows [R][F] in natural channel order go into the LDS buffer in the
@@ -766,7 +837,7 @@ k_tower16s(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restric
 template <class Gm, int F, bool STATS, bool STAMP = false>
 __global__ void __launch_bounds__(T16Threads<F>::V, 2)
 k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, float* __restrict__ out, int nboards, const uint16_t* __restrict__ geo,
-               double* __restrict__ part, const float* __restrict__ addend, long long* __restrict__ stamps) {
+               double* __restrict__ part, const float* __restrict__ addend, long long* __restrict__ stamps, BnIn bn = BnIn{}, TrFinal fin = TrFinal{}) {
   long long ts[4] = {0, 0, 0, 0};
   if constexpr (STAMP) ts[0] = wall_clock64();
   using T = T16<Gm, F, 11>;
@@ -781,11 +852,22 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
   const int nb = (nboards - board0) < T::TB ? (nboards - board0) : T::TB;
   const int nvalid = nb * P;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float4* in4 = (const float4*)(in + (size_t)board0 * P * F);
+  const float4* in4 = (const float4*)((bn.g ? bn.g : in) + (size_t)board0 * P * F);
+  const float4* res4 = bn.res ? (const float4*)(bn.res + (size_t)board0 * P * F) : nullptr;
+  float4* aout4 = bn.g ? (float4*)(bn.a_out + (size_t)board0 * P * F) : nullptr;
   for (int idx = tid; idx < (T::RPAD + GEO_NZ) * (F / 4); idx += T::THREADS) {
     const int row = idx / (F / 4), c4 = idx % (F / 4);
     const int ps = row < T::RPAD ? (int)geo[row] : 0xffff;          // board * P + position of this buffer row
-    const float4 v = ps < nvalid ? in4[(size_t)ps * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = ps < nvalid ? in4[(size_t)ps * (F / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bn.g && ps < nvalid) {                                       // BnIn: v holds g; the activation is computed here and kept for the backward pass
+      const float4 mu = ((const float4*)bn.mean)[c4], is = ((const float4*)bn.invstd)[c4], ga = ((const float4*)bn.gamma)[c4], be = ((const float4*)bn.beta)[c4];
+      float4 y;
+      y.x = ga.x * ((v.x - mu.x) * is.x) + be.x; y.y = ga.y * ((v.y - mu.y) * is.y) + be.y;
+      y.z = ga.z * ((v.z - mu.z) * is.z) + be.z; y.w = ga.w * ((v.w - mu.w) * is.w) + be.w;
+      if (res4) { const float4 r = res4[(size_t)ps * (F / 4) + c4]; y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w; }
+      v = make_float4(y.x > 0.0f ? y.x : 0.0f, y.y > 0.0f ? y.y : 0.0f, y.z > 0.0f ? y.z : 0.0f, y.w > 0.0f ? y.w : 0.0f);
+      aout4[(size_t)ps * (F / 4) + c4] = v;
+    }
     float* dst = buf + row * STRIDE;
     dst[posF<F>(c4 * 4 + 0)] = v.x; dst[posF<F>(c4 * 4 + 1)] = v.y; dst[posF<F>(c4 * 4 + 2)] = v.z; dst[posF<F>(c4 * 4 + 3)] = v.w;
   }
@@ -818,7 +900,9 @@ k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, f
     // the four row groups of a channel: (g0 + g1) + (g2 + g3), a fixed order
     s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16);
     s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
-    if (g == 0) { part[((size_t)blockIdx.x * 2) * F + ch] = s0; part[((size_t)blockIdx.x * 2 + 1) * F + ch] = s1; }
+    if (g == 0) { part_store(part + ((size_t)blockIdx.x * 2) * F + ch, s0); part_store(part + ((size_t)blockIdx.x * 2 + 1) * F + ch, s1); }
+    __syncthreads();                                                 // every wavefront is done with the LDS buffer: it becomes the finisher's scratch
+    tr_finish(part, F, fin, (double*)lds);
   }
   if constexpr (STAMP) {
     __builtin_amdgcn_s_waitcnt(0);

@@ -73,7 +73,7 @@ constexpr int TR_CHUNK = 64;
 template <int MODE>
 __global__ void __launch_bounds__(256) k_tr_colsum(const float* __restrict__ x, const float* __restrict__ out_act, const float* __restrict__ g,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd, long long R, int C,
-                                                   double* __restrict__ part /* [nchunks][2][C] */) {
+                                                   double* __restrict__ part /* [nchunks][2][C] */, TrFinal fin) {
   __shared__ double sh[2][4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cl;
@@ -95,16 +95,18 @@ __global__ void __launch_bounds__(256) k_tr_colsum(const float* __restrict__ x, 
   sh[0][rl][cl] = s0; sh[1][rl][cl] = s1;
   __syncthreads();
   if (rl == 0 && c < C) {
-    part[((size_t)blockIdx.x * 2) * C + c] = ((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl];
-    part[((size_t)blockIdx.x * 2 + 1) * C + c] = ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl];
+    part_store(part + ((size_t)blockIdx.x * 2) * C + c, ((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl]);
+    part_store(part + ((size_t)blockIdx.x * 2 + 1) * C + c, ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl]);
   }
+  __syncthreads();
+  if (C <= 128) tr_finish(part, C, fin, &sh[0][0][0]);               // 512 doubles of scratch: 256 + 2 C (host: wider layers keep the separate launch)
 }
 // MODE 1 with four channels per thread (C % 4 == 0, 256 % (C/4) == 0): a block = C/4 channel quads x 256/(C/4) row lanes
 // over the same 64-row chunk, 16-byte loads; the row lanes are added in lane order through 8 KB of LDS (it has to fit
 // beside two workgroups of k_wgrad16, and the first form of that kernel left 10 KB).  Same partial layout as k_tr_colsum.
 __global__ void __launch_bounds__(256) k_tr_colsum1v(const float* __restrict__ x, const float* __restrict__ out_act, const float* __restrict__ g,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd, long long R, int C,
-                                                     double* __restrict__ part /* [nchunks][2][C] */) {
+                                                     double* __restrict__ part /* [nchunks][2][C] */, TrFinal fin) {
   __builtin_amdgcn_s_setprio(3);   // HBM-bound and short: its few instructions go first when it shares a SIMD with k_wgrad16's wavefronts
   __shared__ double sh[256][4];
   const int CQ = C >> 2, RL = 256 / CQ;
@@ -151,20 +153,17 @@ __global__ void __launch_bounds__(256) k_tr_colsum1v(const float* __restrict__ x
       for (int k = 0; k < 4; ++k) {
         double v = sh[q][k];
         for (int l = 1; l < RL; ++l) v += sh[q + l * CQ][k];
-        part[((size_t)blockIdx.x * 2 + w) * C + 4 * q + k] = v;
+        part_store(part + ((size_t)blockIdx.x * 2 + w) * C + 4 * q + k, v);
       }
     }
     __syncthreads();
   }
+  tr_finish(part, C, fin, &sh[0][0]);                                // 1024 doubles of scratch >= 256 + 2 C (C <= 256 here... the host checks)
 }
-// what the one thread that holds a channel's two sums does with them (fused into the final reduction: no extra launch)
-struct TrFinal {
-  int mode;                     // 0: sums only; 1: batch-norm statistics (forward); 2: dgamma / dbeta (backward); 3: out0 = sum0 (bias gradient)
-  long long R; float momentum;
-  const float* bias; float *mean, *invstd, *run_mean, *run_var;      // mode 1
-  float *dgamma, *dbeta, *mf;                                         // mode 2 (mf[2][C]: the two sums / R as floats, what k_tr_bn_bwd subtracts)
-  float* out0;                                                        // mode 3
-};
+// the second stage of a column sum: one workgroup per channel adds the producers' partials in a fixed order and does what the
+// mode says (TrFinal, resnet16.h).  A launch of its own after every producer: riding in the producer's LAST workgroup (tr_finish)
+// was built and measured in round 4 -- one workgroup reading 256 ... 672 x 2 C partials through cache-bypassing loads takes
+// longer (3.4 ms per step at 5x64 instead of 1.9) than the ~6 us a dependent launch costs.
 __global__ void __launch_bounds__(64) k_tr_colsum_final(const double* __restrict__ part, int nchunks, int C, double* __restrict__ sums /* [2][C] */, TrFinal f) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ double sh[2][64];
@@ -379,6 +378,8 @@ struct az_trainer {
   float* wg_part; int wg_splits, wg_bpw;                       // k_wgrad16: partial dW per row split, boards per workgroup
   double *part, *sums, *terms, *bsums;
   float* bn_mf;                                                              // [2][C] the batch-norm backward means of the layer in flight
+  bool fin_inside;                                                           // AZHIP_TRAIN_FINISH_INSIDE=1: second stage of the column sums in the producer's last workgroup (measured slower: off)
+  int* fin_counter;                                                          // tr_finish: counter of the workgroups that have left their partial sums
   std::vector<void*> allocs;
   std::vector<int> perm; int64_t perm_pos, epoch; int64_t step;
   float b1t, b2t;
@@ -521,6 +522,8 @@ static int trainer_build(az_trainer* t) {
   const int nchunks = (int)((R + TR_CHUNK - 1) / TR_CHUNK);
   AZCHK(tr_alloc(t, &t->part, (size_t)std::max(nchunks, B + 1) * 2 * std::max(F, 64)));   // chunks of k_tr_colsum or workgroups of k_conv16_layer
   AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64))); AZCHK(tr_alloc(t, &t->bn_mf, (size_t)2 * std::max(F, 64)));
+  { const char* fi = getenv("AZHIP_TRAIN_FINISH_INSIDE"); t->fin_inside = fi && atoi(fi) != 0; }
+  AZCHK(tr_alloc(t, &t->fin_counter, 4, true));                       // tr_finish: workgroups done (every launch leaves it at zero)
   AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 8 + 1024));
   // k_wgrad16: one round of workgroups over the chip
   t->wg_part = nullptr; t->wg_splits = 0; t->wg_bpw = 0;
@@ -536,21 +539,22 @@ static int trainer_build(az_trainer* t) {
   return AZ_OK;
 }
 
-template <class Gm, int F, bool STATS> static int tr_conv16_f(az_trainer* t, const float* in, const float* frag, float* out, const float* addend) {
+template <class Gm, int F, bool STATS> static int tr_conv16_f(az_trainer* t, const float* in, const float* frag, float* out, const float* addend, const BnIn& bn, const TrFinal& fin) {
   using T = T16<Gm, F, 11>;
   static bool attr_done = false;
   if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_layer<Gm, F, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, T::BYTES)); attr_done = true; }
-  hipLaunchKernelGGL((k_conv16_layer<Gm, F, STATS>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[0], t->part, addend, (long long*)nullptr);
+  hipLaunchKernelGGL((k_conv16_layer<Gm, F, STATS>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[0], t->part, addend, (long long*)nullptr, bn, fin);
   return AZ_OK;
 }
 // 3x3 F -> F convolution of [R][F] activations on the MFMA layer kernel; stats: also the first stage of the column sums
 // (sum, sum of squares) of the output in t->part, *nparts workgroup partials
-static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* out, bool stats = false, int* nparts = nullptr, const float* addend = nullptr) {
+static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* out, bool stats = false, int* nparts = nullptr, const float* addend = nullptr,
+                     const BnIn& bn = BnIn{}, const TrFinal& fin = TrFinal{}) {
   DISPATCH_GAME(t->game, {
     using T = T16<Gm, 64, 11>;
     if (nparts) *nparts = (t->B + T::TB - 1) / T::TB;
-    if (t->F == 128) { if (stats) AZCHK((tr_conv16_f<Gm, 128, true>(t, in, frag, out, addend))); else AZCHK((tr_conv16_f<Gm, 128, false>(t, in, frag, out, addend))); }
-    else { if (stats) AZCHK((tr_conv16_f<Gm, 64, true>(t, in, frag, out, addend))); else AZCHK((tr_conv16_f<Gm, 64, false>(t, in, frag, out, addend))); }
+    if (t->F == 128) { if (stats) AZCHK((tr_conv16_f<Gm, 128, true>(t, in, frag, out, addend, bn, fin))); else AZCHK((tr_conv16_f<Gm, 128, false>(t, in, frag, out, addend, bn, fin))); }
+    else { if (stats) AZCHK((tr_conv16_f<Gm, 64, true>(t, in, frag, out, addend, bn, fin))); else AZCHK((tr_conv16_f<Gm, 64, false>(t, in, frag, out, addend, bn, fin))); }
   });
   return AZ_OK;
 }
@@ -583,10 +587,13 @@ template <int MODE>
 static int tr_colsum(az_trainer* t, const float* x, const float* out_act, const float* g, const float* mean, const float* invstd, long long R, int C,
                      TrFinal fin = TrFinal{}) {
   const int nchunks = (int)((R + TR_CHUNK - 1) / TR_CHUNK);
-  if (MODE == 1 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0)
-    hipLaunchKernelGGL(k_tr_colsum1v, dim3(nchunks), dim3(256), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part);
-  else hipLaunchKernelGGL((k_tr_colsum<MODE>), dim3(nchunks, (C + 63) / 64), dim3(256), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part);
-  hipLaunchKernelGGL(k_tr_colsum_final, dim3(C), dim3(64), 0, t->stream, t->part, nchunks, C, t->sums, fin);
+  // (tr_finish -- the second stage in the producer's last workgroup -- is off: measured slower, see k_tr_colsum_final)
+  const bool inside = t->fin_inside && C <= 128;
+  fin.counter = inside ? t->fin_counter : nullptr;
+  if (MODE == 1 && C % 4 == 0 && C <= 128 && 256 % (C / 4) == 0)
+    hipLaunchKernelGGL(k_tr_colsum1v, dim3(nchunks), dim3(256), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part, fin);
+  else hipLaunchKernelGGL((k_tr_colsum<MODE>), dim3(nchunks, (C + 63) / 64), dim3(256), 0, t->stream, x, out_act, g, mean, invstd, R, C, t->part, fin);
+  if (!inside) hipLaunchKernelGGL(k_tr_colsum_final, dim3(C), dim3(64), 0, t->stream, t->part, nchunks, C, t->sums, fin);
   return AZ_OK;
 }
 
@@ -608,22 +615,33 @@ static int tr_forward_backward(az_trainer* t, const int* idx_host, double* d_sum
   hipLaunchKernelGGL(k_tr_gather, dim3(tr_grid((long long)t->nwork)), dim3(256), 0, st, blob, t->map, (long long)t->nwork, t->work);
   HIPCHK(hipMemsetAsync(t->gblob, 0, sizeof(float) * t->nparams, st));
   // ---------------- forward ----------------
+  // (r4) one launch per tower layer: the convolution of layer l computes its INPUT a(l-1) = relu(bn(g(l-1)) (+ skip)) while the rows
+  // go into LDS (BnIn, and writes it for the backward pass), leaves the column sums of its output and its last workgroup turns them
+  // into the layer's batch statistics (tr_finish).  Were three launches (convolution, k_tr_colsum_final, k_tr_bn_apply).
+  auto bn_of = [&](int l) {                                          // what turns g(l) into a(l)
+    TrConv& c = t->convs[l];
+    const bool second = l > 0 && (l % 2) == 0;                       // conv2 of a block: skip connection from the block input
+    return BnIn{c.g, c.mean, c.invstd, blob + c.off_bn, blob + c.off_bn + c.cout, second ? t->convs[l - 2].a : nullptr, c.a};
+  };
   for (int l = 0; l < ntower; ++l) {
     TrConv& c = t->convs[l];
-    const float* in = l == 0 ? t->bX : t->convs[l - 1].a;
-    int nparts = 0;                                                 // > 0: the convolution kernel left the first stage of the statistics in t->part
-    if (c.mfma) AZCHK(tr_conv16(t, in, t->work + c.wk_ffwd, c.g, true, &nparts));
-    else {                                                          // the stem: K = 9 C, im2col + GEMM
-      hipLaunchKernelGGL((k_tr_im2col<true>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, in, R, c.cin, gi.W, gi.H, c.col);
+    TrFinal fin{}; fin.mode = 1; fin.R = R; fin.momentum = t->cfg.batch_norm_momentum; fin.bias = blob + c.off_b; fin.mean = c.mean; fin.invstd = c.invstd;
+    fin.run_mean = blob + c.off_bn + 2 * c.cout; fin.run_var = blob + c.off_bn + 3 * c.cout;
+    if (c.mfma) {
+      int nparts = 0;
+      fin.counter = t->fin_inside ? t->fin_counter : nullptr;
+      AZCHK(tr_conv16(t, nullptr, t->work + c.wk_ffwd, c.g, true, &nparts, nullptr, bn_of(l - 1), fin));
+      if (!fin.counter) hipLaunchKernelGGL(k_tr_colsum_final, dim3(c.cout), dim3(64), 0, st, t->part, nparts, c.cout, t->sums, fin);
+    } else {                                                          // the stem: K = 9 C, im2col + GEMM
+      hipLaunchKernelGGL((k_tr_im2col<true>), dim3(tr_grid(R * 9 * c.cin)), dim3(256), 0, st, t->bX, R, c.cin, gi.W, gi.H, c.col);
       AZCHK(tr_gemm(t, false, false, (int)R, c.cout, 9 * c.cin, 1.f, c.col, 9 * c.cin, t->work + c.wk_wm, c.cout, 0.f, c.g, c.cout));
+      AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout, fin));
     }
-    { TrFinal fin{}; fin.mode = 1; fin.R = R; fin.momentum = t->cfg.batch_norm_momentum; fin.bias = blob + c.off_b; fin.mean = c.mean; fin.invstd = c.invstd;
-      fin.run_mean = blob + c.off_bn + 2 * c.cout; fin.run_var = blob + c.off_bn + 3 * c.cout;
-      if (nparts > 0) hipLaunchKernelGGL(k_tr_colsum_final, dim3(c.cout), dim3(64), 0, st, t->part, nparts, c.cout, t->sums, fin);
-      else AZCHK(tr_colsum<0>(t, c.g, nullptr, nullptr, nullptr, nullptr, R, c.cout, fin)); }
-    const bool second = l > 0 && (l % 2) == 0;                     // conv2 of a block: skip connection from the block input
-    const float* res = second ? t->convs[l - 2].a : nullptr;
-    hipLaunchKernelGGL(k_tr_bn_apply, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, c.g, c.mean, c.invstd, blob + c.off_bn, blob + c.off_bn + c.cout, res, R * c.cout, c.cout, c.a);
+  }
+  { // the trunk: the last layer's activation has no convolution after it to ride in
+    const BnIn b = bn_of(ntower - 1);
+    TrConv& c = t->convs[ntower - 1];
+    hipLaunchKernelGGL(k_tr_bn_apply, dim3(tr_grid(R * c.cout)), dim3(256), 0, st, b.g, b.mean, b.invstd, b.gamma, b.beta, b.res, R * c.cout, c.cout, c.a);
   }
   const float* trunk = t->convs[ntower - 1].a;
   for (TrConv* c : {&hp, &hv}) {

@@ -27,7 +27,7 @@ template <bool STATS> static int run() {
   printf("k_conv16_layer<ConnectFour, 128, STATS = %d>, %d workgroups, %d bytes of LDS\n", (int)STATS, nwg, (int)T::BYTES);
   for (int it = 0; it < 4; ++it) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(T::THREADS), T::BYTES, 0, in, (const float4*)w, out, B, geo, part, (const float*)nullptr, st);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(T::THREADS), T::BYTES, 0, in, (const float4*)w, out, B, geo, part, (const float*)nullptr, st, BnIn{}, TrFinal{});
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<long long> s((size_t)nwg * 4);
