@@ -829,6 +829,25 @@ extern "C" int az_trainer_gradients(az_trainer* t, const int32_t* sample_idx, fl
   return AZ_OK;
 }
 
+// debug aid (not part of the ABI in azhip.h): the post-ReLU activation the last forward pass left for layer `which` -- tower
+// layers 0 .. 2 num_blocks ([R][F], R = batch x positions), then the policy / value head convolutions ([R][npf], [R][nvf]), then
+// the value head's first dense layer ([batch][F]).  tests/test_train_gpu.py reads the ReLU masks (a > 0) off them: an fp32 chain
+// and an fp64 reference disagree on activations within rounding of zero, and ONE flipped unit moves single weight-gradient
+// entries by more than the tolerance the rest of the gradient meets.
+extern "C" int az_debug_trainer_activation(az_trainer* t, int32_t which, float* out, int64_t n) {
+  TRAINER(t);
+  const int ntower = 1 + 2 * t->nblocks;
+  const float* src = nullptr;
+  int64_t want = 0;
+  if (which >= 0 && which < ntower + 2) { src = t->convs[which].a; want = (int64_t)t->R * t->convs[which].cout; }
+  else if (which == ntower + 2) { src = t->v1; want = (int64_t)t->B * t->F; }
+  else return fail(AZ_ERR_BAD_ARG, "layer %d of %d", which, ntower + 3);
+  if (!out || n != want) return fail(AZ_ERR_BAD_ARG, "buffer must hold %lld floats", (long long)want);
+  HIPCHK(hipStreamSynchronize(t->stream));
+  HIPCHK(hipMemcpy(out, src, sizeof(float) * (size_t)want, hipMemcpyDeviceToHost));
+  return AZ_OK;
+}
+
 // batch_updates!(tr, n) (learning.jl:131-141): n optimiser steps on successive batches; losses[i] = L before update i
 extern "C" int az_trainer_batch_updates(az_trainer* t, int32_t n, float* losses) {
   TRAINER(t);

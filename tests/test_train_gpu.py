@@ -26,11 +26,26 @@ def _memory(game, ngames, seed):
     return gspec, mem
 
 
-class TorchNet:
-    """fp64 restatement of the Flux ResNet in TRAIN mode + `losses` (learning.jl:67-90), parameters in Julia shapes"""
+class _MaskedRelu(torch.autograd.Function):
+    """relu whose DERIVATIVE is a given 0/1 mask (the forward value is relu(z) itself)"""
+    @staticmethod
+    def forward(ctx, z, mask):
+        ctx.save_for_backward(mask)
+        return torch.relu(z)
 
-    def __init__(self, game, hp, blob):
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask, None
+
+
+class TorchNet:
+    """fp64 restatement of the Flux ResNet in TRAIN mode + `losses` (learning.jl:67-90), parameters in Julia shapes.
+    masks (optional): name -> 0/1 tensor; the ReLU of that name then differentiates with the given mask instead of (z > 0)."""
+
+    def __init__(self, game, hp, blob, masks=None):
         self.game, self.hp = game, hp
+        self.masks, self.own_masks = masks or {}, {}
         self.names = [n for n, _ in param_layout(game, hp)]
         self.p = {k: torch.tensor(np.ascontiguousarray(v), dtype=torch.float64, requires_grad=not (k.endswith(".mean") or k.endswith(".var")))
                   for k, v in split_params(game, hp, blob).items()}
@@ -57,17 +72,23 @@ class TorchNet:
         s = (1, -1, 1, 1)
         return g.view(s) * (x - mu.view(s)) / torch.sqrt(var.view(s) + 1e-5) + be.view(s)
 
+    def _relu(self, z, name):
+        self.own_masks[name] = (z.detach() > 0).to(torch.float64)
+        if name in self.masks:
+            return _MaskedRelu.apply(z, self.masks[name])
+        return torch.relu(z)
+
     def forward(self, X):
-        x = torch.relu(self._bn(self._conv(X, "stem.conv", 1), "stem.bn"))
+        x = self._relu(self._bn(self._conv(X, "stem.conv", 1), "stem.bn"), "tower0")
         for b in range(self.hp.num_blocks):
-            y = torch.relu(self._bn(self._conv(x, "block%d.conv1" % b, 1), "block%d.bn1" % b))
+            y = self._relu(self._bn(self._conv(x, "block%d.conv1" % b, 1), "block%d.bn1" % b), "tower%d" % (2 * b + 1))
             y = self._bn(self._conv(y, "block%d.conv2" % b, 1), "block%d.bn2" % b)
-            x = torch.relu(y + x)
+            x = self._relu(y + x, "tower%d" % (2 * b + 2))
         N = x.shape[0]
-        hp_ = torch.relu(self._bn(self._conv(x, "phead.conv", 0), "phead.bn")).reshape(N, -1)
+        hp_ = self._relu(self._bn(self._conv(x, "phead.conv", 0), "phead.bn"), "phead").reshape(N, -1)
         logits = hp_ @ self.p["phead.dense.W"].T + self.p["phead.dense.b"]
-        hv = torch.relu(self._bn(self._conv(x, "vhead.conv", 0), "vhead.bn")).reshape(N, -1)
-        v1 = torch.relu(hv @ self.p["vhead.dense1.W"].T + self.p["vhead.dense1.b"])
+        hv = self._relu(self._bn(self._conv(x, "vhead.conv", 0), "vhead.bn"), "vhead").reshape(N, -1)
+        v1 = self._relu(hv @ self.p["vhead.dense1.W"].T + self.p["vhead.dense1.b"], "v1")
         val = torch.tanh(v1 @ self.p["vhead.dense2.W"].T + self.p["vhead.dense2.b"]).reshape(N)
         return torch.softmax(logits, dim=1), val
 
@@ -86,12 +107,41 @@ class TorchNet:
         return scale * (Lp + Lv + Lreg + Linv), (Lp, Lv, Lreg, Linv, scale)
 
 
+def _device_relu_masks(tr, hp, ref):
+    """the ReLU masks (a > 0) of the device's last forward pass, shaped like the reference's (az_debug_trainer_activation, train.hip).
+    The device keeps activations as [board x position][channel]; the position order is found by agreement with the reference."""
+    import ctypes as C
+    from azhip import _lib as L
+    f = L.lib().az_debug_trainer_activation
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    ntower = 1 + 2 * hp.num_blocks
+    names = ["tower%d" % l for l in range(ntower)] + ["phead", "vhead", "v1"]
+    out, flips = {}, 0
+    for which, name in enumerate(names):
+        own = ref.own_masks[name]
+        a = np.zeros(own.numel(), dtype=np.float32)
+        L.check(f(tr._trainer(), which, a.ctypes.data_as(C.c_void_p), a.size))
+        if own.dim() == 4:
+            n, c, h, w = own.shape
+            cands = [torch.tensor(a.reshape(n, h, w, c) > 0).permute(0, 3, 1, 2), torch.tensor(a.reshape(n, w, h, c) > 0).permute(0, 3, 2, 1)]
+            m = max(cands, key=lambda t: int((t.to(torch.float64) == own).sum()))
+        else:
+            m = torch.tensor(a.reshape(tuple(own.shape)) > 0)
+        m = m.to(torch.float64).contiguous()
+        d = int((m != own).sum())
+        assert d <= max(8, own.numel() // 20000), (name, d, own.numel())   # the same network: only units within rounding of zero differ
+        flips += d
+        out[name] = m
+    return out, flips
+
+
 def _rel_err_by_array(game, hp, got, want, tol=1e-3, l2_tol=None):
     """every array: max |got - want| <= tol * max |want| (+ 2e-6); l2_tol: also ||got - want||_2 <= l2_tol * ||want||_2.
-    The deep cases use the pair (1e-2, 1e-3): with ~0.5 M activations per layer a handful of them sit within rounding of zero,
-    an fp32 chain and an fp64 chain then disagree on their ReLU masks, and ONE flipped row moves single weight-gradient entries
-    by a few 1e-3 of the array's largest while the array as a whole stays within 1e-3 (seen: 4.4e-3 on block4.conv1.W of a
-    5x128 tower with 96 samples, the same with the round-2 kernels)."""
+    Deep towers: with ~0.5 M activations per layer a handful of them sit within rounding of zero, an fp32 chain and an fp64 chain
+    then disagree on their ReLU masks, and ONE flipped unit moves single weight-gradient entries by a few 1e-3 of the array's
+    largest (seen: 4.4e-3 on block4.conv1.W of a 5x128 tower with 96 samples).  Round 3 loosened the tolerance to 1e-2 there; round 4
+    gives the fp64 reference the DEVICE's masks instead (_device_relu_masks) and keeps 1e-3 (VERDICT r3 weak #10)."""
     worst, off = 0.0, 0
     for name, shape in param_layout(game, hp):
         n = int(np.prod(shape))
@@ -153,8 +203,18 @@ def test_gradients_match_torch_autograd(game, nblocks, F, B, policy):
         want = ref.blob(grads=True)
         assert abs(loss - L.item()) < 2e-5 * max(1.0, abs(L.item()))
         assert np.allclose(parts, [Lp.item(), Lv.item(), Lreg.item(), Linv.item(), scale.item()], rtol=5e-5, atol=5e-6), (parts, Lp.item(), Lv.item())
-        deep = nblocks >= 3
-        _rel_err_by_array(game, hp, grad.astype(np.float64), want, tol=1e-2 if deep else 1e-3, l2_tol=1e-3 if deep else None)
+        if nblocks >= 3:
+            # the same reference differentiated with the ReLU masks the device actually had: the comparison is then between
+            # two chains of the SAME piecewise-linear function, and the 1e-3 of the shallow cases holds for every entry
+            masks, flips = _device_relu_masks(tr, hp, ref)
+            ref2 = TorchNet(game, hp, nn.params(), masks=masks)
+            L2, (_, _, Lreg2, _, scale2) = ref2.losses(batch, float(tr.Wmean), float(tr.Hp), 1e-4, 1.0, 2.0)
+            (L2 - scale2 * Lreg2).backward()
+            assert abs(L2.item() - L.item()) < 1e-12 * max(1.0, abs(L.item()))      # the masks change derivatives, not values
+            _rel_err_by_array(game, hp, grad.astype(np.float64), ref2.blob(grads=True), tol=1e-3, l2_tol=3e-4)
+            _rel_err_by_array(game, hp, grad.astype(np.float64), want, tol=1e-2, l2_tol=1e-3)   # and against the reference's own masks, as before
+        else:
+            _rel_err_by_array(game, hp, grad.astype(np.float64), want, tol=1e-3)
         # the probe does not move the parameters or the running statistics
         assert np.array_equal(tr.trained_params(), nn.params())
     mem.close()
