@@ -100,7 +100,7 @@ struct az_engine {
   NetDev net;
   Net16bDev net16b;              // bf16 fragments (cfg.net_bf16)
   Net16Dev net16;                // k_tower16 fragments (64 filters)
-  uint16_t* d_geo[4];            // Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h), [3]: 22 tiles (k_tower16b, 8 boards)
+  uint16_t* d_geo[5];            // Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h), [3]: 22 tiles (k_tower16b, 8 boards), [4]: 6 tiles (k_conv16_layer of the trainer at small batches)
   int nts;                       // row tiles of the game's latency tower variant (NTS<Game>, resnet16.h)
   char last_tower[96];           // name of the tower kernel that served the most recent network launch (az_net_last_kernel)
   int heads_pick;                // AZHIP_HEADS=16|32 forces k_heads16 / k_heads_mfma; 0 = by launch size

@@ -59,6 +59,7 @@ template <class Gm> static int set_kernel_attrs(az_engine* e) {
   AZCHK((upload_geo<typename T16<Gm, 64, NTS<Gm>>::Geo>(e, 1)));
   AZCHK((upload_geo<typename T16P<Gm, 64>::Geo>(e, 2)));
   AZCHK((upload_geo<typename T16B<Gm, 128, 22>::Geo>(e, 3)));
+  AZCHK((upload_geo<typename T16<Gm, 64, 6>::Geo>(e, 4)));
   return AZ_OK;
 }
 

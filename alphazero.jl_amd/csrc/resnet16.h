@@ -834,15 +834,18 @@ struct BnIn { const float *g, *mean, *invstd, *gamma, *beta, *res; float* a_out;
 // part[blockIdx.x][2][F] (double), the first stage of the batch-norm statistics -- the accumulators are at hand, a
 // separate pass over the output (k_tr_colsum<0>) is not needed.
 // STAMP (tools/probes/conv_stamps.hip): clock readings of the first wavefront of every workgroup in stamps[workgroup][4]
-template <class Gm, int F, bool STATS, bool STAMP = false>
+// NT (r4): row tiles of a workgroup.  11 = 4 Connect-Four boards; 6 = 2 boards: at the reference's batch of 1024 the 11-tile form is
+// 256 workgroups -- ONE per CU, whose fill, products and epilogue then run one after the other with nothing beside them -- the
+// 6-tile form 512, two per CU.
+template <class Gm, int F, bool STATS, bool STAMP = false, int NT_ = 11>
 __global__ void __launch_bounds__(T16Threads<F>::V, 2)
 k_conv16_layer(const float* __restrict__ in, const float4* __restrict__ wfrag, float* __restrict__ out, int nboards, const uint16_t* __restrict__ geo,
                double* __restrict__ part, const float* __restrict__ addend, long long* __restrict__ stamps, BnIn bn = BnIn{}, TrFinal fin = TrFinal{}) {
   long long ts[4] = {0, 0, 0, 0};
   if constexpr (STAMP) ts[0] = wall_clock64();
-  using T = T16<Gm, F, 11>;
+  using T = T16<Gm, F, NT_>;
   using G = typename T::Geo;
-  constexpr int P = Gm::P, STRIDE = T::STRIDE, NT = 11;
+  constexpr int P = Gm::P, STRIDE = T::STRIDE, NT = NT_;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
   uint16_t* nbr = (uint16_t*)(lds + T::BUF + T::PLANES);

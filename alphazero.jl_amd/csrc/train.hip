@@ -378,6 +378,7 @@ struct az_trainer {
   float* wg_part; int wg_splits, wg_bpw;                       // k_wgrad16: partial dW per row split, boards per workgroup
   double *part, *sums, *terms, *bsums;
   float* bn_mf;                                                              // [2][C] the batch-norm backward means of the layer in flight
+  bool conv_nt6;                                                             // AZHIP_TRAIN_NT6=0 switches the 6-tile layer kernel off (A/B)
   bool fin_inside;                                                           // AZHIP_TRAIN_FINISH_INSIDE=1: second stage of the column sums in the producer's last workgroup (measured slower: off)
   int* fin_counter;                                                          // tr_finish: counter of the workgroups that have left their partial sums
   std::vector<void*> allocs;
@@ -523,6 +524,7 @@ static int trainer_build(az_trainer* t) {
   AZCHK(tr_alloc(t, &t->part, (size_t)std::max(nchunks, B + 1) * 2 * std::max(F, 64)));   // chunks of k_tr_colsum or workgroups of k_conv16_layer
   AZCHK(tr_alloc(t, &t->sums, (size_t)2 * std::max(F, 64))); AZCHK(tr_alloc(t, &t->bn_mf, (size_t)2 * std::max(F, 64)));
   { const char* fi = getenv("AZHIP_TRAIN_FINISH_INSIDE"); t->fin_inside = fi && atoi(fi) != 0; }
+  { const char* n6 = getenv("AZHIP_TRAIN_NT6"); t->conv_nt6 = !(n6 && atoi(n6) == 0); }
   AZCHK(tr_alloc(t, &t->fin_counter, 4, true));                       // tr_finish: workgroups done (every launch leaves it at zero)
   AZCHK(tr_alloc(t, &t->terms, (size_t)4 * B)); AZCHK(tr_alloc(t, &t->bsums, 8 + 1024));
   // k_wgrad16: one round of workgroups over the chip
@@ -539,11 +541,11 @@ static int trainer_build(az_trainer* t) {
   return AZ_OK;
 }
 
-template <class Gm, int F, bool STATS> static int tr_conv16_f(az_trainer* t, const float* in, const float* frag, float* out, const float* addend, const BnIn& bn, const TrFinal& fin) {
-  using T = T16<Gm, F, 11>;
+template <class Gm, int F, bool STATS, int NT> static int tr_conv16_f(az_trainer* t, const float* in, const float* frag, float* out, const float* addend, const BnIn& bn, const TrFinal& fin) {
+  using T = T16<Gm, F, NT>;
   static bool attr_done = false;
-  if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_layer<Gm, F, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, T::BYTES)); attr_done = true; }
-  hipLaunchKernelGGL((k_conv16_layer<Gm, F, STATS>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[0], t->part, addend, (long long*)nullptr, bn, fin);
+  if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_layer<Gm, F, STATS, false, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, T::BYTES)); attr_done = true; }
+  hipLaunchKernelGGL((k_conv16_layer<Gm, F, STATS, false, NT>), dim3((t->B + T::TB - 1) / T::TB), dim3(T::THREADS), T::BYTES, t->stream, in, (const float4*)frag, out, t->B, t->e->d_geo[NT == 11 ? 0 : 4], t->part, addend, (long long*)nullptr, bn, fin);
   return AZ_OK;
 }
 // 3x3 F -> F convolution of [R][F] activations on the MFMA layer kernel; stats: also the first stage of the column sums
@@ -552,9 +554,14 @@ static int tr_conv16(az_trainer* t, const float* in, const float* frag, float* o
                      const BnIn& bn = BnIn{}, const TrFinal& fin = TrFinal{}) {
   DISPATCH_GAME(t->game, {
     using T = T16<Gm, 64, 11>;
-    if (nparts) *nparts = (t->B + T::TB - 1) / T::TB;
-    if (t->F == 128) { if (stats) AZCHK((tr_conv16_f<Gm, 128, true>(t, in, frag, out, addend, bn, fin))); else AZCHK((tr_conv16_f<Gm, 128, false>(t, in, frag, out, addend, bn, fin))); }
-    else { if (stats) AZCHK((tr_conv16_f<Gm, 64, true>(t, in, frag, out, addend, bn, fin))); else AZCHK((tr_conv16_f<Gm, 64, false>(t, in, frag, out, addend, bn, fin))); }
+    using T6 = T16<Gm, 64, 6>;
+    // (r4) 64 filters and a batch that gives the 11-tile form at most one workgroup per CU: the 6-tile form (half the boards per
+    // workgroup, two workgroups per CU) overlaps one workgroup's fill and epilogue with the other's products
+    const bool small = t->F == 64 && t->conv_nt6 && (t->B + T::TB - 1) / T::TB <= (t->e->num_cu > 0 ? t->e->num_cu : 256);
+    if (nparts) *nparts = small ? (t->B + T6::TB - 1) / T6::TB : (t->B + T::TB - 1) / T::TB;
+    if (t->F == 128) { if (stats) AZCHK((tr_conv16_f<Gm, 128, true, 11>(t, in, frag, out, addend, bn, fin))); else AZCHK((tr_conv16_f<Gm, 128, false, 11>(t, in, frag, out, addend, bn, fin))); }
+    else if (small) { if (stats) AZCHK((tr_conv16_f<Gm, 64, true, 6>(t, in, frag, out, addend, bn, fin))); else AZCHK((tr_conv16_f<Gm, 64, false, 6>(t, in, frag, out, addend, bn, fin))); }
+    else { if (stats) AZCHK((tr_conv16_f<Gm, 64, true, 11>(t, in, frag, out, addend, bn, fin))); else AZCHK((tr_conv16_f<Gm, 64, false, 11>(t, in, frag, out, addend, bn, fin))); }
   });
   return AZ_OK;
 }
