@@ -37,7 +37,9 @@ extern "C" int az_abi_struct_size(int32_t which) {
 }
 
 // Streams of this process that may launch split towers (k_tower16s) on a device at the same time: the sum of the slot groups of
-// all live engines with 128-filter fp32 networks (an arena drives two engines side by side).  pick_tower keeps the split only
+// all engines with 128-filter fp32 networks that have a search IN PROGRESS (between az_selfplay_begin / explore_begin and their
+// end: an arena drives two engines side by side; an idle engine -- a host keeps them cached between phases -- holds no CU and is
+// not counted: counting it cost the arena of a training iteration 12.7 s instead of 5.6).  pick_tower keeps the split only
 // while all of them together fit the chip, so that every pair of workgroups is co-resident.
 static std::mutex g_split_mu;
 static std::map<int, int> g_split_streams;
@@ -47,6 +49,7 @@ int split_streams_on_device(int device) {
   return it == g_split_streams.end() ? 0 : it->second;
 }
 static void split_register(az_engine* e, int n) {
+  if (!(e->cfg.oracle == AZ_ORACLE_RESNET && e->cfg.num_filters == 128 && !e->cfg.net_bf16)) n = 0;   // never launches split towers
   std::lock_guard<std::mutex> lk(g_split_mu);
   g_split_streams[e->device] += n - e->split_registered;
   e->split_registered = n;
@@ -373,7 +376,6 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     p.prior_temp = c->prior_temperature; p.nsims = c->num_iters_per_turn; p.temp_len = c->temperature_len;
     for (int i = 0; i < AZ_SCHED_MAX; ++i) { p.temp_xs[i] = c->temperature_xs[i]; p.temp_ys[i] = c->temperature_ys[i]; }
     p.seed = c->seed; p.oracle = c->oracle; p.reset_every = c->reset_every; p.retire = 0;
-    if (c->oracle == AZ_ORACLE_RESNET && c->num_filters == 128 && !c->net_bf16) split_register(e, e->ngroups);
     if (e->vm_rows) {
       // Budget of the growing pool: what the device has left AFTER this engine's fixed allocations, minus what is
       // still to come -- the phase buffer of a bounded phase (num_workers x 4 games of move records is the usual order), the
@@ -985,6 +987,7 @@ static int explore_begin(az_engine* e, const std::vector<int>& slots, const std:
   const int n = (int)slots.size();
   *nga = 0;
   if (!n) return AZ_OK;
+  split_register(e, e->ngroups);                                     // a search is in progress on this engine (explore_end takes it back)
   int maxslot = 0;
   for (int s : slots) maxslot = std::max(maxslot, s);
   AZCHK(reset_wave_state(e));
@@ -1000,6 +1003,7 @@ static int explore_begin(az_engine* e, const std::vector<int>& slots, const std:
   return AZ_OK;
 }
 template <class Gm> static int explore_end(az_engine* e, int nga) {
+  struct Unreg { az_engine* e; ~Unreg() { split_register(e, 0); } } unreg{e};
   if (!nga) return AZ_OK;
   AZCHK(flush_pending<Gm>(e));                                     // the last simulation's expand + backup
   AZCHK(sync_groups(e));
@@ -1144,6 +1148,7 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   e->active_slots = n0;
   for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->group_active[g] = 0;
   for (int i = 0; i < n0; ++i) e->group_active[i / e->gv[0].G]++;
+  split_register(e, e->ngroups);
   e->p.retire = 1;                                                  // an overflowing slot is retired, the phase goes on; set only once
                                                                     // nothing can fail any more (the hooks must never see it: ADVICE r3)
   e->running = true;
@@ -1321,6 +1326,7 @@ extern "C" int az_selfplay_aborted(az_engine* e, int32_t* game_ids, int32_t cap,
 extern "C" int az_selfplay_end(az_engine* e) {
   ENGINE(e);
   e->p.retire = 0;
+  split_register(e, 0);
   if (!e->running) return AZ_OK;
   AZCHK(reset_wave_state(e));                                      // an unfinished simulation (stepping form stopped mid-move) is dropped
   hipLaunchKernelGGL(k_slot_records, dim3((e->v.G + 255) / 256), dim3(256), 0, e->stream, e->v, (int)SR_CLEAR_ACTIVE);

@@ -82,18 +82,23 @@ def test_two_engines_count_together_for_co_residency():
     blob = random_params(0, hp, seed=1)
     kw = dict(game=0, oracle=azhip.ORACLE_RESNET, num_workers=96, batch_size=96, num_iters_per_turn=4, num_blocks=1, num_filters=128,
               num_policy_head_filters=32, num_value_head_filters=32)
-    def full_launch_kernel(e):                                       # steady state: every one of the 96 slots has a leaf
+    def full_launch_kernel(e, other=None):                           # steady state: every one of the 96 slots has a leaf
+        if other is not None:
+            other.selfplay_begin(-1, 0)                              # the other engine has a search in progress
         e.selfplay_begin(-1, 0)
         e.selfplay_step(6)
         k = e.net_last_kernel()
         e.selfplay_end()
+        if other is not None:
+            other.selfplay_end()
         return k
     with azhip.Engine(**kw) as a:
         a.net_set_params(blob)
         alone = full_launch_kernel(a)                                # 2 x 96 workgroups fit 256 CUs
         with azhip.Engine(seed=9, **kw) as b:
             b.net_set_params(blob)
-            together = full_launch_kernel(b)                         # 2 engines x 2 x 96 do not
+            idle = full_launch_kernel(b)                             # `a` exists but is idle (a host keeps engines cached): not counted
+            together = full_launch_kernel(b, other=a)                # both searching: 2 engines x 2 x 96 workgroups do not fit
         again = full_launch_kernel(a)                                # the second engine is gone: split again
-    assert "k_tower16s" in again
+    assert "k_tower16s" in again and "k_tower16s" in idle
     assert "k_tower16s" in alone and "k_tower16s" not in together
