@@ -121,39 +121,46 @@ __global__ void __launch_bounds__(256) k_mem_merge(const az_sample* __restrict__
 }
 // Segments of MERGE_LONG or more samples (the opening positions: one sample per game): a workgroup of 14
 // wavefronts per segment, wavefront f owns word f.  The 64 lanes load 64 consecutive samples at once (all the
-// memory parallelism the serial walk lacks); the additions stay strictly in buffer order -- every lane adds the
-// 64 loaded values one after the other, broadcast with __shfl.
+// memory parallelism the serial walk lacks); the additions stay strictly in buffer order -- the reference's mean over a
+// generator is a sequential fold (memory.jl:89-96), and a Float64 sum in another order is another number.
+// (r4) The 64 loaded words go through LDS and every lane adds them in order from broadcast reads (independent, pipelined; the
+// dependent chain is one v_add_f64 per sample).  Round 3 fetched lane k's word with two v_readlane per sample inside a
+// predicated, fully unrolled loop: 1.5 ms for the 32 768-sample segment of the opening position (16 384 games x 2 images),
+// a third of the whole data-set build of bench.py's memory block.
 __global__ void __launch_bounds__(14 * 64) k_mem_merge_long(const az_sample* __restrict__ s, const unsigned int* __restrict__ order,
                                                             const int* __restrict__ segid, const int* __restrict__ long_count,
                                                             const long long* __restrict__ long_list, az_sample* __restrict__ out) {
   if ((int)blockIdx.x >= *long_count) return;
+  __shared__ unsigned long long sh[14][64];
   const long long i = long_list[2 * blockIdx.x], end = long_list[2 * blockIdx.x + 1], cnt = end - i;
   const int f = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned long long* base = (const unsigned long long*)s;
   unsigned long long* o = (unsigned long long*)(out + (segid[i] - 1));
-  if (f < 2) { if (lane == 0) o[f] = base[(size_t)order[i] * 14 + f]; return; }
   double acc = 0.0;
   long long iacc = 0;
   unsigned long long wn = i + lane < end ? base[(size_t)order[i + lane] * 14 + f] : 0ULL;
-  for (long long j0 = i; j0 < end; j0 += 64) {
-    const unsigned long long w = wn;
+  for (long long j0 = i; j0 < end; j0 += 64) {                       // uniform over the workgroup: every wavefront walks the same segment
+    sh[f][lane] = wn;
     const long long jn = j0 + 64 + lane;                             // the next 64 samples travel while these are added
     wn = jn < end ? base[(size_t)order[jn] * 14 + f] : 0ULL;
+    __syncthreads();
     const int m = (int)((end - j0) < 64 ? (end - j0) : 64);
-    const int wlo = (int)(unsigned int)w, whi = (int)(unsigned int)(w >> 32);
-    const bool first_chunk = j0 == i;
-    // lane k's word through v_readlane (k is a compile-time constant after unrolling): two scalar reads + one add per sample
+    if (f >= 2 && f < 13) {
+      int k = 0;
+      if (j0 == i) { acc = az_u2d(sh[f][0]); k = 1; }                // the sum STARTS with the first sample (keeps -0.0)
+      if (m == 64) {
 #pragma unroll
-    for (int k = 0; k < 64; ++k) {
-      if (k < m) {
-        const unsigned long long x = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(whi, k) << 32) |
-                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(wlo, k);
-        if (f == 13) iacc += (long long)x;
-        else acc = (first_chunk && k == 0) ? az_u2d(x) : acc + az_u2d(x);   // the sum STARTS with the first sample (keeps -0.0)
-      }
+        for (int q = 0; q < 64; ++q) if (q >= k) acc += az_u2d(sh[f][q]);
+      } else for (; k < m; ++k) acc += az_u2d(sh[f][k]);
+    } else if (f == 13) {
+      for (int k = 0; k < m; ++k) iacc += (long long)sh[f][k];
     }
+    __syncthreads();
   }
-  if (lane == 0) o[f] = f == 13 ? (unsigned long long)iacc : az_d2u(acc / (double)cnt);
+  if (lane == 0) {
+    if (f < 2) o[f] = base[(size_t)order[i] * 14 + f];
+    else o[f] = f == 13 ? (unsigned long long)iacc : az_d2u(acc / (double)cnt);
+  }
 }
 // convert_samples (learning.jl:17-51) + per-sample entropy term of Hp (learning.jl:65,111)
 template <class Gm>
