@@ -696,6 +696,7 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
     AZCHK(up(c16_w, &tmp)); n16.conv_w = (const float4*)tmp; n16.conv_ss = nd.conv_ss;
     AZCHK(up(h16_w, &tmp)); n16.head_w = (const float4*)tmp; n16.head_ss = nd.head_ss;
     for (int k = 0; k < 3; ++k) n16.geo[k] = e->d_geo[k];
+    n16.geo[3] = e->d_geo[5];
   }
   e->net16 = n16;
   {

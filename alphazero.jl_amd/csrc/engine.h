@@ -100,11 +100,12 @@ struct az_engine {
   NetDev net;
   Net16bDev net16b;              // bf16 fragments (cfg.net_bf16)
   Net16Dev net16;                // k_tower16 fragments (64 filters)
-  uint16_t* d_geo[5];            // Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h), [3]: 22 tiles (k_tower16b, 8 boards), [4]: 6 tiles (k_conv16_layer of the trainer at small batches)
+  uint16_t* d_geo[6];            // Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h), [3]: 22 tiles (k_tower16b, 8 boards), [4]: 6 tiles (k_conv16_layer of the trainer at small batches), [5]: the exact-fit variant (NTM<Game> tiles), if the game has one
   int nts;                       // row tiles of the game's latency tower variant (NTS<Game>, resnet16.h)
+  int ntm;                       // row tiles of the game's exact-fit variant (NTM<Game>), 0 = none
   char last_tower[96];           // name of the tower kernel that served the most recent network launch (az_net_last_kernel)
   int heads_pick;                // AZHIP_HEADS=16|32 forces k_heads16 / k_heads_mfma; 0 = by launch size
-  int tower_pick;                // AZHIP_TOWER=16|32|3|21|22 forces a tower kernel (3 = k_tower16 with 3 row tiles, 21 = k_tower16x2); 0 = choose per launch
+  int tower_pick;                // AZHIP_TOWER=16|32|3|21|22|7 forces a tower kernel (3 = k_tower16 with 3 row tiles, 21 = k_tower16x2, 7 = the exact-fit variant NTM); 0 = choose per launch
   int num_cu;
   int nn_cap;
   float* d_hfeat; float* d_X; float* d_A; float* d_P; float* d_V; float* d_Pinv;

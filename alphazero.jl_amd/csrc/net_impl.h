@@ -8,6 +8,10 @@
 template <class Gm, int F, bool PLANES_ONLY = false> static int set_kernel_attrs_f() {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F>::BYTES));
+  if constexpr (NTM<Gm> > 0) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, false, NTM<Gm>>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F, NTM<Gm>>::BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16<Gm, F, true, NTM<Gm>>), hipFuncAttributeMaxDynamicSharedMemorySize, T16<Gm, F, NTM<Gm>>::BYTES));
+  }
   if constexpr (F == 64) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
@@ -60,6 +64,9 @@ template <class Gm> static int set_kernel_attrs(az_engine* e) {
   AZCHK((upload_geo<typename T16P<Gm, 64>::Geo>(e, 2)));
   AZCHK((upload_geo<typename T16B<Gm, 128, 22>::Geo>(e, 3)));
   AZCHK((upload_geo<typename T16<Gm, 64, 6>::Geo>(e, 4)));
+  e->d_geo[5] = nullptr;
+  if constexpr (NTM<Gm> > 0) AZCHK((upload_geo<typename T16<Gm, 64, NTM<Gm>>::Geo>(e, 5)));
+  e->ntm = NTM<Gm>;
   return AZ_OK;
 }
 
@@ -70,6 +77,7 @@ static void note_tower(az_engine* e, int tw, int F) {
   if (tw == 2) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16s<%s,%d>", g, F);
   else if (tw == 21) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d>", g, F);
   else if (tw == 3) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=%d>", g, F, e->nts);
+  else if (tw == 7) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=%d>", g, F, e->ntm);
   else if (tw == 16) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=11>", g, F);
   else snprintf(e->last_tower, sizeof e->last_tower, "k_tower<%s,%d>", g, F);
 }
@@ -90,7 +98,7 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
   const bool can_split = F == 128 && !e->cfg.net_bf16 && !e->use_graphs && e->cfg.num_blocks <= 127 && !e->split_off &&
                          2 * std::max(std::max(1, e->ngroups), split_streams_on_device(e->device)) * ((n + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB) <= (e->num_cu > 0 ? e->num_cu : 256);
   if (e->tower_pick == 2 && can_split) return 2;
-  if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64))) return e->tower_pick;
+  if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64) || (e->tower_pick == 7 && NTM<Gm> > 0))) return e->tower_pick;
   if (e->cfg.net_bf16) {                                           // k_tower16b: 22 (128 filters), 11 or 3 row tiles
     if (e->tower_pick == 3 || e->tower_pick == 16) return e->tower_pick;
     if (e->tower_pick == 22 && F == 128) return 22;
@@ -121,6 +129,15 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
   const double c32 = (double)((b32 + cu - 1) / cu) * TOWER_ROWS;     // k_tower (32x32x2) computes every tap
   const double c3 = 1.1 * (double)((b3 + cu - 1) / cu) * T16<Gm, F, NTS<Gm>>::RPAD * f3;
   if (c3 <= c16 && c3 <= c32) return can_split && e->tower_pick != 3 ? 2 : 3;
+  // (r4) the exact-fit variant (NTM tiles: whole boards, no padding rows): where its workgroups fill the CUs evenly it beats
+  // the 11-tile form by the padding rows and by the last, partly filled round of workgroups
+  if constexpr (NTM<Gm> > 0) {
+    using TM = T16<Gm, F, NTM<Gm>>;
+    constexpr double fm = TM::Geo::tab.cost / (9.0 * NTM<Gm>);
+    const long bm = (n + TM::TB - 1) / TM::TB;
+    const double cm = 1.03 * (double)((bm + cu - 1) / cu) * TM::RPAD * fm;     // +3 %: fewer rows per weight fragment
+    if (cm < c16 && cm < c32 && (F != 64 || cm < (double)(((n + T16P<Gm, 64>::TB - 1) / T16P<Gm, 64>::TB + cu - 1) / cu) * T16P<Gm, 64>::RPAD * f21)) return 7;
+  }
   // paired k_tower16x2: 336 rows = 8 Connect-Four boards per workgroup, no padding rows.  Its 92 KB of LDS allow one
   // workgroup per CU, so with several slot groups the groups' towers cannot interleave on a CU (Connect-Four, two groups:
   // 3.80 vs 4.11 M sims/s in round 1): +8 % on its cost there
@@ -141,6 +158,7 @@ template <class Gm, int F> static double tower_exec_frac(const az_engine* e, int
     return T16B<Gm, F>::Geo::tab.cost / (9.0 * 11);
   }
   if (tw == 2 || tw == 3) return T16<Gm, F, NTS<Gm>>::Geo::tab.cost / (9.0 * NTS<Gm>);
+  if constexpr (NTM<Gm> > 0) { if (tw == 7) return T16<Gm, F, NTM<Gm>>::Geo::tab.cost / (9.0 * NTM<Gm>); }
   if (tw == 16) return T16<Gm, F>::Geo::tab.cost / (9.0 * T16<Gm, F>::NTILE);
   if (tw == 21) return T16P<Gm, 64>::Geo::tab.cost / (9.0 * T16P<Gm, 64>::NTW);
   return 1.0;
@@ -221,6 +239,11 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
   } else if (tw == 21) {
     if constexpr (F == 64)
       LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
+  } else if (tw == 7) {
+    if constexpr (NTM<Gm> > 0) {
+      using TM = T16<Gm, F, NTM<Gm>>;
+      LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES, NTM<Gm>>), (n_max + TM::TB - 1) / TM::TB, THR16, (TM::BYTES), e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
+    }
   } else if (tw == 3)
     LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16<Gm, F, FROM_PLANES, NTS<Gm>>), (n_max + TB3 - 1) / TB3, THR16, LDS3, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
   else if (tw == 16)
@@ -271,6 +294,11 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   } else if (tw == 21) {
     if constexpr (F == 64)
       LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+  } else if (tw == 7) {
+    if constexpr (NTM<Gm> > 0) {
+      using TM = T16<Gm, F, NTM<Gm>>;
+      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, NTM<Gm>>), (N + TM::TB - 1) / TM::TB, THR16, (TM::BYTES), e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+    }
   } else if (tw == 3)
     LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, NTS<Gm>>), (N + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   else if (tw == 16)

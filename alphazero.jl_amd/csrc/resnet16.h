@@ -31,7 +31,7 @@ struct Net16Dev {
   const float* conv_ss;     // [2*nblocks][2][64]
   const float4* head_w;     // [4 col tiles][4][64] float4
   const float* head_ss;     // [2][64]
-  const uint16_t* geo[3];   // row permutation tables (Geo16: pos [RPAD], nbr [9][RPAD]) of the 11-tile, 3-tile and 21-tile kernels
+  const uint16_t* geo[4];   // row permutation tables (Geo16: pos [RPAD], nbr [9][RPAD]) of the 11-tile, 3-tile and 21-tile kernels, [3]: the exact-fit variant (NTM)
   unsigned long long* dbg;  // optional [workgroups][8] s_memtime stamps (az_debug_tower_timeline): 0 start, 1 stem done, 2 tower done, 3 features written; layer 2: 6 start, 4 convolution done, 5 barrier passed, 7 epilogue done
 };
 // ---------------------------------------------------------------------------------------------------------------
@@ -412,6 +412,12 @@ __device__ __forceinline__ void conv16p(const float* __restrict__ buf, const uin
 template <int F> struct T16Threads { static constexpr int V = 64 * (F / 16); };
 // row tiles of the latency variant: 3 (one Connect-Four board, 5 Tic-tac-toe, 3 Mancala), or what one board needs (9x9: 6)
 template <class Gm> constexpr int NTS = Gm::P <= 48 ? 3 : (Gm::P + 15) / 16;
+// (r4) row tiles of the EXACT-FIT variant: the smallest tile count (4 .. 10) whose rows are a whole number of boards -- no
+// padding rows and, for the slot counts of the BASELINE configurations, a whole number of workgroups per CU: Mancala 7 tiles =
+// 112 rows = 8 boards (8192 slots = 1024 workgroups = 4 per CU; the 11-tile form: 12 boards of 176 rows, 683 workgroups = 2.67
+// per CU), Tic-tac-toe 9 tiles = 16 boards.  0 = the game has none (Connect-Four's is the paired 21-tile kernel).
+template <class Gm> constexpr int ntm_of() { for (int nt = 4; nt <= 10; ++nt) if ((16 * nt) % Gm::P == 0) return nt; return 0; }
+template <class Gm> constexpr int NTM = ntm_of<Gm>();
 
 // What a workgroup does after it has written a layer's outputs (its own channels) into the activation buffer.
 // NoXch: the workgroup owns every channel -- a barrier.
@@ -669,7 +675,7 @@ __device__ __forceinline__ void tower16_fill(float* __restrict__ buf, float* __r
 }
 
 template <class Gm, int F, bool FROM_PLANES, int NT = 11>
-__global__ void __launch_bounds__(T16Threads<F>::V, 2)
+__global__ void __launch_bounds__(T16Threads<F>::V, 2)   // (three workgroups per CU for the LDS-light exact-fit variants: measured, no gain: 28.6 vs 28.9 M sims/s on Mancala)
 k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
           const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
   using T = T16<Gm, F, NT>;
@@ -681,7 +687,7 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
   const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
   const int board0 = blockIdx.x * T::TB;
   if (board0 >= n) return;
-  tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[NT == 11 ? 0 : 1], leaf_env, eval_slots, X, n, board0, threadIdx.x);
+  tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[NT == 11 ? 0 : NT == NTS<Gm> ? 1 : 3], leaf_env, eval_slots, X, n, board0, threadIdx.x);
   __syncthreads();
   tower16_wave<T, FROM_PLANES, NT, 0>(net, buf, planes, nbr, pos, threadIdx.x >> 6, threadIdx.x & 63, n, board0, hfeat);
 }

@@ -98,7 +98,7 @@ def test_param_count_matches_reference_doc():
 @pytest.mark.parametrize("game,nblocks,n,F,heads", [(R.C4, 5, 64, 64, (32, 32)), (R.C4, 1, 7, 64, (32, 32)), (R.TTT, 2, 33, 64, (32, 32)),
                                                       (R.MANCALA, 2, 20, 64, (32, 32)), (R.C4, 2, 40, 128, (32, 32)),
                                                       (R.C4, 1, 9, 64, (2, 1)), (R.TTT, 1, 5, 128, (16, 8))])
-@pytest.mark.parametrize("tower", ["16", "32", "3", "21", "2"])
+@pytest.mark.parametrize("tower", ["16", "32", "3", "21", "2", "7"])
 def test_hip_forward_bit_exact_vs_oracle(game, nblocks, n, F, heads, tower, monkeypatch):
     """F = 128 is the shipped connect-four network (games/connect-four/params.jl:7-13); heads (2, 1) are the
     ResNetHP defaults (resnet.jl:30-37) and take the VALU dense-head kernel.  All tower kernels (k_tower16 on
@@ -120,6 +120,8 @@ def test_hip_forward_bit_exact_vs_oracle(game, nblocks, n, F, heads, tower, monk
         keys = np.array([g.key() for g in envs], dtype=np.uint64)
         Pk, Vk = e.net_evaluate_keys(keys)
         Xd, Ad = e.encode(keys)
+        if tower == "7" and game in (R.MANCALA, R.TTT):             # the exact-fit variant: 7 row tiles = 8 Mancala boards, 9 = 16 Tic-tac-toe boards
+            assert e.net_last_kernel().endswith("NT=%d>" % (7 if game == R.MANCALA else 9)), e.net_last_kernel()
     assert np.array_equal(Xd, X) and np.array_equal(Ad, A)          # vectorize_state / actions_mask twins
     Pr, Vr, Pir = R.net_forward_normalized(game, (nblocks, F, npf, nvf), blob, X, A)
     Pt, Vt, Pit = torch_forward_normalized(game, hp, blob, X, A)
