@@ -509,6 +509,7 @@ def main():
     ap.add_argument("--no-iteration", action="store_true", help="skip extra.iteration (one whole training iteration at the reference's shipped Connect-Four parameters, ~1-2 min)")
     ap.add_argument("--iteration", action="store_true", help="run ONLY the headline and extra.iteration (skips the other extras and the CPU baseline)")
     ap.add_argument("--backend", default="gloo", help="torch.distributed backend of the RENDEZVOUS for N > 1: a barrier, two scalar reductions and the 128-byte RCCL id are all that goes through it, so gloo (CPU) is the default and the process holds exactly ONE RCCL instance, the one libazhip.so loads for az_comm_*; nccl = torch's bundled RCCL as well")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed region (no one-group leg, no extras, no CPU baseline): the run whose rocprofv3 kernel stats are comparable with roofline.avg_launch_ms (profiles/r4/bench_headline_kernel_stats.csv)")
     ap.add_argument("--no-prof", action="store_true", help="do not wrap launches in HIP events")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel class (default: only the dominant kernel, k_tower)")
     args = ap.parse_args()
@@ -648,7 +649,7 @@ def main():
             if out["roofline"]["traffic"] is None:
                 out["roofline"]["traffic"] = pmc_traffic(eng_kernel, out["roofline"]["avg_boards_per_launch"])
             out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
-        if prof is not None and world == 1:
+        if prof is not None and world == 1 and not args.headline_only:
             alone, tree = alone_and_tree(args, blob, hp, dev_index, eng_kernel)
             out["roofline_kernel_alone"] = alone
             out["roofline_tree"] = tree
@@ -656,7 +657,7 @@ def main():
             if world > 1 and "error" not in gather and gather.get("ranks") != world:
                 gather["error"] = "the exchange saw %s ranks, the job has %d" % (gather.get("ranks"), world)
             out["gather"] = gather
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and not args.headline_only:
             # The rest of DESIGN.md §0's table, measured here so that the driver's line carries it (bounded: ~40 s in all).
             # None of it is part of `value`.  A failing block reports its error instead of taking the headline with it.
             mk = ResNetHP
@@ -687,7 +688,7 @@ def main():
                     out["extra"][name] = fn()
                 except Exception as ex:
                     out["extra"][name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-        if world == 1 and not args.no_cpu_baseline and not args.iteration:
+        if world == 1 and not args.no_cpu_baseline and not args.iteration and not args.headline_only:
             out["cpu_baseline"] = cpu_baseline(blob, hp, args.sims)
         print(json.dumps(out), flush=True)
     if gather_hung:

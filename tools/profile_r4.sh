@@ -7,8 +7,14 @@
 cd "$(dirname "$0")/.."
 ROOT=$PWD; TAG=${TAG:-r4prof}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 d=/tmp/prof_bench; rm -rf $d
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python $ROOT/bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-iteration > $OUT/bench_line.json 2> $OUT/bench_stderr.txt)
+[ -z "$HEADLINE_ONLY" ] && (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python $ROOT/bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-iteration > $OUT/bench_line.json 2> $OUT/bench_stderr.txt)
 f=$(find $d -name "*kernel_stats.csv" -printf "%s %p\n" | sort -n | tail -1 | cut -d" " -f2); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv    # the bench process itself (the host-stepped example is a child with its own, smaller file)
+# (1b) the timed region ALONE (--headline-only): the only k_tower16 launches of this process are the 2048-board launches of the two
+# slot groups, so the trace's average duration is comparable with the line's roofline.avg_launch_ms (HIP events in the same run)
+d=/tmp/prof_headline; rm -rf $d
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python $ROOT/bench.py --steps 2000 --warmup 5 --headline-only > $OUT/bench_headline_line.json 2> $OUT/bench_headline_stderr.txt)
+f=$(find $d -name "*kernel_stats.csv" -printf "%s %p\n" | sort -n | tail -1 | cut -d" " -f2); [ -n "$f" ] && cp $f $OUT/bench_headline_kernel_stats.csv
+[ -n "$HEADLINE_ONLY" ] && exit 0
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32"; do
   i=$((i+1)); d=/tmp/pmc_f32_$i; rm -rf $d
