@@ -87,7 +87,14 @@ def _run_case(game_hip, game_ref, slots, groups, nsims, nsample, first_id, sched
                 dev_tensors = d.tensors()
             mem.close()
 
+    try:                                                             # every replay is one worker: no OpenMP team per call (64 calls x a
+        gomp = C.CDLL("libgomp.so.1")                                # team of all cores, spinning, is what made this slow)
+    except OSError:
+        gomp = None
+
     def replay(gid):
+        if gomp is not None:
+            gomp.omp_set_num_threads(1)                              # per calling thread
         rg, rm, _ = R.simulate(game_ref, R.ORACLE_NET, 1, 1, nsims, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0,
                                temp_xs=sched[0], temp_ys=sched[1], reset_every=1, seed=1, net=(5, 64, 32, 32, blob), first_game_id=gid)
         return _rec(rg[0], rm), [rm[rg[0].first_move + k] for k in range(rg[0].num_moves)]
