@@ -261,6 +261,13 @@ def memory_block(azhip, dev_index, games=16384):
                                       "algorithmic_bytes": ds_bytes, "note": "wall time of the call (host loop, launches and synchronisations included)"}}}
 
 
+def _tower_fallbacks(azhip):
+    """az_selfplay_stats.tower_fallbacks summed over the engines the mirror keeps cached (arena players, the self-play engine): > 0
+    means a split tower gave up on a partner workgroup (2 s of waiting) and those engines run unsplit since"""
+    from azhip import engine as E
+    return int(sum(e.selfplay_stats().tower_fallbacks for e in E._cache.values() if e._h is not None))
+
+
 def arena_block(azhip, dev_index, filters=128, games=128, sims=600):
     """one checkpoint evaluation compare_networks (src/training.jl:159-172) at the reference's arena
     parameters (games/connect-four/params.jl:31-44): 128 games on 128 workers, 600 sims/move, two ResNet 5x128, flip 0.5,
@@ -275,7 +282,7 @@ def arena_block(azhip, dev_index, filters=128, games=128, sims=600):
     ev = azhip.compare_networks(gspec, c, b, params, device=dev_index)
     dt = time.perf_counter() - t0
     return {"workload": "compare_networks: %d games, %d workers, %d sims/move, two ResNet 5x%d fp32 (random weights)" % (games, games, sims, filters),
-            "seconds": dt, "seconds_inside_simulate": ev.time, "avgr": ev.avgr, "redundancy": ev.redundancy}
+            "seconds": dt, "seconds_inside_simulate": ev.time, "avgr": ev.avgr, "redundancy": ev.redundancy, "tower_fallbacks": _tower_fallbacks(azhip)}
 
 
 def iteration_block(azhip, dev_index, num_games=5000, workers=4096):
@@ -320,7 +327,7 @@ def iteration_block(azhip, dev_index, num_games=5000, workers=4096):
     return {"workload": iteration_block.__doc__.split("\n")[0].strip() + " -- games/connect-four/params.jl:5-75, %d workers" % workers,
             "seconds": total, "games": num_games, "samples": samples, "sims_per_sec_self_play": samples * 600 / t_sim,
             "optimiser_steps": int(len(lr.losses)), "loss_first_last": [float(lr.losses[0]), float(lr.losses[-1])] if len(lr.losses) else None,
-            "arena_avgr": lr.checkpoints[0].evaluation.avgr if lr.checkpoints else None, "nn_replaced": bool(lr.nn_replaced),
+            "arena_avgr": lr.checkpoints[0].evaluation.avgr if lr.checkpoints else None, "nn_replaced": bool(lr.nn_replaced), "tower_fallbacks": _tower_fallbacks(azhip),
             "phases_seconds": phases, "phases_share": {k: v / total for k, v in phases.items()},
             "reference": "README.md:76-78: 'about one hour' per iteration on the authors' desktop GPU -- quoted, NOT reproduced here (no Julia in the image)"}
 
@@ -682,6 +689,8 @@ def main():
                 blocks.append(("iteration", lambda: iteration_block(azhip, dev_index)))
             if args.iteration:
                 blocks = [b for b in blocks if b[0] == "iteration"]
+            if os.environ.get("AZ_BENCH_ONLY"):                      # A/B aid: a comma-separated subset of the extra blocks
+                blocks = [b for b in blocks if b[0] in os.environ["AZ_BENCH_ONLY"].split(",")]
             out["extra"] = {}
             for name, fn in blocks:
                 try:
