@@ -686,7 +686,7 @@ def main():
             blocks += [("trainer_5x64", lambda: trainer_block(azhip, dev_index, 64)), ("trainer_5x128", lambda: trainer_block(azhip, dev_index, 128)),
                        ("memory_pipeline", lambda: memory_block(azhip, dev_index)), ("arena_128", lambda: arena_block(azhip, dev_index))]
             if not args.no_iteration:
-                blocks.append(("iteration", lambda: iteration_block(azhip, dev_index)))
+                blocks.append(("iteration", lambda: iteration_block(azhip, dev_index, workers=int(os.environ.get("AZ_BENCH_ITER_WORKERS", "4096")))))
             if args.iteration:
                 blocks = [b for b in blocks if b[0] == "iteration"]
             if os.environ.get("AZ_BENCH_ONLY"):                      # A/B aid: a comma-separated subset of the extra blocks

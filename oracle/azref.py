@@ -21,7 +21,7 @@ CELLS = 42
 
 def build(force=False):
     src = os.path.join(HERE, "azref.c")
-    hdr = os.path.join(HERE, "..", "include", "az_numerics.h")
+    hdr = os.path.join(HERE, "ref_numerics.h")            # the oracle's own numerics (not the product's include/az_numerics.h)
     if (force or not os.path.exists(LIB)
             or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
         subprocess.check_call(["make", "-s", "-C", HERE, "libazref.so"])
