@@ -55,6 +55,11 @@ static int load() {
   Dl_info info;
   const char* forced = getenv("AZHIP_RCCL_LIB");
   if (forced && *forced) {
+    // a transport seam for the tests (several ranks on one GPU: tests/rccl_stub), not a plug-in point: only a library that calls
+    // itself librccl* is accepted, and it must export the NCCL entry points below like the real one
+    const char* base = strrchr(forced, '/');
+    base = base ? base + 1 : forced;
+    if (strncmp(base, "librccl", 7) != 0) return fail(AZ_ERR_COMM, "AZHIP_RCCL_LIB=%s: not a librccl* library", forced);
     so = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
     if (!so) return fail(AZ_ERR_COMM, "cannot load AZHIP_RCCL_LIB=%s (%s)", forced, dlerror());
   }
