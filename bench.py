@@ -268,6 +268,12 @@ def _tower_fallbacks(azhip):
     return int(sum(e.selfplay_stats().tower_fallbacks for e in E._cache.values() if e._h is not None))
 
 
+def _cached_kernels(azhip):
+    """tower kernel of the last network launch of every cached engine (role: kernel)"""
+    from azhip import engine as E
+    return {k[0] or "engine%d" % i: e.net_last_kernel() for i, (k, e) in enumerate(E._cache.items()) if e._h is not None}
+
+
 def arena_block(azhip, dev_index, filters=128, games=128, sims=600):
     """one checkpoint evaluation compare_networks (src/training.jl:159-172) at the reference's arena
     parameters (games/connect-four/params.jl:31-44): 128 games on 128 workers, 600 sims/move, two ResNet 5x128, flip 0.5,
@@ -327,7 +333,7 @@ def iteration_block(azhip, dev_index, num_games=5000, workers=4096):
     return {"workload": iteration_block.__doc__.split("\n")[0].strip() + " -- games/connect-four/params.jl:5-75, %d workers" % workers,
             "seconds": total, "games": num_games, "samples": samples, "sims_per_sec_self_play": samples * 600 / t_sim,
             "optimiser_steps": int(len(lr.losses)), "loss_first_last": [float(lr.losses[0]), float(lr.losses[-1])] if len(lr.losses) else None,
-            "arena_avgr": lr.checkpoints[0].evaluation.avgr if lr.checkpoints else None, "nn_replaced": bool(lr.nn_replaced), "tower_fallbacks": _tower_fallbacks(azhip),
+            "arena_avgr": lr.checkpoints[0].evaluation.avgr if lr.checkpoints else None, "nn_replaced": bool(lr.nn_replaced), "tower_fallbacks": _tower_fallbacks(azhip), "last_tower_kernels": _cached_kernels(azhip),
             "phases_seconds": phases, "phases_share": {k: v / total for k, v in phases.items()},
             "reference": "README.md:76-78: 'about one hour' per iteration on the authors' desktop GPU -- quoted, NOT reproduced here (no Julia in the image)"}
 
