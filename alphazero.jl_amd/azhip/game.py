@@ -130,3 +130,10 @@ class GameEnv:
 
     def vectorize_state(self):
         return self._spec.vectorize_state(self._state)
+
+    def apply_random_symmetry(self, rng):
+        """GI.apply_random_symmetry! (game.jl:329-336)."""
+        syms = self._spec.symmetries(self._state) if hasattr(self._spec, "symmetries") else []
+        assert syms, "no symmetries were declared for this game"
+        symstate, _ = syms[int(rng.integers(len(syms)))]
+        self.set_state(symstate)

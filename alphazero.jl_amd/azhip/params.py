@@ -85,8 +85,6 @@ def check_sim_params(p: SimParams, arena=False):
         raise ValueError("batch_size must be <= num_workers")
     if not 0.0 <= p.flip_probability <= 1.0:
         raise ValueError("flip_probability must be in [0, 1]")
-    if p.flip_probability != 0.0 and not arena:
-        raise ValueError("flip_probability > 0 is not supported on the device self-play path (arena only)")
 
 
 def engine_options(mcts: MctsParams, sim: SimParams, seed=1, arena=False):

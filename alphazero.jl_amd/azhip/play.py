@@ -1,4 +1,6 @@
 """Player abstraction of the path (src/play.jl:156-214,298-315): MctsPlayer, think, play_game."""
+import time
+
 import numpy as np
 
 from . import mcts as MCTS
@@ -44,10 +46,10 @@ class MctsPlayer:
     """MctsPlayer(gspec, oracle, params::MctsParams; timeout=nothing), play.jl:156-214"""
 
     def __init__(self, gspec, oracle, params: MctsParams, timeout=None, seed=1):
-        if timeout is not None:
-            raise ValueError("timeout-driven search is not supported on the device path")
         assert params.num_iters_per_turn > 0
-        self.gspec, self.oracle, self.params = gspec, oracle, params
+        if timeout is not None and not timeout >= 0:
+            raise ValueError("timeout must be None or a number of seconds >= 0")
+        self.gspec, self.oracle, self.params, self.timeout = gspec, oracle, params, timeout
         self.niters, self.τ, self.seed = params.num_iters_per_turn, params.temperature, seed
         self._mcts = None
 
@@ -60,7 +62,12 @@ class MctsPlayer:
         return self._mcts
 
     def think(self, game):
-        self.mcts.explore(game, self.niters)
+        if self.timeout is None:                      # fixed number of MCTS simulations, play.jl:198
+            self.mcts.explore(game, self.niters)
+        else:                                         # whole explore! calls (each with its own noise draw) until the time is up,
+            start = time.monotonic()                  # play.jl:199-204; wall-clock driven, so not reproducible by construction
+            while time.monotonic() - start < self.timeout:
+                self.mcts.explore(game, self.niters)
         return self.mcts.policy(game)
 
     def player_temperature(self, game, turn):
@@ -132,14 +139,14 @@ def flipped_colors(p: TwoPlayers):
 def play_game(gspec, player, flip_probability=0.0, rng=None):
     """play_game, play.jl:298-315 -- host-stepped (one device search per move).  Self-play at scale goes
     through simulations.simulate instead, which runs this loop for thousands of games on the GPU."""
-    if flip_probability != 0.0:
-        raise ValueError("flip_probability > 0 is not supported")
     rng = rng or np.random.Generator(np.random.Philox(1))
     game = gspec.init()
     trace = Trace(game.current_state())
     while True:
         if game.game_terminated():
             return trace
+        if flip_probability != 0.0 and rng.random() < flip_probability:      # play.jl:305-307
+            game.apply_random_symmetry(rng)
         actions, pi_target = player.think(game)
         tau = player.player_temperature(game, len(trace))
         pi_sample = apply_temperature(pi_target, tau)

@@ -376,6 +376,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     p.prior_temp = c->prior_temperature; p.nsims = c->num_iters_per_turn; p.temp_len = c->temperature_len;
     for (int i = 0; i < AZ_SCHED_MAX; ++i) { p.temp_xs[i] = c->temperature_xs[i]; p.temp_ys[i] = c->temperature_ys[i]; }
     p.seed = c->seed; p.oracle = c->oracle; p.reset_every = c->reset_every; p.retire = 0;
+    p.flip_p = c->flip_probability;                                  // read by the self-play kernels only (k_move, k_start_games without roots)
     if (e->vm_rows) {
       // Budget of the growing pool: what the device has left AFTER this engine's fixed allocations, minus what is
       // still to come -- the phase buffer of a bounded phase (num_workers x 4 games of move records is the usual order), the
@@ -1115,7 +1116,11 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   if (e->running) return fail(AZ_ERR_STATE, "self-play already in progress");
   if (num_games == 0) return fail(AZ_ERR_BAD_ARG, "num_games must be != 0");
   if (e->p.nsims < 2) return fail(AZ_ERR_BAD_ARG, "num_iters_per_turn = 0 (NetworkPlayer) is for az_arena_run only");
-  if (e->cfg.flip_probability != 0.0) return fail(AZ_ERR_BAD_ARG, "flip_probability != 0 is honoured by az_arena_run only (self-play configs use 0: the reference's traces pair the un-flipped state with the flipped policy, play.jl:305-313)");
+  if (e->cfg.flip_probability != 0.0) {
+    bool nosym = false;
+    DISPATCH_GAME(e->cfg.game, nosym = Gm::NSYM == 0);
+    if (nosym) return fail(AZ_ERR_BAD_ARG, "flip_probability != 0 but no symmetries were declared for this game (game.jl:332)");
+  }
   if (e->cfg.oracle == AZ_ORACLE_RESNET && !e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
   const int G = e->v.G;
   // a fresh player per worker (simulations.jl:217-218): empty trees, zero counters

@@ -41,6 +41,7 @@ struct DParams {
   double temp_ys[AZ_SCHED_MAX];
   uint64_t seed;
   int oracle, reset_every;
+  double flip_p;          // play_game's flip_probability (play.jl:305-307) for the self-play loop on the device; the arena flips on the host
   int retire;             // 1 (self-play): a slot whose node pool or move record overflows is RETIRED (finished = 2, the game is
                           // reported as aborted, the phase goes on); 0 (explore! / arena hooks): a device error
 };
@@ -657,6 +658,28 @@ __host__ __device__ inline int select_action_net(const DParams& p, const float* 
   return sample_policy(p, acts, pi, n, mv, game_id);
 }
 
+// play_game's per-turn flip (play.jl:305-307 -> apply_random_symmetry!, game.jl:329-336) for the device's self-play loop: turn
+// `mv` of the slot's game starts from `env`.  The turn's trace record gets the state BEFORE the flip (trace.states[i] is pushed
+// before the next turn's flip, play.jl:313) and 1 + the symmetry's index in N[AZ_MAX_ACTIONS]; `env` becomes the image the
+// player thinks about and plays on.  Same draws as the arena's host loop (az_arena_run) and the oracle.
+template <class Gm>
+__device__ inline void turn_flip(const DView& v, const DParams& p, int slot, GEnv& env, uint32_t game_id, uint32_t mv) {
+  if ((int)mv >= v.max_moves) return;                             // the next k_move retires the slot before it reads the record
+  az_move_rec* rec = v.trace + (size_t)slot * v.max_moves + mv;
+  rec->key[0] = env.a; rec->key[1] = env.b;
+  int k1 = 0;
+  if (Gm::NSYM > 0) {
+    az_rng r = az_rng_make(p.seed, game_id, mv, AZ_RNG_FLIP);
+    if (az_rng_f64(&r) < p.flip_p) {
+      int k = (int)(az_rng_f64(&r) * (double)Gm::NSYM);
+      if (k >= Gm::NSYM) k = Gm::NSYM - 1;
+      env = Gm::sym(env, k);
+      k1 = k + 1;
+    }
+  }
+  rec->N[AZ_MAX_ACTIONS] = k1;
+}
+
 template <class Gm>
 __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
   __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
@@ -680,8 +703,21 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
     return;
   }
   az_move_rec* rec = v.trace + (size_t)slot * v.max_moves + mv;
-  rec->key[0] = env.a; rec->key[1] = env.b;
-  for (int a = 0; a < AZ_MAX_ACTIONS + 1; ++a) rec->N[a] = (a < Gm::A && ((m >> a) & 1)) ? Nn[a] : 0;
+  if (p.flip_p == 0.0) {
+    rec->key[0] = env.a; rec->key[1] = env.b;
+    for (int a = 0; a < AZ_MAX_ACTIONS + 1; ++a) rec->N[a] = (a < Gm::A && ((m >> a) & 1)) ? Nn[a] : 0;
+  } else {
+    // turn_flip has written the turn's un-flipped state and the symmetry.  The reference's trace keeps pi_target as a vector
+    // over the AVAILABLE actions of the state the player saw; convert_sample and apply_symmetry spread it over the actions mask of
+    // trace.states[i], the un-flipped state (learning.jl:31-33, memory.jl:115-118): the i-th available action of the image lands on the i-th available action of the
+    // state.  The record stores the counts that way, so that everything downstream of the trace reads it as before.
+    GEnv pre; pre.a = rec->key[0]; pre.b = rec->key[1]; pre.fin = env.fin;
+    const uint32_t mp = rec->N[AZ_MAX_ACTIONS] ? Gm::mask(pre) : m;
+    int cnt[AZ_MAX_ACTIONS], n = 0;
+    for (int a = 0; a < Gm::A; ++a) if ((m >> a) & 1) cnt[n++] = Nn[a];
+    n = 0;
+    for (int a = 0; a < AZ_MAX_ACTIONS; ++a) rec->N[a] = (a < Gm::A && ((mp >> a) & 1)) ? cnt[n++] : 0;
+  }
   const int act = select_action<Gm>(p, Nn, m, mv, v.game_id[slot]);
   Gm::play(env, act);
   rec->action = act;
@@ -708,6 +744,7 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
       sr->node_count = 0;
     }
   } else {
+    if (p.flip_p != 0.0) { turn_flip<Gm>(v, p, slot, env, v.game_id[slot], mv + 1); sr->set_root(env); }
     arm_noise<Gm>(v, p, slot, env);                               // next explore! draws its eta
   }
   (void)L;
@@ -737,6 +774,7 @@ __global__ void __launch_bounds__(256) k_start_games(DView v, DParams p, const i
     ep = 1; sr->node_count = 0;
   }
   sr->epoch = ep;
+  if (!roots && p.flip_p != 0.0) { turn_flip<Gm>(v, p, slot, env, v.game_id[slot], 0); sr->set_root(env); }   // self-play: the first turn's flip
 }
 // eta for explore!: given by the caller (full action index) or drawn from the RNG contract
 template <class Gm>

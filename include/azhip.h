@@ -112,7 +112,7 @@ typedef struct {
                                  evaluates every pending leaf of a wave in one pass */
   int32_t reset_every;        /* reset a slot's tree every n games; 0 = never (`nothing`) */
   int32_t fill_batches;       /* accepted, no effect: test-mode BN is per sample (Appendix A.13) */
-  double flip_probability;    /* play.jl:305-307; honoured by az_arena_run, self-play requires 0 */
+  double flip_probability;    /* play.jl:305-307; honoured by az_selfplay_* (on the device) and az_arena_run */
   uint64_t seed;
   /* capacities; 0 = derive from the game and num_iters_per_turn */
   int32_t max_nodes_per_slot;
@@ -198,7 +198,12 @@ int az_mcts_counters(az_engine* e, int32_t slot, int64_t* total_simulations,
 
 /* ---- self-play (simulate, src/simulations.jl:207-244; play_game, src/play.jl:298-315) --- */
 /* One record per move: state BEFORE the move, visit counts by full action index (policy =
- * N / sum N, src/mcts.jl:255-271), the action played (0-based), white reward after it. */
+ * N / sum N, src/mcts.jl:255-271), the action played (0-based), white reward after it.
+ * Self-play with flip_probability > 0 (play.jl:305-307): key is trace.states[i], the state BEFORE the turn's random
+ * symmetry; N[AZ_MAX_ACTIONS] = 1 + the symmetry's index in GI.symmetries (0 = the turn was not flipped); `action` is
+ * the action played on the IMAGE; N[0..A) hold the image's visit counts placed on the AVAILABLE actions of `key` by
+ * rank -- what the reference's convert_sample does with the trace's policy vector (learning.jl:31-33, memory.jl:115-118),
+ * so az_memory_push* read a flipped trace like any other. */
 typedef struct {
   uint64_t key[2];
   int32_t N[AZ_MAX_ACTIONS + 1];

@@ -154,7 +154,6 @@ pad8(v, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), 8)
 "MctsParams + SimParams + ResNetHP -> az_engine_cfg (SURVEY.md §8b config mapping)"
 function make_cfg(gspec, mcts::MctsParams, sim::SimParams, hp; oracle=2, seed=1, device=0, arena=false, bf16=false)
   xs, ys = schedule_points(mcts.temperature)
-  @assert arena || iszero(sim.flip_probability) "flip_probability > 0 is honoured by the arena only"
   EngineCfg(Int32(sizeof(EngineCfg)), device, game_id(gspec), oracle,
     mcts.gamma, mcts.cpuct, mcts.dirichlet_noise_ϵ, mcts.dirichlet_noise_α, mcts.prior_temperature,
     mcts.num_iters_per_turn, length(xs), pad8(xs, Int32), pad8(ys, Float64),

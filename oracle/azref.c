@@ -948,6 +948,7 @@ typedef struct {
   int game, oracle_kind;
   int nblocks, F, npf, nvf; const float* blob;
   int first_game_id;   /* azr_simulate: global id of the first game (a shard of simulate_distributed, simulations.jl:268-278) */
+  double flip_probability;   /* azr_simulate: play_game's keyword (play.jl:297, simulations.jl:227); azr_arena takes its own argument */
 } azr_sim_params;
 
 /* One trace record per move: state BEFORE the move (packed key), visit counts by action
@@ -976,12 +977,16 @@ typedef struct {
  * game ids are handed out in increasing order, ties between workers finishing in the same
  * round resolved by worker index (the reference's assignment is a race, util.jl:181-188).
  * Returns the number of move records written. */
+int azr_num_symmetries(int game);
+static void apply_symmetry(azr_env* g, int k);
 int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap) {
   int G = p->num_workers < p->num_games ? p->num_workers : p->num_games;
   azr_slot* slots = calloc((size_t)G, sizeof(azr_slot));
   int64_t nm = 0;
   int next_game = 0, finished = 0;
   int A = azr_num_actions_(p->game);
+  int nsym = azr_num_symmetries(p->game);
+  if (p->flip_probability != 0. && nsym == 0) { fprintf(stderr, "azref: no symmetries were declared for this game\n"); abort(); }
   for (int s = 0; s < G; ++s) {
     slots[s].mcts = azr_mcts_new(p->game, p->oracle_kind, p->gamma, p->cpuct, p->noise_eps, p->noise_alpha, p->prior_temperature);
     if (p->oracle_kind == AZR_ORACLE_NET) azr_mcts_set_net(slots[s].mcts, p->nblocks, p->F, p->npf, p->nvf, p->blob);
@@ -1000,16 +1005,30 @@ int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
     for (int s = 0; s < G; ++s) {
       azr_slot* sl = &slots[s];
       if (!sl->active) continue;
+      azr_move_rec* mr = &stage[(size_t)s * maxlen + sl->nmoves];
+      memset(mr, 0, sizeof *mr);
+      azr_pack_key(p->game, &sl->game.s, mr->key);                    /* trace.states[i]: pushed BEFORE this turn's flip (play.jl:299, 313) */
+      int pre_acts[AZR_AMAX]; int pre_n = available(&sl->game, pre_acts);   /* available actions of that state, in order */
+      (void)A;
+      if (p->flip_probability != 0.) {                                /* play.jl:305-307 */
+        rn_stream r = rn_open(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, RN_FLIP);
+        if (rn_u64(&r) < p->flip_probability) {
+          int k = (int)(rn_u64(&r) * (double)nsym);
+          if (k >= nsym) k = nsym - 1;
+          apply_symmetry(&sl->game, k);
+          mr->N[AZR_AMAX] = k + 1;
+        }
+      }
       /* think (play.jl:196-206) */
       azr_mcts_explore(sl->mcts, &sl->game, p->num_iters_per_turn, 0, p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves);
       int acts[AZR_AMAX]; double pi[AZR_AMAX], pis[AZR_AMAX];
       int n = azr_mcts_policy(sl->mcts, &sl->game, acts, pi);
-      azr_move_rec* mr = &stage[(size_t)s * maxlen + sl->nmoves];
-      memset(mr, 0, sizeof *mr);
-      azr_pack_key(p->game, &sl->game.s, mr->key);
+      /* the trace holds pi_target over the available actions of the state the player SAW; convert_sample and apply_symmetry
+       * spread it over the actions mask of trace.states[i], the state before the flip (learning.jl:31-33, memory.jl:115-118):
+       * entry i goes to that state's i-th available action.  Without a flip the two lists are the same. */
       { azr_node* nd = tree_find(sl->mcts, &sl->game.s, 0);
-        for (int i = 0; i < n; ++i) mr->N[acts[i]] = (int32_t)nd->N[i]; }
-      (void)A;
+        if (n != pre_n) { fprintf(stderr, "azref: a symmetry changed the number of available actions\n"); abort(); }
+        for (int i = 0; i < n; ++i) mr->N[pre_acts[i]] = (int32_t)nd->N[i]; }
       /* temperature index = #moves already played (play.jl:309) */
       double tau = azr_plschedule(p->temp_xs, p->temp_ys, p->temp_len, sl->nmoves);
       apply_temperature(pi, n, tau, pis);

@@ -44,7 +44,8 @@ class SimParams(C.Structure):
                 ("temp_ys", C.c_double * 8), ("num_games", C.c_int), ("num_workers", C.c_int),
                 ("reset_every", C.c_int), ("seed", C.c_uint64), ("game", C.c_int),
                 ("oracle_kind", C.c_int), ("nblocks", C.c_int), ("F", C.c_int), ("npf", C.c_int),
-                ("nvf", C.c_int), ("blob", C.POINTER(C.c_float)), ("first_game_id", C.c_int)]
+                ("nvf", C.c_int), ("blob", C.POINTER(C.c_float)), ("first_game_id", C.c_int),
+                ("flip_probability", C.c_double)]
 
 
 class MoveRec(C.Structure):
@@ -252,7 +253,7 @@ def net_forward_normalized(game, hp, blob, X, A):
 
 
 def _sim_params(game, oracle, num_games, num_workers, nsims, gamma=1.0, cpuct=1.0, noise_eps=0.0, noise_alpha=1.0,
-                prior_temperature=1.0, temp_xs=(0,), temp_ys=(1.0,), reset_every=1, seed=1, net=None, first_game_id=0):
+                prior_temperature=1.0, temp_xs=(0,), temp_ys=(1.0,), reset_every=1, seed=1, net=None, first_game_id=0, flip_probability=0.0):
     p = SimParams()
     p.gamma, p.cpuct, p.noise_eps, p.noise_alpha, p.prior_temperature = gamma, cpuct, noise_eps, noise_alpha, prior_temperature
     p.num_iters_per_turn = nsims
@@ -263,6 +264,7 @@ def _sim_params(game, oracle, num_games, num_workers, nsims, gamma=1.0, cpuct=1.
     p.num_games, p.num_workers, p.reset_every, p.seed = num_games, num_workers, reset_every or 0, seed
     p.game, p.oracle_kind = game, oracle
     p.first_game_id = first_game_id
+    p.flip_probability = flip_probability          # azr_simulate only; azr_arena takes its own argument
     blob = None
     if net is not None:
         p.nblocks, p.F, p.npf, p.nvf, blob = net[0], net[1], net[2], net[3], np.ascontiguousarray(net[4], dtype=np.float32)

@@ -95,7 +95,7 @@ def test_arena_errors():
             a.arena_run(b, 2)
         with pytest.raises(L.AzError, match="two engines"):
             a.arena_run(a, 2)
-        with pytest.raises(L.AzError, match="flip_probability"):  # self-play keeps requiring 0
+        with pytest.raises(L.AzError, match="symmetries"):        # self-play: the same assert
             a.selfplay_run(2)
         b.arena_run(a, 2)                                         # baseline's flip setting is not consulted
     with azhip.Engine(game=L.GAME_TICTACTOE, **kw) as a, azhip.Engine(game=L.GAME_CONNECT_FOUR, **kw) as b:

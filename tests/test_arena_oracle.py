@@ -2,6 +2,7 @@
 src/simulations.jl:207-244,296-311, src/play.jl:248-315): symmetries against the reference's definitions,
 reward / colour bookkeeping, redundancy, replay of every recorded game through the game rules."""
 import numpy as np
+import pytest
 
 import azref as R
 
@@ -172,3 +173,54 @@ def _replay_any(game, g, moves):
         assert env.actions_mask()[m.action]
         env.play(m.action)
     assert env.terminated() and env.key() == (g.final_key[0], g.final_key[1])
+
+
+@pytest.mark.parametrize("game,flip", [(R.C4, 0.5), (R.TTT, 0.7), (R.TTT, 1.0)])
+def test_self_play_flips_follow_play_game(game, flip):
+    """azr_simulate with flip_probability (play.jl:299-313), rebuilt move by move from the oracle's single-step entry
+    points: trace.states[i] is the state BEFORE the turn's flip, the turn is flipped iff the first f64 draw of the
+    (game, move, FLIP) stream is below p, the image is symmetries[floor(u2 * n)], the player thinks and plays on the
+    image, and the visit counts land on the un-flipped state's available actions by rank (learning.jl:31-33)."""
+    import ctypes as C
+    nsims, seed, n = 20, 6, 5
+    kw = dict(cpuct=1.5, noise_eps=0.25, noise_alpha=1.0, seed=seed)
+    games, moves, nm = R.simulate(game, R.ORACLE_HASH, n, n, nsims, reset_every=1, flip_probability=flip, **kw)
+    L = R.lib()
+    L.azr_stream_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    nsym = L.azr_num_symmetries(game)
+    A = R.NUM_ACTIONS[game]
+    nflip = 0
+    for i in range(n):
+        g = games[i]
+        env, tree = R.Game(game), R.Mcts(game, R.ORACLE_HASH, cpuct=1.5, noise_eps=0.25, noise_alpha=1.0)
+        for k in range(g.num_moves):
+            m = moves[g.first_move + k]
+            assert env.key() == (m.key[0], m.key[1]), (i, k)
+            pre_avail = list(env.available_actions())
+            u64, u32 = np.zeros(2), np.zeros(2, np.float32)
+            L.azr_stream_uniforms(seed, i, k, 3, 2, u64.ctypes.data, u32.ctypes.data)       # purpose 3 = FLIP
+            if u64[0] < flip:
+                ks = min(int(u64[1] * nsym), nsym - 1)
+                assert m.N[R.AMAX] == ks + 1, (i, k)
+                st = env.state()
+                cells, cur = R.symmetry(game, list(st.cells), st.curplayer, ks)
+                img = R.State()
+                for j, c in enumerate(cells):
+                    img.cells[j] = c
+                img.curplayer = cur
+                env = R.Game(game, img)
+                nflip += 1
+            else:
+                assert m.N[R.AMAX] == 0, (i, k)
+            tree.explore(env, nsims, seed=seed, game_id=i, move=k)
+            N = tree.root_stats(env)[0]
+            assert len(N) == len(pre_avail)
+            want = [0] * A
+            for a, c in zip(pre_avail, N):
+                want[a] = int(c)
+            assert [m.N[a] for a in range(A)] == want, (i, k)
+            assert env.actions_mask()[m.action]                      # the action is one of the IMAGE's
+            env.play(m.action)
+            assert env.white_reward() == m.reward
+        assert env.terminated() and env.key() == (g.final_key[0], g.final_key[1])
+    assert nflip == nm if flip == 1.0 else 0 < nflip < nm

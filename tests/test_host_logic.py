@@ -26,9 +26,8 @@ def test_engine_options_mapping():
     assert engine_options(MctsParams(2, 0.0, 1.0, temperature=ConstSchedule(0.5)), SimParams(1, 1, 1))["temperature"] == ([0], [0.5])
     with pytest.raises(ValueError):
         check_sim_params(SimParams(10, 4, 8))                  # batch_size <= num_workers, params.jl:361-384
-    with pytest.raises(ValueError):
-        check_sim_params(SimParams(10, 8, 8, flip_probability=0.3))
-    check_sim_params(SimParams(10, 8, 8, flip_probability=0.3), arena=True)    # the arena honours flips (play.jl:305-307)
+    check_sim_params(SimParams(10, 8, 8, flip_probability=0.3))                # self-play and the arena honour flips (play.jl:305-307)
+    check_sim_params(SimParams(10, 8, 8, flip_probability=0.3), arena=True)
     with pytest.raises(ValueError):
         check_sim_params(SimParams(10, 8, 8, flip_probability=1.3), arena=True)
 

@@ -46,6 +46,25 @@ def test_reset_every_never_and_ragged_game_counts():
     _compare(0, R.ORACLE_HASH, 5, 1, 30, dict(reset_every=3, **kw), dict(reset_every=3, **rkw))
 
 
+@pytest.mark.parametrize("game,flip", [(0, 0.5), (1, 0.5), (0, 1.0), (1, 1.0)])
+def test_flip_probability_in_self_play(game, flip):
+    """play_game's per-turn random symmetry (play.jl:305-307, game.jl:329-336) inside the device's self-play loop: states
+    recorded before the flip, counts spread over the un-flipped state's mask by rank (learning.jl:31-33), the symmetry's
+    index + 1 in N[AZ_MAX_ACTIONS]; tic-tac-toe draws among 7 images, trees persist over two games (reset_every 2), so
+    a flipped root is sometimes found in the table and sometimes not."""
+    kw = dict(cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, seed=9, temperature=((0, 4), (1.0, 0.5)))
+    rkw = dict(cpuct=2.0, noise_eps=0.25, noise_alpha=1.0, seed=9, temp_xs=(0, 4), temp_ys=(1.0, 0.5))
+    import azhip
+    games, moves, nm = R.simulate(game, R.ORACLE_HASH, 10, 4, 48, reset_every=2, flip_probability=flip, **rkw)
+    flips = sum(1 for k in range(nm) if moves[k].N[R.AMAX])
+    assert flips == nm if flip == 1.0 else 0 < flips < nm
+    _compare(game, R.ORACLE_HASH, 10, 4, 48, dict(reset_every=2, flip_probability=flip, **kw),
+             dict(reset_every=2, flip_probability=flip, **rkw))
+    with pytest.raises(azhip.AzError, match="symmetries"):          # mancala declares none: the assert of game.jl:332
+        with azhip.Engine(game=2, oracle=R.ORACLE_HASH, num_workers=2, batch_size=2, num_iters_per_turn=8, flip_probability=0.5) as e:
+            e.selfplay_run(2)
+
+
 def test_noise_alpha_below_one_uses_the_boosted_gamma_sampler():
     """Dirichlet(n, 0.03)-style sparse noise: Gamma(alpha < 1) = Gamma(alpha + 1) * U^(1/alpha) on both sides."""
     _compare(0, R.ORACLE_UNIFORM, 4, 4, 40, dict(cpuct=2.0, dirichlet_noise_eps=0.5, dirichlet_noise_alpha=0.1, seed=3),

@@ -85,6 +85,44 @@ def test_mcts_env_and_play_game_mirror():
     assert len(p) == 7 and abs(p.sum() - 1) < 1e-5 and -1 <= v <= 1
 
 
+def test_timeout_search_and_flips_in_the_host_stepped_play_game():
+    """think with a timeout (play.jl:199-204): whole explore! calls until the wall clock says stop, so the tree holds a
+    positive multiple of num_iters_per_turn simulations and timeout = 0 leaves the tree empty (MCTS.policy then errors
+    like the reference).  play_game's flip_probability (play.jl:305-307) on the host-stepped loop: the trace stays a
+    valid game (every state is the image-or-not successor of the one before)."""
+    import azhip
+    gspec = azhip.ConnectFourSpec()
+    mp = azhip.MctsParams(16, 0.25, 1.0, cpuct=2.0)
+    player = azhip.MctsPlayer(gspec, azhip.MCTS.RandomOracle(gspec), mp, timeout=0.05)
+    g = gspec.init()
+    acts, pi = player.think(g)
+    n = player.mcts.total_simulations
+    assert n >= 16 and n % 16 == 0 and abs(pi.sum() - 1) < 1e-12 and len(acts) == 7
+    lazy = azhip.MctsPlayer(gspec, azhip.MCTS.RandomOracle(gspec), mp, timeout=0.0)
+    with pytest.raises(azhip.AzError):
+        lazy.think(g)
+    with pytest.raises(ValueError):
+        azhip.MctsPlayer(gspec, azhip.MCTS.RandomOracle(gspec), mp, timeout=-1.0)
+    fixed = azhip.MctsPlayer(gspec, azhip.MCTS.RandomOracle(gspec), mp)
+    t = azhip.play_game(gspec, fixed, flip_probability=0.5, rng=np.random.default_rng(4))
+    assert 7 <= len(t) <= 42 and t.rewards[-1] in (-1.0, 0.0, 1.0)
+    mirror = lambda s: gspec.symmetries(s)[0][0]
+
+    def succ(state):
+        out = set()
+        for a in gspec.init(state).available_actions():
+            e = gspec.init(state)
+            e.play(a)
+            out.add(e.current_state())
+        return out
+    flips = 0
+    for i in range(len(t)):
+        plain, image = succ(t.states[i]), succ(mirror(t.states[i]))
+        assert t.states[i + 1] in plain | image, i
+        flips += t.states[i + 1] not in plain
+    assert flips > 0                                                # some successor is reachable only through the image
+
+
 def test_full_size_slot_count_independence():
     """BASELINE configs[1] size: 4096 slots, 400 sims/move, ResNet 5x64.  Size-independent properties:
     (i) two runs are identical (determinism); (ii) game g's trace does not depend on how many slots run
