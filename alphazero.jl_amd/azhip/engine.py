@@ -1,6 +1,7 @@
 """Engine: one MI355X self-play engine (a thin object wrapper over the C ABI, numpy in / numpy out)."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -288,6 +289,13 @@ def _cache_bytes():
     return sum(e.device_bytes() for e in _cache.values() if e._h is not None)
 
 
+def _evict():
+    k = next(iter(_cache))
+    if os.environ.get("AZHIP_TRACE_CACHE"):
+        print("azhip cache: evicting '%s' (%.1f GB)" % (k[0], _cache[k].device_bytes() / 2**30), file=sys.stderr)
+    _cache.pop(k).close()
+
+
 def cached_engine(role="", **kw):
     import ctypes
     cfg = default_cfg(**kw)
@@ -295,11 +303,13 @@ def cached_engine(role="", **kw):
     e = _cache.pop(key, None)
     if e is None or e._h is None:
         while len(_cache) >= CACHE_MAX:
-            _cache.pop(next(iter(_cache))).close()
+            _evict()
         e = Engine(cfg=cfg)
         need = e.device_bytes()
         while _cache and _cache_bytes() + need > CACHE_MAX_BYTES:
-            _cache.pop(next(iter(_cache))).close()
+            _evict()
+        if os.environ.get("AZHIP_TRACE_CACHE"):
+            print("azhip cache: new engine '%s' %.1f GB (cache now %.1f GB in %d engines)" % (role, need / 2**30, (_cache_bytes() + need) / 2**30, len(_cache) + 1), file=sys.stderr)
     _cache[key] = e                                                 # most recently used last
     return e
 

@@ -229,7 +229,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   e->h_xflag = nullptr; e->d_xflag = nullptr; e->split_off = false; e->split_registered = 0; e->xch_launches = 0;
   { const char* fa = getenv("AZHIP_XCH_FAIL_AT"); e->xch_fail_at = fa ? atoll(fa) : 0; }
   e->net_loaded = false; e->running = false; e->prof_on = false; { const char* ug = getenv("AZHIP_GRAPH"); e->use_graphs = ug ? atoi(ug) : 0; }
-  e->d_phase = nullptr; e->phase_cap = 0; e->phase_n = 0; e->host_moves = true; e->last_tower[0] = 0; e->prof_mask = 0; e->prof_used = 0;
+  e->d_phase = nullptr; e->phase_cap = 0; e->phase_n = 0; e->host_moves = true; e->last_tower[0] = 0; memset(e->tower_hist, 0, sizeof e->tower_hist); e->prof_mask = 0; e->prof_used = 0;
   memset(&e->prof, 0, sizeof e->prof);
   memset(&e->stats, 0, sizeof e->stats);
   int st = [&]() -> int {
@@ -1540,7 +1540,17 @@ extern "C" int az_arena_run(az_engine* contender, az_engine* baseline, int32_t n
   for (az_engine* e : {contender, baseline})
     if (e->cfg.oracle == AZ_ORACLE_RESNET && !e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
   if (out && (!out->games || !out->moves)) return fail(AZ_ERR_BAD_ARG, "NULL trace buffers");
+  const bool trace = getenv("AZHIP_TRACE_ARENA") != nullptr;      // which tower forms served the evaluation, and who else counted as a split-tower user
+  long long h0[2][4];
+  const int others = split_streams_on_device(contender->device);
+  for (int k = 0; k < 2; ++k) memcpy(h0[k], (k ? baseline : contender)->tower_hist, sizeof h0[k]);
   DISPATCH_GAME(contender->cfg.game, AZCHK(arena_run<Gm>(contender, baseline, num_games, first_game_id, alternate_colors != 0, out, rewards, redundancy, cb, user)));
+  if (trace)
+    for (int k = 0; k < 2; ++k) {
+      const long long* h = (k ? baseline : contender)->tower_hist;
+      fprintf(stderr, "azhip arena: %s launches split %lld, 3-tile %lld, packed %lld, other %lld; split-tower streams registered before the call: %d, split_off %d\n",
+              k ? "baseline" : "contender", h[0] - h0[k][0], h[1] - h0[k][1], h[2] - h0[k][2], h[3] - h0[k][3], others, (int)(k ? baseline : contender)->split_off);
+    }
   return AZ_OK;
 }
 

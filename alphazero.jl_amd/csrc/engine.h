@@ -103,6 +103,7 @@ struct az_engine {
   uint16_t* d_geo[6];            // Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h), [3]: 22 tiles (k_tower16b, 8 boards), [4]: 6 tiles (k_conv16_layer of the trainer at small batches), [5]: the exact-fit variant (NTM<Game> tiles), if the game has one
   int nts;                       // row tiles of the game's latency tower variant (NTS<Game>, resnet16.h)
   int ntm;                       // row tiles of the game's exact-fit variant (NTM<Game>), 0 = none
+  long long tower_hist[4];       // network launches served by: the split tower, the 3-row-tile form, the packed 11 / 21-tile forms, others (AZHIP_TRACE_ARENA)
   char last_tower[96];           // name of the tower kernel that served the most recent network launch (az_net_last_kernel)
   int heads_pick;                // AZHIP_HEADS=16|32 forces k_heads16 / k_heads_mfma; 0 = by launch size
   int tower_pick;                // AZHIP_TOWER=16|32|3|21|22|7 forces a tower kernel (3 = k_tower16 with 3 row tiles, 21 = k_tower16x2, 7 = the exact-fit variant NTM); 0 = choose per launch

@@ -73,6 +73,7 @@ template <class Gm> static int set_kernel_attrs(az_engine* e) {
 static void note_tower(az_engine* e, int tw, int F) {
   static const char* const gn[] = {"ConnectFour", "TicTacToe", "Mancala", "Go9Planes"};
   const char* g = gn[e->cfg.game];
+  e->tower_hist[tw == 2 ? 0 : tw == 3 ? 1 : (tw == 16 || tw == 21) ? 2 : 3]++;
   if (e->cfg.net_bf16) { snprintf(e->last_tower, sizeof e->last_tower, "k_tower16b<%s,%d,NT=%d>", g, F, tw == 3 ? e->nts : tw == 22 ? 22 : 11); return; }
   if (tw == 2) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16s<%s,%d>", g, F);
   else if (tw == 21) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d>", g, F);

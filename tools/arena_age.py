@@ -40,5 +40,48 @@ elif what == "memory":
     arena("with 27 GB of replay memories held")
     [m.close() for m in mems]
     arena("after releasing them")
+elif what == "alive":
+    # engines that stay ALIVE (the bench's engine cache): their streams keep their share of the hardware queues
+    blob = random_params(0, ResNetHP(num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32), seed=1)
+    held = []
+    for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
+        e = azhip.Engine(game=0, oracle=azhip.ORACLE_RESNET, num_workers=1024 + 64 * i, batch_size=512 + 32 * i, num_iters_per_turn=100, num_blocks=5,
+                         num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+        e.net_set_params(blob)
+        e.selfplay_begin(-1, 0); e.selfplay_step(20); e.selfplay_end()
+        held.append(e)
+        if i in (0, 1, 3, 7, 11, 15):
+            arena("%d two-group engines alive (cached arena engines)" % (i + 1))
+    azhip.engine.clear_engine_cache()
+    arena("%d alive, NEW arena engines" % len(held))
+    [e.close() for e in held]
+    arena("all closed, same arena engines")
+elif what == "load":
+    # the bench's order: a long self-play phase of the big network first, the arena right behind it.  Is it the chip's state
+    # (clocks under a power / temperature limit) rather than anything in the process?
+    import subprocess
+
+    def smi(tag):
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True)
+        keep = [ln.strip() for ln in r.stdout.splitlines() if any(k in ln for k in ("sclk", "Power", "junction", "edge", "mclk"))]
+        print("  [%s] %s" % (tag, " | ".join(keep)), flush=True)
+    smi("idle")
+    blob = random_params(0, hp, seed=3)
+    secs = float(sys.argv[2]) if len(sys.argv) > 2 else 45.0
+    with azhip.Engine(game=0, oracle=azhip.ORACLE_RESNET, num_workers=4096, batch_size=2048, num_iters_per_turn=600, num_blocks=5, num_filters=128,
+                      num_policy_head_filters=32, num_value_head_filters=32) as e:
+        e.net_set_params(blob)
+        e.selfplay_begin(-1, 0)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < secs:
+            e.selfplay_step(600)
+        smi("under load, %.0f s in" % (time.perf_counter() - t0))
+        e.selfplay_end()
+    arena("right after %.0f s of 5x128 self-play" % secs)
+    smi("after that arena")
+    arena("once more")
+    time.sleep(30)
+    smi("after 30 s idle")
+    arena("after 30 s idle")
 azhip.engine.clear_engine_cache()
 arena("fresh engines, old process")
