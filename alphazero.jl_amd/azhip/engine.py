@@ -281,7 +281,7 @@ class Engine:
 # release them once pushed, see training.py).
 CACHE_MAX = 4
 CACHE_MAX_BYTES = int(float(os.environ.get("AZHIP_CACHE_GB", "96")) * (1 << 30))
-CREATE_ENV = ("AZHIP_TOWER", "AZHIP_HEADS", "AZHIP_GRAPH", "AZHIP_XCH_EPOCH0", "AZHIP_VMM", "AZHIP_POOL_GB", "AZHIP_XCH_FAIL_AT")
+CREATE_ENV = ("AZHIP_TOWER", "AZHIP_HEADS", "AZHIP_GRAPH", "AZHIP_XCH_EPOCH0", "AZHIP_VMM", "AZHIP_POOL_GB", "AZHIP_XCH_FAIL_AT", "AZHIP_POOLED_QUEUE")
 _cache = {}
 
 

@@ -233,7 +233,21 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   memset(&e->prof, 0, sizeof e->prof);
   memset(&e->stats, 0, sizeof e->stats);
   int st = [&]() -> int {
-    HIPCHK(hipStreamCreate(&e->stream));
+    // The engine's own stream gets a hardware queue of its own (a stream made with a CU mask -- here: every CU -- is not folded
+    // into the runtime's pool of GPU_MAX_HW_QUEUES shared queues).  Two one-group engines searching side by side (the arena's two
+    // players) otherwise overlap or take turns depending on which pooled queue their streams happened to land on (DESIGN.md 6b:
+    // 5.6 s against 8.2 s for the same evaluation).  AZHIP_POOLED_QUEUE=1 keeps the runtime's assignment.
+    {
+      int ncu = 0;
+      HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
+      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+      for (int i = 0; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+      if (getenv("AZHIP_POOLED_QUEUE") || ncu <= 0 || hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        e->stream = nullptr;
+        HIPCHK(hipStreamCreate(&e->stream));
+      }
+    }
     const int G = c->num_workers;
     DView& v = e->v;
     memset(&v, 0, sizeof v);
