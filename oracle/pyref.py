@@ -65,6 +65,12 @@ class ConnectFour:
     def reward(g):
         return (1.0 if g[3] == 1 else -1.0 if g[3] == 2 else 0.0) if g[2] else 0.0
 
+    @staticmethod
+    def symmetries(g):
+        """GI.symmetries, games/connect-four/game.jl:247-257: board[col, row] for col in reverse(1:NUM_COLS)"""
+        b = g[0]
+        return [(tuple(b[(6 - c) + 7 * r] for r in range(6) for c in range(7)), g[1], g[2], g[3])]
+
 
 class TicTacToe:
     A = 9
@@ -101,6 +107,24 @@ class TicTacToe:
     @staticmethod
     def reward(g):
         return (1.0 if g[3] == 1 else -1.0 if g[3] == 2 else 0.0) if g[2] else 0.0
+
+    @staticmethod
+    def symmetries(g):
+        """GI.symmetries, games/tictactoe/game.jl:149-168: the seven non-trivial dihedral maps; image board = board[sym]
+        with sym[p] = pos_of_xy(f(xy_of_pos(p))), positions 1-based, pos_of_xy((x, y)) = (y-1)*3 + x (game.jl:39-41)."""
+        N = 3
+        rot = lambda xy: (xy[1], N - xy[0] + 1)
+        flip = lambda xy: (xy[0], N - xy[1] + 1)
+        comp = lambda f, h: (lambda xy: f(h(xy)))
+        rot2 = comp(rot, rot)
+        rot3 = comp(rot2, rot)
+        xy_of = lambda p: ((p - 1) % N + 1, (p - 1) // N + 1)
+        pos_of = lambda xy: (xy[1] - 1) * N + (xy[0] - 1) + 1
+        out = []
+        for f in (rot, rot2, rot3, flip, comp(flip, rot), comp(flip, rot2), comp(flip, rot3)):
+            sym = [pos_of(f(xy_of(p))) for p in range(1, 10)]
+            out.append((tuple(g[0][q - 1] for q in sym), g[1], g[2], g[3]))
+        return out
 
 
 class Mancala:

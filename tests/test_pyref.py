@@ -46,3 +46,27 @@ def test_search_agrees(game, oracle, nsims):
         yN, yW, yP, yV = y.root_stats(g)
         assert list(N) == yN and list(W) == yW and [np.float32(p) for p in P] == yP and np.float32(V) == yV
         assert (m.total_simulations, m.total_nodes_traversed, m.num_nodes) == (y.total_simulations, y.total_nodes_traversed, len(y.tree))
+
+
+@pytest.mark.parametrize("game", [0, 1])
+def test_symmetries_agree(game):
+    """GI.symmetries restated twice from games/*/game.jl (pyref: position maps composed like generate_dihedral_symmetries;
+    azref.c: the coordinate form): same images in the same order on random positions."""
+    G = Y.GAMES[game]
+    rng = np.random.default_rng(game + 1)
+    assert len(G.symmetries(G.init())) == R.lib().azr_num_symmetries(game)
+    for _ in range(60):
+        g = G.init()
+        for _ in range(int(rng.integers(0, 9))):
+            g2 = G.play(g, int(rng.choice([i for i, ok in enumerate(G.mask(g)) if ok])))
+            if Y.finished(G, g2):
+                break
+            g = g2
+        st = R.unpack_key(game, G.key(g))
+        for k, img in enumerate(G.symmetries(g)):
+            cells, cur = R.symmetry(game, list(st.cells), st.curplayer, k)
+            o = R.State()
+            for j, c in enumerate(cells):
+                o.cells[j] = c
+            o.curplayer = cur
+            assert R.Game(game, o).key() == G.key(img), (game, k)

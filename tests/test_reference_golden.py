@@ -45,6 +45,17 @@ def full_eta(game, key, eta):
     return out
 
 
+def image_of(game, g, k):
+    """the k-th entry of GI.symmetries for the oracle game g, as a new oracle game"""
+    st = g.state()
+    cells, cur = R.symmetry(game, list(st.cells), st.curplayer, k)
+    img = R.State()
+    for j, c in enumerate(cells):
+        img.cells[j] = c
+    img.curplayer = cur
+    return R.Game(game, img)
+
+
 # ------------------------------------------------------------------------------------------------ the checks
 def check_mcts_cpu(dirname):
     for c in load(dirname, "ref_mcts.json")["cases"]:
@@ -72,8 +83,11 @@ def check_play_cpu(dirname):
         m = R.Mcts(game, oracle=ORACLES[c["oracle"]], cpuct=c["cpuct"], noise_eps=0.25)
         sched = ConstSchedule(c["temp_ys"][0]) if len(c["temp_xs"]) == 1 else PLSchedule(c["temp_xs"], c["temp_ys"])
         g = R.Game(game)
+        flips = c.get("flips") or [0] * len(c["actions"])           # play_game's per-turn symmetry: 0 = none, else 1 + its index in GI.symmetries
         for k, action in enumerate(c["actions"]):
-            assert g.key() == key_of(c["states"][k])
+            assert g.key() == key_of(c["states"][k])                # trace.states[k]: the state BEFORE the turn's flip (play.jl:305-313)
+            if flips[k]:
+                g = image_of(game, g, flips[k] - 1)                 # the player thinks and plays on the image; policy / N are by rank
             m.explore(g, c["nsims"], eta=np.array(c["etas"][k]))    # the tree persists between the moves of a game
             acts, pi = m.policy(g)
             assert list(pi) == c["policies"][k], (game, k)
@@ -129,8 +143,11 @@ def check_play_gpu(dirname):
         game = c["game"]
         with azhip.Engine(game=game, oracle=ORACLES[c["oracle"]], num_workers=1, batch_size=1, num_iters_per_turn=c["nsims"],
                           cpuct=c["cpuct"], dirichlet_noise_eps=0.25, max_nodes_per_slot=c["nsims"] * (len(c["actions"]) + 1)) as e:
+            flips = c.get("flips") or [0] * len(c["actions"])
             for k in range(len(c["actions"])):
                 key = key_of(c["states"][k])
+                if flips[k]:
+                    key = image_of(game, R.Game(game, R.unpack_key(game, key)), flips[k] - 1).key()
                 e.mcts_explore([key], c["nsims"], eta=full_eta(game, key, c["etas"][k])[None, :])   # slot 0 keeps its tree
                 N, W, P, V, mask = e.mcts_node_stats(0, key)
                 assert [int(N[a]) for a in range(e.num_actions) if (mask >> a) & 1] == c["N"][k], (game, k)
@@ -210,15 +227,22 @@ def write_mock_golden(dirname):
                                actions=[i for i, ok in enumerate(G.mask(g)) if ok], N=N, W=W, P=[float(p) for p in P], Vest=float(V),
                                pi=[x / s for x in pi], total_simulations=y.total_simulations,
                                total_nodes_traversed=y.total_nodes_traversed, num_nodes=len(y.tree)))
-    for game, nsims, cpuct, xs, ys, seed, gid in ((1, 40, 1.0, [0], [1.0], 1, 3), (0, 30, 2.0, [0, 4, 8], [1.0, 0.5, 0.0], 7, 12345)):
+    for game, nsims, cpuct, xs, ys, seed, gid, flip_p in ((1, 40, 1.0, [0], [1.0], 1, 3, 0.0), (0, 30, 2.0, [0, 4, 8], [1.0, 0.5, 0.0], 7, 12345, 0.0),
+                                                          (0, 30, 2.0, [0, 10], [1.0, 0.5], 3, 77, 0.5), (1, 40, 1.0, [0], [1.0], 2, 5, 0.6)):
         G = Y.GAMES[game]
         y = Y.Mcts(G, Y.hash_oracle, cpuct=cpuct, eps=0.25)
         sched = ConstSchedule(ys[0]) if len(xs) == 1 else PLSchedule(xs, ys)
         g = G.init()
         case = dict(game=game, oracle="hash", nsims=nsims, cpuct=cpuct, temp_xs=xs, temp_ys=ys, seed=str(seed), game_id=gid, etas=[], us=[],
-                    states=[[str(k) for k in G.key(g)]], policies=[], rewards=[], actions=[], N=[])
+                    states=[[str(k) for k in G.key(g)]], policies=[], rewards=[], actions=[], N=[], flips=[])
         k = 0
         while not Y.finished(G, g):
+            flip = 0
+            if flip_p and rng.random() < flip_p:                    # play.jl:305-307 with the image chosen here (data, like eta)
+                syms = G.symmetries(g)
+                flip = 1 + int(rng.integers(len(syms)))
+                g = syms[flip - 1]
+            case["flips"].append(flip)
             acts = [i for i, ok in enumerate(G.mask(g)) if ok]
             eta = list(rng.dirichlet(np.ones(len(acts))))
             u = R.lib().azr_move_uniform(seed, gid, k)

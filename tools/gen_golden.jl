@@ -17,7 +17,8 @@
 #
 # Output (schema shared with tests/test_reference_golden.py):
 #   ref_mcts.json   explore! from a given root: η (by rank among available actions), N, W, P, Vest, π, counters
-#   ref_play.json   whole play_game traces with per-move η and u: states (packed keys), π targets, actions, rewards
+#   ref_play.json   whole play_game traces with per-move η and u: states (packed keys), π targets, actions, rewards; two cases
+#                   with flip_probability > 0 ("flips": which symmetry each turn took)
 #   ref_net.json    ResNet outputs (P over available actions, V) for a list of states + ref_net_blob.f32 (parameters in
 #                   the blob order of az_net_set_params, flattened by julia/AlphaZeroHIP.jl's HipResNet(::ResNet))
 using AlphaZero
@@ -135,11 +136,15 @@ end
 
 # ---- ref_play.json ----------------------------------------------------------------------------------------------------------------
 play_cases = []
-for (gname, oname, nsims, cpuct, xs, ys, seed, gid) in [
-    ("connect-four", "hash", 100, 2.0, [0, 20, 30], [1.0, 1.0, 0.3], UInt64(1), 0),
-    ("connect-four", "hash", 60, 2.0, [0, 4, 8], [1.0, 0.5, 0.0], UInt64(7), 12345),
-    ("tictactoe", "hash", 64, 1.0, [0], [1.0], UInt64(1), 3),
-    ("mancala", "hash", 80, 2.0, [0, 20, 30], [1.0, 1.0, 0.3], UInt64(5), 42)]
+for (gname, oname, nsims, cpuct, xs, ys, seed, gid, flip_p) in [
+    ("connect-four", "hash", 100, 2.0, [0, 20, 30], [1.0, 1.0, 0.3], UInt64(1), 0, 0.0),
+    ("connect-four", "hash", 60, 2.0, [0, 4, 8], [1.0, 0.5, 0.0], UInt64(7), 12345, 0.0),
+    ("tictactoe", "hash", 64, 1.0, [0], [1.0], UInt64(1), 3, 0.0),
+    ("mancala", "hash", 80, 2.0, [0, 20, 30], [1.0, 1.0, 0.3], UInt64(5), 42, 0.0),
+    # play_game's flip_probability (play.jl:305-307): the reference's own apply_random_symmetry! picks the image, which one it
+    # was is recorded as data ("flips": 0 = the turn was not flipped, else 1 + index in GI.symmetries)
+    ("connect-four", "hash", 60, 2.0, [0, 10], [1.0, 0.5], UInt64(3), 77, 0.5),
+    ("tictactoe", "hash", 64, 1.0, [0], [1.0], UInt64(2), 5, 0.6)]
   gspec = AlphaZero.Examples.games[gname]
   τ = length(xs) == 1 ? ConstSchedule(ys[1]) : PLSchedule(xs, ys)
   params = MctsParams(num_iters_per_turn=nsims, cpuct=cpuct, temperature=τ, dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0)
@@ -151,8 +156,15 @@ for (gname, oname, nsims, cpuct, xs, ys, seed, gid) in [
   # therefore driven move by move through `think` (the body of play.jl:298-315 is reproduced by calling its own pieces)
   game = GI.init(gspec)
   trace = AlphaZero.Trace(GI.current_state(game))
-  Ns = Vector{Vector{Int}}(); acts = Int[]
+  Ns = Vector{Vector{Int}}(); acts = Int[]; flips = Int[]
   while !GI.game_terminated(game)
+    flip = 0
+    if !iszero(flip_p) && rand(rng) < flip_p                         # play.jl:305-307
+      before = GI.current_state(game)
+      GI.apply_random_symmetry!(game)
+      flip = findfirst(sym -> sym[1] == GI.current_state(game), GI.symmetries(gspec, before))
+    end
+    push!(flips, flip)
     n = length(GI.available_actions(game))
     η = rand(rng, Dirichlet(n, 1.0)); push!(etas, η); push!(ETA_QUEUE, copy(η))
     u = move_uniform(seed, gid, length(trace)); push!(us, u); push!(SHIM.queue, u)
@@ -169,7 +181,7 @@ for (gname, oname, nsims, cpuct, xs, ys, seed, gid) in [
     "game" => game_ids[gname], "oracle" => oname, "nsims" => nsims, "cpuct" => cpuct, "temp_xs" => xs, "temp_ys" => ys,
     "seed" => string(seed), "game_id" => gid, "etas" => etas, "us" => [Float64(u) for u in us],
     "states" => [keystr(encode_state(gspec, s)) for s in trace.states], "policies" => trace.policies,
-    "rewards" => trace.rewards, "actions" => acts, "N" => Ns,
+    "rewards" => trace.rewards, "actions" => acts, "N" => Ns, "flips" => flips,
     "total_simulations" => player.mcts.total_simulations, "total_nodes_traversed" => player.mcts.total_nodes_traversed,
     "num_nodes" => length(player.mcts.tree)))
 end
