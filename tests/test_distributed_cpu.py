@@ -21,10 +21,13 @@ def _worker(rank, world, port, out_dir):
     import azref as R
     from azhip.simulations import GAME_DTYPE, MOVE_DTYPE, gather_records, shard_games
     first, count = shard_games(7, world, rank)
-    # the oracle keys its RNG by game id, so a shard is simulated by running ids first..first+count-1:
-    # simulate all 7 and keep ours (the oracle has no first_game_id argument)
-    games, moves, nm = R.simulate(R.TTT, R.ORACLE_HASH, 7, 7, 20, cpuct=1.5, noise_eps=0.25, seed=3)
-    g = np.frombuffer(bytes(games), dtype=GAME_DTYPE)[first:first + count].copy()
+    # the oracle keys its RNG streams (noise, move, flip) by GLOBAL game id: the rank simulates its own shard, ids
+    # first .. first+count-1 (simulations.jl:268-278), with play_game's random symmetries switched on
+    games, moves, nm = R.simulate(R.TTT, R.ORACLE_HASH, count, count, 20, cpuct=1.5, noise_eps=0.25, seed=3, first_game_id=first,
+                                  flip_probability=0.4)
+    g = np.frombuffer(bytes(games), dtype=GAME_DTYPE)[:count].copy()
+    assert list(g["game_id"]) == list(range(first, first + count))
+    # the oracle writes a game's moves when the game ends: pack them in game-id order like the engine's trace buffer
     m = np.concatenate([np.frombuffer(bytes(moves), dtype=MOVE_DTYPE)[r["first_move"]:r["first_move"] + r["num_moves"]] for r in g])
     g["first_move"] = np.cumsum([0] + list(g["num_moves"][:-1]))
     G, M = gather_records(g, m)
@@ -39,7 +42,8 @@ def test_gather_records_gloo_world2(tmp_path):
     sys.path[:0] = [os.path.join(ROOT, "oracle")]
     import azref as R
     from azhip.simulations import GAME_DTYPE, MOVE_DTYPE
-    games, moves, nm = R.simulate(R.TTT, R.ORACLE_HASH, 7, 7, 20, cpuct=1.5, noise_eps=0.25, seed=3)
+    games, moves, nm = R.simulate(R.TTT, R.ORACLE_HASH, 7, 7, 20, cpuct=1.5, noise_eps=0.25, seed=3, flip_probability=0.4)   # unsharded
+    assert any(moves[k].N[R.AMAX] for k in range(nm))                   # some turns were flipped
     ref_g = np.frombuffer(bytes(games), dtype=GAME_DTYPE)[:7]
     ref_m = np.frombuffer(bytes(moves), dtype=MOVE_DTYPE)[:nm]
     G0, M0 = np.load(tmp_path / "G0.npy"), np.load(tmp_path / "M0.npy")
