@@ -588,7 +588,6 @@ __host__ __device__ inline double pl_schedule(const DParams& p, int i) {   // sc
 template <class Gm>
 __device__ inline const char* find_node(const DView& v, int slot, unsigned long long ka, unsigned long long kb,
                                         uint32_t* idx_out = nullptr) {
-  using NL = NodeL<Gm>;
   const uint32_t epoch = v.sr[slot].epoch;
   const unsigned long long hk = az_hash_key(ka, kb);
   const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;

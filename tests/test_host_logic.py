@@ -207,3 +207,46 @@ def test_register_budget_of_the_kernels_that_share_a_cu():
     assert 2 * conv + wg <= 512, (conv, wg)
     assert 2 * wg + alloc("k_tr_colsum1v") <= 512 and 2 * wg + 2 * alloc("k_tr_bn_bwd<4>") <= 512
     assert conv + wg + alloc("k_wgrad_reduce") <= 512 + conv      # the reduction beside one convolution wavefront pair and the weight gradient
+
+
+def test_engine_cache_policy(monkeypatch):
+    """azhip.engine.cached_engine (host logic, no device): engines are kept per (role, az_engine_cfg bytes, creation-time
+    environment), at most CACHE_MAX of them and CACHE_MAX_BYTES of device memory, least recently used first out."""
+    from azhip import engine as E
+
+    class Fake:
+        made = []
+
+        def __init__(self, cfg=None, **kw):
+            self.cfg, self._h, self.closed = cfg, object(), False
+            self.bytes = int(cfg.num_workers) << 20                # 1 MB per worker
+            Fake.made.append(self)
+
+        def device_bytes(self):
+            return self.bytes
+
+        def close(self):
+            self._h, self.closed = None, True
+
+    monkeypatch.setattr(E, "Engine", Fake)
+    monkeypatch.setattr(E, "_cache", {})
+    monkeypatch.setattr(E, "CACHE_MAX_BYTES", 1000 << 20)
+    a = E.cached_engine("white", num_workers=100)
+    assert E.cached_engine("white", num_workers=100) is a and len(Fake.made) == 1       # same role + configuration: reused
+    b = E.cached_engine("black", num_workers=100)                                         # another role: its own engine
+    c = E.cached_engine("white", num_workers=100, seed=7)                                 # any cfg byte differs: a new engine
+    assert b is not a and c is not a and len(E._cache) == 3
+    monkeypatch.setenv("AZHIP_TOWER", "3")
+    d = E.cached_engine("white", num_workers=100)                                         # built under an override: not the same engine
+    assert d is not a and len(E._cache) == 4
+    monkeypatch.delenv("AZHIP_TOWER")
+    assert E.cached_engine("white", num_workers=100) is a                                 # ... and `a` is now the most recently used
+    e = E.cached_engine("selfplay", num_workers=200)                                      # a fifth: the least recently used (b) goes
+    assert b.closed and not a.closed and len(E._cache) == E.CACHE_MAX == 4
+    big = E.cached_engine("selfplay", num_workers=700)                                    # over the byte budget: oldest first until it fits
+    assert c.closed and d.closed and not big.closed and E._cache_bytes() <= 1000 << 20
+    assert sum(1 for f in Fake.made if not f.closed) == len(E._cache)
+    a.close()                                                                              # a closed engine in the cache is rebuilt, not handed out
+    assert E.cached_engine("white", num_workers=100) is not a
+    E.clear_engine_cache()
+    assert not E._cache and all(f.closed for f in Fake.made)
