@@ -76,6 +76,33 @@ def test_push_and_experience_match_oracle(game):
     mem.close()
 
 
+@pytest.mark.parametrize("game", [0, 1])
+def test_flipped_self_play_reaches_the_data_set_like_the_oracles(game):
+    """play_game's random symmetries (play.jl:305-307) end to end on both sides, independently: device self-play with
+    flip_probability 0.5 -> az_memory_push -> symmetries + merge + tensors, against the oracle's own flipped simulate ->
+    push_trace! -> augment_with_symmetries -> merge_by_state -> convert_samples.  The samples pair the un-flipped state with the
+    image's policy by rank, as the reference's do (learning.jl:31-33)."""
+    import azhip
+    gspec = getattr(azhip, SPECS[game])()
+    nA = R.NUM_ACTIONS[game]
+    with azhip.Engine(game=game, oracle=azhip.ORACLE_HASH, num_workers=5, batch_size=5, num_iters_per_turn=24, dirichlet_noise_eps=0.25, cpuct=1.0,
+                      reset_every=2, temperature=([0], [1.0]), seed=5, flip_probability=0.5) as e:
+        games, moves, ng, nm, _ = e.selfplay_run(10)
+    rg, rm, rnm = R.simulate(game, R.ORACLE_HASH, 10, 5, 24, cpuct=1.0, noise_eps=0.25, reset_every=2, seed=5, flip_probability=0.5)
+    assert rnm == nm and any(rm[k].N[R.AMAX] for k in range(rnm))
+    ref = _oracle_samples(game, rg, rm, 10, 0.95)
+    mem = azhip.MemoryBuffer(gspec, 10000)
+    mem.push_records(games, moves, ng, nm, 0.95)
+    with mem.dataset() as d:
+        _same_samples(d.raw_samples(), ref, nA)
+    ref2 = R.merge_by_state(game, R.augment_with_symmetries(game, ref))
+    with mem.dataset(use_symmetries=True, use_position_averaging=True, weighing_policy=azhip.LOG_WEIGHT) as d:
+        _same_samples(d.raw_samples(), ref2, nA)
+        for a, b in zip(d.tensors(), R.convert_samples(game, 1, ref2)):
+            assert np.array_equal(a, b)
+    mem.close()
+
+
 def test_long_segments_merge_in_buffer_order():
     """600 short games: the opening positions (x8 symmetric images that coincide) form segments of thousands of
     samples, which take the wavefront-parallel merge kernel; the averages must still be the sequential ones."""
