@@ -123,8 +123,10 @@ def test_timeout_search_and_flips_in_the_host_stepped_play_game():
     assert flips > 0                                                # some successor is reachable only through the image
 
 
-def test_full_size_slot_count_independence():
-    """BASELINE configs[1] size: 4096 slots, 400 sims/move, ResNet 5x64.  Size-independent properties:
+@pytest.mark.parametrize("flip", [0.0, 0.5])
+def test_full_size_slot_count_independence(flip):
+    """BASELINE configs[1] size: 4096 slots, 400 sims/move, ResNet 5x64 (flip 0.5: with play_game's random symmetries, whose
+    draws are keyed by game id and move like everything else).  Size-independent properties:
     (i) two runs are identical (determinism); (ii) game g's trace does not depend on how many slots run
     beside it: games 0..47 of the 4096-slot run equal a 48-slot run (RNG keyed by game id, reset_every 1);
     (iii) conservation: sum of root visits = sims - 1 on the first move, every policy sums to 1,
@@ -134,7 +136,7 @@ def test_full_size_slot_count_independence():
     blob = random_params(azhip.GAME_CONNECT_FOUR, _hp(5), seed=2026)
     kw = dict(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, num_iters_per_turn=400, cpuct=2.0,
               dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)),
-              reset_every=1, seed=1, num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+              reset_every=1, seed=1, num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32, flip_probability=flip)
 
     def first_moves(G, nmoves):
         with azhip.Engine(num_workers=G, batch_size=G, **kw) as e:
