@@ -52,6 +52,31 @@ def test_simulate_with_resnet_matches_oracle(game, spec, ngames, workers, batch,
         assert res[i]["edepth"] == g.total_nodes_traversed / g.total_simulations
 
 
+def test_simulate_with_flips_and_the_network_matches_oracle():
+    """simulate with SimParams.flip_probability = 0.5 (play.jl:305-307) and the ResNet in the loop, through the Python mirror:
+    Trace.states are the un-flipped states, Trace.policies the image's policy vectors (by rank), as in the reference's traces."""
+    import azhip
+    from azhip.network import copy as netcopy
+    from azhip.trace import trace_from_records
+    gspec = azhip.ConnectFourSpec()
+    nn = azhip.ResNet(gspec, _hp(2), seed=11)
+    mp = azhip.MctsParams(num_iters_per_turn=32, dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0, cpuct=2.0,
+                          temperature=azhip.PLSchedule([0, 6, 10], [1.0, 1.0, 0.3]), gamma=1.0)
+    sp = azhip.SimParams(num_games=8, num_workers=4, batch_size=4, use_gpu=True, reset_every=2, flip_probability=0.5)
+    sim = azhip.Simulator(lambda oracle: azhip.MctsPlayer(gspec, oracle, mp), lambda: netcopy(nn, on_gpu=True, test_mode=True),
+                          azhip.self_play_measurements)
+    res = azhip.simulate(sim, gspec, sp, seed=5)
+    games, moves, nm = R.simulate(R.C4, R.ORACLE_NET, 8, 4, 32, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0, temp_xs=(0, 6, 10),
+                                  temp_ys=(1.0, 1.0, 0.3), reset_every=2, seed=5, net=(2, 64, 32, 32, nn.params()), flip_probability=0.5)
+    assert 0 < sum(1 for k in range(nm) if moves[k].N[R.AMAX]) < nm
+    for i in range(8):
+        t = res[i]["trace"]
+        ref = trace_from_records(games[i], moves, 7, lambda key: R.Game(R.C4, R.unpack_key(R.C4, key)).actions_mask())
+        assert t.states == ref.states and t.rewards == ref.rewards, i
+        assert all(np.array_equal(a, b) for a, b in zip(t.policies, ref.policies)), i
+        assert res[i]["edepth"] == games[i].total_nodes_traversed / games[i].total_simulations
+
+
 def test_mcts_env_and_play_game_mirror():
     """MCTS.Env explore!/policy (mcts.jl:239-271) with the ResNet, vs the oracle; play_game runs to the end."""
     import azhip
