@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("AZHIP_LIB", os.path.join(CSRC, "libazhip.so"))   # override: A/B builds
 
-ABI_VERSION = 2              # include/azhip.h AZ_ABI_VERSION: struct layouts below are version 2's
+ABI_VERSION = 3              # include/azhip.h AZ_ABI_VERSION: struct layouts below are version 3's
 REPLACEMENT_GAME_BIT = 0x40000000
 AZ_OK, AZ_ERR_BAD_ARG, AZ_ERR_CAPACITY, AZ_ERR_HIP, AZ_ERR_STATE = 0, -1, -2, -3, -4
 GAME_CONNECT_FOUR, GAME_TICTACTOE, GAME_MANCALA = 0, 1, 2
@@ -62,7 +62,7 @@ class TraceBuf(C.Structure):
 class SelfplayStats(C.Structure):
     _fields_ = [("simulations", C.c_int64), ("nodes_traversed", C.c_int64), ("leaf_evals", C.c_int64),
                 ("moves", C.c_int64), ("games", C.c_int64), ("waves", C.c_int64), ("seconds", C.c_double),
-                ("aborted_games", C.c_int64), ("tower_fallbacks", C.c_int64)]
+                ("aborted_games", C.c_int64), ("tower_fallbacks", C.c_int64), ("evals_reused", C.c_int64)]
 
 
 class Prof(C.Structure):
@@ -102,7 +102,7 @@ _VP, _I32, _I64, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
 class GatherStats(C.Structure):
     _fields_ = [("games", C.c_int64), ("moves", C.c_int64), ("bytes", C.c_int64), ("gather_ms", C.c_double), ("total_ms", C.c_double),
                 ("ranks", C.c_int64), ("total_simulations", C.c_int64), ("total_nodes_traversed", C.c_int64), ("max_nodes", C.c_int64),
-                ("mean_game_depth", C.c_double)]
+                ("mean_game_depth", C.c_double), ("replaced_games", C.c_int64)]
 
 
 AZ_ERR_COMM = -5

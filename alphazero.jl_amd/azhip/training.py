@@ -116,20 +116,28 @@ def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_pl
     # `elapsed` is the time of simulate_distributed alone (training.jl:284-287: its fetch of the workers' results is inside,
     # push_trace! is not): the clock stops here, plus the gather where there is one
     elapsed = time.perf_counter() - t0
-    if stats.aborted_games:
-        # a slot ran out of tree nodes / move records (the reference's Dict has no bound, src/mcts.jl:124-151): the engine played
-        # replacement games, so the count is right unless a replacement overflowed too; long games are the ones that go, which
-        # biases the data -- tell the user, and refuse when it is more than a few
+    # A slot that ran out of tree nodes / move records (the reference's Dict has no bound, src/mcts.jl:124-151) was retired and its
+    # game played again under a replacement id, so the count is right unless a replacement overflowed too; long games are the ones
+    # that go, which biases the data: warn, and refuse when it is more than a few.  The verdict is formed AFTER the
+    # exchange, from numbers every rank sees alike (a rank raising on its own left the others in the all-gather):
+    # `asked` games were wanted over all ranks, `came` came back, `replaced` of those carry the replacement bit.
+    def abort_policy(asked, came, replaced):
+        aborted = replaced + (asked - came)                         # games played again + games given up for good
+        if not aborted:
+            return
         import warnings
-        msg = ("azhip: %d of %d self-play games were aborted (tree node pool / move record full) and replayed with replacement ids; "
-               "%d games came back.  Raise max_nodes_per_slot / max_moves_per_game." % (stats.aborted_games, sim.num_games, ng))
-        if stats.aborted_games * 20 > max(sim.num_games, 1) or ng < sim.num_games:
+        msg = ("azhip: %d of %d self-play games were aborted (tree node pool / move record full) and played again under replacement "
+               "ids; %d games came back.  Raise max_nodes_per_slot / max_moves_per_game." % (aborted, asked, came))
+        if aborted * 20 > max(asked, 1) or came < asked:
             raise L.AzError(L.AZ_ERR_CAPACITY, msg)
-        warnings.warn(msg, RuntimeWarning, stacklevel=2)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+    if comm is None and not torch_group:
+        abort_policy(sim.num_games, ng, stats.aborted_games)        # one process: nothing is pushed when the phase is refused
     memory.new_batch()
     depth = footprint = None
     if comm is not None:
         gs = comm.gather_push(eng, memory, params.mcts.gamma)
+        abort_policy(params.sim.num_games, int(gs.games), int(gs.replaced_games))   # every rank alike: nobody is left inside a collective
         nm = gs.moves
         elapsed += gs.gather_ms * 1e-3
         # mean / maximum over ALL ranks' games (training.jl:293-294), from the gathered game records
@@ -139,6 +147,7 @@ def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_pl
         tg = time.perf_counter()
         g, mm = repack_by_game_id(*gather_records(*records_to_numpy(games, moves, ng, nm), group))
         ng, nm = len(g), len(mm)
+        abort_policy(params.sim.num_games, ng, int(np.count_nonzero(g["game_id"] & L.REPLACEMENT_GAME_BIT)))
         elapsed += time.perf_counter() - tg
         games = (L.GameRec * max(ng, 1)).from_buffer_copy(g.tobytes() or bytes(C.sizeof(L.GameRec)))
         moves = (L.MoveRec * max(nm, 1)).from_buffer_copy(mm.tobytes() or bytes(C.sizeof(L.MoveRec)))

@@ -269,6 +269,11 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     int hs = 1024;
     while ((long long)hs * 2 < cap * 3) hs <<= 1;
     v.ht_size = hs;
+    // test knobs for events that are rare at the shipped sizes: AZHIP_HT_TAG_BITS narrows the 16-bit tag of a table entry (unequal
+    // states then share tags and every probe chain is decided by the exact key compare), AZHIP_HT_EPOCH0 starts the 16-bit table
+    // epoch near its wrap (a reset past 0xfffe really clears the table)
+    { const char* tb = getenv("AZHIP_HT_TAG_BITS"); const int b = tb ? atoi(tb) : 16; v.tag_mask = b >= 16 ? 0xffffu : b <= 0 ? 0u : ((1u << b) - 1u); }
+    { const char* e0 = getenv("AZHIP_HT_EPOCH0"); const long x = e0 ? atol(e0) : 1; v.epoch0 = (uint32_t)(x >= 1 && x < 0xffff ? x : 1); }
     AZCHK(dalloc(e, &v.sr, G)); AZCHK(dalloc(e, &v.game_id, G));
     AZCHK(dalloc(e, &v.move_idx, G)); AZCHK(dalloc(e, &e->d_node_count, G));
     AZCHK(dalloc(e, &v.worker_sim_id, G));
@@ -1066,7 +1071,7 @@ __global__ void k_node_stats(DView v, int slot, unsigned long long ka, unsigned 
   using NL = NodeL<Gm>;
   const uint32_t epoch = v.sr[slot].epoch;
   const unsigned long long hk = az_hash_key(ka, kb);
-  const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
+  const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & v.tag_mask;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
   int* found = (int*)out;
   *found = 0;
@@ -1130,6 +1135,10 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   if (e->running) return fail(AZ_ERR_STATE, "self-play already in progress");
   if (num_games == 0) return fail(AZ_ERR_BAD_ARG, "num_games must be != 0");
   if (e->p.nsims < 2) return fail(AZ_ERR_BAD_ARG, "num_iters_per_turn = 0 (NetworkPlayer) is for az_arena_run only");
+  // ids with bit 30 set are replacement games (an id that already had it would be given up at its first overflow, and its RNG
+  // streams could collide with a replacement's): ADVICE r4
+  if (first_game_id < 0 || (long long)first_game_id + std::max<long long>(num_games, e->v.G) >= (long long)AZ_REPLACEMENT_GAME_BIT)
+    return fail(AZ_ERR_BAD_ARG, "game ids must stay below AZ_REPLACEMENT_GAME_BIT (first_game_id %d, num_games %d)", (int)first_game_id, (int)num_games);
   if (e->cfg.flip_probability != 0.0) {
     bool nosym = false;
     DISPATCH_GAME(e->cfg.game, nosym = Gm::NSYM == 0);
@@ -1176,6 +1185,10 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   return AZ_OK;
 }
 
+// another game id to hand out?  An unbounded phase (bench, polling) stops refilling before its ids reach the replacement bit.
+static inline bool more_games(const az_engine* e) {
+  return e->total_games < 0 ? (long long)e->first_game_id + e->next_game < (long long)AZ_REPLACEMENT_GAME_BIT : e->next_game < e->total_games;
+}
 // the move step (play.jl:308-313) for every slot, then collection of finished games and refill
 template <class Gm> static int move_round(az_engine* e) {
   const int G = e->v.G;
@@ -1217,7 +1230,7 @@ template <class Gm> static int move_round(az_engine* e) {
         continue;
       }
       e->games_done++;                                               // the replacement overflowed too: given up, counted, reported
-      if (e->total_games < 0 || e->next_game < e->total_games) {
+      if (more_games(e)) {
         aslots_refill.push_back(sl); agids.push_back((uint32_t)(e->first_game_id + e->next_game++));
         e->active_slots++; e->group_active[sl / e->gv[0].G]++;
       }
@@ -1250,7 +1263,7 @@ template <class Gm> static int move_round(az_engine* e) {
     e->stats.games++;
     e->active_slots--;
     e->group_active[fslots[i] / e->gv[0].G]--;
-    if (e->total_games < 0 || e->next_game < e->total_games) {      // next id, in slot order (util.jl:181-188)
+    if (more_games(e)) {      // next id, in slot order (util.jl:181-188)
       rslots.push_back(fslots[i]);
       rgids.push_back((uint32_t)(e->first_game_id + e->next_game++));
       e->active_slots++;

@@ -297,10 +297,11 @@ extern "C" int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, doubl
       stats->gather_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
       stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       // Report.SelfPlay wants mean depth and the largest tree over ALL games (training.jl:293-296), not the rank's own
-      long long sims = 0, trav = 0, nodes = 0;
+      long long sims = 0, trav = 0, nodes = 0, repl = 0;
       for (int r = 0; r < W; ++r)
         for (long long i = 0; i < all[3 * r]; ++i) {
           const az_game_rec& gr = gall[(size_t)r * maxg + i];
+          repl += (gr.game_id & AZ_REPLACEMENT_GAME_BIT) != 0;
           sims += gr.total_simulations; trav += gr.total_nodes_traversed; nodes = std::max<long long>(nodes, gr.nodes);
         }
       double dsum = 0.0;                 // mean over games of each game's average depth, in global game-id order
@@ -318,6 +319,7 @@ extern "C" int az_comm_gather_push(az_comm* c, az_engine* e, az_memory* m, doubl
       stats->ranks = W;
       stats->total_simulations = sims; stats->total_nodes_traversed = trav; stats->max_nodes = nodes;
       stats->mean_game_depth = totg ? dsum / (double)totg : 0.0;
+      stats->replaced_games = repl;
     }
     return AZ_OK;
   }();

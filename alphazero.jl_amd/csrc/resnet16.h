@@ -772,9 +772,12 @@ struct TrFinal {
   int* counter;                 // workgroups of the launch that have left their partials (back to 0 when the last one is done)
 };
 // The partials cross workgroups (and XCDs, whose L2s are not coherent with each other) inside one launch: they are written and
-// read with agent-scope relaxed atomics (write-through stores, cache-bypassing loads -- the exchange idiom of k_tower16s), the
-// counter likewise; no fence, no cache-wide write-back (a __threadfence() per workgroup flushes the XCD's dirty L2 -- the layer's
-// whole output -- and doubled the step time when it was tried).
+// read with agent-scope atomics (write-through stores, cache-bypassing loads -- the exchange idiom of k_tower16s).  Ordering
+// (ADVICE r4): the counter's increment is a RELEASE at agent scope -- everything the workgroup's threads stored before the barrier
+// happens-before it -- and the workgroup that sees the last count takes an ACQUIRE fence before it reads the partials, so the
+// reduction is ordered by the HIP memory model, not by gfx9's write-through behaviour.  (The release writes the XCD's dirty L2
+// lines back, which is part of why this form is SLOWER than a dependent launch and off by default: AZHIP_TRAIN_FINISH_INSIDE=1,
+// tests/test_train_gpu.py holds it bit-identical to the separate launch.)
 __device__ __forceinline__ void part_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double part_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // scratch: (blockDim.x + 2 C) doubles of LDS nobody else uses any more.  All threads of the workgroup call it, after part_store.
@@ -783,9 +786,10 @@ __device__ __forceinline__ void tr_finish(const double* __restrict__ part, int C
   __shared__ int s_last;
   __builtin_amdgcn_s_waitcnt(0);                                     // this thread's partials have been performed at the device's coherence point
   __syncthreads();
-  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(f.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y) - 1;
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(f.counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y) - 1;
   __syncthreads();
   if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // pairs with every other workgroup's release on the counter
   const int nparts = (int)gridDim.x, T = (int)blockDim.x, t = (int)threadIdx.x, npair = 2 * C;
   double* fin = scratch + T;                                         // [2][C] the finished sums
   if (npair <= T) {

@@ -442,6 +442,11 @@ static int trainer_build(az_trainer* t) {
   };
   add_conv(C, F, 9);
   for (int l = 0; l < 2 * t->nblocks; ++l) add_conv(F, F, 9);
+  // tr_forward_backward takes the input of every MFMA layer from the layer below (bn_of(l - 1)) and the stem's from the batch's planes:
+  // that holds only while the stem is the one non-MFMA tower layer.  A game with as many planes as filters would make it one.
+  t->convs[0].mfma = false; t->convs[0].wk_ffwd = t->convs[0].wk_fdg = 0;
+  for (int l = 1; l <= 2 * t->nblocks; ++l)
+    if (!t->convs[l].mfma) return fail(AZ_ERR_STATE, "trainer: tower layer %d is not an MFMA layer", l);
   add_conv(F, npf, 1);                                              // policy head: conv, (bn), then dense
   t->off_pd_w = off; off += (size_t)A * P * npf; t->off_pd_b = off; off += A;
   add_conv(F, nvf, 1);                                              // value head

@@ -72,6 +72,8 @@ static_assert(sizeof(SlotRec) == 64, "slot record");
 
 struct DView {
   int G, cap_nodes, ht_size, max_depth, max_moves;
+  uint32_t tag_mask;      // 0xffff; tests narrow it (AZHIP_HT_TAG_BITS) so that unequal states share tags and every probe chain reaches the exact key compare
+  uint32_t epoch0;        // first live epoch of a slot's table: 1; tests start near the 16-bit wrap (AZHIP_HT_EPOCH0)
   SlotRec* sr;            // [G] the search state of a slot that k_tree reads and writes every wave, ONE 64-byte record (round 4)
   uint32_t* game_id;
   uint32_t* move_idx;
@@ -198,7 +200,7 @@ __device__ inline int ht_lookup(const DView& v, int slot, int lane, unsigned lon
   const unsigned long long hk = az_hash_key(ka, kb);
   const uint32_t H1 = (uint32_t)v.ht_size - 1;
   const uint32_t h0 = (uint32_t)hk & H1;
-  const uint32_t tag = (uint32_t)(hk >> 40) & 0xffff;
+  const uint32_t tag = (uint32_t)(hk >> 40) & v.tag_mask;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
   const unsigned long long* keys = v.keys + (size_t)slot * v.cap_nodes * 4;
   const int iters = v.ht_size / L;
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
             unsigned long long* kk = side_at(v, slot, idx);
             kk[0] = env.a; kk[1] = env.b; kk[2] = (unsigned long long)__float_as_uint(V);
             const unsigned long long hk = az_hash_key(env.a, env.b);
-            const unsigned long long tag = (hk >> 40) & 0xffff;
+            const unsigned long long tag = (hk >> 40) & v.tag_mask;
             v.ht[(size_t)slot * v.ht_size + ins0] =
                 ((unsigned long long)epoch0 << 48) | (tag << 32) | (unsigned long long)(idx + 1);
             sr->node_count = idx + 1;
@@ -590,7 +592,7 @@ __device__ inline const char* find_node(const DView& v, int slot, unsigned long 
                                         uint32_t* idx_out = nullptr) {
   const uint32_t epoch = v.sr[slot].epoch;
   const unsigned long long hk = az_hash_key(ka, kb);
-  const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & 0xffff;
+  const uint32_t H1 = (uint32_t)v.ht_size - 1, tag = (uint32_t)(hk >> 40) & v.tag_mask;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
   for (uint32_t i = 0; i <= H1; ++i) {
     unsigned long long e = tab[((uint32_t)hk + i) & H1];
@@ -822,11 +824,11 @@ static __global__ void __launch_bounds__(256) k_slot_records(DView v, int what) 
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= v.G) return;
   SlotRec* const sr = v.sr + slot;
-  if (what & SR_ZERO) { SlotRec z = {}; z.epoch = 1; z.root_idx = -1; *sr = z; return; }
+  if (what & SR_ZERO) { SlotRec z = {}; z.epoch = v.epoch0; z.root_idx = -1; *sr = z; return; }
   if (what & SR_CLEAR_ACTIVE) sr->active = 0;
   if (what & SR_CLEAR_LEAF) sr->leaf_kd = LEAF_NONE;
   if (what & SR_CLEAR_TOTALS) { sr->tot_sims = 0; sr->tot_trav = 0; }
-  if (what & SR_RESET_TREE) { sr->node_count = 0; sr->epoch = 1; sr->root_idx = -1; }   // the caller has zeroed the hash tables
+  if (what & SR_RESET_TREE) { sr->node_count = 0; sr->epoch = v.epoch0; sr->root_idx = -1; }   // the caller has zeroed the hash tables
 }
 // node counts of all slots, dense (the host maps pool chunks ahead of the slots, azhip.hip vm_grow)
 static __global__ void __launch_bounds__(256) k_node_counts(DView v, int* out) {

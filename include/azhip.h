@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define AZ_ABI_VERSION 2   /* 2 (round 4): az_selfplay_stats.aborted_games, az_gather_stats' report fields, az_prof.exec_units, az_comm_version */
+#define AZ_ABI_VERSION 3   /* 3 (round 5): az_gather_stats.replaced_games, az_selfplay_stats.evals_reused; 2 (round 4): az_selfplay_stats.aborted_games, az_gather_stats' report fields, az_prof.exec_units, az_comm_version */
 
 typedef enum {
   AZ_OK = 0,
@@ -245,6 +245,13 @@ typedef struct {
                                      * of every layer) gave up waiting for a partner that was not co-resident and the engine fell back
                                      * to the unsplit kernel for good: results are unaffected, small launches get slower.  0 unless
                                      * something else (a trainer, another process) holds the device's CUs. */
+  int64_t evals_reused;             /* of leaf_evals: oracle answers taken from the engine's evaluation cache -- the same state already
+                                     * evaluated for another slot in this wave, or in an earlier wave since az_net_set_params -- instead
+                                     * of a network evaluation.  The reference evaluates every query on its own
+                                     * (src/simulations.jl:23-38, src/networks/network.jl:308-315); a test-mode evaluation is a pure
+                                     * function of the state and every tower form gives the same bits, so the answers -- and with them
+                                     * every record of the phase -- are unchanged (tests/test_eval_cache_gpu.py).  leaf_evals -
+                                     * evals_reused = boards the network evaluated.  0 when the cache is off (AZHIP_EVAL_CACHE=0). */
 } az_selfplay_stats;
 #define AZ_REPLACEMENT_GAME_BIT 0x40000000   /* game ids handed to az_selfplay_* must stay below it */
 typedef void (*az_progress_cb)(void* user);   /* game_simulated(), once per finished game */
@@ -386,6 +393,9 @@ typedef struct {
    * the largest tree (nodes; x memory_footprint_per_node = mcts_memory_footprint), and the raw totals */
   int64_t ranks, total_simulations, total_nodes_traversed, max_nodes;
   double mean_game_depth;
+  int64_t replaced_games;           /* gathered games whose id carries AZ_REPLACEMENT_GAME_BIT: games some rank aborted and played again.
+                                     * Every rank sees the same number, so a host can apply its abort policy AFTER the collective and
+                                     * fail on all ranks together (asked games - `games` = games given up for good) */
 } az_gather_stats;
 /* ncclGetUniqueId on ONE rank; the 128 bytes go to the other ranks by the host's own means (Distributed, MPI, a file). */
 int az_comm_unique_id(uint8_t id[AZ_COMM_ID_BYTES]);

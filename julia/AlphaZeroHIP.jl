@@ -51,10 +51,11 @@ mutable struct SelfplayStats
   seconds::Float64
   aborted_games::Int64
   tower_fallbacks::Int64
-  SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0, 0, 0)
+  evals_reused::Int64
+  SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0)
 end
-@assert sizeof(EngineCfg) == 224 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56 && sizeof(SelfplayStats) == 72
-const ABI_VERSION = 2   # include/azhip.h AZ_ABI_VERSION the structs above are written against
+@assert sizeof(EngineCfg) == 224 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56 && sizeof(SelfplayStats) == 80
+const ABI_VERSION = 3   # include/azhip.h AZ_ABI_VERSION the structs above are written against
 "Called once before the first engine is created: a library built from another header must not be written into these structs."
 function check_abi()
   v = ccall((:az_abi_version, LIB), Cint, ())
@@ -311,7 +312,11 @@ function AlphaZero.simulate(simulator::Simulator, gspec::DeviceGameSpec, p::SimP
       e.h, p.num_games, first_game_id, tb, @cfunction(c_progress, Cvoid, (Ptr{Cvoid},)), C_NULL, stats))
     resize!(games, tb.num_games)
   end
-  stats.aborted_games == 0 || @warn "azhip: $(stats.aborted_games) games were aborted (tree node pool / move record full): raise max_nodes_per_slot"
+  # the Python host's policy (azhip/training.py): warn, and refuse when games are missing or more than 5 % were aborted
+  if stats.aborted_games > 0
+    msg = "azhip: $(stats.aborted_games) of $(p.num_games) games were aborted (tree node pool / move record full), $(tb.num_games) came back: raise max_nodes_per_slot / max_moves_per_game"
+    (tb.num_games < p.num_games || 20 * stats.aborted_games > max(p.num_games, 1)) ? error(msg) : @warn msg
+  end
   nA = GI.num_actions(gspec)
   hb = nA <= 8 ? 2 : 4                                            # width of the child-link high bits (NodeL, csrc/tree.h)
   nbytes = cld(cld(cld(8nA, 8) * 8 + 8nA + 2nA, hb) * hb + hb, 32) * 32 + 32 + 12   # node record + side record (key, Vest) + hash-table share
@@ -347,6 +352,7 @@ import Distributed
 struct GatherStats
   games::Int64; moves::Int64; bytes::Int64; gather_ms::Float64; total_ms::Float64
   ranks::Int64; total_simulations::Int64; total_nodes_traversed::Int64; max_nodes::Int64; mean_game_depth::Float64
+  replaced_games::Int64
 end
 const COMM_ID_BYTES = 128
 
@@ -372,7 +378,7 @@ end
 
 "Collective: every rank's device-resident phase records -> (optionally) this rank's DeviceMemory, global game-id order"
 function gather_push!(c::Comm, e::Engine, m::Union{Nothing, DeviceMemory}, gamma)
-  st = Ref(GatherStats(0, 0, 0, 0.0, 0.0, 0, 0, 0, 0, 0.0))
+  st = Ref(GatherStats(0, 0, 0, 0.0, 0.0, 0, 0, 0, 0, 0.0, 0))
   check(ccall((:az_comm_gather_push, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ref{GatherStats}),
     c.h, e.h, isnothing(m) ? C_NULL : m.h, gamma, st))
   return st[]

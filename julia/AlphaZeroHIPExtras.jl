@@ -216,7 +216,7 @@ const UNBOUND = Dict(
   :az_selfplay_get_stats => "az_selfplay_run returns the statistics",
   :az_selfplay_active => "stepping form, see az_selfplay_begin",
   :az_selfplay_end => "stepping form, see az_selfplay_begin",
-  :az_selfplay_aborted => "ids of aborted games: simulate checks SelfplayStats.aborted_games and raises instead",
+  :az_selfplay_aborted => "ids of aborted games: simulate checks SelfplayStats.aborted_games, warns, and raises when games are missing or more than 5 % were aborted (the Python host's policy)",
   :az_push_trace => "host-side helper for foreign hosts; Julia has the reference's push_trace!",
   :az_memory_push_samples => "host TrainingSamples -> device memory: only needed when mixing host and device memories",
   :az_memory_empty => "empty!(mem): not used by the training loop (src/training.jl)",

@@ -662,6 +662,34 @@ typedef struct {
 #define AZR_ORACLE_HASH 1      /* synthetic: priors/value derived from the packed key */
 #define AZR_ORACLE_NET 2       /* Network.evaluate, src/networks/network.jl:287-298 */
 #define AZR_ORACLE_ROLLOUT 3   /* MCTS.RolloutOracle, src/mcts.jl:35-60 (gamma = 1, src/benchmark.jl:141-143) */
+#define AZR_ORACLE_EXTERNAL 4  /* REPLAY MODE (SURVEY.md §7 hard part 3): oracle(state) answers come from a table the CALLER fills --
+                                * e.g. with the device network's P / V -- so the reference's tree (this file) runs on another
+                                * evaluator's numbers.  A state the table does not hold yet suspends the simulation (no side effect:
+                                * run_simulation! touches the tree only after the oracle has answered, src/mcts.jl:205-222). */
+
+/* The caller-filled evaluation table of replay mode: state key -> (P by FULL action index, V).  An evaluation is a pure function of
+ * the state (Network.evaluate_batch evaluates every query on its own, src/networks/network.jl:308-315; test-mode BatchNorm), so one
+ * table serves every worker.  Read by the workers in parallel, written only between their rounds. */
+typedef struct { uint64_t k0, k1; float P[AZR_AMAX]; float V; int32_t st; int32_t pad; } azr_eval_ent;   /* st: 0 empty, 1 asked for, 2 answered */
+typedef struct { azr_eval_ent* tab; size_t cap, count; int64_t asked, answered, wipes; } azr_evals;
+azr_evals* azr_evals_new(int log2cap) {
+  azr_evals* t = calloc(1, sizeof *t);
+  t->cap = (size_t)1 << log2cap;
+  t->tab = calloc(t->cap, sizeof(azr_eval_ent));
+  return t;
+}
+void azr_evals_free(azr_evals* t) { if (t) { free(t->tab); free(t); } }
+void azr_evals_counters(const azr_evals* t, int64_t* out) { out[0] = t->asked; out[1] = t->answered; out[2] = t->wipes; out[3] = (int64_t)t->count; }
+static azr_eval_ent* evals_find(const azr_evals* t, const uint64_t* key, int insert) {
+  size_t j = (size_t)rn_mix64(key[0] ^ rn_mix64(key[1] + 0x9e3779b97f4a7c15ULL)) & (t->cap - 1);
+  while (t->tab[j].st) {
+    if (t->tab[j].k0 == key[0] && t->tab[j].k1 == key[1]) return &t->tab[j];
+    j = (j + 1) & (t->cap - 1);
+  }
+  if (!insert) return 0;
+  t->tab[j].k0 = key[0]; t->tab[j].k1 = key[1];
+  return &t->tab[j];
+}
 
 typedef struct {
   int game;
@@ -676,6 +704,8 @@ typedef struct {
   int64_t oracle_calls;
   /* RNG context of the running simulation (rollout oracle): seed, game id, move, simulation index */
   uint64_t rng_seed; uint32_t rng_game, rng_move, rng_sim;
+  /* replay mode (AZR_ORACLE_EXTERNAL): the caller's table, and the state the running simulation is suspended on */
+  const azr_evals* ext; int ext_miss; uint64_t ext_key[2];
 } azr_mcts;
 
 static uint64_t state_hash(const azr_state* s) {
@@ -776,6 +806,19 @@ static void call_oracle(azr_mcts* e, const azr_state* st, float* P, float* V) {
     float pf[AZR_AMAX];
     azr_hash_oracle(e->game, st, g.amask, pf, V);
     for (int i = 0; i < n; ++i) P[i] = pf[acts[i]];
+  } else if (e->oracle_kind == AZR_ORACLE_EXTERNAL) {
+    /* the answer is the caller's: P over all actions, compressed to the available ones like evaluate_batch's P[A[:,i],i] (network.jl:314) */
+    uint64_t key[2]; azr_pack_key(e->game, st, key);
+    const azr_eval_ent* ent = e->ext ? evals_find(e->ext, key, 0) : 0;
+    if (!ent || ent->st != 2) {                      /* not answered yet: suspend (the caller evaluates, then the simulation is run again) */
+      e->ext_miss = 1; e->ext_key[0] = key[0]; e->ext_key[1] = key[1];
+      e->oracle_calls--;
+      for (int i = 0; i < n; ++i) P[i] = 0.f;
+      *V = 0.f;
+      return;
+    }
+    for (int i = 0; i < n; ++i) P[i] = ent->P[acts[i]];
+    *V = ent->V;
   } else {
     /* Network.evaluate (src/networks/network.jl:287-298) */
     int A = e->net.A;
@@ -808,6 +851,7 @@ static azr_node* state_info(azr_mcts* e, const azr_state* st, int* new_node) {
   if (nd) { *new_node = 0; return nd; }
   float P[AZR_AMAX], V;
   call_oracle(e, st, P, &V);
+  if (e->ext_miss) { *new_node = 0; return 0; }     /* replay mode: suspended before anything was stored */
   nd = tree_find(e, st, 1);
   azr_env g; azr_init_state(&g, e->game, st);
   int acts[AZR_AMAX]; int n = available(&g, acts);
@@ -845,6 +889,7 @@ static double run_simulation(azr_mcts* e, azr_env* game, const double* eta, int 
   int acts[AZR_AMAX]; available(game, acts);
   int new_node;
   azr_node* info = state_info(e, &st, &new_node);
+  if (!info) return 0.;                             /* replay mode: suspended (e->ext_miss) */
   if (new_node) return (double)info->Vest;
   double eps = root ? e->noise_eps : 0.;
   int aid = select_action(info, e->cpuct, eps, eta);
@@ -855,6 +900,7 @@ static double run_simulation(azr_mcts* e, azr_env* game, const double* eta, int 
   double r = wp ? wr : -wr;
   int pswitch = wp != azr_white_playing(game);
   double qnext = run_simulation(e, game, eta, 0);
+  if (e->ext_miss) return 0.;                       /* replay mode: unwind without update_state_info! */
   qnext = pswitch ? -qnext : qnext;
   double q = r + e->gamma * qnext;
   /* update_state_info! (:190-194) -- re-find: the table may have been rehashed */
@@ -864,21 +910,33 @@ static double run_simulation(azr_mcts* e, azr_env* game, const double* eta, int 
   return q;
 }
 
-/* explore! (src/mcts.jl:239-245).  eta: caller-provided noise (length = #available
- * actions) or NULL to draw it from the RNG contract keyed by (seed, game id, move). */
-void azr_mcts_explore(azr_mcts* e, const azr_env* game, int nsims, const double* eta_in, uint64_t seed,
-                      uint32_t game_id, uint32_t move) {
-  double eta[AZR_AMAX];
+/* explore! (src/mcts.jl:239-245) in two parts so that replay mode can suspend it between simulations.
+ * explore_begin: the noise of this call -- caller-provided (length = #available actions) or drawn from the RNG contract keyed by
+ * (seed, game id, move) -- and the RNG context.  explore_run: simulations `from` .. nsims-1; returns the index of the first simulation
+ * that did NOT complete (nsims when all did; less only in replay mode, with e->ext_key the state to evaluate). */
+static void explore_begin(azr_mcts* e, const azr_env* game, const double* eta_in, uint64_t seed, uint32_t game_id, uint32_t move, double* eta) {
   int acts[AZR_AMAX]; int n = available(game, acts);
   if (eta_in) memcpy(eta, eta_in, sizeof(double) * (size_t)n);
   else { rn_stream r = rn_open(seed, game_id, move, RN_NOISE); rn_dirichlet(&r, n, e->noise_alpha, eta); }
   e->rng_seed = seed; e->rng_game = game_id; e->rng_move = move;
-  for (int i = 0; i < nsims; ++i) {
+}
+static int explore_run(azr_mcts* e, const azr_env* game, int from, int nsims, const double* eta) {
+  for (int i = from; i < nsims; ++i) {
     e->rng_sim = (uint32_t)i;
-    e->total_simulations += 1;
+    e->ext_miss = 0;
     azr_env clone = *game;                       /* GI.clone */
     run_simulation(e, &clone, eta, 1);
+    if (e->ext_miss) return i;                   /* nothing was counted or stored: simulation i runs again once the state is answered */
+    e->total_simulations += 1;
   }
+  return nsims;
+}
+void azr_mcts_explore(azr_mcts* e, const azr_env* game, int nsims, const double* eta_in, uint64_t seed,
+                      uint32_t game_id, uint32_t move) {
+  double eta[AZR_AMAX];
+  explore_begin(e, game, eta_in, seed, game_id, move, eta);
+  int done = explore_run(e, game, 0, nsims, eta);
+  if (done != nsims) { fprintf(stderr, "azref: azr_mcts_explore cannot suspend (replay mode goes through azr_sim_step)\n"); abort(); }
 }
 /* Convenience for tests: explore from a state, returning root statistics by rank. */
 int azr_mcts_root_stats(azr_mcts* e, const azr_state* st, int64_t* N, double* W, float* P, float* Vest) {
@@ -970,84 +1028,168 @@ typedef struct {
   azr_mcts* mcts;
   azr_env game;
   int game_id, nmoves, first_move, worker_sim_id, active;
+  /* the turn in progress (stepping form): 0 = not started, 1 = thinking (explore! at simulation sim_i), 2 = move played */
+  int turn, sim_i, pre_n, pre_acts[AZR_AMAX];
+  double eta[AZR_AMAX];
 } azr_slot;
 
 /* simulate (src/simulations.jl:207-244) with num_workers lock-step workers: every round
  * each active worker plays ONE move of its game (think -> sample -> play!, play.jl:298-315);
  * game ids are handed out in increasing order, ties between workers finishing in the same
  * round resolved by worker index (the reference's assignment is a race, util.jl:181-188).
- * Returns the number of move records written. */
+ *
+ * Stepping form.  azr_sim_new / azr_sim_step / azr_sim_free hold that loop's state in an object so that, in replay mode
+ * (AZR_ORACLE_EXTERNAL), a round can stop where workers wait for evaluations: azr_sim_step runs every worker until it has played
+ * its move or is suspended on a state the evaluation table does not hold, and returns the (distinct) states to evaluate;
+ * the caller answers them (azr_sim_feed) and steps again.  0 = the phase is over.  With the built-in oracles nothing ever
+ * suspends and azr_simulate is one azr_sim_step call: the loop below IS simulate for every oracle kind. */
 int azr_num_symmetries(int game);
 static void apply_symmetry(azr_env* g, int k);
-int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap) {
-  int G = p->num_workers < p->num_games ? p->num_workers : p->num_games;
-  azr_slot* slots = calloc((size_t)G, sizeof(azr_slot));
-  int64_t nm = 0;
-  int next_game = 0, finished = 0;
-  int A = azr_num_actions_(p->game);
-  int nsym = azr_num_symmetries(p->game);
-  if (p->flip_probability != 0. && nsym == 0) { fprintf(stderr, "azref: no symmetries were declared for this game\n"); abort(); }
-  for (int s = 0; s < G; ++s) {
-    slots[s].mcts = azr_mcts_new(p->game, p->oracle_kind, p->gamma, p->cpuct, p->noise_eps, p->noise_alpha, p->prior_temperature);
-    if (p->oracle_kind == AZR_ORACLE_NET) azr_mcts_set_net(slots[s].mcts, p->nblocks, p->F, p->npf, p->nvf, p->blob);
-    slots[s].game_id = p->first_game_id + next_game++; slots[s].active = 1;
-    azr_init(&slots[s].game, p->game);
-    slots[s].first_move = -1;
+typedef struct {
+  azr_sim_params p;
+  int G, maxlen;
+  azr_slot* slots;
+  azr_move_rec* stage;          /* move records of one game must be contiguous: per-slot staging area first */
+  int64_t nm;
+  int next_game, finished;
+  azr_game_rec* games; azr_move_rec* moves; int64_t moves_cap;   /* the caller's */
+  azr_evals* ext; int own_ext;
+  int64_t rounds, steps;
+} azr_sim;
+
+azr_sim* azr_sim_new(const azr_sim_params* p, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap, azr_evals* evals) {
+  azr_sim* h = calloc(1, sizeof *h);
+  h->p = *p; h->games = games; h->moves = moves; h->moves_cap = moves_cap;
+  int G = h->G = p->num_workers < p->num_games ? p->num_workers : p->num_games;
+  if (p->flip_probability != 0. && azr_num_symmetries(p->game) == 0) { fprintf(stderr, "azref: no symmetries were declared for this game\n"); abort(); }
+  if (p->oracle_kind == AZR_ORACLE_EXTERNAL) {
+    h->ext = evals ? evals : azr_evals_new(22); h->own_ext = !evals;
+    if (h->ext->cap < (size_t)8 * (size_t)(G > 0 ? G : 1)) { fprintf(stderr, "azref: evaluation table too small for %d workers\n", G); abort(); }
   }
-  /* move records of one game must be contiguous: reserve max game length per game lazily
-   * by writing into a per-slot staging area first */
-  int maxlen = 512;
-  azr_move_rec* stage = calloc((size_t)G * maxlen, sizeof(azr_move_rec));
-  while (finished < p->num_games) {
+  h->slots = calloc((size_t)(G > 0 ? G : 1), sizeof(azr_slot));
+  for (int s = 0; s < G; ++s) {
+    azr_slot* sl = &h->slots[s];
+    sl->mcts = azr_mcts_new(p->game, p->oracle_kind, p->gamma, p->cpuct, p->noise_eps, p->noise_alpha, p->prior_temperature);
+    if (p->oracle_kind == AZR_ORACLE_NET) azr_mcts_set_net(sl->mcts, p->nblocks, p->F, p->npf, p->nvf, p->blob);
+    sl->mcts->ext = h->ext;
+    sl->game_id = p->first_game_id + h->next_game++; sl->active = 1;
+    azr_init(&sl->game, p->game);
+    sl->first_move = -1;
+  }
+  h->maxlen = 512;
+  h->stage = calloc((size_t)(G > 0 ? G : 1) * h->maxlen, sizeof(azr_move_rec));
+  return h;
+}
+void azr_sim_free(azr_sim* h) {
+  for (int s = 0; s < h->G; ++s) azr_mcts_free(h->slots[s].mcts);
+  if (h->own_ext) azr_evals_free(h->ext);
+  free(h->slots); free(h->stage); free(h);
+}
+int64_t azr_sim_num_moves(const azr_sim* h) { return h->nm; }
+/* out: move rounds completed, azr_sim_step calls, oracle calls of the live workers (answered evaluations the trees consumed) */
+void azr_sim_counters(const azr_sim* h, int64_t* out) {
+  int64_t oc = 0;
+  for (int s = 0; s < h->G; ++s) oc += h->slots[s].mcts->oracle_calls;
+  out[0] = h->rounds; out[1] = h->steps; out[2] = oc;
+}
+
+/* One worker's turn (the body of play_game's loop, play.jl:298-315), resumable.  Returns 1 when the worker is suspended on an
+ * evaluation (replay mode), 0 when its move has been played. */
+static int slot_turn(azr_sim* h, int s) {
+  const azr_sim_params* p = &h->p;
+  azr_slot* sl = &h->slots[s];
+  azr_move_rec* mr = &h->stage[(size_t)s * h->maxlen + sl->nmoves];
+  if (sl->turn == 0) {
+    memset(mr, 0, sizeof *mr);
+    azr_pack_key(p->game, &sl->game.s, mr->key);                    /* trace.states[i]: pushed BEFORE this turn's flip (play.jl:299, 313) */
+    sl->pre_n = available(&sl->game, sl->pre_acts);                 /* available actions of that state, in order */
+    if (p->flip_probability != 0.) {                                /* play.jl:305-307 */
+      int nsym = azr_num_symmetries(p->game);
+      rn_stream r = rn_open(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, RN_FLIP);
+      if (rn_u64(&r) < p->flip_probability) {
+        int k = (int)(rn_u64(&r) * (double)nsym);
+        if (k >= nsym) k = nsym - 1;
+        apply_symmetry(&sl->game, k);
+        mr->N[AZR_AMAX] = k + 1;
+      }
+    }
+    /* think (play.jl:196-206) */
+    explore_begin(sl->mcts, &sl->game, 0, p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, sl->eta);
+    sl->sim_i = 0; sl->turn = 1;
+  }
+  if (sl->turn == 1) {
+    sl->sim_i = explore_run(sl->mcts, &sl->game, sl->sim_i, p->num_iters_per_turn, sl->eta);
+    if (sl->sim_i < p->num_iters_per_turn) return 1;
+    int acts[AZR_AMAX]; double pi[AZR_AMAX], pis[AZR_AMAX];
+    int n = azr_mcts_policy(sl->mcts, &sl->game, acts, pi);
+    /* the trace holds pi_target over the available actions of the state the player SAW; convert_sample and apply_symmetry
+     * spread it over the actions mask of trace.states[i], the state before the flip (learning.jl:31-33, memory.jl:115-118):
+     * entry i goes to that state's i-th available action.  Without a flip the two lists are the same. */
+    { azr_node* nd = tree_find(sl->mcts, &sl->game.s, 0);
+      if (n != sl->pre_n) { fprintf(stderr, "azref: a symmetry changed the number of available actions\n"); abort(); }
+      for (int i = 0; i < n; ++i) mr->N[sl->pre_acts[i]] = (int32_t)nd->N[i]; }
+    /* temperature index = #moves already played (play.jl:309) */
+    double tau = azr_plschedule(p->temp_xs, p->temp_ys, p->temp_len, sl->nmoves);
+    apply_temperature(pi, n, tau, pis);
+    rn_stream r = rn_open(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, RN_MOVE);
+    int a = acts[azr_rand_categorical(pis, n, rn_u32(&r))];
+    azr_play(&sl->game, a);
+    mr->action = a; mr->reward = (float)azr_white_reward(&sl->game);
+    sl->nmoves++;
+    if (sl->nmoves >= h->maxlen) { fprintf(stderr, "azref: game too long\n"); abort(); }
+    sl->turn = 2;
+  }
+  return 0;
+}
+
+/* Runs the phase until workers wait for evaluations or it is over.  keys_out (2 x keys_cap words; replay mode only): the distinct
+ * states to evaluate, each reported once.  Returns their number, 0 when every game has been played. */
+int64_t azr_sim_step(azr_sim* h, uint64_t* keys_out, int64_t keys_cap) {
+  const azr_sim_params* p = &h->p;
+  const int G = h->G;
+  h->steps++;
+  uint8_t* waiting = calloc((size_t)(G > 0 ? G : 1), 1);
+  while (h->finished < p->num_games) {
     /* the workers are independent (one tree, one game, one RNG stream each): a round's moves may run on
      * separate host threads without changing any result */
-#pragma omp parallel for schedule(dynamic, 1)
+    const int chunk = h->ext ? 8 : 1;              /* replay mode: a turn slice is one simulation or so; otherwise a whole move */
+#pragma omp parallel for schedule(dynamic, chunk)
     for (int s = 0; s < G; ++s) {
-      azr_slot* sl = &slots[s];
-      if (!sl->active) continue;
-      azr_move_rec* mr = &stage[(size_t)s * maxlen + sl->nmoves];
-      memset(mr, 0, sizeof *mr);
-      azr_pack_key(p->game, &sl->game.s, mr->key);                    /* trace.states[i]: pushed BEFORE this turn's flip (play.jl:299, 313) */
-      int pre_acts[AZR_AMAX]; int pre_n = available(&sl->game, pre_acts);   /* available actions of that state, in order */
-      (void)A;
-      if (p->flip_probability != 0.) {                                /* play.jl:305-307 */
-        rn_stream r = rn_open(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, RN_FLIP);
-        if (rn_u64(&r) < p->flip_probability) {
-          int k = (int)(rn_u64(&r) * (double)nsym);
-          if (k >= nsym) k = nsym - 1;
-          apply_symmetry(&sl->game, k);
-          mr->N[AZR_AMAX] = k + 1;
-        }
+      waiting[s] = 0;
+      if (h->slots[s].active && h->slots[s].turn != 2) waiting[s] = (uint8_t)slot_turn(h, s);
+    }
+    int64_t nk = 0, nwait = 0;
+    for (int s = 0; s < G; ++s) nwait += waiting[s];
+    if (nwait) {
+      azr_evals* t = h->ext;
+      if ((t->count + (size_t)nwait) * 10 > t->cap * 6) {          /* full: forget everything (an evaluation can always be asked for again) */
+        memset(t->tab, 0, t->cap * sizeof(azr_eval_ent)); t->count = 0; t->wipes++;
       }
-      /* think (play.jl:196-206) */
-      azr_mcts_explore(sl->mcts, &sl->game, p->num_iters_per_turn, 0, p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves);
-      int acts[AZR_AMAX]; double pi[AZR_AMAX], pis[AZR_AMAX];
-      int n = azr_mcts_policy(sl->mcts, &sl->game, acts, pi);
-      /* the trace holds pi_target over the available actions of the state the player SAW; convert_sample and apply_symmetry
-       * spread it over the actions mask of trace.states[i], the state before the flip (learning.jl:31-33, memory.jl:115-118):
-       * entry i goes to that state's i-th available action.  Without a flip the two lists are the same. */
-      { azr_node* nd = tree_find(sl->mcts, &sl->game.s, 0);
-        if (n != pre_n) { fprintf(stderr, "azref: a symmetry changed the number of available actions\n"); abort(); }
-        for (int i = 0; i < n; ++i) mr->N[pre_acts[i]] = (int32_t)nd->N[i]; }
-      /* temperature index = #moves already played (play.jl:309) */
-      double tau = azr_plschedule(p->temp_xs, p->temp_ys, p->temp_len, sl->nmoves);
-      apply_temperature(pi, n, tau, pis);
-      rn_stream r = rn_open(p->seed, (uint32_t)sl->game_id, (uint32_t)sl->nmoves, RN_MOVE);
-      int a = acts[azr_rand_categorical(pis, n, rn_u32(&r))];
-      azr_play(&sl->game, a);
-      mr->action = a; mr->reward = (float)azr_white_reward(&sl->game);
-      sl->nmoves++;
-      if (sl->nmoves >= maxlen) { fprintf(stderr, "azref: game too long\n"); abort(); }
+      for (int s = 0; s < G; ++s) if (waiting[s]) {
+        azr_eval_ent* ent = evals_find(t, h->slots[s].mcts->ext_key, 1);
+        if (ent->st == 2) continue;                                 /* (answered meanwhile: cannot happen within a step, harmless) */
+        if (ent->st == 0) { ent->st = 1; t->count++; }
+        else if (ent->pad == (int32_t)(h->steps & 0x7fffffff)) continue;   /* already reported in this step */
+        ent->pad = (int32_t)(h->steps & 0x7fffffff);               /* asked for in an earlier step and never answered: report again */
+        if (nk >= keys_cap) { fprintf(stderr, "azref: azr_sim_step needs room for one key per worker\n"); abort(); }
+        keys_out[2 * nk] = ent->k0; keys_out[2 * nk + 1] = ent->k1; nk++;
+        t->asked++;
+      }
+      free(waiting);
+      return nk;
     }
     /* end-of-round bookkeeping in worker order */
+    h->rounds++;
     for (int s = 0; s < G; ++s) {
-      azr_slot* sl = &slots[s];
-      if (!sl->active || !azr_terminated(&sl->game)) continue;
-      azr_game_rec* gr = &games[sl->game_id - p->first_game_id];
-      gr->game_id = sl->game_id; gr->slot = s; gr->num_moves = sl->nmoves; gr->first_move = (int32_t)nm;
-      if (nm + sl->nmoves > moves_cap) { fprintf(stderr, "azref: move buffer too small\n"); abort(); }
-      memcpy(moves + nm, stage + (size_t)s * maxlen, sizeof(azr_move_rec) * (size_t)sl->nmoves);
-      nm += sl->nmoves;
+      azr_slot* sl = &h->slots[s];
+      if (!sl->active) continue;
+      sl->turn = 0;
+      if (!azr_terminated(&sl->game)) continue;
+      azr_game_rec* gr = &h->games[sl->game_id - p->first_game_id];
+      gr->game_id = sl->game_id; gr->slot = s; gr->num_moves = sl->nmoves; gr->first_move = (int32_t)h->nm;
+      if (h->nm + sl->nmoves > h->moves_cap) { fprintf(stderr, "azref: move buffer too small\n"); abort(); }
+      memcpy(h->moves + h->nm, h->stage + (size_t)s * h->maxlen, sizeof(azr_move_rec) * (size_t)sl->nmoves);
+      h->nm += sl->nmoves;
       /* measure (training.jl:269-273) happens BEFORE the periodic reset */
       gr->nodes = azr_mcts_num_nodes(sl->mcts);
       gr->total_simulations = sl->mcts->total_simulations;
@@ -1055,16 +1197,64 @@ int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
       azr_pack_key(p->game, &sl->game.s, gr->final_key);
       sl->worker_sim_id++;
       if (p->reset_every > 0 && sl->worker_sim_id % p->reset_every == 0) azr_mcts_reset(sl->mcts);
-      finished++;
-      if (next_game < p->num_games) {
-        sl->game_id = p->first_game_id + next_game++; sl->nmoves = 0;
+      h->finished++;
+      if (h->next_game < p->num_games) {
+        sl->game_id = p->first_game_id + h->next_game++; sl->nmoves = 0;
         azr_init(&sl->game, p->game);
       } else sl->active = 0;
     }
   }
-  for (int s = 0; s < G; ++s) azr_mcts_free(slots[s].mcts);
-  free(slots); free(stage);
+  free(waiting);
+  return 0;
+}
+/* The caller's answers: P [n][A] by FULL action index (0 on unavailable actions, as Network.evaluate_batch's masked
+ * forward_normalized gives them, network.jl:264-271), V [n]. */
+void azr_sim_feed(azr_sim* h, const uint64_t* keys, const float* P, const float* V, int64_t n) {
+  int A = azr_num_actions_(h->p.game);
+  for (int64_t i = 0; i < n; ++i) {
+    azr_eval_ent* ent = evals_find(h->ext, keys + 2 * i, 0);
+    if (!ent) { fprintf(stderr, "azref: azr_sim_feed: a state nobody asked for\n"); abort(); }
+    for (int a = 0; a < A; ++a) ent->P[a] = P[(size_t)i * A + a];
+    ent->V = V[i];
+    if (ent->st != 2) h->ext->answered++;
+    ent->st = 2;
+  }
+}
+int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap) {
+  if (p->oracle_kind == AZR_ORACLE_EXTERNAL) { fprintf(stderr, "azref: replay mode goes through azr_sim_step\n"); abort(); }
+  azr_sim* h = azr_sim_new(p, games, moves, moves_cap, 0);
+  int64_t r = azr_sim_step(h, 0, 0);
+  if (r != 0) abort();
+  int64_t nm = h->nm;
+  azr_sim_free(h);
   return nm;
+}
+
+/* Batch forms of two built-in oracles by state key, for feeding replay mode from this file (CPU tests: replay mode fed with the
+ * oracle's own answers must reproduce the direct run).  P [n][A] full width, V [n]. */
+void azr_hash_oracle_keys(int game, const uint64_t* keys, int64_t n, float* P, float* V) {
+  int A = azr_num_actions_(game);
+  for (int64_t i = 0; i < n; ++i) {
+    azr_state st; azr_unpack_key(game, keys + 2 * i, &st);
+    azr_env g; azr_init_state(&g, game, &st);
+    azr_hash_oracle(game, &st, g.amask, P + (size_t)i * A, V + i);
+  }
+}
+void azr_net_evaluate_keys(int game, int nblocks, int F, int npf, int nvf, const float* blob, const uint64_t* keys, int64_t n, float* P, float* V) {
+  int W, H, C; azr_state_dims(game, &W, &H, &C);
+  int A = azr_num_actions_(game);
+  azr_net net = {W, H, C, A, nblocks, F, npf, nvf, blob, 0};
+  net.pk = net_pack(&net);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t i = 0; i < n; ++i) {
+    azr_state st; azr_unpack_key(game, keys + 2 * i, &st);
+    azr_env g; azr_init_state(&g, game, &st);
+    float x[AZR_CELLS * 5], am[AZR_AMAX], pinv;
+    azr_vectorize_state(game, &st, x);
+    for (int a = 0; a < A; ++a) am[a] = g.amask[a] ? 1.0f : 0.0f;
+    forward_normalized_one(&net, x, am, P + (size_t)i * A, V + i, &pinv);
+  }
+  free(net.pk);
 }
 
 /* ================================ arena ================================== */

@@ -15,6 +15,7 @@ LIB = os.path.join(HERE, "libazref.so")
 C4, TTT, MANCALA = 0, 1, 2
 GO9 = 3           # tensor geometry only (9 x 9 x 4 planes, 82 actions): the network restatement takes any dimensions
 ORACLE_UNIFORM, ORACLE_HASH, ORACLE_NET, ORACLE_ROLLOUT = 0, 1, 2, 3
+ORACLE_EXTERNAL = 4   # replay mode: oracle(state) answers supplied by the caller (azr_sim_step / azr_sim_feed)
 AMAX = 9
 CELLS = 42
 
@@ -280,6 +281,95 @@ def simulate(game, oracle, num_games, num_workers, nsims, **kw):
     moves = (MoveRec * cap)()
     nm = lib().azr_simulate(C.byref(p), games, moves, cap)
     return games, moves, nm
+
+
+class Evals:
+    """The evaluation table of replay mode (state key -> P, V), shareable between several replays of one network."""
+
+    def __init__(self, log2cap=22):
+        lib().azr_evals_new.restype = C.c_void_p
+        self.h = C.c_void_p(lib().azr_evals_new(int(log2cap)))
+
+    def counters(self):
+        out = (C.c_int64 * 4)()
+        lib().azr_evals_counters(self.h, out)
+        return dict(asked=out[0], answered=out[1], wipes=out[2], entries=out[3])
+
+    def close(self):
+        if self.h:
+            lib().azr_evals_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def replay(game, evaluate, num_games, num_workers, nsims, evals=None, **kw):
+    """REPLAY MODE (SURVEY.md §7 hard part 3): `simulate` -- the same lock-step loop, the same tree code -- with every oracle answer
+    supplied by `evaluate(keys uint64[n, 2]) -> (P float32[n, A] by full action index, V float32[n])`, e.g. the device network
+    behind az_net_evaluate_keys.  The oracle's trees then run on the other evaluator's numbers, at CPU-tree speed on all host
+    threads.  Returns (games, moves, num_moves, info); info: steps (evaluate calls + 1), evaluated (states sent to evaluate),
+    oracle_calls (evaluations the trees consumed: what a direct run would have computed), rounds."""
+    L = lib()
+    p, blob = _sim_params(game, ORACLE_EXTERNAL, num_games, num_workers, nsims, **kw)
+    games = (GameRec * num_games)()
+    cap = num_games * 512
+    moves = (MoveRec * cap)()
+    L.azr_sim_new.restype = C.c_void_p
+    L.azr_sim_new.argtypes = [C.POINTER(SimParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.azr_sim_step.restype = C.c_int64
+    L.azr_sim_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.azr_sim_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.azr_sim_free.argtypes = [C.c_void_p]
+    L.azr_sim_num_moves.restype = C.c_int64
+    L.azr_sim_num_moves.argtypes = [C.c_void_p]
+    L.azr_sim_counters.argtypes = [C.c_void_p, C.c_void_p]
+    own = evals is None
+    if own:
+        evals = Evals(max(16, int(np.ceil(np.log2(16 * max(1, min(num_workers, num_games)))))))
+    h = C.c_void_p(L.azr_sim_new(C.byref(p), games, moves, cap, evals.h))
+    G = min(num_workers, num_games)
+    keys = np.zeros((max(G, 1), 2), dtype=np.uint64)
+    nA = NUM_ACTIONS[game]
+    evaluated = 0
+    try:
+        while True:
+            n = L.azr_sim_step(h, keys.ctypes.data_as(C.c_void_p), G)
+            if n == 0:
+                break
+            P, V = evaluate(keys[:n])
+            P = np.ascontiguousarray(P, dtype=np.float32).reshape(n, nA)
+            V = np.ascontiguousarray(V, dtype=np.float32).reshape(n)
+            L.azr_sim_feed(h, keys.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p), V.ctypes.data_as(C.c_void_p), n)
+            evaluated += int(n)
+        nm = L.azr_sim_num_moves(h)
+        out = (C.c_int64 * 3)()
+        L.azr_sim_counters(h, out)
+        info = dict(rounds=out[0], steps=out[1], oracle_calls=out[2], evaluated=evaluated)
+    finally:
+        L.azr_sim_free(h)
+        if own:
+            evals.close()
+    return games, moves, nm, info
+
+
+def hash_oracle_keys(game, keys):
+    """the synthetic hash oracle for a batch of state keys: (P [n, A] full width, V [n])"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1, 2)
+    n = keys.shape[0]
+    P = np.zeros((n, NUM_ACTIONS[game]), dtype=np.float32); V = np.zeros(n, dtype=np.float32)
+    lib().azr_hash_oracle_keys(game, keys.ctypes.data_as(C.c_void_p), C.c_int64(n), P.ctypes.data_as(C.c_void_p), V.ctypes.data_as(C.c_void_p))
+    return P, V
+
+
+def net_evaluate_keys(game, hp, blob, keys):
+    """Network.evaluate_batch (network.jl:308-315) of the oracle's fp32 network for a batch of state keys"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1, 2)
+    blob = np.ascontiguousarray(blob, dtype=np.float32)
+    n = keys.shape[0]
+    P = np.zeros((n, NUM_ACTIONS[game]), dtype=np.float32); V = np.zeros(n, dtype=np.float32)
+    lib().azr_net_evaluate_keys(game, hp[0], hp[1], hp[2], hp[3], blob.ctypes.data_as(C.c_void_p), keys.ctypes.data_as(C.c_void_p),
+                                C.c_int64(n), P.ctypes.data_as(C.c_void_p), V.ctypes.data_as(C.c_void_p))
+    return P, V
 
 
 def arena(game, num_games, num_workers, contender, baseline, alternate_colors=False, flip_probability=0.0,

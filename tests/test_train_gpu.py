@@ -386,3 +386,22 @@ def test_weight_gradient_stream_does_not_change_the_values(monkeypatch):
             grads.append(g[0])
     assert np.array_equal(grads[0], grads[1])
     mem.close()
+
+
+def test_column_sums_finished_inside_the_producer_do_not_change_the_values(monkeypatch):
+    """round 4's opt-in form (AZHIP_TRAIN_FINISH_INSIDE=1: the second stage of every column sum in the producer's last workgroup,
+    release / acquire on its counter -- ADVICE r4) adds the same partials in the same order as the separate launch: trained
+    parameters bit-identical, and repeatable"""
+    import azhip
+    gspec, mem = _memory(0, 40, 3)
+    hp = azhip.ResNetHP(num_blocks=3, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+    lp = azhip.LearningParams(samples_weighing_policy=1, l2_regularization=1e-4, loss_computation_batch_size=64, batch_size=150)
+    outs = []
+    for inside in ("0", "1", "1"):
+        monkeypatch.setenv("AZHIP_TRAIN_FINISH_INSIDE", inside)
+        nn = azhip.ResNet(gspec, hp, seed=3)
+        with azhip.Trainer(gspec, nn, mem, lp, use_symmetries=True) as tr:
+            idx = np.arange(150) * 3 % len(tr.data.tensors()[0])
+            outs.append(tr.gradients(idx)[2].copy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    mem.close()
