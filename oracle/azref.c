@@ -25,6 +25,8 @@
  * Build: see oracle/Makefile  (gcc -O3 -ffp-contract=off -mavx2 -mfma).
  */
 #include <math.h>
+#include <omp.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -680,8 +682,9 @@ azr_evals* azr_evals_new(int log2cap) {
 }
 void azr_evals_free(azr_evals* t) { if (t) { free(t->tab); free(t); } }
 void azr_evals_counters(const azr_evals* t, int64_t* out) { out[0] = t->asked; out[1] = t->answered; out[2] = t->wipes; out[3] = (int64_t)t->count; }
+static size_t evals_home(const azr_evals* t, const uint64_t* key) { return (size_t)rn_mix64(key[0] ^ rn_mix64(key[1] + 0x9e3779b97f4a7c15ULL)) & (t->cap - 1); }
 static azr_eval_ent* evals_find(const azr_evals* t, const uint64_t* key, int insert) {
-  size_t j = (size_t)rn_mix64(key[0] ^ rn_mix64(key[1] + 0x9e3779b97f4a7c15ULL)) & (t->cap - 1);
+  size_t j = evals_home(t, key);
   while (t->tab[j].st) {
     if (t->tab[j].k0 == key[0] && t->tab[j].k1 == key[1]) return &t->tab[j];
     j = (j + 1) & (t->cap - 1);
@@ -1055,6 +1058,8 @@ typedef struct {
   azr_game_rec* games; azr_move_rec* moves; int64_t moves_cap;   /* the caller's */
   azr_evals* ext; int own_ext;
   int64_t rounds, steps;
+  uint8_t* waiting;             /* [G] the worker is suspended on an evaluation */
+  double tm[4];                 /* azr_sim_run, seconds on the calling thread: its share of the workers' turns, waiting for the other threads, serial part, inside the evaluator */
 } azr_sim;
 
 azr_sim* azr_sim_new(const azr_sim_params* p, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap, azr_evals* evals) {
@@ -1076,6 +1081,7 @@ azr_sim* azr_sim_new(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
     azr_init(&sl->game, p->game);
     sl->first_move = -1;
   }
+  h->waiting = calloc((size_t)(G > 0 ? G : 1), 1);
   h->maxlen = 512;
   h->stage = calloc((size_t)(G > 0 ? G : 1) * h->maxlen, sizeof(azr_move_rec));
   return h;
@@ -1083,7 +1089,7 @@ azr_sim* azr_sim_new(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
 void azr_sim_free(azr_sim* h) {
   for (int s = 0; s < h->G; ++s) azr_mcts_free(h->slots[s].mcts);
   if (h->own_ext) azr_evals_free(h->ext);
-  free(h->slots); free(h->stage); free(h);
+  free(h->slots); free(h->stage); free(h->waiting); free(h);
 }
 int64_t azr_sim_num_moves(const azr_sim* h) { return h->nm; }
 /* out: move rounds completed, azr_sim_step calls, oracle calls of the live workers (answered evaluations the trees consumed) */
@@ -1142,75 +1148,87 @@ static int slot_turn(azr_sim* h, int s) {
   return 0;
 }
 
+/* The three parts of a step.  sim_work: workers [s0, s1) run until each has played its move or is suspended (parallel part: the
+ * workers are independent -- one tree, one game, one RNG stream each -- so a round's turns may run on separate host threads without
+ * changing any result).  sim_collect: the distinct states the suspended workers wait for, each reported once (serial).
+ * sim_round_end: end-of-round bookkeeping in worker order (serial). */
+static void sim_work(azr_sim* h, int s0, int s1) {
+  for (int s = s0; s < s1; ++s) {
+    h->waiting[s] = 0;
+    if (h->slots[s].active && h->slots[s].turn != 2) h->waiting[s] = (uint8_t)slot_turn(h, s);
+  }
+}
+static int64_t sim_collect(azr_sim* h, uint64_t* keys_out, int64_t keys_cap) {
+  const int G = h->G;
+  int64_t nk = 0, nwait = 0;
+  for (int s = 0; s < G; ++s) nwait += h->waiting[s];
+  if (!nwait) return 0;
+  azr_evals* t = h->ext;
+  if ((t->count + (size_t)nwait) * 10 > t->cap * 6) {              /* full: forget everything (an evaluation can always be asked for again) */
+    memset(t->tab, 0, t->cap * sizeof(azr_eval_ent)); t->count = 0; t->wipes++;
+  }
+  for (int s = 0; s < G; ++s) if (h->waiting[s]) __builtin_prefetch(&t->tab[evals_home(t, h->slots[s].mcts->ext_key)], 1);
+  const int32_t stamp = (int32_t)(h->steps & 0x7fffffff);
+  for (int s = 0; s < G; ++s) if (h->waiting[s]) {
+    azr_eval_ent* ent = evals_find(t, h->slots[s].mcts->ext_key, 1);
+    if (ent->st == 2) continue;                                     /* (answered meanwhile: cannot happen within a step, harmless) */
+    if (ent->st == 0) { ent->st = 1; t->count++; }
+    else if (ent->pad == stamp) continue;                           /* already reported in this step */
+    ent->pad = stamp;                                               /* asked for in an earlier step and never answered: report again */
+    if (nk >= keys_cap) { fprintf(stderr, "azref: replay needs room for one key per worker\n"); abort(); }
+    keys_out[2 * nk] = ent->k0; keys_out[2 * nk + 1] = ent->k1; nk++;
+    t->asked++;
+  }
+  return nk;
+}
+static void sim_round_end(azr_sim* h) {
+  const azr_sim_params* p = &h->p;
+  h->rounds++;
+  for (int s = 0; s < h->G; ++s) {
+    azr_slot* sl = &h->slots[s];
+    if (!sl->active) continue;
+    sl->turn = 0;
+    if (!azr_terminated(&sl->game)) continue;
+    azr_game_rec* gr = &h->games[sl->game_id - p->first_game_id];
+    gr->game_id = sl->game_id; gr->slot = s; gr->num_moves = sl->nmoves; gr->first_move = (int32_t)h->nm;
+    if (h->nm + sl->nmoves > h->moves_cap) { fprintf(stderr, "azref: move buffer too small\n"); abort(); }
+    memcpy(h->moves + h->nm, h->stage + (size_t)s * h->maxlen, sizeof(azr_move_rec) * (size_t)sl->nmoves);
+    h->nm += sl->nmoves;
+    /* measure (training.jl:269-273) happens BEFORE the periodic reset */
+    gr->nodes = azr_mcts_num_nodes(sl->mcts);
+    gr->total_simulations = sl->mcts->total_simulations;
+    gr->total_nodes_traversed = sl->mcts->total_nodes_traversed;
+    azr_pack_key(p->game, &sl->game.s, gr->final_key);
+    sl->worker_sim_id++;
+    if (p->reset_every > 0 && sl->worker_sim_id % p->reset_every == 0) azr_mcts_reset(sl->mcts);
+    h->finished++;
+    if (h->next_game < p->num_games) {
+      sl->game_id = p->first_game_id + h->next_game++; sl->nmoves = 0;
+      azr_init(&sl->game, p->game);
+    } else sl->active = 0;
+  }
+}
+
 /* Runs the phase until workers wait for evaluations or it is over.  keys_out (2 x keys_cap words; replay mode only): the distinct
  * states to evaluate, each reported once.  Returns their number, 0 when every game has been played. */
 int64_t azr_sim_step(azr_sim* h, uint64_t* keys_out, int64_t keys_cap) {
-  const azr_sim_params* p = &h->p;
   const int G = h->G;
   h->steps++;
-  uint8_t* waiting = calloc((size_t)(G > 0 ? G : 1), 1);
-  while (h->finished < p->num_games) {
-    /* the workers are independent (one tree, one game, one RNG stream each): a round's moves may run on
-     * separate host threads without changing any result */
+  while (h->finished < h->p.num_games) {
     const int chunk = h->ext ? 8 : 1;              /* replay mode: a turn slice is one simulation or so; otherwise a whole move */
 #pragma omp parallel for schedule(dynamic, chunk)
-    for (int s = 0; s < G; ++s) {
-      waiting[s] = 0;
-      if (h->slots[s].active && h->slots[s].turn != 2) waiting[s] = (uint8_t)slot_turn(h, s);
-    }
-    int64_t nk = 0, nwait = 0;
-    for (int s = 0; s < G; ++s) nwait += waiting[s];
-    if (nwait) {
-      azr_evals* t = h->ext;
-      if ((t->count + (size_t)nwait) * 10 > t->cap * 6) {          /* full: forget everything (an evaluation can always be asked for again) */
-        memset(t->tab, 0, t->cap * sizeof(azr_eval_ent)); t->count = 0; t->wipes++;
-      }
-      for (int s = 0; s < G; ++s) if (waiting[s]) {
-        azr_eval_ent* ent = evals_find(t, h->slots[s].mcts->ext_key, 1);
-        if (ent->st == 2) continue;                                 /* (answered meanwhile: cannot happen within a step, harmless) */
-        if (ent->st == 0) { ent->st = 1; t->count++; }
-        else if (ent->pad == (int32_t)(h->steps & 0x7fffffff)) continue;   /* already reported in this step */
-        ent->pad = (int32_t)(h->steps & 0x7fffffff);               /* asked for in an earlier step and never answered: report again */
-        if (nk >= keys_cap) { fprintf(stderr, "azref: azr_sim_step needs room for one key per worker\n"); abort(); }
-        keys_out[2 * nk] = ent->k0; keys_out[2 * nk + 1] = ent->k1; nk++;
-        t->asked++;
-      }
-      free(waiting);
-      return nk;
-    }
-    /* end-of-round bookkeeping in worker order */
-    h->rounds++;
-    for (int s = 0; s < G; ++s) {
-      azr_slot* sl = &h->slots[s];
-      if (!sl->active) continue;
-      sl->turn = 0;
-      if (!azr_terminated(&sl->game)) continue;
-      azr_game_rec* gr = &h->games[sl->game_id - p->first_game_id];
-      gr->game_id = sl->game_id; gr->slot = s; gr->num_moves = sl->nmoves; gr->first_move = (int32_t)h->nm;
-      if (h->nm + sl->nmoves > h->moves_cap) { fprintf(stderr, "azref: move buffer too small\n"); abort(); }
-      memcpy(h->moves + h->nm, h->stage + (size_t)s * h->maxlen, sizeof(azr_move_rec) * (size_t)sl->nmoves);
-      h->nm += sl->nmoves;
-      /* measure (training.jl:269-273) happens BEFORE the periodic reset */
-      gr->nodes = azr_mcts_num_nodes(sl->mcts);
-      gr->total_simulations = sl->mcts->total_simulations;
-      gr->total_nodes_traversed = sl->mcts->total_nodes_traversed;
-      azr_pack_key(p->game, &sl->game.s, gr->final_key);
-      sl->worker_sim_id++;
-      if (p->reset_every > 0 && sl->worker_sim_id % p->reset_every == 0) azr_mcts_reset(sl->mcts);
-      h->finished++;
-      if (h->next_game < p->num_games) {
-        sl->game_id = p->first_game_id + h->next_game++; sl->nmoves = 0;
-        azr_init(&sl->game, p->game);
-      } else sl->active = 0;
-    }
+    for (int s = 0; s < G; ++s) sim_work(h, s, s + 1);
+    const int64_t nk = sim_collect(h, keys_out, keys_cap);
+    if (nk) return nk;
+    sim_round_end(h);
   }
-  free(waiting);
   return 0;
 }
 /* The caller's answers: P [n][A] by FULL action index (0 on unavailable actions, as Network.evaluate_batch's masked
  * forward_normalized gives them, network.jl:264-271), V [n]. */
 void azr_sim_feed(azr_sim* h, const uint64_t* keys, const float* P, const float* V, int64_t n) {
   int A = azr_num_actions_(h->p.game);
+  for (int64_t i = 0; i < n; ++i) __builtin_prefetch(&h->ext->tab[evals_home(h->ext, keys + 2 * i)], 1);
   for (int64_t i = 0; i < n; ++i) {
     azr_eval_ent* ent = evals_find(h->ext, keys + 2 * i, 0);
     if (!ent) { fprintf(stderr, "azref: azr_sim_feed: a state nobody asked for\n"); abort(); }
@@ -1220,6 +1238,67 @@ void azr_sim_feed(azr_sim* h, const uint64_t* keys, const float* P, const float*
     ent->st = 2;
   }
 }
+/* The whole replay in ONE call: azr_sim_step's loop with the evaluator called from inside (`fn`: the address of any function with
+ * Network.evaluate_batch's meaning -- keys in, P [n][A] and V [n] out, 0 = ok; the tests pass the device library's
+ * az_net_evaluate_keys with its engine as `user`, or a ctypes callback).  Same three parts as azr_sim_step; what differs is only how
+ * the host threads are kept: one team for the whole call, waiting for the serial part (and the evaluator) in a spin barrier, because
+ * a fork / join per step costs more than the step's work on a large host (12 k - 36 k steps per phase).  fn runs on the calling
+ * thread.  Returns 0, or fn's status if it fails. */
+typedef int (*azr_eval_fn)(void* user, const uint64_t* keys, int32_t n, float* P, float* V);
+static inline void cpu_relax(void) { __builtin_ia32_pause(); }
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+void azr_sim_times(const azr_sim* h, double* out) { for (int i = 0; i < 4; ++i) out[i] = h->tm[i]; }
+int azr_sim_run(azr_sim* h, azr_eval_fn fn, void* user, int nthreads, int64_t* evaluated) {
+  const int G = h->G, A = azr_num_actions_(h->p.game);
+  const int CH = 4, nchunks = (G + CH - 1) / CH;
+  uint64_t* keys = malloc(sizeof(uint64_t) * 2 * (size_t)(G > 0 ? G : 1));
+  float* P = malloc(sizeof(float) * (size_t)A * (size_t)(G > 0 ? G : 1));
+  float* V = malloc(sizeof(float) * (size_t)(G > 0 ? G : 1));
+  int next_chunk = 0, arrived = 0, gen = 0, done = h->finished >= h->p.num_games, status = 0;
+  int64_t nev = 0;
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+    const int me = omp_get_thread_num(), nt = omp_get_num_threads();
+    int mygen = 0;
+    while (!__atomic_load_n(&done, __ATOMIC_ACQUIRE)) {
+      int c;
+      const double t0 = me == 0 ? now_s() : 0.;
+      while ((c = __atomic_fetch_add(&next_chunk, 1, __ATOMIC_RELAXED)) < nchunks) sim_work(h, c * CH, (c + 1) * CH < G ? (c + 1) * CH : G);
+      if (me != 0) {
+        __atomic_fetch_add(&arrived, 1, __ATOMIC_RELEASE);
+        while (__atomic_load_n(&gen, __ATOMIC_ACQUIRE) == mygen) cpu_relax();
+      } else {
+        const double t1 = now_s();
+        while (__atomic_load_n(&arrived, __ATOMIC_ACQUIRE) != nt - 1) cpu_relax();
+        const double t2 = now_s();
+        double te = 0.;
+        /* serial part, on the calling thread */
+        h->steps++;
+        const int64_t nk = sim_collect(h, keys, G);
+        if (nk) {
+          const double t3 = now_s();
+          const int rc = fn(user, keys, (int32_t)nk, P, V);
+          te = now_s() - t3;
+          if (rc != 0) { status = rc; __atomic_store_n(&done, 1, __ATOMIC_RELEASE); }
+          else { azr_sim_feed(h, keys, P, V, nk); nev += nk; }
+        } else {
+          sim_round_end(h);
+          if (h->finished >= h->p.num_games) __atomic_store_n(&done, 1, __ATOMIC_RELEASE);
+        }
+        h->tm[0] += t1 - t0; h->tm[1] += t2 - t1; h->tm[2] += now_s() - t2 - te; h->tm[3] += te;
+        __atomic_store_n(&arrived, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&next_chunk, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&gen, mygen + 1, __ATOMIC_RELEASE);
+      }
+      mygen++;
+    }
+  }
+  free(keys); free(P); free(V);
+  if (evaluated) *evaluated = nev;
+  return status;
+}
+
 int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap) {
   if (p->oracle_kind == AZR_ORACLE_EXTERNAL) { fprintf(stderr, "azref: replay mode goes through azr_sim_step\n"); abort(); }
   azr_sim* h = azr_sim_new(p, games, moves, moves_cap, 0);
@@ -1239,6 +1318,11 @@ void azr_hash_oracle_keys(int game, const uint64_t* keys, int64_t n, float* P, f
     azr_env g; azr_init_state(&g, game, &st);
     azr_hash_oracle(game, &st, g.amask, P + (size_t)i * A, V + i);
   }
+}
+/* the hash oracle with azr_sim_run's evaluator signature (user = the game id): the C-function-pointer form of the CPU tests */
+int azr_eval_hash(void* user, const uint64_t* keys, int32_t n, float* P, float* V) {
+  azr_hash_oracle_keys((int)(intptr_t)user, keys, n, P, V);
+  return 0;
 }
 void azr_net_evaluate_keys(int game, int nblocks, int F, int npf, int nvf, const float* blob, const uint64_t* keys, int64_t n, float* P, float* V) {
   int W, H, C; azr_state_dims(game, &W, &H, &C);

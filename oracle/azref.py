@@ -303,12 +303,18 @@ class Evals:
     __del__ = close
 
 
-def replay(game, evaluate, num_games, num_workers, nsims, evals=None, **kw):
+EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+
+def replay(game, evaluate, num_games, num_workers, nsims, evals=None, threads=None, **kw):
     """REPLAY MODE (SURVEY.md §7 hard part 3): `simulate` -- the same lock-step loop, the same tree code -- with every oracle answer
-    supplied by `evaluate(keys uint64[n, 2]) -> (P float32[n, A] by full action index, V float32[n])`, e.g. the device network
-    behind az_net_evaluate_keys.  The oracle's trees then run on the other evaluator's numbers, at CPU-tree speed on all host
-    threads.  Returns (games, moves, num_moves, info); info: steps (evaluate calls + 1), evaluated (states sent to evaluate),
-    oracle_calls (evaluations the trees consumed: what a direct run would have computed), rounds."""
+    supplied by the caller, e.g. by the device network behind az_net_evaluate_keys.  The oracle's trees then run on the other
+    evaluator's numbers, at CPU-tree speed on `threads` host threads (default: up to 64).
+    evaluate: a callable  keys uint64[n, 2] -> (P float32[n, A] by full action index, V float32[n]),  or a pair (address, user) of a C
+    function  int f(void* user, const uint64_t* keys, int32_t n, float* P, float* V)  (0 = ok) that is called without Python in between.
+    Returns (games, moves, num_moves, info); info: steps (rounds of evaluation + move rounds), evaluated (states sent to the
+    evaluator: each distinct state once while the table holds it), oracle_calls (evaluations the trees consumed: what a direct run
+    computes), rounds (move rounds)."""
     L = lib()
     p, blob = _sim_params(game, ORACLE_EXTERNAL, num_games, num_workers, nsims, **kw)
     games = (GameRec * num_games)()
@@ -316,35 +322,50 @@ def replay(game, evaluate, num_games, num_workers, nsims, evals=None, **kw):
     moves = (MoveRec * cap)()
     L.azr_sim_new.restype = C.c_void_p
     L.azr_sim_new.argtypes = [C.POINTER(SimParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
-    L.azr_sim_step.restype = C.c_int64
-    L.azr_sim_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-    L.azr_sim_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.azr_sim_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
     L.azr_sim_free.argtypes = [C.c_void_p]
     L.azr_sim_num_moves.restype = C.c_int64
     L.azr_sim_num_moves.argtypes = [C.c_void_p]
     L.azr_sim_counters.argtypes = [C.c_void_p, C.c_void_p]
+    L.azr_sim_times.argtypes = [C.c_void_p, C.c_void_p]
     own = evals is None
-    if own:
-        evals = Evals(max(16, int(np.ceil(np.log2(16 * max(1, min(num_workers, num_games)))))))
-    h = C.c_void_p(L.azr_sim_new(C.byref(p), games, moves, cap, evals.h))
     G = min(num_workers, num_games)
-    keys = np.zeros((max(G, 1), 2), dtype=np.uint64)
+    if own:
+        evals = Evals(max(16, int(np.ceil(np.log2(16 * max(1, G))))))
     nA = NUM_ACTIONS[game]
-    evaluated = 0
+    failure = []
+    if callable(evaluate):
+        def _cb(user, keys, n, P, V):
+            try:
+                k = np.ctypeslib.as_array(keys, shape=(n, 2))
+                Pn, Vn = evaluate(k)
+                np.ctypeslib.as_array(P, shape=(n, nA))[:] = np.asarray(Pn, dtype=np.float32).reshape(n, nA)
+                np.ctypeslib.as_array(V, shape=(n,))[:] = np.asarray(Vn, dtype=np.float32).reshape(n)
+                return 0
+            except BaseException as ex:                  # an exception must not unwind through the C loop: stop it, re-raise below
+                failure.append(ex)
+                return -1
+        cb = EVAL_FN(_cb)
+        fn, user = C.cast(cb, C.c_void_p), None
+    else:
+        fn, user = C.c_void_p(evaluate[0]), C.c_void_p(evaluate[1])
+    if threads is None:
+        threads = max(1, min(64, os.cpu_count() or 1, (G + 15) // 16))
+    h = C.c_void_p(L.azr_sim_new(C.byref(p), games, moves, cap, evals.h))
+    nev = C.c_int64(0)
     try:
-        while True:
-            n = L.azr_sim_step(h, keys.ctypes.data_as(C.c_void_p), G)
-            if n == 0:
-                break
-            P, V = evaluate(keys[:n])
-            P = np.ascontiguousarray(P, dtype=np.float32).reshape(n, nA)
-            V = np.ascontiguousarray(V, dtype=np.float32).reshape(n)
-            L.azr_sim_feed(h, keys.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p), V.ctypes.data_as(C.c_void_p), n)
-            evaluated += int(n)
+        rc = L.azr_sim_run(h, fn, user, int(threads), C.byref(nev))
+        if failure:
+            raise failure[0]
+        if rc != 0:
+            raise RuntimeError("replay: the evaluator returned status %d" % rc)
         nm = L.azr_sim_num_moves(h)
         out = (C.c_int64 * 3)()
         L.azr_sim_counters(h, out)
-        info = dict(rounds=out[0], steps=out[1], oracle_calls=out[2], evaluated=evaluated)
+        tm = (C.c_double * 4)()
+        L.azr_sim_times(h, tm)
+        info = dict(rounds=out[0], steps=out[1], oracle_calls=out[2], evaluated=int(nev.value), threads=int(threads),
+                    seconds=dict(turns=round(tm[0], 3), waiting_for_threads=round(tm[1], 3), serial=round(tm[2], 3), evaluator=round(tm[3], 3)))
     finally:
         L.azr_sim_free(h)
         if own:

@@ -92,14 +92,19 @@ def _phase_vs_replay(name, game_hip, game_ref, slots, groups, nsims, first_id, n
         one_per_slot = reset_every == 1 and num_games <= slots
         chunk = _chunk_size(nsims, plies, reset_every, num_games) if one_per_slot else num_games
         ev = R.Evals(26)                                             # 64 M states x 64 B: forgets everything when 60 % full
+        # the evaluator is the device library's az_net_evaluate_keys itself, called from the replay loop with no Python in between
+        evaluator = (C.cast(azhip._lib.lib().az_net_evaluate_keys, C.c_void_p).value, e._h.value)
         t1 = time.time()
         tot = dict(evaluated=0, oracle_calls=0, steps=0)
+        secs = {}
         for c0 in range(0, num_games, chunk):
             n = min(chunk, num_games - c0)
-            rg_, rm_, rnm, info = R.replay(game_ref, e.net_evaluate_keys, n, n if one_per_slot else slots, nsims, evals=ev,
+            rg_, rm_, rnm, info = R.replay(game_ref, evaluator, n, n if one_per_slot else slots, nsims, evals=ev,
                                            first_game_id=first_id + c0, **kw)
             for k in tot:
                 tot[k] += info[k]
+            for k, v in info["seconds"].items():
+                secs[k] = round(secs.get(k, 0.0) + v, 2)
             rg, rm = _views(rg_, rm_, n, rnm)
             _compare(hg[c0:c0 + n], hm, rg, rm, "%s games %d..%d" % (name, first_id + c0, first_id + c0 + n - 1))
         t_rep = time.time() - t1
@@ -109,7 +114,7 @@ def _phase_vs_replay(name, game_hip, game_ref, slots, groups, nsims, first_id, n
     rec = dict(case=name, games=num_games, moves=int(nm), simulations=int(stats.simulations), leaf_evals=int(stats.leaf_evals),
                distinct_states_evaluated=tot["evaluated"], distinct_over_leaf_evals=tot["evaluated"] / max(1, stats.leaf_evals),
                table_wipes=cnt["wipes"], replay_steps=tot["steps"], replay_chunk=chunk, seconds_device_phase=round(t_dev, 2),
-               seconds_replay=round(t_rep, 2), host_threads=os.cpu_count())
+               seconds_replay=round(t_rep, 2), seconds_replay_parts=secs, replay_threads=info["threads"], host_threads=os.cpu_count())
     out = os.path.join(os.path.dirname(HERE), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "replay_all_games.jsonl"), "a") as f:

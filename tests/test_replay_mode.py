@@ -84,3 +84,21 @@ def test_replay_fed_with_the_oracle_network_equals_the_direct_run():
     dg, dm, dnm = R.simulate(R.TTT, R.ORACLE_NET, 6, 6, 24, net=hp + (blob,), **kw)
     rg, rm, rnm, info = R.replay(R.TTT, lambda k: R.net_evaluate_keys(R.TTT, hp, blob, k), 6, 6, 24, **kw)
     assert rnm == dnm and _bytes(rg, rm, 6, rnm) == _bytes(dg, dm, 6, dnm)
+
+
+def test_the_evaluator_may_be_a_c_function():
+    """the form the GPU test uses (the device library's az_net_evaluate_keys + its engine): here the oracle's own hash oracle
+    behind the same signature, several host threads"""
+    kw = dict(cpuct=2.0, noise_eps=0.25, noise_alpha=1.0, temp_xs=SCHED[0], temp_ys=SCHED[1], reset_every=1, seed=12)
+    dg, dm, dnm = R.simulate(R.MANCALA, R.ORACLE_HASH, 40, 40, 30, **kw)
+    fn = C.cast(R.lib().azr_eval_hash, C.c_void_p).value
+    for threads in (1, 3):
+        rg, rm, rnm, info = R.replay(R.MANCALA, (fn, R.MANCALA), 40, 40, 30, threads=threads, **kw)
+        assert info["threads"] == threads and rnm == dnm and _bytes(rg, rm, 40, rnm) == _bytes(dg, dm, 40, dnm)
+
+
+def test_an_evaluator_that_fails_stops_the_replay():
+    def bad(keys):
+        raise ValueError("no device")
+    with pytest.raises(ValueError):
+        R.replay(R.TTT, bad, 4, 4, 8, seed=1)
