@@ -226,6 +226,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0; e->alloc_bytes = 0;
   e->vm_base = nullptr; e->vm_bytes = 0; e->vm_chunk = 0; e->vm_rows = 0; e->vm_chunk_nodes = 0; e->d_slot_cap = nullptr; e->vm_budget = 0; e->vm_mapped = 0;
   e->next_exec = 1.0;
+  e->d_ec = nullptr; e->ec_mask = 0; e->ec_seq = 0; e->d_ec_claim = nullptr; e->d_Phit = nullptr; e->d_Vhit = nullptr;
   e->h_xflag = nullptr; e->d_xflag = nullptr; e->split_off = false; e->split_registered = 0; e->xch_launches = 0;
   { const char* fa = getenv("AZHIP_XCH_FAIL_AT"); e->xch_fail_at = fa ? atoll(fa) : 0; }
   e->net_loaded = false; e->running = false; e->prof_on = false; { const char* ug = getenv("AZHIP_GRAPH"); e->use_graphs = ug ? atoi(ug) : 0; }
@@ -316,6 +317,25 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &v.keys, (size_t)G * cap * 4, false)); 
     hipLaunchKernelGGL(k_slot_records, dim3((G + 255) / 256), dim3(256), 0, e->stream, v, (int)SR_ZERO);   // epoch 1, no root, nothing else
     AZCHK(dalloc(e, &v.Pout, (size_t)std::max(G, 1) * gi.APAD)); AZCHK(dalloc(e, &v.Vout, G));
+    {
+      // Evaluation cache (tree.h): on for the ResNet oracle -- what an evaluation costs there makes a repeated one worth a look-up.
+      // AZHIP_EVAL_CACHE=0 switches it off, =1 forces it on for the exact synthetic oracles as well (tests; never for the rollout
+      // oracle, whose answer depends on the simulation's RNG stream, nor under hipGraph replay: the launch number is a kernel argument).
+      // AZHIP_EVAL_CACHE_LOG2 = log2 of the number of 64-byte entries (default 24: 1 GB; a BASELINE phase evaluates 2-6 x 10^7 states).
+      const char* ce = getenv("AZHIP_EVAL_CACHE");
+      const bool on = ce ? atoi(ce) != 0 && c->oracle != AZ_ORACLE_ROLLOUT : c->oracle == AZ_ORACLE_RESNET;
+      if (on && !e->use_graphs) {
+        const char* cl = getenv("AZHIP_EVAL_CACHE_LOG2");
+        int lg = cl ? atoi(cl) : 24;
+        lg = std::min(std::max(lg, 4), 28);
+        AZCHK(dalloc(e, &e->d_ec, (size_t)1 << lg));                // zeroed: every entry EC_EMPTY
+        e->ec_mask = ((uint32_t)1 << lg) - 1u;
+        AZCHK(dalloc(e, &e->d_ec_claim, (size_t)2 * G, false));
+        HIPCHK(hipMemsetAsync(e->d_ec_claim, 0xff, sizeof(int) * 2 * (size_t)G, e->stream));
+        AZCHK(dalloc(e, &e->d_Phit, (size_t)G * gi.APAD)); AZCHK(dalloc(e, &e->d_Vhit, G));
+        v.ec = e->d_ec; v.ec_mask = e->ec_mask; v.ec_seq = 0; v.ec_claim = e->d_ec_claim; v.Phit = e->d_Phit; v.Vhit = e->d_Vhit;
+      }
+    }
     AZCHK(dalloc(e, &v.trace, (size_t)G * v.max_moves)); AZCHK(dalloc(e, &v.grec, G));
     AZCHK(dalloc(e, &v.finished, G)); AZCHK(dalloc(e, &v.err, 1));
     // split tower fallback: one exchange word per slot group (+ one nobody sets for the whole-engine view), the counters of the
@@ -371,6 +391,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       gv.ht += o * hs; gv.nodes += o * v.node_stride; gv.path += o * v.max_depth;
       if (gv.slot_cap) gv.slot_cap += o;
       gv.leaf_env += o; gv.eval_slots += o;
+      if (gv.ec) { gv.ec_claim += 2 * o; gv.Phit += o * gi.APAD; gv.Vhit += o; }
       gv.xerr = e->d_xerr + g; gv.skipped = e->d_skipped + 2 * g;
       gv.n_eval += 2 * g; gv.keys += o * (size_t)cap * 4; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;
@@ -526,6 +547,7 @@ static void pack_conv(const float* Wt, int ksz, int Cin, int Cout, int CoutPad, 
   }
 }
 
+static int ec_empty(az_engine* e);
 extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   ENGINE(e);
   if (e->cfg.oracle != AZ_ORACLE_RESNET) return fail(AZ_ERR_STATE, "engine was created without the ResNet oracle");
@@ -742,6 +764,7 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   HIPCHK(hipStreamSynchronize(e->stream));
   e->net = nd;
   e->net_loaded = true;
+  AZCHK(ec_empty(e));                                                // the answers of the old network are gone with it
   return AZ_OK;
 }
 extern "C" int az_net_last_kernel(const az_engine* e, char* name, int32_t cap) {
@@ -843,9 +866,27 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
 // One wave = one run_simulation! for every active slot of every group: k_tree (the previous wave's expand + backup,
 // this wave's select + leaf gathering) -> oracle.  Nothing is read back by the host.  The simulation a wave starts is
 // completed by the group's next k_tree launch: the next wave's, or flush_pending's.
+// Evaluation cache: every k_tree launch of the engine gets a number (claims carry it, tree.h).  30 bits of it are kept in an entry:
+// long before they wrap the table is emptied and the count starts again.
+static int ec_empty(az_engine* e) {
+  if (!e->d_ec) return AZ_OK;
+  AZCHK(sync_all(e));
+  HIPCHK(hipMemsetAsync(e->d_ec, 0, sizeof(ECEnt) * ((size_t)e->ec_mask + 1), e->stream));
+  HIPCHK(hipMemsetAsync(e->d_ec_claim, 0xff, sizeof(int) * 2 * (size_t)e->v.G, e->stream));   // no slot holds an entry any more
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->ec_seq = 0;
+  return AZ_OK;
+}
+static int ec_next_launch(az_engine* e, DView* v) {
+  if (!e->d_ec) return AZ_OK;
+  if (e->ec_seq >= (1u << 29)) AZCHK(ec_empty(e));
+  v->ec_seq = ++e->ec_seq;
+  return AZ_OK;
+}
 // sim_idx: index of this simulation within the current explore! (keys the rollout oracle's RNG stream)
 template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx) {
   constexpr int L = Gm::APAD;
+  AZCHK(ec_next_launch(e, &e->gv[g]));
   const DView& v = e->gv[g];
   hipStream_t st = e->gs[g], sn = e->gt[g];
   const bool split = st != sn;
@@ -906,6 +947,7 @@ template <class Gm> static int flush_pending(az_engine* e) {
   constexpr int L = Gm::APAD;
   for (int g = 0; g < e->ngroups; ++g) {
     if (!e->pending[g]) continue;
+    AZCHK(ec_next_launch(e, &e->gv[g]));
     const DView& v = e->gv[g];
     LAUNCH_ON(e, e->gs[g], AZ_K_EXPAND, v.G, (k_tree<Gm>), (v.G * L + 255) / 256, 256, 0, v, e->p, 1, 0, e->wave_par[g]);
     e->pending[g] = false;
@@ -1308,7 +1350,7 @@ extern "C" int az_selfplay_get_stats(az_engine* e, az_selfplay_stats* s) {
   HIPCHK(hipMemcpyAsync(e->h_stat.data(), e->gv[0].stat, sizeof(long long) * e->stat_words, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   for (size_t i = 0; i < e->stat_words; ++i) st[i & 3] += e->h_stat[i];
-  e->stats.simulations = st[0]; e->stats.nodes_traversed = st[1]; e->stats.leaf_evals = st[2];
+  e->stats.simulations = st[0]; e->stats.nodes_traversed = st[1]; e->stats.leaf_evals = st[2]; e->stats.evals_reused = st[3];
   e->stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - e->t_begin).count();
   *s = e->stats;
   return AZ_OK;

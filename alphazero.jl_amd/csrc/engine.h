@@ -91,6 +91,8 @@ struct az_engine {
   char* vm_base; size_t vm_bytes, vm_chunk; int vm_rows, vm_chunk_nodes;
   std::vector<hipMemGenericAllocationHandle_t> vm_handles; std::vector<char*> vm_at;
   std::vector<int> h_slot_cap, h_node_count; int* d_slot_cap; int* d_node_count; size_t vm_budget, vm_mapped;
+  // evaluation cache (tree.h ECEnt): one table per engine = per network; az_net_set_params empties it
+  ECEnt* d_ec; uint32_t ec_mask; uint32_t ec_seq; int* d_ec_claim; float* d_Phit; float* d_Vhit;
   size_t stat_words; std::vector<long long> h_stat;   // per-workgroup statistics accumulators of k_tree (DView::stat), summed on request
   std::vector<int32_t> aborted_ids;   // games retired because their slot ran out of nodes / move records (az_selfplay_aborted)
   std::vector<void*> net_allocs;   // device copies of the packed network (replaced by az_net_set_params)

@@ -70,8 +70,31 @@ struct alignas(64) SlotRec {
 };
 static_assert(sizeof(SlotRec) == 64, "slot record");
 
+// Evaluation cache (round 5): oracle answers by state, shared by all slots of the engine.  The reference evaluates every query on its
+// own (src/simulations.jl:23-38, src/networks/network.jl:308-315); a test-mode evaluation is a pure function of the state and every
+// tower form gives the same bits (tests/test_net.py), so an answer that was computed once -- for another slot, in an earlier wave --
+// IS the answer: the records of a phase do not change (tests/test_eval_cache_gpu.py), the network evaluates each state once while
+// the entry lives.  Direct-mapped, 64-byte entries, RAW oracle output (prior_temperature is applied by the slot that stores the node).
+//   meta = seq << 2 | state:  0 empty;  EC_PENDING claimed by the slot that sent the state to the network (launch seq of the claim);
+//          EC_FILLING its answer is being written (exclusive: taken by CAS);  EC_READY answered.  seq makes every value of meta
+//          unique per claim.
+//   cs   = checksum over key, P, V and the READY value of meta: a reader takes ONE look at the entry (all of it in one round of
+//          loads) and believes it only if the state is READY, the key is its own and the checksum holds, so a look that straddles
+//          an eviction + refill -- a mixture of two claims' words -- is refused (2^-32 per such look; they need a concurrent
+//          writer of the same entry inside the ~1 us of the look to exist at all).  Writers own the entry (FILLING) while they write,
+//          and wait for their stores (s_waitcnt) before the READY that publishes them.
+// All accesses are agent-scope relaxed atomics (cache-bypassing loads, write-through stores): workgroups on other XCDs fill and
+// evict concurrently in the same launch -- the idiom of k_tower16s' exchange.
+struct alignas(64) ECEnt { unsigned long long ka, kb; float P[AZ_MAX_ACTIONS]; float V; uint32_t cs; uint32_t meta; };
+static_assert(sizeof(ECEnt) == 64, "evaluation cache entry");
+enum { EC_EMPTY = 0, EC_PENDING = 1, EC_READY = 2, EC_FILLING = 3, EC_STALE_AFTER = 64 };
+
 struct DView {
   int G, cap_nodes, ht_size, max_depth, max_moves;
+  ECEnt* ec;              // evaluation cache [ec_mask + 1] or NULL (off)
+  uint32_t ec_mask, ec_seq;   // ec_seq: number of this k_tree launch (any slot group of the engine), > 0
+  int* ec_claim;          // [G][2] cache entry the slot's pending leaf claimed (its answer goes there when the leaf is expanded; -1 = none) and the meta value of the claim
+  float* Phit; float* Vhit; // [G][APAD], [G]: the answer of a leaf the cache answered, by SLOT (written by the slot's phase B, read by its next phase A; SlotRec::eidx = -1 says so)
   uint32_t tag_mask;      // 0xffff; tests narrow it (AZHIP_HT_TAG_BITS) so that unequal states share tags and every probe chain reaches the exact key compare
   uint32_t epoch0;        // first live epoch of a slot's table: 1; tests start near the 16-bit wrap (AZHIP_HT_EPOCH0)
   SlotRec* sr;            // [G] the search state of a slot that k_tree reads and writes every wave, ONE 64-byte record (round 4)
@@ -191,6 +214,39 @@ template <int L> __device__ __forceinline__ int group_argmax(double s, int lane,
 }
 template <int L> __device__ __forceinline__ int group_argmax(double s, int lane) { int c = 0; return group_argmax<L>(s, lane, &c); }
 
+// ---- evaluation cache helpers ----------------------------------------------------------------
+template <int L> __device__ __forceinline__ uint32_t group_xor(uint32_t x) {
+  x ^= (uint32_t)dpp_partner<0>((int)x);
+  x ^= (uint32_t)dpp_partner<1>((int)x);
+  x ^= (uint32_t)dpp_partner<2>((int)x);
+  if constexpr (L == 16) x ^= (uint32_t)dpp_partner<3>((int)x);
+  return x;
+}
+// value of the group's lane 0 in every lane (DPP adds of one non-zero term: no LDS round trip)
+template <int L> __device__ __forceinline__ int group_bcast0(int x, int lane) { return group_sum<L>(lane == 0 ? x : 0); }
+__device__ __forceinline__ uint32_t ec_ld32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ec_ld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ec_ldf(const float* p) { return __uint_as_float(__hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void ec_st32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ec_st64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ec_stf(float* p, float v) { __hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool ec_cas(uint32_t* p, uint32_t expect, uint32_t want) {
+  return __hip_atomic_compare_exchange_strong(p, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ec_term(float p, int lane) {    // a lane's share of the checksum: its prior's bits, rotated by its action
+  const uint32_t b = __float_as_uint(p), r = (uint32_t)(5 * lane + 1) & 31u;
+  return (b << r) | (b >> ((32u - r) & 31u));
+}
+__device__ __forceinline__ uint32_t ec_checksum(uint32_t px, unsigned long long ka, unsigned long long kb, float V, uint32_t ready_meta) {
+  unsigned long long h = az_hash_key(ka, kb);
+  h = az_mix64(h ^ (((unsigned long long)px << 32) | (unsigned long long)__float_as_uint(V)));
+  h = az_mix64(h + (unsigned long long)ready_meta);
+  return (uint32_t)(h >> 32) ^ (uint32_t)h;
+}
+__device__ __forceinline__ uint32_t ec_index(unsigned long long ka, unsigned long long kb, uint32_t mask) {
+  return (uint32_t)(az_hash_key(ka, kb) >> 17) & mask;              // other bits than the slot table's position (low) -- and than its tag where the mask allows
+}
+
 // ---- Dict lookup: haskey(env.tree, state) (src/mcts.jl:165-174) ---------------------------
 // Returns the node index or -1; *ins receives the table position a new entry would take.
 template <class Gm>
@@ -269,7 +325,7 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
   __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
   constexpr int L = Gm::APAD;
   using NL = NodeL<Gm>;
-  __shared__ int s_new[4], s_sims[4], s_trav[4], s_base;   // (workgroups of 1024 threads -- a quarter of the returning atomics -- gain 10 % at 64 k slots and lose 30 % at 256 k and 1 M)
+  __shared__ int s_new[4], s_hit[4], s_sims[4], s_trav[4], s_base;   // (workgroups of 1024 threads -- a quarter of the returning atomics -- gain 10 % at 64 k slots and lose 30 % at 256 k and 1 M)
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int slot = tid / L, lane = tid % L;
   const int wl = threadIdx.x & 63, w = threadIdx.x >> 6, gbase = wl & ~(L - 1);
@@ -300,14 +356,17 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
   uint32_t epoch0 = s0.epoch, ins0 = s0.leaf_ins;
   long long trav0 = s0.tot_trav, sims0 = s0.tot_sims;
   int ridx0 = s0.root_idx, active0 = s0.active;
+  int claim0 = -1; uint32_t cmeta0 = 0;                             // the pending leaf's cache entry (its answer is stored there), if it holds one
+  if (v.ec) { const int2 c2 = ((const int2*)v.ec_claim)[pslot]; claim0 = c2.x; cmeta0 = (uint32_t)c2.y; }
   // (The compiler sinks a load into the branch that uses it, which turned this one round trip into several dependent ones; the
   // values are therefore pinned into registers right here -- one wait for all of them.)
 #define AZ_PIN(x) asm volatile("" : "+v"(x))
   AZ_PIN(kind0); AZ_PIN(depth0); AZ_PIN(e0); AZ_PIN(nc0); AZ_PIN(st0); AZ_PIN(root0.a); AZ_PIN(root0.b); AZ_PIN(root0.fin);
-  AZ_PIN(epoch0); AZ_PIN(ins0); AZ_PIN(lenv0.a); AZ_PIN(lenv0.b); AZ_PIN(lenv0.fin); AZ_PIN(trav0); AZ_PIN(sims0); AZ_PIN(ridx0); AZ_PIN(active0);
+  AZ_PIN(epoch0); AZ_PIN(ins0); AZ_PIN(claim0); AZ_PIN(cmeta0); AZ_PIN(lenv0.a); AZ_PIN(lenv0.b); AZ_PIN(lenv0.fin); AZ_PIN(trav0); AZ_PIN(sims0); AZ_PIN(ridx0); AZ_PIN(active0);
   if (!(do_backup && live)) kind0 = LEAF_NONE;
   bool retired = false;
   int new_root = -1;
+  const bool inrecA = lane < Gm::A;
 
   // ------------------------------------------------------------------ phase A: expand + backup
   if (do_backup && live) {
@@ -319,6 +378,24 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
       if (kind == LEAF_NEW) {
         const int e = e0;
         const int idx = nc0;
+        if (v.ec && claim0 >= 0) {
+          // this leaf went to the network and holds a cache entry: the answer goes in, for whoever reaches the state next.  The
+          // entry is still this claim's iff meta is unchanged (unique per claim) -- taken exclusively, written, published.
+          ECEnt* const ent = v.ec + claim0;
+          const float Praw = inrecA ? v.Pout[(size_t)e * L + lane] : 0.f;
+          const float Vraw = v.Vout[e];
+          const uint32_t fill = (cmeta0 & ~3u) | EC_FILLING, ready = (cmeta0 & ~3u) | EC_READY;
+          int got = 0;
+          if (lane == 0) got = ec_cas(&ent->meta, cmeta0, fill) ? 1 : 0;
+          got = group_bcast0<L>(got, lane);
+          const uint32_t px = group_xor<L>(inrecA ? ec_term(Praw, lane) : 0u);
+          if (got) {
+            if (inrecA) ec_stf(&ent->P[lane], Praw);
+            if (lane == 0) { ec_stf(&ent->V, Vraw); ec_st32(&ent->cs, ec_checksum(px, lenv0.a, lenv0.b, Vraw, ready)); }
+            __builtin_amdgcn_s_waitcnt(0);                           // every lane's stores have been performed ...
+            if (lane == 0) ec_st32(&ent->meta, ready);              // ... before the value that lets readers in
+          }
+        }
         if (idx >= (v.slot_cap ? v.slot_cap[slot] : v.cap_nodes)) {
           // the slot's pool is exhausted (the reference has no such limit, src/mcts.jl:124-151): self-play retires the slot --
           // its game is reported as aborted and the phase goes on; the hooks report a capacity error
@@ -328,8 +405,9 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
         } else {
           const GEnv env = lenv0;
           const uint32_t m = Gm::mask(env);
-          float Pf = v.Pout[(size_t)e * L + lane];
-          const float V = v.Vout[e];
+          // the oracle's answer: from the network's batch, or (eidx = -1) from the evaluation cache -- the same bits either way
+          float Pf = e >= 0 ? v.Pout[(size_t)e * L + lane] : v.Phit[(size_t)slot * L + lane];
+          const float V = e >= 0 ? v.Vout[e] : v.Vhit[slot];
           if (p.prior_temp != 1.0) {                                // Util.apply_temperature, util.jl:98-110
             const bool av = (m >> lane) & 1;
             double res;
@@ -404,6 +482,8 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
 
   // ------------------------------------------------------------------ phase B: select
   int depth = 0, kind = LEAF_NONE;
+  bool ishit = false;                                               // the leaf's answer came from the evaluation cache (group-uniform)
+  int claim = -1; uint32_t cmeta = 0;
   if (live && active0 && !retired) {
     GEnv env = root0;
     const uint32_t epoch = epoch0;
@@ -480,29 +560,56 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
       v.leaf_env[slot] = env;
       sr->leaf_ins = ins;
     }
+    if (v.ec && kind == LEAF_NEW) {
+      // oracle(state): has the engine evaluated this state before (for another slot, in an earlier wave)?  One look at the entry.
+      const uint32_t ci = ec_index(env.a, env.b, v.ec_mask);
+      ECEnt* const ent = v.ec + ci;
+      const uint32_t m1 = ec_ld32(&ent->meta);
+      const unsigned long long ka = ec_ld64(&ent->ka), kb = ec_ld64(&ent->kb);
+      const float pl = inrec ? ec_ldf(&ent->P[lane]) : 0.f;
+      const float vv = ec_ldf(&ent->V);
+      const uint32_t cs = ec_ld32(&ent->cs);
+      const uint32_t px = group_xor<L>(inrec ? ec_term(pl, lane) : 0u);
+      const bool ok = (m1 & 3u) == EC_READY && ka == env.a && kb == env.b && cs == ec_checksum(px, ka, kb, vv, m1);
+      ishit = group_bcast0<L>(ok ? 1 : 0, lane) != 0;               // lane 0's verdict (its checksum covers every lane's prior)
+      if (ishit) {
+        // no network for this leaf: the answer waits where the slot's next phase A looks when eidx = -1
+        v.Phit[(size_t)slot * L + lane] = inrec ? pl : 0.f;
+        if (lane == 0) { v.Vhit[slot] = vv; sr->eidx = -1; }
+      } else if (lane == 0) {
+        // the state goes to the network; its answer goes into the cache if the entry can be taken: empty, answered (the older
+        // answer makes room), or a claim so old that its slot has gone away (a phase that ended, a retired slot)
+        const uint32_t age = v.ec_seq - (m1 >> 2);
+        if (m1 == 0u || (m1 & 3u) == EC_READY || age > (uint32_t)EC_STALE_AFTER) {
+          const uint32_t mine = (v.ec_seq << 2) | EC_PENDING;
+          if (ec_cas(&ent->meta, m1, mine)) { ec_st64(&ent->ka, env.a); ec_st64(&ent->kb, env.b); claim = (int)ci; cmeta = mine; }
+        }
+      }
+    }
   }
   if (live && lane == 0) sr->leaf_kd = kind | (depth << 2);
   if (dbg) dbg[4] = __builtin_readcyclecounter();
 
   // ------------------------------------------------------------------ evaluation batch + statistics of the wave
   const bool head = live && lane == 0;
-  const bool isnew = head && kind == LEAF_NEW;
-  const unsigned long long bal = __ballot(isnew);
+  const bool isnew = head && kind == LEAF_NEW && !ishit;            // goes to the network
+  const bool hith = head && ishit;                                   // answered by the cache
+  const unsigned long long bal = __ballot(isnew), balh = __ballot(hith);
   int sims = (head && kind != LEAF_NONE) ? 1 : 0, trav = (head && kind != LEAF_NONE) ? depth : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { sims += __shfl_down(sims, o); trav += __shfl_down(trav, o); }
-  if (wl == 0) { s_new[w] = __popcll(bal); s_sims[w] = sims; s_trav[w] = trav; }
+  if (wl == 0) { s_new[w] = __popcll(bal); s_hit[w] = __popcll(balh); s_sims[w] = sims; s_trav[w] = trav; }
   __syncthreads();
   if (threadIdx.x == 0) {
     const int nw = blockDim.x >> 6;
-    int tot = 0, ts = 0, tt = 0;
-    for (int i = 0; i < nw; ++i) { tot += s_new[i]; ts += s_sims[i]; tt += s_trav[i]; }
+    int tot = 0, toth = 0, ts = 0, tt = 0;
+    for (int i = 0; i < nw; ++i) { tot += s_new[i]; toth += s_hit[i]; ts += s_sims[i]; tt += s_trav[i]; }
     s_base = tot ? atomicAdd(v.n_eval + par, tot) : 0;
     if (ts) {                                                       // statistics: simulations (mcts.jl:242), traversed nodes (:222), oracle calls
       // per-workgroup accumulators, summed by the host when somebody asks: three same-address atomics per workgroup and wave
       // were what bounded the kernel at 1 M slots (32 768 workgroups)
       long long* sp = v.stat + (size_t)blockIdx.x * 4;
-      sp[0] += ts; sp[1] += tt; sp[2] += tot;
+      sp[0] += ts; sp[1] += tt; sp[2] += tot + toth; sp[3] += toth;
     }
     if (blockIdx.x == 0) v.n_eval[par ^ 1] = 0;                     // the next wave's counter
   }
@@ -515,6 +622,7 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
     sr->eidx = e;
     v.eval_slots[e] = slot;
   }
+  if (v.ec && head && kind == LEAF_NEW) ((int2*)v.ec_claim)[slot] = make_int2(claim, (int)cmeta);
   if (dbg) dbg[6] = __builtin_readcyclecounter();
 }
 

@@ -131,12 +131,14 @@ def steady_block(azhip, dev_index, label, game, slots, groups, sims, hp, waves, 
 def block_report(label, game, hp, bf16, kernel, prof, s0, s1, dt, waves, slots, groups, sims, note, dev_bytes):
     sims_n, evals, trav, moves = (s1.simulations - s0.simulations, s1.leaf_evals - s0.leaf_evals,
                                   s1.nodes_traversed - s0.nodes_traversed, s1.moves - s0.moves)
+    net_evals = evals - (s1.evals_reused - s0.evals_reused)         # boards the network evaluated: the rest came from the evaluation cache
     out = {"workload": "%s self-play, %d sims/move, %d parallel games, ResNet %dx%d %s, %d slot group(s)%s"
                        % (GAME_DIMS[game][0], sims, slots, hp.num_blocks, hp.num_filters, "bf16 tower (opt-in, NOT the reference's fp32 precision)" if bf16 else "fp32", groups, "; " + note if note else ""),
            "value": sims_n / dt, "unit": "sims/s", "steps": waves, "ms_per_step": 1e3 * dt / max(waves, 1), "dtype": "bf16" if bf16 else "f32",
            "samples_per_sec": moves / dt, "avg_exploration_depth": trav / max(sims_n, 1), "leaf_evals_per_sim": evals / max(sims_n, 1),
+           "unique_leaf_frac": net_evals / max(evals, 1),
            "engine_device_GB": dev_bytes / 2.0**30,
-           "roofline": tower_roofline(game, hp, bf16, kernel, prof["tower"], evals, dt)}
+           "roofline": tower_roofline(game, hp, bf16, kernel, prof["tower"], net_evals, dt)}
     return out
 
 
@@ -433,7 +435,7 @@ def alone_and_tree(args, blob, hp, dev_index, kernel, waves=200):
     eng.selfplay_end()
     eng.close()
     evals, sims, trav = s1.leaf_evals - s0.leaf_evals, s1.simulations - s0.simulations, s1.nodes_traversed - s0.nodes_traversed
-    alone = tower_roofline(azhip.GAME_CONNECT_FOUR, hp, False, name, prof["tower"], evals, 1e9)
+    alone = tower_roofline(azhip.GAME_CONNECT_FOUR, hp, False, name, prof["tower"], evals - (s1.evals_reused - s0.evals_reused), 1e9)
     alone.update(slot_groups=1, waves=waves)
     tree_cls = [c for c in ("select", "compact", "expand") if prof[c]["launches"]]
     tree_ms = sum(prof[c]["ms"] for c in tree_cls)
@@ -602,7 +604,8 @@ def main():
     evals = s1.leaf_evals - s0.leaf_evals
     trav = s1.nodes_traversed - s0.nodes_traversed
     moves = s1.moves - s0.moves
-    local_evals = evals
+    reused = s1.evals_reused - s0.evals_reused
+    local_evals = evals - reused                                     # boards this rank's network evaluated (the rest came from the evaluation cache)
     local_elapsed = elapsed
     per_rank = [sims / elapsed]
     if dist is not None:
@@ -612,9 +615,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([sims, evals, trav, moves], dtype=torch.float64, device=red_dev)
+        c = torch.tensor([sims, evals, trav, moves, reused], dtype=torch.float64, device=red_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        sims, evals, trav, moves = [float(x) for x in c.tolist()]
+        sims, evals, trav, moves, reused = [float(x) for x in c.tolist()]
     eng.selfplay_end()
     eng.close()                        # frees its ~10 GB before the extra legs build their own engine
 
@@ -655,6 +658,9 @@ def main():
             "samples_per_sec": moves / elapsed,
             "avg_exploration_depth": trav / max(sims, 1),
             "leaf_evals_per_sim": evals / max(sims, 1),
+            # oracle calls the network evaluated / oracle calls: the others were answered by the engine's evaluation cache (the same
+            # state evaluated before for another slot or in an earlier wave; bit-identical answers, tests/test_eval_cache_gpu.py)
+            "unique_leaf_frac": (evals - reused) / max(evals, 1),
         }
         if prof is not None:
             out["roofline"] = tower_roofline(azhip.GAME_CONNECT_FOUR, hp, False, eng_kernel, prof["tower"], local_evals, local_elapsed)
