@@ -18,7 +18,7 @@ def _records(games, moves, ng):
                               for k in range(games[i].num_moves)] for i in range(ng)}
 
 
-def _phase(monkeypatch, fail_at, workers, batch, ngames=6, nsims=24):
+def _phase(monkeypatch, fail_at, workers, batch, ngames=6, nsims=24, cache=False):
     import azhip
     from azhip.network import ResNetHP, random_params
     hp = ResNetHP(num_blocks=2, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32)
@@ -27,6 +27,9 @@ def _phase(monkeypatch, fail_at, workers, batch, ngames=6, nsims=24):
         monkeypatch.setenv("AZHIP_XCH_FAIL_AT", str(fail_at))
     else:
         monkeypatch.delenv("AZHIP_XCH_FAIL_AT", raising=False)
+    # the injected fault is "the n-th split launch loses a workgroup": it is only FELT when that workgroup's board exists, i.e. when
+    # the launch is full -- so every leaf must go to the network here (round 5: the evaluation cache would answer some of them)
+    monkeypatch.setenv("AZHIP_EVAL_CACHE", "1" if cache else "0")
     with azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, num_workers=workers, batch_size=batch, num_iters_per_turn=nsims,
                       cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=((0,), (1.0,)), reset_every=1, seed=3,
                       num_blocks=2, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32) as e:
@@ -47,6 +50,16 @@ def test_a_lost_partner_costs_two_seconds_not_the_phase(monkeypatch, workers, ba
     rg, rm, _ = R.simulate(R.C4, R.ORACLE_NET, 6, workers, 24, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0, temp_xs=(0,), temp_ys=(1.0,),
                            reset_every=1, seed=3, net=(2, 128, 32, 32, blob))
     assert clean == _records(rg, rm, 6)
+
+
+def test_a_lost_partner_with_the_evaluation_cache_on(monkeypatch):
+    """the same with the cache answering part of every wave: whether the lost workgroup's board exists is then up to the wave, so
+    the fall-back may or may not engage -- the records must be the undisturbed run's either way (recover_split evaluates the
+    pending network leaves again; leaves the cache answered keep their answers)"""
+    clean, st0, _, _ = _phase(monkeypatch, 0, 6, 3, cache=False)
+    for fail_at in (3, 14, 40):
+        hurt, st1, _, _ = _phase(monkeypatch, fail_at, 6, 3, cache=True)
+        assert hurt == clean and st1.simulations == st0.simulations and st1.leaf_evals == st0.leaf_evals and st1.tower_fallbacks in (0, 1)
 
 
 def test_the_network_seam_retries_without_the_split(monkeypatch):
