@@ -115,6 +115,10 @@ extern "C" int az_engine_destroy(az_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   split_register(e, 0);
   if (e->h_xflag) (void)hipHostFree(e->h_xflag);
+  if (e->h_nleaf) (void)hipHostFree(e->h_nleaf);
+  if (e->h_env) (void)hipHostFree(e->h_env);
+  if (e->h_n) (void)hipHostFree(e->h_n);
+  if (e->h_pv) (void)hipHostFree(e->h_pv);
   drop_wave_graphs(e);
   for (auto& r : e->prof_pool) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); }
   for (void* q : e->net_allocs) (void)hipFree(q);
@@ -226,6 +230,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0; e->alloc_bytes = 0;
   e->vm_base = nullptr; e->vm_bytes = 0; e->vm_chunk = 0; e->vm_rows = 0; e->vm_chunk_nodes = 0; e->d_slot_cap = nullptr; e->vm_budget = 0; e->vm_mapped = 0;
   e->next_exec = 1.0;
+  e->h_env = nullptr; e->h_n = nullptr; e->h_pv = nullptr; e->h_nleaf = nullptr; e->d_nleaf = nullptr;
   e->d_ec = nullptr; e->ec_mask = 0; e->ec_seq = 0; e->d_ec_claim = nullptr; e->d_Phit = nullptr; e->d_Vhit = nullptr;
   e->h_xflag = nullptr; e->d_xflag = nullptr; e->split_off = false; e->split_registered = 0; e->xch_launches = 0;
   { const char* fa = getenv("AZHIP_XCH_FAIL_AT"); e->xch_fail_at = fa ? atoll(fa) : 0; }
@@ -345,6 +350,9 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     HIPCHK(hipHostMalloc((void**)&e->h_xflag, sizeof(int), hipHostMallocMapped));
     *e->h_xflag = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&e->d_xflag, e->h_xflag, 0));
+    HIPCHK(hipHostMalloc((void**)&e->h_nleaf, sizeof(int) * AZ_MAX_GROUPS, hipHostMallocMapped));
+    for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->h_nleaf[g] = -1;      // nothing reported yet: launches are priced at their upper bound
+    HIPCHK(hipHostGetDevicePointer((void**)&e->d_nleaf, e->h_nleaf, 0));
 
     // staging
     e->io_cap = std::max(G, 4096);
@@ -361,6 +369,9 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &e->d_X, (size_t)e->nn_cap * gi.C * gi.P)); AZCHK(dalloc(e, &e->d_A, (size_t)e->nn_cap * gi.A));
     AZCHK(dalloc(e, &e->d_P, (size_t)e->nn_cap * std::max(16, gi.APAD))); AZCHK(dalloc(e, &e->d_V, e->nn_cap)); AZCHK(dalloc(e, &e->d_Pinv, e->nn_cap));
     AZCHK(dalloc(e, &e->d_tmp_env, e->nn_cap)); AZCHK(dalloc(e, &e->d_iota, e->nn_cap)); AZCHK(dalloc(e, &e->d_ntmp, 1));
+    HIPCHK(hipHostMalloc((void**)&e->h_env, sizeof(GEnv) * (size_t)e->nn_cap, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&e->h_n, sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&e->h_pv, sizeof(float) * (size_t)e->nn_cap * (gi.A + 1), hipHostMallocDefault));
     hipLaunchKernelGGL(k_iota, dim3((e->nn_cap + 255) / 256), dim3(256), 0, e->stream, e->d_iota, e->nn_cap);
     memset(&e->net, 0, sizeof e->net);
     memset(&e->net16, 0, sizeof e->net16);
@@ -393,6 +404,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       gv.leaf_env += o; gv.eval_slots += o;
       if (gv.ec) { gv.ec_claim += 2 * o; gv.Phit += o * gi.APAD; gv.Vhit += o; }
       gv.xerr = e->d_xerr + g; gv.skipped = e->d_skipped + 2 * g;
+      gv.nleaf_host = e->d_ec ? e->d_nleaf + g : nullptr;            // only the evaluation cache makes a wave's network batch differ from its active slots
       gv.n_eval += 2 * g; gv.keys += o * (size_t)cap * 4; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;
       if (ng == 1) { e->gs[g] = e->gt[g] = e->stream; }
@@ -844,18 +856,21 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
   if (!e->net_loaded) return fail(AZ_ERR_STATE, "az_net_set_params has not been called");
   if (N < 0 || (N > 0 && (!keys || !P || !V))) return fail(AZ_ERR_BAD_ARG, "NULL buffer");
   const GameInfo& gi = e->gi;
-  std::vector<GEnv> envs;
   for (int off = 0; off < N; off += e->nn_cap) {
-    int m = std::min(e->nn_cap, N - off);
-    envs.resize(m);
+    const int m = std::min(e->nn_cap, N - off);
+    GEnv* envs = e->h_env;                                          // pinned: the copies below are real asynchronous DMA
     DISPATCH_GAME(e->cfg.game, { for (int i = 0; i < m; ++i) envs[i] = Gm::from_key(keys[2 * (size_t)(off + i)], keys[2 * (size_t)(off + i) + 1]); });
-    HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs.data(), sizeof(GEnv) * m, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d_ntmp, &m, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    *e->h_n = m;
+    float* hP = e->h_pv; float* hV = e->h_pv + (size_t)gi.A * e->nn_cap;
+    HIPCHK(hipMemcpyAsync(e->d_tmp_env, envs, sizeof(GEnv) * m, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_ntmp, e->h_n, sizeof(int), hipMemcpyHostToDevice, e->stream));
     AZCHK(net_launch(e, e->stream, false, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A));
     if (split_gave_up(e)) AZCHK(net_launch(e, e->stream, false, e->d_hfeat, e->d_tmp_env, e->d_iota, e->d_ntmp, m, nullptr, nullptr, e->d_P, e->d_V, nullptr, gi.A));
-    HIPCHK(hipMemcpyAsync(P + (size_t)gi.A * off, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(V + off, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(hP, e->d_P, sizeof(float) * gi.A * m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(hV, e->d_V, sizeof(float) * m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    memcpy(P + (size_t)gi.A * off, hP, sizeof(float) * gi.A * m);
+    memcpy(V + off, hV, sizeof(float) * m);
   }
   HIPCHK(hipGetLastError());
   if (e->xch_epoch) AZCHK(check_device_error(e));                  // k_tower16s: a bounded wait can give up (DERR_EXCHANGE)

@@ -80,6 +80,7 @@ struct az_engine {
   unsigned long long* xch[AZ_MAX_GROUPS + 1]; unsigned long long xch_epoch;
   // (r4) a split tower whose exchange gives up degrades instead of failing the phase (azhip.hip recover_split)
   int* d_xerr; int* d_skipped;   // [AZ_MAX_GROUPS + 1] exchange words, [..][2] counters of idle k_tree launches (DView::xerr / skipped)
+  int* h_nleaf; int* d_nleaf;    // [AZ_MAX_GROUPS] host-mapped: network batch of each group's previous wave (k_tree writes, pick_tower's estimate reads)
   int* h_xflag; int* d_xflag;    // host-mapped word the kernel sets when an exchange gives up; looked at before every launch
   bool split_off;                // the split is disabled for this engine after the first time
   long long xch_fail_at, xch_launches;   // AZHIP_XCH_FAIL_AT = n: the n-th split launch loses a partner (fault injection for the tests)
@@ -113,6 +114,8 @@ struct az_engine {
   int nn_cap;
   float* d_hfeat; float* d_X; float* d_A; float* d_P; float* d_V; float* d_Pinv;
   GEnv* d_tmp_env; int* d_iota; int* d_ntmp;
+  // pinned staging of the key-based network seam (az_net_evaluate_keys): states + count in, P / V out -- pageable copies were most of a call
+  GEnv* h_env; int* h_n; float* h_pv;
   // staging
   int* d_slots; uint32_t* d_gids; GEnv* d_roots; uint32_t* d_moves; double* d_eta; int* d_offsets;
   az_move_rec* d_stage; unsigned long long* d_keys; int* d_actions; unsigned long long* d_next; signed char* d_term; float* d_reward;

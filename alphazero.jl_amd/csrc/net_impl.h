@@ -90,14 +90,17 @@ static void note_tower(az_engine* e, int tw, int F) {
 // k_tower 128 (3 boards, every tap), k_tower16 with 3 row tiles 48 (1 board; +10 %: a third of the weight reuse, more
 // barriers per row).  Measured round 2 (tools/run_config.py): Mancala 8192 slots 13.5 M sims/s on k_tower, 21.5 M on
 // k_tower16 (31 of 99 products); 5x128 two groups 1.10 vs 1.20 M.  Returns 16, 21, 32 or 3.
-template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
+// n = boards the launch is expected to hold (what the forms are priced with), nb >= n = the most it can hold (what the split
+// tower's co-residency needs; the grid is sized for nb in any case and workgroups beyond the device's count leave at once).
+template <class Gm, int F> static int pick_tower(const az_engine* e, int n, int nb = -1) {
+  if (nb < n) nb = n;
   // split tower (k_tower16s, 128 filters): both workgroups of every pair must be resident at once -> all slot groups'
   // launches together at most num_cu workgroups (beyond that the towers queue for CUs and the split only costs: 256
   // slots in two groups 0.62 vs 0.71 M sims/s); its kernel arguments change per launch (epoch): not under hipGraph replay
   // (r4) the count runs over ALL engines of the process on this device that may launch split towers side by side (an arena has
   // two); an engine whose exchange has given up once (another process, a trainer: work this count cannot see) stays unsplit
   const bool can_split = F == 128 && !e->cfg.net_bf16 && !e->use_graphs && e->cfg.num_blocks <= 127 && !e->split_off &&
-                         2 * std::max(std::max(1, e->ngroups), split_streams_on_device(e->device)) * ((n + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB) <= (e->num_cu > 0 ? e->num_cu : 256);
+                         2 * std::max(std::max(1, e->ngroups), split_streams_on_device(e->device)) * ((nb + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB) <= (e->num_cu > 0 ? e->num_cu : 256);
   if (e->tower_pick == 2 && can_split) return 2;
   if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64) || (e->tower_pick == 7 && NTM<Gm> > 0))) return e->tower_pick;
   if (e->cfg.net_bf16) {                                           // k_tower16b: 22 (128 filters), 11 or 3 row tiles
@@ -136,7 +139,9 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n) {
     using TM = T16<Gm, F, NTM<Gm>>;
     constexpr double fm = TM::Geo::tab.cost / (9.0 * NTM<Gm>);
     const long bm = (n + TM::TB - 1) / TM::TB;
-    const double cm = 1.03 * (double)((bm + cu - 1) / cu) * TM::RPAD * fm;     // +3 %: fewer rows per weight fragment
+    // +3 %: fewer rows per weight fragment; the half-size form at 128 filters +20 %: half the rows per weight fragment there (the
+    // vector-memory path that streams the weights is what a 128-filter layer waits for: DESIGN.md 4d, the trainer's 6-tile layer)
+    const double cm = (Gm::P == 42 && F == 128 ? 1.2 : 1.03) * (double)((bm + cu - 1) / cu) * TM::RPAD * fm;
     if (cm < c16 && cm < c32 && (F != 64 || cm < (double)(((n + T16P<Gm, 64>::TB - 1) / T16P<Gm, 64>::TB + cu - 1) / cu) * T16P<Gm, 64>::RPAD * f21)) return 7;
   }
   // paired k_tower16x2: 336 rows = 8 Connect-Four boards per workgroup, no padding rows.  Its 92 KB of LDS allow one
@@ -275,7 +280,11 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   // -- and picks its tower kernel -- for what is left, not for the group's capacity)
   const int N = std::max(1, std::min(G, nmax));
   const int* nev = v.n_eval + e->wave_par[g];                      // the leaf counter of this wave (k_tree)
-  const int tw = pick_tower<Gm, F>(e, N);
+  // how many boards the launch will really hold: with the evaluation cache answering part of every wave, what the device
+  // reported for the group's last completed wave (+ 1/8: a launch priced too small costs more than one priced too large)
+  int npick = N;
+  if (v.nleaf_host) { const int seen = ((volatile int*)e->h_nleaf)[g]; if (seen >= 0) npick = std::max(1, std::min(N, seen + seen / 8 + 8)); }
+  const int tw = pick_tower<Gm, F>(e, npick, N);
   note_tower(e, tw, F);
   e->next_exec = tower_exec_frac<Gm, F>(e, tw);
   if (e->cfg.net_bf16) {

@@ -416,7 +416,11 @@ template <class Gm> constexpr int NTS = Gm::P <= 48 ? 3 : (Gm::P + 15) / 16;
 // padding rows and, for the slot counts of the BASELINE configurations, a whole number of workgroups per CU: Mancala 7 tiles =
 // 112 rows = 8 boards (8192 slots = 1024 workgroups = 4 per CU; the 11-tile form: 12 boards of 176 rows, 683 workgroups = 2.67
 // per CU), Tic-tac-toe 9 tiles = 16 boards.  0 = the game has none (Connect-Four's is the paired 21-tile kernel).
-template <class Gm> constexpr int ntm_of() { for (int nt = 4; nt <= 10; ++nt) if ((16 * nt) % Gm::P == 0) return nt; return 0; }
+// (r5) A game without one (Connect-Four: 42 positions) gets the HALF-SIZE form instead -- 6 tiles = 96 rows = 2 boards + 12 padding
+// rows: since the evaluation cache answers part of every wave, a launch holds 1000 ... 1600 boards instead of 2048 / 4096, and what
+// a launch costs is set by the CU with the most boards: with 4-board workgroups that is 8 boards wherever 256 CUs share more than
+// 1024, with 2-board workgroups 6 (pick_tower prices both with the launch size the device reported for the last waves).
+template <class Gm> constexpr int ntm_of() { for (int nt = 4; nt <= 10; ++nt) if ((16 * nt) % Gm::P == 0) return nt; return Gm::P == 42 ? 6 : 0; }
 template <class Gm> constexpr int NTM = ntm_of<Gm>();
 
 // What a workgroup does after it has written a layer's outputs (its own channels) into the activation buffer.

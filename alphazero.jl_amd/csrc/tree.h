@@ -94,6 +94,7 @@ struct DView {
   ECEnt* ec;              // evaluation cache [ec_mask + 1] or NULL (off)
   uint32_t ec_mask, ec_seq;   // ec_seq: number of this k_tree launch (any slot group of the engine), > 0
   int* ec_claim;          // [G][2] cache entry the slot's pending leaf claimed (its answer goes there when the leaf is expanded; -1 = none) and the meta value of the claim
+  int* nleaf_host;        // host-mapped word: the network batch of this group's previous wave (pick_tower's launch-size estimate), or NULL
   float* Phit; float* Vhit; // [G][APAD], [G]: the answer of a leaf the cache answered, by SLOT (written by the slot's phase B, read by its next phase A; SlotRec::eidx = -1 says so)
   uint32_t tag_mask;      // 0xffff; tests narrow it (AZHIP_HT_TAG_BITS) so that unequal states share tags and every probe chain reaches the exact key compare
   uint32_t epoch0;        // first live epoch of a slot's table: 1; tests start near the 16-bit wrap (AZHIP_HT_EPOCH0)
@@ -611,7 +612,12 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
       long long* sp = v.stat + (size_t)blockIdx.x * 4;
       sp[0] += ts; sp[1] += tt; sp[2] += tot + toth; sp[3] += toth;
     }
-    if (blockIdx.x == 0) v.n_eval[par ^ 1] = 0;                     // the next wave's counter
+    if (blockIdx.x == 0) {
+      // the previous wave's network batch goes to the host (a mapped word it looks at without synchronising: the size of the
+      // launches to come decides which tower form serves them), then its counter becomes the next wave's
+      if (v.nleaf_host && do_select) __hip_atomic_store(v.nleaf_host, v.n_eval[par ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v.n_eval[par ^ 1] = 0;
+    }
   }
   __syncthreads();
   if (dbg) dbg[5] = __builtin_readcyclecounter();

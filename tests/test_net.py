@@ -120,8 +120,8 @@ def test_hip_forward_bit_exact_vs_oracle(game, nblocks, n, F, heads, tower, monk
         keys = np.array([g.key() for g in envs], dtype=np.uint64)
         Pk, Vk = e.net_evaluate_keys(keys)
         Xd, Ad = e.encode(keys)
-        if tower == "7" and game in (R.MANCALA, R.TTT):             # the exact-fit variant: 7 row tiles = 8 Mancala boards, 9 = 16 Tic-tac-toe boards
-            assert e.net_last_kernel().endswith("NT=%d>" % (7 if game == R.MANCALA else 9)), e.net_last_kernel()
+        if tower == "7":             # the exact-fit variant: 7 row tiles = 8 Mancala boards, 9 = 16 Tic-tac-toe boards; Connect-Four (r5): the half-size form, 6 tiles = 2 boards
+            assert e.net_last_kernel().endswith("NT=%d>" % {R.MANCALA: 7, R.TTT: 9, R.C4: 6}[game]), e.net_last_kernel()
     assert np.array_equal(Xd, X) and np.array_equal(Ad, A)          # vectorize_state / actions_mask twins
     Pr, Vr, Pir = R.net_forward_normalized(game, (nblocks, F, npf, nvf), blob, X, A)
     Pt, Vt, Pit = torch_forward_normalized(game, hp, blob, X, A)
