@@ -126,6 +126,7 @@ extern "C" int az_engine_destroy(az_engine* e) {
   if (e->d_phase) (void)hipFree(e->d_phase);
   for (size_t i = 0; i < e->vm_handles.size(); ++i) { (void)hipMemUnmap(e->vm_at[i], e->vm_chunk); (void)hipMemRelease(e->vm_handles[i]); }
   if (e->vm_base) (void)hipMemAddressFree(e->vm_base, e->vm_bytes);
+  if (e->vmk_base) (void)hipMemAddressFree(e->vmk_base, e->vmk_bytes);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return AZ_OK;
@@ -153,13 +154,12 @@ __global__ void k_iota(int* p, int n) {
 // a slot simply stops growing and is retired when it fills up (DParams::retire).
 static constexpr size_t VM_CHUNK = (size_t)2 << 20;
 static constexpr size_t VM_THRESHOLD = (size_t)24 << 30;
-static int vm_map(az_engine* e, int row, int slot) {
+static int vm_map_at(az_engine* e, char* at) {
   if (e->vm_mapped + VM_CHUNK > e->vm_budget) return 1;             // budget reached: not an error, the slot stops growing
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = e->device;
   hipMemGenericAllocationHandle_t h;
   if (hipMemCreate(&h, VM_CHUNK, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return 1; }
-  char* at = e->vm_base + ((size_t)row * e->v.G + slot) * VM_CHUNK;
   hipMemAccessDesc acc = {};
   acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
   if (hipMemMap(at, VM_CHUNK, 0, h, 0) != hipSuccess || hipMemSetAccess(at, VM_CHUNK, &acc, 1) != hipSuccess) {
@@ -169,6 +169,20 @@ static int vm_map(az_engine* e, int row, int slot) {
   e->vm_handles.push_back(h); e->vm_at.push_back(at);
   e->vm_mapped += VM_CHUNK;
   return AZ_OK;
+}
+// chunk (row, slot) of the node pool -- and, first, the 2 MB granule its side records lie in (round 5: the side records follow the
+// node chunks; one granule holds the pieces of VM_CHUNK / vmk_piece neighbouring (row, slot) pairs and is mapped when the first of
+// them is needed).  1 = out of budget / memory: the slot keeps what it has.
+static int vm_map(az_engine* e, int row, int slot) {
+  if (e->vmk_base) {
+    const size_t gi = ((size_t)row * e->v.G + slot) * e->vmk_piece / VM_CHUNK;
+    if (!e->vmk_granule[gi]) {
+      const int st = vm_map_at(e, e->vmk_base + gi * VM_CHUNK);
+      if (st != AZ_OK) return st;
+      e->vmk_granule[gi] = 1;
+    }
+  }
+  return vm_map_at(e, e->vm_base + ((size_t)row * e->v.G + slot) * VM_CHUNK);
 }
 // backs the chunks the slots will need before the host looks again (`ahead` nodes from now); uploads the new capacities
 static int vm_grow(az_engine* e, int ahead) {
@@ -229,6 +243,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   if (!e) return fail(AZ_ERR_HIP, "out of host memory");
   e->cfg = *c; e->gi = gi; e->device = c->device; e->stream = nullptr; e->ngroups = 0; e->alloc_bytes = 0;
   e->vm_base = nullptr; e->vm_bytes = 0; e->vm_chunk = 0; e->vm_rows = 0; e->vm_chunk_nodes = 0; e->d_slot_cap = nullptr; e->vm_budget = 0; e->vm_mapped = 0;
+  e->vmk_base = nullptr; e->vmk_bytes = 0; e->vmk_piece = 0; e->tree_sort = 0; e->d_perm = nullptr; e->d_perm_prev = nullptr;
   e->next_exec = 1.0;
   e->h_env = nullptr; e->h_n = nullptr; e->h_pv = nullptr; e->h_nleaf = nullptr; e->d_nleaf = nullptr;
   e->d_ec = nullptr; e->ec_mask = 0; e->ec_seq = 0; e->d_ec_claim = nullptr; e->d_Phit = nullptr; e->d_Vhit = nullptr;
@@ -319,7 +334,30 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     AZCHK(dalloc(e, &v.leaf_env, G));
     AZCHK(dalloc(e, &v.eval_slots, G));
     AZCHK(dalloc(e, &v.n_eval, 2 * AZ_MAX_GROUPS));
-    AZCHK(dalloc(e, &v.keys, (size_t)G * cap * 4, false)); 
+    {
+      // side records (state key + Vest, 32 B per node).  Plain pool: dense [G][cap][4].  Mapped-on-demand pool: a second virtual
+      // range whose pieces follow the node chunks (DView::keys), so that they cost 32 B per node that EXISTS -- dense they were
+      // 26.8 GB of BASELINE configs[3]'s 57 GB engine.  AZHIP_VMM_KEYS=0 keeps the dense array beside a mapped pool.
+      const char* fk = getenv("AZHIP_VMM_KEYS");
+      const size_t piece = (size_t)e->vm_chunk_nodes * 32;
+      void* kbase = nullptr;
+      bool mapped_keys = e->vm_rows > 0 && !(fk && atoi(fk) == 0) && piece > 0 && VM_CHUNK % piece == 0;
+      size_t kbytes = 0;
+      if (mapped_keys) {
+        kbytes = ((size_t)e->vm_rows * G * piece + VM_CHUNK - 1) / VM_CHUNK * VM_CHUNK;
+        if (hipMemAddressReserve(&kbase, kbytes, VM_CHUNK, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); mapped_keys = false; }
+      }
+      if (mapped_keys) {
+        e->vmk_base = (char*)kbase; e->vmk_bytes = kbytes; e->vmk_piece = piece;
+        e->vmk_granule.assign(kbytes / VM_CHUNK, 0);
+        v.keys = (unsigned long long*)kbase;
+        v.key_row = (size_t)G * piece / 8; v.key_stride = piece / 8;
+      } else {
+        AZCHK(dalloc(e, &v.keys, (size_t)G * cap * 4, false));
+        v.key_row = 0; v.key_stride = (size_t)cap * 4;
+        if (e->vm_rows) v.key_row = (size_t)e->vm_chunk_nodes * 4;   // dense array under a mapped pool: idx = (row, offset) again, rows of a slot are contiguous
+      }
+    }
     hipLaunchKernelGGL(k_slot_records, dim3((G + 255) / 256), dim3(256), 0, e->stream, v, (int)SR_ZERO);   // epoch 1, no root, nothing else
     AZCHK(dalloc(e, &v.Pout, (size_t)std::max(G, 1) * gi.APAD)); AZCHK(dalloc(e, &v.Vout, G));
     {
@@ -380,6 +418,11 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     { const char* ep = getenv("AZHIP_XCH_EPOCH0"); e->xch_epoch = ep ? strtoull(ep, nullptr, 0) : 0; }   // tests: start k_tower16s' launch epoch near its 24-bit wrap
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); e->num_cu = pr.multiProcessorCount; }
     AZCHK(net_set_kernel_attrs(e));
+    // round-5 experiments on k_tree (off by default, measured in profiles/r5/ktree_experiments): AZHIP_TREE_ATOMIC = 1 | 2
+    // backs up with no-return atomics (DView::bk_mode), AZHIP_TREE_SORT = 1 orders the slots of a launch by depth at every move step
+    { const char* ta = getenv("AZHIP_TREE_ATOMIC"); const int m = ta ? atoi(ta) : 0; v.bk_mode = m == 1 || m == 2 ? m : 0; }
+    { const char* ts = getenv("AZHIP_TREE_SORT"); e->tree_sort = ts && atoi(ts) != 0 ? 1 : 0; }
+    if (e->tree_sort) { AZCHK(dalloc(e, &e->d_perm, (size_t)2 * G)); AZCHK(dalloc(e, &e->d_perm_prev, (size_t)2 * G)); }
     // slot groups
     int ng = c->batch_size > 0 ? G / c->batch_size : 1;
     if (ng < 1) ng = 1;
@@ -404,8 +447,12 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       gv.leaf_env += o; gv.eval_slots += o;
       if (gv.ec) { gv.ec_claim += 2 * o; gv.Phit += o * gi.APAD; gv.Vhit += o; }
       gv.xerr = e->d_xerr + g; gv.skipped = e->d_skipped + 2 * g;
+      if (e->tree_sort) {                                            // group-relative order, identity until the first move step
+        gv.perm = e->d_perm + o;
+        hipLaunchKernelGGL(k_iota, dim3((Gh + 255) / 256), dim3(256), 0, e->stream, e->d_perm + o, Gh);
+      }
       gv.nleaf_host = e->d_ec ? e->d_nleaf + g : nullptr;            // only the evaluation cache makes a wave's network batch differ from its active slots
-      gv.n_eval += 2 * g; gv.keys += o * (size_t)cap * 4; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
+      gv.n_eval += 2 * g; gv.keys += o * v.key_stride; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;
       if (ng == 1) { e->gs[g] = e->gt[g] = e->stream; }
       else {
@@ -1256,6 +1303,11 @@ template <class Gm> static int move_round(az_engine* e) {
     if (*(volatile int*)e->h_xflag) { AZCHK(recover_split<Gm>(e)); AZCHK(flush_pending<Gm>(e)); AZCHK(sync_all(e)); }
   }
   LAUNCH(e, AZ_K_MOVE, G, (k_move<Gm>), (G + 255) / 256, 256, 0, e->v, e->p);
+  if (e->tree_sort)                                                // the explore! that just ended says how deep each slot searches now
+    for (int g = 0; g < e->ngroups; ++g) {
+      const size_t o = (size_t)g * e->gv[0].G;
+      hipLaunchKernelGGL(k_depth_order, dim3(1), dim3(1024), 0, e->stream, e->gv[g], e->d_perm_prev + 2 * o, e->d_perm + o, e->d_perm + G + o);
+    }
   HIPCHK(hipMemcpyAsync(e->h_finished.data(), e->v.finished, sizeof(int) * G, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->h_grec.data(), e->v.grec, sizeof(az_game_rec) * G, hipMemcpyDeviceToHost, e->stream));
   AZCHK(check_device_error(e));   // synchronises

@@ -92,6 +92,12 @@ struct az_engine {
   char* vm_base; size_t vm_bytes, vm_chunk; int vm_rows, vm_chunk_nodes;
   std::vector<hipMemGenericAllocationHandle_t> vm_handles; std::vector<char*> vm_at;
   std::vector<int> h_slot_cap, h_node_count; int* d_slot_cap; int* d_node_count; size_t vm_budget, vm_mapped;
+  // (r5) the side records of a mapped-on-demand pool follow the node chunks: a second virtual range of rows x G pieces of
+  // vm_chunk_nodes x 32 B, backed by 2 MB granules (vmk_granule[i] = granule i is mapped); vmk_base = NULL: dense [G][cap][4] array
+  char* vmk_base; size_t vmk_bytes, vmk_piece; std::vector<uint8_t> vmk_granule;
+  // (r5 experiments) AZHIP_TREE_SORT: slot order of k_tree by the depth of the last explore! (d_perm [G] order | [G] keys,
+  // d_perm_prev [G][2] totals at the last move step); AZHIP_TREE_ATOMIC: DView::bk_mode
+  int tree_sort; int* d_perm; long long* d_perm_prev;
   // evaluation cache (tree.h ECEnt): one table per engine = per network; az_net_set_params empties it
   ECEnt* d_ec; uint32_t ec_mask; uint32_t ec_seq; int* d_ec_claim; float* d_Phit; float* d_Vhit;
   size_t stat_words; std::vector<long long> h_stat;   // per-workgroup statistics accumulators of k_tree (DView::stat), summed on request

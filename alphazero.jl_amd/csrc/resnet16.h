@@ -440,14 +440,16 @@ struct NoXch {
 // ~1270 across XCDs; sc0 or plain loads, also RMW atomics at workgroup scope, keep returning the CU's cached copy and
 // never see the partner's word, even on the same XCD -- so pairs are simply (b, b ^ 1).)
 // (Waiting on one word per wavefront before reading all twelve cost a round trip more than it saved: 172 vs 167 us.)
-// The poll is bounded IN TIME (2 s of the 100 MHz constant clock, looked at every 256 polls): a partner that never
+// The poll is bounded IN TIME (50 ms of the 100 MHz constant clock -- round 5; rounds 3-4: 2 s -- looked at every 256 polls): a partner that never
 // arrives raises DERR_EXCHANGE instead of hanging the GPU.  Workgroups of a launch are dispatched in order and a pair is
 // (b, b ^ 1), so at any moment at most ONE pair of a launch is half resident and every other resident workgroup of it
 // belongs to a complete pair, which finishes and frees its CU: a pair cannot deadlock, it can only wait for CUs that
 // other work holds (another engine's tower in an arena, a trainer, another process) -- for as long as that work runs,
-// which is why the bound is wall time (round 2 counted 2^20 polls, ~0.7 s alone but arbitrarily little under contention).
+// which is why the bound is wall time (round 2 counted 2^20 polls, ~0.7 s alone but arbitrarily little under contention).  A co-resident
+// partner answers in ~1 us and the longest kernel this library puts beside a split tower runs ~1 ms, so 50 ms is still four orders
+// of magnitude of slack; waiting longer only delays the fallback (recover_split, azhip.hip), which costs nothing but the split.
 enum { DERR_EXCHANGE = 6 };
-static constexpr unsigned long long XCH_WAIT_TICKS = 200000000ull;
+static constexpr unsigned long long XCH_WAIT_TICKS = 5000000ull;
 struct PairXch {
   static constexpr int STEM_HALVES = 2;              // the stem is cheap: both halves computed locally, one exchange less
   unsigned long long* mine;          // [2][NT * 4][THREADS]

@@ -111,7 +111,16 @@ struct DView {
   // row r of a run of slots with one mapping; slot_cap[s] = nodes of slot s that are backed by memory right now.
   int node_sh; uint32_t node_mask; size_t node_row, node_stride;
   const int* slot_cap;    // [G] or NULL (plain pool: cap_nodes for every slot)
-  unsigned long long* keys; // [G][cap][4]: state key (2 words), Vest (f32, StateInfo.Vest, src/mcts.jl:86) in word 2
+  unsigned long long* keys; // side record of node idx of slot s: state key (2 words), Vest (f32, StateInfo.Vest, src/mcts.jl:86) in word 2, at
+                            // keys + (idx >> node_sh) * key_row + s * key_stride + (idx & node_mask) * 4 (in u64 words; side_at).  Plain pool:
+                            // [G][cap][4].  Mapped-on-demand pool (round 5): the pieces follow the node chunks -- chunk row r of slot s has its
+                            // 2^node_sh side records at piece (r * G + s); the host backs the 2 MB granule a piece lies in together with the
+                            // node chunk, so the side records cost a quarter of the nodes that exist instead of a quarter of the worst case
+  size_t key_row, key_stride;
+  const int* perm;          // [G] or NULL: lane group i of k_tree serves slot perm[i] (AZHIP_TREE_SORT: slots ordered by the depth of their
+                            // last explore!, so that the 8 slots of a wavefront finish together; results are by slot, whatever the order)
+  int bk_mode;              // backup of phase A: 0 = read-modify-write by the ply's lane; 1 / 2 = no-return atomics at agent scope (AZHIP_TREE_ATOMIC,
+                            // 1: phase B waits for them and drops the CU's L1 copy, 2: only drops the copy -- an experiment, see k_tree)
   unsigned long long* path;
   GEnv* leaf_env;         // [G] state of the slot's pending leaf (read by the network kernels through eval_slots)
   int* eval_slots;        // evaluation batch -> slot
@@ -152,7 +161,9 @@ static_assert(sizeof(NodeL<ConnectFour>::Stat) == 16, "ActionStats record");
 template <class Gm> __device__ __forceinline__ char* node_at(const DView& v, int slot, int idx) {
   return v.nodes + (size_t)((uint32_t)idx >> v.node_sh) * v.node_row + (size_t)slot * v.node_stride + (size_t)((uint32_t)idx & v.node_mask) * NodeL<Gm>::BYTES;
 }
-__device__ __forceinline__ unsigned long long* side_at(const DView& v, int slot, int idx) { return v.keys + ((size_t)slot * v.cap_nodes + idx) * 4; }
+__device__ __forceinline__ unsigned long long* side_at(const DView& v, int slot, int idx) {
+  return v.keys + (size_t)((uint32_t)idx >> v.node_sh) * v.key_row + (size_t)slot * v.key_stride + (size_t)((uint32_t)idx & v.node_mask) * 4;
+}
 static constexpr int LINK_MAX = (1 << 18) - 2;
 
 __device__ inline void dev_fail(const DView& v, int code) { atomicCAS(v.err, 0, code); }
@@ -259,7 +270,6 @@ __device__ inline int ht_lookup(const DView& v, int slot, int lane, unsigned lon
   const uint32_t h0 = (uint32_t)hk & H1;
   const uint32_t tag = (uint32_t)(hk >> 40) & v.tag_mask;
   const unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
-  const unsigned long long* keys = v.keys + (size_t)slot * v.cap_nodes * 4;
   const int iters = v.ht_size / L;
   for (int i = 0; i < iters; ++i) {
     uint32_t pos = (h0 + (uint32_t)(i * L + lane)) & H1;
@@ -268,7 +278,7 @@ __device__ inline int ht_lookup(const DView& v, int slot, int lane, unsigned lon
     bool live = ((uint32_t)(e >> 48) == epoch) && idx1 != 0;
     bool match = false;
     if (live && ((uint32_t)(e >> 32) & 0xffff) == tag) {
-      const unsigned long long* k = keys + (size_t)(idx1 - 1) * 4;
+      const unsigned long long* k = side_at(v, slot, (int)(idx1 - 1));
       match = (k[0] == ka) && (k[1] == kb);
     }
     unsigned mb = group_ballot<L>(match), db = group_ballot<L>(!live);
@@ -328,9 +338,11 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
   using NL = NodeL<Gm>;
   __shared__ int s_new[4], s_hit[4], s_sims[4], s_trav[4], s_base;   // (workgroups of 1024 threads -- a quarter of the returning atomics -- gain 10 % at 64 k slots and lose 30 % at 256 k and 1 M)
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int slot = tid / L, lane = tid % L;
+  const int lgrp = tid / L, lane = tid % L;
   const int wl = threadIdx.x & 63, w = threadIdx.x >> 6, gbase = wl & ~(L - 1);
-  const bool live = slot < v.G;
+  const bool live = lgrp < v.G;
+  // which slot this lane group advances: its own index, or (AZHIP_TREE_SORT) the slot the last move step's ordering put here
+  const int slot = (live && v.perm) ? v.perm[lgrp] : lgrp;
   const int pslot = live ? slot : 0;
   unsigned long long* path = v.path + (size_t)pslot * v.max_depth;
   const bool links_ok = v.cap_nodes <= LINK_MAX;
@@ -465,8 +477,16 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
           }
           if (lane < kn) {
             typename NL::Stat* sa = NL::stat(node_at<Gm>(v, slot, (int)(uint32_t)st), (int)((st >> 32) & 0xff));
-            sa->W += qmine;                                         // update_state_info!, mcts.jl:190-194
-            sa->N += 1;
+            if (v.bk_mode) {
+              // (round 5 experiment, VERDICT r4 #6 ii) the update leaves the dependent chain: one (node, action) record gets exactly
+              // one update per slot and wave, so the sum is the same IEEE add wherever it is performed -- here by L2's atomic unit,
+              // nothing comes back.  Phase B must not read the record from this CU's L1 afterwards (see the fence below).
+              unsafeAtomicAdd(&sa->W, qmine);
+              __hip_atomic_fetch_add(&sa->N, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              sa->W += qmine;                                       // update_state_info!, mcts.jl:190-194
+              sa->N += 1;
+            }
           }
         }
         if (lane == 0) {
@@ -479,7 +499,9 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
   }
   if (!do_select) return;
   if (dbg) dbg[1] = __builtin_readcyclecounter();
-  __threadfence_block();            // phase A's stores (other lanes of the group) are ordered before phase B's loads
+  if (v.bk_mode == 0) __threadfence_block();   // phase A's stores (other lanes of the group) are ordered before phase B's loads
+  else if (v.bk_mode == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the atomics have been performed at L2; this CU's L1 copies of the path's lines (set_link read them) are dropped
+  else { __threadfence_block(); asm volatile("buffer_inv sc1" ::: "memory"); }  // experiment: stores ordered, L1 dropped, the atomics NOT waited for (same address = same L2 channel, in order)
 
   // ------------------------------------------------------------------ phase B: select
   int depth = 0, kind = LEAF_NONE;
@@ -948,6 +970,32 @@ static __global__ void __launch_bounds__(256) k_slot_records(DView v, int what) 
 static __global__ void __launch_bounds__(256) k_node_counts(DView v, int* out) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot < v.G) out[slot] = v.sr[slot].node_count;
+}
+
+// AZHIP_TREE_SORT (round 5 experiment, VERDICT r4 #6 i): the order in which k_tree's lane groups take the slots of a slot group.
+// A wavefront advances 8 slots and runs until its DEEPEST slot is done; with more wavefronts than the chip holds at once (64 k slots
+// and up) a launch costs the sum over wavefronts of their deepest slot, so slots of similar depth belong together.  Key = mean depth
+// of the slot's last explore! in half plies ((tot_trav - previous) * 2 / (tot_sims - previous), 0 ... 62; idle slots last): a counting
+// sort by one workgroup at the move step, order inside a bin arbitrary -- results are by slot whatever the order.
+static __global__ void __launch_bounds__(1024) k_depth_order(DView v, long long* prev /* [G][2] */, int* perm /* [G] */, int* kbuf /* [G] */) {
+  __shared__ int bins[64], base[64];
+  const int t = threadIdx.x;
+  if (t < 64) bins[t] = 0;
+  __syncthreads();
+  for (int s = t; s < v.G; s += blockDim.x) {
+    const SlotRec* r = v.sr + s;
+    const long long tt = r->tot_trav, ts = r->tot_sims;
+    const long long dt = tt - prev[2 * s], ds = ts - prev[2 * s + 1];
+    prev[2 * s] = tt; prev[2 * s + 1] = ts;
+    int k = 63;
+    if (r->active) { const long long h = ds > 0 ? 2 * dt / ds : 0; k = h < 0 ? 0 : h > 62 ? 62 : (int)h; }
+    kbuf[s] = k;
+    atomicAdd(&bins[k], 1);
+  }
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int k = 0; k < 64; ++k) { base[k] = acc; acc += bins[k]; } }
+  __syncthreads();
+  for (int s = t; s < v.G; s += blockDim.x) perm[atomicAdd(&base[kbuf[s]], 1)] = s;
 }
 
 // gather the move records of finished games into one contiguous staging area

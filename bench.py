@@ -82,11 +82,11 @@ def tower_roofline(game, hp, bf16, kernel, tw, evals, wall_s):
 
 
 def pmc_lookup(kernel, config="f32"):
-    """HBM bytes per launch of `kernel` from this round's separate rocprofv3 --pmc passes (profiles/r4/pmc_summary.json, r3's as a
-    fall-back; tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE in KB, FETCH doubled on gfx950 as MI355X_MICROARCH.md prescribes --
+    """HBM bytes per launch of `kernel` from the latest separate rocprofv3 --pmc passes (profiles/r5/pmc_summary.json if the round took
+    any, else r4's, r3's; tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE in KB, FETCH doubled on gfx950 as MI355X_MICROARCH.md prescribes --
     tools/fetch_calib.sh, profiles/r4/fetch_calibration.txt: 2 x FETCH_SIZE = 128-byte LINES requested, WRITE_SIZE exact);
     returns (bytes, units per launch) or None: counters cannot be read from inside this process."""
-    for rnd in ("r4", "r3"):                                         # this round's passes first
+    for rnd in ("r5", "r4", "r3"):                                   # this round's passes first
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")))
             ks = d.get("kernels", [])
@@ -276,7 +276,7 @@ def memory_block(azhip, dev_index, games=16384):
 
 def _tower_fallbacks(azhip):
     """az_selfplay_stats.tower_fallbacks summed over the engines the mirror keeps cached (arena players, the self-play engine): > 0
-    means a split tower gave up on a partner workgroup (2 s of waiting) and those engines run unsplit since"""
+    means a split tower gave up on a partner workgroup (50 ms of waiting) and those engines run unsplit since"""
     from azhip import engine as E
     return int(sum(e.selfplay_stats().tower_fallbacks for e in E._cache.values() if e._h is not None))
 
@@ -683,6 +683,11 @@ def main():
         if prof is not None:
             out["roofline"] = tower_roofline(azhip.GAME_CONNECT_FOUR, hp, False, eng_kernel, prof["tower"], local_evals, local_elapsed)
             out["roofline"]["kernel_ms_per_step"] = out["roofline"]["exclusive_ms"] / args.steps
+            if args.groups > 1:
+                out["roofline"]["time_basis"] = ("wall time of the timed region: the slot groups' tower launches run side by side, so avg_launch_ms x launches "
+                                                 "(launch_ms_sum) exceeds the wall time and a per-launch average -- HIP events here, rocprofv3 in profiles/ -- is NOT "
+                                                 "exclusive time; the same kernel alone, one launch at a time: roofline_kernel_alone (rocprof cross-check: "
+                                                 "profiles/r5/headline_one_group_kernel_stats.csv)")
             if out["roofline"]["traffic"] is None:
                 out["roofline"]["traffic"] = pmc_traffic(eng_kernel, out["roofline"]["avg_boards_per_launch"])
             out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
@@ -702,6 +707,9 @@ def main():
                 ("whole_phase", lambda: whole_phase(azhip, dev_index, blob, hp, args.slots, args.sims, args.groups)),
                 ("c3", lambda: steady_block(azhip, dev_index, "c3", azhip.GAME_CONNECT_FOUR, 4096, 2, 600, hp, 200,
                                             note="BASELINE configs[2] per GPU (games/connect-four/params.jl:25)")),
+                ("c2_5x128", lambda: steady_block(azhip, dev_index, "c2_5x128", azhip.GAME_CONNECT_FOUR, 4096, 2, 600,
+                                                  mk(num_blocks=5, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32), 120,
+                                                  note="the reference's shipped network and sims/move (games/connect-four/params.jl:7-30) at the BASELINE batch")),
                 ("c4_mancala", lambda: steady_block(azhip, dev_index, "c4_mancala", azhip.GAME_MANCALA, 8192, 1, 800, hp, 200, max_moves=256,
                                                     note="BASELINE configs[3] (games/mancala/params.jl:23-29), bug-compatible flip_colors")),
                 ("bf16_10x128", lambda: steady_block(azhip, dev_index, "bf16_10x128", azhip.GAME_CONNECT_FOUR, 4096, 1, 400,
@@ -739,6 +747,38 @@ def main():
                 out["learning"] = it["learning_status"]
         if world == 1 and not args.no_cpu_baseline and not args.iteration and not args.headline_only:
             out["cpu_baseline"] = cpu_baseline(blob, hp, args.sims)
+        if "extra" in out:
+            # The figures a reader of the line's END should not have to dig for (the driver keeps the tail of stdout): the headline,
+            # SURVEY 8(d)'s whole phase, the shipped network at the BASELINE batch, what one iteration learnt, the tree kernel.
+            ex = out["extra"]
+
+            def pick(name, *keys):
+                b = ex.get(name, {})
+                return {k: (b.get("roofline", {}).get(k[9:]) if k.startswith("roofline.") else b.get(k)) for k in keys} if "error" not in b else {"error": b["error"]}
+            out["summary"] = {
+                "headline_sims_per_sec": out["value"], "headline_unique_leaf_frac": out["unique_leaf_frac"],
+                "headline_tower_frac_of_fp32_mfma_peak": out.get("roofline", {}).get("frac"),
+                "kernel_alone_frac": out.get("roofline_kernel_alone", {}).get("frac"), "kernel_alone_avg_launch_ms": out.get("roofline_kernel_alone", {}).get("avg_launch_ms"),
+                "tree_us_per_wave": out.get("roofline_tree", {}).get("us_per_wave"), "tree_frac_of_hbm_peak": out.get("roofline_tree", {}).get("frac"),
+                "phase": out.get("phase"),
+                "c2_5x128": pick("c2_5x128", "value", "ms_per_step", "unique_leaf_frac", "roofline.frac", "roofline.kernel"),
+                "workers_128_5x128": pick("workers_128_5x128", "value", "roofline.frac", "roofline.kernel"),
+                "c4_mancala": pick("c4_mancala", "value", "engine_device_GB", "roofline.frac"),
+                "iteration": pick("iteration", "seconds", "sims_per_sec_self_play", "arena_avgr", "nn_replaced", "phases_share"),
+                "learning": out.get("learning"),
+                "cpu_baseline_sims_per_sec": out.get("cpu_baseline", {}).get("value"),
+            }
+            if "roofline" in out:
+                # ... and as flat scalars of `roofline` (the driver's record keeps that object's scalar fields): VERDICT r4 #2c
+                sm, rf = out["summary"], out["roofline"]
+                rf["also_kernel_alone_frac"], rf["also_kernel_alone_avg_launch_ms"] = sm["kernel_alone_frac"], sm["kernel_alone_avg_launch_ms"]
+                rf["also_tree_us_per_wave"], rf["also_tree_frac_of_hbm_peak"] = sm["tree_us_per_wave"], sm["tree_frac_of_hbm_peak"]
+                ph = sm["phase"] or {}
+                rf["also_phase_sims_per_sec"], rf["also_phase_unique_leaf_frac"], rf["also_phase_tower_frac"] = ph.get("sims_per_sec"), ph.get("unique_leaf_frac"), ph.get("tower_frac_of_fp32_mfma_peak")
+                rf["also_c2_5x128_sims_per_sec"], rf["also_c2_5x128_tower_frac"] = sm["c2_5x128"].get("value"), sm["c2_5x128"].get("roofline.frac")
+                rf["also_iteration_seconds"] = sm["iteration"].get("seconds")
+                lb, la = ((sm["learning"] or {}).get("before") or {}), ((sm["learning"] or {}).get("after") or {})
+                rf["also_learning_loss_before"], rf["also_learning_loss_after"] = lb.get("L"), la.get("L")
         print(json.dumps(out), flush=True)
     if gather_hung:
         os._exit(0)                                                 # a helper thread is stuck in a collective: no orderly shutdown

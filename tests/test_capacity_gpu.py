@@ -68,12 +68,18 @@ def test_mapped_on_demand_pool_gives_the_plain_pool_s_games_and_holds_less_memor
     kw = dict(game=R.MANCALA, oracle=azhip.ORACLE_HASH, num_workers=6, batch_size=3, num_iters_per_turn=600, cpuct=2.0, dirichlet_noise_eps=0.25,
               reset_every=1, seed=5, max_moves_per_game=256, temperature=((0, 10), (1.0, 0.5)))
     out = {}
-    for vmm in ("0", "1"):
-        monkeypatch.setenv("AZHIP_VMM", vmm)
+    for vmm in ("0", "1", "1 dense side records"):
+        monkeypatch.setenv("AZHIP_VMM", vmm[0])
+        if len(vmm) > 1:
+            monkeypatch.setenv("AZHIP_VMM_KEYS", "0")                # round 4's form: nodes mapped on demand, [G][cap] side records beside them
         with azhip.Engine(**kw) as e:
             g, m, ng, nm, st = e.selfplay_run(8)
             out[vmm] = (_records(g, m, ng), st.aborted_games, e.device_bytes(), max(g[i].nodes for i in range(ng)))
-    assert out["0"][0] == out["1"][0] and out["0"][1] == out["1"][1] == 0
+    monkeypatch.delenv("AZHIP_VMM_KEYS")
+    assert out["0"][0] == out["1"][0] == out["1 dense side records"][0] and out["0"][1] == out["1"][1] == 0
+    # (r5) the side records follow the node chunks: 32 B per node of the chunks that exist instead of 32 B x the worst case
+    # (dense: 6 x 600 x 128 x 32 B = 14.7 MB; mapped: 2 MB granules of four 16 384-record pieces, as far as the six trees grew)
+    assert out["1 dense side records"][2] > out["1"][2], (out["1 dense side records"][2], out["1"][2])
     assert out["1"][3] > 16384                                       # at least one tree grew past its first 2 MB chunk
     pool = 6 * 600 * 128 * 128                                       # the plain pool: slots x sims x 128 plies x 128 B
     assert out["0"][2] - out["1"][2] > pool // 3, (out["0"][2], out["1"][2])

@@ -3,7 +3,7 @@ when a workgroup's partner is not co-resident -- another engine, a trainer, anot
 gives up, and the engine then (i) notices without a synchronisation per wave (a host-mapped word), (ii) lets every queued launch
 pass as a no-op (k_tree stands still and is counted), (iii) evaluates the pending leaves again with the unsplit kernel, (iv) replays
 the waves that stood still, (v) keeps the split off, and reports it (az_selfplay_stats.tower_fallbacks).  The fault is injected
-(AZHIP_XCH_FAIL_AT = n: the n-th split launch of the engine loses a partner; the wait is 2 s of wall time).  Every record of the
+(AZHIP_XCH_FAIL_AT = n: the n-th split launch of the engine loses a partner; the wait is 50 ms of wall time).  Every record of the
 phase must equal the undisturbed run's -- all tower kernels produce the same bits -- and the oracle's."""
 import numpy as np
 import pytest

@@ -13,7 +13,7 @@ for G in GS:
     e = azhip.Engine(game=0, oracle=azhip.ORACLE_HASH, num_workers=G, batch_size=G, num_iters_per_turn=nsims, cpuct=2.0,
                      dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, reset_every=1, max_nodes_per_slot=nsims * 3)
     e.selfplay_begin(-1, 0)
-    e.selfplay_step(100)
+    e.selfplay_step(int(os.environ.get("TREE_BENCH_WARM", "100")))   # AZHIP_TREE_SORT orders the slots at move steps (every nsims waves): TREE_BENCH_WARM=200 times sorted waves only
     s0 = e.selfplay_stats()
     e.prof_reset(); e.prof_enable(True)
     e.selfplay_step(waves)
