@@ -8,11 +8,15 @@ O=gpurun_out/r5d; mkdir -p $O; export TMPDIR=/tmp
 timeout 780 python -m pytest tests -q -m gpu --durations=25 -p no:cacheprovider > $O/suite.log 2>&1
 echo "suite rc $?" >> $O/suite.log; tail -45 $O/suite.log
 [ -f gpurun_out/replay_all_games.jsonl ] && cp gpurun_out/replay_all_games.jsonl $O/
-# 2. k_tree: read-modify-write backup vs no-return atomics (1: waited for, 2: not), slots in depth order
-{ for knob in "" "AZHIP_TREE_ATOMIC=1" "AZHIP_TREE_ATOMIC=2" "AZHIP_TREE_SORT=1"; do
-    echo "== ${knob:-baseline}"; env $knob TREE_BENCH_WARM=200 timeout 240 python tools/tree_bench.py 4096 65536 1048576
-  done; } > $O/ktree_experiments.txt 2>&1
-cat $O/ktree_experiments.txt
+# 2. the driver's command (default line: headline, extras incl. whole phase / c2_5x128 / iteration, CPU baseline), evaluation cache on (default)
+timeout 420 python bench.py > $O/bench_default_line.json 2> $O/bench_default.err
+echo "bench rc $?"; python - <<PY
+import json
+try:
+    d=json.load(open("$O/bench_default_line.json")); print(json.dumps(d["summary"])[:3000]); print({k: (v.get("error") if isinstance(v, dict) and "error" in v else "ok") for k, v in d["extra"].items()})
+except Exception as ex:
+    print("bench line unreadable:", ex); print(open("$O/bench_default.err").read()[-1500:])
+PY
 # 3. the headline's kernel alone (one slot group, forced to the two-group run's kernel), rocprofv3 kernel stats + the line's HIP events
 d=/tmp/prof_h1; rm -rf $d
 (cd /tmp && AZHIP_TOWER=16 AZHIP_EVAL_CACHE=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python $GRAFT_REPO_ROOT/bench.py --groups 1 --steps 400 --warmup 50 --headline-only > $GRAFT_REPO_ROOT/$O/headline_one_group_cache_off_line.json 2> $GRAFT_REPO_ROOT/$O/headline_one_group_cache_off.err)
@@ -20,24 +24,25 @@ f=$(find $d -name "*kernel_stats.csv" -printf "%s %p\n" | sort -n | tail -1 | cu
 d=/tmp/prof_h2; rm -rf $d
 (cd /tmp && AZHIP_TOWER=16 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python $GRAFT_REPO_ROOT/bench.py --groups 1 --steps 400 --warmup 50 --headline-only > $GRAFT_REPO_ROOT/$O/headline_one_group_line.json 2> $GRAFT_REPO_ROOT/$O/headline_one_group.err)
 f=$(find $d -name "*kernel_stats.csv" -printf "%s %p\n" | sort -n | tail -1 | cut -d" " -f2); [ -n "$f" ] && cp $f $O/headline_one_group_kernel_stats.csv && head -6 $f | cut -c1-200
-# 4. evaluation cache on / off: headline + whole phase (+ the shipped 5x128 network at the BASELINE batch with the default)
-for c in 1 0; do
-  only=whole_phase; [ $c = 1 ] && only=whole_phase,c2_5x128
-  AZHIP_EVAL_CACHE=$c AZ_BENCH_ONLY=$only timeout 420 python bench.py --no-cpu-baseline --no-iteration > $O/bench_cache$c.json 2> $O/bench_cache$c.err
-  python - <<PY
+# 4. k_tree: read-modify-write backup vs no-return atomics (1: waited for, 2: not), slots in depth order
+{ for knob in "" "AZHIP_TREE_ATOMIC=1" "AZHIP_TREE_ATOMIC=2" "AZHIP_TREE_SORT=1"; do
+    echo "== ${knob:-baseline}"; env $knob TREE_BENCH_WARM=200 timeout 240 python tools/tree_bench.py 4096 1048576
+  done; } > $O/ktree_experiments.txt 2>&1
+cat $O/ktree_experiments.txt
+# 5. the same phase with the evaluation cache off
+AZHIP_EVAL_CACHE=0 AZ_BENCH_ONLY=whole_phase timeout 300 python bench.py --no-cpu-baseline --no-iteration > $O/bench_cache0.json 2> $O/bench_cache0.err
+python - <<PY
 import json
 try:
-    d=json.load(open("$O/bench_cache$c.json")); r=d["roofline"]; w=d["extra"].get("whole_phase",{}); x=d["extra"].get("c2_5x128",{})
-    print("cache=$c headline %.3f M sims/s ms/step %.3f unique %.3f frac %.3f kernel %s boards/launch %.0f | alone frac %.3f avg ms %.4f | tree us/wave %s | phase %.3f M sims/s unique %.3f frac %.3f | c2_5x128 %s" % (
-      d["value"]/1e6, d["ms_per_step"], d["unique_leaf_frac"], r["frac"], r["kernel"], r["avg_boards_per_launch"], d["roofline_kernel_alone"]["frac"], d["roofline_kernel_alone"]["avg_launch_ms"],
-      d["roofline_tree"]["us_per_wave"], w.get("value",0)/1e6, w.get("unique_leaf_frac",-1), w.get("roofline",{}).get("frac",-1),
-      {k: x.get(k) for k in ("value","ms_per_step","unique_leaf_frac","error")} | {"frac": x.get("roofline",{}).get("frac"), "kernel": x.get("roofline",{}).get("kernel"), "boards": x.get("roofline",{}).get("avg_boards_per_launch")}))
+    d=json.load(open("$O/bench_cache0.json")); r=d["roofline"]; w=d["extra"].get("whole_phase",{})
+    print("cache=0 headline %.3f M sims/s ms/step %.3f unique %.3f frac %.3f kernel %s | alone frac %.3f avg ms %.4f | tree us/wave %s | phase %.3f M sims/s frac %.3f" % (
+      d["value"]/1e6, d["ms_per_step"], d["unique_leaf_frac"], r["frac"], r["kernel"], d["roofline_kernel_alone"]["frac"], d["roofline_kernel_alone"]["avg_launch_ms"],
+      d["roofline_tree"]["us_per_wave"], w.get("value",0)/1e6, w.get("roofline",{}).get("frac",-1)))
 except Exception as ex:
-    print("cache=$c failed:", ex); print(open("$O/bench_cache$c.err").read()[-800:])
+    print("cache=0 failed:", ex); print(open("$O/bench_cache0.err").read()[-800:])
 PY
-done
-# 5. does the loop learn at the shipped learning parameters?
-timeout 300 python tools/iterations.py --iters 3 --games 1024 --workers 1024 > $O/iterations.jsonl 2> $O/iterations.err
+# 6. does the loop learn at the shipped learning parameters?
+timeout 240 python tools/iterations.py --iters 3 --games 512 --workers 512 > $O/iterations.jsonl 2> $O/iterations.err
 echo "iterations rc $?"; tail -1 $O/iterations.jsonl | cut -c1-600
 find /tmp/prof_h1 /tmp/prof_h2 -name "*.csv" -size +20M -delete 2>/dev/null
 du -sh $O
