@@ -536,7 +536,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--slots", type=int, default=4096)
     ap.add_argument("--sims", type=int, default=400)
-    ap.add_argument("--groups", type=int, default=2, help="interleaved slot groups = num_workers / batch_size: 2 (default) overlaps the tree kernels of one half-batch with the network of the other, the reference's num_workers = 2 x batch_size; 1 = one 4096-leaf batch per wave")
+    ap.add_argument("--groups", type=int, default=1, help="slot groups = num_workers / batch_size: 1 (default since round 5) = one network launch per wave for all 4096 slots (batch_size 4096, BASELINE's 'batch 4096'); 2 = two interleaved half-batches, the tree kernels of one under the network of the other -- the better form while every leaf went to the network (rounds 1-4: 4.9 vs 4.85 M sims/s), the worse one since the evaluation cache answers ~40 %% of the leaves and a half-batch no longer fills the chip (8.0 vs 8.5 M sims/s, profiles/r5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra configurations (whole phase, C3, C4 Mancala, bf16 10x128, 128 workers) reported under `extra`")
     ap.add_argument("--no-iteration", action="store_true", help="skip extra.iteration (one whole training iteration at the reference's shipped Connect-Four parameters, ~1-2 min)")
@@ -667,7 +667,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Connect-Four self-play, %d sims/move, %d parallel games per GPU, ResNet 5x64 fp32 "
                                    "(heads 32/32), cpuct 2, eps 0.25, alpha 1, PLSchedule([0,20,30],[1,1,.3]), reset_every 1, num_workers/batch_size = %d; "
-                                   "step = one search wave (1 simulation per slot)" % (args.sims, args.slots, args.groups),
+                                   "step = one search wave (1 simulation per slot); evaluation cache %s" % (args.sims, args.slots, args.groups, "off (AZHIP_EVAL_CACHE=0)" if os.environ.get("AZHIP_EVAL_CACHE") == "0" else "on"),
                        "slots_per_gpu": args.slots, "sims_per_move": args.sims, "slot_groups": args.groups, "leaves_per_network_launch": args.slots // args.groups, "parallelism": "dp%d (games sharded, no collective in the timed region)" % world,
                        "device": dev_name, "compute_units": ncu},
             "sims_per_sec_per_gpu": sims / elapsed / world,
@@ -683,6 +683,9 @@ def main():
         if prof is not None:
             out["roofline"] = tower_roofline(azhip.GAME_CONNECT_FOUR, hp, False, eng_kernel, prof["tower"], local_evals, local_elapsed)
             out["roofline"]["kernel_ms_per_step"] = out["roofline"]["exclusive_ms"] / args.steps
+            # the same executed FLOPs over the WALL time of the timed region (tree kernels, dense heads, launch gaps included)
+            out["roofline"]["achieved_over_wall"] = out["roofline"]["achieved"] * out["roofline"]["exclusive_ms"] / out["roofline"]["wall_ms"]
+            out["roofline"]["frac_over_wall"] = out["roofline"]["achieved_over_wall"] / out["roofline"]["peak"]
             if args.groups > 1:
                 out["roofline"]["time_basis"] = ("wall time of the timed region: the slot groups' tower launches run side by side, so avg_launch_ms x launches "
                                                  "(launch_ms_sum) exceeds the wall time and a per-launch average -- HIP events here, rocprofv3 in profiles/ -- is NOT "
@@ -705,7 +708,7 @@ def main():
             mk = ResNetHP
             blocks = [
                 ("whole_phase", lambda: whole_phase(azhip, dev_index, blob, hp, args.slots, args.sims, args.groups)),
-                ("c3", lambda: steady_block(azhip, dev_index, "c3", azhip.GAME_CONNECT_FOUR, 4096, 2, 600, hp, 200,
+                ("c3", lambda: steady_block(azhip, dev_index, "c3", azhip.GAME_CONNECT_FOUR, 4096, args.groups, 600, hp, 200,
                                             note="BASELINE configs[2] per GPU (games/connect-four/params.jl:25)")),
                 ("c2_5x128", lambda: steady_block(azhip, dev_index, "c2_5x128", azhip.GAME_CONNECT_FOUR, 4096, 2, 600,
                                                   mk(num_blocks=5, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32), 120,
