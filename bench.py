@@ -25,6 +25,14 @@ sys.path.insert(0, os.path.join(ROOT, "alphazero.jl_amd"))
 
 import numpy as np  # noqa: E402
 
+_T0 = time.perf_counter()
+
+
+def trace(msg):
+    """AZ_BENCH_TRACE=1: progress marks on stderr (rank, seconds since start) -- where a run that does not finish stands"""
+    if os.environ.get("AZ_BENCH_TRACE"):
+        print("[bench rank %s +%.1f s] %s" % (os.environ.get("RANK", "0"), time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
 # algorithmic work per evaluated leaf, ResNet 5x64 heads 32/32 on 7x6x3 planes (SURVEY.md §8d)
 TOWER_FLOP = 2 * 42 * 64 * (27 + 10 * 576 + 64)     # stem + 10 tower convs + both 1x1 head convs
 HEADS_FLOP = 2 * (1344 * 7 + 1344 * 64 + 64)
@@ -479,7 +487,9 @@ def gather_leg(azhip, blob, dev_index, rank, world, games_per_rank=512, nsims=48
     """RCCL trace gather (BASELINE configs[2]'s exchange step) on a short phase: `games_per_rank` Connect-Four games per
     rank with global game ids, device-only; then one collective puts every rank's samples into every rank's memory."""
     from azhip import comm
+    trace("exchange: id broadcast + communicator")
     c = comm.Comm(dev_index, rank, world, comm.torch_broadcast_id(rank))
+    trace("exchange: communicator up")
     eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=dev_index, num_workers=games_per_rank,
                        batch_size=games_per_rank, num_iters_per_turn=nsims, cpuct=2.0, dirichlet_noise_eps=0.25,
                        dirichlet_noise_alpha=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
@@ -487,8 +497,10 @@ def gather_leg(azhip, blob, dev_index, rank, world, games_per_rank=512, nsims=48
     if rank == 0:
         eng.net_set_params(blob)
     c.broadcast_params(eng, root=0)                                 # the weights reach the other ranks over RCCL
+    trace("exchange: weights broadcast")
     mem = azhip.MemoryBuffer(azhip.ConnectFourSpec(), 1 << 22, device=dev_index)
     eng.selfplay_run(games_per_rank, first_game_id=rank * games_per_rank, device_only=True)
+    trace("exchange: phase played")
     c.gather_push(eng, mem, 1.0)                                    # warm-up of the communicator's rings
     mem.empty()
     t0 = time.perf_counter()
@@ -592,6 +604,7 @@ def main():
     eng.net_set_params(blob)
     dev_name, ncu, hbm = eng.device_info()
     eng.selfplay_begin(-1, first_game_id=rank * (1 << 24))
+    trace("engine ready (%d slots, %d group(s)), world %d" % (args.slots, args.groups, world))
 
     def barrier():
         if dist is not None:
@@ -602,6 +615,7 @@ def main():
     warm = max(args.warmup, mixing_warmup(azhip.GAME_CONNECT_FOUR, args.sims) + args.sims // 2)
     eng.selfplay_step(warm)
     s0 = eng.selfplay_stats()
+    trace("warm-up done (%d waves)" % warm)
     if not args.no_prof:
         eng.prof_reset()
         eng.prof_enable(True, classes=None if args.prof_all else ("tower",))
@@ -613,6 +627,7 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
+    trace("timed region done (%.3f s)" % (t1 - t0))
     prof = eng.prof_get() if not args.no_prof else None
     eng.prof_enable(False)
     eng_kernel = eng.net_last_kernel()
@@ -653,10 +668,12 @@ def main():
                 box["r"] = gather_leg(azhip, blob, dev_index, rank, world)
             except Exception as ex:
                 box["r"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        trace("exchange leg starts")
         th = threading.Thread(target=run_gather, daemon=True)
         th.start()
         th.join(240.0)
         gather_hung = th.is_alive()
+        trace("exchange leg %s" % ("did NOT finish" if gather_hung else "done: %s" % json.dumps(box.get("r"))[:200]))
         gather = {"error": "the exchange leg did not finish within 240 s"} if gather_hung else box.get("r")
 
     if rank == 0:
@@ -734,6 +751,7 @@ def main():
                 blocks = [b for b in blocks if b[0] in os.environ["AZ_BENCH_ONLY"].split(",")]
             out["extra"] = {}
             for name, fn in blocks:
+                trace("extra block %s" % name)
                 try:
                     out["extra"][name] = fn()
                 except Exception as ex:
@@ -783,6 +801,7 @@ def main():
                 lb, la = ((sm["learning"] or {}).get("before") or {}), ((sm["learning"] or {}).get("after") or {})
                 rf["also_learning_loss_before"], rf["also_learning_loss_after"] = lb.get("L"), la.get("L")
         print(json.dumps(out), flush=True)
+    trace("line printed" if rank == 0 else "done")
     if gather_hung:
         os._exit(0)                                                 # a helper thread is stuck in a collective: no orderly shutdown
     if dist is not None:
