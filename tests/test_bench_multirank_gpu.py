@@ -14,17 +14,31 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_on_one_gpu_print_one_line_with_the_gather_leg():
+def _run(cmd, env, tmp_path, limit=240):
+    """runs bench.py with its progress marks on (AZ_BENCH_TRACE), output into files: a run that does not finish within `limit` seconds
+    fails with the marks of every rank in the message instead of a bare TimeoutExpired (the 8-second run once sat for two minutes
+    behind other work on the test box and nothing said where)"""
+    out, err = tmp_path / "stdout.txt", tmp_path / "stderr.txt"
+    with open(out, "w") as fo, open(err, "w") as fe:
+        try:
+            rc = subprocess.run(cmd, stdout=fo, stderr=fe, timeout=limit, env=dict(env, AZ_BENCH_TRACE="1"), cwd=ROOT).returncode
+        except subprocess.TimeoutExpired:
+            rc = None
+    so, se = out.read_text(), err.read_text()
+    assert rc is not None, "bench.py did not finish within %d s; progress marks:\n%s" % (limit, "\n".join(ln for ln in se.splitlines() if "bench rank" in ln)[-3000:] or se[-3000:])
+    return rc, so, se
+
+
+def test_two_ranks_on_one_gpu_print_one_line_with_the_gather_leg(tmp_path):
     stub = os.path.join(ROOT, "tests", "rccl_stub", "librccl_stub.so")
     if not os.path.exists(stub):
         subprocess.check_call(["make", "-C", os.path.dirname(stub)])
     env = dict(os.environ, AZHIP_RCCL_LIB=stub, HSA_ENABLE_IPC_MODE_LEGACY="0")
     port = 29000 + os.getpid() % 900
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--slots", "512"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]          # rank 0 prints ONE line
+    rc, so, se = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--slots", "512"], env, tmp_path)
+    lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+    assert rc == 0 and len(lines) == 1, so[-2000:] + se[-2000:]                                # rank 0 prints ONE line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["sims_per_sec_per_gpu"] * 2 - d["value"]) < 1e-6 * d["value"]
@@ -35,7 +49,7 @@ def test_two_ranks_on_one_gpu_print_one_line_with_the_gather_leg():
     assert "extra" not in d and "cpu_baseline" not in d                                         # those legs belong to N = 1
 
 
-def test_plain_bench_with_gpus_2_launches_two_ranks_itself():
+def test_plain_bench_with_gpus_2_launches_two_ranks_itself(tmp_path):
     """`python bench.py --gpus 2` exactly as a driver without a launcher calls it: the script re-executes itself under
     torch.distributed.run with two ranks (stub transport on the one GPU) and rank 0 prints ONE line with n_gpus = 2."""
     stub = os.path.join(ROOT, "tests", "rccl_stub", "librccl_stub.so")
@@ -43,10 +57,9 @@ def test_plain_bench_with_gpus_2_launches_two_ranks_itself():
         subprocess.check_call(["make", "-C", os.path.dirname(stub)])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(AZHIP_RCCL_LIB=stub, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--slots", "512"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    rc, so, se = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--slots", "512"], env, tmp_path)
+    lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+    assert rc == 0 and len(lines) == 1, so[-2000:] + se[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["launcher"].startswith("self") and len(d["sims_per_sec_by_rank"]) == 2
     assert all(v > 0 for v in d["sims_per_sec_by_rank"]) and d["value"] <= sum(d["sims_per_sec_by_rank"]) * (1 + 1e-9)
