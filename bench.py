@@ -358,6 +358,8 @@ def iteration_block(azhip, dev_index, num_games=5000, workers=4096):
     return {"workload": iteration_block.__doc__.split("\n")[0].strip() + " -- games/connect-four/params.jl:5-75, %d workers" % workers,
             "seconds": total, "games": num_games, "samples": samples, "sims_per_sec_self_play": samples * 600 / t_sim,
             "optimiser_steps": int(len(lr.losses)), "loss_first_last": [float(lr.losses[0]), float(lr.losses[-1])] if len(lr.losses) else None,
+            # train-mode mini-batch losses, mean of each quarter of the epoch: the trend inside batch_updates! (single batches are noisy)
+            "minibatch_loss_quarter_means": [float(np.mean(q)) for q in np.array_split(np.asarray(lr.losses, dtype=np.float64), 4)] if len(lr.losses) >= 4 else None,
             # learning_status (src/learning.jl:148-181) over the WHOLE data set, test-mode network, before batch_updates! and after:
             # what the iteration learnt (loss_first_last above are two single mini-batches of the train-mode network)
             "learning_status": {"before": _status(lr.initial_status), "after": _status(lr.checkpoints[-1].status_after) if lr.checkpoints else None},
