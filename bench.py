@@ -670,6 +670,11 @@ def main():
                 box["r"] = gather_leg(azhip, blob, dev_index, rank, world)
             except Exception as ex:
                 box["r"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        if rank == 0:
+            # the exchange leg is the first time real RCCL runs with W > 1: should the process die inside it, the measured number
+            # is already on stderr (the ONE JSON line on stdout comes after the leg, with its `gather` object)
+            print("[bench] provisional (before the exchange leg): %s" % json.dumps({"metric": "self-play MCTS sims/sec", "value": sims / elapsed, "unit": "sims/s",
+                  "n_gpus": world, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps, "sims_per_sec_by_rank": per_rank}), file=sys.stderr, flush=True)
         trace("exchange leg starts")
         th = threading.Thread(target=run_gather, daemon=True)
         th.start()
