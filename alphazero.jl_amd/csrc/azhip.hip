@@ -418,7 +418,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     { const char* ep = getenv("AZHIP_XCH_EPOCH0"); e->xch_epoch = ep ? strtoull(ep, nullptr, 0) : 0; }   // tests: start k_tower16s' launch epoch near its 24-bit wrap
     { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); e->num_cu = pr.multiProcessorCount; }
     AZCHK(net_set_kernel_attrs(e));
-    // round-5 experiments on k_tree (off by default, measured in profiles/r5/ktree_experiments): AZHIP_TREE_ATOMIC = 1 | 2
+    // round-5 experiments on k_tree (off by default, measured in profiles/r5/README.md): AZHIP_TREE_ATOMIC = 1 | 2
     // backs up with no-return atomics (DView::bk_mode), AZHIP_TREE_SORT = 1 orders the slots of a launch by depth at every move step
     { const char* ta = getenv("AZHIP_TREE_ATOMIC"); const int m = ta ? atoi(ta) : 0; v.bk_mode = m == 1 || m == 2 ? m : 0; }
     { const char* ts = getenv("AZHIP_TREE_SORT"); e->tree_sort = ts && atoi(ts) != 0 ? 1 : 0; }

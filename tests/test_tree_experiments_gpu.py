@@ -1,4 +1,4 @@
-"""Round-5 forms of k_tree that are off by default (profiles/r5/ktree_experiments): whatever they do to the
+"""Round-5 forms of k_tree that are off by default (profiles/r5/README.md): whatever they do to the
 kernel's time, every record of a phase must stay the oracle's.
   * AZHIP_TREE_ATOMIC = 1 | 2: the backup W += q, N += 1 (update_state_info!, src/mcts.jl:190-194) as no-return atomics performed by L2
     instead of a read-modify-write in the lane (one update per (node, action), slot and wave, so the same IEEE add);
