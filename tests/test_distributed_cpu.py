@@ -77,3 +77,93 @@ def test_broadcast_params_gloo_world2(tmp_path):
     w0, w1 = np.load(tmp_path / "W0.npy"), np.load(tmp_path / "W1.npy")
     ref = random_params(0, ResNetHP(num_blocks=1, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32), seed=100)
     assert np.array_equal(w0, ref) and np.array_equal(w1, ref)
+
+
+class _FakeMemory:
+    """what self_play_step_device needs of a MemoryBuffer, on the host"""
+
+    def __init__(self):
+        self.pushed = []
+
+    def new_batch(self):
+        pass
+
+    def push_records(self, games, moves, ng, nm, gamma):
+        self.pushed.append((ng, nm, sorted(int(games[i].game_id) for i in range(ng))))
+
+    def __len__(self):
+        return sum(p[1] for p in self.pushed)
+
+    def dataset(self, **kw):
+        import contextlib
+        n = len(self)
+
+        class D:
+            def __len__(self):
+                return n
+        return contextlib.nullcontext(D())
+
+
+def _abort_worker(rank, world, port, out_dir, num_games, replaced_on_rank1):
+    """self_play_step_device over a gloo group with the local phase replaced by oracle-made records; rank 1 reports
+    `replaced_on_rank1` of its games under replacement ids (games its slots aborted and played again)"""
+    import ctypes as C
+    import json
+    import warnings
+    sys.path[:0] = [os.path.join(ROOT, "alphazero.jl_amd"), os.path.join(ROOT, "oracle")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import azref as R
+    from azhip import _lib as L
+    from azhip import simulations as S
+    from azhip import training as T
+    from azhip.params import MctsParams, SimParams
+
+    def fake_run_local(simulator, gspec, p, first_game_id=0, game_simulated=None, device=0, seed=1, device_only=False):
+        games, moves, nm = R.simulate(R.TTT, R.ORACLE_HASH, p.num_games, p.num_games, 12, cpuct=1.5, noise_eps=0.25, seed=5, first_game_id=first_game_id)
+        g = (L.GameRec * max(p.num_games, 1)).from_buffer_copy(bytes(games)[:C.sizeof(L.GameRec) * max(p.num_games, 1)])
+        m = (L.MoveRec * max(nm, 1)).from_buffer_copy(bytes(moves)[:C.sizeof(L.MoveRec) * max(nm, 1)])
+        if rank == 1:
+            for i in range(replaced_on_rank1):
+                g[i].game_id |= L.REPLACEMENT_GAME_BIT
+        st = L.SelfplayStats()
+        st.aborted_games = replaced_on_rank1 if rank == 1 else 0
+        st.moves = nm
+        return g, m, p.num_games, nm, st, None
+    S.run_local = fake_run_local
+    mem = _FakeMemory()
+    params = T.SelfPlayParams(mcts=MctsParams(num_iters_per_turn=12, dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0), sim=SimParams(num_games=num_games, num_workers=4, batch_size=4, use_gpu=False))
+    outcome = {"rank": rank}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        try:
+            T.self_play_step_device(None, None, params, mem)
+            outcome["raised"] = None
+        except L.AzError as ex:
+            outcome["raised"] = str(ex)
+        outcome["warned"] = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+    outcome["pushed"] = mem.pushed
+    # the group must still be whole: a rank that had left on its own would have left the other in all_gather, and this
+    # barrier is where a survivor of such a split would hang
+    dist.barrier()
+    json.dump(outcome, open(os.path.join(out_dir, "abort%d.json" % rank), "w"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_games,replaced,expect_raise", [(6, 2, True), (60, 1, False)])
+def test_abort_verdict_is_formed_after_the_gather_on_every_rank_alike(tmp_path, num_games, replaced, expect_raise):
+    """a rank whose slots aborted games used to raise BEFORE the collective and leave the other ranks in the
+    all-gather.  Now every rank gathers first and forms the verdict from the gathered records: above 5 % every rank refuses -- with the
+    same message -- and nothing is pushed anywhere; below, every rank warns and pushes the same games."""
+    import json
+    port = 33500 + (os.getpid() + num_games) % 2000
+    mp.spawn(_abort_worker, args=(2, port, str(tmp_path), num_games, replaced), nprocs=2, join=True)
+    o = [json.load(open(tmp_path / ("abort%d.json" % r))) for r in range(2)]
+    if expect_raise:
+        assert o[0]["raised"] and o[0]["raised"] == o[1]["raised"] and "%d of %d" % (replaced, num_games) in o[0]["raised"]
+        assert o[0]["pushed"] == o[1]["pushed"] == []
+    else:
+        assert o[0]["raised"] is None and o[1]["raised"] is None
+        assert len(o[0]["warned"]) == len(o[1]["warned"]) == 1 and o[0]["warned"] == o[1]["warned"]
+        assert o[0]["pushed"] == o[1]["pushed"] and o[0]["pushed"][0][0] == num_games
