@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("AZHIP_LIB", os.path.join(CSRC, "libazhip.so"))   # override: A/B builds
 
-ABI_VERSION = 3              # include/azhip.h AZ_ABI_VERSION: struct layouts below are version 3's
+ABI_VERSION = 4              # include/azhip.h AZ_ABI_VERSION: struct layouts below are version 4's
 REPLACEMENT_GAME_BIT = 0x40000000
 AZ_OK, AZ_ERR_BAD_ARG, AZ_ERR_CAPACITY, AZ_ERR_HIP, AZ_ERR_STATE = 0, -1, -2, -3, -4
 GAME_CONNECT_FOUR, GAME_TICTACTOE, GAME_MANCALA = 0, 1, 2
@@ -39,7 +39,7 @@ class EngineCfg(C.Structure):
         ("fill_batches", C.c_int32), ("flip_probability", C.c_double), ("seed", C.c_uint64),
         ("max_nodes_per_slot", C.c_int32), ("max_moves_per_game", C.c_int32),
         ("num_blocks", C.c_int32), ("num_filters", C.c_int32),
-        ("num_policy_head_filters", C.c_int32), ("num_value_head_filters", C.c_int32), ("net_bf16", C.c_int32),
+        ("num_policy_head_filters", C.c_int32), ("num_value_head_filters", C.c_int32), ("net_bf16", C.c_int32), ("lock_step", C.c_int32),
     ]
 
 
@@ -62,7 +62,7 @@ class TraceBuf(C.Structure):
 class SelfplayStats(C.Structure):
     _fields_ = [("simulations", C.c_int64), ("nodes_traversed", C.c_int64), ("leaf_evals", C.c_int64),
                 ("moves", C.c_int64), ("games", C.c_int64), ("waves", C.c_int64), ("seconds", C.c_double),
-                ("aborted_games", C.c_int64), ("tower_fallbacks", C.c_int64), ("evals_reused", C.c_int64)]
+                ("aborted_games", C.c_int64), ("tower_fallbacks", C.c_int64), ("evals_reused", C.c_int64), ("slot_launches", C.c_int64)]
 
 
 class Prof(C.Structure):

@@ -282,7 +282,7 @@ class Engine:
 CACHE_MAX = 4
 CACHE_MAX_BYTES = int(float(os.environ.get("AZHIP_CACHE_GB", "96")) * (1 << 30))
 CREATE_ENV = ("AZHIP_TOWER", "AZHIP_HEADS", "AZHIP_GRAPH", "AZHIP_XCH_EPOCH0", "AZHIP_VMM", "AZHIP_POOL_GB", "AZHIP_XCH_FAIL_AT", "AZHIP_POOLED_QUEUE",
-              "AZHIP_HT_TAG_BITS", "AZHIP_HT_EPOCH0", "AZHIP_EVAL_CACHE", "AZHIP_EVAL_CACHE_LOG2", "AZHIP_VMM_KEYS", "AZHIP_TREE_ATOMIC", "AZHIP_TREE_SORT")
+              "AZHIP_HT_TAG_BITS", "AZHIP_HT_EPOCH0", "AZHIP_EVAL_CACHE", "AZHIP_EVAL_CACHE_LOG2", "AZHIP_VMM_KEYS", "AZHIP_TREE_ATOMIC", "AZHIP_TREE_SORT")   # (AZHIP_FREE_RUN / AZHIP_RUN_K / AZHIP_FR_ROUND are read per phase, not at creation)
 _cache = {}
 
 

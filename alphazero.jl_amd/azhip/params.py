@@ -77,6 +77,9 @@ class SimParams:
     reset_every: Optional[int] = 1
     flip_probability: float = 0.0
     alternate_colors: bool = False
+    # not a field of the reference: az_engine_cfg.lock_step (include/azhip.h).  False = free-running workers (which worker plays which
+    # game is an outcome of the reference's own race, util.jl:181-188, reported per game); True = rounds in lock step, fixed assignment
+    lock_step: bool = False
 
 
 def check_sim_params(p: SimParams, arena=False):
@@ -96,4 +99,5 @@ def engine_options(mcts: MctsParams, sim: SimParams, seed=1, arena=False):
                 num_iters_per_turn=mcts.num_iters_per_turn, temperature=(xs, ys),
                 num_workers=sim.num_workers, batch_size=sim.batch_size,
                 reset_every=0 if sim.reset_every is None else sim.reset_every,
-                fill_batches=1 if sim.fill_batches else 0, flip_probability=sim.flip_probability, seed=seed)
+                fill_batches=1 if sim.fill_batches else 0, flip_probability=sim.flip_probability, seed=seed,
+                lock_step=1 if getattr(sim, "lock_step", False) else 0)

@@ -40,12 +40,13 @@ class _WorkerView:
 
     def __init__(self, gspec, rec):
         self.mcts = _WorkerView._M(gspec, rec)
+        self.worker = int(rec.slot)      # which worker played the game (az_game_rec.slot): the outcome of the id race, util.jl:181-188
 
 
 def self_play_measurements(trace, _, player):
-    """training.jl:269-273"""
+    """training.jl:269-273; + `worker`: the worker that played the game (not in the reference's report: its assignment is a race)"""
     return {"trace": trace, "mem": player.mcts.approximate_memory_footprint(),
-            "edepth": player.mcts.average_exploration_depth()}
+            "edepth": player.mcts.average_exploration_depth(), "worker": getattr(player, "worker", -1)}
 
 
 def _engine_for(gspec, player, p, device, seed):

@@ -107,6 +107,7 @@ static void drop_wave_graphs(az_engine* e);
 extern "C" int az_engine_destroy(az_engine* e) {
   if (!e) return AZ_OK;
   (void)hipSetDevice(e->device);
+  if (e->ngroups == 1 && e->fr_s[0] && e->gs[0] == e->fr_s[0]) { for (int i = 0; i < 3; ++i) (void)hipStreamSynchronize(e->fr_s[i]); e->gs[0] = e->gt[0] = e->stream; }
   for (int g = 0; g < e->ngroups; ++g) if (e->gs[g] && e->gs[g] != e->stream) {
     (void)hipStreamSynchronize(e->gt[g]); (void)hipStreamSynchronize(e->gs[g]);
     (void)hipStreamDestroy(e->gt[g]); (void)hipStreamDestroy(e->gs[g]);
@@ -116,6 +117,10 @@ extern "C" int az_engine_destroy(az_engine* e) {
   split_register(e, 0);
   if (e->h_xflag) (void)hipHostFree(e->h_xflag);
   if (e->h_nleaf) (void)hipHostFree(e->h_nleaf);
+  if (e->h_fr_words) (void)hipHostFree(e->h_fr_words);
+  for (int i = 0; i < 3; ++i) { if (e->fr_s[i]) { (void)hipStreamSynchronize(e->fr_s[i]); (void)hipStreamDestroy(e->fr_s[i]); } if (e->fr_ev[i]) (void)hipEventDestroy(e->fr_ev[i]); }
+  if (e->d_done) (void)hipFree(e->d_done);
+  if (e->d_done_off) (void)hipFree(e->d_done_off);
   if (e->h_env) (void)hipHostFree(e->h_env);
   if (e->h_n) (void)hipHostFree(e->h_n);
   if (e->h_pv) (void)hipHostFree(e->h_pv);
@@ -227,6 +232,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   if (!(c->flip_probability >= 0.0 && c->flip_probability <= 1.0)) return fail(AZ_ERR_BAD_ARG, "flip_probability must be in [0, 1]");
   if (c->temperature_len < 1 || c->temperature_len > AZ_SCHED_MAX) return fail(AZ_ERR_BAD_ARG, "temperature schedule needs 1..%d breakpoints", AZ_SCHED_MAX);
   if (c->reset_every < 0) return fail(AZ_ERR_BAD_ARG, "reset_every must be >= 0");
+  if (c->lock_step != 0 && c->lock_step != 1) return fail(AZ_ERR_BAD_ARG, "lock_step must be 0 (free-running self-play) or 1");
   if (!(c->prior_temperature >= 0.0)) return fail(AZ_ERR_BAD_ARG, "prior_temperature must be >= 0");
   if (c->oracle == AZ_ORACLE_RESNET) {
     if (c->num_filters != 64 && c->num_filters != 128) return fail(AZ_ERR_BAD_ARG, "num_filters = %d: this build instantiates the 64- and 128-filter towers", c->num_filters);
@@ -247,6 +253,8 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   e->next_exec = 1.0;
   e->h_env = nullptr; e->h_n = nullptr; e->h_pv = nullptr; e->h_nleaf = nullptr; e->d_nleaf = nullptr;
   e->d_ec = nullptr; e->ec_mask = 0; e->ec_seq = 0; e->d_ec_claim = nullptr; e->d_Phit = nullptr; e->d_Vhit = nullptr;
+  e->fr_on = false; e->fr_k = 0; e->fr_kbg = 0; e->fr_round_waves = 0; e->fr_s[0] = e->fr_s[1] = e->fr_s[2] = nullptr; e->fr_ev[0] = e->fr_ev[1] = e->fr_ev[2] = nullptr; e->d_fr = nullptr; e->d_done = nullptr; e->d_done_off = nullptr; e->done_cap = 0;
+  e->h_fr_words = nullptr; e->d_fr_words = nullptr; e->fr_prev_done = 0; e->fr_since_round = 0; e->fr_given_up = 0; e->fr_prev_recs = 0;
   e->h_xflag = nullptr; e->d_xflag = nullptr; e->split_off = false; e->split_registered = 0; e->xch_launches = 0;
   { const char* fa = getenv("AZHIP_XCH_FAIL_AT"); e->xch_fail_at = fa ? atoll(fa) : 0; }
   e->net_loaded = false; e->running = false; e->prof_on = false; { const char* ug = getenv("AZHIP_GRAPH"); e->use_graphs = ug ? atoi(ug) : 0; }
@@ -332,7 +340,8 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     }
     AZCHK(dalloc(e, &v.path, (size_t)G * v.max_depth));
     AZCHK(dalloc(e, &v.leaf_env, G));
-    AZCHK(dalloc(e, &v.eval_slots, G));
+    AZCHK(dalloc(e, &v.eval_slots, (size_t)2 * G)); v.eval_stride = G;
+    AZCHK(dalloc(e, &v.bg_list, (size_t)2 * G)); AZCHK(dalloc(e, &v.bg_cnt, 2 * AZ_MAX_GROUPS));
     AZCHK(dalloc(e, &v.n_eval, 2 * AZ_MAX_GROUPS));
     {
       // side records (state key + Vest, 32 B per node).  Plain pool: dense [G][cap][4].  Mapped-on-demand pool: a second virtual
@@ -391,6 +400,11 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     HIPCHK(hipHostMalloc((void**)&e->h_nleaf, sizeof(int) * AZ_MAX_GROUPS, hipHostMallocMapped));
     for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->h_nleaf[g] = -1;      // nothing reported yet: launches are priced at their upper bound
     HIPCHK(hipHostGetDevicePointer((void**)&e->d_nleaf, e->h_nleaf, 0));
+    // free-running phases: the device's own bookkeeping (FRState) and two host-mapped progress words
+    AZCHK(dalloc(e, &e->d_fr, 1)); AZCHK(dalloc(e, &e->d_bg_stop, 1)); e->bg_seq = 0; e->bg_signal = false;
+    HIPCHK(hipHostMalloc((void**)&e->h_fr_words, sizeof(int) * 2, hipHostMallocMapped));
+    e->h_fr_words[0] = e->h_fr_words[1] = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&e->d_fr_words, e->h_fr_words, 0));
 
     // staging
     e->io_cap = std::max(G, 4096);
@@ -439,12 +453,12 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       DView gv = v;
       gv.stat = stat_base + (size_t)4 * blk_group * g;
       const size_t o = (size_t)g * Gh;
-      gv.G = Gh;
+      gv.G = Gh; gv.slot0 = (int)o;
       gv.sr += o; gv.game_id += o; gv.move_idx += o;
       gv.worker_sim_id += o; gv.eta += o * gi.APAD;
       gv.ht += o * hs; gv.nodes += o * v.node_stride; gv.path += o * v.max_depth;
       if (gv.slot_cap) gv.slot_cap += o;
-      gv.leaf_env += o; gv.eval_slots += o;
+      gv.leaf_env += o; gv.eval_slots += o; gv.bg_list += o; gv.bg_cnt += 2 * g;
       if (gv.ec) { gv.ec_claim += 2 * o; gv.Phit += o * gi.APAD; gv.Vhit += o; }
       gv.xerr = e->d_xerr + g; gv.skipped = e->d_skipped + 2 * g;
       if (e->tree_sort) {                                            // group-relative order, identity until the first move step
@@ -454,8 +468,16 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       gv.nleaf_host = e->d_ec ? e->d_nleaf + g : nullptr;            // only the evaluation cache makes a wave's network batch differ from its active slots
       gv.n_eval += 2 * g; gv.keys += o * v.key_stride; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;
-      if (ng == 1) { e->gs[g] = e->gt[g] = e->stream; }
-      else {
+      if (ng == 1) {
+        e->gs[g] = e->gt[g] = e->stream;
+        // a free-running phase runs the group's tree kernels under its own network launch: two streams for that (az_selfplay_begin / _end)
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&e->fr_s[0], hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&e->fr_s[1], hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&e->fr_s[2], hipStreamNonBlocking, hi));
+        for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&e->fr_ev[i], hipEventDisableTiming));
+      } else {
         // the short latency-bound tree kernels must not queue behind the other group's tower workgroups:
         // they get the high-priority queue, the tower the normal one
         int lo = 0, hi = 0;
@@ -955,12 +977,47 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
   const int G = v.G;
   const int gb = (G * L + 255) / 256;
   const int par = (e->wave_par[g] ^= 1);
-  LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_tree<Gm>), gb, 256, 0, v, e->p, e->pending[g] ? 1 : 0, 1, par);
+  e->stats.slot_launches += e->group_active[g];                     // (the host's count: as of its last look in a free-running phase)
+  LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_tree<Gm>), gb, 256, 0, v, e->p, (e->pending[g] || e->fr_on) ? 1 : 0, 1, par);
   e->pending[g] = true;
+  // One slot group, free-running: the wave's launch, the tower and the heads follow each other on ONE stream (no event between them: a
+  // dependency across streams costs ~10 us, three of them per wave were 3 % of it); the move step and the background search go to a second
+  // stream, behind an event recorded here, and the next wave's launch waits for them.
+  hipStream_t s2 = st;
+  e->bg_signal = false;
+  const bool side = e->fr_on && !split && e->cfg.oracle == AZ_ORACLE_RESNET && e->fr_s[1] && st == e->fr_s[0];
+  if (side) { s2 = e->fr_s[1]; HIPCHK(hipEventRecord(e->fr_ev[0], st)); ++e->bg_seq; e->bg_signal = e->fr_kbg > 0; }
   if (e->cfg.oracle == AZ_ORACLE_RESNET) {
     AZCHK(net_wave(e, g, split, e->group_active[g]));
   } else {
     LAUNCH_ON(e, st, AZ_K_SYNTH, G, (k_synth_oracle<Gm>), (G + 255) / 256, 256, 0, v, e->p, sim_idx, par);
+  }
+  if (e->fr_on) {
+    // Under the wave's network launch (the tree stream has not been made to wait for it yet): the slots whose explore! is complete play
+    // their move (and take their next game if it was the last one), then every slot that has no question pending -- it moved just now,
+    // or the wave's launch left it without one -- searches on in the background; what it finds joins the NEXT wave's batch.
+    FRArgs fa;
+    fa.st = e->d_fr; fa.done = e->d_done; fa.done_off = e->d_done_off;
+    fa.recs = e->d_phase ? e->d_phase : e->d_stage; fa.recs_cap = e->d_phase ? (long long)e->phase_cap : (long long)e->v.G * e->v.max_moves;
+    fa.done_cap = e->done_cap; fa.total_games = e->total_games; fa.first_game_id = (uint32_t)e->first_game_id; fa.group = g; fa.host_words = e->d_fr_words;
+    static const int bg_prio = getenv("AZHIP_BG_PRIO") ? atoi(getenv("AZHIP_BG_PRIO")) : 0;   // A/B aid: 3 = the background launches keep the wave launches' priority
+    // (side streams: the move step and the background search touch different slots -- explore! complete / still searching -- and run
+    // side by side: one serial move under a busy tower takes 0.4 ms, which the background search would otherwise wait out)
+    hipStream_t s3 = side ? e->fr_s[2] : s2;
+    if (side) { HIPCHK(hipStreamWaitEvent(s2, e->fr_ev[0], 0)); HIPCHK(hipStreamWaitEvent(s3, e->fr_ev[0], 0)); }
+    { DView mv = v; mv.low_prio = bg_prio ? 0 : 1; LAUNCH_ON(e, s3, AZ_K_MOVE, G, (k_move_fr<Gm>), (G + 255) / 256, 256, 0, mv, e->p, fa); }
+    if (e->fr_kbg > 0) {
+      AZCHK(ec_next_launch(e, &e->gv[g]));
+      DView bv = e->gv[g];
+      bv.run_k = e->fr_kbg; bv.low_prio = bg_prio ? 0 : 1;
+      if (side) { bv.bg_stop = e->d_bg_stop; bv.bg_seq = e->bg_seq; }   // ... until the wave's tower has run (net_impl.h sets the word)
+      LAUNCH_ON(e, s2, AZ_K_EXPAND, G, (k_tree<Gm>), gb, 256, 0, bv, e->p, 0, 1, par ^ 1);
+    }
+    if (side) {
+      HIPCHK(hipEventRecord(e->fr_ev[1], s2)); HIPCHK(hipStreamWaitEvent(st, e->fr_ev[1], 0));
+      HIPCHK(hipEventRecord(e->fr_ev[2], s3)); HIPCHK(hipStreamWaitEvent(st, e->fr_ev[2], 0));
+    }   // the next wave's launch finds the slots' state settled
+    else if (split && e->cfg.oracle == AZ_ORACLE_RESNET) HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0));   // the next wave's launch needs this wave's answers
   }
   return AZ_OK;
 }
@@ -990,7 +1047,10 @@ template <class Gm> static int recover_split(az_engine* e) {
   }
   if (e->cfg.oracle == AZ_ORACLE_RESNET)
     for (int g = 0; g < e->ngroups; ++g)
-      if (e->pending[g] && e->group_active[g] > 0) AZCHK(net_wave(e, g, e->gs[g] != e->gt[g], e->group_active[g]));
+      if (e->pending[g] && e->group_active[g] > 0) {
+        AZCHK(net_wave(e, g, e->gs[g] != e->gt[g], e->group_active[g]));
+        if (e->fr_on && e->gs[g] != e->gt[g]) HIPCHK(hipStreamWaitEvent(e->gs[g], e->ev_net[g], 0));   // (a free-running wave_group waits at its end; this launch has none)
+      }
   for (int g = 0; g < e->ngroups; ++g)
     for (int i = 0; i < skipped[2 * g]; ++i) AZCHK(wave_group<Gm>(e, g, 0));
   return AZ_OK;
@@ -1074,6 +1134,7 @@ static int reset_wave_state(az_engine* e) {
   AZCHK(sync_groups(e));
   hipLaunchKernelGGL(k_slot_records, dim3((e->v.G + 255) / 256), dim3(256), 0, e->stream, e->v, (int)SR_CLEAR_LEAF);
   HIPCHK(hipMemsetAsync(e->v.n_eval, 0, sizeof(int) * 2 * AZ_MAX_GROUPS, e->stream));
+  HIPCHK(hipMemsetAsync(e->v.bg_cnt, 0, sizeof(int) * 2 * AZ_MAX_GROUPS, e->stream));
   for (int g = 0; g < AZ_MAX_GROUPS; ++g) { e->pending[g] = false; e->wave_par[g] = 0; }
   return AZ_OK;
 }
@@ -1281,6 +1342,47 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
   e->active_slots = n0;
   for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->group_active[g] = 0;
   for (int i = 0; i < n0; ++i) e->group_active[i / e->gv[0].G]++;
+  {
+    // free-running or lock step (az_engine_cfg.lock_step; AZHIP_FREE_RUN=0|1 overrides).  Always lock step: the rollout oracle (its
+    // answer is keyed by the simulation's index in the wave sequence), hipGraph replay (fixed launch sequences), the depth-ordering experiment
+    const char* fr = getenv("AZHIP_FREE_RUN");
+    const bool want = fr ? atoi(fr) != 0 : e->cfg.lock_step == 0;
+    const bool on = want && e->cfg.oracle != AZ_ORACLE_ROLLOUT && !e->use_graphs && !e->tree_sort;
+    const char* rk = getenv("AZHIP_RUN_K"); const char* rw = getenv("AZHIP_FR_ROUND");
+    const char* rb = getenv("AZHIP_RUN_KBG");
+    // wave launch: up to 3 simulations per slot (it is on the wave's critical path: 35 / 50 / 62 / 75 us for 1 / 2 / 3 / 4 at 4096 slots);
+    // background launch: one slot group -- up to 32 more, or until the tower has run (the stop word); several groups -- a few (it runs on
+    // the group's tree stream, ahead of the next wave's launch).  profiles/r6/README.md has the sweeps.
+    e->fr_k = std::max(1, rk ? atoi(rk) : 3);
+    e->fr_kbg = std::max(0, rb ? atoi(rb) : (e->ngroups == 1 ? 32 : 8));
+    e->fr_round_waves = std::max(1, rw ? atoi(rw) : 128);
+    if (on) {
+      const int want_cap = num_games > 0 ? num_games : G;
+      if (want_cap > e->done_cap) {
+        if (e->d_done) (void)hipFree(e->d_done);
+        if (e->d_done_off) (void)hipFree(e->d_done_off);
+        e->d_done = nullptr; e->d_done_off = nullptr; e->done_cap = 0;
+        HIPCHK(hipMalloc((void**)&e->d_done, sizeof(az_game_rec) * (size_t)want_cap));
+        HIPCHK(hipMalloc((void**)&e->d_done_off, sizeof(long long) * (size_t)want_cap));
+        e->done_cap = want_cap;
+      }
+      if (num_games < 0) e->done_cap = std::min(e->done_cap, G);     // an unbounded phase's staging area holds G games' records
+      FRState fs;
+      memset(&fs, 0, sizeof fs);
+      fs.next_game = e->next_game;
+      for (int g = 0; g < AZ_MAX_GROUPS; ++g) fs.active[g] = e->group_active[g];
+      HIPCHK(hipMemcpyAsync(e->d_fr, &fs, sizeof fs, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      e->h_fr_words[0] = 0; e->h_fr_words[1] = n0;
+      e->fr_prev_done = 0; e->fr_prev_recs = 0; e->fr_since_round = 0; e->fr_given_up = 0;
+    }
+    for (int g = 0; g < e->ngroups; ++g) { e->gv[g].run_k = on ? e->fr_k : 0; e->gv[g].fr_active = on ? &e->d_fr->active[g] : nullptr; }
+    if (on && e->ngroups == 1 && e->cfg.oracle == AZ_ORACLE_RESNET) {   // tree kernels under the group's own network launch: two streams (ev_* with them)
+      HIPCHK(hipStreamSynchronize(e->stream));
+      e->gs[0] = e->gt[0] = e->fr_s[0];                                // (the second stream, fr_s[1], carries the move step and the background search: wave_group)
+    }
+    e->fr_on = on;
+  }
   split_register(e, e->ngroups);
   e->p.retire = 1;                                                  // an overflowing slot is retired, the phase goes on; set only once
                                                                     // nothing can fail any more (the hooks must never see it: ADVICE r3)
@@ -1385,9 +1487,109 @@ template <class Gm> static int move_round(az_engine* e) {
   return vm_grow(e, e->p.nsims + 2);                                 // chunks for the next explore! of every slot
 }
 
+// Free-running phase: what the host still does, every fr_round_waves waves and at the end of every az_selfplay_step -- wait for the
+// device, fetch the games that ended since its last look (game records and, if the caller wants host traces, their move records),
+// deal with retired slots (replacement games), back the node-pool chunks the slots will reach before the next look.
+template <class Gm> static int fr_round(az_engine* e) {
+  const int G = e->v.G;
+  e->fr_since_round = 0;
+  AZCHK(sync_groups(e));
+  if (e->xch_epoch && !e->split_off) {                              // split towers have run: did one give up? (the word is only valid once the device is idle)
+    AZCHK(sync_all(e));
+    if (*(volatile int*)e->h_xflag) { AZCHK(recover_split<Gm>(e)); AZCHK(sync_all(e)); }
+  }
+  FRState fs;
+  HIPCHK(hipMemcpyAsync(&fs, e->d_fr, sizeof fs, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_finished.data(), e->v.finished, sizeof(int) * G, hipMemcpyDeviceToHost, e->stream));
+  AZCHK(check_device_error(e));   // synchronises
+  bool dirty = false;
+  const int done = (int)(fs.resv >> 40);
+  const long long nrec = (long long)(fs.resv & ((1ULL << 40) - 1));
+  const int nd = done - e->fr_prev_done;
+  if (nd > 0) {
+    e->h_done.resize(nd); e->h_done_off.resize(nd);
+    HIPCHK(hipMemcpyAsync(e->h_done.data(), e->d_done + e->fr_prev_done, sizeof(az_game_rec) * nd, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_done_off.data(), e->d_done_off + e->fr_prev_done, sizeof(long long) * nd, hipMemcpyDeviceToHost, e->stream));
+    const size_t m0 = e->q_moves.size();
+    const long long nm = nrec - e->fr_prev_recs;
+    const bool to_host = (e->host_moves || !e->d_phase) && nm > 0;
+    if (to_host) {
+      e->q_moves.resize(m0 + (size_t)nm);
+      const az_move_rec* src = (e->d_phase ? e->d_phase : e->d_stage) + e->fr_prev_recs;
+      HIPCHK(hipMemcpyAsync(e->q_moves.data() + m0, src, sizeof(az_move_rec) * (size_t)nm, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < nd; ++i) {
+      az_game_rec g = e->h_done[i];
+      g.first_move = (int32_t)((long long)m0 + e->h_done_off[i] - e->fr_prev_recs);
+      if (e->d_phase) { e->ph_games.push_back(g); e->ph_off.push_back(e->h_done_off[i]); }
+      e->q_games.push_back(g);
+      e->games_done++;
+      e->stats.games++;
+    }
+    if (e->d_phase) e->phase_n = nrec;
+  }
+  e->fr_prev_done = done; e->fr_prev_recs = nrec;
+  e->stats.moves = fs.moves;
+  if (e->total_games >= 0) fs.next_game = std::min(fs.next_game, e->total_games);   // slots that asked in vain pushed the counter past the end
+  e->next_game = fs.next_game;
+  // retired slots (node pool or move records full; the kernels have taken them out of the counts): reported as aborted; the slot
+  // plays ONE replacement game, or the next game, with an empty tree -- as in lock step (move_round)
+  std::vector<int> aslots, aslots_refill;
+  std::vector<uint32_t> agids;
+  for (int sl = 0; sl < G; ++sl) if (e->h_finished[sl] == 2) aslots.push_back(sl);
+  if (!aslots.empty()) {
+    std::vector<uint32_t> gid(G);
+    HIPCHK(hipMemcpyAsync(gid.data(), e->v.game_id, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int sl : aslots) {
+      const int32_t id = (int32_t)gid[sl];
+      e->aborted_ids.push_back(id);
+      e->stats.aborted_games++;
+      if (!(id & AZ_REPLACEMENT_GAME_BIT)) {
+        aslots_refill.push_back(sl); agids.push_back((uint32_t)(id | AZ_REPLACEMENT_GAME_BIT));
+        fs.active[sl / e->gv[0].G]++;
+        continue;
+      }
+      e->games_done++; e->fr_given_up++;                             // the replacement overflowed too: given up, counted, reported
+      if (more_games(e)) {
+        aslots_refill.push_back(sl); agids.push_back((uint32_t)(e->first_game_id + e->next_game++));
+        fs.active[sl / e->gv[0].G]++;
+      }
+    }
+    fs.next_game = e->next_game;
+    HIPCHK(hipMemsetAsync(e->v.finished, 0, sizeof(int) * G, e->stream));
+    AZCHK(start_games<Gm>(e, aslots_refill, agids, nullptr, 1, 1));  // a retired slot starts over with an empty tree
+    dirty = true;
+  }
+  if (!e->d_phase && (done > 0 || nrec > 0)) {                      // unbounded phase: the staging area has been drained
+    fs.resv = 0; e->fr_prev_done = 0; e->fr_prev_recs = 0; dirty = true;
+  }
+  if (dirty) {
+    HIPCHK(hipMemcpyAsync(e->d_fr, &fs, sizeof fs, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  e->active_slots = 0;
+  for (int g = 0; g < AZ_MAX_GROUPS; ++g) { e->group_active[g] = g < e->ngroups ? std::max(0, fs.active[g]) : 0; e->active_slots += e->group_active[g]; }
+  e->h_fr_words[0] = e->fr_prev_done; e->h_fr_words[1] = e->active_slots;
+  return vm_grow(e, e->fr_round_waves * e->fr_k + 2);               // a slot adds at most run_k nodes per wave
+}
+template <class Gm> static int fr_step(az_engine* e, int nwaves) {
+  for (int w = 0; w < nwaves; ++w) {
+    if (e->active_slots == 0) break;
+    // the device's own progress words, one wave late and read without synchronising: every game played, or nobody left searching?
+    const int seen_done = ((volatile int*)e->h_fr_words)[0], seen_active = ((volatile int*)e->h_fr_words)[1];
+    if (seen_active == 0 || (e->total_games > 0 && e->d_phase && seen_done + e->fr_given_up >= e->total_games)) break;
+    AZCHK(wave<Gm>(e, e->ngroups, 0));
+    if (++e->fr_since_round >= e->fr_round_waves) AZCHK(fr_round<Gm>(e));
+  }
+  return fr_round<Gm>(e);                                           // the call returns with the device idle and every finished game collectable
+}
+
 extern "C" int az_selfplay_step(az_engine* e, int32_t nwaves) {
   ENGINE(e);
   if (!e->running) return fail(AZ_ERR_STATE, "az_selfplay_begin has not been called");
+  if (e->fr_on) { DISPATCH_GAME(e->cfg.game, AZCHK(fr_step<Gm>(e, nwaves))); return AZ_OK; }
   for (int w = 0; w < nwaves;) {
     if (e->active_slots == 0) break;
     const int chunk = std::min(nwaves - w, e->p.nsims - e->wave_in_move);      // up to the next move step
@@ -1475,6 +1677,12 @@ extern "C" int az_selfplay_end(az_engine* e) {
   HIPCHK(hipStreamSynchronize(e->stream));
   e->running = false;
   e->active_slots = 0;
+  e->fr_on = false;
+  for (int g = 0; g < e->ngroups; ++g) { e->gv[g].run_k = 0; e->gv[g].fr_active = nullptr; }
+  if (e->ngroups == 1 && e->gs[0] != e->stream) {                    // back to the engine's one stream
+    HIPCHK(hipStreamSynchronize(e->gs[0])); HIPCHK(hipStreamSynchronize(e->fr_s[1])); HIPCHK(hipStreamSynchronize(e->fr_s[2]));
+    e->gs[0] = e->gt[0] = e->stream;
+  }
   return AZ_OK;
 }
 
@@ -1491,7 +1699,7 @@ extern "C" int az_selfplay_run(az_engine* e, int32_t num_games, int32_t first_ga
   int reported = 0;
   int st = AZ_OK;
   while (e->games_done < num_games) {
-    st = az_selfplay_step(e, e->p.nsims);
+    st = az_selfplay_step(e, e->fr_on ? e->fr_round_waves : e->p.nsims);
     if (st != AZ_OK) break;
     if (cb) for (; reported < e->games_done; ++reported) cb(user);   // game_simulated()
   }

@@ -58,7 +58,7 @@ inline bool game_info(int gid, GameInfo* gi) {
 }
 
 // ------------------------------------------------------------------------------- engine
-static constexpr int AZ_MAX_GROUPS = 4;
+// AZ_MAX_GROUPS: tree.h
 struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; };
 struct az_engine {
   az_engine_cfg cfg;
@@ -137,6 +137,16 @@ struct az_engine {
   bool pending[AZ_MAX_GROUPS];       // the group's last wave awaits its expand + backup (flush_pending)
   int wave_par[AZ_MAX_GROUPS];       // parity of the group's last wave: which of its two leaf counters is current
   int group_active[AZ_MAX_GROUPS];   // active slots per slot group (host count; bounds the leaves of a network launch)
+  // (r6) free-running phases (az_engine_cfg.lock_step = 0; tree.h k_tree / k_move_fr): the device hands out game ids and writes
+  // finished games into the phase buffer itself; the host looks every fr_round_waves waves (fr_round, azhip.hip)
+  bool fr_on;                        // the phase in progress is free-running
+  int fr_k, fr_kbg, fr_round_waves;  // simulations a slot may select per wave launch / per background launch (DView::run_k); waves between two looks of the host
+  hipStream_t fr_s[3]; hipEvent_t fr_ev[3];   // one slot group: the tree / network streams and events of its free-running phases (gs[0] / gt[0] / ev_* point at them meanwhile)
+  FRState* d_fr; az_game_rec* d_done; long long* d_done_off; int done_cap;
+  int* d_bg_stop; int bg_seq; bool bg_signal;   // the background search's stop word: set to bg_seq on the wave's stream once its tower has run (bg_signal: this wave has one)
+  int* h_fr_words; int* d_fr_words;  // host-mapped: finished games / searching slots as of the previous wave (FRArgs::host_words)
+  int fr_prev_done, fr_since_round, fr_given_up; long long fr_prev_recs;
+  std::vector<az_game_rec> h_done; std::vector<long long> h_done_off;
   std::vector<az_game_rec> q_games;
   std::vector<az_move_rec> q_moves;
   // device-resident records of the current phase (az_selfplay_run / begin with num_games > 0): the move records of every
@@ -174,6 +184,7 @@ inline int sync_groups(az_engine* e) {
     HIPCHK(hipStreamSynchronize(e->gt[g]));
     HIPCHK(hipStreamSynchronize(e->gs[g]));
   }
+  if (e->fr_on && e->fr_s[1]) { HIPCHK(hipStreamSynchronize(e->fr_s[1])); HIPCHK(hipStreamSynchronize(e->fr_s[2])); }   // one slot group, free-running: the side stream (move step, background search)
   return AZ_OK;
 }
 inline int sync_all(az_engine* e) {

@@ -280,6 +280,7 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   // -- and picks its tower kernel -- for what is left, not for the group's capacity)
   const int N = std::max(1, std::min(G, nmax));
   const int* nev = v.n_eval + e->wave_par[g];                      // the leaf counter of this wave (k_tree)
+  const int* const eslots = v.eval_slots + (size_t)e->wave_par[g] * v.eval_stride;   // ... and its batch -> slot list
   // how many boards the launch will really hold: with the evaluation cache answering part of every wave, what the device
   // reported for the group's last completed wave (+ 1/8: a launch priced too small costs more than one priced too large)
   int npick = N;
@@ -291,32 +292,38 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
     constexpr int TBb = T16B<Gm, F>::TB, THRb = T16B<Gm, F>::THREADS, LDSb = T16B<Gm, F>::BYTES, TBb3 = T16B<Gm, F, NTS<Gm>>::TB, LDSb3 = T16B<Gm, F, NTS<Gm>>::BYTES;
     if (tw == 22) {
       constexpr int TB22 = T16B<Gm, F, 22>::TB, LDS22 = T16B<Gm, F, 22>::BYTES;
-      if constexpr (F == 128) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 22>), (N + TB22 - 1) / TB22, THRb, LDS22, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
-    } else if (tw == 3) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, NTS<Gm>>), (N + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
-    else LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 11>), (N + TBb - 1) / TBb, THRb, LDSb, e->net16b, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+      if constexpr (F == 128) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 22>), (N + TB22 - 1) / TB22, THRb, LDS22, e->net16b, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+    } else if (tw == 3) LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, NTS<Gm>>), (N + TBb3 - 1) / TBb3, THRb, LDSb3, e->net16b, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+    else LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16b<Gm, F, false, 11>), (N + TBb - 1) / TBb, THRb, LDSb, e->net16b, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   } else if (tw == 2) {
     if constexpr (F == 128) {
       unsigned long long* xa; unsigned long long ep;
       AZCHK(xch_slot<Gm>(e, e->g_hfeat[g], &xa, &ep));
-      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16s<Gm, F, false>), 2 * ((N + TB3 - 1) / TB3), (T16S<Gm, F>::THREADS), LDS3, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g],
+      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16s<Gm, F, false>), 2 * ((N + TB3 - 1) / TB3), (T16S<Gm, F>::THREADS), LDS3, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g],
                 xa, ep, v.xerr, e->d_xflag);
     }
   } else if (tw == 21) {
     if constexpr (F == 64)
-      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   } else if (tw == 7) {
     if constexpr (NTM<Gm> > 0) {
       using TM = T16<Gm, F, NTM<Gm>>;
-      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, NTM<Gm>>), (N + TM::TB - 1) / TM::TB, THR16, (TM::BYTES), e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, NTM<Gm>>), (N + TM::TB - 1) / TM::TB, THR16, (TM::BYTES), e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
     }
   } else if (tw == 3)
-    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, NTS<Gm>>), (N + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false, NTS<Gm>>), (N + TB3 - 1) / TB3, THR16, LDS3, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   else if (tw == 16)
-    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false>), (N + TB16 - 1) / TB16, THR16, LDS16, e->net16, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16<Gm, F, false>), (N + TB16 - 1) / TB16, THR16, LDS16, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
   else
-    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower<Gm, F, false>), (N + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
-  if (split) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
-  AZCHK((launch_heads<Gm, F>(e, st, e->g_hfeat[g], v.leaf_env, v.eval_slots, nev, N, (const float*)nullptr, v.Pout, v.Vout, (float*)nullptr, L)));
+    LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower<Gm, F, false>), (N + TB - 1) / TB, TowerCfg<F>::THREADS, TowerLds<F>::BYTES, e->net, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+  // Free-running phase: the heads follow the tower on the network stream and the tree stream is NOT made to wait here -- the caller
+  // (wave_group, azhip.hip) first queues the group's move step and its background search behind k_tree, then the wait for ev_net: both
+  // run under this tower.
+  const bool fr = e->fr_on && split;
+  if (e->bg_signal) hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, sn, e->d_bg_stop, e->bg_seq);   // the tower has run: the background search of this wave winds up while the heads run
+  if (split && !fr) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
+  AZCHK((launch_heads<Gm, F>(e, fr ? sn : st, e->g_hfeat[g], v.leaf_env, eslots, nev, N, (const float*)nullptr, v.Pout, v.Vout, (float*)nullptr, L)));
+  if (fr) HIPCHK(hipEventRecord(e->ev_net[g], sn));
   return AZ_OK;
 }
 template <class Gm> static int wave_net(az_engine* e, int g, bool split, int nmax) {

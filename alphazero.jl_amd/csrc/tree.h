@@ -50,13 +50,15 @@ struct DParams {
 // written per slot and wave, of which 4 to 24 bytes each were used -- is one 64-byte record: two sectors.
 //   root_a / root_b / root_fin   the live game (GI state of the root, play.jl:299-313)
 //   tot_sims / tot_trav          MCTS.Env.total_simulations / total_nodes_traversed (mcts.jl:128-130)
-//   leaf_kd                      pending leaf: kind (LEAF_*) | depth << 2
+//   leaf_kd                      pending leaf: kind (LEAF_*) | depth << 2 | (free-running) parity of the evaluation batch it is in << 30
 //   eidx                         slot -> index in the evaluation batch
 //   node_count                   length(env.tree)
 //   epoch                        live epoch of the slot's hash table (MCTS.reset! is a new epoch)
 //   leaf_ins                     table position the pending leaf will take
 //   root_idx                     node index of the current root, -1 = not looked up yet this move
-//   active                       the slot searches
+//   active                       bit 0 (SR_ACTIVE): the slot searches; bits 8.. (round 6, free-running phases only): simulations of the
+//                                current explore! that are complete -- at num_iters_per_turn the slot waits for k_move_fr
+enum { SR_ACTIVE = 1, SR_MS_SHIFT = 8 };
 struct alignas(64) SlotRec {
   unsigned long long root_a, root_b;
   long long tot_sims, tot_trav;
@@ -123,7 +125,12 @@ struct DView {
                             // 1: phase B waits for them and drops the CU's L1 copy, 2: only drops the copy -- an experiment, see k_tree)
   unsigned long long* path;
   GEnv* leaf_env;         // [G] state of the slot's pending leaf (read by the network kernels through eval_slots)
-  int* eval_slots;        // evaluation batch -> slot
+  int* eval_slots;        // [2][eval_stride] evaluation batch -> slot, double-buffered by wave parity like n_eval (a free-running phase's
+                          // background search adds to the NEXT wave's batch while the network reads this wave's)
+  int eval_stride;
+  const int* bg_stop; int bg_seq;   // background launch: leave when *bg_stop >= bg_seq -- the host's stream sets the word when the wave's tower has run (NULL: run to run_k)
+  int* bg_list; int* bg_cnt; // free-running: [2][eval_stride] / [2] the slots a wave's launch left without a question for the network (by wave parity):
+                          // the background launch that follows serves exactly these -- a handful of wavefronts instead of one per 8 slots
   int* n_eval;            // [2] leaves of the wave, double-buffered by wave parity (k_tree zeroes the other one)
   float* Pout;            // [n_eval][APAD] masked-normalised priors, full width
   float* Vout;            // [n_eval]
@@ -137,6 +144,32 @@ struct DView {
   long long* stat;        // [workgroups of k_tree][4]: simulations, nodes traversed, leaf evals, spare -- accumulated per workgroup
   unsigned long long* dbg; // optional [16] cycle stamps of k_tree's first wavefront (az_debug_tree_stamps): start, phase A done,
                           // root loaded, descent done, leaf stored, block atomics done, end
+  // (round 6) free-running phases (az_selfplay_*): a slot does not wait for the other slots' simulations.  One k_tree launch carries
+  // a slot through up to run_k simulations -- every one that ends on a terminal state or on a state the evaluation cache answers is
+  // completed on the spot -- until it needs the network (a cache miss), has done num_iters_per_turn of them (k_move_fr then plays its
+  // move, whatever the other slots are doing) or reaches run_k.  0 = lock step: one simulation per slot and launch, moves in rounds.
+  int run_k;
+  int low_prio;           // 1: a background launch -- it must not take issue slots from the network launch it runs under (no s_setprio)
+  int slot0;              // engine-wide index of this view's first slot (az_game_rec.slot)
+  int* fr_active;         // free-running: the view's count of searching slots (FRState::active[group]), or NULL
+};
+
+// Device words of a free-running phase (k_move_fr and k_tree write, the host reads at its synchronisation points).
+static constexpr int AZ_MAX_GROUPS = 4;
+struct FRState {
+  unsigned long long resv;          // finished games << 40 | move records written to the phase buffer: reserved together by one CAS
+  long long moves;                  // moves played (az_selfplay_stats.moves)
+  int next_game;                    // index (from first_game_id) of the next game to hand out (Util.mapreduce's `next`, util.jl:169-200)
+  int active[AZ_MAX_GROUPS];        // slots of each slot group that search
+};
+struct FRArgs {
+  FRState* st;
+  az_game_rec* done; long long* done_off;   // [done_cap] records of the finished games in finishing order, offset of each one's first move record
+  az_move_rec* recs; long long recs_cap;    // the phase buffer (bounded phase) or the staging area the host drains (unbounded)
+  int done_cap, total_games;                // total_games < 0: refill forever
+  uint32_t first_game_id;
+  int group;
+  int* host_words;                          // host-mapped [2]: finished games, searching slots -- as of the previous wave; the host looks without synchronising
 };
 
 // Node record: N i32[A] | P f32[A] | W f64[A] | LO u16[A] | HI, padded to a multiple of 32 B.  With A = 7 that is
@@ -321,30 +354,40 @@ template <class Gm> __device__ inline void set_link(char* nd, int act, uint32_t 
 
 // =========================================================================================
 // k_tree: ONE kernel per search wave and slot group.
-//   phase A (do_backup): the second half of the previous wave's run_simulation! -- init_state_info for the new leaf
-//           with the oracle's answer (mcts.jl:157-161, util.jl:98-110), update_state_info! along the path
-//           (mcts.jl:190-194, 218-223)
-//   phase B (do_select): the descent of this wave's run_simulation! (mcts.jl:199-217) until an unseen or a terminal
-//           state, and the compaction of the new leaves into the evaluation batch (Batchifier.launch_server,
-//           batchifier.jl:47-81; the batch order is arbitrary -- test-mode evaluations are independent, Appendix A.13)
+//   phase A (do_backup): the second half of a run_simulation! -- init_state_info for the new leaf with the oracle's answer
+//           (mcts.jl:157-161, util.jl:98-110), update_state_info! along the path (mcts.jl:190-194, 218-223)
+//   phase B (do_select): the descent of the next run_simulation! (mcts.jl:199-217) until an unseen or a terminal state, and the
+//           compaction of the new leaves into the evaluation batch (Batchifier.launch_server, batchifier.jl:47-81; the batch order
+//           is arbitrary -- test-mode evaluations are independent, Appendix A.13)
 // The network runs between two launches; the last simulation of an explore! is completed by a launch with do_select = 0.
+// Lock step (DView::run_k = 0): one A and one B per slot and launch -- a wave is one simulation of every slot.
+// Free-running (run_k > 0, round 6): A, B, A, B ... inside the launch for as long as the slot's simulations end on a terminal state or on
+// a state the evaluation cache answers, i.e. until the slot really has a question for the network (or has finished its explore!, or
+// has selected run_k times).  A worker of the reference runs its simulations one after the other and independently of the other
+// workers (mcts.jl:239-245, simulations.jl:216-243) and the oracle is a pure function of the state, so the slot's sequence of
+// simulations -- and with it every record -- is the same; what changes is that a wave's network batch holds one board of EVERY
+// searching slot instead of the 44 % of them whose simulation happened to need one.
 // APAD lanes per slot (lane = action).  Dependent loads: phase A path -> statistics of the path's nodes (all at once,
 // one lane per ply); phase B one node record per ply (child links), a table probe only on edges never taken before.
 // =========================================================================================
+struct KArgs { DView v; DParams p; };   // the head of k_tree's kernarg segment
 template <class Gm>
-__global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_backup, int do_select, int par) {   // 6 waves per SIMD = 80 VGPRs: fits beside two tower waves (2 x 176 + 80 of 512)
-  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_tree(DView v_arg, DParams p_arg, int do_backup, int do_select, int par) {   // at most 160 VGPRs: one wavefront still fits beside two tower waves on a SIMD (2 x 176 + 160 of 512)
+  if (!v_arg.low_prio) __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel on the wave's critical path: win issue arbitration against co-resident tower waves
+  const DView& v = v_arg;
   constexpr int L = Gm::APAD;
   using NL = NodeL<Gm>;
-  __shared__ int s_new[4], s_hit[4], s_sims[4], s_trav[4], s_base;   // (workgroups of 1024 threads -- a quarter of the returning atomics -- gain 10 % at 64 k slots and lose 30 % at 256 k and 1 M)
+  __shared__ int s_new[4], s_hit[4], s_evl[4], s_sims[4], s_trav[4], s_need[4], s_base, s_nbase;   // (workgroups of 1024 threads -- a quarter of the returning atomics -- gain 10 % at 64 k slots and lose 30 % at 256 k and 1 M)
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int lgrp = tid / L, lane = tid % L;
   const int wl = threadIdx.x & 63, w = threadIdx.x >> 6, gbase = wl & ~(L - 1);
-  const bool live = lgrp < v.G;
-  // which slot this lane group advances: its own index, or (AZHIP_TREE_SORT) the slot the last move step's ordering put here
-  const int slot = (live && v.perm) ? v.perm[lgrp] : lgrp;
-  const int pslot = live ? slot : 0;
-  unsigned long long* path = v.path + (size_t)pslot * v.max_depth;
+  // which slot this lane group advances: its own index, (AZHIP_TREE_SORT) the slot the last move step's ordering put here, or -- the
+  // background launch of a free-running phase -- the next entry of the list the wave's launch left
+  int nlive = v.G;
+  const int* map = v.perm;
+  if (v.run_k && !do_backup && v.bg_list) { nlive = v.bg_cnt[par ^ 1]; map = v.bg_list + (size_t)(par ^ 1) * v.eval_stride; }
+  const bool live = lgrp < nlive;
+  const int slot_in = live ? (map ? map[lgrp] : lgrp) : 0;
   const bool links_ok = v.cap_nodes <= LINK_MAX;
   unsigned long long* dbg = (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) ? v.dbg : nullptr;
   if (dbg) dbg[0] = __builtin_readcyclecounter();
@@ -353,58 +396,84 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
   // the split and launches the skipped waves again (azhip.hip recover_split).  Uniform over the grid: the word belongs to this
   // slot group, only the group's own tower (earlier on the same stream order) sets it and only the host clears it, between launches.
   if (__hip_atomic_load(v.xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)DERR_EXCHANGE) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(v.skipped + (do_select ? 0 : 1), 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (do_backup || !v.run_k)) atomicAdd(v.skipped + (do_select ? 0 : 1), 1);   // (a background launch is not a wave)
     return;
   }
 
   // Everything whose address does not depend on another load is requested up front, in one round trip: the pending leaf's
   // kind / depth / batch index, the node count, the first L path entries (one per lane) and, for phase B, the root state and
   // the epoch.  (Inside the branches below they were three dependent rounds: kind -> depth, eidx -> path, Pout.)
-  SlotRec* const sr = v.sr + pslot;
-  const SlotRec s0 = *sr;                                           // 64 bytes, the same for all lanes of the slot
-  unsigned long long st0 = path[lane < v.max_depth ? lane : 0];
-  GEnv lenv0 = v.leaf_env[pslot];
-  int kind0 = s0.leaf_kd & 3, depth0 = s0.leaf_kd >> 2, e0 = s0.eidx, nc0 = s0.node_count;
+  const SlotRec s0 = v.sr[slot_in];                                 // 64 bytes, the same for all lanes of the slot
+  unsigned long long st = (v.path + (size_t)slot_in * v.max_depth)[lane < v.max_depth ? lane : 0];   // path entry `lane` of the simulation in hand (phase B keeps it current)
+  GEnv lenv = v.leaf_env[slot_in];                                  // state of its leaf
+  int kind = s0.leaf_kd & 3, depth = (s0.leaf_kd >> 2) & 0x0fffffff, e0 = s0.eidx, nc = s0.node_count;
   GEnv root0 = s0.root();
-  uint32_t epoch0 = s0.epoch, ins0 = s0.leaf_ins;
-  long long trav0 = s0.tot_trav, sims0 = s0.tot_sims;
-  int ridx0 = s0.root_idx, active0 = s0.active;
+  uint32_t epoch0 = s0.epoch, ins = s0.leaf_ins;
+  int ridx = s0.root_idx, active0 = s0.active;
   int claim0 = -1; uint32_t cmeta0 = 0;                             // the pending leaf's cache entry (its answer is stored there), if it holds one
-  if (v.ec) { const int2 c2 = ((const int2*)v.ec_claim)[pslot]; claim0 = c2.x; cmeta0 = (uint32_t)c2.y; }
+  if (v.ec) { const int2 c2 = ((const int2*)v.ec_claim)[slot_in]; claim0 = c2.x; cmeta0 = (uint32_t)c2.y; }
   // (The compiler sinks a load into the branch that uses it, which turned this one round trip into several dependent ones; the
   // values are therefore pinned into registers right here -- one wait for all of them.)
 #define AZ_PIN(x) asm volatile("" : "+v"(x))
-  AZ_PIN(kind0); AZ_PIN(depth0); AZ_PIN(e0); AZ_PIN(nc0); AZ_PIN(st0); AZ_PIN(root0.a); AZ_PIN(root0.b); AZ_PIN(root0.fin);
-  AZ_PIN(epoch0); AZ_PIN(ins0); AZ_PIN(claim0); AZ_PIN(cmeta0); AZ_PIN(lenv0.a); AZ_PIN(lenv0.b); AZ_PIN(lenv0.fin); AZ_PIN(trav0); AZ_PIN(sims0); AZ_PIN(ridx0); AZ_PIN(active0);
-  if (!(do_backup && live)) kind0 = LEAF_NONE;
-  bool retired = false;
-  int new_root = -1;
-  const bool inrecA = lane < Gm::A;
+  AZ_PIN(kind); AZ_PIN(depth); AZ_PIN(e0); AZ_PIN(nc); AZ_PIN(st); AZ_PIN(root0.a); AZ_PIN(root0.b); AZ_PIN(root0.fin);
+  AZ_PIN(epoch0); AZ_PIN(ins); AZ_PIN(claim0); AZ_PIN(cmeta0); AZ_PIN(lenv.a); AZ_PIN(lenv.b); AZ_PIN(lenv.fin); AZ_PIN(ridx); AZ_PIN(active0);
+  // Free-running: which of the slots are this launch's business.  A wave's launch (do_backup) completes the simulations whose leaves
+  // were in the PREVIOUS wave's batch -- the network has answered them -- and selects on; the background launch that follows it
+  // (do_backup = 0, under the wave's network launch) carries on with the slots that have no question pending, and what they find joins the
+  // NEXT wave's batch (`par`): a slot waiting for the network, and in the next wave's launch a slot that is already in the batch being
+  // gathered, is left alone.
+  const bool mine = live && !(v.run_k && kind != LEAF_NONE && (!do_backup || ((s0.leaf_kd >> 30) & 1) == par));
+  if (!(do_backup && mine)) kind = LEAF_NONE;
+  const int nc_in = nc, ridx_in = ridx;
+  const bool inrec = lane < Gm::A;
+  // the oracle's answer to the pending leaf: from the network's batch, or (eidx = -1, lock step only) from the evaluation cache -- the
+  // same bits either way
+  float Pans = 0.f, Vans = 0.f;
+  if (kind == LEAF_NEW) {
+    Pans = e0 >= 0 ? v.Pout[(size_t)e0 * L + lane] : v.Phit[(size_t)slot_in * L + lane];
+    Vans = e0 >= 0 ? v.Vout[e0] : v.Vhit[slot_in];
+  }
+  const bool searching = mine && (active0 & SR_ACTIVE);
+  int msims = active0 >> SR_MS_SHIFT;                               // free-running: simulations of this explore! that are complete
+  int done_sims = 0, done_trav = 0;                                 // completed in this launch (mcts.jl:242, :222)
+  int n_sel = 0, n_trav = 0, n_evl = 0, n_hit = 0;                  // started in this launch: simulations, their depths, oracle calls, of those answered by the cache
+  bool retired = false, ishit = false;
+  int claim = -1; uint32_t cmeta = 0;
 
-  // ------------------------------------------------------------------ phase A: expand + backup
-  if (do_backup && live) {
-    const int kind = kind0;
+  for (int it = 0;; ++it) {
+    // Every iteration reads the kernel's arguments again (scalar loads from the kernarg segment through a pointer the compiler cannot
+    // see through) and recomputes its addresses from a laundered slot index: with the arguments and the per-lane addresses of BOTH phases
+    // loop-invariant the compiler kept all of them in registers across the loop -- 128 VGPRs + 52 bytes of scratch and 102 spilled
+    // SGPRs against 73 / 0 / 4 for the straight-line kernel of round 5.
+    KArgs ka;
+    {
+      auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));
+      __builtin_memcpy(&ka, (const void*)kp, sizeof(KArgs));
+    }
+    const DView& v = ka.v;
+    const DParams& p = ka.p;
+    int slot = slot_in; asm volatile("" : "+v"(slot));
+    unsigned long long* const path = v.path + (size_t)slot * v.max_depth;
+    // ---------------------------------------------------------------- phase A: expand + backup of the simulation in hand
     if (kind != LEAF_NONE) {
-      const int depth = depth0;
       double q = 0.0;                                               // terminal: return 0.
       bool ok = true;
       if (kind == LEAF_NEW) {
-        const int e = e0;
-        const int idx = nc0;
-        if (v.ec && claim0 >= 0) {
+        const int idx = nc;
+        if (it == 0 && v.ec && claim0 >= 0) {
           // this leaf went to the network and holds a cache entry: the answer goes in, for whoever reaches the state next.  The
           // entry is still this claim's iff meta is unchanged (unique per claim) -- taken exclusively, written, published.
           ECEnt* const ent = v.ec + claim0;
-          const float Praw = inrecA ? v.Pout[(size_t)e * L + lane] : 0.f;
-          const float Vraw = v.Vout[e];
+          const float Praw = inrec ? Pans : 0.f;
           const uint32_t fill = (cmeta0 & ~3u) | EC_FILLING, ready = (cmeta0 & ~3u) | EC_READY;
           int got = 0;
           if (lane == 0) got = ec_cas(&ent->meta, cmeta0, fill) ? 1 : 0;
           got = group_bcast0<L>(got, lane);
-          const uint32_t px = group_xor<L>(inrecA ? ec_term(Praw, lane) : 0u);
+          const uint32_t px = group_xor<L>(inrec ? ec_term(Praw, lane) : 0u);
           if (got) {
-            if (inrecA) ec_stf(&ent->P[lane], Praw);
-            if (lane == 0) { ec_stf(&ent->V, Vraw); ec_st32(&ent->cs, ec_checksum(px, lenv0.a, lenv0.b, Vraw, ready)); }
+            if (inrec) ec_stf(&ent->P[lane], Praw);
+            if (lane == 0) { ec_stf(&ent->V, Vans); ec_st32(&ent->cs, ec_checksum(px, lenv.a, lenv.b, Vans, ready)); }
             __builtin_amdgcn_s_waitcnt(0);                           // every lane's stores have been performed ...
             if (lane == 0) ec_st32(&ent->meta, ready);              // ... before the value that lets readers in
           }
@@ -414,13 +483,13 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
           // its game is reported as aborted and the phase goes on; the hooks report a capacity error
           ok = false;
           if (!p.retire) dev_fail(v, DERR_NODE_POOL);
-          else { retired = true; if (lane == 0) { v.finished[slot] = 2; sr->active = 0; sr->leaf_kd = LEAF_NONE; } }
+          else {
+            retired = true;
+            if (lane == 0) { v.finished[slot] = 2; if (v.fr_active) atomicSub(v.fr_active, 1); }
+          }
         } else {
-          const GEnv env = lenv0;
-          const uint32_t m = Gm::mask(env);
-          // the oracle's answer: from the network's batch, or (eidx = -1) from the evaluation cache -- the same bits either way
-          float Pf = e >= 0 ? v.Pout[(size_t)e * L + lane] : v.Phit[(size_t)slot * L + lane];
-          const float V = e >= 0 ? v.Vout[e] : v.Vhit[slot];
+          const uint32_t m = Gm::mask(lenv);
+          float Pf = Pans;
           if (p.prior_temp != 1.0) {                                // Util.apply_temperature, util.jl:98-110
             const bool av = (m >> lane) & 1;
             double res;
@@ -435,10 +504,10 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
             }
             Pf = av ? (float)res : 0.f;
           }
-          if (depth == 0) new_root = idx;
+          if (depth == 0) ridx = idx;
           char* nd = node_at<Gm>(v, slot, idx);
-          // the edge that reached the new node: entry depth - 1 of the path, already in lane depth - 1's register when depth <= L
-          const unsigned long long st_par = (depth >= 1 && depth <= L) ? __shfl(st0, gbase + depth - 1) : (depth > L ? path[depth - 1] : 0ULL);
+          // the edge that reached the new node: entry depth - 1 of the path, in lane depth - 1's register when depth <= L
+          const unsigned long long st_par = (depth >= 1 && depth <= L) ? __shfl(st, gbase + depth - 1) : (depth > L ? path[depth - 1] : 0ULL);
           if (lane < Gm::A) {
             *NL::stat(nd, lane) = typename NL::Stat{0.0, 0, Pf};
             ((uint16_t*)(nd + NL::OFF_LO))[lane] = 0;
@@ -446,18 +515,16 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
           if (lane == 0) {
             *(typename NL::hi_t*)(nd + NL::OFF_HI) = 0;
             unsigned long long* kk = side_at(v, slot, idx);
-            kk[0] = env.a; kk[1] = env.b; kk[2] = (unsigned long long)__float_as_uint(V);
-            const unsigned long long hk = az_hash_key(env.a, env.b);
+            kk[0] = lenv.a; kk[1] = lenv.b; kk[2] = (unsigned long long)__float_as_uint(Vans);
+            const unsigned long long hk = az_hash_key(lenv.a, lenv.b);
             const unsigned long long tag = (hk >> 40) & v.tag_mask;
-            v.ht[(size_t)slot * v.ht_size + ins0] =
+            v.ht[(size_t)slot * v.ht_size + ins] =
                 ((unsigned long long)epoch0 << 48) | (tag << 32) | (unsigned long long)(idx + 1);
-            sr->node_count = idx + 1;
-            if (depth == 0) sr->root_idx = idx;
-            else if (links_ok) {                                    // memoise tree[state] on the edge that reached it
+            if (depth != 0 && links_ok)                             // memoise tree[state] on the edge that reached it
               set_link<Gm>(node_at<Gm>(v, slot, (int)(uint32_t)st_par), (int)((st_par >> 32) & 0xff), (uint32_t)(idx + 1));
-            }
           }
-          q = (double)V;                                            // return info.Vest
+          nc = idx + 1;
+          q = (double)Vans;                                         // return info.Vest
         }
       }
       if (ok) {
@@ -465,10 +532,10 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
         // arithmetic on shuffled path entries, the read-modify-writes of a chunk of L plies go out together
         for (int c = (depth - 1) / L; c >= 0 && depth > 0; --c) {
           const int k0 = c * L, kn = (depth - k0) < L ? (depth - k0) : L;
-          const unsigned long long st = lane < kn ? (c == 0 ? st0 : path[k0 + lane]) : 0ULL;
+          const unsigned long long sc = lane < kn ? (c == 0 ? st : path[k0 + lane]) : 0ULL;
           double qmine = 0.0;
           for (int k = kn - 1; k >= 0; --k) {
-            const unsigned long long sk = __shfl(st, gbase + k);
+            const unsigned long long sk = __shfl(sc, gbase + k);
             const bool psw = (sk >> 40) & 1;
             const double r = (double)((int)((sk >> 41) & 3) - 1);
             q = psw ? -q : q;
@@ -476,10 +543,10 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
             if (lane == k) qmine = q;
           }
           if (lane < kn) {
-            typename NL::Stat* sa = NL::stat(node_at<Gm>(v, slot, (int)(uint32_t)st), (int)((st >> 32) & 0xff));
+            typename NL::Stat* sa = NL::stat(node_at<Gm>(v, slot, (int)(uint32_t)sc), (int)((sc >> 32) & 0xff));
             if (v.bk_mode) {
               // (round 5 experiment, VERDICT r4 #6 ii) the update leaves the dependent chain: one (node, action) record gets exactly
-              // one update per slot and wave, so the sum is the same IEEE add wherever it is performed -- here by L2's atomic unit,
+              // one update per slot and simulation, so the sum is the same IEEE add wherever it is performed -- here by L2's atomic unit,
               // nothing comes back.  Phase B must not read the record from this CU's L1 afterwards (see the fence below).
               unsafeAtomicAdd(&sa->W, qmine);
               __hip_atomic_fetch_add(&sa->N, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -489,156 +556,182 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
             }
           }
         }
-        if (lane == 0) {
-          sr->tot_trav = trav0 + depth;                             // mcts.jl:222
-          sr->tot_sims = sims0 + 1;                                 // mcts.jl:242
+        done_trav += depth;                                         // mcts.jl:222
+        done_sims += 1;                                             // mcts.jl:242
+        msims += v.run_k ? 1 : 0;
+      }
+      kind = LEAF_NONE;                                             // the simulation in hand is complete
+    }
+    if (!do_select) break;
+    if (dbg && it == 0) dbg[1] = __builtin_readcyclecounter();
+    if (v.bk_mode == 0) __threadfence_block();   // phase A's stores (other lanes of the group) are ordered before phase B's loads
+    else if (v.bk_mode == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the atomics have been performed at L2; this CU's L1 copies of the path's lines (set_link read them) are dropped
+    else { __threadfence_block(); asm volatile("buffer_inv sc1" ::: "memory"); }  // experiment: stores ordered, L1 dropped, the atomics NOT waited for (same address = same L2 channel, in order)
+    if (!searching || retired) break;
+    if (v.run_k) { if (msims >= p.nsims || it >= v.run_k) break; }  // explore! complete (k_move_fr is due) / enough for one launch
+    else if (it >= 1) break;
+    if (v.bg_stop && it > 0 && __hip_atomic_load(v.bg_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v.bg_seq >= 0) break;   // background: the network launch it ran under is over
+
+    // ---------------------------------------------------------------- phase B: select
+    {
+      GEnv env = root0;
+      int idx = ridx;
+      bool probe = idx < 0;
+      int pidx = 0, pact = 0;
+      depth = 0; ins = 0; ishit = false;
+      // what a lane holds of a node: its action's statistics (one 16-byte load), its link's low half, the shared high bits
+      typename NL::Stat sa = {0.0, 0, 0.0f};
+      uint32_t lo = 0, hi = 0;
+      bool have = false;                                            // sa / lo / hi already hold node idx (requested a ply ago)
+      for (;;) {
+        if (env.fin & 1) { kind = LEAF_TERMINAL; break; }           // mcts.jl:200-201
+        if (probe) {                                                // haskey(env.tree, state), mcts.jl:165-174
+          idx = ht_lookup<Gm>(v, slot, lane, env.a, env.b, epoch0, &ins);
+          if (idx < 0) { kind = LEAF_NEW; break; }                  // mcts.jl:205-207
+          if (depth == 0) ridx = idx;
+          else if (lane == 0 && links_ok) set_link<Gm>(node_at<Gm>(v, slot, pidx), pact, (uint32_t)(idx + 1));
+          have = false;
+        }
+        if (depth >= v.max_depth) { dev_fail(v, DERR_DEPTH); kind = LEAF_NONE; break; }
+        if (!have) {
+          const char* nd = node_at<Gm>(v, slot, idx);
+          if (inrec) { sa = *NL::stat(nd, lane); lo = ((const uint16_t*)(nd + NL::OFF_LO))[lane]; }
+          hi = *(const typename NL::hi_t*)(nd + NL::OFF_HI);
+        }
+        const uint32_t amask = Gm::mask(env);
+        const int N = sa.N;
+        const float Pf = sa.P;
+        const double W = sa.W;
+        const int link = (int)(lo | (((hi >> (2 * lane)) & 3u) << 16));
+        if (dbg && it == 0 && depth == 0) dbg[2] = __builtin_readcyclecounter() + (unsigned long long)(N & 0);   // after the root record has arrived
+        // uct_scores (mcts.jl:180-188): Float64, evaluated left to right
+        const int Ntot = group_sum<L>(N);
+        const double sqrtNtot = __builtin_sqrt((double)Ntot);
+        const double Q = W / (double)(N > 1 ? N : 1);
+        double Pd = (double)Pf;
+        if (depth == 0 && p.eps != 0.0) Pd = (1.0 - p.eps) * Pd + p.eps * v.eta[(size_t)slot * L + lane];
+        double sc = Q + p.cpuct * Pd * sqrtNtot / (double)(N + 1);
+        if (!((amask >> lane) & 1)) sc = -__builtin_inf();
+        int nxt = link;                                             // the winner's child link travels with the argmax
+        if (dbg && it == 0 && depth == 0) dbg[7] = __builtin_readcyclecounter() + (unsigned long long)(__double2loint(sc) & 0);   // scores of the root ready
+        const int act = group_argmax<L>(sc, lane, &nxt);
+        if (dbg && it == 0 && depth == 0) dbg[8] = __builtin_readcyclecounter() + (unsigned long long)(act & 0);   // argmax done
+        // The child's record is requested NOW, before play! / the terminal test / the path entry: its address needs only the link,
+        // and the ~840 cycles of a dependent load cover that work (round 2 issued it a ply later, after all of it).  A link is
+        // only ever written for a stored state, so the address is valid even if the child turns out to be unreachable because
+        // the game ended (then the data is dropped).
+        have = nxt != 0;
+        if (have) {
+          const char* nd = node_at<Gm>(v, slot, nxt - 1);
+          if (inrec) { sa = *NL::stat(nd, lane); lo = ((const uint16_t*)(nd + NL::OFF_LO))[lane]; }
+          hi = *(const typename NL::hi_t*)(nd + NL::OFF_HI);
+        }
+        const bool wp = Gm::white_playing(env);
+        Gm::play(env, act);                                         // mcts.jl:213-217
+        const float wr = Gm::white_reward(env);
+        const int r = (int)(wp ? wr : -wr);
+        const bool psw = wp != Gm::white_playing(env);
+        const unsigned long long ent = (unsigned long long)(uint32_t)idx | ((unsigned long long)act << 32) |
+                                       ((unsigned long long)(psw ? 1 : 0) << 40) | ((unsigned long long)(r + 1) << 41);
+        if (lane == 0) path[depth] = ent;                           // the stack of run_simulation!'s recursion: in memory for the next launch ...
+        if (lane == depth) st = ent;                                // ... and entry `lane` in a register for this one
+        pidx = idx; pact = act;
+        if (dbg && it == 0 && depth == 0) dbg[9] = __builtin_readcyclecounter() + (env.a & 0);   // play! / reward / path entry of the first ply done
+        depth++;
+        probe = nxt == 0;
+        idx = nxt - 1;
+      }
+      if (dbg && it == 0) dbg[3] = __builtin_readcyclecounter();
+      lenv = env;
+      if (kind != LEAF_NONE) { n_sel += 1; n_trav += depth; }
+      if (kind == LEAF_NEW) {
+        n_evl += 1;
+        if (v.ec) {
+          // oracle(state): has the engine evaluated this state before (for another slot, in an earlier wave)?  One look at the entry.
+          const uint32_t ci = ec_index(env.a, env.b, v.ec_mask);
+          ECEnt* const ent = v.ec + ci;
+          const uint32_t m1 = ec_ld32(&ent->meta);
+          const unsigned long long ka = ec_ld64(&ent->ka), kb = ec_ld64(&ent->kb);
+          const float pl = inrec ? ec_ldf(&ent->P[lane]) : 0.f;
+          const float vv = ec_ldf(&ent->V);
+          const uint32_t cs = ec_ld32(&ent->cs);
+          const uint32_t px = group_xor<L>(inrec ? ec_term(pl, lane) : 0u);
+          const bool okc = (m1 & 3u) == EC_READY && ka == env.a && kb == env.b && cs == ec_checksum(px, ka, kb, vv, m1);
+          ishit = group_bcast0<L>(okc ? 1 : 0, lane) != 0;          // lane 0's verdict (its checksum covers every lane's prior)
+          if (ishit) { Pans = inrec ? pl : 0.f; Vans = vv; n_hit += 1; }   // no network for this leaf
+          else {
+            // the state goes to the network; its answer goes into the cache if the entry can be taken: empty, answered (the older
+            // answer makes room), or a claim so old that its slot has gone away (a phase that ended, a retired slot).  Launches of
+            // other slot groups run side by side and may carry a HIGHER number than this one: a claim "from the future" is fresh
+            // (signed age).
+            claim = -1; cmeta = 0;
+            if (lane == 0) {
+              const int32_t age = (int32_t)(v.ec_seq - (m1 >> 2));
+              if (m1 == 0u || (m1 & 3u) == EC_READY || age > (int32_t)EC_STALE_AFTER) {
+                const uint32_t mine = (v.ec_seq << 2) | EC_PENDING;
+                if (ec_cas(&ent->meta, m1, mine)) { ec_st64(&ent->ka, env.a); ec_st64(&ent->kb, env.b); claim = (int)ci; cmeta = mine; }
+              }
+            }
+          }
         }
       }
     }
-    if (!do_select && lane == 0) sr->leaf_kd = LEAF_NONE;           // the pending simulation has been completed
+    if (kind == LEAF_NONE) break;                                   // a device error was raised
+    if (kind == LEAF_NEW && !ishit) break;                          // the slot has a question for the network
+    if (!v.run_k) break;                                            // lock step: the answer the slot already holds waits for the next launch
+    __threadfence_block();                                          // the path entries lane 0 stored are read by the other lanes' phase A
+  }
+
+  // ------------------------------------------------------------------ the slot's state for the next launch
+  const int slot = slot_in;
+  SlotRec* const sr = v.sr + slot;
+  if (mine && lane == 0) {
+    sr->leaf_kd = kind == LEAF_NONE ? (int)LEAF_NONE : (kind | (depth << 2) | (par << 30));
+    if (do_select && kind != LEAF_NONE) { v.leaf_env[slot] = lenv; sr->leaf_ins = ins; }
+    if (nc != nc_in) sr->node_count = nc;
+    if (ridx != ridx_in) sr->root_idx = ridx;
+    if (done_sims) { sr->tot_trav += done_trav; sr->tot_sims += done_sims; }   // mcts.jl:222, :242
+    const int aw = retired ? 0 : ((active0 & ((1 << SR_MS_SHIFT) - 1)) | (msims << SR_MS_SHIFT));
+    if (aw != active0) sr->active = aw;
   }
   if (!do_select) return;
-  if (dbg) dbg[1] = __builtin_readcyclecounter();
-  if (v.bk_mode == 0) __threadfence_block();   // phase A's stores (other lanes of the group) are ordered before phase B's loads
-  else if (v.bk_mode == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the atomics have been performed at L2; this CU's L1 copies of the path's lines (set_link read them) are dropped
-  else { __threadfence_block(); asm volatile("buffer_inv sc1" ::: "memory"); }  // experiment: stores ordered, L1 dropped, the atomics NOT waited for (same address = same L2 channel, in order)
-
-  // ------------------------------------------------------------------ phase B: select
-  int depth = 0, kind = LEAF_NONE;
-  bool ishit = false;                                               // the leaf's answer came from the evaluation cache (group-uniform)
-  int claim = -1; uint32_t cmeta = 0;
-  if (live && active0 && !retired) {
-    GEnv env = root0;
-    const uint32_t epoch = epoch0;
-    int idx = new_root >= 0 ? new_root : ridx0;
-    bool probe = idx < 0;
-    uint32_t ins = 0;
-    int pidx = 0, pact = 0;
-    const bool inrec = lane < Gm::A;
-    // what a lane holds of a node: its action's statistics (one 16-byte load), its link's low half, the shared high bits
-    typename NL::Stat sa = {0.0, 0, 0.0f};
-    uint32_t lo = 0, hi = 0;
-    bool have = false;                                              // sa / lo / hi already hold node idx (requested a ply ago)
-    for (;;) {
-      if (env.fin & 1) { kind = LEAF_TERMINAL; break; }             // mcts.jl:200-201
-      if (probe) {                                                  // haskey(env.tree, state), mcts.jl:165-174
-        idx = ht_lookup<Gm>(v, slot, lane, env.a, env.b, epoch, &ins);
-        if (idx < 0) { kind = LEAF_NEW; break; }                    // mcts.jl:205-207
-        if (lane == 0) {
-          if (depth == 0) sr->root_idx = idx;
-          else if (links_ok) set_link<Gm>(node_at<Gm>(v, slot, pidx), pact, (uint32_t)(idx + 1));
-        }
-        have = false;
-      }
-      if (depth >= v.max_depth) { dev_fail(v, DERR_DEPTH); kind = LEAF_NONE; break; }
-      if (!have) {
-        const char* nd = node_at<Gm>(v, slot, idx);
-        if (inrec) { sa = *NL::stat(nd, lane); lo = ((const uint16_t*)(nd + NL::OFF_LO))[lane]; }
-        hi = *(const typename NL::hi_t*)(nd + NL::OFF_HI);
-      }
-      const uint32_t amask = Gm::mask(env);
-      const int N = sa.N;
-      const float Pf = sa.P;
-      const double W = sa.W;
-      const int link = (int)(lo | (((hi >> (2 * lane)) & 3u) << 16));
-      if (dbg && depth == 0) dbg[2] = __builtin_readcyclecounter() + (unsigned long long)(N & 0);   // after the root record has arrived
-      // uct_scores (mcts.jl:180-188): Float64, evaluated left to right
-      const int Ntot = group_sum<L>(N);
-      const double sqrtNtot = __builtin_sqrt((double)Ntot);
-      const double Q = W / (double)(N > 1 ? N : 1);
-      double Pd = (double)Pf;
-      if (depth == 0 && p.eps != 0.0) Pd = (1.0 - p.eps) * Pd + p.eps * v.eta[(size_t)slot * L + lane];
-      double sc = Q + p.cpuct * Pd * sqrtNtot / (double)(N + 1);
-      if (!((amask >> lane) & 1)) sc = -__builtin_inf();
-      int nxt = link;                                               // the winner's child link travels with the argmax
-      if (dbg && depth == 0) dbg[7] = __builtin_readcyclecounter() + (unsigned long long)(__double2loint(sc) & 0);   // scores of the root ready
-      const int act = group_argmax<L>(sc, lane, &nxt);
-      if (dbg && depth == 0) dbg[8] = __builtin_readcyclecounter() + (unsigned long long)(act & 0);   // argmax done
-      // The child's record is requested NOW, before play! / the terminal test / the path entry: its address needs only the link,
-      // and the ~840 cycles of a dependent load cover that work (round 2 issued it a ply later, after all of it).  A link is
-      // only ever written for a stored state, so the address is valid even if the child turns out to be unreachable because
-      // the game ended (then the data is dropped).
-      have = nxt != 0;
-      if (have) {
-        const char* nd = node_at<Gm>(v, slot, nxt - 1);
-        if (inrec) { sa = *NL::stat(nd, lane); lo = ((const uint16_t*)(nd + NL::OFF_LO))[lane]; }
-        hi = *(const typename NL::hi_t*)(nd + NL::OFF_HI);
-      }
-      const bool wp = Gm::white_playing(env);
-      Gm::play(env, act);                                           // mcts.jl:213-217
-      const float wr = Gm::white_reward(env);
-      const int r = (int)(wp ? wr : -wr);
-      const bool psw = wp != Gm::white_playing(env);
-      if (lane == 0)
-        path[depth] = (unsigned long long)(uint32_t)idx | ((unsigned long long)act << 32) |
-                      ((unsigned long long)(psw ? 1 : 0) << 40) | ((unsigned long long)(r + 1) << 41);
-      pidx = idx; pact = act;
-      if (dbg && depth == 0) dbg[9] = __builtin_readcyclecounter() + (env.a & 0);   // play! / reward / path entry of the first ply done
-      depth++;
-      probe = nxt == 0;
-      idx = nxt - 1;
-    }
-    if (dbg) dbg[3] = __builtin_readcyclecounter();
-    if (lane == 0) {
-      v.leaf_env[slot] = env;
-      sr->leaf_ins = ins;
-    }
-    if (v.ec && kind == LEAF_NEW) {
-      // oracle(state): has the engine evaluated this state before (for another slot, in an earlier wave)?  One look at the entry.
-      const uint32_t ci = ec_index(env.a, env.b, v.ec_mask);
-      ECEnt* const ent = v.ec + ci;
-      const uint32_t m1 = ec_ld32(&ent->meta);
-      const unsigned long long ka = ec_ld64(&ent->ka), kb = ec_ld64(&ent->kb);
-      const float pl = inrec ? ec_ldf(&ent->P[lane]) : 0.f;
-      const float vv = ec_ldf(&ent->V);
-      const uint32_t cs = ec_ld32(&ent->cs);
-      const uint32_t px = group_xor<L>(inrec ? ec_term(pl, lane) : 0u);
-      const bool ok = (m1 & 3u) == EC_READY && ka == env.a && kb == env.b && cs == ec_checksum(px, ka, kb, vv, m1);
-      ishit = group_bcast0<L>(ok ? 1 : 0, lane) != 0;               // lane 0's verdict (its checksum covers every lane's prior)
-      if (ishit) {
-        // no network for this leaf: the answer waits where the slot's next phase A looks when eidx = -1
-        v.Phit[(size_t)slot * L + lane] = inrec ? pl : 0.f;
-        if (lane == 0) { v.Vhit[slot] = vv; sr->eidx = -1; }
-      } else if (lane == 0) {
-        // the state goes to the network; its answer goes into the cache if the entry can be taken: empty, answered (the older
-        // answer makes room), or a claim so old that its slot has gone away (a phase that ended, a retired slot)
-        const uint32_t age = v.ec_seq - (m1 >> 2);
-        if (m1 == 0u || (m1 & 3u) == EC_READY || age > (uint32_t)EC_STALE_AFTER) {
-          const uint32_t mine = (v.ec_seq << 2) | EC_PENDING;
-          if (ec_cas(&ent->meta, m1, mine)) { ec_st64(&ent->ka, env.a); ec_st64(&ent->kb, env.b); claim = (int)ci; cmeta = mine; }
-        }
-      }
-    }
+  if (ishit && kind == LEAF_NEW) {
+    // (lock step) the cache's answer waits where the slot's next phase A looks when eidx = -1
+    v.Phit[(size_t)slot * L + lane] = Pans;
+    if (lane == 0) { v.Vhit[slot] = Vans; sr->eidx = -1; }
   }
-  if (live && lane == 0) sr->leaf_kd = kind | (depth << 2);
   if (dbg) dbg[4] = __builtin_readcyclecounter();
 
   // ------------------------------------------------------------------ evaluation batch + statistics of the wave
-  const bool head = live && lane == 0;
+  const bool head = mine && lane == 0;
   const bool isnew = head && kind == LEAF_NEW && !ishit;            // goes to the network
-  const bool hith = head && ishit;                                   // answered by the cache
-  const unsigned long long bal = __ballot(isnew), balh = __ballot(hith);
-  int sims = (head && kind != LEAF_NONE) ? 1 : 0, trav = (head && kind != LEAF_NONE) ? depth : 0;
+  const unsigned long long bal = __ballot(isnew);
+  // (free-running, a wave's launch) still searching, nothing to ask: the background launch carries on with this slot
+  const bool needy = head && v.run_k && do_backup && v.bg_list && searching && !retired && kind == LEAF_NONE && msims < p_arg.nsims;
+  const unsigned long long baln = __ballot(needy);
+  int sims = head ? n_sel : 0, trav = head ? n_trav : 0, evl = head ? n_evl : 0, hits = head ? n_hit : 0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { sims += __shfl_down(sims, o); trav += __shfl_down(trav, o); }
-  if (wl == 0) { s_new[w] = __popcll(bal); s_hit[w] = __popcll(balh); s_sims[w] = sims; s_trav[w] = trav; }
+  for (int o = 32; o > 0; o >>= 1) { sims += __shfl_down(sims, o); trav += __shfl_down(trav, o); evl += __shfl_down(evl, o); hits += __shfl_down(hits, o); }
+  if (wl == 0) { s_need[w] = __popcll(baln); s_new[w] = __popcll(bal); s_hit[w] = hits; s_evl[w] = evl; s_sims[w] = sims; s_trav[w] = trav; }
   __syncthreads();
   if (threadIdx.x == 0) {
     const int nw = blockDim.x >> 6;
-    int tot = 0, toth = 0, ts = 0, tt = 0;
-    for (int i = 0; i < nw; ++i) { tot += s_new[i]; toth += s_hit[i]; ts += s_sims[i]; tt += s_trav[i]; }
+    int tot = 0, toth = 0, te = 0, ts = 0, tt = 0;
+    for (int i = 0; i < nw; ++i) { tot += s_new[i]; toth += s_hit[i]; te += s_evl[i]; ts += s_sims[i]; tt += s_trav[i]; }
     s_base = tot ? atomicAdd(v.n_eval + par, tot) : 0;
+    { int tn = 0; for (int i = 0; i < nw; ++i) tn += s_need[i]; s_nbase = tn ? atomicAdd(v.bg_cnt + par, tn) : 0; }
     if (ts) {                                                       // statistics: simulations (mcts.jl:242), traversed nodes (:222), oracle calls
       // per-workgroup accumulators, summed by the host when somebody asks: three same-address atomics per workgroup and wave
       // were what bounded the kernel at 1 M slots (32 768 workgroups)
       long long* sp = v.stat + (size_t)blockIdx.x * 4;
-      sp[0] += ts; sp[1] += tt; sp[2] += tot + toth; sp[3] += toth;
+      sp[0] += ts; sp[1] += tt; sp[2] += te; sp[3] += toth;
     }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && (do_backup || !v.run_k)) {
       // the previous wave's network batch goes to the host (a mapped word it looks at without synchronising: the size of the
       // launches to come decides which tower form serves them), then its counter becomes the next wave's
       if (v.nleaf_host && do_select) __hip_atomic_store(v.nleaf_host, v.n_eval[par ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       v.n_eval[par ^ 1] = 0;
+      if (v.bg_cnt) v.bg_cnt[par ^ 1] = 0;
     }
   }
   __syncthreads();
@@ -648,9 +741,14 @@ __global__ void __launch_bounds__(256, 6) k_tree(DView v, DParams p, int do_back
     for (int i = 0; i < w; ++i) base += s_new[i];
     const int e = base + __popcll(bal & ((1ULL << wl) - 1ULL));
     sr->eidx = e;
-    v.eval_slots[e] = slot;
+    (v.eval_slots + (size_t)par * v.eval_stride)[e] = slot;
   }
-  if (v.ec && head && kind == LEAF_NEW) ((int2*)v.ec_claim)[slot] = make_int2(claim, (int)cmeta);
+  if (needy) {
+    int base = s_nbase;
+    for (int i = 0; i < w; ++i) base += s_need[i];
+    (v.bg_list + (size_t)par * v.eval_stride)[base + __popcll(baln & ((1ULL << wl) - 1ULL))] = slot;
+  }
+  if (v.ec && head && kind == LEAF_NEW) ((int2*)v.ec_claim)[slot] = make_int2(ishit ? -1 : claim, ishit ? 0 : (int)cmeta);
   if (dbg) dbg[6] = __builtin_readcyclecounter();
 }
 
@@ -683,7 +781,8 @@ __global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p, uint32
   constexpr int L = Gm::APAD;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= v.n_eval[par]) return;
-  const GEnv env = v.leaf_env[v.eval_slots[e]];
+  const int* const eslots = v.eval_slots + (size_t)par * v.eval_stride;
+  const GEnv env = v.leaf_env[eslots[e]];
   const uint32_t m = Gm::mask(env);
   float P[L];
   float V = 0.f;
@@ -691,7 +790,7 @@ __global__ void __launch_bounds__(256) k_synth_oracle(DView v, DParams p, uint32
     const float u = (float)(1.0 / (double)__popc(m));             // Float32(ones(n) ./ n)
     for (int a = 0; a < L; ++a) P[a] = ((m >> a) & 1) ? u : 0.f;
     if (p.oracle == AZ_ORACLE_ROLLOUT) {
-      const int slot = v.eval_slots[e];
+      const int slot = eslots[e];
       V = rollout_value<Gm>(env, p.seed, v.game_id[slot], v.move_idx[slot], sim_idx);
     }
   } else {
@@ -817,15 +916,41 @@ __device__ inline void turn_flip(const DView& v, const DParams& p, int slot, GEn
   rec->N[AZ_MAX_ACTIONS] = k1;
 }
 
+// GI.init(gspec) on a slot (play.jl:299) + MCTS.reset! when asked: what k_start_games does for a listed slot and what a free-running
+// slot does for itself when its game has ended
 template <class Gm>
-__global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
-  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
-  using NL = NodeL<Gm>;
-  constexpr int L = Gm::APAD;
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;       // one lane per slot: n <= 9, serial
-  if (slot >= v.G) return;
+__device__ inline void start_game_on_slot(const DView& v, const DParams& p, int slot, GEnv env, bool have_root, uint32_t game_id, int reset_tree) {
   SlotRec* const sr = v.sr + slot;
-  if (!sr->active) return;
+  sr->set_root(env);
+  sr->root_idx = -1;
+  sr->leaf_kd = LEAF_NONE;
+  v.game_id[slot] = game_id;
+  v.move_idx[slot] = 0;
+  sr->active = SR_ACTIVE;
+  v.finished[slot] = 0;
+  uint32_t ep = sr->epoch;
+  if (reset_tree) { ep += 1; sr->node_count = 0; }
+  if (ep == 0 || ep >= 0xffff) {                                  // epoch space exhausted: really clear
+    unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
+    for (int k = 0; k < v.ht_size; ++k) tab[k] = 0;
+    ep = 1; sr->node_count = 0;
+  }
+  sr->epoch = ep;
+  if (!have_root && p.flip_p != 0.0) { turn_flip<Gm>(v, p, slot, env, game_id, 0); sr->set_root(env); }   // self-play: the first turn's flip
+}
+
+// The move step of one slot (the body of play_game's loop after think, play.jl:308-313, and simulate's end-of-game bookkeeping,
+// simulations.jl:231-240).  FR = false: every slot of the engine, in rounds, the host collects finished games and refills.
+// FR = true (free-running phase): the slot whose explore! is complete plays its move as soon as the next k_move_fr comes by; when
+// its game ends it writes the game out itself -- game record and move records into the phase buffer, space for both reserved by
+// one CAS -- and takes the next game id from the phase's counter: Util.mapreduce's lock (util.jl:181-188) as an atomic.
+template <class Gm, bool FR>
+__device__ inline void move_slot(const DView& v, const DParams& p, int slot, const FRArgs& fa) {
+  using NL = NodeL<Gm>;
+  SlotRec* const sr = v.sr + slot;
+  const int aw = sr->active;
+  if (!(aw & SR_ACTIVE)) return;
+  if (FR && ((aw >> SR_MS_SHIFT) < p.nsims || (sr->leaf_kd & 3) != LEAF_NONE)) return;   // still thinking
   GEnv env = sr->root();
   const uint32_t epoch = sr->epoch;
   const char* nd = find_node<Gm>(v, slot, env.a, env.b);          // tree[state] must exist after explore!
@@ -834,10 +959,26 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
   int Nn[AZ_MAX_ACTIONS];
   for (int a = 0; a < Gm::A; ++a) Nn[a] = NL::stat(nd, a)->N;
   const uint32_t mv = v.move_idx[slot];
+  const uint32_t gid = v.game_id[slot];
   if ((int)mv >= v.max_moves) {                                   // a game longer than the trace can hold: retired like a full node pool
     if (!p.retire) dev_fail(v, DERR_MOVES);
-    else { v.finished[slot] = 2; sr->active = 0; }
+    else { v.finished[slot] = 2; sr->active = 0; if (FR && v.fr_active) atomicSub(v.fr_active, 1); }
     return;
+  }
+  const int act = select_action<Gm>(p, Nn, m, mv, gid);
+  GEnv nxt = env;
+  Gm::play(nxt, act);
+  unsigned long long off = 0; int di = 0;
+  if (FR && (nxt.fin & 1)) {
+    // room for the game's records (a bounded phase always has it; an unbounded one -- bench, polling -- waits here, the slot's
+    // move still unplayed, until the host has drained the staging area)
+    const unsigned long long nm = (unsigned long long)mv + 1;
+    unsigned long long cur = __hip_atomic_load(&fa.st->resv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      di = (int)(cur >> 40); off = cur & ((1ULL << 40) - 1);
+      if (di >= fa.done_cap || (long long)(off + nm) > fa.recs_cap) return;
+      if (__hip_atomic_compare_exchange_strong(&fa.st->resv, &cur, cur + (1ULL << 40) + nm, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
   }
   az_move_rec* rec = v.trace + (size_t)slot * v.max_moves + mv;
   if (p.flip_p == 0.0) {
@@ -855,36 +996,79 @@ __global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
     n = 0;
     for (int a = 0; a < AZ_MAX_ACTIONS; ++a) rec->N[a] = (a < Gm::A && ((mp >> a) & 1)) ? cnt[n++] : 0;
   }
-  const int act = select_action<Gm>(p, Nn, m, mv, v.game_id[slot]);
-  Gm::play(env, act);
+  env = nxt;
   rec->action = act;
   rec->reward = Gm::white_reward(env);
   sr->set_root(env);
   sr->root_idx = -1;
   v.move_idx[slot] = mv + 1;
+  if (FR) { sr->active = SR_ACTIVE; atomicAdd((unsigned long long*)&fa.st->moves, 1ULL); }   // the next explore! starts at simulation 0
   if (env.fin & 1) {
-    az_game_rec* g = v.grec + slot;
-    g->game_id = (int32_t)v.game_id[slot];
-    g->slot = slot;
-    g->num_moves = (int32_t)(mv + 1);
-    g->first_move = 0;
-    g->nodes = sr->node_count;                                   // measured BEFORE the periodic reset
-    g->total_simulations = sr->tot_sims;
-    g->total_nodes_traversed = sr->tot_trav;
-    g->final_key[0] = env.a; g->final_key[1] = env.b;
-    v.finished[slot] = 1;
-    sr->active = 0;
+    az_game_rec gr;
+    gr.game_id = (int32_t)gid;
+    gr.slot = v.slot0 + slot;
+    gr.num_moves = (int32_t)(mv + 1);
+    gr.first_move = 0;
+    gr.nodes = sr->node_count;                                   // measured BEFORE the periodic reset
+    gr.total_simulations = sr->tot_sims;
+    gr.total_nodes_traversed = sr->tot_trav;
+    gr.final_key[0] = env.a; gr.final_key[1] = env.b;
     const int ws = v.worker_sim_id[slot] + 1;
     v.worker_sim_id[slot] = ws;
-    if (p.reset_every > 0 && ws % p.reset_every == 0) {          // reset_player!, simulations.jl:235-237
-      sr->epoch = epoch + 1;                                      // wrap handled by k_start_games
-      sr->node_count = 0;
+    const bool reset = p.reset_every > 0 && ws % p.reset_every == 0;   // reset_player!, simulations.jl:235-237
+    if (!FR) {
+      v.grec[slot] = gr;
+      v.finished[slot] = 1;
+      sr->active = 0;
+      if (reset) { sr->epoch = epoch + 1; sr->node_count = 0; }    // wrap handled by k_start_games
+    } else {
+      // the trace: the slot's move records, packed behind the games that finished before it
+      const uint4* src = (const uint4*)(v.trace + (size_t)slot * v.max_moves);
+      uint4* dst = (uint4*)(fa.recs + off);
+      for (int k = 0; k < (int)(mv + 1) * (int)(sizeof(az_move_rec) / 16); ++k) dst[k] = src[k];
+      gr.first_move = (int32_t)(off > 0x7fffffffULL ? 0x7fffffffULL : off);
+      fa.done[di] = gr;
+      fa.done_off[di] = (long long)off;
+      // the next game id, or no more games: the slot goes idle (util.jl:181-188)
+      const int k = atomicAdd(&fa.st->next_game, 1);
+      const bool more = fa.total_games < 0 ? (long long)fa.first_game_id + k < (long long)AZ_REPLACEMENT_GAME_BIT : k < fa.total_games;
+      if (more) {
+        start_game_on_slot<Gm>(v, p, slot, Gm::init(), false, fa.first_game_id + (uint32_t)k, reset ? 1 : 0);
+        arm_noise<Gm>(v, p, slot, sr->root());
+      } else {
+        sr->active = 0;
+        if (reset) { sr->epoch = epoch + 1; sr->node_count = 0; }
+        if (v.fr_active) atomicSub(v.fr_active, 1);
+      }
     }
   } else {
-    if (p.flip_p != 0.0) { turn_flip<Gm>(v, p, slot, env, v.game_id[slot], mv + 1); sr->set_root(env); }
+    if (p.flip_p != 0.0) { turn_flip<Gm>(v, p, slot, env, gid, mv + 1); sr->set_root(env); }
     arm_noise<Gm>(v, p, slot, env);                               // next explore! draws its eta
   }
-  (void)L;
+}
+
+template <class Gm>
+__global__ void __launch_bounds__(256) k_move(DView v, DParams p) {
+  __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel: win issue arbitration against co-resident tower waves
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;       // one lane per slot: n <= 9, serial
+  if (slot >= v.G) return;
+  move_slot<Gm, false>(v, p, slot, FRArgs{});
+}
+// free-running phase: once per wave and slot group, behind the group's k_tree; almost every lane leaves at its first test
+template <class Gm>
+__global__ void __launch_bounds__(256) k_move_fr(DView v, DParams p, FRArgs fa) {
+  if (!v.low_prio) __builtin_amdgcn_s_setprio(3);
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && fa.host_words && fa.group == 0) {
+    // progress for the host, one wave late (it looks at the mapped words without synchronising: is the phase over?)
+    const unsigned long long r = __hip_atomic_load(&fa.st->resv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int act = 0;
+    for (int g = 0; g < AZ_MAX_GROUPS; ++g) act += __hip_atomic_load(&fa.st->active[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fa.host_words, (int)(r >> 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fa.host_words + 1, act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (slot >= v.G) return;
+  move_slot<Gm, true>(v, p, slot, fa);
 }
 
 // start games on a list of slots (GI.init(gspec), play.jl:299); MCTS.reset! when asked
@@ -893,25 +1077,7 @@ __global__ void __launch_bounds__(256) k_start_games(DView v, DParams p, const i
                                                      const GEnv* roots, int n, int reset_tree) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int slot = slots[i];
-  GEnv env = roots ? roots[i] : Gm::init();
-  SlotRec* const sr = v.sr + slot;
-  sr->set_root(env);
-  sr->root_idx = -1;
-  sr->leaf_kd = LEAF_NONE;
-  v.game_id[slot] = game_ids ? game_ids[i] : 0;
-  v.move_idx[slot] = 0;
-  sr->active = 1;
-  v.finished[slot] = 0;
-  uint32_t ep = sr->epoch;
-  if (reset_tree) { ep += 1; sr->node_count = 0; }
-  if (ep == 0 || ep >= 0xffff) {                                  // epoch space exhausted: really clear
-    unsigned long long* tab = v.ht + (size_t)slot * v.ht_size;
-    for (int k = 0; k < v.ht_size; ++k) tab[k] = 0;
-    ep = 1; sr->node_count = 0;
-  }
-  sr->epoch = ep;
-  if (!roots && p.flip_p != 0.0) { turn_flip<Gm>(v, p, slot, env, v.game_id[slot], 0); sr->set_root(env); }   // self-play: the first turn's flip
+  start_game_on_slot<Gm>(v, p, slots[i], roots ? roots[i] : Gm::init(), roots != nullptr, game_ids ? game_ids[i] : 0, reset_tree);
 }
 // eta for explore!: given by the caller (full action index) or drawn from the RNG contract
 template <class Gm>
@@ -966,6 +1132,8 @@ static __global__ void __launch_bounds__(256) k_slot_records(DView v, int what) 
   if (what & SR_CLEAR_TOTALS) { sr->tot_sims = 0; sr->tot_trav = 0; }
   if (what & SR_RESET_TREE) { sr->node_count = 0; sr->epoch = v.epoch0; sr->root_idx = -1; }   // the caller has zeroed the hash tables
 }
+// stream-ordered store of one word (the stop signal of a free-running phase's background search)
+static __global__ void k_set_word(int* p, int val) { __hip_atomic_store(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // node counts of all slots, dense (the host maps pool chunks ahead of the slots, azhip.hip vm_grow)
 static __global__ void __launch_bounds__(256) k_node_counts(DView v, int* out) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;

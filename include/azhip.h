@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define AZ_ABI_VERSION 3   /* 3 (round 5): az_gather_stats.replaced_games, az_selfplay_stats.evals_reused; 2 (round 4): az_selfplay_stats.aborted_games, az_gather_stats' report fields, az_prof.exec_units, az_comm_version */
+#define AZ_ABI_VERSION 4   /* 4 (round 6): az_engine_cfg.lock_step, az_selfplay_stats.slot_launches; 3 (round 5): az_gather_stats.replaced_games, az_selfplay_stats.evals_reused; 2 (round 4): az_selfplay_stats.aborted_games, az_gather_stats' report fields, az_prof.exec_units, az_comm_version */
 
 typedef enum {
   AZ_OK = 0,
@@ -126,6 +126,20 @@ typedef struct {
    * rounded to bf16, fp32 accumulation, csrc/resnet16b.h) -- BASELINE configs[4] "ResNet 10x128 bf16"; outputs agree with
    * the fp32 network to bf16 accuracy, not bit for bit, so searches are not comparable move for move with the oracle. */
   int32_t net_bf16;
+  /* How az_selfplay_* schedules the workers (round 6).
+   * 0 (default): FREE-RUNNING.  A worker of the reference runs its simulations and its games at its own pace (simulations.jl:216-243,
+   *   util.jl:169-200: the next game id is taken under a lock by whichever worker finishes first).  So does a slot: within one launch
+   *   of the tree kernel it completes every simulation that ends on a terminal state or on a state the engine has evaluated before,
+   *   and stops only where it needs the network; it plays its move when ITS explore! is complete and takes the next game id from an
+   *   atomic counter when ITS game ends.  Every network launch then holds one board of every searching slot.  A game's records depend
+   *   on its id and on the games that shared its tree; with reset_every = 1 on the id alone, whatever the schedule.  With
+   *   reset_every != 1 the slot -> game assignment (az_game_rec.slot; a slot plays its games in increasing id order) is one outcome
+   *   of the reference's own race and can differ from run to run; the parity tests hand the assignment the device reports to the oracle.
+   * 1: LOCK STEP, rounds 1-5: one simulation per slot and wave, all slots move together every num_iters_per_turn waves, finished
+   *   slots take the next ids in slot order -- a fixed assignment, reproducible for every reset_every.
+   * The hooks (az_mcts_explore), the arena, the rollout oracle and hipGraph replay always run in lock step.  AZHIP_FREE_RUN=0|1
+   * overrides the field (tests, A/B runs). */
+  int32_t lock_step;
 } az_engine_cfg;
 
 typedef struct az_engine az_engine;
@@ -231,7 +245,7 @@ typedef struct {
   int64_t leaf_evals;               /* oracle calls */
   int64_t moves;                    /* samples */
   int64_t games;
-  int64_t waves;
+  int64_t waves;                    /* launches of the wave sequence (tree kernel, network) per slot group */
   double seconds;
   int64_t aborted_games;            /* games whose slot ran out of tree nodes (max_nodes_per_slot / device memory) or of move
                                      * records (max_moves_per_game): the slot is retired, the game dropped and counted here
@@ -252,6 +266,8 @@ typedef struct {
                                      * function of the state and every tower form gives the same bits, so the answers -- and with them
                                      * every record of the phase -- are unchanged (tests/test_eval_cache_gpu.py).  leaf_evals -
                                      * evals_reused = boards the network evaluated.  0 when the cache is off (AZHIP_EVAL_CACHE=0). */
+  int64_t slot_launches;            /* sum over the waves of the slots that searched in them: simulations / slot_launches = simulations a slot
+                                     * completes per launch of the tree kernel (1 in lock step, ~2 free-running with the evaluation cache) */
 } az_selfplay_stats;
 #define AZ_REPLACEMENT_GAME_BIT 0x40000000   /* game ids handed to az_selfplay_* must stay below it */
 typedef void (*az_progress_cb)(void* user);   /* game_simulated(), once per finished game */
@@ -261,9 +277,10 @@ typedef void (*az_progress_cb)(void* user);   /* game_simulated(), once per fini
  * count) and writes the traces sorted by game id. */
 int az_selfplay_run(az_engine* e, int32_t num_games, int32_t first_game_id, az_trace_buf* out,
                     az_progress_cb cb, void* user, az_selfplay_stats* stats);
-/* Stepping form of the same loop (bench, polling): begin, step `nwaves` search waves (one
- * simulation per active slot per wave; the move step runs after every num_iters_per_turn
- * waves), collect finished games, end.  num_games < 0 = refill slots forever. */
+/* Stepping form of the same loop (bench, polling): begin, step `nwaves` search waves, collect finished games, end.
+ * num_games < 0 = refill slots forever.  Lock step (az_engine_cfg.lock_step): one simulation per active slot per wave, the move
+ * step runs after every num_iters_per_turn waves.  Free-running: a wave carries every slot to its next network evaluation; az_selfplay_step
+ * returns with the device idle and every game that ended collectable. */
 int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_game_id);
 int az_selfplay_step(az_engine* e, int32_t nwaves);
 int az_selfplay_collect(az_engine* e, az_trace_buf* out);   /* finished, not yet collected */

@@ -34,6 +34,7 @@ struct EngineCfg
   max_nodes_per_slot::Int32; max_moves_per_game::Int32
   num_blocks::Int32; num_filters::Int32; num_policy_head_filters::Int32; num_value_head_filters::Int32
   net_bf16::Int32
+  lock_step::Int32   # 0 = free-running workers (the reference's own schedule: util.jl:181-188), 1 = rounds in lock step
 end
 struct MoveRec
   key::NTuple{2,UInt64}; N::NTuple{10,Int32}; action::Int32; reward::Float32
@@ -52,10 +53,11 @@ mutable struct SelfplayStats
   aborted_games::Int64
   tower_fallbacks::Int64
   evals_reused::Int64
-  SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0)
+  slot_launches::Int64
+  SelfplayStats() = new(0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0)
 end
-@assert sizeof(EngineCfg) == 224 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56 && sizeof(SelfplayStats) == 80
-const ABI_VERSION = 3   # include/azhip.h AZ_ABI_VERSION the structs above are written against
+@assert sizeof(EngineCfg) == 224 && sizeof(MoveRec) == 64 && sizeof(GameRec) == 56 && sizeof(SelfplayStats) == 88
+const ABI_VERSION = 4   # include/azhip.h AZ_ABI_VERSION the structs above are written against
 "Called once before the first engine is created: a library built from another header must not be written into these structs."
 function check_abi()
   v = ccall((:az_abi_version, LIB), Cint, ())
@@ -160,7 +162,7 @@ function make_cfg(gspec, mcts::MctsParams, sim::SimParams, hp; oracle=2, seed=1,
     mcts.num_iters_per_turn, length(xs), pad8(xs, Int32), pad8(ys, Float64),
     sim.num_workers, sim.batch_size, isnothing(sim.reset_every) ? 0 : sim.reset_every, sim.fill_batches ? 1 : 0,
     sim.flip_probability, UInt64(seed), 0, 0,
-    hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters, bf16 ? 1 : 0)
+    hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters, bf16 ? 1 : 0, 0)
 end
 
 # ---- seam 3: the network plugin -------------------------------------------------------------------------

@@ -1079,6 +1079,7 @@ typedef struct {
   azr_evals* ext; int own_ext;
   int64_t rounds, steps;
   uint8_t* waiting;             /* [G] the worker is suspended on an evaluation */
+  int32_t* next_of;             /* azr_sim_set_assignment: index of the next game of the same worker, -1 = none; NULL = ids in finishing order */
   double tm[4];                 /* azr_sim_run, seconds on the calling thread: its share of the workers' turns, waiting for the other threads, serial part, inside the evaluator */
 } azr_sim;
 
@@ -1109,7 +1110,32 @@ azr_sim* azr_sim_new(const azr_sim_params* p, azr_game_rec* games, azr_move_rec*
 void azr_sim_free(azr_sim* h) {
   for (int s = 0; s < h->G; ++s) azr_mcts_free(h->slots[s].mcts);
   if (h->own_ext) azr_evals_free(h->ext);
-  free(h->slots); free(h->stage); free(h->waiting); free(h);
+  free(h->slots); free(h->stage); free(h->waiting); free(h->next_of); free(h);
+}
+/* Which worker plays which game.  The reference hands the next id to whichever worker asks first, under a lock (util.jl:181-188): the
+ * assignment is a race, and with reset_every != 1 (or the cumulative per-worker counters of self_play_measurements) the results depend
+ * on it.  By default this file resolves the race in lock step (ids in finishing order, ties by worker index).  A free-running device
+ * phase resolves it its own way and reports how (az_game_rec.slot): worker_of[i] = worker of game first_game_id + i replays THAT
+ * outcome -- every worker plays its games in increasing id order, as any outcome of the reference's race has it.  Must be called before
+ * the first step; the first min(num_workers, num_games) games belong to workers 0, 1, 2 ... (that is how every phase starts).
+ * Returns 0, or -1 if the assignment is not one the reference could produce. */
+int azr_sim_set_assignment(azr_sim* h, const int32_t* worker_of) {
+  const int n = h->p.num_games, G = h->G;
+  if (h->rounds || h->steps) return -1;
+  for (int i = 0; i < n; ++i) if (worker_of[i] < 0 || worker_of[i] >= G) return -1;
+  for (int s = 0; s < G; ++s) if (worker_of[s] != s) return -1;
+  free(h->next_of);
+  h->next_of = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  int32_t* last = malloc(sizeof(int32_t) * (size_t)(G > 0 ? G : 1));
+  for (int s = 0; s < G; ++s) last[s] = -1;
+  for (int i = 0; i < n; ++i) {
+    h->next_of[i] = -1;
+    const int s = worker_of[i];
+    if (last[s] >= 0) h->next_of[last[s]] = i;
+    last[s] = i;
+  }
+  free(last);
+  return 0;
 }
 int64_t azr_sim_num_moves(const azr_sim* h) { return h->nm; }
 /* out: move rounds completed, azr_sim_step calls, oracle calls of the live workers (answered evaluations the trees consumed) */
@@ -1222,7 +1248,11 @@ static void sim_round_end(azr_sim* h) {
     sl->worker_sim_id++;
     if (p->reset_every > 0 && sl->worker_sim_id % p->reset_every == 0) azr_mcts_reset(sl->mcts);
     h->finished++;
-    if (h->next_game < p->num_games) {
+    if (h->next_of) {                                               /* a given outcome of the race (azr_sim_set_assignment) */
+      const int nx = h->next_of[sl->game_id - p->first_game_id];
+      if (nx >= 0) { sl->game_id = p->first_game_id + nx; sl->nmoves = 0; h->next_game++; azr_init(&sl->game, p->game); }
+      else sl->active = 0;
+    } else if (h->next_game < p->num_games) {
       sl->game_id = p->first_game_id + h->next_game++; sl->nmoves = 0;
       azr_init(&sl->game, p->game);
     } else sl->active = 0;
@@ -1319,6 +1349,17 @@ int azr_sim_run(azr_sim* h, azr_eval_fn fn, void* user, int nthreads, int64_t* e
   return status;
 }
 
+/* worker_of: NULL, or the assignment to replay (azr_sim_set_assignment); -1 if it is not a valid one */
+int64_t azr_simulate_assigned(const azr_sim_params* p, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap, const int32_t* worker_of) {
+  if (p->oracle_kind == AZR_ORACLE_EXTERNAL) { fprintf(stderr, "azref: replay mode goes through azr_sim_step\n"); abort(); }
+  azr_sim* h = azr_sim_new(p, games, moves, moves_cap, 0);
+  if (worker_of && azr_sim_set_assignment(h, worker_of) != 0) { azr_sim_free(h); return -1; }
+  int64_t r = azr_sim_step(h, 0, 0);
+  if (r != 0) abort();
+  int64_t nm = h->nm;
+  azr_sim_free(h);
+  return nm;
+}
 int64_t azr_simulate(const azr_sim_params* p, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap) {
   if (p->oracle_kind == AZR_ORACLE_EXTERNAL) { fprintf(stderr, "azref: replay mode goes through azr_sim_step\n"); abort(); }
   azr_sim* h = azr_sim_new(p, games, moves, moves_cap, 0);

@@ -273,13 +273,40 @@ def _sim_params(game, oracle, num_games, num_workers, nsims, gamma=1.0, cpuct=1.
     return p, blob
 
 
-def simulate(game, oracle, num_games, num_workers, nsims, **kw):
-    """simulate (src/simulations.jl:207-244) in lock-step; returns (games, moves) record arrays."""
+def assignment_of(device_games, num_games, first_game_id=0):
+    """worker_of[i] = the worker (slot) that played game first_game_id + i, from the game records a device phase returned
+    (az_game_rec.slot): the outcome of the reference's id race (util.jl:181-188) that phase took"""
+    w = np.full(num_games, -1, dtype=np.int32)
+    for i in range(num_games):
+        g = device_games[i]
+        w[g.game_id - first_game_id] = g.slot
+    assert (w >= 0).all(), "assignment_of: a game is missing from the records"
+    return w
+
+
+def _worker_of(assignment, num_games):
+    if assignment is None:
+        return None, None
+    w = np.ascontiguousarray(assignment, dtype=np.int32)
+    assert w.shape == (num_games,)
+    return w, w.ctypes.data_as(C.c_void_p)
+
+
+def simulate(game, oracle, num_games, num_workers, nsims, assignment=None, **kw):
+    """simulate (src/simulations.jl:207-244) in lock-step; returns (games, moves) record arrays.
+    assignment: None = game ids in finishing order (ties by worker index), or worker_of[num_games] -- the outcome of the reference's
+    id race to replay (assignment_of: what a free-running device phase reports)."""
     p, blob = _sim_params(game, oracle, num_games, num_workers, nsims, **kw)
     games = (GameRec * num_games)()
     cap = num_games * 512
     moves = (MoveRec * cap)()
-    nm = lib().azr_simulate(C.byref(p), games, moves, cap)
+    w, wp = _worker_of(assignment, num_games)
+    L = lib()
+    L.azr_simulate_assigned.restype = C.c_int64
+    L.azr_simulate_assigned.argtypes = [C.POINTER(SimParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    nm = L.azr_simulate_assigned(C.byref(p), games, moves, cap, wp)
+    if nm < 0:
+        raise ValueError("simulate: not an assignment the reference's worker pool could produce")
     return games, moves, nm
 
 
@@ -306,10 +333,10 @@ class Evals:
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float))
 
 
-def replay(game, evaluate, num_games, num_workers, nsims, evals=None, threads=None, **kw):
+def replay(game, evaluate, num_games, num_workers, nsims, evals=None, threads=None, assignment=None, **kw):
     """REPLAY MODE (SURVEY.md §7 hard part 3): `simulate` -- the same lock-step loop, the same tree code -- with every oracle answer
     supplied by the caller, e.g. by the device network behind az_net_evaluate_keys.  The oracle's trees then run on the other
-    evaluator's numbers, at CPU-tree speed on `threads` host threads (default: up to 64).
+    evaluator's numbers, at CPU-tree speed on `threads` host threads (default: all of them, 16 workers or more per thread).
     evaluate: a callable  keys uint64[n, 2] -> (P float32[n, A] by full action index, V float32[n]),  or a pair (address, user) of a C
     function  int f(void* user, const uint64_t* keys, int32_t n, float* P, float* V)  (0 = ok) that is called without Python in between.
     Returns (games, moves, num_moves, info); info: steps (rounds of evaluation + move rounds), evaluated (states sent to the
@@ -350,9 +377,15 @@ def replay(game, evaluate, num_games, num_workers, nsims, evals=None, threads=No
     else:
         fn, user = C.c_void_p(evaluate[0]), C.c_void_p(evaluate[1])
     if threads is None:
-        threads = max(1, min(64, os.cpu_count() or 1, (G + 15) // 16))
+        threads = max(1, min(os.cpu_count() or 1, (G + 15) // 16))
     h = C.c_void_p(L.azr_sim_new(C.byref(p), games, moves, cap, evals.h))
     nev = C.c_int64(0)
+    w, wp = _worker_of(assignment, num_games)
+    if w is not None:
+        L.azr_sim_set_assignment.argtypes = [C.c_void_p, C.c_void_p]
+        if L.azr_sim_set_assignment(h, wp) != 0:
+            L.azr_sim_free(h)
+            raise ValueError("replay: not an assignment the reference's worker pool could produce")
     try:
         rc = L.azr_sim_run(h, fn, user, int(threads), C.byref(nev))
         if failure:

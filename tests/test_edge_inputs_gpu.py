@@ -42,7 +42,8 @@ def test_fewer_games_than_slots_and_ragged_groups(ngames, workers, batch):
     with azhip.Engine(game=R.TTT, oracle=azhip.ORACLE_HASH, num_workers=workers, batch_size=batch, num_iters_per_turn=20, cpuct=1.0,
                       dirichlet_noise_eps=0.25, reset_every=1, seed=4, temperature=((0,), (1.0,))) as e:
         g, m, ng, nm, st = e.selfplay_run(ngames)
-    rg, rm, rnm = R.simulate(R.TTT, R.ORACLE_HASH, ngames, workers, 20, cpuct=1.0, noise_eps=0.25, reset_every=1, seed=4, temp_xs=(0,), temp_ys=(1.0,))
+    rg, rm, rnm = R.simulate(R.TTT, R.ORACLE_HASH, ngames, workers, 20, cpuct=1.0, noise_eps=0.25, reset_every=1, seed=4, temp_xs=(0,), temp_ys=(1.0,),
+                              assignment=R.assignment_of(g, ngames))
     assert ng == ngames and nm == rnm and st.aborted_games == 0
     for i in range(ngames):
         assert (g[i].game_id, g[i].num_moves) == (rg[i].game_id, rg[i].num_moves)

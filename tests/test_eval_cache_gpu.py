@@ -23,11 +23,13 @@ pytestmark = pytest.mark.gpu
 SCHED = ((0, 6, 12), (1.0, 1.0, 0.3))
 
 
-def _recs(games, moves, ng):
+def _recs(games, moves, ng, cumulative=True):
+    """cumulative=False: without the per-worker counters (self_play_measurements, training.jl:269-273) -- they depend on which games the
+    worker played before, i.e. on the outcome of the id race (util.jl:181-188), which two free-running runs need not share"""
     out = {}
     for i in range(ng):
         g = games[i]
-        out[g.game_id] = (g.num_moves, g.nodes, g.total_simulations, g.total_nodes_traversed, tuple(g.final_key),
+        out[g.game_id] = (g.num_moves, g.nodes, (g.total_simulations, g.total_nodes_traversed) if cumulative else None, tuple(g.final_key),
                           [bytes(moves[g.first_move + k]) for k in range(g.num_moves)])
     return out
 
@@ -45,13 +47,15 @@ def test_hash_oracle_phases_with_the_cache_forced_on_equal_the_oracle(monkeypatc
                       dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=SCHED, reset_every=2, flip_probability=flip, seed=3) as e:
         g, m, ng, nm, st = e.selfplay_run(192)
         dev = _recs(g, m, ng)
+        asg = R.assignment_of(g, 192)                                # the outcome of the id race this phase took (util.jl:181-188)
         # a second phase on the same engine: the table is warm (and the launch numbers go on)
         g2, m2, ng2, nm2, st2 = e.selfplay_run(64, first_game_id=1000)
         dev2 = _recs(g2, m2, ng2)
+        asg2 = R.assignment_of(g2, 64, 1000)
     kw = dict(cpuct=2.0, noise_eps=0.25, noise_alpha=1.0, temp_xs=SCHED[0], temp_ys=SCHED[1], reset_every=2, seed=3, flip_probability=flip)
-    rg, rm, rnm = R.simulate(gr, R.ORACLE_HASH, 192, 64, nsims, **kw)
+    rg, rm, rnm = R.simulate(gr, R.ORACLE_HASH, 192, 64, nsims, assignment=asg, **kw)
     assert dev == _recs(rg, rm, 192)
-    rg2, rm2, _ = R.simulate(gr, R.ORACLE_HASH, 64, 64, nsims, first_game_id=1000, **kw)
+    rg2, rm2, _ = R.simulate(gr, R.ORACLE_HASH, 64, 64, nsims, first_game_id=1000, assignment=asg2, **kw)
     assert dev2 == _recs(rg2, rm2, 64)
     assert 0 < st.evals_reused < st.leaf_evals and st2.evals_reused > 0
     if log2 >= 20:
@@ -72,7 +76,7 @@ def test_resnet_phase_is_the_same_with_and_without_the_cache(monkeypatch):
                           num_blocks=2, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32) as e:
             e.net_set_params(blob)
             g, m, ng, nm, st = e.selfplay_run(1024)                  # two games per slot: the second ones start on a warm table
-            out[mode] = (_recs(g, m, ng), st.leaf_evals, st.evals_reused, st.simulations)
+            out[mode] = (_recs(g, m, ng, cumulative=False), st.leaf_evals, st.evals_reused, st.simulations)
     assert out["0"][0] == out["1"][0] == out["tiny"][0]
     assert out["0"][1] == out["1"][1] == out["tiny"][1] and out["0"][3] == out["1"][3]   # the reference's counts do not move
     assert out["0"][2] == 0 and out["1"][2] > 0.25 * out["1"][1] and 0 < out["tiny"][2] < out["1"][2]
@@ -93,11 +97,11 @@ def test_new_parameters_empty_the_cache():
         ga, ma, nga, _, sta = e.selfplay_run(64)
         e.net_set_params(b)
         gb, mb, ngb, _, stb = e.selfplay_run(64)
-        warm_b = _recs(gb, mb, ngb)
-        first_a = _recs(ga, ma, nga)
+        warm_b = _recs(gb, mb, ngb, cumulative=False)
+        first_a = _recs(ga, ma, nga, cumulative=False)
     with azhip.Engine(**kw) as e:
         e.net_set_params(b)
         g, m, ng, _, st = e.selfplay_run(64)
-        fresh_b = _recs(g, m, ng)
+        fresh_b = _recs(g, m, ng, cumulative=False)
     assert warm_b == fresh_b and warm_b != first_a and sta.evals_reused > 0 and stb.evals_reused > 0 and st.evals_reused > 0
     assert stb.leaf_evals == st.leaf_evals

@@ -88,7 +88,8 @@ def test_flipped_self_play_reaches_the_data_set_like_the_oracles(game):
     with azhip.Engine(game=game, oracle=azhip.ORACLE_HASH, num_workers=5, batch_size=5, num_iters_per_turn=24, dirichlet_noise_eps=0.25, cpuct=1.0,
                       reset_every=2, temperature=([0], [1.0]), seed=5, flip_probability=0.5) as e:
         games, moves, ng, nm, _ = e.selfplay_run(10)
-    rg, rm, rnm = R.simulate(game, R.ORACLE_HASH, 10, 5, 24, cpuct=1.0, noise_eps=0.25, reset_every=2, seed=5, flip_probability=0.5)
+    rg, rm, rnm = R.simulate(game, R.ORACLE_HASH, 10, 5, 24, cpuct=1.0, noise_eps=0.25, reset_every=2, seed=5, flip_probability=0.5,
+                              assignment=R.assignment_of(games, 10))
     assert rnm == nm and any(rm[k].N[R.AMAX] for k in range(rnm))
     ref = _oracle_samples(game, rg, rm, 10, 0.95)
     mem = azhip.MemoryBuffer(gspec, 10000)

@@ -88,7 +88,7 @@ def _phase_vs_replay(name, game_hip, game_ref, slots, groups, nsims, first_id, n
                   seed=1, flip_probability=flip)
         # reset_every = 1: a game depends on its id alone, so the phase is replayed in chunks of workers that fit the host's memory
         # (each chunk's games on fresh workers, exactly as the device's slots played them: one game per slot).  Otherwise the
-        # worker <-> game assignment matters and all workers are replayed together.
+        # worker <-> game assignment matters and all workers are replayed together, with the assignment the device reports.
         one_per_slot = reset_every == 1 and num_games <= slots
         chunk = _chunk_size(nsims, plies, reset_every, num_games) if one_per_slot else num_games
         ev = R.Evals(26)                                             # 64 M states x 64 B: forgets everything when 60 % full
@@ -99,8 +99,9 @@ def _phase_vs_replay(name, game_hip, game_ref, slots, groups, nsims, first_id, n
         secs = {}
         for c0 in range(0, num_games, chunk):
             n = min(chunk, num_games - c0)
+            # which worker played which game is a race in the reference (util.jl:181-188): the replay takes the outcome the device reports
             rg_, rm_, rnm, info = R.replay(game_ref, evaluator, n, n if one_per_slot else slots, nsims, evals=ev,
-                                           first_game_id=first_id + c0, **kw)
+                                           first_game_id=first_id + c0, assignment=None if one_per_slot else hg["slot"].astype(np.int32), **kw)
             for k in tot:
                 tot[k] += info[k]
             for k, v in info["seconds"].items():

@@ -38,9 +38,10 @@ def test_simulate_with_resnet_matches_oracle(game, spec, ngames, workers, batch,
     count = [0]
     res = azhip.simulate(sim, gspec, sp, game_simulated=lambda: count.__setitem__(0, count[0] + 1), seed=5)
     assert count[0] == ngames == len(res)
+    # which worker plays which game is a race in the reference (util.jl:181-188); the oracle replays the outcome the device took
     games, moves, nm = R.simulate(game, R.ORACLE_NET, ngames, workers, nsims, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0,
                                   temp_xs=(0, 6, 10), temp_ys=(1.0, 1.0, 0.3), reset_every=2, seed=5,
-                                  net=(2, F, 32, 32, nn.params()))
+                                  net=(2, F, 32, 32, nn.params()), assignment=[r["worker"] for r in res])
     from azhip.trace import trace_from_records
     for i in range(ngames):
         t = res[i]["trace"]
@@ -67,7 +68,8 @@ def test_simulate_with_flips_and_the_network_matches_oracle():
                           azhip.self_play_measurements)
     res = azhip.simulate(sim, gspec, sp, seed=5)
     games, moves, nm = R.simulate(R.C4, R.ORACLE_NET, 8, 4, 32, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0, temp_xs=(0, 6, 10),
-                                  temp_ys=(1.0, 1.0, 0.3), reset_every=2, seed=5, net=(2, 64, 32, 32, nn.params()), flip_probability=0.5)
+                                  temp_ys=(1.0, 1.0, 0.3), reset_every=2, seed=5, net=(2, 64, 32, 32, nn.params()), flip_probability=0.5,
+                                  assignment=[r["worker"] for r in res])
     assert 0 < sum(1 for k in range(nm) if moves[k].N[R.AMAX]) < nm
     for i in range(8):
         t = res[i]["trace"]
@@ -161,7 +163,8 @@ def test_full_size_slot_count_independence(flip):
     blob = random_params(azhip.GAME_CONNECT_FOUR, _hp(5), seed=2026)
     kw = dict(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, num_iters_per_turn=400, cpuct=2.0,
               dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)),
-              reset_every=1, seed=1, num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32, flip_probability=flip)
+              reset_every=1, seed=1, num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32, flip_probability=flip,
+              lock_step=1)       # "400 waves = one move of every slot" is the lock-step schedule; the free-running one: test_free_running_gpu.py
 
     def first_moves(G, nmoves):
         with azhip.Engine(num_workers=G, batch_size=G, **kw) as e:

@@ -36,8 +36,9 @@ def _both(game_hip, game_ref, workers, games, nsims, reset_every, flip=0.0, **en
         g, m, ng, nm, st = e.selfplay_run(games)
         assert ng == games and st.aborted_games == 0
         dev = _bytes(g, m, ng)
+        asg = R.assignment_of(g, games)                              # the outcome of the id race the phase took (util.jl:181-188)
     rg, rm, rnm = R.simulate(game_ref, R.ORACLE_HASH, games, workers, nsims, cpuct=2.0, noise_eps=0.25, noise_alpha=1.0,
-                             temp_xs=SCHED[0], temp_ys=SCHED[1], reset_every=reset_every, seed=7, flip_probability=flip)
+                             temp_xs=SCHED[0], temp_ys=SCHED[1], reset_every=reset_every, seed=7, flip_probability=flip, assignment=asg)
     assert C.sizeof(rm[0]) == 64
     assert dev == _bytes(rg, rm, games)
     return dev
