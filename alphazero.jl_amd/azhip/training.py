@@ -136,8 +136,11 @@ def self_play_step_device(gspec, bestnn, params: SelfPlayParams, memory, game_pl
     memory.new_batch()
     depth = footprint = None
     if comm is not None:
+        # gather first (no memory: nothing is pushed), judge the phase from numbers every rank sees alike, THEN gather into the memory
+        # (a refused phase must not leave its samples behind; the records of a phase are a few MB, the second collective ~1 ms)
+        probe = comm.gather_push(eng, None, params.mcts.gamma)
+        abort_policy(params.sim.num_games, int(probe.games), int(probe.replaced_games))   # every rank alike: nobody is left inside a collective
         gs = comm.gather_push(eng, memory, params.mcts.gamma)
-        abort_policy(params.sim.num_games, int(gs.games), int(gs.replaced_games))   # every rank alike: nobody is left inside a collective
         nm = gs.moves
         elapsed += gs.gather_ms * 1e-3
         # mean / maximum over ALL ranks' games (training.jl:293-294), from the gathered game records

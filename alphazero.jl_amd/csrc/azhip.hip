@@ -118,6 +118,7 @@ extern "C" int az_engine_destroy(az_engine* e) {
   if (e->h_xflag) (void)hipHostFree(e->h_xflag);
   if (e->h_nleaf) (void)hipHostFree(e->h_nleaf);
   if (e->h_fr_words) (void)hipHostFree(e->h_fr_words);
+  if (e->h_busy) (void)hipHostFree(e->h_busy);
   for (int i = 0; i < 3; ++i) { if (e->fr_s[i]) { (void)hipStreamSynchronize(e->fr_s[i]); (void)hipStreamDestroy(e->fr_s[i]); } if (e->fr_ev[i]) (void)hipEventDestroy(e->fr_ev[i]); }
   if (e->d_done) (void)hipFree(e->d_done);
   if (e->d_done_off) (void)hipFree(e->d_done_off);
@@ -254,7 +255,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   e->h_env = nullptr; e->h_n = nullptr; e->h_pv = nullptr; e->h_nleaf = nullptr; e->d_nleaf = nullptr;
   e->d_ec = nullptr; e->ec_mask = 0; e->ec_seq = 0; e->d_ec_claim = nullptr; e->d_Phit = nullptr; e->d_Vhit = nullptr;
   e->fr_on = false; e->fr_k = 0; e->fr_kbg = 0; e->fr_round_waves = 0; e->fr_s[0] = e->fr_s[1] = e->fr_s[2] = nullptr; e->fr_ev[0] = e->fr_ev[1] = e->fr_ev[2] = nullptr; e->d_fr = nullptr; e->d_done = nullptr; e->d_done_off = nullptr; e->done_cap = 0;
-  e->h_fr_words = nullptr; e->d_fr_words = nullptr; e->fr_prev_done = 0; e->fr_since_round = 0; e->fr_given_up = 0; e->fr_prev_recs = 0;
+  e->h_fr_words = nullptr; e->d_fr_words = nullptr; e->h_busy = nullptr; e->d_busy = nullptr; e->explore_k = 0; e->fr_prev_done = 0; e->fr_since_round = 0; e->fr_given_up = 0; e->fr_prev_recs = 0;
   e->h_xflag = nullptr; e->d_xflag = nullptr; e->split_off = false; e->split_registered = 0; e->xch_launches = 0;
   { const char* fa = getenv("AZHIP_XCH_FAIL_AT"); e->xch_fail_at = fa ? atoll(fa) : 0; }
   e->net_loaded = false; e->running = false; e->prof_on = false; { const char* ug = getenv("AZHIP_GRAPH"); e->use_graphs = ug ? atoi(ug) : 0; }
@@ -377,8 +378,12 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
       const char* ce = getenv("AZHIP_EVAL_CACHE");
       const bool on = ce ? atoi(ce) != 0 && c->oracle != AZ_ORACLE_ROLLOUT : c->oracle == AZ_ORACLE_RESNET;
       if (on && !e->use_graphs) {
+        // sized from the workload: 8 x slots x simulations per move entries, 2^16 (4 MB) ... 2^24 (1 GB: BASELINE configs[1];
+        // a phase there evaluates 2-6 x 10^7 states) -- an 8-slot test engine and the 128-worker arena players no longer hold 1 GB each
         const char* cl = getenv("AZHIP_EVAL_CACHE_LOG2");
-        int lg = cl ? atoi(cl) : 24;
+        int lg = 16;
+        while (lg < 24 && ((long long)1 << lg) < 8LL * G * std::max(1, c->num_iters_per_turn)) ++lg;
+        if (cl) lg = atoi(cl);
         lg = std::min(std::max(lg, 4), 28);
         AZCHK(dalloc(e, &e->d_ec, (size_t)1 << lg));                // zeroed: every entry EC_EMPTY
         e->ec_mask = ((uint32_t)1 << lg) - 1u;
@@ -402,6 +407,10 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     HIPCHK(hipHostGetDevicePointer((void**)&e->d_nleaf, e->h_nleaf, 0));
     // free-running phases: the device's own bookkeeping (FRState) and two host-mapped progress words
     AZCHK(dalloc(e, &e->d_fr, 1)); AZCHK(dalloc(e, &e->d_bg_stop, 1)); e->bg_seq = 0; e->bg_signal = false;
+    HIPCHK(hipHostMalloc((void**)&e->h_busy, sizeof(int) * AZ_MAX_GROUPS, hipHostMallocMapped));
+    for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->h_busy[g] = -1;
+    HIPCHK(hipHostGetDevicePointer((void**)&e->d_busy, e->h_busy, 0));
+    { const char* ek = getenv("AZHIP_EXPLORE_K"); e->explore_k = ek ? atoi(ek) : 8; }
     HIPCHK(hipHostMalloc((void**)&e->h_fr_words, sizeof(int) * 2, hipHostMallocMapped));
     e->h_fr_words[0] = e->h_fr_words[1] = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&e->d_fr_words, e->h_fr_words, 0));
@@ -628,7 +637,7 @@ static void pack_conv(const float* Wt, int ksz, int Cin, int Cout, int CoutPad, 
   }
 }
 
-static int ec_empty(az_engine* e);
+static int ec_empty(az_engine* e, bool wipe = false);
 extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
   ENGINE(e);
   if (e->cfg.oracle != AZ_ORACLE_RESNET) return fail(AZ_ERR_STATE, "engine was created without the ResNet oracle");
@@ -952,18 +961,22 @@ extern "C" int az_net_evaluate_keys(az_engine* e, const uint64_t* keys, int32_t 
 // completed by the group's next k_tree launch: the next wave's, or flush_pending's.
 // Evaluation cache: every k_tree launch of the engine gets a number (claims carry it, tree.h).  30 bits of it are kept in an entry:
 // long before they wrap the table is emptied and the count starts again.
-static int ec_empty(az_engine* e) {
+// Empties the table.  wipe = false (new parameters): every claim made so far falls below the floor (DView::ec_floor) -- nothing is
+// written but the slots' claim words; wipe = true (the claim numbers are about to wrap): the entries are really cleared.
+static int ec_empty(az_engine* e, bool wipe) {
   if (!e->d_ec) return AZ_OK;
   AZCHK(sync_all(e));
-  HIPCHK(hipMemsetAsync(e->d_ec, 0, sizeof(ECEnt) * ((size_t)e->ec_mask + 1), e->stream));
+  if (wipe) HIPCHK(hipMemsetAsync(e->d_ec, 0, sizeof(ECEnt) * ((size_t)e->ec_mask + 1), e->stream));
   HIPCHK(hipMemsetAsync(e->d_ec_claim, 0xff, sizeof(int) * 2 * (size_t)e->v.G, e->stream));   // no slot holds an entry any more
   HIPCHK(hipStreamSynchronize(e->stream));
-  e->ec_seq = 0;
+  if (wipe) e->ec_seq = 0;
+  e->v.ec_floor = e->ec_seq;
+  for (int g = 0; g < e->ngroups; ++g) e->gv[g].ec_floor = e->ec_seq;
   return AZ_OK;
 }
 static int ec_next_launch(az_engine* e, DView* v) {
   if (!e->d_ec) return AZ_OK;
-  if (e->ec_seq >= (1u << 29)) AZCHK(ec_empty(e));
+  if (e->ec_seq >= (1u << 29)) AZCHK(ec_empty(e, true));
   v->ec_seq = ++e->ec_seq;
   return AZ_OK;
 }
@@ -1186,10 +1199,30 @@ static int explore_begin(az_engine* e, const std::vector<int>& slots, const std:
   *nga = std::min(e->ngroups, maxslot / e->gv[0].G + 1);
   for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->group_active[g] = 0;
   for (int sl : slots) e->group_active[sl / e->gv[0].G]++;
+  // (round 6) the explore! runs ahead: inside one launch a slot completes every simulation that ends on a terminal state or on a
+  // state the evaluation cache answers (tree.h k_tree, run_k > 0 with fr = 0), every slot exactly nsims of them; the host launches
+  // waves until the device reports nobody busy (explore_waves).  Not for the rollout oracle (keyed by the wave's index) nor under hipGraph replay.
+  const bool ahead = e->explore_k > 1 && e->cfg.oracle != AZ_ORACLE_ROLLOUT && !e->use_graphs && !e->tree_sort;
+  for (int g = 0; g < e->ngroups; ++g) { e->gv[g].run_k = ahead ? e->explore_k : 0; e->gv[g].fr = 0; e->gv[g].busy_host = ahead ? e->d_busy + g : nullptr; e->h_busy[g] = -1; }
+  return AZ_OK;
+}
+// the waves of an explore! of `nsims` simulations per slot on `nga` slot groups: nsims lock-step waves, or -- running ahead -- as many
+// as it takes until every slot has done its nsims (at most nsims; the device's count of busy slots is looked at every 16 waves)
+template <class Gm> static int explore_waves(az_engine* e, int nga, int nsims) {
+  if (!e->gv[0].run_k) return run_waves<Gm>(e, nga, nsims, 0);
+  for (int i = 0; i < nsims + 1; ++i) {
+    AZCHK(wave<Gm>(e, nga, (uint32_t)i));
+    if ((i & 15) == 15) {
+      AZCHK(sync_groups(e)); HIPCHK(hipStreamSynchronize(e->stream));
+      bool busy = false;
+      for (int g = 0; g < nga; ++g) busy = busy || (e->group_active[g] > 0 && ((volatile int*)e->h_busy)[g] != 0);
+      if (!busy) break;
+    }
+  }
   return AZ_OK;
 }
 template <class Gm> static int explore_end(az_engine* e, int nga) {
-  struct Unreg { az_engine* e; ~Unreg() { split_register(e, 0); } } unreg{e};
+  struct Unreg { az_engine* e; ~Unreg() { split_register(e, 0); for (int g = 0; g < e->ngroups; ++g) { e->gv[g].run_k = 0; e->gv[g].busy_host = nullptr; } } } unreg{e};
   if (!nga) return AZ_OK;
   AZCHK(flush_pending<Gm>(e));                                     // the last simulation's expand + backup
   AZCHK(sync_groups(e));
@@ -1206,7 +1239,9 @@ static int explore_slots(az_engine* e, const std::vector<int>& slots, const std:
   int nga = 0;
   AZCHK(explore_begin<Gm>(e, slots, roots, gids, mv, eta, &nga));
   AZCHK(vm_grow(e, nsims + 2));                                    // mapped-on-demand pool: room for this explore! (a no-op for plain pools)
-  if (nga) AZCHK(run_waves<Gm>(e, nga, nsims, 0));
+  struct Sims { az_engine* e; int keep; ~Sims() { e->p.nsims = keep; } } sims{e, e->p.nsims};   // the kernel counts a slot's simulations against DParams::nsims
+  e->p.nsims = nsims;
+  if (nga) AZCHK(explore_waves<Gm>(e, nga, nsims));
   return explore_end<Gm>(e, nga);
 }
 
@@ -1376,7 +1411,7 @@ extern "C" int az_selfplay_begin(az_engine* e, int32_t num_games, int32_t first_
       e->h_fr_words[0] = 0; e->h_fr_words[1] = n0;
       e->fr_prev_done = 0; e->fr_prev_recs = 0; e->fr_since_round = 0; e->fr_given_up = 0;
     }
-    for (int g = 0; g < e->ngroups; ++g) { e->gv[g].run_k = on ? e->fr_k : 0; e->gv[g].fr_active = on ? &e->d_fr->active[g] : nullptr; }
+    for (int g = 0; g < e->ngroups; ++g) { e->gv[g].run_k = on ? e->fr_k : 0; e->gv[g].fr = on ? 1 : 0; e->gv[g].fr_active = on ? &e->d_fr->active[g] : nullptr; }
     if (on && e->ngroups == 1 && e->cfg.oracle == AZ_ORACLE_RESNET) {   // tree kernels under the group's own network launch: two streams (ev_* with them)
       HIPCHK(hipStreamSynchronize(e->stream));
       e->gs[0] = e->gt[0] = e->fr_s[0];                                // (the second stream, fr_s[1], carries the move step and the background search: wave_group)
@@ -1678,7 +1713,7 @@ extern "C" int az_selfplay_end(az_engine* e) {
   e->running = false;
   e->active_slots = 0;
   e->fr_on = false;
-  for (int g = 0; g < e->ngroups; ++g) { e->gv[g].run_k = 0; e->gv[g].fr_active = nullptr; }
+  for (int g = 0; g < e->ngroups; ++g) { e->gv[g].run_k = 0; e->gv[g].fr = 0; e->gv[g].fr_active = nullptr; }
   if (e->ngroups == 1 && e->gs[0] != e->stream) {                    // back to the engine's one stream
     HIPCHK(hipStreamSynchronize(e->gs[0])); HIPCHK(hipStreamSynchronize(e->fr_s[1])); HIPCHK(hipStreamSynchronize(e->fr_s[2]));
     e->gs[0] = e->gt[0] = e->stream;
@@ -1802,8 +1837,22 @@ static int arena_run(az_engine* ec, az_engine* eb, int num_games, int first_game
     // contender's and the baseline's searches overlap on the GPU (each has only part of the workers)
     int nga[2] = {0, 0};
     for (int k = 0; k < 2; ++k) if (eng[k]->p.nsims > 0) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(explore_begin<Gm>(eng[k], slots[k], roots[k], gids[k], mvs[k], nullptr, &nga[k])); }
-    for (int i = 0; i < std::max(ec->p.nsims, eb->p.nsims); ++i)
-      for (int k = 0; k < 2; ++k) if (nga[k] && i < eng[k]->p.nsims) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(wave<Gm>(eng[k], nga[k], (uint32_t)i)); }
+    // (round 6: the explores run ahead -- explore_begin -- and a player is done when its device reports no busy slot: looked at every 16 waves)
+    bool done[2] = {nga[0] == 0, nga[1] == 0};
+    for (int i = 0; i < std::max(ec->p.nsims, eb->p.nsims) + 1 && !(done[0] && done[1]); ++i) {
+      for (int k = 0; k < 2; ++k) if (!done[k]) {
+        const bool ahead = eng[k]->gv[0].run_k > 0;
+        if (i >= eng[k]->p.nsims + (ahead ? 1 : 0)) { done[k] = true; continue; }
+        HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(wave<Gm>(eng[k], nga[k], (uint32_t)i));
+      }
+      if ((i & 15) == 15)
+        for (int k = 0; k < 2; ++k) if (!done[k] && eng[k]->gv[0].run_k > 0) {
+          HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(sync_groups(eng[k])); HIPCHK(hipStreamSynchronize(eng[k]->stream));
+          bool busy = false;
+          for (int g = 0; g < nga[k]; ++g) busy = busy || (eng[k]->group_active[g] > 0 && ((volatile int*)eng[k]->h_busy)[g] != 0);
+          done[k] = !busy;
+        }
+    }
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipSetDevice(eng[k]->device));
       if (eng[k]->p.nsims > 0) {

@@ -143,6 +143,8 @@ struct az_engine {
   int fr_k, fr_kbg, fr_round_waves;  // simulations a slot may select per wave launch / per background launch (DView::run_k); waves between two looks of the host
   hipStream_t fr_s[3]; hipEvent_t fr_ev[3];   // one slot group: the tree / network streams and events of its free-running phases (gs[0] / gt[0] / ev_* point at them meanwhile)
   FRState* d_fr; az_game_rec* d_done; long long* d_done_off; int done_cap;
+  int* h_busy; int* d_busy;      // [AZ_MAX_GROUPS] host-mapped: slots of each group still inside an explore! that runs ahead (DView::busy_host)
+  int explore_k;                 // simulations per slot and launch inside MCTS.explore! of the hooks and the arena (AZHIP_EXPLORE_K; 0 / 1 = lock step)
   int* d_bg_stop; int bg_seq; bool bg_signal;   // the background search's stop word: set to bg_seq on the wave's stream once its tower has run (bg_signal: this wave has one)
   int* h_fr_words; int* d_fr_words;  // host-mapped: finished games / searching slots as of the previous wave (FRArgs::host_words)
   int fr_prev_done, fr_since_round, fr_given_up; long long fr_prev_recs;

@@ -92,6 +92,10 @@ static void note_tower(az_engine* e, int tw, int F) {
 // k_tower16 (31 of 99 products); 5x128 two groups 1.10 vs 1.20 M.  Returns 16, 21, 32 or 3.
 // n = boards the launch is expected to hold (what the forms are priced with), nb >= n = the most it can hold (what the split
 // tower's co-residency needs; the grid is sized for nb in any case and workgroups beyond the device's count leave at once).
+// INVARIANT: the choice depends on a launch size the host reads from a device-written word WITHOUT synchronising
+// (wave_net_f: h_nleaf), so which form serves a wave differs from run to run.  Results do not, because every fp32 tower form
+// computes the same bits and every bf16 form the same bits (tests/test_net.py, tests/test_net_bf16_gpu.py force each form and compare).
+// A new form must pass those cross-form equality tests before it may be returned from here.
 template <class Gm, int F> static int pick_tower(const az_engine* e, int n, int nb = -1) {
   if (nb < n) nb = n;
   // split tower (k_tower16s, 128 filters): both workgroups of every pair must be resident at once -> all slot groups'

@@ -95,6 +95,7 @@ struct DView {
   int G, cap_nodes, ht_size, max_depth, max_moves;
   ECEnt* ec;              // evaluation cache [ec_mask + 1] or NULL (off)
   uint32_t ec_mask, ec_seq;   // ec_seq: number of this k_tree launch (any slot group of the engine), > 0
+  uint32_t ec_floor;          // entries whose claim number is <= ec_floor are EMPTY: az_net_set_params empties the table by raising the floor (a 1 GB memset per weight update before)
   int* ec_claim;          // [G][2] cache entry the slot's pending leaf claimed (its answer goes there when the leaf is expanded; -1 = none) and the meta value of the claim
   int* nleaf_host;        // host-mapped word: the network batch of this group's previous wave (pick_tower's launch-size estimate), or NULL
   float* Phit; float* Vhit; // [G][APAD], [G]: the answer of a leaf the cache answered, by SLOT (written by the slot's phase B, read by its next phase A; SlotRec::eidx = -1 says so)
@@ -149,6 +150,9 @@ struct DView {
   // completed on the spot -- until it needs the network (a cache miss), has done num_iters_per_turn of them (k_move_fr then plays its
   // move, whatever the other slots are doing) or reaches run_k.  0 = lock step: one simulation per slot and launch, moves in rounds.
   int run_k;
+  int fr;                 // 1: a free-running PHASE (two batches in flight, background launches, k_move_fr); run_k > 0 with fr = 0: an explore!
+                          // of the hooks / the arena that runs ahead -- every slot up to nsims simulations, the host moves (busy_host tells it when)
+  int* busy_host;         // host-mapped: slots that had not finished their explore! after the launch before the previous one (run_k > 0, fr = 0), or NULL
   int low_prio;           // 1: a background launch -- it must not take issue slots from the network launch it runs under (no s_setprio)
   int slot0;              // engine-wide index of this view's first slot (az_game_rec.slot)
   int* fr_active;         // free-running: the view's count of searching slots (FRState::active[group]), or NULL
@@ -385,7 +389,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_t
   // background launch of a free-running phase -- the next entry of the list the wave's launch left
   int nlive = v.G;
   const int* map = v.perm;
-  if (v.run_k && !do_backup && v.bg_list) { nlive = v.bg_cnt[par ^ 1]; map = v.bg_list + (size_t)(par ^ 1) * v.eval_stride; }
+  if (v.fr && !do_backup && v.bg_list) { nlive = v.bg_cnt[par ^ 1]; map = v.bg_list + (size_t)(par ^ 1) * v.eval_stride; }
   const bool live = lgrp < nlive;
   const int slot_in = live ? (map ? map[lgrp] : lgrp) : 0;
   const bool links_ok = v.cap_nodes <= LINK_MAX;
@@ -396,7 +400,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_t
   // the split and launches the skipped waves again (azhip.hip recover_split).  Uniform over the grid: the word belongs to this
   // slot group, only the group's own tower (earlier on the same stream order) sets it and only the host clears it, between launches.
   if (__hip_atomic_load(v.xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)DERR_EXCHANGE) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && (do_backup || !v.run_k)) atomicAdd(v.skipped + (do_select ? 0 : 1), 1);   // (a background launch is not a wave)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (do_backup || !v.fr)) atomicAdd(v.skipped + (do_select ? 0 : 1), 1);   // (a background launch is not a wave)
     return;
   }
 
@@ -422,7 +426,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_t
   // (do_backup = 0, under the wave's network launch) carries on with the slots that have no question pending, and what they find joins the
   // NEXT wave's batch (`par`): a slot waiting for the network, and in the next wave's launch a slot that is already in the batch being
   // gathered, is left alone.
-  const bool mine = live && !(v.run_k && kind != LEAF_NONE && (!do_backup || ((s0.leaf_kd >> 30) & 1) == par));
+  const bool mine = live && !(v.fr && kind != LEAF_NONE && (!do_backup || ((s0.leaf_kd >> 30) & 1) == par));
   if (!(do_backup && mine)) kind = LEAF_NONE;
   const int nc_in = nc, ridx_in = ridx;
   const bool inrec = lane < Gm::A;
@@ -656,7 +660,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_t
           const float vv = ec_ldf(&ent->V);
           const uint32_t cs = ec_ld32(&ent->cs);
           const uint32_t px = group_xor<L>(inrec ? ec_term(pl, lane) : 0u);
-          const bool okc = (m1 & 3u) == EC_READY && ka == env.a && kb == env.b && cs == ec_checksum(px, ka, kb, vv, m1);
+          const bool okc = (m1 & 3u) == EC_READY && (m1 >> 2) > v.ec_floor && ka == env.a && kb == env.b && cs == ec_checksum(px, ka, kb, vv, m1);
           ishit = group_bcast0<L>(okc ? 1 : 0, lane) != 0;          // lane 0's verdict (its checksum covers every lane's prior)
           if (ishit) { Pans = inrec ? pl : 0.f; Vans = vv; n_hit += 1; }   // no network for this leaf
           else {
@@ -667,7 +671,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_t
             claim = -1; cmeta = 0;
             if (lane == 0) {
               const int32_t age = (int32_t)(v.ec_seq - (m1 >> 2));
-              if (m1 == 0u || (m1 & 3u) == EC_READY || age > (int32_t)EC_STALE_AFTER) {
+              if (m1 == 0u || (m1 & 3u) == EC_READY || age > (int32_t)EC_STALE_AFTER || (m1 >> 2) <= v.ec_floor) {
                 const uint32_t mine = (v.ec_seq << 2) | EC_PENDING;
                 if (ec_cas(&ent->meta, m1, mine)) { ec_st64(&ent->ka, env.a); ec_st64(&ent->kb, env.b); claim = (int)ci; cmeta = mine; }
               }
@@ -707,7 +711,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_t
   const bool isnew = head && kind == LEAF_NEW && !ishit;            // goes to the network
   const unsigned long long bal = __ballot(isnew);
   // (free-running, a wave's launch) still searching, nothing to ask: the background launch carries on with this slot
-  const bool needy = head && v.run_k && do_backup && v.bg_list && searching && !retired && kind == LEAF_NONE && msims < p_arg.nsims;
+  // (an explore! that runs ahead, fr = 0: the same counter holds the slots that are not done yet -- a question pending, or simulations to go)
+  const bool needy = head && v.run_k && v.bg_list && (v.fr ? (do_backup && searching && !retired && kind == LEAF_NONE && msims < p_arg.nsims)
+                                                           : (kind != LEAF_NONE || (searching && !retired && msims < p_arg.nsims)));
   const unsigned long long baln = __ballot(needy);
   int sims = head ? n_sel : 0, trav = head ? n_trav : 0, evl = head ? n_evl : 0, hits = head ? n_hit : 0;
 #pragma unroll
@@ -726,12 +732,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_t
       long long* sp = v.stat + (size_t)blockIdx.x * 4;
       sp[0] += ts; sp[1] += tt; sp[2] += te; sp[3] += toth;
     }
-    if (blockIdx.x == 0 && (do_backup || !v.run_k)) {
+    if (blockIdx.x == 0 && (do_backup || !v.fr)) {
       // the previous wave's network batch goes to the host (a mapped word it looks at without synchronising: the size of the
       // launches to come decides which tower form serves them), then its counter becomes the next wave's
       if (v.nleaf_host && do_select) __hip_atomic_store(v.nleaf_host, v.n_eval[par ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       v.n_eval[par ^ 1] = 0;
-      if (v.bg_cnt) v.bg_cnt[par ^ 1] = 0;
+      if (v.bg_cnt) {
+        if (v.busy_host && v.run_k && !v.fr && do_backup) __hip_atomic_store(v.busy_host, v.bg_cnt[par ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v.bg_cnt[par ^ 1] = 0;
+      }
     }
   }
   __syncthreads();
@@ -743,7 +752,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_t
     sr->eidx = e;
     (v.eval_slots + (size_t)par * v.eval_stride)[e] = slot;
   }
-  if (needy) {
+  if (needy && v.fr) {
     int base = s_nbase;
     for (int i = 0; i < w; ++i) base += s_need[i];
     (v.bg_list + (size_t)par * v.eval_stride)[base + __popcll(baln & ((1ULL << wl) - 1ULL))] = slot;

@@ -1,11 +1,14 @@
 #!/usr/bin/env python
 """bench.py -- self-play MCTS simulations/sec on MI355X (BASELINE.json metric).
 
-A *step* is one search wave of the hot path over one batch of game slots: select -> gather misses
--> ResNet tower + heads -> expand + backup for every one of the G = 4096 Connect-Four slots (one
-run_simulation! each, src/mcts.jl:199-226), plus the move step of play_game (src/play.jl:308-313) after
-every 400th wave and slot refill when games end.  Workload = BASELINE.json configs[1]:
-Connect-Four, 400 sims/move, 4096 parallel games, ResNet 5x64 fp32, synthetic weights.
+A *step* is one search wave of the hot path over one batch of game slots: expand + backup of the leaves the
+network answered -> select -> gather misses -> ResNet tower + heads, for the G = 4096 Connect-Four slots.
+Round 6 (free-running, az_engine_cfg.lock_step = 0): a wave carries every slot through as many run_simulation!
+calls (src/mcts.jl:199-226) as end on a terminal state or on a state the evaluation cache answers, up to its next
+question for the network (~2 per slot and wave); a slot plays its move (src/play.jl:308-313) when ITS explore! is
+complete and takes the next game id when ITS game ends.  Rounds 1-5 (lock step, `value_lock_step`): one simulation per
+slot and wave, all slots move every 400th wave.  The metric counts simulations, not waves.  Workload = BASELINE.json
+configs[1]: Connect-Four, 400 sims/move, 4096 parallel games, ResNet 5x64 fp32, synthetic weights.
 
 N > 1 (one rank per GPU): games shard embarrassingly -- every rank runs its own 4096 slots with global
 game ids offset by rank, no collective in the timed region (weak scaling); value = simulations of all
@@ -94,7 +97,7 @@ def pmc_lookup(kernel, config="f32"):
     any, else r4's, r3's; tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE in KB, FETCH doubled on gfx950 as MI355X_MICROARCH.md prescribes --
     tools/fetch_calib.sh, profiles/r4/fetch_calibration.txt: 2 x FETCH_SIZE = 128-byte LINES requested, WRITE_SIZE exact);
     returns (bytes, units per launch) or None: counters cannot be read from inside this process."""
-    for rnd in ("r5", "r4", "r3"):                                   # this round's passes first
+    for rnd in ("r6", "r5", "r4", "r3"):                             # this round's passes first
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")))
             ks = d.get("kernels", [])
@@ -117,6 +120,20 @@ def mixing_warmup(game, sims):
     return int(1.5 * MEAN_MOVES[game] * sims)
 
 
+def warm_up(eng, game, sims, slots, extra_waves=0):
+    """Steps the phase until it is in the steady state mixing_warmup describes, whatever the schedule: a lock-step wave is one simulation
+    per slot, a free-running one about two, so the warm-up is counted in SIMULATIONS (mixing_warmup x slots) and stepped in chunks."""
+    target = (mixing_warmup(game, sims) + sims // 2) * slots
+    waves = 0
+    while eng.selfplay_stats().simulations < target:
+        eng.selfplay_step(500)
+        waves += 500
+    if extra_waves > waves:
+        eng.selfplay_step(extra_waves - waves)
+        waves = extra_waves
+    return waves
+
+
 def steady_block(azhip, dev_index, label, game, slots, groups, sims, hp, waves, bf16=False, note=None, max_moves=0):
     """One extra configuration, measured like the headline: steady state of a long phase (mixing_warmup), `waves`
     timed search waves, tower launches timed with HIP events, roofline on the tower kernel."""
@@ -130,7 +147,7 @@ def steady_block(azhip, dev_index, label, game, slots, groups, sims, hp, waves, 
         eng.net_set_params(random_params(game, hp, seed=2026))
         dev_bytes = eng.device_bytes()
         eng.selfplay_begin(-1, first_game_id=1 << 27)
-        eng.selfplay_step(mixing_warmup(game, sims) + sims // 2)
+        warm_up(eng, game, sims, slots)
         s0 = eng.selfplay_stats()
         eng.prof_reset()
         eng.prof_enable(True, classes=("tower",))
@@ -156,6 +173,7 @@ def block_report(label, game, hp, bf16, kernel, prof, s0, s1, dt, waves, slots, 
            "value": sims_n / dt, "unit": "sims/s", "steps": waves, "ms_per_step": 1e3 * dt / max(waves, 1), "dtype": "bf16" if bf16 else "f32",
            "samples_per_sec": moves / dt, "avg_exploration_depth": trav / max(sims_n, 1), "leaf_evals_per_sim": evals / max(sims_n, 1),
            "unique_leaf_frac": net_evals / max(evals, 1),
+           "sims_per_slot_per_wave": sims_n / max(s1.slot_launches - s0.slot_launches, 1),
            "engine_device_GB": dev_bytes / 2.0**30,
            "roofline": tower_roofline(game, hp, bf16, kernel, prof["tower"], net_evals, dt)}
     return out
@@ -331,7 +349,7 @@ def iteration_block(azhip, dev_index, num_games=5000, workers=4096):
     cur = best.copy_()
     mcts = azhip.MctsParams(num_iters_per_turn=600, cpuct=2.0, prior_temperature=1.0, temperature=azhip.PLSchedule([0, 20, 30], [1.0, 1.0, 0.3]),
                             dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0)
-    sp = SelfPlayParams(mcts=mcts, sim=azhip.SimParams(num_games=num_games, num_workers=workers, batch_size=workers // 2, use_gpu=True, reset_every=2,
+    sp = SelfPlayParams(mcts=mcts, sim=azhip.SimParams(num_games=num_games, num_workers=workers, batch_size=workers, use_gpu=True, reset_every=2,
                                                       flip_probability=0.0, alternate_colors=False))
     amcts = azhip.MctsParams(num_iters_per_turn=600, cpuct=2.0, prior_temperature=1.0, temperature=azhip.ConstSchedule(0.2), dirichlet_noise_ϵ=0.05, dirichlet_noise_α=1.0)
     arena = azhip.ArenaParams(mcts=amcts, sim=azhip.SimParams(num_games=128, num_workers=128, batch_size=128, use_gpu=True, reset_every=2,
@@ -392,7 +410,9 @@ def cpu_baseline(blob, hp, nsims, seconds=8.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import azref as R
     R.lib()
-    ncpu = min(os.cpu_count() or 1, 32)
+    # all the CPUs this process can use -- the affinity mask cut down to the cgroup's CPU quota (the GPU box shows 256
+    # hardware threads and grants 16 CPUs' worth of time: more threads than that only take turns).  Rounds 2-5 used min(cpu_count, 32).
+    ncpu = R.usable_cpus()
     net = (hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters, blob)
 
     def sample(threads, oracle, secs):
@@ -420,6 +440,10 @@ def cpu_baseline(blob, hp, nsims, seconds=8.0):
     out["sample"] = main["sample"] + ", ResNet 5x64 fp32"
     out["variants"] = [sample(1, R.ORACLE_NET, seconds * 0.75), sample(1, R.ORACLE_UNIFORM, seconds * 0.4),
                        sample(ncpu, R.ORACLE_UNIFORM, seconds * 0.4)]
+    if ncpu != 32:
+        out["variants"].append(sample(32, R.ORACLE_NET, seconds * 0.5))      # the configuration of rounds 2-5 (32 threads), for continuity
+    out["hardware_threads"], out["usable_cpus"] = os.cpu_count(), ncpu
+    out["cores_note"] = "cores = threads run = usable_cpus (affinity mask and cgroup cpu.max quota); hardware_threads is what the box has"
     out["us_per_sim_uniform_1_thread"] = 1e6 / out["variants"][1]["value"]
     return out
 
@@ -428,51 +452,59 @@ TOWER_CODE = {"k_tower16x2": "21", "k_tower16<": "16", "k_tower<": "32"}
 
 
 def alone_and_tree(args, blob, hp, dev_index, kernel, waves=200):
-    """Extra evidence, measured live after the timed region (not part of `value`): the same workload with ONE slot group, so
-    nothing is co-scheduled with a launch and HIP-event durations are exclusive.  (i) the kernel of the timed region, alone
-    (forced with AZHIP_TOWER so that it is the SAME kernel, not the one a single group would pick); (ii) the search-tree
-    kernels against the HBM roofline: algorithmic bytes of SURVEY.md §8(d) without the network's share --
-    148 B per traversed node + per new leaf 16 (probe miss) + 136 (node write) + 64 (P, V written by the network, read by the expansion)."""
+    """Extra evidence, measured live after the timed region (not part of `value`), one slot group, every kernel class timed with HIP
+    events.  (i) the shipped (free-running) schedule: the tower kernel alone -- with one group nothing runs beside a tower launch but
+    the side streams' move step and background search -- and what a wave spends in each kernel class; (ii) the search-tree kernel
+    against the HBM roofline on the LOCK-STEP schedule (one simulation per slot and launch, nothing overlapped: HIP-event durations
+    are exclusive and comparable with rounds 2-5): algorithmic bytes of SURVEY.md §8(d) without the network's share -- 148 B per
+    traversed node + per new leaf 16 (probe miss) + 136 (node write) + 64 (P, V written by the network, read by the expansion)."""
     import azhip
-    code = "3" if "NT=3" in kernel else next((v for k, v in TOWER_CODE.items() if kernel.startswith(k)), None)
-    old = os.environ.get("AZHIP_TOWER")
-    if code:
-        os.environ["AZHIP_TOWER"] = code
-    try:
+
+    def leg(lock_step):
         eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=dev_index,
                            num_workers=args.slots, batch_size=args.slots, num_iters_per_turn=args.sims,
                            gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
                            prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
-                           num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
-    finally:
-        if old is None:
-            os.environ.pop("AZHIP_TOWER", None)
-        else:
-            os.environ["AZHIP_TOWER"] = old
-    eng.net_set_params(blob)
-    eng.selfplay_begin(-1, first_game_id=1 << 28)
-    eng.selfplay_step(mixing_warmup(azhip.GAME_CONNECT_FOUR, args.sims) + args.sims // 2)
-    s0 = eng.selfplay_stats()
-    eng.prof_reset()
-    eng.prof_enable(True)
-    eng.selfplay_step(waves)
-    s1 = eng.selfplay_stats()
-    prof = eng.prof_get()
-    name = eng.net_last_kernel()
-    eng.prof_enable(False)
-    eng.selfplay_end()
-    eng.close()
-    evals, sims, trav = s1.leaf_evals - s0.leaf_evals, s1.simulations - s0.simulations, s1.nodes_traversed - s0.nodes_traversed
+                           num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32, lock_step=1 if lock_step else 0)
+        try:
+            eng.net_set_params(blob)
+            eng.selfplay_begin(-1, first_game_id=1 << 28)
+            warm_up(eng, azhip.GAME_CONNECT_FOUR, args.sims, args.slots)
+            s0 = eng.selfplay_stats()
+            eng.prof_reset()
+            eng.prof_enable(True)
+            t0 = time.perf_counter()
+            eng.selfplay_step(waves)
+            s1 = eng.selfplay_stats()
+            dt = time.perf_counter() - t0
+            prof = eng.prof_get()
+            name = eng.net_last_kernel()
+            eng.prof_enable(False)
+            eng.selfplay_end()
+        finally:
+            eng.close()
+        return s0, s1, prof, name, dt
+    s0, s1, prof, name, dt = leg(False)
+    evals, sims = s1.leaf_evals - s0.leaf_evals, s1.simulations - s0.simulations
     alone = tower_roofline(azhip.GAME_CONNECT_FOUR, hp, False, name, prof["tower"], evals - (s1.evals_reused - s0.evals_reused), 1e9)
-    alone.update(slot_groups=1, waves=waves)
+    alone.update(slot_groups=1, waves=waves, schedule="free-running",
+                 us_per_wave_by_kernel_class={c: 1e3 * prof[c]["ms"] / waves for c in prof if prof[c]["launches"]},
+                 class_note="select = the wave's tree launch (on the critical path), expand = the background search and move = the move step "
+                            "(side streams, under the tower: their durations overlap it), tower, heads; HIP events around every launch slow the wave itself by ~2 %",
+                 sims_per_slot_per_wave=sims / max(s1.slot_launches - s0.slot_launches, 1), ms_per_wave=1e3 * dt / waves)
+    s0, s1, prof, _, _ = leg(True)
+    evals, sims, trav = s1.leaf_evals - s0.leaf_evals, s1.simulations - s0.simulations, s1.nodes_traversed - s0.nodes_traversed
     tree_cls = [c for c in ("select", "compact", "expand") if prof[c]["launches"]]
     tree_ms = sum(prof[c]["ms"] for c in tree_cls)
     tree_bytes = 148.0 * trav + (16 + 136 + 64) * evals + 16.0 * (sims - evals)
     gbs = tree_bytes / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
-    tree = {"bound": "hbm", "kernels": {c: {"launches": prof[c]["launches"], "avg_us": 1e3 * prof[c]["ms"] / prof[c]["launches"]} for c in tree_cls},
+    tree = {"bound": "hbm", "schedule": "lock step (one simulation per slot and launch; exclusive launch times)",
+            "kernels": {c: {"launches": prof[c]["launches"], "avg_us": 1e3 * prof[c]["ms"] / prof[c]["launches"]} for c in tree_cls},
             "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
             "bytes_per_sim": tree_bytes / max(sims, 1), "avg_exploration_depth": trav / max(sims, 1), "slots": args.slots,
-            "us_per_wave": 1e3 * tree_ms / waves, "traffic": None}
+            "us_per_wave": 1e3 * tree_ms / waves, "traffic": None,
+            "free_running_wave_launch_us": alone["us_per_wave_by_kernel_class"].get("select"),
+            "free_running_sims_per_slot_per_wave": alone["sims_per_slot_per_wave"]}
     # what 4096 dependent chains can move at all (see TREE_LOAD_LATENCY_S): the ceiling this kernel is judged against
     ceiling = args.slots * TREE_LINE_BYTES / TREE_LOAD_LATENCY_S / 1e9
     tree["littles_law_ceiling_GBs"] = ceiling
@@ -483,6 +515,88 @@ def alone_and_tree(args, blob, hp, dev_index, kernel, waves=200):
         tree["traffic"] = t[0] * args.slots / t[1]
         tree["traffic_over_algorithmic"] = tree["traffic"] / (tree_bytes / waves)
     return alone, tree
+
+
+def headline_variant(args, blob, dev_index, waves, lock_step=False, env=None):
+    """The headline workload once more under another switch (not part of `value`): same engine parameters, same warm-up, `waves` timed
+    waves without HIP events.  env: environment overrides the library reads when the engine is created (AZHIP_EVAL_CACHE=0)."""
+    import azhip
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        eng = azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, device=dev_index,
+                           num_workers=args.slots, batch_size=args.slots // args.groups, num_iters_per_turn=args.sims,
+                           gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
+                           prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
+                           num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32, lock_step=1 if lock_step else 0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        eng.net_set_params(blob)
+        eng.selfplay_begin(-1, first_game_id=1 << 25)
+        warm_up(eng, azhip.GAME_CONNECT_FOUR, args.sims, args.slots)
+        s0 = eng.selfplay_stats()
+        t0 = time.perf_counter()
+        eng.selfplay_step(waves)
+        s1 = eng.selfplay_stats()
+        dt = time.perf_counter() - t0
+        eng.selfplay_end()
+    finally:
+        eng.close()
+    sims, evals = s1.simulations - s0.simulations, s1.leaf_evals - s0.leaf_evals
+    return {"value": sims / dt, "unit": "sims/s", "waves": waves, "ms_per_wave": 1e3 * dt / waves, "schedule": "lock step" if lock_step else "free-running",
+            "sims_per_slot_per_wave": sims / max(s1.slot_launches - s0.slot_launches, 1),
+            "unique_leaf_frac": (evals - (s1.evals_reused - s0.evals_reused)) / max(evals, 1), "env": env or {}}
+
+
+def iterations_block(azhip, dev_index, iters=3, games=1024, workers=1024):
+    """`iters` training iterations (train!'s loop body, src/training.jl:321-333) at the reference's shipped Connect-Four learning and MCTS
+    parameters (games/connect-four/params.jl:5-75; tools/iterations.py is the stand-alone form) with a REDUCED number of games per
+    iteration, so that the driver's line shows whether the loop learns beyond the first epoch: learning_status of the
+    whole data set before / after each iteration's batch_updates!, the arena result, the replacement decision, and the evaluation
+    cache's hit rate as the network trains (unique_leaf_frac of the self-play phase)."""
+    from azhip.training import SelfPlayParams, train_iteration
+    from azhip import engine as E
+    gspec = azhip.ConnectFourSpec()
+    hp = azhip.ResNetHP(num_blocks=5, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32)
+    best = azhip.ResNet(gspec, hp, seed=1)
+    cur = best.copy_()
+    mcts = azhip.MctsParams(num_iters_per_turn=600, cpuct=2.0, prior_temperature=1.0, temperature=azhip.PLSchedule([0, 20, 30], [1.0, 1.0, 0.3]),
+                            dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0)
+    sp = SelfPlayParams(mcts=mcts, sim=azhip.SimParams(num_games=games, num_workers=workers, batch_size=workers, use_gpu=True, reset_every=2,
+                                                      flip_probability=0.0, alternate_colors=False))
+    amcts = azhip.MctsParams(num_iters_per_turn=600, cpuct=2.0, prior_temperature=1.0, temperature=azhip.ConstSchedule(0.2), dirichlet_noise_ϵ=0.05, dirichlet_noise_α=1.0)
+    arena = azhip.ArenaParams(mcts=amcts, sim=azhip.SimParams(num_games=128, num_workers=128, batch_size=128, use_gpu=True, reset_every=2,
+                                                               flip_probability=0.5, alternate_colors=True), update_threshold=0.05)
+    lp = azhip.LearningParams(use_position_averaging=True, samples_weighing_policy=azhip.LOG_WEIGHT, batch_size=1024, loss_computation_batch_size=1024,
+                              optimiser=azhip.Adam(lr=2e-3), l2_regularization=1e-4, nonvalidity_penalty=1.0, min_checkpoints_per_epoch=1,
+                              max_batches_per_checkpoint=2000, num_checkpoints=1)
+    mem = azhip.MemoryBuffer(gspec, 400000, device=dev_index)
+    rows = []
+    try:
+        for it in range(iters):
+            t0 = time.perf_counter()
+            cur, best, rep, lr = train_iteration(gspec, cur, best, mem, sp, lp, arena, seed=1 + it)
+            ck = lr.checkpoints[-1]
+            st = next((e.selfplay_stats() for k, e in E._cache.items() if k[0] == "selfplay" and e._h is not None), None)
+            rows.append({"iteration": it + 1, "seconds": time.perf_counter() - t0, "memory_size": rep.memory_size, "samples_per_sec": rep.samples_gen_speed,
+                         "sims_per_sec_self_play": rep.samples_gen_speed * 600,
+                         "unique_leaf_frac": (st.leaf_evals - st.evals_reused) / max(st.leaf_evals, 1) if st is not None else None,
+                         "leaf_evals_per_sim": st.leaf_evals / max(st.simulations, 1) if st is not None else None,
+                         "optimiser_steps": int(len(lr.losses)), "status_before": _status(lr.initial_status), "status_after": _status(ck.status_after),
+                         "arena_avgr": float(ck.evaluation.avgr), "nn_replaced": bool(ck.nn_replaced)})
+    finally:
+        mem.close()
+    return {"workload": "%d training iterations, %d self-play games each on %d workers (600 sims, ResNet 5x128, reset_every 2), shipped learning parameters "
+                        "(games/connect-four/params.jl:46-75), arena 128 games; random initial weights" % (iters, games, workers),
+            "iterations": rows,
+            "L_before_after": [[r["status_before"]["L"], r["status_after"]["L"]] for r in rows],
+            "arena_avgr": [r["arena_avgr"] for r in rows], "nn_replaced": [r["nn_replaced"] for r in rows],
+            "unique_leaf_frac": [r["unique_leaf_frac"] for r in rows]}
 
 
 def gather_leg(azhip, blob, dev_index, rank, world, games_per_rank=512, nsims=48):
@@ -551,6 +665,8 @@ def main():
     ap.add_argument("--slots", type=int, default=4096)
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--groups", type=int, default=1, help="slot groups = num_workers / batch_size: 1 (default since round 5) = one network launch per wave for all 4096 slots (batch_size 4096, BASELINE's 'batch 4096'); 2 = two interleaved half-batches, the tree kernels of one under the network of the other -- the better form while every leaf went to the network (rounds 1-4: 4.9 vs 4.85 M sims/s), the worse one since the evaluation cache answers ~40 %% of the leaves and a half-batch no longer fills the chip (8.0 vs 8.5 M sims/s, profiles/r5)")
+    ap.add_argument("--lock-step", action="store_true", help="az_engine_cfg.lock_step = 1: the schedule of rounds 1-5 (one simulation per slot and wave, moves in rounds)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the headline variants (2000-wave run, evaluation cache off, lock step: ~30 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra configurations (whole phase, C3, C4 Mancala, bf16 10x128, 128 workers) reported under `extra`")
     ap.add_argument("--no-iteration", action="store_true", help="skip extra.iteration (one whole training iteration at the reference's shipped Connect-Four parameters, ~1-2 min)")
@@ -602,7 +718,7 @@ def main():
                        num_workers=args.slots, batch_size=args.slots // args.groups, num_iters_per_turn=args.sims,
                        gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
                        prior_temperature=1.0, temperature=((0, 20, 30), (1.0, 1.0, 0.3)), reset_every=1, seed=1,
-                       num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32)
+                       num_blocks=5, num_filters=64, num_policy_head_filters=32, num_value_head_filters=32, lock_step=1 if args.lock_step else 0)
     eng.net_set_params(blob)
     dev_name, ncu, hbm = eng.device_info()
     eng.selfplay_begin(-1, first_game_id=rank * (1 << 24))
@@ -614,8 +730,7 @@ def main():
 
     # steady state whatever --warmup says: the state of a LONG phase -- slots at every stage of a game, the evaluation cache
     # holding what earlier games left in it -- not 4096 games in lock step through the same opening (mixing_warmup)
-    warm = max(args.warmup, mixing_warmup(azhip.GAME_CONNECT_FOUR, args.sims) + args.sims // 2)
-    eng.selfplay_step(warm)
+    warm = warm_up(eng, azhip.GAME_CONNECT_FOUR, args.sims, args.slots, extra_waves=args.warmup)
     s0 = eng.selfplay_stats()
     trace("warm-up done (%d waves)" % warm)
     if not args.no_prof:
@@ -640,6 +755,7 @@ def main():
     trav = s1.nodes_traversed - s0.nodes_traversed
     moves = s1.moves - s0.moves
     reused = s1.evals_reused - s0.evals_reused
+    slot_launches = s1.slot_launches - s0.slot_launches
     local_evals = evals - reused                                     # boards this rank's network evaluated (the rest came from the evaluation cache)
     local_elapsed = elapsed
     per_rank = [sims / elapsed]
@@ -691,7 +807,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Connect-Four self-play, %d sims/move, %d parallel games per GPU, ResNet 5x64 fp32 "
                                    "(heads 32/32), cpuct 2, eps 0.25, alpha 1, PLSchedule([0,20,30],[1,1,.3]), reset_every 1, num_workers/batch_size = %d; "
-                                   "step = one search wave (1 simulation per slot); evaluation cache %s" % (args.sims, args.slots, args.groups, "off (AZHIP_EVAL_CACHE=0)" if os.environ.get("AZHIP_EVAL_CACHE") == "0" else "on"),
+                                   "step = one search wave (%s); evaluation cache %s" % (args.sims, args.slots, args.groups,
+                                       "lock step: 1 simulation per slot" if args.lock_step or os.environ.get("AZHIP_FREE_RUN") == "0" else "free-running: every slot up to its next network evaluation, sims_per_slot_per_wave simulations on average",
+                                       "off (AZHIP_EVAL_CACHE=0)" if os.environ.get("AZHIP_EVAL_CACHE") == "0" else "on"),
+                       "schedule": "lock step" if args.lock_step or os.environ.get("AZHIP_FREE_RUN") == "0" else "free-running",
                        "slots_per_gpu": args.slots, "sims_per_move": args.sims, "slot_groups": args.groups, "leaves_per_network_launch": args.slots // args.groups, "parallelism": "dp%d (games sharded, no collective in the timed region)" % world,
                        "device": dev_name, "compute_units": ncu},
             "sims_per_sec_per_gpu": sims / elapsed / world,
@@ -703,6 +822,8 @@ def main():
             # oracle calls the network evaluated / oracle calls: the others were answered by the engine's evaluation cache (the same
             # state evaluated before for another slot or in an earlier wave; bit-identical answers, tests/test_eval_cache_gpu.py)
             "unique_leaf_frac": (evals - reused) / max(evals, 1),
+            # simulations a slot completes per wave (= per launch of the tree kernel): 1 in lock step
+            "sims_per_slot_per_wave": sims / max(slot_launches * (world if dist is not None else 1), 1),
         }
         if prof is not None:
             out["roofline"] = tower_roofline(azhip.GAME_CONNECT_FOUR, hp, False, eng_kernel, prof["tower"], local_evals, local_elapsed)
@@ -722,6 +843,16 @@ def main():
             alone, tree = alone_and_tree(args, blob, hp, dev_index, eng_kernel)
             out["roofline_kernel_alone"] = alone
             out["roofline_tree"] = tree
+        if world == 1 and not args.headline_only and not args.no_variants and not args.iteration:
+            # The driver times 20 waves (~18 ms): the same workload over 2000 waves gives that number its error bar; and the two switches a
+            # reader wants beside `value` -- the evaluation cache off (every oracle call a network evaluation: the kernel-only comparable of
+            # rounds 1-4) and the lock-step schedule of rounds 1-5
+            try:
+                out["value_long"] = headline_variant(args, blob, dev_index, 2000)
+                out["value_cache_off"] = headline_variant(args, blob, dev_index, 1000, env={"AZHIP_EVAL_CACHE": "0"})
+                out["value_lock_step"] = headline_variant(args, blob, dev_index, 2000, lock_step=True)
+            except Exception as ex:
+                out["value_variants_error"] = "%s: %s" % (type(ex).__name__, ex)
         if gather is not None:
             if world > 1 and "error" not in gather and gather.get("ranks") != world:
                 gather["error"] = "the exchange saw %s ranks, the job has %d" % (gather.get("ranks"), world)
@@ -734,7 +865,7 @@ def main():
                 ("whole_phase", lambda: whole_phase(azhip, dev_index, blob, hp, args.slots, args.sims, args.groups)),
                 ("c3", lambda: steady_block(azhip, dev_index, "c3", azhip.GAME_CONNECT_FOUR, 4096, args.groups, 600, hp, 200,
                                             note="BASELINE configs[2] per GPU (games/connect-four/params.jl:25)")),
-                ("c2_5x128", lambda: steady_block(azhip, dev_index, "c2_5x128", azhip.GAME_CONNECT_FOUR, 4096, 2, 600,
+                ("c2_5x128", lambda: steady_block(azhip, dev_index, "c2_5x128", azhip.GAME_CONNECT_FOUR, 4096, 1, 600,
                                                   mk(num_blocks=5, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32), 120,
                                                   note="the reference's shipped network and sims/move (games/connect-four/params.jl:7-30) at the BASELINE batch")),
                 ("c4_mancala", lambda: steady_block(azhip, dev_index, "c4_mancala", azhip.GAME_MANCALA, 8192, 1, 800, hp, 200, max_moves=256,
@@ -752,8 +883,9 @@ def main():
                        ("memory_pipeline", lambda: memory_block(azhip, dev_index)), ("arena_128", lambda: arena_block(azhip, dev_index))]
             if not args.no_iteration:
                 blocks.append(("iteration", lambda: iteration_block(azhip, dev_index, workers=int(os.environ.get("AZ_BENCH_ITER_WORKERS", "4096")))))
+                blocks.append(("iterations", lambda: iterations_block(azhip, dev_index)))
             if args.iteration:
-                blocks = [b for b in blocks if b[0] == "iteration"]
+                blocks = [b for b in blocks if b[0] in ("iteration", "iterations")]
             if os.environ.get("AZ_BENCH_ONLY"):                      # A/B aid: a comma-separated subset of the extra blocks
                 blocks = [b for b in blocks if b[0] in os.environ["AZ_BENCH_ONLY"].split(",")]
             out["extra"] = {}
@@ -784,7 +916,10 @@ def main():
                 b = ex.get(name, {})
                 return {k: (b.get("roofline", {}).get(k[9:]) if k.startswith("roofline.") else b.get(k)) for k in keys} if "error" not in b else {"error": b["error"]}
             out["summary"] = {
-                "headline_sims_per_sec": out["value"], "headline_unique_leaf_frac": out["unique_leaf_frac"],
+                "headline_sims_per_sec": out["value"], "headline_unique_leaf_frac": out["unique_leaf_frac"], "headline_sims_per_slot_per_wave": out["sims_per_slot_per_wave"],
+                "value_long": (out.get("value_long") or {}).get("value"), "value_cache_off": (out.get("value_cache_off") or {}).get("value"),
+                "value_lock_step": (out.get("value_lock_step") or {}).get("value"),
+                "iterations": {k: (ex.get("iterations") or {}).get(k) for k in ("L_before_after", "arena_avgr", "nn_replaced", "unique_leaf_frac", "error") if (ex.get("iterations") or {}).get(k) is not None},
                 "headline_tower_frac_of_fp32_mfma_peak": out.get("roofline", {}).get("frac"),
                 "kernel_alone_frac": out.get("roofline_kernel_alone", {}).get("frac"), "kernel_alone_avg_launch_ms": out.get("roofline_kernel_alone", {}).get("avg_launch_ms"),
                 "tree_us_per_wave": out.get("roofline_tree", {}).get("us_per_wave"), "tree_frac_of_hbm_peak": out.get("roofline_tree", {}).get("frac"),
@@ -805,6 +940,8 @@ def main():
                 rf["also_phase_sims_per_sec"], rf["also_phase_unique_leaf_frac"], rf["also_phase_tower_frac"] = ph.get("sims_per_sec"), ph.get("unique_leaf_frac"), ph.get("tower_frac_of_fp32_mfma_peak")
                 rf["also_c2_5x128_sims_per_sec"], rf["also_c2_5x128_tower_frac"] = sm["c2_5x128"].get("value"), sm["c2_5x128"].get("roofline.frac")
                 rf["also_iteration_seconds"] = sm["iteration"].get("seconds")
+                rf["also_value_long"], rf["also_value_cache_off"], rf["also_value_lock_step"] = sm["value_long"], sm["value_cache_off"], sm["value_lock_step"]
+                rf["also_sims_per_slot_per_wave"] = out["sims_per_slot_per_wave"]
                 lb, la = ((sm["learning"] or {}).get("before") or {}), ((sm["learning"] or {}).get("after") or {})
                 rf["also_learning_loss_before"], rf["also_learning_loss_after"] = lb.get("L"), la.get("L")
         print(json.dumps(out), flush=True)

@@ -21,7 +21,8 @@ def main(iters=2, games=256, workers=128, sims=100, filters=64, batch=256, seed=
     sp = SelfPlayParams(
         mcts=azhip.MctsParams(num_iters_per_turn=sims, cpuct=2.0, dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0,
                               temperature=azhip.PLSchedule([0, 20, 30], [1.0, 1.0, 0.3])),
-        sim=azhip.SimParams(num_games=games, num_workers=workers, batch_size=max(1, workers // 2), use_gpu=True, reset_every=2))
+        sim=azhip.SimParams(num_games=games, num_workers=workers, batch_size=max(1, workers // 2), use_gpu=True, reset_every=2,
+                            lock_step=True))   # reset_every 2: which games share a tree is a race between free-running workers (as in the reference); lock step makes the run repeatable
     ng = max(2, games // 4)
     arena = azhip.ArenaParams(
         mcts=azhip.MctsParams(num_iters_per_turn=sims, cpuct=2.0, dirichlet_noise_ϵ=0.05, dirichlet_noise_α=1.0,

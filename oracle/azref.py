@@ -333,10 +333,28 @@ class Evals:
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float))
 
 
+def usable_cpus():
+    """CPUs this process can really use: the affinity mask, cut down to the cgroup's CPU quota (cpu.max: the GPU box shows 256 hardware
+    threads and grants 16 CPUs' worth of time; 64 spinning threads then take 71 s for a replay, 128 take 103 s, 256 do not finish)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def replay(game, evaluate, num_games, num_workers, nsims, evals=None, threads=None, assignment=None, **kw):
     """REPLAY MODE (SURVEY.md §7 hard part 3): `simulate` -- the same lock-step loop, the same tree code -- with every oracle answer
     supplied by the caller, e.g. by the device network behind az_net_evaluate_keys.  The oracle's trees then run on the other
-    evaluator's numbers, at CPU-tree speed on `threads` host threads (default: all of them, 16 workers or more per thread).
+    evaluator's numbers, at CPU-tree speed on `threads` host threads (default: as many as the process may really use -- usable_cpus -- with 16 workers or more each).
     evaluate: a callable  keys uint64[n, 2] -> (P float32[n, A] by full action index, V float32[n]),  or a pair (address, user) of a C
     function  int f(void* user, const uint64_t* keys, int32_t n, float* P, float* V)  (0 = ok) that is called without Python in between.
     Returns (games, moves, num_moves, info); info: steps (rounds of evaluation + move rounds), evaluated (states sent to the
@@ -377,7 +395,8 @@ def replay(game, evaluate, num_games, num_workers, nsims, evals=None, threads=No
     else:
         fn, user = C.c_void_p(evaluate[0]), C.c_void_p(evaluate[1])
     if threads is None:
-        threads = max(1, min(os.cpu_count() or 1, (G + 15) // 16))
+        # the workers spin at a barrier between the rounds: never more threads than CPUs this process may run on (AZ_REPLAY_THREADS overrides)
+        threads = int(os.environ.get("AZ_REPLAY_THREADS", 0)) or max(1, min(usable_cpus(), (G + 15) // 16))
     h = C.c_void_p(L.azr_sim_new(C.byref(p), games, moves, cap, evals.h))
     nev = C.c_int64(0)
     w, wp = _worker_of(assignment, num_games)
