@@ -107,7 +107,7 @@ static void drop_wave_graphs(az_engine* e);
 extern "C" int az_engine_destroy(az_engine* e) {
   if (!e) return AZ_OK;
   (void)hipSetDevice(e->device);
-  if (e->ngroups == 1 && e->fr_s[0] && e->gs[0] == e->fr_s[0]) { for (int i = 0; i < 3; ++i) (void)hipStreamSynchronize(e->fr_s[i]); e->gs[0] = e->gt[0] = e->stream; }
+  if (e->ngroups == 1 && e->fr_s[0] && e->gs[0] == e->fr_s[0]) { for (int i = 0; i < 4; ++i) (void)hipStreamSynchronize(e->fr_s[i]); e->gs[0] = e->gt[0] = e->stream; }
   for (int g = 0; g < e->ngroups; ++g) if (e->gs[g] && e->gs[g] != e->stream) {
     (void)hipStreamSynchronize(e->gt[g]); (void)hipStreamSynchronize(e->gs[g]);
     (void)hipStreamDestroy(e->gt[g]); (void)hipStreamDestroy(e->gs[g]);
@@ -119,7 +119,7 @@ extern "C" int az_engine_destroy(az_engine* e) {
   if (e->h_nleaf) (void)hipHostFree(e->h_nleaf);
   if (e->h_fr_words) (void)hipHostFree(e->h_fr_words);
   if (e->h_busy) (void)hipHostFree(e->h_busy);
-  for (int i = 0; i < 3; ++i) { if (e->fr_s[i]) { (void)hipStreamSynchronize(e->fr_s[i]); (void)hipStreamDestroy(e->fr_s[i]); } if (e->fr_ev[i]) (void)hipEventDestroy(e->fr_ev[i]); }
+  for (int i = 0; i < 4; ++i) { if (e->fr_s[i]) { (void)hipStreamSynchronize(e->fr_s[i]); (void)hipStreamDestroy(e->fr_s[i]); } if (e->fr_ev[i]) (void)hipEventDestroy(e->fr_ev[i]); }
   if (e->d_done) (void)hipFree(e->d_done);
   if (e->d_done_off) (void)hipFree(e->d_done_off);
   if (e->h_env) (void)hipHostFree(e->h_env);
@@ -254,7 +254,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   e->next_exec = 1.0;
   e->h_env = nullptr; e->h_n = nullptr; e->h_pv = nullptr; e->h_nleaf = nullptr; e->d_nleaf = nullptr;
   e->d_ec = nullptr; e->ec_mask = 0; e->ec_seq = 0; e->d_ec_claim = nullptr; e->d_Phit = nullptr; e->d_Vhit = nullptr;
-  e->fr_on = false; e->fr_k = 0; e->fr_kbg = 0; e->fr_round_waves = 0; e->fr_s[0] = e->fr_s[1] = e->fr_s[2] = nullptr; e->fr_ev[0] = e->fr_ev[1] = e->fr_ev[2] = nullptr; e->d_fr = nullptr; e->d_done = nullptr; e->d_done_off = nullptr; e->done_cap = 0;
+  e->fr_on = false; e->fr_k = 0; e->fr_kbg = 0; e->fr_round_waves = 0; for (int i = 0; i < 4; ++i) { e->fr_s[i] = nullptr; e->fr_ev[i] = nullptr; } e->d_fr = nullptr; e->d_done = nullptr; e->d_done_off = nullptr; e->done_cap = 0;
   e->h_fr_words = nullptr; e->d_fr_words = nullptr; e->h_busy = nullptr; e->d_busy = nullptr; e->explore_k = 0; e->fr_prev_done = 0; e->fr_since_round = 0; e->fr_given_up = 0; e->fr_prev_recs = 0;
   e->h_xflag = nullptr; e->d_xflag = nullptr; e->split_off = false; e->split_registered = 0; e->xch_launches = 0;
   { const char* fa = getenv("AZHIP_XCH_FAIL_AT"); e->xch_fail_at = fa ? atoll(fa) : 0; }
@@ -485,7 +485,8 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
         HIPCHK(hipStreamCreateWithPriority(&e->fr_s[0], hipStreamNonBlocking, hi));
         HIPCHK(hipStreamCreateWithPriority(&e->fr_s[1], hipStreamNonBlocking, hi));
         HIPCHK(hipStreamCreateWithPriority(&e->fr_s[2], hipStreamNonBlocking, hi));
-        for (int i = 0; i < 3; ++i) HIPCHK(hipEventCreateWithFlags(&e->fr_ev[i], hipEventDisableTiming));
+        HIPCHK(hipStreamCreateWithPriority(&e->fr_s[3], hipStreamNonBlocking, hi));
+        for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&e->fr_ev[i], hipEventDisableTiming));
       } else {
         // the short latency-bound tree kernels must not queue behind the other group's tower workgroups:
         // they get the high-priority queue, the tower the normal one
@@ -829,6 +830,7 @@ extern "C" int az_net_set_params(az_engine* e, const float* blob, int64_t n) {
     AZCHK(up(h16_w, &tmp)); n16.head_w = (const float4*)tmp; n16.head_ss = nd.head_ss;
     for (int k = 0; k < 3; ++k) n16.geo[k] = e->d_geo[k];
     n16.geo[3] = e->d_geo[5];
+    n16.geo[4] = e->d_geo[6];
   }
   e->net16 = n16;
   {
@@ -999,7 +1001,10 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
   hipStream_t s2 = st;
   e->bg_signal = false;
   const bool side = e->fr_on && !split && e->cfg.oracle == AZ_ORACLE_RESNET && e->fr_s[1] && st == e->fr_s[0];
-  if (side) { s2 = e->fr_s[1]; HIPCHK(hipEventRecord(e->fr_ev[0], st)); ++e->bg_seq; e->bg_signal = e->fr_kbg > 0; }
+  // (the stop word of the background search: without it a background launch of fr_kbg simulations outlasts a SHORT tower and the next wave
+  // waits for it -- Mancala, 8192 slots: 19.8 instead of 39.7 M sims/s; AZHIP_BG_STOP=0 switches it off)
+  static const bool bg_stop_on = !(getenv("AZHIP_BG_STOP") && atoi(getenv("AZHIP_BG_STOP")) == 0);
+  if (side) { s2 = e->fr_s[1]; HIPCHK(hipEventRecord(e->fr_ev[0], st)); ++e->bg_seq; e->bg_signal = bg_stop_on && e->fr_kbg > 0; }
   if (e->cfg.oracle == AZ_ORACLE_RESNET) {
     AZCHK(net_wave(e, g, split, e->group_active[g]));
   } else {
@@ -1023,7 +1028,7 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
       AZCHK(ec_next_launch(e, &e->gv[g]));
       DView bv = e->gv[g];
       bv.run_k = e->fr_kbg; bv.low_prio = bg_prio ? 0 : 1;
-      if (side) { bv.bg_stop = e->d_bg_stop; bv.bg_seq = e->bg_seq; }   // ... until the wave's tower has run (net_impl.h sets the word)
+      if (side && e->bg_signal) { bv.bg_stop = e->d_bg_stop; bv.bg_seq = e->bg_seq; }   // ... until the wave's tower has run (net_impl.h sets the word)
       LAUNCH_ON(e, s2, AZ_K_EXPAND, G, (k_tree<Gm>), gb, 256, 0, bv, e->p, 0, 1, par ^ 1);
     }
     if (side) {
@@ -1715,7 +1720,7 @@ extern "C" int az_selfplay_end(az_engine* e) {
   e->fr_on = false;
   for (int g = 0; g < e->ngroups; ++g) { e->gv[g].run_k = 0; e->gv[g].fr = 0; e->gv[g].fr_active = nullptr; }
   if (e->ngroups == 1 && e->gs[0] != e->stream) {                    // back to the engine's one stream
-    HIPCHK(hipStreamSynchronize(e->gs[0])); HIPCHK(hipStreamSynchronize(e->fr_s[1])); HIPCHK(hipStreamSynchronize(e->fr_s[2]));
+    HIPCHK(hipStreamSynchronize(e->gs[0])); for (int i = 1; i < 4; ++i) HIPCHK(hipStreamSynchronize(e->fr_s[i]));
     e->gs[0] = e->gt[0] = e->stream;
   }
   return AZ_OK;

@@ -109,7 +109,7 @@ struct az_engine {
   NetDev net;
   Net16bDev net16b;              // bf16 fragments (cfg.net_bf16)
   Net16Dev net16;                // k_tower16 fragments (64 filters)
-  uint16_t* d_geo[6];            // Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h), [3]: 22 tiles (k_tower16b, 8 boards), [4]: 6 tiles (k_conv16_layer of the trainer at small batches), [5]: the exact-fit variant (NTM<Game> tiles), if the game has one
+  uint16_t* d_geo[7];            // [6]: the 19-tile paired form (k_tower16x2<.., 10, 9>); [0..5]: Geo16 tables of the 11-tile, 3-tile and 21-tile tower kernels (resnet16.h), [3]: 22 tiles (k_tower16b, 8 boards), [4]: 6 tiles (k_conv16_layer of the trainer at small batches), [5]: the exact-fit variant (NTM<Game> tiles), if the game has one
   int nts;                       // row tiles of the game's latency tower variant (NTS<Game>, resnet16.h)
   int ntm;                       // row tiles of the game's exact-fit variant (NTM<Game>), 0 = none
   long long tower_hist[4];       // network launches served by: the split tower, the 3-row-tile form, the packed 11 / 21-tile forms, others (AZHIP_TRACE_ARENA)
@@ -141,7 +141,7 @@ struct az_engine {
   // finished games into the phase buffer itself; the host looks every fr_round_waves waves (fr_round, azhip.hip)
   bool fr_on;                        // the phase in progress is free-running
   int fr_k, fr_kbg, fr_round_waves;  // simulations a slot may select per wave launch / per background launch (DView::run_k); waves between two looks of the host
-  hipStream_t fr_s[3]; hipEvent_t fr_ev[3];   // one slot group: the tree / network streams and events of its free-running phases (gs[0] / gt[0] / ev_* point at them meanwhile)
+  hipStream_t fr_s[4]; hipEvent_t fr_ev[4];   // one slot group: the tree / network streams and events of its free-running phases (gs[0] / gt[0] / ev_* point at them meanwhile)
   FRState* d_fr; az_game_rec* d_done; long long* d_done_off; int done_cap;
   int* h_busy; int* d_busy;      // [AZ_MAX_GROUPS] host-mapped: slots of each group still inside an explore! that runs ahead (DView::busy_host)
   int explore_k;                 // simulations per slot and launch inside MCTS.explore! of the hooks and the arena (AZHIP_EXPLORE_K; 0 / 1 = lock step)
@@ -186,7 +186,7 @@ inline int sync_groups(az_engine* e) {
     HIPCHK(hipStreamSynchronize(e->gt[g]));
     HIPCHK(hipStreamSynchronize(e->gs[g]));
   }
-  if (e->fr_on && e->fr_s[1]) { HIPCHK(hipStreamSynchronize(e->fr_s[1])); HIPCHK(hipStreamSynchronize(e->fr_s[2])); }   // one slot group, free-running: the side stream (move step, background search)
+  if (e->fr_on && e->fr_s[1]) for (int i = 1; i < 4; ++i) HIPCHK(hipStreamSynchronize(e->fr_s[i]));   // one slot group, free-running: the side stream (move step, background search)
   return AZ_OK;
 }
 inline int sync_all(az_engine* e) {

@@ -15,6 +15,8 @@ template <class Gm, int F, bool PLANES_ONLY = false> static int set_kernel_attrs
   if constexpr (F == 64) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, false, 10, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F, 10, 9>::BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, true, 10, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F, 10, 9>::BYTES));
   }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
@@ -62,6 +64,7 @@ template <class Gm> static int set_kernel_attrs(az_engine* e) {
   AZCHK((upload_geo<typename T16<Gm, 64, 11>::Geo>(e, 0)));
   AZCHK((upload_geo<typename T16<Gm, 64, NTS<Gm>>::Geo>(e, 1)));
   AZCHK((upload_geo<typename T16P<Gm, 64>::Geo>(e, 2)));
+  AZCHK((upload_geo<typename T16P<Gm, 64, 10, 9>::Geo>(e, 6)));
   AZCHK((upload_geo<typename T16B<Gm, 128, 22>::Geo>(e, 3)));
   AZCHK((upload_geo<typename T16<Gm, 64, 6>::Geo>(e, 4)));
   e->d_geo[5] = nullptr;
@@ -73,10 +76,11 @@ template <class Gm> static int set_kernel_attrs(az_engine* e) {
 static void note_tower(az_engine* e, int tw, int F) {
   static const char* const gn[] = {"ConnectFour", "TicTacToe", "Mancala", "Go9Planes"};
   const char* g = gn[e->cfg.game];
-  e->tower_hist[tw == 2 ? 0 : tw == 3 ? 1 : (tw == 16 || tw == 21) ? 2 : 3]++;
+  e->tower_hist[tw == 2 ? 0 : tw == 3 ? 1 : (tw == 16 || tw == 21 || tw == 19) ? 2 : 3]++;
   if (e->cfg.net_bf16) { snprintf(e->last_tower, sizeof e->last_tower, "k_tower16b<%s,%d,NT=%d>", g, F, tw == 3 ? e->nts : tw == 22 ? 22 : 11); return; }
   if (tw == 2) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16s<%s,%d>", g, F);
   else if (tw == 21) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d>", g, F);
+  else if (tw == 19) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d,NT=19>", g, F);
   else if (tw == 3) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=%d>", g, F, e->nts);
   else if (tw == 7) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=%d>", g, F, e->ntm);
   else if (tw == 16) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=11>", g, F);
@@ -106,7 +110,7 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n, int 
   const bool can_split = F == 128 && !e->cfg.net_bf16 && !e->use_graphs && e->cfg.num_blocks <= 127 && !e->split_off &&
                          2 * std::max(std::max(1, e->ngroups), split_streams_on_device(e->device)) * ((nb + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB) <= (e->num_cu > 0 ? e->num_cu : 256);
   if (e->tower_pick == 2 && can_split) return 2;
-  if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || (e->tower_pick == 21 && F == 64) || (e->tower_pick == 7 && NTM<Gm> > 0))) return e->tower_pick;
+  if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || ((e->tower_pick == 21 || e->tower_pick == 19) && F == 64) || (e->tower_pick == 7 && NTM<Gm> > 0))) return e->tower_pick;
   if (e->cfg.net_bf16) {                                           // k_tower16b: 22 (128 filters), 11 or 3 row tiles
     if (e->tower_pick == 3 || e->tower_pick == 16) return e->tower_pick;
     if (e->tower_pick == 22 && F == 128) return 22;
@@ -171,6 +175,7 @@ template <class Gm, int F> static double tower_exec_frac(const az_engine* e, int
   if constexpr (NTM<Gm> > 0) { if (tw == 7) return T16<Gm, F, NTM<Gm>>::Geo::tab.cost / (9.0 * NTM<Gm>); }
   if (tw == 16) return T16<Gm, F>::Geo::tab.cost / (9.0 * T16<Gm, F>::NTILE);
   if (tw == 21) return T16P<Gm, 64>::Geo::tab.cost / (9.0 * T16P<Gm, 64>::NTW);
+  if (tw == 19) return T16P<Gm, 64, 10, 9>::Geo::tab.cost / (9.0 * T16P<Gm, 64, 10, 9>::NTW);
   return 1.0;
 }
 // publish areas of k_tower16s for the launches that write `hfeat` (one feature buffer = one stream at a time)
@@ -248,7 +253,12 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
     }
   } else if (tw == 21) {
     if constexpr (F == 64)
-      LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat);
+      LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat, 0);
+  } else if (tw == 19) {
+    if constexpr (F == 64) {
+      using T19 = T16P<Gm, 64, 10, 9>;
+      LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES, 10, 9>), (n_max + T19::TB - 1) / T19::TB, (T19::THREADS), (T19::BYTES), e->net16, envs, eslots, n_ptr, n_max, X, hfeat, 0);
+    }
   } else if (tw == 7) {
     if constexpr (NTM<Gm> > 0) {
       using TM = T16<Gm, F, NTM<Gm>>;
@@ -306,9 +316,29 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
       LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16s<Gm, F, false>), 2 * ((N + TB3 - 1) / TB3), (T16S<Gm, F>::THREADS), LDS3, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g],
                 xa, ep, v.xerr, e->d_xflag);
     }
-  } else if (tw == 21) {
-    if constexpr (F == 64)
-      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g]);
+  } else if (tw == 21 || tw == 19) {
+    if constexpr (F == 64) {
+      // (r6, measured, OFF by default) Two rounds of workgroups, the second one lighter.  A batch of b boards with 8 cu < b <= 8 cu + 7 cu
+      // (cu = 256: 2048 < b <= 3840 -- a free-running wave's batch at 4096 slots is ~3800) costs two rounds of the 8-board form whatever b
+      // is; served as one launch of cu 8-board workgroups and one of up to cu 7-board workgroups for the rest, the second round should be
+      // 7/8 as long.  It is not: a launch of ONE round lasts as long as its slowest workgroup (490 us against the 399 us a round
+      // averages inside a two-round launch, where a CU that is done early simply takes the next workgroup; the 7-board launch 677 us):
+      // 1.10 ms per wave instead of 0.80 (profiles/r6/README.md).  The 19-tile form stays (bit-exact like every form, tests/test_net.py
+      // forces it with AZHIP_TOWER=19; 355 us per round of 7-board workgroups); AZHIP_TOWER_ROUNDS=1 switches the two-launch scheme on.
+      using T19 = T16P<Gm, 64, 10, 9>;
+      static const bool rounds_on = getenv("AZHIP_TOWER_ROUNDS") && atoi(getenv("AZHIP_TOWER_ROUNDS")) != 0;
+      const int cu = e->num_cu > 0 ? e->num_cu : 256, first = cu * TB21;
+      const int seen = v.nleaf_host ? ((volatile int*)e->h_nleaf)[g] : -1;
+      if (tw == 19) {
+        LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false, 10, 9>), (N + T19::TB - 1) / T19::TB, (T19::THREADS), (T19::BYTES), e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g], 0);
+      } else if (rounds_on && e->tower_pick == 0 && N > first && seen > first && seen + 16 <= first + cu * T19::TB) {
+        LAUNCH_ON(e, sn, AZ_K_TOWER, first, (k_tower16x2<Gm, F, false>), cu, THR21, LDS21, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g], 0);
+        e->next_exec = tower_exec_frac<Gm, F>(e, 19);
+        LAUNCH_ON(e, sn, AZ_K_TOWER, N - first, (k_tower16x2<Gm, F, false, 10, 9>), (N - first + T19::TB - 1) / T19::TB, (T19::THREADS), (T19::BYTES), e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g], first);
+      } else {
+        LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g], 0);
+      }
+    }
   } else if (tw == 7) {
     if constexpr (NTM<Gm> > 0) {
       using TM = T16<Gm, F, NTM<Gm>>;
@@ -324,7 +354,13 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   // (wave_group, azhip.hip) first queues the group's move step and its background search behind k_tree, then the wait for ev_net: both
   // run under this tower.
   const bool fr = e->fr_on && split;
-  if (e->bg_signal) hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, sn, e->d_bg_stop, e->bg_seq);   // the tower has run: the background search of this wave winds up while the heads run
+  if (e->bg_signal) {
+    // the tower has run: the background search of this wave winds up while the heads run.  The word is set from a stream of its own behind
+    // an event (a one-thread launch IN the wave's stream sat 7.6 us between tower and heads)
+    HIPCHK(hipEventRecord(e->fr_ev[3], sn));
+    HIPCHK(hipStreamWaitEvent(e->fr_s[3], e->fr_ev[3], 0));
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, e->fr_s[3], e->d_bg_stop, e->bg_seq);
+  }
   if (split && !fr) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
   AZCHK((launch_heads<Gm, F>(e, fr ? sn : st, e->g_hfeat[g], v.leaf_env, eslots, nev, N, (const float*)nullptr, v.Pout, v.Vout, (float*)nullptr, L)));
   if (fr) HIPCHK(hipEventRecord(e->ev_net[g], sn));

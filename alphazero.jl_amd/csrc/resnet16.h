@@ -31,7 +31,7 @@ struct Net16Dev {
   const float* conv_ss;     // [2*nblocks][2][64]
   const float4* head_w;     // [4 col tiles][4][64] float4
   const float* head_ss;     // [2][64]
-  const uint16_t* geo[4];   // row permutation tables (Geo16: pos [RPAD], nbr [9][RPAD]) of the 11-tile, 3-tile and 21-tile kernels, [3]: the exact-fit variant (NTM)
+  const uint16_t* geo[5];   // row permutation tables (Geo16: pos [RPAD], nbr [9][RPAD]) of the 11-tile, 3-tile and 21-tile kernels, [3]: the exact-fit variant (NTM), [4]: the 19-tile paired form
   unsigned long long* dbg;  // optional [workgroups][8] s_memtime stamps (az_debug_tower_timeline): 0 start, 1 stem done, 2 tower done, 3 features written; layer 2: 6 start, 4 convolution done, 5 barrier passed, 7 epilogue done
 };
 // ---------------------------------------------------------------------------------------------------------------
@@ -247,8 +247,11 @@ template <class Gm, int F = 64, int NT = 11> struct T16 {
 // 336 rows = exactly 8 Connect-Four boards (24 Mancala, 37 Tic-tac-toe).  Set 0 owns tiles 0..10, set 1 tiles
 // 11..20: 21 tile-units per 8 boards instead of the 22 (2 x 11, 8 padding rows per 4 boards) of two k_tower16
 // workgroups -- the same two wavefronts per SIMD, 4.5 % fewer MFMAs per board.  92 KB of LDS, one workgroup per CU.
-template <class Gm, int F = 64> struct T16P {
-  static constexpr int NT0 = 11, NT1 = 10, NTW = NT0 + NT1, RPAD = NTW * 16;
+// (r6) NT0_ / NT1_ = 10 / 9: 19 row tiles = 304 rows = 7 Connect-Four boards -- the form of a launch's SECOND round of workgroups when
+// the batch is between 15 and 16 boards per CU (a free-running wave's 3700-3840 boards: 256 workgroups of 8 + up to 256 of 7 instead
+// of two rounds of 8, the second 86 % full: net_impl.h wave_net_f).
+template <class Gm, int F = 64, int NT0_ = 11, int NT1_ = 10> struct T16P {
+  static constexpr int NT0 = NT0_, NT1 = NT1_, NTW = NT0 + NT1, RPAD = NTW * 16;
   static constexpr int TB = RPAD / Gm::P;
   static constexpr int ROWS = TB * Gm::P;
   static constexpr int STRIDE = F + 8;
@@ -699,20 +702,21 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
 }
 
 // The paired form (T16P): wavefronts 0..CT-1 run tiles 0..10, wavefronts CT..2CT-1 tiles 11..20 of ONE buffer.
-template <class Gm, int F, bool FROM_PLANES>
+// base = index of the launch's first board (a batch served by two launches: the first 8 x num_cu boards by the 21-tile form, the rest by the 19-tile one)
+template <class Gm, int F, bool FROM_PLANES, int NT0 = 11, int NT1 = 10>
 __global__ void __launch_bounds__(2 * T16Threads<F>::V, 1)
 k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
-            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat) {
-  using T = T16P<Gm, F>;
+            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat, int base) {
+  using T = T16P<Gm, F, NT0, NT1>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
   float* planes = lds + T::BUF;
   uint16_t* nbr = (uint16_t*)(planes + T::PLANES);
   uint16_t* pos = nbr + 9 * T::RPAD;
   const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
-  const int board0 = blockIdx.x * T::TB;
+  const int board0 = base + blockIdx.x * T::TB;
   if (board0 >= n) return;
-  tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[2], leaf_env, eval_slots, X, n, board0, threadIdx.x);
+  tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[NT0 == 11 ? 2 : 4], leaf_env, eval_slots, X, n, board0, threadIdx.x);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave < T::CT) tower16_wave<T, FROM_PLANES, T::NT0, 0>(net, buf, planes, nbr, pos, wave, lane, n, board0, hfeat);

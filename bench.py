@@ -109,34 +109,47 @@ def pmc_lookup(kernel, config="f32"):
     return None
 
 
+HEADLINE_WARMUP_GAME_LENGTHS = 3.0
 MEAN_MOVES = {0: 23, 1: 7, 2: 24}     # moves per self-play game at the shipped parameters (measured: 92 961 / 4096, 194 061 / 8192)
 
 
-def mixing_warmup(game, sims):
+def mixing_warmup(game, sims, lengths=1.5):
     """Waves after which a batch of slots that all started at wave 0 is in the steady state of a long phase: slots at every stage
     of a game (1.5 mean game lengths: the first generation of games has ended at moves 7 ... 42, every slot is somewhere in its
     second or third game).  Round 5: with the evaluation cache the state of the batch matters -- 4096 games in lock step through
     the same opening ask for the same evaluations (86 % repeats in the second move), a long phase's batch does not."""
-    return int(1.5 * MEAN_MOVES[game] * sims)
+    return int(lengths * MEAN_MOVES[game] * sims)
 
 
-def warm_up(eng, game, sims, slots, extra_waves=0):
+def warm_up(eng, game, sims, slots, extra_waves=0, lengths=1.5):
     """Steps the phase until it is in the steady state mixing_warmup describes, whatever the schedule: a lock-step wave is one simulation
-    per slot, a free-running one about two, so the warm-up is counted in SIMULATIONS (mixing_warmup x slots) and stepped in chunks."""
-    target = (mixing_warmup(game, sims) + sims // 2) * slots
+    per slot, a free-running one about two, so the warm-up is counted in SIMULATIONS (mixing_warmup x slots) and stepped in chunks.
+    lengths: mean game lengths to play first.  1.5 (rounds 2-5) leaves the batch lumpy -- the 4096 games that started together still
+    end in bunches, and network evaluations per simulation swing between 0.41 and 0.49 with the period of a game (profiles/r6/
+    drift_lock_step.jsonl), i.e. +-10 % of throughput depending on WHEN a short window looks; after ~2.5 game lengths the swing is
+    below 2 %.  The headline and its variants use 3, the extra blocks (their windows are not the driver's 20 waves) keep 1.5."""
+    target = (mixing_warmup(game, sims, lengths) + sims // 2) * slots
     waves = 0
+
+    def drain():
+        # the games that end are queued for az_selfplay_collect; a refill-forever phase nobody collects grows that queue by 64 B per move
+        # -- and the reallocation of a 20 MB vector inside a 20-wave timed region is a 7 ms stall (seen once in three runs): collect and drop
+        eng.selfplay_collect(2 * slots)
     while eng.selfplay_stats().simulations < target:
         eng.selfplay_step(500)
         waves += 500
+        drain()
     if extra_waves > waves:
         eng.selfplay_step(extra_waves - waves)
         waves = extra_waves
+        drain()
     return waves
 
 
 def steady_block(azhip, dev_index, label, game, slots, groups, sims, hp, waves, bf16=False, note=None, max_moves=0):
     """One extra configuration, measured like the headline: steady state of a long phase (mixing_warmup), `waves`
     timed search waves, tower launches timed with HIP events, roofline on the tower kernel."""
+    groups = int(os.environ.get("AZ_BENCH_GROUPS", groups))         # A/B aid
     from azhip.network import random_params
     eng = azhip.Engine(game=game, oracle=azhip.ORACLE_RESNET, device=dev_index, num_workers=slots, batch_size=slots // groups,
                        num_iters_per_turn=sims, gamma=1.0, cpuct=2.0, dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0,
@@ -349,7 +362,7 @@ def iteration_block(azhip, dev_index, num_games=5000, workers=4096):
     cur = best.copy_()
     mcts = azhip.MctsParams(num_iters_per_turn=600, cpuct=2.0, prior_temperature=1.0, temperature=azhip.PLSchedule([0, 20, 30], [1.0, 1.0, 0.3]),
                             dirichlet_noise_ϵ=0.25, dirichlet_noise_α=1.0)
-    sp = SelfPlayParams(mcts=mcts, sim=azhip.SimParams(num_games=num_games, num_workers=workers, batch_size=workers, use_gpu=True, reset_every=2,
+    sp = SelfPlayParams(mcts=mcts, sim=azhip.SimParams(num_games=num_games, num_workers=workers, batch_size=workers // 2, use_gpu=True, reset_every=2,
                                                       flip_probability=0.0, alternate_colors=False))
     amcts = azhip.MctsParams(num_iters_per_turn=600, cpuct=2.0, prior_temperature=1.0, temperature=azhip.ConstSchedule(0.2), dirichlet_noise_ϵ=0.05, dirichlet_noise_α=1.0)
     arena = azhip.ArenaParams(mcts=amcts, sim=azhip.SimParams(num_games=128, num_workers=128, batch_size=128, use_gpu=True, reset_every=2,
@@ -469,7 +482,7 @@ def alone_and_tree(args, blob, hp, dev_index, kernel, waves=200):
         try:
             eng.net_set_params(blob)
             eng.selfplay_begin(-1, first_game_id=1 << 28)
-            warm_up(eng, azhip.GAME_CONNECT_FOUR, args.sims, args.slots)
+            warm_up(eng, azhip.GAME_CONNECT_FOUR, args.sims, args.slots, lengths=HEADLINE_WARMUP_GAME_LENGTHS)
             s0 = eng.selfplay_stats()
             eng.prof_reset()
             eng.prof_enable(True)
@@ -538,7 +551,7 @@ def headline_variant(args, blob, dev_index, waves, lock_step=False, env=None):
     try:
         eng.net_set_params(blob)
         eng.selfplay_begin(-1, first_game_id=1 << 25)
-        warm_up(eng, azhip.GAME_CONNECT_FOUR, args.sims, args.slots)
+        warm_up(eng, azhip.GAME_CONNECT_FOUR, args.sims, args.slots, lengths=HEADLINE_WARMUP_GAME_LENGTHS)
         s0 = eng.selfplay_stats()
         t0 = time.perf_counter()
         eng.selfplay_step(waves)
@@ -730,7 +743,7 @@ def main():
 
     # steady state whatever --warmup says: the state of a LONG phase -- slots at every stage of a game, the evaluation cache
     # holding what earlier games left in it -- not 4096 games in lock step through the same opening (mixing_warmup)
-    warm = warm_up(eng, azhip.GAME_CONNECT_FOUR, args.sims, args.slots, extra_waves=args.warmup)
+    warm = warm_up(eng, azhip.GAME_CONNECT_FOUR, args.sims, args.slots, extra_waves=args.warmup, lengths=HEADLINE_WARMUP_GAME_LENGTHS)
     s0 = eng.selfplay_stats()
     trace("warm-up done (%d waves)" % warm)
     if not args.no_prof:
@@ -865,12 +878,12 @@ def main():
                 ("whole_phase", lambda: whole_phase(azhip, dev_index, blob, hp, args.slots, args.sims, args.groups)),
                 ("c3", lambda: steady_block(azhip, dev_index, "c3", azhip.GAME_CONNECT_FOUR, 4096, args.groups, 600, hp, 200,
                                             note="BASELINE configs[2] per GPU (games/connect-four/params.jl:25)")),
-                ("c2_5x128", lambda: steady_block(azhip, dev_index, "c2_5x128", azhip.GAME_CONNECT_FOUR, 4096, 1, 600,
+                ("c2_5x128", lambda: steady_block(azhip, dev_index, "c2_5x128", azhip.GAME_CONNECT_FOUR, 4096, 2, 600,
                                                   mk(num_blocks=5, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32), 120,
                                                   note="the reference's shipped network and sims/move (games/connect-four/params.jl:7-30) at the BASELINE batch")),
                 ("c4_mancala", lambda: steady_block(azhip, dev_index, "c4_mancala", azhip.GAME_MANCALA, 8192, 1, 800, hp, 200, max_moves=256,
                                                     note="BASELINE configs[3] (games/mancala/params.jl:23-29), bug-compatible flip_colors")),
-                ("bf16_10x128", lambda: steady_block(azhip, dev_index, "bf16_10x128", azhip.GAME_CONNECT_FOUR, 4096, 1, 400,
+                ("bf16_10x128", lambda: steady_block(azhip, dev_index, "bf16_10x128", azhip.GAME_CONNECT_FOUR, 4096, 2, 400,
                                                      mk(num_blocks=10, num_filters=128, num_policy_head_filters=32, num_value_head_filters=32), 200, bf16=True,
                                                      note="BASELINE configs[4]'s network on Connect-Four boards")),
                 ("workers_128_5x128", lambda: steady_block(azhip, dev_index, "workers_128_5x128", azhip.GAME_CONNECT_FOUR, 128, 1, 600,
