@@ -17,6 +17,7 @@ template <class Gm, int F, bool PLANES_ONLY = false> static int set_kernel_attrs
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, false, 10, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F, 10, 9>::BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, true, 10, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F, 10, 9>::BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2m<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
   }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
@@ -325,12 +326,23 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
       // averages inside a two-round launch, where a CU that is done early simply takes the next workgroup; the 7-board launch 677 us):
       // 1.10 ms per wave instead of 0.80 (profiles/r6/README.md).  The 19-tile form stays (bit-exact like every form, tests/test_net.py
       // forces it with AZHIP_TOWER=19; 355 us per round of 7-board workgroups); AZHIP_TOWER_ROUNDS=1 switches the two-launch scheme on.
+      // (r6) ... and as ONE launch of both forms (k_tower16x2m, AZHIP_TOWER_MIXED=1): 1.09 ms per wave as well.  So it is not the lost
+      // balance between two launches: a workgroup's time hardly shrinks with its boards (399 us for 8, 355 for 7 when a whole launch is
+      // 7-board workgroups) because every workgroup streams the same 1.5 MB of weights through its CU's vector-memory path, and a second
+      // round of 252 seven-board workgroups beside a first round's stragglers is no cheaper than 221 eight-board ones.  Boards per
+      // workgroup want to go UP (k_tower16b's 22 tiles), which fp32 activations in 160 KB of LDS do not allow.  Both schemes stay off.
+      static const bool mixed_on = getenv("AZHIP_TOWER_MIXED") && atoi(getenv("AZHIP_TOWER_MIXED")) != 0;
       using T19 = T16P<Gm, 64, 10, 9>;
       static const bool rounds_on = getenv("AZHIP_TOWER_ROUNDS") && atoi(getenv("AZHIP_TOWER_ROUNDS")) != 0;
       const int cu = e->num_cu > 0 ? e->num_cu : 256, first = cu * TB21;
       const int seen = v.nleaf_host ? ((volatile int*)e->h_nleaf)[g] : -1;
       if (tw == 19) {
         LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2<Gm, F, false, 10, 9>), (N + T19::TB - 1) / T19::TB, (T19::THREADS), (T19::BYTES), e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g], 0);
+      } else if (mixed_on && !rounds_on && e->tower_pick == 0 && N > first && seen > first && seen + 16 <= first + cu * T19::TB) {
+        // the launch holds boards of both forms: price the executed fraction by their shares of the expected batch
+        e->next_exec = (first * tower_exec_frac<Gm, F>(e, 21) + (seen - first) * tower_exec_frac<Gm, F>(e, 19)) / (double)seen;
+        LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2m<Gm, F, false>), cu + (N - first + T19::TB - 1) / T19::TB, THR21, LDS21, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g], cu);
+        snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2m<%s,%d>", Gm::ID == 0 ? "ConnectFour" : Gm::ID == 1 ? "TicTacToe" : "Mancala", F);
       } else if (rounds_on && e->tower_pick == 0 && N > first && seen > first && seen + 16 <= first + cu * T19::TB) {
         LAUNCH_ON(e, sn, AZ_K_TOWER, first, (k_tower16x2<Gm, F, false>), cu, THR21, LDS21, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g], 0);
         e->next_exec = tower_exec_frac<Gm, F>(e, 19);

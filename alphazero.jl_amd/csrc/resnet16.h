@@ -702,25 +702,52 @@ k_tower16(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict
 }
 
 // The paired form (T16P): wavefronts 0..CT-1 run tiles 0..10, wavefronts CT..2CT-1 tiles 11..20 of ONE buffer.
-// base = index of the launch's first board (a batch served by two launches: the first 8 x num_cu boards by the 21-tile form, the rest by the 19-tile one)
-template <class Gm, int F, bool FROM_PLANES, int NT0 = 11, int NT1 = 10>
-__global__ void __launch_bounds__(2 * T16Threads<F>::V, 1)
-k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
-            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat, int base) {
-  using T = T16P<Gm, F, NT0, NT1>;
+// one workgroup of the paired form on the boards board0 .. board0 + T::TB - 1
+template <class T, bool FROM_PLANES>
+__device__ __forceinline__ void tower16x2_body(const Net16Dev& net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots, int n,
+                                               const float* __restrict__ X, float* __restrict__ hfeat, int board0, const uint16_t* __restrict__ geo) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* buf = lds;
   float* planes = lds + T::BUF;
   uint16_t* nbr = (uint16_t*)(planes + T::PLANES);
   uint16_t* pos = nbr + 9 * T::RPAD;
-  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
-  const int board0 = base + blockIdx.x * T::TB;
-  if (board0 >= n) return;
-  tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, net.geo[NT0 == 11 ? 2 : 4], leaf_env, eval_slots, X, n, board0, threadIdx.x);
+  tower16_fill<T, FROM_PLANES>(buf, planes, nbr, pos, geo, leaf_env, eval_slots, X, n, board0, threadIdx.x);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave < T::CT) tower16_wave<T, FROM_PLANES, T::NT0, 0>(net, buf, planes, nbr, pos, wave, lane, n, board0, hfeat);
   else tower16_wave<T, FROM_PLANES, T::NT1, T::NT0>(net, buf, planes, nbr, pos, wave - T::CT, lane, n, board0, hfeat);
+}
+// base = index of the launch's first board
+template <class Gm, int F, bool FROM_PLANES, int NT0 = 11, int NT1 = 10>
+__global__ void __launch_bounds__(2 * T16Threads<F>::V, 1)
+k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+            const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat, int base) {
+  using T = T16P<Gm, F, NT0, NT1>;
+  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
+  const int board0 = base + blockIdx.x * T::TB;
+  if (board0 >= n) return;
+  tower16x2_body<T, FROM_PLANES>(net, leaf_env, eval_slots, n, X, hfeat, board0, net.geo[NT0 == 11 ? 2 : 4]);
+}
+// (r6) Both paired forms in ONE launch: workgroups 0 .. first - 1 take 8 boards each (21 row tiles), the workgroups behind them 7 (19 tiles).
+// A batch between 15 and 16 boards per CU -- a free-running wave's 3700-3840 boards on 256 CUs -- is two rounds of workgroups either
+// way; with first = the number of CUs the second round is an eighth lighter, and because it is one launch a CU that is done early
+// simply takes the next workgroup (two separate launches each last as long as their slowest workgroup: resnet16.h T16P, profiles/r6).
+template <class Gm, int F, bool FROM_PLANES>
+__global__ void __launch_bounds__(2 * T16Threads<F>::V, 1)
+k_tower16x2m(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+             const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat, int first) {
+  using T8 = T16P<Gm, F, 11, 10>;
+  using T7 = T16P<Gm, F, 10, 9>;
+  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
+  if ((int)blockIdx.x < first) {
+    const int board0 = blockIdx.x * T8::TB;
+    if (board0 >= n) return;
+    tower16x2_body<T8, FROM_PLANES>(net, leaf_env, eval_slots, n, X, hfeat, board0, net.geo[2]);
+  } else {
+    const int board0 = first * T8::TB + ((int)blockIdx.x - first) * T7::TB;
+    if (board0 >= n) return;
+    tower16x2_body<T7, FROM_PLANES>(net, leaf_env, eval_slots, n, X, hfeat, board0, net.geo[4]);
+  }
 }
 
 // Split form for launches that leave most CUs idle (k_tower16s, 128 filters): TWO workgroups per board tile, each with

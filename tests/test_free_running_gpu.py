@@ -134,3 +134,31 @@ def test_retired_slots_get_their_replacement_in_a_free_running_phase():
     for gid, rec in got.items():
         if not gid & BIT:
             assert rec == want[gid], gid
+
+
+def test_the_mixed_8_and_7_board_tower_launch_changes_no_record(monkeypatch):
+    """4096 slots in ONE group: a free-running wave's batch (~3800 boards) CAN be served by k_tower16x2m -- 256 workgroups of 8 boards and up
+    to 256 of 7 in one launch (csrc/resnet16.h; measured slower than two rounds of 8-board workgroups and off by default: AZHIP_TOWER_MIXED=1).
+    Every fp32 tower form computes the same bits, so the phase's records must be those of the plain 8-board launches and of the lock-step
+    schedule; and the mixed launch must really have been in use."""
+    import azhip
+    from azhip.network import ResNetHP, random_params
+    hp = ResNetHP(**_resnet_kw(blocks=1))
+    blob = random_params(azhip.GAME_CONNECT_FOUR, hp, seed=3)
+    kw = dict(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, num_workers=4096, batch_size=4096, num_iters_per_turn=48, cpuct=2.0,
+              dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=SCHED, reset_every=1, seed=17, **_resnet_kw(blocks=1))
+    out = {}
+    for mode in ("mixed", "plain", "lock"):
+        monkeypatch.setenv("AZHIP_TOWER_MIXED", "0" if mode == "plain" else "1")
+        with azhip.Engine(lock_step=1 if mode == "lock" else 0, **kw) as e:
+            e.net_set_params(blob)
+            if mode == "mixed":
+                e.selfplay_begin(-1, 0)
+                e.selfplay_step(150)
+                seen = e.net_last_kernel()
+                e.selfplay_end()
+                assert seen.startswith("k_tower16x2m<"), seen
+            g, m, ng, nm, st = e.selfplay_run(6000)
+            assert ng == 6000 and st.aborted_games == 0
+            out[mode] = _by_id(g, m, ng)
+    assert out["mixed"] == out["plain"] == out["lock"]
