@@ -461,9 +461,6 @@ def cpu_baseline(blob, hp, nsims, seconds=8.0):
     return out
 
 
-TOWER_CODE = {"k_tower16x2": "21", "k_tower16<": "16", "k_tower<": "32"}
-
-
 def alone_and_tree(args, blob, hp, dev_index, kernel, waves=200):
     """Extra evidence, measured live after the timed region (not part of `value`), one slot group, every kernel class timed with HIP
     events.  (i) the shipped (free-running) schedule: the tower kernel alone -- with one group nothing runs beside a tower launch but
