@@ -155,14 +155,14 @@ schedule_points(s::PLSchedule) = (Int32.(s.xs), Float64.(s.ys))
 pad8(v, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), 8)
 
 "MctsParams + SimParams + ResNetHP -> az_engine_cfg (SURVEY.md §8b config mapping)"
-function make_cfg(gspec, mcts::MctsParams, sim::SimParams, hp; oracle=2, seed=1, device=0, arena=false, bf16=false)
+function make_cfg(gspec, mcts::MctsParams, sim::SimParams, hp; oracle=2, seed=1, device=0, arena=false, bf16=false, lock_step=false)
   xs, ys = schedule_points(mcts.temperature)
   EngineCfg(Int32(sizeof(EngineCfg)), device, game_id(gspec), oracle,
     mcts.gamma, mcts.cpuct, mcts.dirichlet_noise_ϵ, mcts.dirichlet_noise_α, mcts.prior_temperature,
     mcts.num_iters_per_turn, length(xs), pad8(xs, Int32), pad8(ys, Float64),
     sim.num_workers, sim.batch_size, isnothing(sim.reset_every) ? 0 : sim.reset_every, sim.fill_batches ? 1 : 0,
     sim.flip_probability, UInt64(seed), 0, 0,
-    hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters, bf16 ? 1 : 0, 0)
+    hp.num_blocks, hp.num_filters, hp.num_policy_head_filters, hp.num_value_head_filters, bf16 ? 1 : 0, lock_step ? 1 : 0)
 end
 
 # ---- seam 3: the network plugin -------------------------------------------------------------------------
