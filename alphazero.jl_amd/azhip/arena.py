@@ -29,6 +29,8 @@ class Evaluation:
     rewards: np.ndarray
     baseline_rewards: Optional[np.ndarray]
     time: float
+    workers: Optional[np.ndarray] = None      # not in the reference's report: the worker that played each game (az_game_rec.slot) -- with
+                                              # reset_every != 1 which games share a tree is an outcome of the id race (util.jl:181-188)
 
 
 def _engine(gspec, player, sim, device, seed, role):
@@ -81,6 +83,7 @@ def pit_players(gspec, players: TwoPlayers, sim, game_simulated=None, device=0, 
     ec, eb = _engine(gspec, players.white, sim, device, seed, "arena-white"), _engine(gspec, players.black, sim, device, seed, "arena-black")
     games, moves, ng, nm, rewards, red = ec.arena_run(eb, sim.num_games, first_game_id=first_game_id,
                                                       alternate_colors=sim.alternate_colors, progress=game_simulated)
+    pit_players.last_workers = np.array([games[i].slot for i in range(ng)], dtype=np.int32)   # by game id (az_arena_run sorts the records)
     return rewards, red, arena_traces(games, moves, ng, gspec.num_actions())
 
 
@@ -98,4 +101,4 @@ def compare_networks(gspec, contender, baseline, params: ArenaParams, handler=No
     t0 = time.perf_counter()
     rewards, red = pit_networks(gspec, contender, baseline, params, handler, device, seed)
     return Evaluation("Most recent NN versus best NN so far", float(np.mean(rewards)), red, rewards, None,
-                      time.perf_counter() - t0)
+                      time.perf_counter() - t0, getattr(pit_players, "last_workers", None))

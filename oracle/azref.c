@@ -1441,10 +1441,23 @@ static int cmp_key(const void* a, const void* b) { return memcmp(a, b, 16); }
  * network.  Writes traces (key = state BEFORE the turn's flip, N / action in the flipped frame,
  * N[AZR_AMAX] = 1 + symmetry index), rewards from the contender's side and the redundancy
  * (rewards_and_redundancy, simulations.jl:296-311).  Returns the number of move records. */
-int64_t azr_arena(const azr_sim_params* pc, const azr_sim_params* pb, int alternate_colors, double flip_probability,
-                  int first_game_id, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap, double* rewards,
-                  double* redundancy) {
+/* worker_of: NULL (ids in finishing order, ties by worker index), or the outcome of the reference's id race to replay -- worker_of[i] =
+ * worker of game first_game_id + i, as a free-running device arena reports it (azr_sim_set_assignment's rules; -1 if it breaks them) */
+int64_t azr_arena_assigned(const azr_sim_params* pc, const azr_sim_params* pb, int alternate_colors, double flip_probability,
+                           int first_game_id, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap, double* rewards,
+                           double* redundancy, const int32_t* worker_of) {
   int G = pc->num_workers < pc->num_games ? pc->num_workers : pc->num_games;
+  int32_t* next_of = 0;
+  if (worker_of) {
+    const int n = pc->num_games;
+    for (int i = 0; i < n; ++i) if (worker_of[i] < 0 || worker_of[i] >= G) return -1;
+    for (int s = 0; s < G; ++s) if (worker_of[s] != s) return -1;
+    next_of = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    int32_t* last = malloc(sizeof(int32_t) * (size_t)(G > 0 ? G : 1));
+    for (int s = 0; s < G; ++s) last[s] = -1;
+    for (int i = 0; i < n; ++i) { next_of[i] = -1; if (last[worker_of[i]] >= 0) next_of[last[worker_of[i]]] = i; last[worker_of[i]] = i; }
+    free(last);
+  }
   const azr_sim_params* pp[2] = {pc, pb};
   azr_slot* slots = calloc((size_t)G, sizeof(azr_slot));
   azr_mcts** trees[2];
@@ -1524,10 +1537,15 @@ int64_t azr_arena(const azr_sim_params* pc, const azr_sim_params* pb, int altern
       sl->worker_sim_id++;
       if (pc->reset_every > 0 && sl->worker_sim_id % pc->reset_every == 0) { azr_mcts_reset(trees[0][s]); azr_mcts_reset(trees[1][s]); }
       finished++;
-      if (next_game < pc->num_games) { sl->game_id = first_game_id + next_game++; sl->nmoves = 0; azr_init(&sl->game, pc->game); }
+      if (next_of) {
+        const int nx = next_of[gi];
+        if (nx >= 0) { sl->game_id = first_game_id + nx; sl->nmoves = 0; next_game++; azr_init(&sl->game, pc->game); }
+        else sl->active = 0;
+      } else if (next_game < pc->num_games) { sl->game_id = first_game_id + next_game++; sl->nmoves = 0; azr_init(&sl->game, pc->game); }
       else sl->active = 0;
     }
   }
+  free(next_of);
   if (redundancy) {                                                   /* compute_redundancy, simulations.jl:296-299 */
     int64_t ns = nm + pc->num_games, j = 0;
     uint64_t* keys = malloc((size_t)ns * 16);
@@ -1542,6 +1560,12 @@ int64_t azr_arena(const azr_sim_params* pc, const azr_sim_params* pb, int altern
   for (int k = 0; k < 2; ++k) { for (int s = 0; s < G; ++s) azr_mcts_free(trees[k][s]); free(trees[k]); }
   free(slots); free(stage);
   return nm;
+}
+
+int64_t azr_arena(const azr_sim_params* pc, const azr_sim_params* pb, int alternate_colors, double flip_probability,
+                  int first_game_id, azr_game_rec* games, azr_move_rec* moves, int64_t moves_cap, double* rewards,
+                  double* redundancy) {
+  return azr_arena_assigned(pc, pb, alternate_colors, flip_probability, first_game_id, games, moves, moves_cap, rewards, redundancy, 0);
 }
 
 /* push_trace! (src/memory.jl:74-87): discounted side-relative z and t for each position */

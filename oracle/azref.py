@@ -446,7 +446,7 @@ def net_evaluate_keys(game, hp, blob, keys):
 
 
 def arena(game, num_games, num_workers, contender, baseline, alternate_colors=False, flip_probability=0.0,
-          reset_every=1, seed=1, first_game_id=0):
+          reset_every=1, seed=1, first_game_id=0, assignment=None):
     """pit_networks (src/training.jl:130-144).  contender / baseline: dicts of _sim_params keywords
     (oracle, nsims, cpuct, noise_eps, ..., temp_xs, temp_ys, net, seed).
     Returns (games, moves, num_moves, rewards, redundancy)."""
@@ -463,11 +463,14 @@ def arena(game, num_games, num_workers, contender, baseline, alternate_colors=Fa
     moves = (MoveRec * cap)()
     rewards = np.zeros(num_games, dtype=np.float64)
     red = C.c_double()
-    lib().azr_arena.restype = C.c_int64
-    lib().azr_arena.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
-                                C.c_void_p, C.c_void_p]
-    nm = lib().azr_arena(C.byref(ps[0]), C.byref(ps[1]), int(alternate_colors), float(flip_probability), first_game_id,
-                         games, moves, cap, rewards.ctypes.data_as(C.c_void_p), C.byref(red))
+    w, wp = _worker_of(assignment, num_games)       # the outcome of the id race to replay (assignment_of), or None
+    lib().azr_arena_assigned.restype = C.c_int64
+    lib().azr_arena_assigned.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    nm = lib().azr_arena_assigned(C.byref(ps[0]), C.byref(ps[1]), int(alternate_colors), float(flip_probability), first_game_id,
+                                  games, moves, cap, rewards.ctypes.data_as(C.c_void_p), C.byref(red), wp)
+    if nm < 0:
+        raise ValueError("arena: not an assignment the reference's worker pool could produce")
     return games, moves, nm, rewards, red.value
 
 

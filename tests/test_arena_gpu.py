@@ -37,20 +37,23 @@ def test_arena_matches_oracle_hash_players(game, ngames, workers, batch, flip, a
     import azhip
     c = dict(oracle=R.ORACLE_HASH, nsims=30, cpuct=2.0, noise_eps=0.05, noise_alpha=1.0, temp_xs=(0,), temp_ys=(0.2,))
     b = dict(oracle=R.ORACLE_HASH, nsims=12, cpuct=1.0, noise_eps=0.25, noise_alpha=0.7, temp_xs=(0, 4), temp_ys=(1.0, 0.5))
-    g_ref, m_ref, nm_ref, rew_ref, red_ref = R.arena(game, ngames, workers, c, b, alternate_colors=alt, flip_probability=flip,
-                                                     reset_every=2, seed=21)
     count = [0]
     with azhip.Engine(**_engine_kw(c, game, workers, batch, 2, flip, 21)) as ec, \
             azhip.Engine(**_engine_kw(b, game, workers, batch, 2, flip, 21)) as eb:
         games, moves, ng, nm, rew, red = ec.arena_run(eb, ngames, alternate_colors=alt,
                                                      progress=lambda: count.__setitem__(0, count[0] + 1))
+        # (r6) one slot group per engine: the free-running arena -- which worker plays which game is an outcome of the reference's id
+        # race (util.jl:181-188), reported per game; the oracle replays it.  batch < workers: the lock-step arena (the same call with
+        # the default assignment)
+        g_ref, m_ref, nm_ref, rew_ref, red_ref = R.arena(game, ngames, workers, c, b, alternate_colors=alt, flip_probability=flip,
+                                                         reset_every=2, seed=21, assignment=R.assignment_of(games, ngames))
         assert count[0] == ngames and nm == nm_ref
         _same_records(games, moves, ng, g_ref, m_ref, nm_ref, R.NUM_ACTIONS[game])
         assert np.array_equal(rew, rew_ref) and red == red_ref
         # the engines stay usable: a second run from a different id range is independent of the first
         games2, moves2, ng2, nm2, rew2, _ = ec.arena_run(eb, 4, first_game_id=100, alternate_colors=alt)
         g2, m2, nm2_ref, rew2_ref, _ = R.arena(game, 4, workers, c, b, alternate_colors=alt, flip_probability=flip,
-                                               reset_every=2, seed=21, first_game_id=100)
+                                               reset_every=2, seed=21, first_game_id=100, assignment=R.assignment_of(games2, 4, 100))
         _same_records(games2, moves2, ng2, g2, m2, nm2_ref, R.NUM_ACTIONS[game])
         assert np.array_equal(rew2, rew2_ref)
 
@@ -76,13 +79,16 @@ def test_pit_networks_two_resnets_matches_oracle():
     pl = dict(oracle=R.ORACLE_NET, nsims=24, cpuct=2.0, noise_eps=0.05, noise_alpha=1.0, temp_xs=(0,), temp_ys=(0.2,))
     _, _, _, rew_ref, red_ref = R.arena(R.C4, 8, 4, dict(pl, net=(2, 64, 32, 32, contender.params())),
                                         dict(pl, net=(2, 64, 32, 32, baseline.params())), alternate_colors=True,
-                                        flip_probability=0.5, reset_every=2, seed=13)
+                                        flip_probability=0.5, reset_every=2, seed=13, assignment=ev.workers)
     assert H.n == 8 and np.array_equal(ev.rewards, rew_ref) and ev.redundancy == red_ref
     assert ev.avgr == float(np.mean(rew_ref)) and ev.baseline_rewards is None and ev.time > 0
     # a network against itself, colours alternating: same trees on both sides is NOT the same as self-play, but
     # the result must be deterministic
-    ev2 = azhip.compare_networks(gspec, contender, contender, ap, None, seed=13)
-    ev3 = azhip.compare_networks(gspec, contender, contender, ap, None, seed=13)
+    # (with trees kept over two games that needs the fixed assignment of the lock-step schedule: SimParams.lock_step)
+    import dataclasses
+    ap_ls = dataclasses.replace(ap, sim=dataclasses.replace(ap.sim, lock_step=True))
+    ev2 = azhip.compare_networks(gspec, contender, contender, ap_ls, None, seed=13)
+    ev3 = azhip.compare_networks(gspec, contender, contender, ap_ls, None, seed=13)
     assert np.array_equal(ev2.rewards, ev3.rewards)
 
 
