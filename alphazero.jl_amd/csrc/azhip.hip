@@ -255,7 +255,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   e->h_env = nullptr; e->h_n = nullptr; e->h_pv = nullptr; e->h_nleaf = nullptr; e->d_nleaf = nullptr;
   e->d_ec = nullptr; e->ec_mask = 0; e->ec_seq = 0; e->d_ec_claim = nullptr; e->d_Phit = nullptr; e->d_Vhit = nullptr;
   e->fr_on = false; e->fr_k = 0; e->fr_kbg = 0; e->fr_round_waves = 0; for (int i = 0; i < 4; ++i) { e->fr_s[i] = nullptr; e->fr_ev[i] = nullptr; } e->d_fr = nullptr; e->d_done = nullptr; e->d_done_off = nullptr; e->done_cap = 0;
-  e->arena_args = nullptr; e->arena_me = 0;
+  e->arena_args = nullptr; e->arena_eng = nullptr; e->arena_me = 0; e->arena_side = nullptr;
   e->h_fr_words = nullptr; e->d_fr_words = nullptr; e->h_busy = nullptr; e->d_busy = nullptr; e->explore_k = 0; e->fr_prev_done = 0; e->fr_since_round = 0; e->fr_given_up = 0; e->fr_prev_recs = 0;
   e->h_xflag = nullptr; e->d_xflag = nullptr; e->split_off = false; e->split_registered = 0; e->xch_launches = 0;
   { const char* fa = getenv("AZHIP_XCH_FAIL_AT"); e->xch_fail_at = fa ? atoll(fa) : 0; }
@@ -994,6 +994,7 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
   const int gb = (G * L + 255) / 256;
   const int par = (e->wave_par[g] ^= 1);
   e->stats.slot_launches += e->group_active[g];                     // (the host's count: as of its last look in a free-running phase)
+  if (e->arena_args) LAUNCH_ON(e, st, AZ_K_START, G, (k_arena_take<Gm>), (e->arena_args->G + 255) / 256, 256, 0, v, *e->arena_args, e->arena_me);   // a free-running arena: the turns handed to this player
   LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_tree<Gm>), gb, 256, 0, v, e->p, (e->pending[g] || e->fr_on) ? 1 : 0, 1, par);
   e->pending[g] = true;
   // One slot group, free-running: the wave's launch, the tower and the heads follow each other on ONE stream (no event between them: a
@@ -1005,7 +1006,9 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
   // (the stop word of the background search: without it a background launch of fr_kbg simulations outlasts a SHORT tower and the next wave
   // waits for it -- Mancala, 8192 slots: 19.8 instead of 39.7 M sims/s; AZHIP_BG_STOP=0 switches it off)
   static const bool bg_stop_on = !(getenv("AZHIP_BG_STOP") && atoi(getenv("AZHIP_BG_STOP")) == 0);
-  if (side) { s2 = e->fr_s[1]; HIPCHK(hipEventRecord(e->fr_ev[0], st)); ++e->bg_seq; e->bg_signal = bg_stop_on && e->fr_kbg > 0; }
+  // (a free-running arena drives two engines at once and the runtime has four hardware queues for its streams: the two players' wave
+  // streams and the contender's two side streams: one for both players' background searches, one for both players' move steps)
+  if (side) { s2 = e->arena_side ? e->arena_side : e->fr_s[1]; HIPCHK(hipEventRecord(e->fr_ev[0], st)); ++e->bg_seq; e->bg_signal = bg_stop_on && e->fr_kbg > 0; }
   if (e->cfg.oracle == AZ_ORACLE_RESNET) {
     AZCHK(net_wave(e, g, split, e->group_active[g]));
   } else {
@@ -1022,9 +1025,9 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
     static const int bg_prio = getenv("AZHIP_BG_PRIO") ? atoi(getenv("AZHIP_BG_PRIO")) : 0;   // A/B aid: 3 = the background launches keep the wave launches' priority
     // (side streams: the move step and the background search touch different slots -- explore! complete / still searching -- and run
     // side by side: one serial move under a busy tower takes 0.4 ms, which the background search would otherwise wait out)
-    hipStream_t s3 = side ? e->fr_s[2] : s2;
-    if (side) { HIPCHK(hipStreamWaitEvent(s2, e->fr_ev[0], 0)); HIPCHK(hipStreamWaitEvent(s3, e->fr_ev[0], 0)); }
-    if (e->arena_args) LAUNCH_ON(e, s3, AZ_K_MOVE, G, (k_move_arena<Gm>), (e->arena_args->G + 255) / 256, 256, 0, v, e->p, *e->arena_args, e->arena_me);   // a free-running arena: the turn may go to the other player's engine
+    hipStream_t s3 = side ? (e->arena_side ? e->arena_eng_move : e->fr_s[2]) : s2;
+    if (side) { HIPCHK(hipStreamWaitEvent(s2, e->fr_ev[0], 0)); if (s3 != s2) HIPCHK(hipStreamWaitEvent(s3, e->fr_ev[0], 0)); }
+    if (e->arena_args) LAUNCH_ON(e, s3, AZ_K_MOVE, G, (k_move_arena<Gm>), (e->arena_args->G + 255) / 256, 256, 0, *e->arena_eng, *e->arena_args, e->arena_me);   // a free-running arena: the turn may go to the other player's engine
     else { DView mv = v; mv.low_prio = bg_prio ? 0 : 1; LAUNCH_ON(e, s3, AZ_K_MOVE, G, (k_move_fr<Gm>), (G + 255) / 256, 256, 0, mv, e->p, fa); }
     if (e->fr_kbg > 0) {
       AZCHK(ec_next_launch(e, &e->gv[g]));
@@ -1035,7 +1038,7 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
     }
     if (side) {
       HIPCHK(hipEventRecord(e->fr_ev[1], s2)); HIPCHK(hipStreamWaitEvent(st, e->fr_ev[1], 0));
-      HIPCHK(hipEventRecord(e->fr_ev[2], s3)); HIPCHK(hipStreamWaitEvent(st, e->fr_ev[2], 0));
+      if (!e->arena_args) { HIPCHK(hipEventRecord(e->fr_ev[2], s3)); HIPCHK(hipStreamWaitEvent(st, e->fr_ev[2], 0)); }   // (an arena's move step is waited for by nobody: tree.h k_move_arena)
     }   // the next wave's launch finds the slots' state settled
     else if (split && e->cfg.oracle == AZ_ORACLE_RESNET) HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0));   // the next wave's launch needs this wave's answers
   }
@@ -1855,6 +1858,8 @@ static int arena_run_fr(az_engine* ec, az_engine* eb, int num_games, int first_g
     HIPCHK(hipMemcpy(ec->d_fr, &fs, sizeof fs, hipMemcpyHostToDevice));
     ec->h_fr_words[0] = 0; ec->h_fr_words[1] = G;
   }
+  ArenaEngines E;                                                  // the two players' (whole-engine = their one group's) views and parameters
+  for (int k = 0; k < 2; ++k) { E.v[k] = eng[k]->gv[0]; E.p[k] = eng[k]->p; }
   // both engines in free-running mode (az_selfplay_begin's switches, without its game bookkeeping); undone on every way out
   struct Mode {
     az_engine* e[2];
@@ -1862,7 +1867,7 @@ static int arena_run_fr(az_engine* ec, az_engine* eb, int num_games, int first_g
       for (az_engine* x : e) {
         (void)hipSetDevice(x->device);
         (void)sync_all(x);
-        x->fr_on = false; x->arena_args = nullptr;
+        x->fr_on = false; x->arena_args = nullptr; x->arena_eng = nullptr; x->arena_side = nullptr;
         x->gv[0].run_k = 0; x->gv[0].fr = 0; x->gv[0].fr_active = nullptr;
         if (x->gs[0] != x->stream) { x->gs[0] = x->gt[0] = x->stream; }
         hipLaunchKernelGGL(k_slot_records, dim3((x->v.G + 255) / 256), dim3(256), 0, x->stream, x->v, (int)(SR_CLEAR_ACTIVE | SR_CLEAR_LEAF));
@@ -1882,16 +1887,18 @@ static int arena_run_fr(az_engine* ec, az_engine* eb, int num_games, int first_g
     HIPCHK(hipStreamSynchronize(e->stream));
     e->gv[0].run_k = e->fr_k; e->gv[0].fr = 1; e->gv[0].fr_active = nullptr; e->gv[0].busy_host = nullptr;
     if (e->cfg.oracle == AZ_ORACLE_RESNET && e->fr_s[0]) e->gs[0] = e->gt[0] = e->fr_s[0];
-    e->fr_on = true; e->arena_args = &a; e->arena_me = k;
+    e->fr_on = true; e->arena_args = &a; e->arena_eng = &E; e->arena_me = k; e->arena_side = ec->fr_s[1]; e->arena_eng_move = ec->fr_s[2];
     for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->group_active[g] = 0;
     e->group_active[0] = G;
     split_register(e, 1);
   }
-  hipLaunchKernelGGL((k_arena_start<Gm>), dim3((G + 255) / 256), dim3(256), 0, ec->stream, a, G);
+  hipLaunchKernelGGL((k_arena_start<Gm>), dim3((G + 255) / 256), dim3(256), 0, ec->stream, a, E, G);
   HIPCHK(hipStreamSynchronize(ec->stream));
   // waves of the two engines, alternately enqueued; the host looks every 32 waves
   int reported = 0, done = 0, idle_looks = 0;
+  long looks = 0; const auto t0 = std::chrono::steady_clock::now();
   while (done < num_games) {
+    ++looks;
     for (int i = 0; i < 32; ++i)
       for (int k = 0; k < 2; ++k) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(wave<Gm>(eng[k], 1, 0)); }
     for (int k = 0; k < 2; ++k) AZCHK(check_device_error(eng[k]));   // synchronises
@@ -1903,6 +1910,7 @@ static int arena_run_fr(az_engine* ec, az_engine* eb, int num_games, int first_g
     if (cb) for (; reported < done; ++reported) cb(user);
     if (idle_looks > 4 * (ec->p.nsims + eb->p.nsims) / 32 + 64) return fail(AZ_ERR_STATE, "free-running arena: no game finished in %d looks", idle_looks);
   }
+  if (getenv("AZHIP_ARENA_TRACE")) fprintf(stderr, "free-running arena: %ld waves per engine, %.3f s\n", looks * 32, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   // the records: finished games in finishing order, their move records packed
   std::vector<az_game_rec> hg(num_games);
   std::vector<long long> ho(num_games);

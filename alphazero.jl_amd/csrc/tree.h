@@ -1086,8 +1086,10 @@ __global__ void __launch_bounds__(256) k_move_fr(DView v, DParams p, FRArgs fa) 
 // The engine whose turn it is searches slot w like a free-running self-play slot; when its explore! is complete, its k_move_arena
 // plays the move, sets up the next turn (trace.states[i], the random symmetry of play.jl:305-307, who is to think) and HANDS THE TURN
 // OVER through a mailbox: it never writes the other engine's slot records (that engine's tree kernel may be reading them), it writes
-// a message and raises its flag (release); the addressee's own k_move_arena -- ordered before its next wave's launch like k_move_fr --
-// takes the message (acquire) and activates its slot.  Game ends, game ids and trace write-out as in k_move_fr.
+// a message and raises its flag (release); the addressee's k_arena_take -- in the addressee's own stream order, right before its wave's
+// tree launch -- takes the message (acquire) and activates its slot.  The move step runs on a side stream and NOBODY waits for it (a
+// serial Dirichlet draw takes 0.3 ms under a busy tower, longer than the 64-board tower of an arena wave): a slot whose explore! is
+// complete is left alone by the tree launches until the move step has got to it.  Game ends, game ids and trace write-out as in k_move_fr.
 // =========================================================================================
 struct ArenaMsg { unsigned long long a, b; uint32_t fin, gid, mv, flag; };     // the turn handed to a player: state to think about, game, move index
 static_assert(sizeof(ArenaMsg) == 32, "arena message");
@@ -1107,9 +1109,14 @@ struct ArenaArgs {
   int reset_every; double flip_p; uint64_t flip_seed;
   int G;
 };
-// trace.states[i] for the turn that starts from `env` (before the flip), the turn's random symmetry, who thinks; the message goes out last
+// the two players' engines as a move step sees them: it writes the trace, the mailboxes and -- for the slot it hands a turn to, which
+// is inactive in the addressee's engine and therefore read by nobody there -- the addressee's game id / move index / Dirichlet noise
+struct ArenaEngines { DView v[2]; DParams p[2]; };
+// trace.states[i] for the turn that starts from `env` (before the flip), the turn's random symmetry, who thinks, that player's noise
+// for the explore! to come (the expensive part: the addressee's k_arena_take is on its wave's critical path and only copies); the
+// message goes out last
 template <class Gm>
-__device__ inline void arena_setup_turn(const ArenaArgs& a, int w, GEnv env, uint32_t gid, uint32_t mv) {
+__device__ inline void arena_setup_turn(const ArenaArgs& a, const ArenaEngines& E, int w, GEnv env, uint32_t gid, uint32_t mv) {
   int k1 = 0;
   GEnv seen = env;
   if (Gm::NSYM > 0 && a.flip_p != 0.0) {
@@ -1129,17 +1136,49 @@ __device__ inline void arena_setup_turn(const ArenaArgs& a, int w, GEnv env, uin
   }
   const bool colors_flipped = a.alternate && (((int)gid - (int)a.first_game_id + 1) % 2 == 1);
   const int who = (Gm::white_playing(seen) != colors_flipped) ? 0 : 1;           // 0 contender, 1 baseline
+  E.v[who].game_id[w] = gid;
+  E.v[who].move_idx[w] = mv;
+  arm_noise<Gm>(E.v[who], E.p[who], w, seen);                                    // dirichlet_noise (mcts.jl:228-232), keyed by (game, move)
   ArenaMsg* m = a.mail + (size_t)who * a.G + w;
   m->a = seen.a; m->b = seen.b; m->fin = seen.fin; m->gid = gid; m->mv = mv;
   __hip_atomic_store(&m->flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <class Gm>
-__global__ void __launch_bounds__(256) k_arena_start(ArenaArgs a, int n) {
+__global__ void __launch_bounds__(256) k_arena_start(ArenaArgs a, ArenaEngines E, int n) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < n) arena_setup_turn<Gm>(a, w, Gm::init(), a.first_game_id + (uint32_t)w, 0);
+  if (w < n) arena_setup_turn<Gm>(a, E, w, Gm::init(), a.first_game_id + (uint32_t)w, 0);
+}
+// the turns handed to engine `me`: its slots are activated here, in its own stream order right before its wave's tree launch (a handful
+// of instructions per worker; everything expensive was done by the sender)
+template <class Gm>
+__global__ void __launch_bounds__(256) k_arena_take(DView v, ArenaArgs a, int me) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= a.G) return;
+  ArenaMsg* const mm = a.mail + (size_t)me * a.G + w;
+  if (__hip_atomic_load(&mm->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) return;
+  SlotRec* const sr = v.sr + w;
+  GEnv env; env.a = mm->a; env.b = mm->b; env.fin = mm->fin;
+  int* const mine = a.my_gen + (size_t)me * a.G + w;
+  if (*mine != a.tree_gen[w]) {                                   // MCTS.reset!: a new epoch empties the table in O(1)
+    uint32_t ep = sr->epoch + 1;
+    if (ep >= 0xffff) {
+      unsigned long long* tab = v.ht + (size_t)w * v.ht_size;
+      for (int k = 0; k < v.ht_size; ++k) tab[k] = 0;
+      ep = 1;
+    }
+    sr->epoch = ep; sr->node_count = 0;
+    *mine = a.tree_gen[w];
+  }
+  sr->set_root(env);
+  sr->root_idx = -1;
+  sr->leaf_kd = LEAF_NONE;
+  sr->active = SR_ACTIVE;
+  __hip_atomic_store(&mm->flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <class Gm>
-__global__ void __launch_bounds__(256) k_move_arena(DView v, DParams p, ArenaArgs a, int me) {
+__global__ void __launch_bounds__(256) k_move_arena(ArenaEngines E, ArenaArgs a, int me) {
+  const DView& v = E.v[me];
+  const DParams& p = E.p[me];
   using NL = NodeL<Gm>;
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w == 0 && me == 0 && a.host_words) {
@@ -1200,31 +1239,7 @@ __global__ void __launch_bounds__(256) k_move_arena(DView v, DParams p, ArenaArg
       if (k < a.total_games) { ngid = a.first_game_id + (uint32_t)k; nmv = 0; e2 = Gm::init(); }
       else { more = false; atomicSub(&a.st->active[0], 1); }
     }
-    if (more) arena_setup_turn<Gm>(a, w, e2, ngid, nmv);
-  }
-  // ---- a turn handed to me
-  ArenaMsg* const mm = a.mail + (size_t)me * a.G + w;
-  if (__hip_atomic_load(&mm->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1u) {
-    GEnv env; env.a = mm->a; env.b = mm->b; env.fin = mm->fin;
-    int* const mine = a.my_gen + (size_t)me * a.G + w;
-    if (*mine != a.tree_gen[w]) {                                 // MCTS.reset!: a new epoch empties the table in O(1)
-      uint32_t ep = sr->epoch + 1;
-      if (ep >= 0xffff) {
-        unsigned long long* tab = v.ht + (size_t)w * v.ht_size;
-        for (int k = 0; k < v.ht_size; ++k) tab[k] = 0;
-        ep = 1;
-      }
-      sr->epoch = ep; sr->node_count = 0;
-      *mine = a.tree_gen[w];
-    }
-    sr->set_root(env);
-    sr->root_idx = -1;
-    sr->leaf_kd = LEAF_NONE;
-    v.game_id[w] = mm->gid;
-    v.move_idx[w] = mm->mv;
-    arm_noise<Gm>(v, p, w, env);
-    sr->active = SR_ACTIVE;
-    __hip_atomic_store(&mm->flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (more) arena_setup_turn<Gm>(a, E, w, e2, ngid, nmv);
   }
 }
 
