@@ -255,7 +255,6 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   e->h_env = nullptr; e->h_n = nullptr; e->h_pv = nullptr; e->h_nleaf = nullptr; e->d_nleaf = nullptr;
   e->d_ec = nullptr; e->ec_mask = 0; e->ec_seq = 0; e->d_ec_claim = nullptr; e->d_Phit = nullptr; e->d_Vhit = nullptr;
   e->fr_on = false; e->fr_k = 0; e->fr_kbg = 0; e->fr_round_waves = 0; for (int i = 0; i < 4; ++i) { e->fr_s[i] = nullptr; e->fr_ev[i] = nullptr; } e->d_fr = nullptr; e->d_done = nullptr; e->d_done_off = nullptr; e->done_cap = 0;
-  e->arena_args = nullptr; e->arena_eng = nullptr; e->arena_me = 0; e->arena_side = nullptr;
   e->h_fr_words = nullptr; e->d_fr_words = nullptr; e->h_busy = nullptr; e->d_busy = nullptr; e->explore_k = 0; e->fr_prev_done = 0; e->fr_since_round = 0; e->fr_given_up = 0; e->fr_prev_recs = 0;
   e->h_xflag = nullptr; e->d_xflag = nullptr; e->split_off = false; e->split_registered = 0; e->xch_launches = 0;
   { const char* fa = getenv("AZHIP_XCH_FAIL_AT"); e->xch_fail_at = fa ? atoll(fa) : 0; }
@@ -994,7 +993,6 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
   const int gb = (G * L + 255) / 256;
   const int par = (e->wave_par[g] ^= 1);
   e->stats.slot_launches += e->group_active[g];                     // (the host's count: as of its last look in a free-running phase)
-  if (e->arena_args) LAUNCH_ON(e, st, AZ_K_START, G, (k_arena_take<Gm>), (e->arena_args->G + 255) / 256, 256, 0, v, *e->arena_args, e->arena_me);   // a free-running arena: the turns handed to this player
   LAUNCH_ON(e, st, AZ_K_SELECT, G, (k_tree<Gm>), gb, 256, 0, v, e->p, (e->pending[g] || e->fr_on) ? 1 : 0, 1, par);
   e->pending[g] = true;
   // One slot group, free-running: the wave's launch, the tower and the heads follow each other on ONE stream (no event between them: a
@@ -1006,9 +1004,7 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
   // (the stop word of the background search: without it a background launch of fr_kbg simulations outlasts a SHORT tower and the next wave
   // waits for it -- Mancala, 8192 slots: 19.8 instead of 39.7 M sims/s; AZHIP_BG_STOP=0 switches it off)
   static const bool bg_stop_on = !(getenv("AZHIP_BG_STOP") && atoi(getenv("AZHIP_BG_STOP")) == 0);
-  // (a free-running arena drives two engines at once and the runtime has four hardware queues for its streams: the two players' wave
-  // streams and the contender's two side streams: one for both players' background searches, one for both players' move steps)
-  if (side) { s2 = e->arena_side ? e->arena_side : e->fr_s[1]; HIPCHK(hipEventRecord(e->fr_ev[0], st)); ++e->bg_seq; e->bg_signal = bg_stop_on && e->fr_kbg > 0; }
+  if (side) { s2 = e->fr_s[1]; HIPCHK(hipEventRecord(e->fr_ev[0], st)); ++e->bg_seq; e->bg_signal = bg_stop_on && e->fr_kbg > 0; }
   if (e->cfg.oracle == AZ_ORACLE_RESNET) {
     AZCHK(net_wave(e, g, split, e->group_active[g]));
   } else {
@@ -1025,10 +1021,9 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
     static const int bg_prio = getenv("AZHIP_BG_PRIO") ? atoi(getenv("AZHIP_BG_PRIO")) : 0;   // A/B aid: 3 = the background launches keep the wave launches' priority
     // (side streams: the move step and the background search touch different slots -- explore! complete / still searching -- and run
     // side by side: one serial move under a busy tower takes 0.4 ms, which the background search would otherwise wait out)
-    hipStream_t s3 = side ? (e->arena_side ? e->arena_eng_move : e->fr_s[2]) : s2;
-    if (side) { HIPCHK(hipStreamWaitEvent(s2, e->fr_ev[0], 0)); if (s3 != s2) HIPCHK(hipStreamWaitEvent(s3, e->fr_ev[0], 0)); }
-    if (e->arena_args) LAUNCH_ON(e, s3, AZ_K_MOVE, G, (k_move_arena<Gm>), (e->arena_args->G + 255) / 256, 256, 0, *e->arena_eng, *e->arena_args, e->arena_me);   // a free-running arena: the turn may go to the other player's engine
-    else { DView mv = v; mv.low_prio = bg_prio ? 0 : 1; LAUNCH_ON(e, s3, AZ_K_MOVE, G, (k_move_fr<Gm>), (G + 255) / 256, 256, 0, mv, e->p, fa); }
+    hipStream_t s3 = side ? e->fr_s[2] : s2;
+    if (side) { HIPCHK(hipStreamWaitEvent(s2, e->fr_ev[0], 0)); HIPCHK(hipStreamWaitEvent(s3, e->fr_ev[0], 0)); }
+    { DView mv = v; mv.low_prio = bg_prio ? 0 : 1; LAUNCH_ON(e, s3, AZ_K_MOVE, G, (k_move_fr<Gm>), (G + 255) / 256, 256, 0, mv, e->p, fa); }
     if (e->fr_kbg > 0) {
       AZCHK(ec_next_launch(e, &e->gv[g]));
       DView bv = e->gv[g];
@@ -1038,7 +1033,7 @@ template <class Gm> static int wave_group(az_engine* e, int g, uint32_t sim_idx)
     }
     if (side) {
       HIPCHK(hipEventRecord(e->fr_ev[1], s2)); HIPCHK(hipStreamWaitEvent(st, e->fr_ev[1], 0));
-      if (!e->arena_args) { HIPCHK(hipEventRecord(e->fr_ev[2], s3)); HIPCHK(hipStreamWaitEvent(st, e->fr_ev[2], 0)); }   // (an arena's move step is waited for by nobody: tree.h k_move_arena)
+      HIPCHK(hipEventRecord(e->fr_ev[2], s3)); HIPCHK(hipStreamWaitEvent(st, e->fr_ev[2], 0));
     }   // the next wave's launch finds the slots' state settled
     else if (split && e->cfg.oracle == AZ_ORACLE_RESNET) HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0));   // the next wave's launch needs this wave's answers
   }
@@ -1800,157 +1795,6 @@ static int reset_slots(az_engine* e, const std::vector<int>& slots) {
   return AZ_OK;
 }
 
-static void fr_knobs(az_engine* e) {
-  const char* rk = getenv("AZHIP_RUN_K"); const char* rw = getenv("AZHIP_FR_ROUND"); const char* rb = getenv("AZHIP_RUN_KBG");
-  e->fr_k = std::max(1, rk ? atoi(rk) : 3);
-  e->fr_kbg = std::max(0, rb ? atoi(rb) : (e->ngroups == 1 ? 32 : 8));
-  e->fr_round_waves = std::max(1, rw ? atoi(rw) : 128);
-}
-// Free-running arena (tree.h k_move_arena): every worker plays its game at its own pace, the two players' engines search the slots whose
-// turn is theirs and hand turns over through mailboxes.  A ply of the lock-step arena below lasts as long as its SLOWEST worker's explore!
-// (~0.8 x num_iters_per_turn network evaluations of ~0.22 ms each, all workers waiting); here a worker's game costs its OWN evaluations.
-// Used when both players search with a ResNet / exact synthetic oracle in one slot group each; everything else (NetworkPlayer, rollout
-// oracle, slot groups, mapped pools, AZHIP_ARENA_FR=0) takes the lock-step loop.  Which worker plays which game is an outcome of the
-// reference's id race (util.jl:181-188), reported in az_game_rec.slot; the oracle replays it (azr_arena_assigned).
-static bool arena_fr_ok(const az_engine* ec, const az_engine* eb, int num_games) {
-  const char* sw = getenv("AZHIP_ARENA_FR");
-  if (sw ? atoi(sw) == 0 : ec->cfg.lock_step != 0) return false;     // az_engine_cfg.lock_step of the contender: the fixed assignment
-  for (const az_engine* e : {ec, eb})
-    if (e->ngroups != 1 || e->p.nsims < 2 || e->cfg.oracle == AZ_ORACLE_ROLLOUT || e->use_graphs || e->tree_sort || e->vm_rows || e->device != ec->device) return false;
-  return std::min(ec->v.G, num_games) <= eb->v.G;
-}
-template <class Gm>
-static int arena_run_fr(az_engine* ec, az_engine* eb, int num_games, int first_game_id, bool alternate, az_trace_buf* out,
-                        double* rewards, double* redundancy, az_progress_cb cb, void* user) {
-  const int G = std::min(ec->v.G, num_games);
-  const double flip_p = ec->cfg.flip_probability;
-  if (flip_p != 0.0 && Gm::NSYM == 0) return fail(AZ_ERR_BAD_ARG, "flip_probability != 0 but no symmetries were declared for this game (game.jl:332)");
-  az_engine* eng[2] = {ec, eb};
-  AZCHK(az_mcts_reset(ec));                                        // a fresh player per worker (simulations.jl:217-218)
-  AZCHK(az_mcts_reset(eb));
-  HIPCHK(hipSetDevice(ec->device));
-  if (out) { out->num_games = 0; out->num_moves = 0; }
-  const int max_moves = ec->v.max_moves;
-  struct Bufs {                                                    // device scratch of this call
-    std::vector<void*> p;
-    ~Bufs() { for (void* q : p) (void)hipFree(q); }
-    int get(void** out, size_t bytes) { hipError_t r = hipMalloc(out, std::max<size_t>(bytes, 16)); if (r != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r)); p.push_back(*out); return hipMemset(*out, 0, std::max<size_t>(bytes, 16)) == hipSuccess ? AZ_OK : fail(AZ_ERR_HIP, "hipMemset failed"); }
-  } bufs;
-  ArenaArgs a;
-  memset(&a, 0, sizeof a);
-  AZCHK(bufs.get((void**)&a.mail, sizeof(ArenaMsg) * 2 * (size_t)G));
-  AZCHK(bufs.get((void**)&a.tree_gen, sizeof(int) * (size_t)G));
-  AZCHK(bufs.get((void**)&a.my_gen, sizeof(int) * 2 * (size_t)G));
-  AZCHK(bufs.get((void**)&a.worker_sim_id, sizeof(int) * (size_t)G));
-  AZCHK(bufs.get((void**)&a.done, sizeof(az_game_rec) * (size_t)num_games));
-  AZCHK(bufs.get((void**)&a.done_off, sizeof(long long) * (size_t)num_games));
-  AZCHK(bufs.get((void**)&a.recs, sizeof(az_move_rec) * (size_t)num_games * max_moves));
-  a.recs_cap = (long long)num_games * max_moves; a.done_cap = num_games; a.total_games = num_games;
-  a.first_game_id = (uint32_t)first_game_id; a.alternate = alternate ? 1 : 0;
-  a.trace = ec->v.trace; a.max_moves = max_moves;
-  a.host_words = ec->d_fr_words;
-  a.reset_every = ec->p.reset_every; a.flip_p = flip_p; a.flip_seed = ec->p.seed; a.G = G;
-  a.st = ec->d_fr;
-  {
-    FRState fs;
-    memset(&fs, 0, sizeof fs);
-    fs.next_game = G; fs.active[0] = G;
-    HIPCHK(hipMemcpy(ec->d_fr, &fs, sizeof fs, hipMemcpyHostToDevice));
-    ec->h_fr_words[0] = 0; ec->h_fr_words[1] = G;
-  }
-  ArenaEngines E;                                                  // the two players' (whole-engine = their one group's) views and parameters
-  for (int k = 0; k < 2; ++k) { E.v[k] = eng[k]->gv[0]; E.p[k] = eng[k]->p; }
-  // both engines in free-running mode (az_selfplay_begin's switches, without its game bookkeeping); undone on every way out
-  struct Mode {
-    az_engine* e[2];
-    ~Mode() {
-      for (az_engine* x : e) {
-        (void)hipSetDevice(x->device);
-        (void)sync_all(x);
-        x->fr_on = false; x->arena_args = nullptr; x->arena_eng = nullptr; x->arena_side = nullptr;
-        x->gv[0].run_k = 0; x->gv[0].fr = 0; x->gv[0].fr_active = nullptr;
-        if (x->gs[0] != x->stream) { x->gs[0] = x->gt[0] = x->stream; }
-        hipLaunchKernelGGL(k_slot_records, dim3((x->v.G + 255) / 256), dim3(256), 0, x->stream, x->v, (int)(SR_CLEAR_ACTIVE | SR_CLEAR_LEAF));
-        (void)hipMemsetAsync(x->v.n_eval, 0, sizeof(int) * 2 * AZ_MAX_GROUPS, x->stream);
-        (void)hipMemsetAsync(x->v.bg_cnt, 0, sizeof(int) * 2 * AZ_MAX_GROUPS, x->stream);
-        (void)hipStreamSynchronize(x->stream);
-        for (int g = 0; g < AZ_MAX_GROUPS; ++g) { x->pending[g] = false; x->wave_par[g] = 0; }
-        split_register(x, 0);
-      }
-    }
-  } mode{{ec, eb}};
-  for (int k = 0; k < 2; ++k) {
-    az_engine* e = eng[k];
-    fr_knobs(e);
-    AZCHK(reset_wave_state(e));
-    hipLaunchKernelGGL(k_slot_records, dim3((e->v.G + 255) / 256), dim3(256), 0, e->stream, e->v, (int)(SR_CLEAR_ACTIVE | SR_CLEAR_TOTALS));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    e->gv[0].run_k = e->fr_k; e->gv[0].fr = 1; e->gv[0].fr_active = nullptr; e->gv[0].busy_host = nullptr;
-    if (e->cfg.oracle == AZ_ORACLE_RESNET && e->fr_s[0]) e->gs[0] = e->gt[0] = e->fr_s[0];
-    e->fr_on = true; e->arena_args = &a; e->arena_eng = &E; e->arena_me = k; e->arena_side = ec->fr_s[1]; e->arena_eng_move = ec->fr_s[2];
-    for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->group_active[g] = 0;
-    e->group_active[0] = G;
-    split_register(e, 1);
-  }
-  hipLaunchKernelGGL((k_arena_start<Gm>), dim3((G + 255) / 256), dim3(256), 0, ec->stream, a, E, G);
-  HIPCHK(hipStreamSynchronize(ec->stream));
-  // waves of the two engines, alternately enqueued; the host looks every 32 waves
-  int reported = 0, done = 0, idle_looks = 0;
-  long looks = 0; const auto t0 = std::chrono::steady_clock::now();
-  while (done < num_games) {
-    ++looks;
-    for (int i = 0; i < 32; ++i)
-      for (int k = 0; k < 2; ++k) { HIPCHK(hipSetDevice(eng[k]->device)); AZCHK(wave<Gm>(eng[k], 1, 0)); }
-    for (int k = 0; k < 2; ++k) AZCHK(check_device_error(eng[k]));   // synchronises
-    FRState fs;
-    HIPCHK(hipMemcpy(&fs, ec->d_fr, sizeof fs, hipMemcpyDeviceToHost));
-    const int now = (int)(fs.resv >> 40);
-    idle_looks = now == done ? idle_looks + 1 : 0;
-    done = now;
-    if (cb) for (; reported < done; ++reported) cb(user);
-    if (idle_looks > 4 * (ec->p.nsims + eb->p.nsims) / 32 + 64) return fail(AZ_ERR_STATE, "free-running arena: no game finished in %d looks", idle_looks);
-  }
-  if (getenv("AZHIP_ARENA_TRACE")) fprintf(stderr, "free-running arena: %ld waves per engine, %.3f s\n", looks * 32, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-  // the records: finished games in finishing order, their move records packed
-  std::vector<az_game_rec> hg(num_games);
-  std::vector<long long> ho(num_games);
-  std::vector<az_move_rec> hm;
-  {
-    FRState fs;
-    HIPCHK(hipMemcpy(&fs, ec->d_fr, sizeof fs, hipMemcpyDeviceToHost));
-    const long long nrec = (long long)(fs.resv & ((1ULL << 40) - 1));
-    hm.resize((size_t)std::max<long long>(nrec, 1));
-    HIPCHK(hipMemcpy(hg.data(), a.done, sizeof(az_game_rec) * (size_t)num_games, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ho.data(), a.done_off, sizeof(long long) * (size_t)num_games, hipMemcpyDeviceToHost));
-    if (nrec) HIPCHK(hipMemcpy(hm.data(), a.recs, sizeof(az_move_rec) * (size_t)nrec, hipMemcpyDeviceToHost));
-  }
-  std::unordered_set<std::pair<uint64_t, uint64_t>, KeyHash> uniq;
-  int64_t nstates = 0;
-  for (int i = 0; i < num_games; ++i) {
-    const az_game_rec& g = hg[i];
-    const int gi = g.game_id - first_game_id;
-    const az_move_rec* mv = hm.data() + ho[i];
-    const bool colors_flipped = alternate && ((gi + 1) % 2 == 1);
-    double wr = 0.0, gp = 1.0;                                     // total_reward (trace.jl:45-47)
-    for (int k = 0; k < g.num_moves; ++k) { wr += gp * (double)mv[k].reward; gp *= ec->p.gamma; }
-    if (rewards) rewards[gi] = colors_flipped ? -wr : wr;          // rewards_and_redundancy, simulations.jl:304-307
-    for (int k = 0; k < g.num_moves; ++k) uniq.insert({mv[k].key[0], mv[k].key[1]});
-    uniq.insert({g.final_key[0], g.final_key[1]});
-    nstates += (int64_t)g.num_moves + 1;
-    if (out) {
-      if (gi >= out->games_cap || out->num_moves + g.num_moves > out->moves_cap) return fail(AZ_ERR_CAPACITY, "trace buffer too small");
-      az_game_rec& o = out->games[gi];
-      o = g;
-      o.first_move = (int32_t)out->num_moves;
-      memcpy(out->moves + out->num_moves, mv, sizeof(az_move_rec) * (size_t)g.num_moves);
-      out->num_moves += g.num_moves;
-      out->num_games++;
-    }
-  }
-  if (redundancy) *redundancy = nstates ? 1.0 - (double)uniq.size() / (double)nstates : 0.0;   // simulations.jl:296-299
-  return AZ_OK;
-}
-
 template <class Gm>
 static int arena_run(az_engine* ec, az_engine* eb, int num_games, int first_game_id, bool alternate, az_trace_buf* out,
                      double* rewards, double* redundancy, az_progress_cb cb, void* user) {
@@ -2098,11 +1942,7 @@ extern "C" int az_arena_run(az_engine* contender, az_engine* baseline, int32_t n
   long long h0[2][4];
   const int others = split_streams_on_device(contender->device);
   for (int k = 0; k < 2; ++k) memcpy(h0[k], (k ? baseline : contender)->tower_hist, sizeof h0[k]);
-  if (arena_fr_ok(contender, baseline, num_games)) {
-    DISPATCH_GAME(contender->cfg.game, AZCHK(arena_run_fr<Gm>(contender, baseline, num_games, first_game_id, alternate_colors != 0, out, rewards, redundancy, cb, user)));
-  } else {
-    DISPATCH_GAME(contender->cfg.game, AZCHK(arena_run<Gm>(contender, baseline, num_games, first_game_id, alternate_colors != 0, out, rewards, redundancy, cb, user)));
-  }
+  DISPATCH_GAME(contender->cfg.game, AZCHK(arena_run<Gm>(contender, baseline, num_games, first_game_id, alternate_colors != 0, out, rewards, redundancy, cb, user)));
   if (trace)
     for (int k = 0; k < 2; ++k) {
       const long long* h = (k ? baseline : contender)->tower_hist;

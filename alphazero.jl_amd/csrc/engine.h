@@ -145,7 +145,6 @@ struct az_engine {
   FRState* d_fr; az_game_rec* d_done; long long* d_done_off; int done_cap;
   int* h_busy; int* d_busy;      // [AZ_MAX_GROUPS] host-mapped: slots of each group still inside an explore! that runs ahead (DView::busy_host)
   int explore_k;                 // simulations per slot and launch inside MCTS.explore! of the hooks and the arena (AZHIP_EXPLORE_K; 0 / 1 = lock step)
-  const ArenaArgs* arena_args; const ArenaEngines* arena_eng; int arena_me; hipStream_t arena_side, arena_eng_move;   // a free-running arena is in progress on this engine (az_arena_run): its move step is k_move_arena, `arena_me` = 0 contender / 1 baseline
   int* d_bg_stop; int bg_seq; bool bg_signal;   // the background search's stop word: set to bg_seq on the wave's stream once its tower has run (bg_signal: this wave has one)
   int* h_fr_words; int* d_fr_words;  // host-mapped: finished games / searching slots as of the previous wave (FRArgs::host_words)
   int fr_prev_done, fr_since_round, fr_given_up; long long fr_prev_recs;

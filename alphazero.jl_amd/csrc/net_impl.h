@@ -108,11 +108,8 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n, int 
   // slots in two groups 0.62 vs 0.71 M sims/s); its kernel arguments change per launch (epoch): not under hipGraph replay
   // (r4) the count runs over ALL engines of the process on this device that may launch split towers side by side (an arena has
   // two); an engine whose exchange has given up once (another process, a trainer: work this count cannot see) stays unsplit
-  // (a free-running arena: a worker is in ONE of the two engines at a time, so both engines' boards together never exceed the workers --
-  // the grids are sized for the worst case of each, but the workgroups beyond a launch's boards leave before they touch the exchange)
-  const long split_boards = e->arena_args ? (long)(e->arena_args->G + 1) / 2 : nb;
   const bool can_split = F == 128 && !e->cfg.net_bf16 && !e->use_graphs && e->cfg.num_blocks <= 127 && !e->split_off &&
-                         2 * std::max(std::max(1, e->ngroups), split_streams_on_device(e->device)) * ((split_boards + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB) <= (e->num_cu > 0 ? e->num_cu : 256);
+                         2 * std::max(std::max(1, e->ngroups), split_streams_on_device(e->device)) * ((nb + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB) <= (e->num_cu > 0 ? e->num_cu : 256);
   if (e->tower_pick == 2 && can_split) return 2;
   if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || ((e->tower_pick == 21 || e->tower_pick == 19) && F == 64) || (e->tower_pick == 7 && NTM<Gm> > 0))) return e->tower_pick;
   if (e->cfg.net_bf16) {                                           // k_tower16b: 22 (128 filters), 11 or 3 row tiles
@@ -372,12 +369,9 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   if (e->bg_signal) {
     // the tower has run: the background search of this wave winds up while the heads run.  The word is set from a stream of its own behind
     // an event (a one-thread launch IN the wave's stream sat 7.6 us between tower and heads)
-    if (e->arena_args) hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, sn, e->d_bg_stop, e->bg_seq);   // (two engines at once: no stream to spare, azhip.hip arena_run_fr)
-    else {
-      HIPCHK(hipEventRecord(e->fr_ev[3], sn));
-      HIPCHK(hipStreamWaitEvent(e->fr_s[3], e->fr_ev[3], 0));
-      hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, e->fr_s[3], e->d_bg_stop, e->bg_seq);
-    }
+    HIPCHK(hipEventRecord(e->fr_ev[3], sn));
+    HIPCHK(hipStreamWaitEvent(e->fr_s[3], e->fr_ev[3], 0));
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, e->fr_s[3], e->d_bg_stop, e->bg_seq);
   }
   if (split && !fr) { HIPCHK(hipEventRecord(e->ev_net[g], sn)); HIPCHK(hipStreamWaitEvent(st, e->ev_net[g], 0)); }
   AZCHK((launch_heads<Gm, F>(e, fr ? sn : st, e->g_hfeat[g], v.leaf_env, eslots, nev, N, (const float*)nullptr, v.Pout, v.Vout, (float*)nullptr, L)));

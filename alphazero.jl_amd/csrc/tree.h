@@ -1080,169 +1080,6 @@ __global__ void __launch_bounds__(256) k_move_fr(DView v, DParams p, FRArgs fa) 
   move_slot<Gm, true>(v, p, slot, fa);
 }
 
-// =========================================================================================
-// Free-running arena (round 6): pit_networks (training.jl:130-144) = simulate over TwoPlayers (play.jl:248-282) with every worker at
-// its own pace.  Worker w has a tree in each player's engine; a turn belongs to one of them (think(::TwoPlayers), play.jl:255-261).
-// The engine whose turn it is searches slot w like a free-running self-play slot; when its explore! is complete, its k_move_arena
-// plays the move, sets up the next turn (trace.states[i], the random symmetry of play.jl:305-307, who is to think) and HANDS THE TURN
-// OVER through a mailbox: it never writes the other engine's slot records (that engine's tree kernel may be reading them), it writes
-// a message and raises its flag (release); the addressee's k_arena_take -- in the addressee's own stream order, right before its wave's
-// tree launch -- takes the message (acquire) and activates its slot.  The move step runs on a side stream and NOBODY waits for it (a
-// serial Dirichlet draw takes 0.3 ms under a busy tower, longer than the 64-board tower of an arena wave): a slot whose explore! is
-// complete is left alone by the tree launches until the move step has got to it.  Game ends, game ids and trace write-out as in k_move_fr.
-// =========================================================================================
-struct ArenaMsg { unsigned long long a, b; uint32_t fin, gid, mv, flag; };     // the turn handed to a player: state to think about, game, move index
-static_assert(sizeof(ArenaMsg) == 32, "arena message");
-struct ArenaArgs {
-  FRState* st;                              // resv / next_game / active[0] of the arena (the contender's record)
-  az_game_rec* done; long long* done_off;   // finished games in finishing order
-  az_move_rec* recs; long long recs_cap;    // their move records, packed
-  int done_cap, total_games;
-  uint32_t first_game_id;
-  int alternate;                            // alternate_colors (simulations.jl:221-223)
-  az_move_rec* trace; int max_moves;        // [G][max_moves] the workers' move records of the game in progress
-  int* worker_sim_id;                       // [G]
-  int* tree_gen;                            // [G] resets of the worker's player so far (reset_player!, simulations.jl:235-237)
-  int* my_gen;                              // [2][G] how many of them each engine has carried out on its tree
-  ArenaMsg* mail;                           // [2][G]
-  int* host_words;                          // host-mapped [2]: finished games, workers still playing
-  int reset_every; double flip_p; uint64_t flip_seed;
-  int G;
-};
-// the two players' engines as a move step sees them: it writes the trace, the mailboxes and -- for the slot it hands a turn to, which
-// is inactive in the addressee's engine and therefore read by nobody there -- the addressee's game id / move index / Dirichlet noise
-struct ArenaEngines { DView v[2]; DParams p[2]; };
-// trace.states[i] for the turn that starts from `env` (before the flip), the turn's random symmetry, who thinks, that player's noise
-// for the explore! to come (the expensive part: the addressee's k_arena_take is on its wave's critical path and only copies); the
-// message goes out last
-template <class Gm>
-__device__ inline void arena_setup_turn(const ArenaArgs& a, const ArenaEngines& E, int w, GEnv env, uint32_t gid, uint32_t mv) {
-  int k1 = 0;
-  GEnv seen = env;
-  if (Gm::NSYM > 0 && a.flip_p != 0.0) {
-    az_rng r = az_rng_make(a.flip_seed, gid, mv, AZ_RNG_FLIP);
-    if (az_rng_f64(&r) < a.flip_p) {
-      int k = (int)(az_rng_f64(&r) * (double)Gm::NSYM);
-      if (k >= Gm::NSYM) k = Gm::NSYM - 1;
-      seen = Gm::sym(env, k);
-      k1 = k + 1;
-    }
-  }
-  if ((int)mv < a.max_moves) {
-    az_move_rec* rec = a.trace + (size_t)w * a.max_moves + mv;
-    rec->key[0] = env.a; rec->key[1] = env.b;
-    for (int x = 0; x < AZ_MAX_ACTIONS; ++x) rec->N[x] = 0;
-    rec->N[AZ_MAX_ACTIONS] = k1;
-  }
-  const bool colors_flipped = a.alternate && (((int)gid - (int)a.first_game_id + 1) % 2 == 1);
-  const int who = (Gm::white_playing(seen) != colors_flipped) ? 0 : 1;           // 0 contender, 1 baseline
-  E.v[who].game_id[w] = gid;
-  E.v[who].move_idx[w] = mv;
-  arm_noise<Gm>(E.v[who], E.p[who], w, seen);                                    // dirichlet_noise (mcts.jl:228-232), keyed by (game, move)
-  ArenaMsg* m = a.mail + (size_t)who * a.G + w;
-  m->a = seen.a; m->b = seen.b; m->fin = seen.fin; m->gid = gid; m->mv = mv;
-  __hip_atomic_store(&m->flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <class Gm>
-__global__ void __launch_bounds__(256) k_arena_start(ArenaArgs a, ArenaEngines E, int n) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < n) arena_setup_turn<Gm>(a, E, w, Gm::init(), a.first_game_id + (uint32_t)w, 0);
-}
-// the turns handed to engine `me`: its slots are activated here, in its own stream order right before its wave's tree launch (a handful
-// of instructions per worker; everything expensive was done by the sender)
-template <class Gm>
-__global__ void __launch_bounds__(256) k_arena_take(DView v, ArenaArgs a, int me) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= a.G) return;
-  ArenaMsg* const mm = a.mail + (size_t)me * a.G + w;
-  if (__hip_atomic_load(&mm->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) return;
-  SlotRec* const sr = v.sr + w;
-  GEnv env; env.a = mm->a; env.b = mm->b; env.fin = mm->fin;
-  int* const mine = a.my_gen + (size_t)me * a.G + w;
-  if (*mine != a.tree_gen[w]) {                                   // MCTS.reset!: a new epoch empties the table in O(1)
-    uint32_t ep = sr->epoch + 1;
-    if (ep >= 0xffff) {
-      unsigned long long* tab = v.ht + (size_t)w * v.ht_size;
-      for (int k = 0; k < v.ht_size; ++k) tab[k] = 0;
-      ep = 1;
-    }
-    sr->epoch = ep; sr->node_count = 0;
-    *mine = a.tree_gen[w];
-  }
-  sr->set_root(env);
-  sr->root_idx = -1;
-  sr->leaf_kd = LEAF_NONE;
-  sr->active = SR_ACTIVE;
-  __hip_atomic_store(&mm->flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <class Gm>
-__global__ void __launch_bounds__(256) k_move_arena(ArenaEngines E, ArenaArgs a, int me) {
-  const DView& v = E.v[me];
-  const DParams& p = E.p[me];
-  using NL = NodeL<Gm>;
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w == 0 && me == 0 && a.host_words) {
-    const unsigned long long r = __hip_atomic_load(&a.st->resv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(a.host_words, (int)(r >> 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(a.host_words + 1, __hip_atomic_load(&a.st->active[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (w >= a.G) return;
-  SlotRec* const sr = v.sr + w;
-  // ---- my move, if my explore! is complete (play.jl:308-313)
-  const int aw = sr->active;
-  if ((aw & SR_ACTIVE) && (aw >> SR_MS_SHIFT) >= p.nsims && (sr->leaf_kd & 3) == LEAF_NONE) {
-    const GEnv env = sr->root();
-    const uint32_t gid = v.game_id[w], mv = v.move_idx[w];
-    const char* nd = find_node<Gm>(v, w, env.a, env.b);
-    if (!nd) { dev_fail(v, DERR_NO_ROOT); return; }
-    if ((int)mv >= a.max_moves) { dev_fail(v, DERR_MOVES); return; }
-    const uint32_t m = Gm::mask(env);
-    int Nn[AZ_MAX_ACTIONS];
-    for (int x = 0; x < Gm::A; ++x) Nn[x] = NL::stat(nd, x)->N;
-    const int act = select_action<Gm>(p, Nn, m, mv, gid);
-    GEnv nxt = env;
-    Gm::play(nxt, act);
-    const bool over = nxt.fin & 1;
-    unsigned long long off = 0; int di = 0;
-    if (over) {
-      const unsigned long long nm = (unsigned long long)mv + 1;
-      unsigned long long cur = __hip_atomic_load(&a.st->resv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (;;) {
-        di = (int)(cur >> 40); off = cur & ((1ULL << 40) - 1);
-        if (di >= a.done_cap || (long long)(off + nm) > a.recs_cap) return;
-        if (__hip_atomic_compare_exchange_strong(&a.st->resv, &cur, cur + (1ULL << 40) + nm, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      }
-    }
-    az_move_rec* rec = a.trace + (size_t)w * a.max_moves + mv;     // key and symmetry were written when the turn was set up
-    for (int x = 0; x < AZ_MAX_ACTIONS; ++x) rec->N[x] = (x < Gm::A && ((m >> x) & 1)) ? Nn[x] : 0;
-    rec->action = act;
-    rec->reward = Gm::white_reward(nxt);
-    sr->active = 0;                                               // my slot rests until a turn is handed to it (possibly just below)
-    uint32_t ngid = gid, nmv = mv + 1;
-    GEnv e2 = nxt;
-    bool more = true;
-    if (over) {
-      const uint4* src = (const uint4*)(a.trace + (size_t)w * a.max_moves);
-      uint4* dst = (uint4*)(a.recs + off);
-      for (int k = 0; k < (int)(mv + 1) * (int)(sizeof(az_move_rec) / 16); ++k) dst[k] = src[k];
-      az_game_rec gr;
-      gr.game_id = (int32_t)gid; gr.slot = w; gr.num_moves = (int32_t)(mv + 1);
-      gr.first_move = (int32_t)(off > 0x7fffffffULL ? 0x7fffffffULL : off);
-      gr.nodes = 0; gr.total_simulations = 0; gr.total_nodes_traversed = 0;
-      gr.final_key[0] = nxt.a; gr.final_key[1] = nxt.b;
-      a.done[di] = gr;
-      a.done_off[di] = (long long)off;
-      const int ws = a.worker_sim_id[w] + 1;
-      a.worker_sim_id[w] = ws;
-      if (a.reset_every > 0 && ws % a.reset_every == 0) a.tree_gen[w] += 1;      // reset_player!: both players' trees, each by its own engine
-      const int k = atomicAdd(&a.st->next_game, 1);
-      if (k < a.total_games) { ngid = a.first_game_id + (uint32_t)k; nmv = 0; e2 = Gm::init(); }
-      else { more = false; atomicSub(&a.st->active[0], 1); }
-    }
-    if (more) arena_setup_turn<Gm>(a, E, w, e2, ngid, nmv);
-  }
-}
-
 // start games on a list of slots (GI.init(gspec), play.jl:299); MCTS.reset! when asked
 template <class Gm>
 __global__ void __launch_bounds__(256) k_start_games(DView v, DParams p, const int* slots, const uint32_t* game_ids,

@@ -42,9 +42,8 @@ def test_arena_matches_oracle_hash_players(game, ngames, workers, batch, flip, a
             azhip.Engine(**_engine_kw(b, game, workers, batch, 2, flip, 21)) as eb:
         games, moves, ng, nm, rew, red = ec.arena_run(eb, ngames, alternate_colors=alt,
                                                      progress=lambda: count.__setitem__(0, count[0] + 1))
-        # (r6) one slot group per engine: the free-running arena -- which worker plays which game is an outcome of the reference's id
-        # race (util.jl:181-188), reported per game; the oracle replays it.  batch < workers: the lock-step arena (the same call with
-        # the default assignment)
+        # which worker plays which game is an outcome of the reference's id race (util.jl:181-188); the arena reports the one it took per
+        # game (az_game_rec.slot) and the oracle replays it.  (The arena hands ids out in worker order: the oracle's default assignment.)
         g_ref, m_ref, nm_ref, rew_ref, red_ref = R.arena(game, ngames, workers, c, b, alternate_colors=alt, flip_probability=flip,
                                                          reset_every=2, seed=21, assignment=R.assignment_of(games, ngames))
         assert count[0] == ngames and nm == nm_ref
@@ -84,11 +83,8 @@ def test_pit_networks_two_resnets_matches_oracle():
     assert ev.avgr == float(np.mean(rew_ref)) and ev.baseline_rewards is None and ev.time > 0
     # a network against itself, colours alternating: same trees on both sides is NOT the same as self-play, but
     # the result must be deterministic
-    # (with trees kept over two games that needs the fixed assignment of the lock-step schedule: SimParams.lock_step)
-    import dataclasses
-    ap_ls = dataclasses.replace(ap, sim=dataclasses.replace(ap.sim, lock_step=True))
-    ev2 = azhip.compare_networks(gspec, contender, contender, ap_ls, None, seed=13)
-    ev3 = azhip.compare_networks(gspec, contender, contender, ap_ls, None, seed=13)
+    ev2 = azhip.compare_networks(gspec, contender, contender, ap, None, seed=13)
+    ev3 = azhip.compare_networks(gspec, contender, contender, ap, None, seed=13)
     assert np.array_equal(ev2.rewards, ev3.rewards)
 
 
