@@ -21,7 +21,7 @@ C4_SCHED = ((0, 20, 30), (1.0, 1.0, 0.3))          # games/connect-four/params.j
 
 
 NSAMPLE = 64                                        # games compared per configuration (was 8 / 6)
-NSAMPLE_C2 = 96                                     # (r6) the headline configuration: half as many again -- what the box's 16 usable CPUs replay in ~60 s (VERDICT r5 #7 asked for 512: ~6 min here)
+NSAMPLE_C2 = int(__import__("os").environ.get("AZ_NSAMPLE_C2", 96))   # (r6; AZ_NSAMPLE_C2=512: tools/gpu_r6_y.sh, profiles/r6/c2_512_games_oracle_network.txt) the headline configuration: half as many again -- what the box's 16 usable CPUs replay in ~60 s (VERDICT r5 #7 asked for 512: ~6 min here)
 
 
 def _rec(g, moves):
