@@ -117,6 +117,7 @@ extern "C" int az_engine_destroy(az_engine* e) {
   split_register(e, 0);
   if (e->h_xflag) (void)hipHostFree(e->h_xflag);
   if (e->h_nleaf) (void)hipHostFree(e->h_nleaf);
+  if (e->h_needy) (void)hipHostFree(e->h_needy);
   if (e->h_fr_words) (void)hipHostFree(e->h_fr_words);
   if (e->h_busy) (void)hipHostFree(e->h_busy);
   for (int i = 0; i < 4; ++i) { if (e->fr_s[i]) { (void)hipStreamSynchronize(e->fr_s[i]); (void)hipStreamDestroy(e->fr_s[i]); } if (e->fr_ev[i]) (void)hipEventDestroy(e->fr_ev[i]); }
@@ -252,7 +253,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
   e->vm_base = nullptr; e->vm_bytes = 0; e->vm_chunk = 0; e->vm_rows = 0; e->vm_chunk_nodes = 0; e->d_slot_cap = nullptr; e->vm_budget = 0; e->vm_mapped = 0;
   e->vmk_base = nullptr; e->vmk_bytes = 0; e->vmk_piece = 0; e->tree_sort = 0; e->d_perm = nullptr; e->d_perm_prev = nullptr;
   e->next_exec = 1.0;
-  e->h_env = nullptr; e->h_n = nullptr; e->h_pv = nullptr; e->h_nleaf = nullptr; e->d_nleaf = nullptr;
+  e->h_env = nullptr; e->h_n = nullptr; e->h_pv = nullptr; e->h_nleaf = nullptr; e->d_nleaf = nullptr; e->h_needy = nullptr; e->d_needy = nullptr;
   e->d_ec = nullptr; e->ec_mask = 0; e->ec_seq = 0; e->d_ec_claim = nullptr; e->d_Phit = nullptr; e->d_Vhit = nullptr;
   e->fr_on = false; e->fr_k = 0; e->fr_kbg = 0; e->fr_round_waves = 0; for (int i = 0; i < 4; ++i) { e->fr_s[i] = nullptr; e->fr_ev[i] = nullptr; } e->d_fr = nullptr; e->d_done = nullptr; e->d_done_off = nullptr; e->done_cap = 0;
   e->h_fr_words = nullptr; e->d_fr_words = nullptr; e->h_busy = nullptr; e->d_busy = nullptr; e->explore_k = 0; e->fr_prev_done = 0; e->fr_since_round = 0; e->fr_given_up = 0; e->fr_prev_recs = 0;
@@ -405,6 +406,9 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
     HIPCHK(hipHostMalloc((void**)&e->h_nleaf, sizeof(int) * AZ_MAX_GROUPS, hipHostMallocMapped));
     for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->h_nleaf[g] = -1;      // nothing reported yet: launches are priced at their upper bound
     HIPCHK(hipHostGetDevicePointer((void**)&e->d_nleaf, e->h_nleaf, 0));
+    HIPCHK(hipHostMalloc((void**)&e->h_needy, sizeof(int) * AZ_MAX_GROUPS, hipHostMallocMapped));
+    for (int g = 0; g < AZ_MAX_GROUPS; ++g) e->h_needy[g] = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&e->d_needy, e->h_needy, 0));
     // free-running phases: the device's own bookkeeping (FRState) and two host-mapped progress words
     AZCHK(dalloc(e, &e->d_fr, 1)); AZCHK(dalloc(e, &e->d_bg_stop, 1)); e->bg_seq = 0; e->bg_signal = false;
     HIPCHK(hipHostMalloc((void**)&e->h_busy, sizeof(int) * AZ_MAX_GROUPS, hipHostMallocMapped));
@@ -474,6 +478,7 @@ extern "C" int az_engine_create(const az_engine_cfg* c, az_engine** out) {
         gv.perm = e->d_perm + o;
         hipLaunchKernelGGL(k_iota, dim3((Gh + 255) / 256), dim3(256), 0, e->stream, e->d_perm + o, Gh);
       }
+      gv.needy_host = e->d_needy + g;
       gv.nleaf_host = e->d_ec ? e->d_nleaf + g : nullptr;            // only the evaluation cache makes a wave's network batch differ from its active slots
       gv.n_eval += 2 * g; gv.keys += o * v.key_stride; gv.Pout += o * gi.APAD; gv.Vout += o; gv.trace += o * v.max_moves; gv.grec += o; gv.finished += o;
       e->gv[g] = gv;

@@ -80,6 +80,7 @@ struct az_engine {
   unsigned long long* xch[AZ_MAX_GROUPS + 1]; unsigned long long xch_epoch;
   // (r4) a split tower whose exchange gives up degrades instead of failing the phase (azhip.hip recover_split)
   int* d_xerr; int* d_skipped;   // [AZ_MAX_GROUPS + 1] exchange words, [..][2] counters of idle k_tree launches (DView::xerr / skipped)
+  int* h_needy; int* d_needy;    // [AZ_MAX_GROUPS] host-mapped: slots each group's previous wave launch left to the background search (tree.h DView::needy_host)
   int* h_nleaf; int* d_nleaf;    // [AZ_MAX_GROUPS] host-mapped: network batch of each group's previous wave (k_tree writes, pick_tower's estimate reads)
   int* h_xflag; int* d_xflag;    // host-mapped word the kernel sets when an exchange gives up; looked at before every launch
   bool split_off;                // the split is disabled for this engine after the first time

@@ -18,6 +18,8 @@ template <class Gm, int F, bool PLANES_ONLY = false> static int set_kernel_attrs
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, false, 10, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F, 10, 9>::BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2<Gm, F, true, 10, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F, 10, 9>::BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2m<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2c<Gm, F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16x2c<Gm, F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T16P<Gm, F>::BYTES));
   }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, false, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower16b<Gm, F, true, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, T16B<Gm, F, 11>::BYTES));
@@ -77,11 +79,12 @@ template <class Gm> static int set_kernel_attrs(az_engine* e) {
 static void note_tower(az_engine* e, int tw, int F) {
   static const char* const gn[] = {"ConnectFour", "TicTacToe", "Mancala", "Go9Planes"};
   const char* g = gn[e->cfg.game];
-  e->tower_hist[tw == 2 ? 0 : tw == 3 ? 1 : (tw == 16 || tw == 21 || tw == 19) ? 2 : 3]++;
+  e->tower_hist[tw == 2 ? 0 : tw == 3 ? 1 : (tw == 16 || tw == 21 || tw == 19 || tw == 20) ? 2 : 3]++;
   if (e->cfg.net_bf16) { snprintf(e->last_tower, sizeof e->last_tower, "k_tower16b<%s,%d,NT=%d>", g, F, tw == 3 ? e->nts : tw == 22 ? 22 : 11); return; }
   if (tw == 2) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16s<%s,%d>", g, F);
   else if (tw == 21) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d>", g, F);
   else if (tw == 19) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2<%s,%d,NT=19>", g, F);
+  else if (tw == 20) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16x2c<%s,%d>", g, F);
   else if (tw == 3) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=%d>", g, F, e->nts);
   else if (tw == 7) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=%d>", g, F, e->ntm);
   else if (tw == 16) snprintf(e->last_tower, sizeof e->last_tower, "k_tower16<%s,%d,NT=11>", g, F);
@@ -111,7 +114,7 @@ template <class Gm, int F> static int pick_tower(const az_engine* e, int n, int 
   const bool can_split = F == 128 && !e->cfg.net_bf16 && !e->use_graphs && e->cfg.num_blocks <= 127 && !e->split_off &&
                          2 * std::max(std::max(1, e->ngroups), split_streams_on_device(e->device)) * ((nb + T16<Gm, F, NTS<Gm>>::TB - 1) / T16<Gm, F, NTS<Gm>>::TB) <= (e->num_cu > 0 ? e->num_cu : 256);
   if (e->tower_pick == 2 && can_split) return 2;
-  if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || ((e->tower_pick == 21 || e->tower_pick == 19) && F == 64) || (e->tower_pick == 7 && NTM<Gm> > 0))) return e->tower_pick;
+  if (!e->cfg.net_bf16 && (e->tower_pick == 16 || e->tower_pick == 32 || e->tower_pick == 3 || ((e->tower_pick == 21 || e->tower_pick == 19 || e->tower_pick == 20) && F == 64) || (e->tower_pick == 7 && NTM<Gm> > 0))) return e->tower_pick;
   if (e->cfg.net_bf16) {                                           // k_tower16b: 22 (128 filters), 11 or 3 row tiles
     if (e->tower_pick == 3 || e->tower_pick == 16) return e->tower_pick;
     if (e->tower_pick == 22 && F == 128) return 22;
@@ -175,7 +178,7 @@ template <class Gm, int F> static double tower_exec_frac(const az_engine* e, int
   if (tw == 2 || tw == 3) return T16<Gm, F, NTS<Gm>>::Geo::tab.cost / (9.0 * NTS<Gm>);
   if constexpr (NTM<Gm> > 0) { if (tw == 7) return T16<Gm, F, NTM<Gm>>::Geo::tab.cost / (9.0 * NTM<Gm>); }
   if (tw == 16) return T16<Gm, F>::Geo::tab.cost / (9.0 * T16<Gm, F>::NTILE);
-  if (tw == 21) return T16P<Gm, 64>::Geo::tab.cost / (9.0 * T16P<Gm, 64>::NTW);
+  if (tw == 21 || tw == 20) return T16P<Gm, 64>::Geo::tab.cost / (9.0 * T16P<Gm, 64>::NTW);
   if (tw == 19) return T16P<Gm, 64, 10, 9>::Geo::tab.cost / (9.0 * T16P<Gm, 64, 10, 9>::NTW);
   return 1.0;
 }
@@ -255,6 +258,9 @@ static int launch_net_f(az_engine* e, hipStream_t st, float* hfeat, const GEnv* 
   } else if (tw == 21) {
     if constexpr (F == 64)
       LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat, 0);
+  } else if (tw == 20) {
+    if constexpr (F == 64)
+      LAUNCH_ON(e, st, AZ_K_TOWER, n_max, (k_tower16x2c<Gm, F, FROM_PLANES>), (n_max + TB21 - 1) / TB21, THR21, LDS21, e->net16, envs, eslots, n_ptr, n_max, X, hfeat, 0);
   } else if (tw == 19) {
     if constexpr (F == 64) {
       using T19 = T16P<Gm, 64, 10, 9>;
@@ -300,7 +306,20 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   // reported for the group's last completed wave (+ 1/8: a launch priced too small costs more than one priced too large)
   int npick = N;
   if (v.nleaf_host) { const int seen = ((volatile int*)e->h_nleaf)[g]; if (seen >= 0) npick = std::max(1, std::min(N, seen + seen / 8 + 8)); }
-  const int tw = pick_tower<Gm, F>(e, npick, N);
+  int tw = pick_tower<Gm, F>(e, npick, N);
+  if (tw == 21 && e->fr_on && e->ngroups == 1 && e->tower_pick == 0 && e->fr_kbg > 0 && v.nleaf_host && v.needy_host) {
+    // The paired tower beside the side streams' kernels (resnet16.h k_tower16x2c): a CU that holds a workgroup of the background search
+    // (256 threads = 32 Connect-Four slots of the needy list) takes no workgroup of the 198-register form for as long as that search
+    // runs, one that holds a busy workgroup of the move step none for the first round (measured: the launch gains a round of workgroups
+    // beyond ~478 of 512 workgroups in the steady state, ~8 + ~9 such CUs).  Where the counts the device reported for the previous wave
+    // say that this adds a round, the 176-register form serves the launch.
+    const int cu = e->num_cu > 0 ? e->num_cu : 256;
+    const int seen = ((volatile int*)e->h_nleaf)[g], needy = ((volatile int*)e->h_needy)[g];
+    if (seen > 0) {
+      const int wgs = (seen + TB21 - 1) / TB21, rounds = (wgs + cu - 1) / cu, bg = (std::max(needy, 0) * L + 255) / 256;
+      if (wgs > rounds * (cu - bg) - 14) tw = 20;
+    }
+  }
   note_tower(e, tw, F);
   e->next_exec = tower_exec_frac<Gm, F>(e, tw);
   if (e->cfg.net_bf16) {
@@ -317,6 +336,9 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
       LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16s<Gm, F, false>), 2 * ((N + TB3 - 1) / TB3), (T16S<Gm, F>::THREADS), LDS3, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g],
                 xa, ep, v.xerr, e->d_xflag);
     }
+  } else if (tw == 20) {
+    if constexpr (F == 64)
+      LAUNCH_ON(e, sn, AZ_K_TOWER, N, (k_tower16x2c<Gm, F, false>), (N + TB21 - 1) / TB21, THR21, LDS21, e->net16, v.leaf_env, eslots, nev, N, (const float*)nullptr, e->g_hfeat[g], 0);
   } else if (tw == 21 || tw == 19) {
     if constexpr (F == 64) {
       // (r6, measured, OFF by default) Two rounds of workgroups, the second one lighter.  A batch of b boards with 8 cu < b <= 8 cu + 7 cu

@@ -728,6 +728,24 @@ k_tower16x2(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restri
   if (board0 >= n) return;
   tower16x2_body<T, FROM_PLANES>(net, leaf_env, eval_slots, n, X, hfeat, board0, net.geo[NT0 == 11 ? 2 : 4]);
 }
+// (r6) The 8-board form within 176 registers per lane (the compiler takes 198 when it may: 92 B of scratch per lane here, +2 % per launch).
+// A free-running phase runs k_tree's background launch UNDER the tower (azhip.hip wave_group), and a k_tree wavefront (152 registers)
+// shares a SIMD with this kernel's two wavefronts only if they take 2 x 176 of its 512, not 2 x 200: beside the 198-register form
+// every CU that holds a background workgroup is lost to the tower for as long as the background search runs.  With few such CUs that
+// costs nothing (476 workgroups on 246 CUs are two rounds like on 256); when a third of the slots search in the background -- the
+// first seconds of a phase, every game in its opening and the evaluation cache answering -- it costs a third round: 1.04 ms instead
+// of 0.85 for 3930 boards (profiles/r6/README.md §12).  wave_net_f picks this form for the waves where the counts the device reports
+// say so.  amdgpu_num_vgpr counts half of the unified file on gfx90a and later: 88 = 176 registers.
+template <class Gm, int F, bool FROM_PLANES>
+__global__ void __launch_bounds__(2 * T16Threads<F>::V, 1) __attribute__((amdgpu_num_vgpr(88)))
+k_tower16x2c(Net16Dev net, const GEnv* __restrict__ leaf_env, const int* __restrict__ eval_slots,
+             const int* __restrict__ n_eval_ptr, int n_fixed, const float* __restrict__ X, float* __restrict__ hfeat, int base) {
+  using T = T16P<Gm, F, 11, 10>;
+  const int n = FROM_PLANES ? n_fixed : *n_eval_ptr;
+  const int board0 = base + blockIdx.x * T::TB;
+  if (board0 >= n) return;
+  tower16x2_body<T, FROM_PLANES>(net, leaf_env, eval_slots, n, X, hfeat, board0, net.geo[2]);
+}
 // (r6) Both paired forms in ONE launch: workgroups 0 .. first - 1 take 8 boards each (21 row tiles), the workgroups behind them 7 (19 tiles).
 // A batch between 15 and 16 boards per CU -- a free-running wave's 3700-3840 boards on 256 CUs -- is two rounds of workgroups either
 // way; with first = the number of CUs the second round is an eighth lighter, and because it is one launch a CU that is done early

@@ -97,6 +97,7 @@ struct DView {
   uint32_t ec_mask, ec_seq;   // ec_seq: number of this k_tree launch (any slot group of the engine), > 0
   uint32_t ec_floor;          // entries whose claim number is <= ec_floor are EMPTY: az_net_set_params empties the table by raising the floor (a 1 GB memset per weight update before)
   int* ec_claim;          // [G][2] cache entry the slot's pending leaf claimed (its answer goes there when the leaf is expanded; -1 = none) and the meta value of the claim
+  int* needy_host;        // host-mapped word: the slots this group's previous wave launch left to the background search (free-running; wave_net_f's choice between the paired tower's two register budgets), or NULL
   int* nleaf_host;        // host-mapped word: the network batch of this group's previous wave (pick_tower's launch-size estimate), or NULL
   float* Phit; float* Vhit; // [G][APAD], [G]: the answer of a leaf the cache answered, by SLOT (written by the slot's phase B, read by its next phase A; SlotRec::eidx = -1 says so)
   uint32_t tag_mask;      // 0xffff; tests narrow it (AZHIP_HT_TAG_BITS) so that unequal states share tags and every probe chain reaches the exact key compare
@@ -376,7 +377,7 @@ template <class Gm> __device__ inline void set_link(char* nd, int act, uint32_t 
 // =========================================================================================
 struct KArgs { DView v; DParams p; };   // the head of k_tree's kernarg segment
 template <class Gm>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_tree(DView v_arg, DParams p_arg, int do_backup, int do_select, int par) {   // at most 160 VGPRs: one wavefront still fits beside two tower waves on a SIMD (2 x 176 + 160 of 512)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_tree(DView v_arg, DParams p_arg, int do_backup, int do_select, int par) {   // (amdgpu_num_vgpr counts half of the unified register file on gfx90a and later: a budget of 320, without it the loop spills.)  The kernel takes 149 (allocated: 152): a wavefront fits beside the two of a 176-register tower form on a SIMD (k_tower16, k_tower16x2c: 2 x 176 + 152 of 512), not beside k_tower16x2's two of 198 -- net_impl.h wave_net_f picks the form by that
   if (!v_arg.low_prio) __builtin_amdgcn_s_setprio(3);   // short latency-bound kernel on the wave's critical path: win issue arbitration against co-resident tower waves
   const DView& v = v_arg;
   constexpr int L = Gm::APAD;
@@ -739,6 +740,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) k_t
       v.n_eval[par ^ 1] = 0;
       if (v.bg_cnt) {
         if (v.busy_host && v.run_k && !v.fr && do_backup) __hip_atomic_store(v.busy_host, v.bg_cnt[par ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v.needy_host && v.fr && do_backup) __hip_atomic_store(v.needy_host, v.bg_cnt[par ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         v.bg_cnt[par ^ 1] = 0;
       }
     }

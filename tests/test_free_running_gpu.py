@@ -162,3 +162,36 @@ def test_the_mixed_8_and_7_board_tower_launch_changes_no_record(monkeypatch):
             assert ng == 6000 and st.aborted_games == 0
             out[mode] = _by_id(g, m, ng)
     assert out["mixed"] == out["plain"] == out["lock"]
+
+
+def test_the_176_register_paired_tower_changes_no_record(monkeypatch):
+    """4096 slots in ONE group: where the background search's workgroups would cost the 198-register paired tower a round of workgroups
+    (a k_tree wavefront does not fit beside its two on a SIMD), wave_net_f serves the wave with k_tower16x2c, the same kernel body
+    within 176 registers (csrc/resnet16.h, net_impl.h; profiles/r6/README.md §12).  The phase's records must not depend on which
+    waves that happens in: the engine's own choice, the capped form forced for every launch (AZHIP_TOWER=20) and the lock-step
+    schedule give the same games."""
+    import azhip
+    from azhip.network import ResNetHP, random_params
+    hp = ResNetHP(**_resnet_kw(blocks=1))
+    blob = random_params(azhip.GAME_CONNECT_FOUR, hp, seed=5)
+    kw = dict(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, num_workers=4096, batch_size=4096, num_iters_per_turn=48, cpuct=2.0,
+              dirichlet_noise_eps=0.25, dirichlet_noise_alpha=1.0, temperature=SCHED, reset_every=1, seed=23, **_resnet_kw(blocks=1))
+    out, kernels = {}, set()
+    for mode in ("own", "capped", "lock"):
+        if mode == "capped":
+            monkeypatch.setenv("AZHIP_TOWER", "20")
+        else:
+            monkeypatch.delenv("AZHIP_TOWER", raising=False)
+        with azhip.Engine(lock_step=1 if mode == "lock" else 0, **kw) as e:
+            e.net_set_params(blob)
+            if mode != "lock":
+                e.selfplay_begin(-1, 0)
+                for _ in range(12):
+                    e.selfplay_step(25)
+                    kernels.add((mode, e.net_last_kernel().split("<")[0]))
+                e.selfplay_end()
+            g, m, ng, nm, st = e.selfplay_run(6000)
+            assert ng == 6000 and st.aborted_games == 0
+            out[mode] = _by_id(g, m, ng)
+    assert out["own"] == out["capped"] == out["lock"]
+    assert ("capped", "k_tower16x2c") in kernels and {k for md, k in kernels if md == "own"} <= {"k_tower16x2", "k_tower16x2c", "k_tower16x2m", "k_tower16", "k_tower"}, kernels   # (16x2m: the mixed launch, if an earlier test of this process switched it on)

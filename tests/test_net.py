@@ -98,7 +98,7 @@ def test_param_count_matches_reference_doc():
 @pytest.mark.parametrize("game,nblocks,n,F,heads", [(R.C4, 5, 64, 64, (32, 32)), (R.C4, 1, 7, 64, (32, 32)), (R.TTT, 2, 33, 64, (32, 32)),
                                                       (R.MANCALA, 2, 20, 64, (32, 32)), (R.C4, 2, 40, 128, (32, 32)),
                                                       (R.C4, 1, 9, 64, (2, 1)), (R.TTT, 1, 5, 128, (16, 8))])
-@pytest.mark.parametrize("tower", ["16", "32", "3", "21", "2", "7", "19"])      # 19 (r6): the 7-board paired form (64 filters)
+@pytest.mark.parametrize("tower", ["16", "32", "3", "21", "2", "7", "19", "20"])      # 19 (r6): the 7-board paired form (64 filters); 20 (r6): the 8-board paired form within 176 registers
 def test_hip_forward_bit_exact_vs_oracle(game, nblocks, n, F, heads, tower, monkeypatch):
     """F = 128 is the shipped connect-four network (games/connect-four/params.jl:7-13); heads (2, 1) are the
     ResNetHP defaults (resnet.jl:30-37) and take the VALU dense-head kernel.  All tower kernels (k_tower16 on

@@ -1,11 +1,12 @@
 #!/bin/bash
-# round 6, call K2: replay threads within the cgroup's CPU quota; explore! that runs ahead (call J's content)
+# round 6: simulations per wave launch (AZHIP_RUN_K) with the background launch at its default 32
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out/r6k
 export TMPDIR=/tmp
-for t in 16 32; do
-  SECONDS=0
-  AZ_REPLAY_THREADS=$t timeout 500 python -m pytest "tests/test_replay_all_games_gpu.py::test_config2_every_one_of_the_4096_games" -x -q -m gpu -s > gpurun_out/r6k/replay_c2_t$t.log 2>&1
-  echo "threads $t rc $? seconds $SECONDS" | tee -a gpurun_out/r6k/replay_times.txt
-  grep -o '"seconds_device_phase[^}]*}' gpurun_out/r6k/replay_c2_t$t.log | tail -1
-done
-bash tools/gpu_r6_j.sh
+for k in 3 4 5 6 3 4 5; do
+  AZHIP_RUN_K=$k timeout 300 python bench.py --steps 2000 --warmup 50 --headline-only > gpurun_out/r6k/k_$k.json 2> gpurun_out/r6k/k_$k.err
+  python - <<P
+import json
+d=json.load(open("gpurun_out/r6k/k_$k.json")); r=d["roofline"]
+print("K $k: %.3f M sims/s, %.4f ms/step, %.3f sims/slot/wave, %.1f boards/launch, tower %.1f us" % (d["value"]/1e6, d["ms_per_step"], d["sims_per_slot_per_wave"], r["avg_boards_per_launch"], 1e3*r["avg_launch_ms"]))
+P
+done | tee gpurun_out/r6k/sweep.txt

@@ -31,6 +31,7 @@ with azhip.Engine(game=azhip.GAME_CONNECT_FOUR, oracle=azhip.ORACLE_RESNET, num_
         rows.append(dict(t=round(t, 3), active=act, games=int(st.games), sims=int(st.simulations), evals=int(st.leaf_evals), reused=int(st.evals_reused),
                          msims_per_s=round((st.simulations - last[1]) / max(1e-9, t - last[0]) / 1e6, 3),
                          boards_per_wave=round((st.leaf_evals - st.evals_reused - last[2]) / a.waves, 1), ms_per_wave=round((t - last[0]) / a.waves * 1e3, 4)))
+        rows[-1]["tower_kernel"] = e.net_last_kernel()
         if a.prof:
             pr = e.prof_get(); e.prof_reset()
             rows[-1]["kernels_us_x_launches"] = {k: [round(1e3 * v["ms"] / max(1, v["launches"]), 1), int(v["launches"])] for k, v in pr.items() if v["launches"]}
