@@ -310,9 +310,10 @@ template <class Gm, int F> static int wave_net_f(az_engine* e, int g, bool split
   if (tw == 21 && e->fr_on && e->ngroups == 1 && e->tower_pick == 0 && e->fr_kbg > 0 && v.nleaf_host && v.needy_host) {
     // The paired tower beside the side streams' kernels (resnet16.h k_tower16x2c): a CU that holds a workgroup of the background search
     // (256 threads = 32 Connect-Four slots of the needy list) takes no workgroup of the 198-register form for as long as that search
-    // runs, one that holds a busy workgroup of the move step none for the first round (measured: the launch gains a round of workgroups
-    // beyond ~478 of 512 workgroups in the steady state, ~8 + ~9 such CUs).  Where the counts the device reported for the previous wave
-    // say that this adds a round, the 176-register form serves the launch.
+    // runs.  Measured: in the steady state (~8 such workgroups on average, more in some waves) the launch gains a round of workgroups
+    // beyond ~478 of its 512; the margin of 14 is that measurement (the move step is not part of it: within 96 registers it changes
+    // nothing).  Where the counts the device reported for the previous wave say that this adds a round, the 176-register form serves
+    // the launch.
     const int cu = e->num_cu > 0 ? e->num_cu : 256;
     const int seen = ((volatile int*)e->h_nleaf)[g], needy = ((volatile int*)e->h_needy)[g];
     if (seen > 0) {
