@@ -24,6 +24,7 @@
  *
  * Build: see oracle/Makefile  (gcc -O3 -ffp-contract=off -mavx2 -mfma).
  */
+#include <immintrin.h>
 #include <math.h>
 #include <omp.h>
 #include <sys/mman.h>
@@ -496,51 +497,99 @@ static void pack_conv_w(const float* Wt, int ksz, int Cin, int Cout, float* dst)
   }
 }
 
+/* A position's output channel: o[co] = the chain a = fma(vk[k], wk[k][co], a) over k = 0 .. K-1 IN THE ORDER GIVEN, from a = 0 --
+ * the sequence of single-rounding fmas of the scalar loop this replaces (for every k: o[co] = fmaf(v, w[co], o[co])).  Channels and
+ * positions are independent of each other, so eight channels per AVX register, 16 per pass and FOUR positions at once change no
+ * bit: they keep the accumulators in registers instead of storing and reloading o[] for every k, and a weight row fetched once
+ * (from L2: a layer's weights are 147 KB or more) serves four positions (2.2 -> 0.64 ms per 5x64 board and thread).  Channels beyond
+ * a multiple of 16 take the scalar chain. */
+static void fma_chain4(const float* v0, const float* v1, const float* v2, const float* v3, const float* const* wk, int K, int Cout,
+                       float* o0, float* o1, float* o2, float* o3) {
+  int cb = 0;
+  for (; cb + 16 <= Cout; cb += 16) {
+    __m256 a00 = _mm256_setzero_ps(), a01 = a00, a10 = a00, a11 = a00, a20 = a00, a21 = a00, a30 = a00, a31 = a00;
+    for (int k = 0; k < K; ++k) {
+      const float* w = wk[k] + cb;
+      const __m256 w0 = _mm256_loadu_ps(w), w1 = _mm256_loadu_ps(w + 8);
+      __m256 v = _mm256_broadcast_ss(v0 + k); a00 = _mm256_fmadd_ps(v, w0, a00); a01 = _mm256_fmadd_ps(v, w1, a01);
+      v = _mm256_broadcast_ss(v1 + k);        a10 = _mm256_fmadd_ps(v, w0, a10); a11 = _mm256_fmadd_ps(v, w1, a11);
+      v = _mm256_broadcast_ss(v2 + k);        a20 = _mm256_fmadd_ps(v, w0, a20); a21 = _mm256_fmadd_ps(v, w1, a21);
+      v = _mm256_broadcast_ss(v3 + k);        a30 = _mm256_fmadd_ps(v, w0, a30); a31 = _mm256_fmadd_ps(v, w1, a31);
+    }
+    _mm256_storeu_ps(o0 + cb, a00); _mm256_storeu_ps(o0 + cb + 8, a01); _mm256_storeu_ps(o1 + cb, a10); _mm256_storeu_ps(o1 + cb + 8, a11);
+    _mm256_storeu_ps(o2 + cb, a20); _mm256_storeu_ps(o2 + cb + 8, a21); _mm256_storeu_ps(o3 + cb, a30); _mm256_storeu_ps(o3 + cb + 8, a31);
+  }
+  if (cb < Cout) {
+    /* the remaining channels, one position at a time */
+    const float* vv[4] = {v0, v1, v2, v3}; float* oo[4] = {o0, o1, o2, o3};
+    for (int q = 0; q < 4; ++q)
+      for (int c = cb; c < Cout; ++c) {
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) acc = __builtin_fmaf(vv[q][k], wk[k][c], acc);
+        oo[q][c] = acc;
+      }
+  }
+}
+
 /* in: [P][Cin] (position-major, channel fastest); out: [P][Cout]; Wp packed by pack_conv_w. */
 static void conv_bn(const azr_net* n, const float* in, int Cin, int Cout, int ksz, const float* Wp,
                     const float* bias, const float* bn, const float* res, int relu, int paired, float* out) {
   int W = n->W, H = n->H;
-  float* scale = malloc(sizeof(float) * 2 * (size_t)Cout);
+  const int ntap = ksz * ksz, K = ntap * Cin;
+  float* scale = malloc(sizeof(float) * (2 * (size_t)Cout + 4 * (size_t)K));
   float* shift = scale + Cout;
+  float* vk = shift + Cout;                              /* four positions' K input values each, in summation order ... */
+  const float** wk = malloc(sizeof(const float*) * (size_t)K);   /* ... and the weight row [Cout] each of them multiplies */
   bn_fold(bias, bn, Cout, scale, shift);
   int half = Cin / 2;
-  for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
-    float* o = out + (size_t)(x + W * y) * Cout;
-    for (int co = 0; co < Cout; ++co) o[co] = 0.0f;
-    int ntap = ksz * ksz;
-    if (paired == 2) {                      /* stem: pairing over the whole K = 9 Cin */
-      int K = ntap * Cin, K2 = (K + 1) / 2;
-      for (int s = 0; s < 2 * K2; ++s) {
-        int k = (s & 1) ? K2 + (s >> 1) : (s >> 1);
-        if (k >= K) continue;
-        int t = k / Cin, ci = k % Cin;
-        int dy = t / 3 - 1, dx = t % 3 - 1, yy = y + dy, xx = x + dx;
-        int inside = (yy >= 0 && yy < H && xx >= 0 && xx < W);
-        float v = inside ? in[(size_t)(xx + W * yy) * Cin + ci] : 0.0f;
-        const float* wrow = Wp + ((size_t)t * Cin + ci) * Cout;
-        for (int co = 0; co < Cout; ++co) o[co] = __builtin_fmaf(v, wrow[co], o[co]);
-      }
-      ntap = 0;
+  /* the summation order of a position's K terms -- the same for every position: (tap, input channel) of term k */
+  int* tk = malloc(sizeof(int) * 2 * (size_t)K);
+  int* ck = tk + K;
+  int nk = 0;
+  if (paired == 2) {                        /* stem: pairing over the whole K = 9 Cin */
+    int K2 = (K + 1) / 2;
+    for (int s2 = 0; s2 < 2 * K2; ++s2) {
+      int k = (s2 & 1) ? K2 + (s2 >> 1) : (s2 >> 1);
+      if (k >= K) continue;
+      tk[nk] = k / Cin; ck[nk++] = k % Cin;
     }
-    for (int t = 0; t < ntap; ++t) {
-      int dy = ksz == 3 ? t / 3 - 1 : 0, dx = ksz == 3 ? t % 3 - 1 : 0;
-      int yy = y + dy, xx = x + dx;
-      int inside = (yy >= 0 && yy < H && xx >= 0 && xx < W);
-      for (int kk = 0; kk < Cin; ++kk) {
-        int ci = paired ? ((kk & 1) ? half + (kk >> 1) : (kk >> 1)) : kk;
-        float v = inside ? in[(size_t)(xx + W * yy) * Cin + ci] : 0.0f;
-        const float* wrow = Wp + ((size_t)t * Cin + ci) * Cout;
-        for (int co = 0; co < Cout; ++co) o[co] = __builtin_fmaf(v, wrow[co], o[co]);
-      }
-    }
-    for (int co = 0; co < Cout; ++co) {
-      float v = __builtin_fmaf(o[co], scale[co], shift[co]);
-      if (res) v = v + res[(size_t)(x + W * y) * Cout + co];
-      if (relu) v = v > 0.0f ? v : 0.0f;
-      o[co] = v;
+  } else {
+    for (int t = 0; t < ntap; ++t) for (int kk = 0; kk < Cin; ++kk) {
+      tk[nk] = t; ck[nk++] = paired ? ((kk & 1) ? half + (kk >> 1) : (kk >> 1)) : kk;
     }
   }
-  free(scale);
+  for (int k = 0; k < nk; ++k) wk[k] = Wp + ((size_t)tk[k] * Cin + ck[k]) * Cout;
+  const int NP = W * H;
+  float* dummy = malloc(sizeof(float) * (size_t)Cout);           /* output of the positions that pad the last group of four */
+  for (int p0 = 0; p0 < NP; p0 += 4) {
+    float* og[4];
+    for (int q = 0; q < 4; ++q) {
+      const int pz = p0 + q < NP ? p0 + q : p0;                    /* (a padding position repeats the group's first one) */
+      const int x = pz % W, y = pz / W;
+      og[q] = p0 + q < NP ? out + (size_t)pz * Cout : dummy;
+      const float* tap_in[9];               /* the input row [Cin] a tap reads at this position, NULL outside the board (zeros) */
+      for (int t = 0; t < ntap; ++t) {
+        int dy = ksz == 3 ? t / 3 - 1 : 0, dx = ksz == 3 ? t % 3 - 1 : 0;
+        int yy = y + dy, xx = x + dx;
+        tap_in[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in + (size_t)(xx + W * yy) * Cin : 0;
+      }
+      float* vq = vk + (size_t)q * K;
+      for (int k = 0; k < nk; ++k) vq[k] = tap_in[tk[k]] ? tap_in[tk[k]][ck[k]] : 0.0f;
+    }
+    fma_chain4(vk, vk + K, vk + 2 * (size_t)K, vk + 3 * (size_t)K, wk, nk, Cout, og[0], og[1], og[2], og[3]);
+    for (int q = 0; q < 4 && p0 + q < NP; ++q) {
+      float* o = og[q];
+      const size_t pz = (size_t)(p0 + q);
+      for (int co = 0; co < Cout; ++co) {
+        float v = __builtin_fmaf(o[co], scale[co], shift[co]);
+        if (res) v = v + res[pz * Cout + co];
+        if (relu) v = v > 0.0f ? v : 0.0f;
+        o[co] = v;
+      }
+    }
+  }
+  free(dummy);
+  free(scale); free(tk); free((void*)wk);
 }
 
 /* copy of the blob with every conv kernel re-ordered by pack_conv_w and the value head's first dense
