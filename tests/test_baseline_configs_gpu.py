@@ -2,12 +2,12 @@
 
 The engines are created at the configurations' full slot counts and network sizes (C2: 4096 slots, 400 sims/move,
 ResNet 5x64; C3: a rank's 4096-slot shard with 600 sims/move and global game ids; C4: Mancala, 8192 slots, 800
-sims/move); a sample of 64 whole games per configuration (seeded draw + the longest game + the game with the most free turns) is
+sims/move); a sample of whole games per configuration -- 512 of C2's 4096 (r6), 64 of C3's and C4's -- (seeded draw + the longest game + the game with the most free turns) is
 compared move record by move record with the oracle's simulate (visit counts, sampled action, reward, node counts, simulation /
 traversal counters -- all integers or exact floats), and the replay-memory contents built from them (src/memory.jl:74-114).  RNG streams are
 keyed by GLOBAL game id and trees reset after every game (reset_every = 1), so a game's trace does not depend on
 how many slots run beside it (tests/test_selfplay_gpu.py::test_full_size_slot_count_independence): the sampled games
-stand for every game of the full phase.  The oracle runs its workers on host threads (OpenMP), ~30 s per case."""
+stand for every game of the full phase.  The oracle runs its workers on host threads (OpenMP), 16-25 s per 64-game case, 94 s for C2's 512."""
 import ctypes as C
 
 import numpy as np
@@ -21,7 +21,7 @@ C4_SCHED = ((0, 20, 30), (1.0, 1.0, 0.3))          # games/connect-four/params.j
 
 
 NSAMPLE = 64                                        # games compared per configuration (was 8 / 6)
-NSAMPLE_C2 = int(__import__("os").environ.get("AZ_NSAMPLE_C2", 96))   # (r6; AZ_NSAMPLE_C2=512: tools/gpu_r6_y.sh, profiles/r6/c2_512_games_oracle_network.txt) the headline configuration: half as many again -- what the box's 16 usable CPUs replay in ~60 s (VERDICT r5 #7 asked for 512: ~6 min here)
+NSAMPLE_C2 = int(__import__("os").environ.get("AZ_NSAMPLE_C2", 512))   # (r6) the headline configuration: 512 games -- 94 s on the box's 16 usable CPUs since the oracle's network keeps its fma chains in registers (oracle/azref.c conv_bn); rounds 3-5: 64
 
 
 def _rec(g, moves):
@@ -131,7 +131,7 @@ def _run_case(game_hip, game_ref, slots, groups, nsims, nsample, first_id, sched
 
 def test_config2_connect_four_4096_slots_400_sims():
     """BASELINE configs[1]: the WHOLE 4096-game phase runs on the device (4096 slots, two slot groups as bench.py
-    does); 96 of its games -- the longest, the one with the most consecutive moves by one side, 94 by a seeded draw -- are
+    does); 512 of its games (r6) -- the longest, the one with the most consecutive moves by one side, the rest by a seeded draw -- are
     replayed by the oracle and compared record by record, and so are their replay-memory samples (push_trace!, symmetric
     images, merge_by_state, the Float32 tensors)."""
     import azhip
